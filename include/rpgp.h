@@ -1,0 +1,114 @@
+/*
+ * rpgp.h — C-ABI of the MI355X-native additive randomly-projected GP kernel path.
+ *
+ * Drop-in boundary.  The reference (idelbrid/Randomly-Projected-Additive-GPs) is pure
+ * Python on GPyTorch; it has no FFI of its own.  The entry points below are what a GPyTorch
+ * `Kernel.forward` -> `LazyTensor` binding for this path would call; each one names the reference
+ * interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless a name ends in `_host`;
+ *   - row-major, contiguous unless a leading dimension (`ld*`) is given;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     allocates nothing, and is re-entrant (no global mutable state besides a one-time device probe);
+ *   - return value: 0 on success, otherwise a hipError_t value or one of the RPGP_E* codes below;
+ *     `rpgp_error_string` turns either into text.  Python callers raise RuntimeError / ValueError.
+ *
+ * Kernel definition:
+ *   K[i,i'] = scale * sum_{j in [j0,j1)} exp(-0.5 * (Z1[i,j] - Z2[i',j])^2)
+ *   with Z = (X / lengthscale) P  (prescale)  or  (X P) / lengthscale  (postscale);
+ *   for the J20 specs scale = outputscale * (1/J).
+ */
+#ifndef RPGP_H
+#define RPGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPGP_ABI_VERSION 1
+
+#define RPGP_EINVAL     10001 /* bad argument (shape, range, null pointer) */
+#define RPGP_EWORKSPACE 10002 /* workspace too small: call the matching *_workspace_bytes */
+#define RPGP_ENODEVICE  10003 /* no gfx950 device visible */
+
+/* ABI version of the loaded library. */
+int rpgp_version(void);
+
+/* Text for a return code of any function below (static storage). */
+const char *rpgp_error_string(int code);
+
+/* One-time probe of the current device (checks gfx9 wave64, finds the DPP rotate direction used by the
+ * symmetric kernel).  Called lazily by the compute entry points; exposed so hosts can fail early. */
+int rpgp_init(void);
+
+/*
+ * Projection  Z = X @ Peff   (X: N x d, Peff: d x J, Z: N x J).
+ * Replaces gp_models/kernels/scaled_projection_kernel.py:21-27 (`x1.div(lengthscale)` + `projection_module(x1)`);
+ * the caller folds the ARD lengthscale into Peff (prescale: diag(1/l) P; postscale: P diag(1/l)).
+ */
+int rpgp_project(const float *X, const float *Peff, float *Z, int64_t N, int d, int J, void *stream);
+
+/*
+ * Backward of the projection w.r.t. Peff:  dPeff = X^T @ G  (G: N x J, dPeff: d x J).
+ * Replaces autograd through scaled_projection_kernel.py:21-27 for the lengthscale / learn_proj gradients.
+ */
+int rpgp_project_grad(const float *X, const float *G, float *dPeff, int64_t N, int d, int J, void *stream);
+
+/*
+ * Symmetric fused MVM:  out = scale * sum_{j in [j0,j1)} K_j(Z,Z) @ V  +  noise * V      (V, out: N x T)
+ * K is never stored; each unordered pair (i,i') is evaluated once.
+ * Replaces the dense `K @ V` inside gpytorch.utils.linear_cg reached from fitting/optimizing.py:67-71
+ * (kernel built at training_routines.py:148-159,169-171,406 and evaluated by scaled_projection_kernel.py:37).
+ * `ldz` = row stride of Z in floats (>= j1).  Results are deterministic (no float atomics).
+ */
+size_t rpgp_mvm_sym_workspace_bytes(int64_t N, int T);
+int rpgp_mvm_sym(const float *Z, const float *V, float *out, int64_t N, int ldz, int T,
+                 int j0, int j1, float scale, float noise,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Rectangular fused MVM:  out = scale * sum_j K_j(Z1,Z2) @ V      (Z1: M x ., Z2: N x ., V: N x T, out: M x T)
+ * Replaces K(X*,X) @ alpha and K(X,X*) blocks of the prediction strategy driven from training_routines.py:551-575.
+ */
+size_t rpgp_mvm_rect_workspace_bytes(int64_t M, int64_t N, int T);
+int rpgp_mvm_rect(const float *Z1, const float *Z2, const float *V, float *out,
+                  int64_t M, int64_t N, int ldz1, int ldz2, int T,
+                  int j0, int j1, float scale,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Dense block  out[m, n] = scale * sum_j exp(-0.5 (Z1[m,j]-Z2[n,j])^2)   (out: M x N, row stride ldo).
+ * Used for pivoted-Cholesky rows, `evaluate()`/`to_dense()` at small N and the cached-K mode.
+ * Replaces LazyEvaluatedKernelTensor.evaluate_kernel()/_getitem on the kernel of training_routines.py:169-171.
+ */
+int rpgp_dense(const float *Z1, const float *Z2, float *out, int64_t M, int64_t N,
+               int ldz1, int ldz2, int64_t ldo, int j0, int j1, float scale, void *stream);
+
+/*
+ * Bilinear derivative for backward, symmetric operator:
+ *   S = L R^T + R L^T            (L, R: N x T)
+ *   gZ[i,j]  = -scale * sum_i' S[i,i'] e_j(i,i') (Z[i,j]-Z[i',j])     for j in [j0,j1)   (gZ: N x ldg)
+ *   gscale   = 0.5 * sum_{i,i'} S[i,i'] sum_j e_j(i,i')               (1 float, device)
+ * i.e. d/dZ and d/dscale of  sum_{ii'} (L R^T)[i,i'] K[i,i'].
+ * Replaces LazyTensor._quad_form_derivative triggered by loss.backward() at fitting/optimizing.py:72.
+ */
+size_t rpgp_bilinear_grad_workspace_bytes(int64_t N, int J);
+int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ, float *gscale,
+                       int64_t N, int ldz, int ldg, int T, int j0, int j1, float scale,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Dense symmetric-matrix MVM for the cached-K mode:  out = Kd @ V + noise * V   (Kd: N x N fp32 in HBM).
+ * HBM-bound stream of Kd.
+ */
+int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64_t ldk, int T,
+                   float noise, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPGP_H */

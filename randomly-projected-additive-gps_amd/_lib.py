@@ -1,0 +1,83 @@
+"""ctypes binding of the C-ABI in include/rpgp.h (librpgp.so, built from csrc/rpgp_kernels.hip).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "librpgp.so")
+
+RPGP_EINVAL = 10001
+RPGP_EWORKSPACE = 10002
+RPGP_ENODEVICE = 10003
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as integers
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/rpgp.h one to one
+SIGNATURES = {
+    "rpgp_version": (_int, []),
+    "rpgp_error_string": (ctypes.c_char_p, [_int]),
+    "rpgp_init": (_int, []),
+    "rpgp_project": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "rpgp_project_grad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "rpgp_mvm_sym_workspace_bytes": (_sz, [_i64, _int]),
+    "rpgp_mvm_sym": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
+    "rpgp_mvm_rect_workspace_bytes": (_sz, [_i64, _i64, _int]),
+    "rpgp_mvm_rect": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
+    "rpgp_dense": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f32, _vp]),
+    "rpgp_bilinear_grad_workspace_bytes": (_sz, [_i64, _int]),
+    "rpgp_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
+    "rpgp_dense_mvm": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _f32, _vp]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile librpgp.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "all"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building librpgp.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    """Load librpgp.so and attach signatures. Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "librpgp.so not found at %s: the HIP extension is required (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C %s`). There is no CPU fallback." % (LIB_PATH, CSRC_DIR))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.rpgp_version() != 1:
+        raise RuntimeError("librpgp.so ABI version mismatch: %d" % lib.rpgp_version())
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    """Turn a C-ABI return code into a Python exception (ValueError for argument errors)."""
+    if code == 0:
+        return
+    msg = load().rpgp_error_string(code).decode()
+    if code == RPGP_EINVAL:
+        raise ValueError("%s: %s" % (what, msg))
+    raise RuntimeError("%s: %s (code %d)" % (what, msg, code))

@@ -1,0 +1,852 @@
+// rpgp_kernels.hip — hand-written gfx950 (CDNA4) kernels + the C-ABI of include/rpgp.h.
+//
+// Hot path: the additive randomly-projected RBF kernel
+//     K[i,i'] = scale * sum_j exp(-0.5 (Z[i,j]-Z[i',j])^2)
+// applied to a block of vectors without ever storing K.  gfx950 only: wave64, DPP wave rotates,
+// packed fp32 VALU, 160 KB LDS.  No CUDA/compat paths.
+//
+// Tiling of the fused MVM (mvm_tile_kernel):
+//   * a 256-thread workgroup owns BR = 256*R rows; each lane keeps R rows' JT projected coordinates
+//     (pre-multiplied by sqrt(0.5*log2 e) so the inner loop is sub, mul, v_exp_f32, add) and its
+//     R*TT row accumulators in VGPRs;
+//   * the workgroup sweeps one chunk of columns, staged 256 at a time in LDS with coalesced loads;
+//   * inside a 64-column subtile, lane l visits column (l + s) mod 64 at step s (a per-lane LDS read,
+//     bank-conflict free for the padded strides used).  Because every lane holds a DIFFERENT column,
+//     the transposed product  out[i'] += K[i,i'] v[i]  needs no cross-lane reduction: its accumulator
+//     is rotated one lane per step with a DPP wave rotate, so after 64 steps lane l holds column l.
+//     Each unordered pair is therefore evaluated once (SYM=true), halving the exp count;
+//   * partial results go to per-(row-block / chunk) slabs in a caller-provided workspace and a small
+//     reduce kernel sums them in a fixed order: deterministic, no float atomics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/rpgp.h"
+
+namespace {
+
+constexpr float kExp2Scale = 0.8493218002880191f;  // sqrt(0.5 * log2(e)):  exp(-d^2/2) = exp2(-(c d)^2)
+constexpr int kSC = 256;                           // columns staged in LDS per sub-chunk
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// LDS row stride (floats) for a column's JT coordinates: (stride/4) odd keeps the per-lane
+// ds_read_b128 of 16 consecutive columns on 16 distinct 4-bank slots (MI355X_MICROARCH.md §LDS).
+template <int JT> struct ColStride { static constexpr int v = (JT % 8 == 0) ? JT + 4 : JT; };
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// DPP wave rotate by one lane (gfx9: wave_rol:1 = 0x134).  Direction is probed once on the host
+// (rpgp_init) and passed to kernels as `rotdir`, so correctness does not rest on the mnemonic.
+__device__ __forceinline__ float wave_rotate1(float x) {
+  int xi = __builtin_bit_cast(int, x);
+  int r = __builtin_amdgcn_update_dpp(0, xi, 0x134, 0xf, 0xf, false);
+  return __builtin_bit_cast(float, r);
+}
+
+__global__ void probe_rotate_kernel(int *out) {
+  float x = (float)threadIdx.x;
+  float y = wave_rotate1(x);
+  out[threadIdx.x] = (int)y;
+}
+
+// sum_j exp2(-(a_j - b_j)^2), written on float2 so hipcc emits v_pk_add_f32 / v_pk_mul_f32.
+template <int JT>
+__device__ __forceinline__ float pair_kernel_sum(const float (&a)[JT], const float (&b)[JT]) {
+  if constexpr (JT % 2 == 0) {
+    float2v acc = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < JT; j += 2) {
+      float2v av = {a[j], a[j + 1]};
+      float2v bv = {b[j], b[j + 1]};
+      float2v d = av - bv;
+      float2v m = -(d * d);
+      float2v e = {fast_exp2(m.x), fast_exp2(m.y)};
+      acc += e;
+    }
+    return acc.x + acc.y;
+  } else {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      float d = a[j] - b[j];
+      acc += fast_exp2(-(d * d));
+    }
+    return acc;
+  }
+}
+
+template <int JT>
+__device__ __forceinline__ void lds_load_cols(const float *sB, int idx, float (&b)[JT]) {
+  constexpr int STR = ColStride<JT>::v;
+  const float *p = sB + idx * STR;
+  if constexpr (JT % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < JT; j += 4) {
+      float4v q = *reinterpret_cast<const float4v *>(p + j);
+      b[j] = q.x; b[j + 1] = q.y; b[j + 2] = q.z; b[j + 3] = q.w;
+    }
+  } else if constexpr (JT % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < JT; j += 2) {
+      float2v q = *reinterpret_cast<const float2v *>(p + j);
+      b[j] = q.x; b[j + 1] = q.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) b[j] = p[j];
+  }
+}
+
+template <int TT>
+__device__ __forceinline__ void lds_load_vec(const float *sV, int idx, float (&v)[TT]) {
+  const float *p = sV + idx * TT;
+  if constexpr (TT % 4 == 0) {
+#pragma unroll
+    for (int t = 0; t < TT; t += 4) {
+      float4v q = *reinterpret_cast<const float4v *>(p + t);
+      v[t] = q.x; v[t + 1] = q.y; v[t + 2] = q.z; v[t + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < TT; ++t) v[t] = p[t];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused MVM tile kernel.  grid = (max chunks per row block, row blocks); block = 256.
+//   SYM : Z1 == Z2 (N x N), columns of row block rb start at its own first row (upper triangle incl.
+//         the diagonal block); the transposed product is produced for columns beyond the diagonal block.
+//   !SYM: rectangular M x N, every row block sweeps all columns.
+// slabR[k][row][T]  : partial row products of chunk k           (k < chunks of that row block)
+// slabT[rb][col][T] : partial transposed products of row block rb (only col >= (rb+1)*BR written)
+// ---------------------------------------------------------------------------------------------
+template <int JT, int TT, int R, bool SYM>
+__global__ __launch_bounds__(256) void mvm_tile_kernel(
+    const float *__restrict__ Z1, const float *__restrict__ Z2, const float *__restrict__ V,
+    float *__restrict__ slabR, float *__restrict__ slabT, int M, int N, int ldz1, int ldz2, int ldv,
+    int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate) {
+  constexpr int BR = 256 * R;
+  constexpr int STR = ColStride<JT>::v;
+  __shared__ __attribute__((aligned(16))) float sB[kSC * STR];
+  __shared__ __attribute__((aligned(16))) float sV[kSC * TT];
+  __shared__ __attribute__((aligned(16))) float sT[SYM ? 4 * kSC * TT : 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int rb = blockIdx.y;
+  const int kchunk = blockIdx.x;
+  const int r0 = rb * BR;
+  const int cbase = SYM ? r0 : 0;
+  const long long cb = (long long)cbase + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+
+  float a[R][JT];
+  float vrow[R][TT];
+  float accR[R][TT];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+    const bool valid = row < M;
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+      a[r][j] = valid ? Z1[(size_t)row * ldz1 + j0 + j] * kExp2Scale : 0.f;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      vrow[r][t] = (SYM && valid && t < tcnt) ? V[(size_t)row * ldv + t0 + t] : 0.f;
+      accR[r][t] = 0.f;
+    }
+  }
+
+  for (int c0 = c_begin; c0 < c_end; c0 += kSC) {
+    __syncthreads();
+    {
+      const int col = c0 + tid;
+      const bool cv = col < c_end;
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+        sB[tid * STR + j] = cv ? Z2[(size_t)col * ldz2 + j0 + j] * kExp2Scale : 0.f;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+        sV[tid * TT + t] = (cv && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+    }
+    __syncthreads();
+    const int ncol = c_end - c0;
+    const int nsub = ncol >= kSC ? kSC / 64 : (ncol + 63) / 64;
+    for (int sub = 0; sub < nsub; ++sub) {
+      const bool doT = SYM && (c0 + sub * 64 >= r0 + BR);
+      float accT[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) accT[t] = 0.f;
+      if (doT) {
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {
+          const int idx = sub * 64 + ((lane + rotdir * s) & 63);
+          float b[JT], v[TT];
+          lds_load_cols<JT>(sB, idx, b);
+          lds_load_vec<TT>(sV, idx, v);
+          float tsum[TT];
+#pragma unroll
+          for (int t = 0; t < TT; ++t) tsum[t] = accT[t];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float ks = pair_kernel_sum<JT>(a[r], b);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+              accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
+              tsum[t] = __builtin_fmaf(ks, vrow[r][t], tsum[t]);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < TT; ++t) accT[t] = wave_rotate1(tsum[t]);
+        }
+      } else {
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {
+          const int idx = sub * 64 + ((lane + s) & 63);
+          float b[JT], v[TT];
+          lds_load_cols<JT>(sB, idx, b);
+          lds_load_vec<TT>(sV, idx, v);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float ks = pair_kernel_sum<JT>(a[r], b);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
+          }
+        }
+      }
+      if constexpr (SYM) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) sT[(wave * kSC + sub * 64 + lane) * TT + t] = accT[t];
+      }
+    }
+    if constexpr (SYM) {
+      __syncthreads();
+      const int col = c0 + tid;
+      if (col < c_end && col >= r0 + BR) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          if (t < tcnt) {
+            float sum = sT[(0 * kSC + tid) * TT + t] + sT[(1 * kSC + tid) * TT + t] +
+                        sT[(2 * kSC + tid) * TT + t] + sT[(3 * kSC + tid) * TT + t];
+            float *dst = slabT + ((size_t)rb * N + col) * ldv + t0 + t;
+            *dst = accumulate ? *dst + sum : sum;
+          }
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+    if (row < M) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (t < tcnt) {
+          float *dst = slabR + ((size_t)kchunk * M + row) * ldv + t0 + t;
+          *dst = accumulate ? *dst + accR[r][t] : accR[r][t];
+        }
+      }
+    }
+  }
+}
+
+// out[row][t] = scale * (sum_k slabR[k][row][t] + sum_{rb < row/BR} slabT[rb][row][t]) + noise * V[row][t]
+__global__ void mvm_reduce_kernel(const float *__restrict__ slabR, const float *__restrict__ slabT,
+                                  const float *__restrict__ V, float *__restrict__ out, int M, int N, int T,
+                                  int BR, int chunk_cols, int sym, float scale, float noise) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)M * T) return;
+  const int row = (int)(gid / T);
+  const int rb = row / BR;
+  const int cbase = sym ? rb * BR : 0;
+  const int nk = (N - cbase + chunk_cols - 1) / chunk_cols;
+  float acc = 0.f;
+  for (int k = 0; k < nk; ++k) acc += slabR[(size_t)k * M * T + gid];
+  if (sym)
+    for (int b = 0; b < rb; ++b) acc += slabT[(size_t)b * N * T + gid];
+  float r = scale * acc;
+  if (noise != 0.f) r = __builtin_fmaf(noise, V[gid], r);
+  out[gid] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense block: out[m][n] = scale * sum_j exp(-0.5 (Z1[m,j]-Z2[n,j])^2).  One thread per output column
+// (coalesced stores), RT rows per workgroup held in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int JT>
+__global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ Z1, const float *__restrict__ Z2,
+                                                    float *__restrict__ out, int M, int N, int ldz1, int ldz2,
+                                                    long long ldo, int j0, float scale, int accumulate) {
+  constexpr int RT = 16;
+  __shared__ float sA[RT][JT];
+  const int tid = threadIdx.x;
+  const int col = blockIdx.x * 256 + tid;
+  const int m0 = blockIdx.y * RT;
+  for (int e = tid; e < RT * JT; e += 256) {
+    const int r = e / JT, j = e % JT;
+    sA[r][j] = (m0 + r < M) ? Z1[(size_t)(m0 + r) * ldz1 + j0 + j] * kExp2Scale : 0.f;
+  }
+  __syncthreads();
+  if (col >= N) return;
+  float b[JT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) b[j] = Z2[(size_t)col * ldz2 + j0 + j] * kExp2Scale;
+#pragma unroll 4
+  for (int r = 0; r < RT; ++r) {
+    if (m0 + r >= M) break;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      float d = sA[r][j] - b[j];
+      acc += fast_exp2(-(d * d));
+    }
+    float *dst = out + (size_t)(m0 + r) * ldo + col;
+    *dst = accumulate ? __builtin_fmaf(scale, acc, *dst) : scale * acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Projection Z = X @ Peff and its backward dPeff = X^T @ G (thin GEMMs; plain VALU version).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void project_kernel(const float *__restrict__ X, const float *__restrict__ Peff,
+                                                      float *__restrict__ Z, long long N, int d, int J) {
+  extern __shared__ float sP[];  // d*J
+  for (int e = threadIdx.x; e < d * J; e += 256) sP[e] = Peff[e];
+  __syncthreads();
+  const long long total = N * J;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+    const long long n = g / J;
+    const int j = (int)(g % J);
+    const float *x = X + n * d;
+    float acc = 0.f;
+    for (int k = 0; k < d; ++k) acc = __builtin_fmaf(x[k], sP[k * J + j], acc);
+    Z[g] = acc;
+  }
+}
+
+// dPeff[k][j] = sum_n X[n][k] G[n][j]; one workgroup per (k, j-tile) would be overkill: d*J <= ~1024 outputs,
+// each workgroup reduces a slice of n for all (k,j) handled by its threads, then atomics-free two-pass.
+__global__ __launch_bounds__(256) void project_grad_partial_kernel(const float *__restrict__ X,
+                                                                   const float *__restrict__ G,
+                                                                   float *__restrict__ part, long long N, int d,
+                                                                   int J, long long rows_per_block) {
+  // thread e handles output element (k,j) = (e / J, e % J) for e < d*J (loop if d*J > 256)
+  const long long n0 = (long long)blockIdx.x * rows_per_block;
+  const long long n1 = (n0 + rows_per_block < N) ? n0 + rows_per_block : N;
+  for (int e = threadIdx.x; e < d * J; e += 256) {
+    const int k = e / J, j = e % J;
+    float acc = 0.f;
+    for (long long n = n0; n < n1; ++n) acc = __builtin_fmaf(X[n * d + k], G[n * J + j], acc);
+    part[(size_t)blockIdx.x * d * J + e] = acc;
+  }
+}
+
+__global__ void sum_partials_kernel(const float *__restrict__ part, float *__restrict__ out, int count, int nparts,
+                                    float mul) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  float acc = 0.f;
+  for (int p = 0; p < nparts; ++p) acc += part[(size_t)p * count + e];
+  out[e] = acc * mul;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear derivative.  Lane owns a row; columns broadcast from LDS.
+//   S = sum_t L[i,t] R[i',t] + R[i,t] L[i',t]
+//   gz[i][j] += S * e_j * d_j   (d in exp2-scaled units; caller multiplies by -scale/kExp2Scale... see host)
+//   gs[i]    += S * sum_j e_j
+// grid = (column splits, row blocks of 256); partial slabs reduced by bilinear_reduce_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int JT, int TT>
+__global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__ Z, const float *__restrict__ L,
+                                                       const float *__restrict__ Rm, float *__restrict__ slabG,
+                                                       float *__restrict__ slabS, int N, int ldz, int T, int j0,
+                                                       int cols_per_split) {
+  constexpr int STR = JT + 2 * TT;
+  __shared__ __attribute__((aligned(16))) float sC[64 * STR];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.y * 256 + tid;
+  const bool valid = row < N;
+  const int c_begin = blockIdx.x * cols_per_split;
+  if (c_begin >= N) return;
+  const int c_end = (c_begin + cols_per_split < N) ? c_begin + cols_per_split : N;
+
+  float a[JT], li[TT], ri[TT], accG[JT];
+  float accS = 0.f;
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    a[j] = valid ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 0.f;
+    accG[j] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    li[t] = (valid && t < T) ? L[(size_t)row * T + t] : 0.f;
+    ri[t] = (valid && t < T) ? Rm[(size_t)row * T + t] : 0.f;
+  }
+  for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * STR; e += 256) {
+      const int c = e / STR, q = e % STR;
+      const int col = c0 + c;
+      float val = 0.f;
+      if (col < c_end) {
+        if (q < JT) val = Z[(size_t)col * ldz + j0 + q] * kExp2Scale;
+        else if (q < JT + TT) { const int t = q - JT; val = t < T ? L[(size_t)col * T + t] : 0.f; }
+        else { const int t = q - JT - TT; val = t < T ? Rm[(size_t)col * T + t] : 0.f; }
+      }
+      sC[e] = val;
+    }
+    __syncthreads();
+    const int nc = (c_end - c0 < 64) ? c_end - c0 : 64;
+    for (int c = 0; c < nc; ++c) {
+      const float *p = sC + c * STR;
+      float S = 0.f;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        S = __builtin_fmaf(li[t], p[JT + TT + t], S);
+        S = __builtin_fmaf(ri[t], p[JT + t], S);
+      }
+      float ks = 0.f;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const float dd = a[j] - p[j];
+        const float e = fast_exp2(-(dd * dd));
+        ks += e;
+        accG[j] = __builtin_fmaf(S * e, dd, accG[j]);
+      }
+      accS = __builtin_fmaf(S, ks, accS);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) slabG[((size_t)blockIdx.x * N + row) * JT + j] = accG[j];
+    slabS[(size_t)blockIdx.x * N + row] = accS;
+  }
+}
+
+// gZ[row][j0+j] = mulG * sum_split slabG ; rowS[row] = sum_split slabS  (+= if accumulate)
+__global__ void bilinear_reduce_kernel(const float *__restrict__ slabG, const float *__restrict__ slabS,
+                                       float *__restrict__ gZ, float *__restrict__ rowS, int N, int JT, int ldg,
+                                       int j0, int nsplit, float mulG, int accumulate) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)N * (JT + 1)) return;
+  const int row = (int)(gid / (JT + 1));
+  const int q = (int)(gid % (JT + 1));
+  float acc = 0.f;
+  if (q < JT) {
+    for (int s = 0; s < nsplit; ++s) acc += slabG[((size_t)s * N + row) * JT + q];
+    gZ[(size_t)row * ldg + j0 + q] = mulG * acc;
+  } else {
+    for (int s = 0; s < nsplit; ++s) acc += slabS[(size_t)s * N + row];
+    rowS[row] = accumulate ? rowS[row] + acc : acc;
+  }
+}
+
+// deterministic single-block sum: out[0] = mul * sum_i x[i]
+__global__ __launch_bounds__(1024) void sum_vector_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                          int n, float mul) {
+  __shared__ float sh[1024];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += x[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0] * mul;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cached-K mode: out = Kd @ V + noise V, Kd dense N x N fp32 (HBM stream).  One wave per row,
+// float4 loads; V (N x T) comes from L2.
+// ---------------------------------------------------------------------------------------------
+template <int TT>
+__global__ __launch_bounds__(256) void dense_mvm_kernel(const float *__restrict__ Kd, const float *__restrict__ V,
+                                                        float *__restrict__ out, int N, long long ldk, int T,
+                                                        int t0, float noise) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float *kr = Kd + (size_t)row * ldk;
+  float acc[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+  const bool vec_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0);
+  int c = 0;
+  if (vec_ok) {
+    const int n4 = N & ~255;
+    for (c = lane * 4; c < n4; c += 256) {
+      const float4v q = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kr + c));
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (TT == 1 || t0 + t < T) {
+          acc[t] = __builtin_fmaf(q.x, V[(size_t)(c + 0) * T + t0 + t], acc[t]);
+          acc[t] = __builtin_fmaf(q.y, V[(size_t)(c + 1) * T + t0 + t], acc[t]);
+          acc[t] = __builtin_fmaf(q.z, V[(size_t)(c + 2) * T + t0 + t], acc[t]);
+          acc[t] = __builtin_fmaf(q.w, V[(size_t)(c + 3) * T + t0 + t], acc[t]);
+        }
+      }
+    }
+    c = n4;
+  }
+  for (int cc = c + lane; cc < N; cc += 64) {
+    const float q = kr[cc];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+      if (TT == 1 || t0 + t < T) acc[t] = __builtin_fmaf(q, V[(size_t)cc * T + t0 + t], acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    float s = acc[t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0 && t0 + t < T) {
+      const size_t o = (size_t)row * T + t0 + t;
+      out[o] = __builtin_fmaf(noise, V[o], s);
+    }
+  }
+}
+
+// ------------------------------- host-side helpers -------------------------------------------
+
+int g_rotdir = 0;  // +1: wave_rotate1 delivers lane l+1's value to lane l; -1: lane l-1's.  0 = not probed.
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define RPGP_CHECK(expr)                          \
+  do {                                            \
+    hipError_t _e = (expr);                       \
+    if (_e != hipSuccess) return (int)_e;         \
+  } while (0)
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+// decomposition of a j-range into the compiled JT pieces
+const int kJPieces[] = {20, 8, 4, 2, 1};
+inline int next_j_piece(int remaining) {
+  for (int p : kJPieces)
+    if (p <= remaining) return p;
+  return 1;
+}
+const int kTPieces[] = {12, 4, 1};
+inline int next_t_piece(int remaining) {
+  // prefer the smallest compiled piece that covers the remainder, else the largest
+  if (remaining >= 12) return 12;
+  if (remaining > 4) return 12;
+  if (remaining > 1) return 4;
+  return 1;
+}
+
+struct TilePlan {
+  int R;           // rows per lane
+  int BR;          // rows per workgroup
+  int nrb;         // row blocks
+  int chunk_cols;  // columns per workgroup (multiple of BR and kSC)
+  int maxchunks;   // grid.x
+};
+
+inline TilePlan make_plan(int64_t M, int64_t N, bool sym) {
+  TilePlan p;
+  p.R = (M >= 16384) ? 2 : 1;
+  p.BR = 256 * p.R;
+  p.nrb = (int)((M + p.BR - 1) / p.BR);
+  // aim for ~4096 workgroups so the hardware dispatcher can balance the triangular sweep
+  const double pairs = sym ? 0.5 * (double)M * (double)N : (double)M * (double)N;
+  double cc = pairs / ((double)p.BR * 4096.0);
+  int chunk = (int)((cc + p.BR - 1) / p.BR) * p.BR;
+  if (chunk < p.BR) chunk = p.BR;
+  if (chunk > 8192) chunk = 8192 / p.BR * p.BR;
+  p.chunk_cols = chunk;
+  p.maxchunks = (int)((N + chunk - 1) / chunk);
+  return p;
+}
+
+template <int JT, int TT, bool SYM>
+int launch_mvm_tile(const TilePlan &p, const float *Z1, const float *Z2, const float *V, float *slabR, float *slabT,
+                    int M, int N, int ldz1, int ldz2, int ldv, int j0, int t0, int tcnt, int accumulate,
+                    hipStream_t st) {
+  dim3 grid(p.maxchunks, p.nrb), block(256);
+  if (p.R == 2)
+    hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 2, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate);
+  else
+    hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 1, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate);
+  return launch_status();
+}
+
+template <int JT, bool SYM>
+int dispatch_t(int tt, const TilePlan &p, const float *Z1, const float *Z2, const float *V, float *slabR,
+               float *slabT, int M, int N, int ldz1, int ldz2, int ldv, int j0, int t0, int tcnt, int accumulate,
+               hipStream_t st) {
+  switch (tt) {
+    case 1: return launch_mvm_tile<JT, 1, SYM>(p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    case 4: return launch_mvm_tile<JT, 4, SYM>(p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    default: return launch_mvm_tile<JT, 12, SYM>(p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+  }
+}
+
+template <bool SYM>
+int dispatch_jt(int jt, int tt, const TilePlan &p, const float *Z1, const float *Z2, const float *V, float *slabR,
+                float *slabT, int M, int N, int ldz1, int ldz2, int ldv, int j0, int t0, int tcnt, int accumulate,
+                hipStream_t st) {
+  switch (jt) {
+    case 20: return dispatch_t<20, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    case 8: return dispatch_t<8, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    case 4: return dispatch_t<4, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    case 2: return dispatch_t<2, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    default: return dispatch_t<1, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+  }
+}
+
+inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym) {
+  const TilePlan p = make_plan(M, N, sym);
+  size_t f = (size_t)p.maxchunks * M * T;
+  if (sym) f += (size_t)p.nrb * N * T;
+  return f;
+}
+
+template <bool SYM>
+int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int64_t M, int64_t N, int ldz1,
+               int ldz2, int T, int j0, int j1, float scale, float noise, void *ws, size_t ws_bytes, void *stream) {
+  if (!Z1 || !Z2 || !V || !out || M <= 0 || N <= 0 || T <= 0 || j0 < 0 || j1 <= j0 || ldz1 < j1 || ldz2 < j1)
+    return RPGP_EINVAL;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL) return RPGP_EINVAL;
+  int rc = rpgp_init();
+  if (rc) return rc;
+  const size_t need = mvm_workspace_floats(M, N, T, SYM) * sizeof(float);
+  if (!ws || ws_bytes < need) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const TilePlan p = make_plan(M, N, SYM);
+  float *slabR = reinterpret_cast<float *>(ws);
+  float *slabT = slabR + (size_t)p.maxchunks * M * T;
+  int first = 1;
+  for (int j = j0; j < j1;) {
+    const int jt = next_j_piece(j1 - j);
+    for (int t0 = 0; t0 < T;) {
+      const int tt = next_t_piece(T - t0);
+      const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+      rc = dispatch_jt<SYM>(jt, tt, p, Z1, Z2, V, slabR, slabT, (int)M, (int)N, ldz1, ldz2, T, j, t0, tcnt,
+                            first ? 0 : 1, st);
+      if (rc) return rc;
+      t0 += tcnt;
+    }
+    first = 0;
+    j += jt;
+  }
+  const size_t total = (size_t)M * T;
+  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V,
+                     out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise);
+  return launch_status();
+}
+
+template <int JT>
+int launch_dense(const float *Z1, const float *Z2, float *out, int M, int N, int ldz1, int ldz2, long long ldo,
+                 int j0, float scale, int accumulate, hipStream_t st) {
+  dim3 grid((N + 255) / 256, (M + 15) / 16);
+  hipLaunchKernelGGL((dense_kernel<JT>), grid, dim3(256), 0, st, Z1, Z2, out, M, N, ldz1, ldz2, ldo, j0, scale,
+                     accumulate);
+  return launch_status();
+}
+
+template <int JT>
+int launch_bilinear(int tt, const float *Z, const float *L, const float *R, float *slabG, float *slabS, int N,
+                    int ldz, int T, int j0, int cols_per_split, int nsplit, hipStream_t st) {
+  dim3 grid(nsplit, (N + 255) / 256);
+  if (tt <= 1)
+    hipLaunchKernelGGL((bilinear_kernel<JT, 1>), grid, dim3(256), 0, st, Z, L, R, slabG, slabS, N, ldz, T, j0, cols_per_split);
+  else if (tt <= 4)
+    hipLaunchKernelGGL((bilinear_kernel<JT, 4>), grid, dim3(256), 0, st, Z, L, R, slabG, slabS, N, ldz, T, j0, cols_per_split);
+  else
+    hipLaunchKernelGGL((bilinear_kernel<JT, 12>), grid, dim3(256), 0, st, Z, L, R, slabG, slabS, N, ldz, T, j0, cols_per_split);
+  return launch_status();
+}
+
+inline int bilinear_nsplit(int64_t N) {
+  const int64_t nrb = (N + 255) / 256;
+  int64_t ns = (2048 + nrb - 1) / nrb;
+  const int64_t maxs = (N + 255) / 256;
+  if (ns > maxs) ns = maxs;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+
+}  // namespace
+
+// ------------------------------------ C ABI ---------------------------------------------------
+
+extern "C" {
+
+int rpgp_version(void) { return RPGP_ABI_VERSION; }
+
+const char *rpgp_error_string(int code) {
+  switch (code) {
+    case 0: return "success";
+    case RPGP_EINVAL: return "rpgp: invalid argument";
+    case RPGP_EWORKSPACE: return "rpgp: workspace too small";
+    case RPGP_ENODEVICE: return "rpgp: no usable gfx950 device";
+    default: return hipGetErrorString((hipError_t)code);
+  }
+}
+
+int rpgp_init(void) {
+  if (g_rotdir != 0) return 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RPGP_ENODEVICE;
+  int *d = nullptr;
+  RPGP_CHECK(hipMalloc(&d, 64 * sizeof(int)));
+  hipLaunchKernelGGL(probe_rotate_kernel, dim3(1), dim3(64), 0, 0, d);
+  int h[64];
+  hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) return (int)e;
+  if (h[0] == 1 && h[63] == 0) g_rotdir = 1;
+  else if (h[0] == 63 && h[1] == 0) g_rotdir = -1;
+  else return RPGP_ENODEVICE;
+  return 0;
+}
+
+int rpgp_project(const float *X, const float *Peff, float *Z, int64_t N, int d, int J, void *stream) {
+  if (!X || !Peff || !Z || N <= 0 || d <= 0 || J <= 0 || (size_t)d * J * 4 > 64 * 1024) return RPGP_EINVAL;
+  const long long total = N * J;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(project_kernel, dim3(blocks), dim3(256), (size_t)d * J * sizeof(float), as_stream(stream), X,
+                     Peff, Z, (long long)N, d, J);
+  return launch_status();
+}
+
+int rpgp_project_grad(const float *X, const float *G, float *dPeff, int64_t N, int d, int J, void *stream) {
+  if (!X || !G || !dPeff || N <= 0 || d <= 0 || J <= 0) return RPGP_EINVAL;
+  // two-pass deterministic reduction; partials live in a small static-size device buffer per call
+  // (allocated by the caller-visible workspace would be cleaner, but d*J*nblk is tiny) -> use hipMallocAsync.
+  const int nblk = (int)((N + 511) / 512 < 1024 ? (N + 511) / 512 : 1024);
+  const long long rows_per_block = (N + nblk - 1) / nblk;
+  float *part = nullptr;
+  hipStream_t st = as_stream(stream);
+  RPGP_CHECK(hipMallocAsync((void **)&part, (size_t)nblk * d * J * sizeof(float), st));
+  hipLaunchKernelGGL(project_grad_partial_kernel, dim3(nblk), dim3(256), 0, st, X, G, part, (long long)N, d, J,
+                     rows_per_block);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((d * J + 255) / 256), dim3(256), 0, st, part, dPeff, d * J, nblk, 1.0f);
+  int rc = launch_status();
+  hipFreeAsync(part, st);
+  return rc;
+}
+
+size_t rpgp_mvm_sym_workspace_bytes(int64_t N, int T) {
+  if (N <= 0 || T <= 0) return 0;
+  return mvm_workspace_floats(N, N, T, true) * sizeof(float);
+}
+
+int rpgp_mvm_sym(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1, float scale,
+                 float noise, void *workspace, size_t workspace_bytes, void *stream) {
+  return mvm_common<true>(Z, Z, V, out, N, N, ldz, ldz, T, j0, j1, scale, noise, workspace, workspace_bytes, stream);
+}
+
+size_t rpgp_mvm_rect_workspace_bytes(int64_t M, int64_t N, int T) {
+  if (M <= 0 || N <= 0 || T <= 0) return 0;
+  return mvm_workspace_floats(M, N, T, false) * sizeof(float);
+}
+
+int rpgp_mvm_rect(const float *Z1, const float *Z2, const float *V, float *out, int64_t M, int64_t N, int ldz1,
+                  int ldz2, int T, int j0, int j1, float scale, void *workspace, size_t workspace_bytes,
+                  void *stream) {
+  return mvm_common<false>(Z1, Z2, V, out, M, N, ldz1, ldz2, T, j0, j1, scale, 0.f, workspace, workspace_bytes,
+                           stream);
+}
+
+int rpgp_dense(const float *Z1, const float *Z2, float *out, int64_t M, int64_t N, int ldz1, int ldz2, int64_t ldo,
+               int j0, int j1, float scale, void *stream) {
+  if (!Z1 || !Z2 || !out || M <= 0 || N <= 0 || j0 < 0 || j1 <= j0 || ldz1 < j1 || ldz2 < j1 || ldo < N)
+    return RPGP_EINVAL;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL) return RPGP_EINVAL;
+  hipStream_t st = as_stream(stream);
+  int first = 1;
+  for (int j = j0; j < j1;) {
+    const int jt = next_j_piece(j1 - j);
+    int rc;
+    switch (jt) {
+      case 20: rc = launch_dense<20>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
+      case 8: rc = launch_dense<8>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
+      case 4: rc = launch_dense<4>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
+      case 2: rc = launch_dense<2>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
+      default: rc = launch_dense<1>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
+    }
+    if (rc) return rc;
+    first = 0;
+    j += jt;
+  }
+  return 0;
+}
+
+size_t rpgp_bilinear_grad_workspace_bytes(int64_t N, int J) {
+  if (N <= 0 || J <= 0) return 0;
+  const int ns = bilinear_nsplit(N);
+  // slabG [ns][N][<=20] + slabS [ns][N] + rowS [N]
+  return ((size_t)ns * N * 21 + (size_t)N) * sizeof(float);
+}
+
+int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ, float *gscale, int64_t N, int ldz,
+                       int ldg, int T, int j0, int j1, float scale, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+  if (!Z || !L || !R || !gZ || !gscale || N <= 0 || T <= 0 || T > 12 || j0 < 0 || j1 <= j0 || ldz < j1 || ldg < j1)
+    return RPGP_EINVAL;
+  if (N > 0x7fffffffLL) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int ns = bilinear_nsplit(N);
+  int cps = (int)((N + ns - 1) / ns);
+  cps = (cps + 63) / 64 * 64;
+  float *slabG = reinterpret_cast<float *>(workspace);
+  float *slabS = slabG + (size_t)ns * N * 20;
+  float *rowS = slabS + (size_t)ns * N;
+  int first = 1;
+  for (int j = j0; j < j1;) {
+    const int jt = next_j_piece(j1 - j);
+    int rc;
+    switch (jt) {
+      case 20: rc = launch_bilinear<20>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
+      case 8: rc = launch_bilinear<8>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
+      case 4: rc = launch_bilinear<4>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
+      case 2: rc = launch_bilinear<2>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
+      default: rc = launch_bilinear<1>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
+    }
+    if (rc) return rc;
+    // d/dZ = -scale * S e (z_i - z_i') ; kernel accumulated S e (c z_i - c z_i')  ->  multiply by -scale / c
+    const size_t total = (size_t)N * (jt + 1);
+    hipLaunchKernelGGL(bilinear_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabG, slabS,
+                       gZ, rowS, (int)N, jt, ldg, j, ns, -scale / kExp2Scale, first ? 0 : 1);
+    rc = launch_status();
+    if (rc) return rc;
+    first = 0;
+    j += jt;
+  }
+  hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, st, rowS, gscale, (int)N, 0.5f);
+  return launch_status();
+}
+
+int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64_t ldk, int T, float noise,
+                   void *stream) {
+  if (!Kd || !V || !out || N <= 0 || T <= 0 || ldk < N || N > 0x7fffffffLL) return RPGP_EINVAL;
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)((N + 3) / 4)), block(256);
+  if (T == 1) {
+    hipLaunchKernelGGL((dense_mvm_kernel<1>), grid, block, 0, st, Kd, V, out, (int)N, (long long)ldk, T, 0, noise);
+  } else {
+    for (int t0 = 0; t0 < T; t0 += 12) {
+      if (T - t0 <= 4)
+        hipLaunchKernelGGL((dense_mvm_kernel<4>), grid, block, 0, st, Kd, V, out, (int)N, (long long)ldk, T, t0, noise);
+      else
+        hipLaunchKernelGGL((dense_mvm_kernel<12>), grid, block, 0, st, Kd, V, out, (int)N, (long long)ldk, T, t0, noise);
+    }
+  }
+  return launch_status();
+}
+
+}  // extern "C"

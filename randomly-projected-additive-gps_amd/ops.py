@@ -1,0 +1,188 @@
+"""Tensor-level wrappers over the C-ABI (include/rpgp.h): torch supplies device memory and streams only.
+
+All functions require CUDA(=HIP) float32 contiguous tensors and launch on the caller's current stream.
+"""
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _require(t, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a HIP device (got %s): the rpgp kernels have no CPU fallback"
+                           % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must be %d-dimensional (got shape %s)" % (name, ndim, tuple(t.shape)))
+    return t.contiguous()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(device, nbytes):
+    """Grow-only per-(device, stream) scratch buffer; kernels on one stream are ordered so reuse is safe."""
+    key = (device.index, _stream())
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def init():
+    lib = _lib.load()
+    _lib.check(lib.rpgp_init(), "rpgp_init")
+
+
+def project(X, Peff):
+    """Z = X @ Peff  (N x d)(d x J) -> N x J."""
+    lib = _lib.load()
+    X = _require(X, "X", 2)
+    Peff = _require(Peff, "Peff", 2)
+    N, d = X.shape
+    if Peff.shape[0] != d:
+        raise ValueError("Peff must be d x J with d=%d (got %s)" % (d, tuple(Peff.shape)))
+    J = Peff.shape[1]
+    Z = torch.empty((N, J), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _lib.check(lib.rpgp_project(X.data_ptr(), Peff.data_ptr(), Z.data_ptr(), N, d, J, _stream()), "rpgp_project")
+    return Z
+
+
+def project_grad(X, G):
+    """dPeff = X^T @ G  (d x J)."""
+    lib = _lib.load()
+    X = _require(X, "X", 2)
+    G = _require(G, "G", 2)
+    N, d = X.shape
+    if G.shape[0] != N:
+        raise ValueError("G must have N=%d rows" % N)
+    J = G.shape[1]
+    out = torch.empty((d, J), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _lib.check(lib.rpgp_project_grad(X.data_ptr(), G.data_ptr(), out.data_ptr(), N, d, J, _stream()),
+                   "rpgp_project_grad")
+    return out
+
+
+def _as_matrix(V, N, name):
+    squeeze = V.dim() == 1
+    V2 = V.unsqueeze(1) if squeeze else V
+    V2 = _require(V2, name, 2)
+    if V2.shape[0] != N:
+        raise ValueError("%s must have %d rows (got %s)" % (name, N, tuple(V.shape)))
+    return V2, squeeze
+
+
+def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None):
+    """out = scale * sum_{j in [j0,j1)} K_j(Z,Z) @ V + noise * V."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    N, J = Z.shape
+    j1 = J if j1 is None else j1
+    V2, squeeze = _as_matrix(V, N, "V")
+    T = V2.shape[1]
+    if out is None:
+        out = torch.empty_like(V2)
+    with torch.cuda.device(Z.device):
+        nbytes = lib.rpgp_mvm_sym_workspace_bytes(N, T)
+        ws = _workspace(Z.device, nbytes)
+        _lib.check(lib.rpgp_mvm_sym(Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1, float(scale),
+                                    float(noise), ws.data_ptr(), ws.numel(), _stream()), "rpgp_mvm_sym")
+    return out.squeeze(1) if squeeze else out
+
+
+def mvm_rect(Z1, Z2, V, scale, j0=0, j1=None):
+    """out = scale * sum_j K_j(Z1,Z2) @ V   (M x T)."""
+    lib = _lib.load()
+    Z1 = _require(Z1, "Z1", 2)
+    Z2 = _require(Z2, "Z2", 2)
+    M, J = Z1.shape
+    N = Z2.shape[0]
+    if Z2.shape[1] != J:
+        raise ValueError("Z1 and Z2 must have the same number of projections")
+    j1 = J if j1 is None else j1
+    V2, squeeze = _as_matrix(V, N, "V")
+    T = V2.shape[1]
+    out = torch.empty((M, T), dtype=torch.float32, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        nbytes = lib.rpgp_mvm_rect_workspace_bytes(M, N, T)
+        ws = _workspace(Z1.device, nbytes)
+        _lib.check(lib.rpgp_mvm_rect(Z1.data_ptr(), Z2.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N, J, J, T,
+                                     j0, j1, float(scale), ws.data_ptr(), ws.numel(), _stream()), "rpgp_mvm_rect")
+    return out.squeeze(1) if squeeze else out
+
+
+def dense(Z1, Z2, scale, j0=0, j1=None):
+    """Dense block K(Z1,Z2) (M x N)."""
+    lib = _lib.load()
+    Z1 = _require(Z1, "Z1", 2)
+    Z2 = _require(Z2, "Z2", 2)
+    M, J = Z1.shape
+    N = Z2.shape[0]
+    if Z2.shape[1] != J:
+        raise ValueError("Z1 and Z2 must have the same number of projections")
+    j1 = J if j1 is None else j1
+    out = torch.empty((M, N), dtype=torch.float32, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        _lib.check(lib.rpgp_dense(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, j0, j1, float(scale),
+                                  _stream()), "rpgp_dense")
+    return out
+
+
+def bilinear_grad(Z, L, R, scale, j0=0, j1=None):
+    """(gZ [N x J], gscale [scalar tensor]) = d/dZ, d/dscale of sum((L R^T) * K(Z,Z))."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    N, J = Z.shape
+    j1 = J if j1 is None else j1
+    L2, _ = _as_matrix(L, N, "L")
+    R2, _ = _as_matrix(R, N, "R")
+    if L2.shape != R2.shape:
+        raise ValueError("L and R must have the same shape")
+    T = L2.shape[1]
+    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
+    gs = torch.zeros((), dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        if T <= 12:
+            nbytes = lib.rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)
+            ws = _workspace(Z.device, nbytes)
+            _lib.check(lib.rpgp_bilinear_grad(Z.data_ptr(), L2.data_ptr(), R2.data_ptr(), gZ.data_ptr(), gs.data_ptr(),
+                                              N, J, J, T, j0, j1, float(scale), ws.data_ptr(), ws.numel(), _stream()),
+                       "rpgp_bilinear_grad")
+        else:
+            # wide blocks are processed 12 columns at a time (the derivative is additive over columns)
+            nbytes = lib.rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)
+            ws = _workspace(Z.device, nbytes)
+            gZp = torch.empty_like(gZ)
+            gsp = torch.empty_like(gs)
+            for t0 in range(0, T, 12):
+                Lc = L2[:, t0:t0 + 12].contiguous()
+                Rc = R2[:, t0:t0 + 12].contiguous()
+                _lib.check(lib.rpgp_bilinear_grad(Z.data_ptr(), Lc.data_ptr(), Rc.data_ptr(), gZp.data_ptr(),
+                                                  gsp.data_ptr(), N, J, J, Lc.shape[1], j0, j1, float(scale),
+                                                  ws.data_ptr(), ws.numel(), _stream()), "rpgp_bilinear_grad")
+                gZ[:, j0:j1] += gZp[:, j0:j1]
+                gs += gsp
+    return gZ, gs
+
+
+def dense_mvm(Kd, V, noise=0.0):
+    """out = Kd @ V + noise * V for a cached dense symmetric kernel matrix."""
+    lib = _lib.load()
+    Kd = _require(Kd, "Kd", 2)
+    N = Kd.shape[0]
+    V2, squeeze = _as_matrix(V, N, "V")
+    T = V2.shape[1]
+    out = torch.empty_like(V2)
+    with torch.cuda.device(Kd.device):
+        _lib.check(lib.rpgp_dense_mvm(Kd.data_ptr(), V2.data_ptr(), out.data_ptr(), N, Kd.shape[1], T, float(noise),
+                                      _stream()), "rpgp_dense_mvm")
+    return out.squeeze(1) if squeeze else out

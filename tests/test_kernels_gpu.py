@@ -1,0 +1,147 @@
+"""GPU parity of the raw HIP kernels (through the C-ABI) against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_gp as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _data(N, J, T, seed=0, spread=1.0):
+    rng = np.random.default_rng(seed)
+    Z = (rng.standard_normal((N, J)) * spread).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    return Z, V
+
+
+@pytest.mark.parametrize("N,J,T", [(1, 20, 1), (63, 20, 1), (257, 20, 1), (300, 3, 1), (777, 18, 4), (1000, 20, 11),
+                                   (2049, 8, 1), (4096, 20, 1), (1500, 7, 13)])
+def test_mvm_sym_matches_oracle(gpu_device, N, J, T):
+    from rpgp_amd import ops
+    Z, V = _data(N, J, T, seed=N + J)
+    scale, noise = 0.7 / J, 0.1
+    ref = orc.mvm(Z, Z, V, scale, noise)
+    out = ops.mvm_sym(torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device), scale, noise)
+    # tolerance: fp32 accumulation of N terms + v_exp_f32 (1 ulp) -> 1e-5 relative in the 2-norm
+    assert _rel(out.cpu().numpy(), ref) < 1e-5
+
+
+def test_mvm_sym_large_two_rows_per_lane(gpu_device):
+    from rpgp_amd import ops
+    N, J, T = 16500, 20, 1
+    Z, V = _data(N, J, T, seed=5)
+    ref = orc.mvm(Z, Z, V, 1.0 / J, 0.05)
+    out = ops.mvm_sym(torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device), 1.0 / J, 0.05)
+    assert _rel(out.cpu().numpy(), ref) < 1e-5
+
+
+def test_mvm_sym_vector_rhs_and_jrange(gpu_device):
+    from rpgp_amd import ops
+    N, J = 900, 20
+    Z, V = _data(N, J, 1, seed=3)
+    Zt = torch.from_numpy(Z).to(gpu_device)
+    v = torch.from_numpy(V[:, 0].copy()).to(gpu_device)
+    full = ops.mvm_sym(Zt, v, 0.05, 0.0)
+    parts = sum(ops.mvm_sym(Zt, v, 0.05, 0.0, j0=a, j1=b) for a, b in [(0, 3), (3, 6), (6, 13), (13, 20)])
+    assert full.shape == (N,)
+    assert _rel(parts.cpu().numpy(), full.cpu().numpy()) < 1e-6
+    ref = orc.mvm(Z[:, 3:6], Z[:, 3:6], V, 0.05)
+    got = ops.mvm_sym(Zt, v, 0.05, 0.0, j0=3, j1=6)
+    assert _rel(got.cpu().numpy(), ref[:, 0]) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,J,T", [(31, 277, 20, 1), (820, 3000, 20, 1), (100, 1000, 3, 5), (513, 700, 20, 12),
+                                     (1, 50, 2, 1)])
+def test_mvm_rect_matches_oracle(gpu_device, M, N, J, T):
+    from rpgp_amd import ops
+    rng = np.random.default_rng(M)
+    Z1 = rng.standard_normal((M, J)).astype(np.float32)
+    Z2 = rng.standard_normal((N, J)).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    ref = orc.mvm(Z1, Z2, V, 0.3)
+    out = ops.mvm_rect(torch.from_numpy(Z1).to(gpu_device), torch.from_numpy(Z2).to(gpu_device),
+                       torch.from_numpy(V).to(gpu_device), 0.3)
+    assert _rel(out.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,J", [(15, 1000, 20), (277, 277, 6), (3, 2, 3), (700, 300, 18)])
+def test_dense_matches_oracle(gpu_device, M, N, J):
+    from rpgp_amd import ops
+    rng = np.random.default_rng(J)
+    Z1 = rng.standard_normal((M, J)).astype(np.float32)
+    Z2 = rng.standard_normal((N, J)).astype(np.float32)
+    ref = 0.5 * orc.additive_rbf(Z1, Z2)
+    out = ops.dense(torch.from_numpy(Z1).to(gpu_device), torch.from_numpy(Z2).to(gpu_device), 0.5)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-6, atol=2e-6)
+
+
+def test_known_answer_prescale(gpu_device):
+    """test.py:533-573: x=[[1,2,3],[1.1,2.2,3.3]], P=I, l=[1,2,3] -> K = 3*RBF(x[:,0])."""
+    from rpgp_amd import ops
+    x = torch.tensor([[1., 2., 3.], [1.1, 2.2, 3.3]], device=gpu_device)
+    ls = torch.tensor([1., 2., 3.], device=gpu_device)
+    P = torch.eye(3, device=gpu_device)
+    Z = ops.project(x, P / ls[:, None])
+    K = ops.dense(Z, Z, 1.0).cpu().numpy()
+    e = 3.0 * np.exp(-0.5 * 0.1 ** 2)
+    np.testing.assert_allclose(K, np.array([[3.0, e], [e, 3.0]]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,d,J", [(1000, 8, 20), (37, 6, 6), (5000, 20, 20), (300, 3, 3)])
+def test_project_and_grad(gpu_device, N, d, J):
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N)
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    P = rng.standard_normal((d, J)).astype(np.float32)
+    G = rng.standard_normal((N, J)).astype(np.float32)
+    Z = ops.project(torch.from_numpy(X).to(gpu_device), torch.from_numpy(P).to(gpu_device))
+    assert _rel(Z.cpu().numpy(), X.astype(np.float64) @ P.astype(np.float64)) < 1e-6
+    dP = ops.project_grad(torch.from_numpy(X).to(gpu_device), torch.from_numpy(G).to(gpu_device))
+    assert _rel(dP.cpu().numpy(), X.astype(np.float64).T @ G.astype(np.float64)) < 1e-5
+
+
+@pytest.mark.parametrize("N,J,T", [(300, 20, 11), (1000, 3, 1), (2500, 18, 11), (64, 20, 4), (500, 20, 20)])
+def test_bilinear_grad_matches_oracle(gpu_device, N, J, T):
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + T)
+    Z = rng.standard_normal((N, J)).astype(np.float32)
+    L = rng.standard_normal((N, T)).astype(np.float32)
+    R = rng.standard_normal((N, T)).astype(np.float32)
+    gZ_ref, gs_ref = orc.bilinear_grad(Z, L, R, 0.2)
+    gZ, gs = ops.bilinear_grad(torch.from_numpy(Z).to(gpu_device), torch.from_numpy(L).to(gpu_device),
+                               torch.from_numpy(R).to(gpu_device), 0.2)
+    assert _rel(gZ.cpu().numpy(), gZ_ref) < 2e-5
+    assert abs(gs.item() - gs_ref) <= 2e-5 * max(abs(gs_ref), np.abs(L).sum() * 1e-3)
+
+
+@pytest.mark.parametrize("N,T", [(1000, 1), (2049, 11), (300, 3)])
+def test_dense_mvm(gpu_device, N, T):
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N)
+    Z = rng.standard_normal((N, 5)).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    Zt = torch.from_numpy(Z).to(gpu_device)
+    Kd = ops.dense(Zt, Zt, 0.2)
+    out = ops.dense_mvm(Kd, torch.from_numpy(V).to(gpu_device), 0.3)
+    ref = orc.mvm(Z, Z, V, 0.2, 0.3)
+    assert _rel(out.cpu().numpy(), ref) < 1e-5
+
+
+def test_errors_are_python_exceptions(gpu_device):
+    from rpgp_amd import ops
+    Z = torch.zeros((10, 4), device=gpu_device)
+    with pytest.raises(ValueError):
+        ops.mvm_sym(Z, torch.zeros((9, 1), device=gpu_device), 1.0)
+    with pytest.raises(ValueError):
+        ops.mvm_sym(Z, torch.zeros((10, 1), device=gpu_device), 1.0, j0=3, j1=2)
+    with pytest.raises(RuntimeError):
+        ops.mvm_sym(Z.cpu(), torch.zeros((10, 1)), 1.0)
+    with pytest.raises(TypeError):
+        ops.mvm_sym(Z.double(), torch.zeros((10, 1), device=gpu_device).double(), 1.0)

@@ -108,6 +108,15 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
 int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64_t ldk, int T,
                    float noise, void *stream);
 
+/*
+ * Measurement hook used by bench.py (roofline.achieved): between begin/end every rpgp_mvm_sym / rpgp_mvm_rect call
+ * records a HIP-event pair on its stream around the dominant fused tile kernel launch(es) (the small slab-reduce
+ * launch is outside the pair).  `rpgp_profile_end` synchronises those events and returns the mean duration (ms)
+ * and the number of calls in HOST memory.  Not thread-safe; off by default.
+ */
+int rpgp_profile_begin(void);
+int rpgp_profile_end(float *avg_ms_host, int *count_host);
+
 #ifdef __cplusplus
 }
 #endif

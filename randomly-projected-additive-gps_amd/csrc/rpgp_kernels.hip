@@ -518,6 +518,12 @@ __global__ __launch_bounds__(256) void dense_mvm_kernel(const float *__restrict_
 
 int g_rotdir = 0;  // +1: wave_rotate1 delivers lane l+1's value to lane l; -1: lane l-1's.  0 = not probed.
 
+// Optional measurement hook (bench.py): HIP-event pairs around the dominant (tile) kernel launches.
+constexpr int kProfMax = 4096;
+bool g_prof_on = false;
+int g_prof_n = 0;
+hipEvent_t g_prof_ev[2 * kProfMax];
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define RPGP_CHECK(expr)                          \
@@ -628,6 +634,8 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
   float *slabR = reinterpret_cast<float *>(ws);
   float *slabT = slabR + (size_t)p.maxchunks * M * T;
   int first = 1;
+  const bool prof = g_prof_on && g_prof_n < kProfMax;
+  if (prof) RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
   for (int j = j0; j < j1;) {
     const int jt = next_j_piece(j1 - j);
     for (int t0 = 0; t0 < T;) {
@@ -640,6 +648,10 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
     }
     first = 0;
     j += jt;
+  }
+  if (prof) {
+    RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st));
+    ++g_prof_n;
   }
   const size_t total = (size_t)M * T;
   hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V,
@@ -710,6 +722,31 @@ int rpgp_init(void) {
   if (h[0] == 1 && h[63] == 0) g_rotdir = 1;
   else if (h[0] == 63 && h[1] == 0) g_rotdir = -1;
   else return RPGP_ENODEVICE;
+  return 0;
+}
+
+int rpgp_profile_begin(void) {
+  if (!g_prof_on) {
+    for (int i = 0; i < 2 * kProfMax; ++i)
+      if (!g_prof_ev[i]) RPGP_CHECK(hipEventCreate(&g_prof_ev[i]));
+  }
+  g_prof_on = true;
+  g_prof_n = 0;
+  return 0;
+}
+
+int rpgp_profile_end(float *avg_ms_host, int *count_host) {
+  g_prof_on = false;
+  double sum = 0.0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    RPGP_CHECK(hipEventSynchronize(g_prof_ev[2 * i + 1]));
+    float ms = 0.f;
+    RPGP_CHECK(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+    sum += ms;
+  }
+  if (avg_ms_host) *avg_ms_host = g_prof_n ? (float)(sum / g_prof_n) : 0.f;
+  if (count_host) *count_host = g_prof_n;
+  g_prof_n = 0;
   return 0;
 }
 

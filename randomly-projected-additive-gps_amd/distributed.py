@@ -1,0 +1,65 @@
+"""J-sharding of the additive kernel across ranks: K = sum_j K_j, so rank r owns a contiguous
+slice of the J projections, computes its partial MVM over the full N x N index space and the length-N (x T) partials
+are summed with ONE all-reduce per MVM (RCCL over xGMI on MI355X: `torch.distributed` backend "nccl"; gloo on CPU in
+tests).  The noise term is added once, after the reduce, so every rank holds the identical result and runs the
+identical CG recurrences.
+
+Replaces the row-sharded `MultiDeviceKernel(kernel, devices, devices[0])` of training_routines.py:407-408.
+"""
+import torch
+import torch.distributed as dist
+
+
+def j_partition(J, world_size):
+    """Contiguous, balanced split of range(J): the first J % world_size ranks get one extra projection.
+    Returns a list of (j0, j1); ranks beyond J get empty ranges (j0 == j1)."""
+    if J <= 0 or world_size <= 0:
+        raise ValueError("J and world_size must be positive")
+    base, extra = divmod(J, world_size)
+    out, start = [], 0
+    for r in range(world_size):
+        n = base + (1 if r < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+def is_distributed(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def all_reduce_sum_(t, group=None):
+    """In-place SUM all-reduce; identity when not running distributed."""
+    if is_distributed(group):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class JShard:
+    """This rank's slice of the projections."""
+
+    def __init__(self, J, group=None):
+        self.group = group
+        if is_distributed(group):
+            self.world_size = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+        else:
+            self.world_size, self.rank = 1, 0
+        self.J = J
+        self.j0, self.j1 = j_partition(J, self.world_size)[self.rank]
+
+    @property
+    def empty(self):
+        return self.j1 <= self.j0
+
+    def sharded_mvm(self, local_mvm, V, noise):
+        """local_mvm(j0, j1) -> partial product of this rank's projections (no noise term).
+        Returns sum over ranks + noise * V, identical on every rank."""
+        if self.empty:
+            partial = torch.zeros_like(V)
+        else:
+            partial = local_mvm(self.j0, self.j1)
+        all_reduce_sum_(partial, self.group)
+        if noise != 0.0:
+            partial = partial.add_(V, alpha=noise)
+        return partial

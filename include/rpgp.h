@@ -102,6 +102,17 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Same derivative with an explicit symmetric weight matrix S (N x N, row stride lds):
+ *   gZ[i,j] = -scale * sum_i' S[i,i'] e_j(i,i') (Z[i,j]-Z[i',j]) ;  gscale = 0.5 * sum_{ii'} S[i,i'] sum_j e_j(i,i')
+ * i.e. d/dZ, d/dscale of 0.5 * sum(S * K).  Used by the dense Cholesky regime (N <= max_cholesky_size, or
+ * `--use_chol`, gp_experiment_runner.py:236,326) where S = Khat^-1 - alpha alpha^T is formed exactly.
+ * Workspace: rpgp_bilinear_grad_workspace_bytes.
+ */
+int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *gscale,
+                             int64_t N, int ldz, int ldg, int64_t lds, int j0, int j1, float scale,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Dense symmetric-matrix MVM for the cached-K mode:  out = Kd @ V + noise * V   (Kd: N x N fp32 in HBM).
  * HBM-bound stream of Kd.
  */

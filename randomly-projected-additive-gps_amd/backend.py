@@ -1,0 +1,33 @@
+"""Compute backend seam.  The product ships exactly ONE backend: `HipBackend` (the gfx950 library behind include/rpgp.h).
+`set_backend` exists so that host logic (CG, SLQ, sharding, training loop) can be unit-tested on machines without a
+GPU by injecting a test double defined under tests/; the package itself never falls back to anything."""
+from . import ops
+
+
+class HipBackend:
+    """Thin object wrapper over rpgp_amd.ops (fails loudly without librpgp.so / without a HIP device)."""
+    name = "hip-gfx950"
+
+    project = staticmethod(ops.project)
+    project_grad = staticmethod(ops.project_grad)
+    mvm_sym = staticmethod(ops.mvm_sym)
+    mvm_rect = staticmethod(ops.mvm_rect)
+    dense = staticmethod(ops.dense)
+    bilinear_grad = staticmethod(ops.bilinear_grad)
+    bilinear_grad_dense = staticmethod(ops.bilinear_grad_dense)
+    dense_mvm = staticmethod(ops.dense_mvm)
+
+
+_backend = HipBackend()
+
+
+def get_backend():
+    return _backend
+
+
+def set_backend(b):
+    """Install another backend object (tests only). Returns the previous one."""
+    global _backend
+    prev = _backend
+    _backend = b
+    return prev

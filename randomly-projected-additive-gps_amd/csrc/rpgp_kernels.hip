@@ -430,6 +430,57 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
   }
 }
 
+// Dense-weight variant for the Cholesky regime (N <= max_cholesky_size): S is an explicit symmetric N x N matrix
+// (e.g. Khat^-1 - alpha alpha^T).  Lane owns row i and reads S[c][i] (coalesced thanks to symmetry).
+template <int JT>
+__global__ __launch_bounds__(256) void bilinear_dense_kernel(const float *__restrict__ Z, const float *__restrict__ S,
+                                                             float *__restrict__ slabG, float *__restrict__ slabS,
+                                                             int N, int ldz, long long lds_, int j0,
+                                                             int cols_per_split) {
+  __shared__ __attribute__((aligned(16))) float sC[64 * JT];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.y * 256 + tid;
+  const bool valid = row < N;
+  const int c_begin = blockIdx.x * cols_per_split;
+  if (c_begin >= N) return;
+  const int c_end = (c_begin + cols_per_split < N) ? c_begin + cols_per_split : N;
+  float a[JT], accG[JT];
+  float accS = 0.f;
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    a[j] = valid ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 0.f;
+    accG[j] = 0.f;
+  }
+  for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * JT; e += 256) {
+      const int c = e / JT, q = e % JT;
+      const int col = c0 + c;
+      sC[e] = (col < c_end) ? Z[(size_t)col * ldz + j0 + q] * kExp2Scale : 0.f;
+    }
+    __syncthreads();
+    const int nc = (c_end - c0 < 64) ? c_end - c0 : 64;
+    for (int c = 0; c < nc; ++c) {
+      const float *p = sC + c * JT;
+      const float Sv = valid ? S[(size_t)(c0 + c) * lds_ + row] : 0.f;
+      float ks = 0.f;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const float dd = a[j] - p[j];
+        const float e = fast_exp2(-(dd * dd));
+        ks += e;
+        accG[j] = __builtin_fmaf(Sv * e, dd, accG[j]);
+      }
+      accS = __builtin_fmaf(Sv, ks, accS);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) slabG[((size_t)blockIdx.x * N + row) * JT + j] = accG[j];
+    slabS[(size_t)blockIdx.x * N + row] = accS;
+  }
+}
+
 // gZ[row][j0+j] = mulG * sum_split slabG ; rowS[row] = sum_split slabS  (+= if accumulate)
 __global__ void bilinear_reduce_kernel(const float *__restrict__ slabG, const float *__restrict__ slabS,
                                        float *__restrict__ gZ, float *__restrict__ rowS, int N, int JT, int ldg,
@@ -681,6 +732,15 @@ int launch_bilinear(int tt, const float *Z, const float *L, const float *R, floa
   return launch_status();
 }
 
+template <int JT>
+int launch_bilinear_dense(const float *Z, const float *S, float *slabG, float *slabS, int N, int ldz, long long lds_,
+                          int j0, int cols_per_split, int nsplit, hipStream_t st) {
+  dim3 grid(nsplit, (N + 255) / 256);
+  hipLaunchKernelGGL((bilinear_dense_kernel<JT>), grid, dim3(256), 0, st, Z, S, slabG, slabS, N, ldz, lds_, j0,
+                     cols_per_split);
+  return launch_status();
+}
+
 inline int bilinear_nsplit(int64_t N) {
   const int64_t nrb = (N + 255) / 256;
   int64_t ns = (2048 + nrb - 1) / nrb;
@@ -856,6 +916,44 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
     }
     if (rc) return rc;
     // d/dZ = -scale * S e (z_i - z_i') ; kernel accumulated S e (c z_i - c z_i')  ->  multiply by -scale / c
+    const size_t total = (size_t)N * (jt + 1);
+    hipLaunchKernelGGL(bilinear_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabG, slabS,
+                       gZ, rowS, (int)N, jt, ldg, j, ns, -scale / kExp2Scale, first ? 0 : 1);
+    rc = launch_status();
+    if (rc) return rc;
+    first = 0;
+    j += jt;
+  }
+  hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, st, rowS, gscale, (int)N, 0.5f);
+  return launch_status();
+}
+
+int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *gscale, int64_t N, int ldz, int ldg,
+                             int64_t lds_, int j0, int j1, float scale, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+  if (!Z || !S || !gZ || !gscale || N <= 0 || j0 < 0 || j1 <= j0 || ldz < j1 || ldg < j1 || lds_ < N)
+    return RPGP_EINVAL;
+  if (N > 0x7fffffffLL) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int ns = bilinear_nsplit(N);
+  int cps = (int)((N + ns - 1) / ns);
+  cps = (cps + 63) / 64 * 64;
+  float *slabG = reinterpret_cast<float *>(workspace);
+  float *slabS = slabG + (size_t)ns * N * 20;
+  float *rowS = slabS + (size_t)ns * N;
+  int first = 1;
+  for (int j = j0; j < j1;) {
+    const int jt = next_j_piece(j1 - j);
+    int rc;
+    switch (jt) {
+      case 20: rc = launch_bilinear_dense<20>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
+      case 8: rc = launch_bilinear_dense<8>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
+      case 4: rc = launch_bilinear_dense<4>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
+      case 2: rc = launch_bilinear_dense<2>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
+      default: rc = launch_bilinear_dense<1>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
+    }
+    if (rc) return rc;
     const size_t total = (size_t)N * (jt + 1);
     hipLaunchKernelGGL(bilinear_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabG, slabS,
                        gZ, rowS, (int)N, jt, ldg, j, ns, -scale / kExp2Scale, first ? 0 : 1);

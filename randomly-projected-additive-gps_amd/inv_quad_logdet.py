@@ -1,0 +1,154 @@
+"""inv_quad / log-det of Khat = K + sigma^2 I with gradients.
+
+Two regimes, switched like GPyTorch does (Appendix B.1):
+  * N <= settings.max_cholesky_size or fast_computations(log_prob=False): dense Cholesky of rpgp_dense(K);
+    backward through the explicit-weight HIP derivative kernel (rpgp_bilinear_grad_dense);
+  * otherwise: preconditioned mBCG on [probes | y - c] (T = num_trace_samples + 1 = 11), SLQ log-det from the
+    Lanczos tridiagonals (+ log|M| of the preconditioner), backward through the fused bilinear-derivative kernel
+    with L = [Khat^-1 z_p / p, -Khat^-1 r], R = [M^-1 z_p, Khat^-1 r]   (replaces `_quad_form_derivative`
+    triggered by loss.backward() at fitting/optimizing.py:72).
+"""
+import torch
+
+from . import settings
+from .linear_cg import linear_cg
+from .operators import AddedDiagOperator
+from .precond import build_preconditioner
+
+
+def _probe_generator(device):
+    if settings.deterministic_probes.on():
+        g = torch.Generator(device=device)
+        g.manual_seed(12345)
+        return g
+    return None
+
+
+def use_cholesky(N):
+    return N <= settings.max_cholesky_size.value() or not settings.fast_computations.log_prob()
+
+
+def psd_safe_cholesky(A, max_tries=4):
+    """Cholesky with escalating jitter (GPyTorch's psd_safe_cholesky behaviour)."""
+    L, info = torch.linalg.cholesky_ex(A)
+    if not bool(info.any()):
+        return L
+    jitter = 1e-6 if A.dtype == torch.float32 else 1e-8
+    Aj = A.clone()
+    prev = 0.0
+    for i in range(max_tries):
+        new = jitter * (10 ** i)
+        Aj.diagonal().add_(new - prev)
+        prev = new
+        L, info = torch.linalg.cholesky_ex(Aj)
+        if not bool(info.any()):
+            import warnings
+            from .linear_cg import NumericalWarning
+            warnings.warn("A not p.d., added jitter of %.1e to the diagonal" % new, NumericalWarning)
+            return L
+    raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %.1e" % new)
+
+
+def slq_logdet(t_mat, n):
+    """log|A| estimate from Lanczos tridiagonals of unit-norm probes:  (n/p) sum_p sum_m Q_p[0,m]^2 log lambda_pm."""
+    evals, evecs = torch.linalg.eigh(t_mat.double())
+    evals = evals.clamp_min(1e-30)
+    w = evecs[:, 0, :] ** 2
+    return float(n) * (w * torch.log(evals)).sum(-1).mean()
+
+
+class InvQuadLogDet(torch.autograd.Function):
+    """(inv_quad, logdet) = (r^T Khat^-1 r, log|Khat|) for Khat = K(Z) * outputscale + noise I."""
+
+    @staticmethod
+    def forward(ctx, Z, outputscale, noise, rhs, op):
+        # `op` is the AdditiveRPOperator built on (Z, outputscale); passed as a non-tensor argument
+        N = Z.shape[0]
+        khat = AddedDiagOperator(op, noise.detach())
+        r = rhs.detach().reshape(N, 1)
+        ctx.op = op
+        ctx.N = N
+        if use_cholesky(N):
+            Kd = khat.to_dense()
+            Lc = psd_safe_cholesky(Kd)
+            alpha = torch.cholesky_solve(r, Lc)
+            inv_quad = (r * alpha).sum()
+            logdet = 2.0 * torch.log(Lc.diagonal()).sum()
+            ctx.mode = "chol"
+            ctx.save_for_backward(Lc, alpha)
+            return inv_quad, logdet
+
+        num_probes = settings.num_trace_samples.value()
+        pre = build_preconditioner(op, float(noise.detach()), settings)
+        gen = _probe_generator(Z.device)
+        if pre is not None:
+            probes = pre.sample(num_probes, generator=gen)
+            logdet_correction = pre.logdet()
+        else:
+            probes = torch.randn(N, num_probes, generator=gen, device=Z.device, dtype=Z.dtype)
+            logdet_correction = 0.0
+        if op.shard is not None and op.shard.world_size > 1:
+            # every rank must run the identical CG recurrences: rank 0's probes are broadcast
+            import torch.distributed as dist
+            dist.broadcast(probes, src=0, group=op.shard.group)
+        probe_norms = probes.norm(2, dim=0, keepdim=True)
+        probes_n = probes / probe_norms
+        full_rhs = torch.cat([probes_n, r], dim=1)
+        solves, t_mat = linear_cg(khat._matmul, full_rhs, n_tridiag=num_probes,
+                                  tolerance=settings.cg_tolerance.value(),
+                                  max_iter=settings.max_cg_iterations.value(),
+                                  max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),
+                                  preconditioner=pre)
+        alpha = solves[:, num_probes:]
+        inv_quad = (r * alpha).sum()
+        if settings.skip_logdet_forward.on():
+            logdet = torch.zeros((), dtype=Z.dtype, device=Z.device)
+        else:
+            logdet = (slq_logdet(t_mat, N) + logdet_correction).to(Z.dtype)
+        ctx.mode = "cg"
+        ctx.pre = pre
+        ctx.num_probes = num_probes
+        probe_solves = solves[:, :num_probes] * probe_norms          # Khat^-1 z_p
+        ctx.save_for_backward(probe_solves, probes, alpha)
+        return inv_quad, logdet
+
+    @staticmethod
+    def backward(ctx, g_inv_quad, g_logdet):
+        op = ctx.op
+        need = ctx.needs_input_grad
+        gZ = gs = gn = gr = None
+        if ctx.mode == "chol":
+            Lc, alpha = ctx.saved_tensors
+            Kinv = torch.cholesky_inverse(Lc)
+            # d(g_iq * inv_quad + g_ld * logdet) = sum_{ii'} (g_ld Kinv - g_iq alpha alpha^T)[i,i'] dKhat[i,i']
+            S = g_logdet * Kinv - g_inv_quad * (alpha @ alpha.t())
+            if need[0] or need[1]:
+                gZ, gs = op.dense_weight_derivative((2.0 * S).contiguous())
+            if need[2]:
+                gn = S.diagonal().sum()
+            if need[3]:
+                gr = (2.0 * g_inv_quad * alpha).reshape(-1)
+        else:
+            probe_solves, probes, alpha = ctx.saved_tensors
+            p = ctx.num_probes
+            pre_probes = ctx.pre.solve(probes) if ctx.pre is not None else probes
+            left = torch.cat([probe_solves * (g_logdet / p), -g_inv_quad * alpha], dim=1).contiguous()
+            right = torch.cat([pre_probes, alpha], dim=1).contiguous()
+            if need[0] or need[1]:
+                gZ, gs = op._bilinear_derivative(left, right)
+            if need[2]:
+                gn = (left * right).sum()
+            if need[3]:
+                gr = (2.0 * g_inv_quad * alpha).reshape(-1)
+        if gs is not None:
+            gs = gs.reshape(ctx.op.outputscale.shape)
+        if gn is not None:
+            gn = gn.reshape(())
+        return gZ, gs, gn, gr, None
+
+
+def inv_quad_logdet(op, noise, rhs):
+    """op: symmetric AdditiveRPOperator on (Z, outputscale) (both may require grad); noise: 0-dim tensor; rhs: (N,)."""
+    noise_t = noise.reshape(())
+    gr = InvQuadLogDet.apply(op.Z1, op.outputscale, noise_t, rhs, op)
+    return gr

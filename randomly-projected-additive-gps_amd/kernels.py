@@ -1,0 +1,188 @@
+"""Kernel modules mirroring the reference's operator/plugin interface for the hot path
+(gp_models/kernels/scaled_projection_kernel.py, gp_models/kernels/memory_efficient_gam_kernel.py and the GPyTorch
+classes assembled in training_routines.py:131-189,406).  `forward` returns a LinearOperator-shaped object
+(rpgp_amd.operators) instead of a dense tensor — the same move KeOps kernels make in the reference
+(gp_models/kernels/imq_kernel.py:51-58).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import backend as _backend
+from .operators import AdditiveRPOperator
+
+
+def inv_softplus(y):
+    y = torch.as_tensor(y, dtype=torch.float64)
+    return (y + torch.log(-torch.expm1(-y))).to(torch.get_default_dtype())
+
+
+class _Project(torch.autograd.Function):
+    """Z = X @ Peff on the HIP backend; backward dPeff = X^T dZ (X is data: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, X, Peff):
+        ctx.save_for_backward(X)
+        return _backend.get_backend().project(X, Peff.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, gZ):
+        (X,) = ctx.saved_tensors
+        return None, _backend.get_backend().project_grad(X, gZ.contiguous())
+
+
+class Kernel(nn.Module):
+    """Base with the GPyTorch lengthscale parameterisation: lengthscale = softplus(raw_lengthscale), shape (1, ard)."""
+
+    has_lengthscale = False
+
+    def __init__(self, ard_num_dims=None, **kwargs):
+        super().__init__()
+        self.ard_num_dims = ard_num_dims
+        if self.has_lengthscale:
+            n = 1 if ard_num_dims is None else ard_num_dims
+            self.raw_lengthscale = nn.Parameter(torch.zeros(1, n))
+
+    @property
+    def lengthscale(self):
+        return F.softplus(self.raw_lengthscale) if self.has_lengthscale else None
+
+    @lengthscale.setter
+    def lengthscale(self, value):
+        self._set_lengthscale(value)
+
+    def _set_lengthscale(self, value):
+        value = torch.as_tensor(value, dtype=self.raw_lengthscale.dtype).reshape(1, -1)
+        value = value.expand_as(self.raw_lengthscale) if value.numel() == 1 else value
+        self.raw_lengthscale.data = inv_softplus(value).to(self.raw_lengthscale)
+
+    def initialize(self, **kwargs):
+        for name, val in kwargs.items():
+            if name == "lengthscale":
+                self._set_lengthscale(val)
+            elif name == "outputscale":
+                self._set_outputscale(val)
+            elif hasattr(self, name) and isinstance(getattr(self, name), nn.Parameter):
+                getattr(self, name).data = torch.as_tensor(val).to(getattr(self, name)).reshape(getattr(self, name).shape)
+            else:
+                raise AttributeError("Unknown parameter %s for %s" % (name, type(self).__name__))
+        return self
+
+    def __call__(self, x1, x2=None, **params):
+        return self.forward(x1, x1 if x2 is None else x2, **params)
+
+
+class AdditiveStructureRBFKernel(Kernel):
+    """`AdditiveStructureKernel(ScaleKernel(RBFKernel(lengthscale=1), outputscale=1/J), J)` of
+    training_routines.py:148-159,169-171 as ONE module: K_add = (1/J) sum_j exp(-0.5 (z1_j - z2_j)^2).
+    Its parameters (inner lengthscale 1, outputscale 1/J) are frozen by the wrapper
+    (scaled_projection_kernel.py:15-17), so they are plain buffers here."""
+
+    def __init__(self, num_dims, weight=None, inner_lengthscale=1.0):
+        super().__init__()
+        self.num_dims = num_dims
+        self.register_buffer("weight", torch.tensor(1.0 / num_dims if weight is None else float(weight)))
+        self.register_buffer("inner_lengthscale", torch.tensor(float(inner_lengthscale)))
+
+    def operator(self, Z1, Z2, outputscale=None, shard=None):
+        il = float(self.inner_lengthscale)
+        if il != 1.0:
+            Z1 = Z1 / il
+            Z2 = None if Z2 is None else Z2 / il
+        return AdditiveRPOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight), shard=shard)
+
+    def forward(self, z1, z2, **params):
+        return self.operator(z1, None if z2 is z1 else z2)
+
+
+class MemoryEfficientGamKernel(AdditiveStructureRBFKernel):
+    """gp_models/kernels/memory_efficient_gam_kernel.py:62-69 as constructed bare at training_routines.py:168:
+    sum of 1-D RBFs with the DEFAULT lengthscale softplus(0) = ln 2 and no 1/J weight."""
+
+    def __init__(self, num_dims=None):
+        super().__init__(num_dims if num_dims else 1, weight=1.0, inner_lengthscale=math.log(2.0))
+
+
+class ScaledProjectionKernel(Kernel):
+    """ARD-scale -> project -> base additive kernel (gp_models/kernels/scaled_projection_kernel.py:5-37).
+
+    prescale:  Z = (X / lengthscale) @ P      (ard over the d input dims)
+    postscale: Z = (X @ P) / lengthscale      (ard over the J projected dims)
+    The base kernel's parameters are frozen and the projection is frozen unless `learn_proj`
+    (scaled_projection_kernel.py:10-17; pinned by test.py:597-598,619-621)."""
+
+    has_lengthscale = True
+
+    def __init__(self, projection_module, base_kernel, prescale=False, ard_num_dims=None, learn_proj=False, **kwargs):
+        super().__init__(ard_num_dims=ard_num_dims, **kwargs)
+        self.projection_module = projection_module
+        self.learn_proj = learn_proj
+        if not learn_proj:
+            for p in self.projection_module.parameters():
+                p.requires_grad = False
+        self.base_kernel = base_kernel
+        for p in self.base_kernel.parameters():
+            p.requires_grad = False
+        self.prescale = prescale
+
+    def effective_projection(self):
+        """Peff (d x J) with the lengthscale folded in."""
+        P = self.projection_module.weight.t()           # Linear.weight is J x d  (training_routines.py:144-145)
+        ls = self.lengthscale.reshape(-1)
+        if self.prescale:
+            return P / (ls.reshape(-1, 1) if ls.numel() > 1 else ls)
+        return P / (ls.reshape(1, -1) if ls.numel() > 1 else ls)
+
+    def project(self, x):
+        return _Project.apply(x.contiguous(), self.effective_projection())
+
+    def forward(self, x1, x2, outputscale=None, shard=None, **params):
+        # the reference decides with torch.equal(x1, x2) (host sync per call, scaled_projection_kernel.py:22);
+        # identity of the tensor objects is enough for every call site on the path
+        same = x2 is None or x2 is x1 or (x1.shape == x2.shape and x1.data_ptr() == x2.data_ptr())
+        z1 = self.project(x1)
+        z2 = None if same else self.project(x2)
+        return self.base_kernel.operator(z1, z2, outputscale=outputscale, shard=shard)
+
+
+class ScaleKernel(Kernel):
+    """Outer `gpytorch.kernels.ScaleKernel(kernel)` of training_routines.py:406: K = softplus(raw_outputscale) * K_base."""
+
+    def __init__(self, base_kernel):
+        super().__init__()
+        self.base_kernel = base_kernel
+        self.raw_outputscale = nn.Parameter(torch.zeros(()))
+        self.shard = None
+
+    @property
+    def outputscale(self):
+        return F.softplus(self.raw_outputscale)
+
+    @outputscale.setter
+    def outputscale(self, value):
+        self._set_outputscale(value)
+
+    def _set_outputscale(self, value):
+        self.raw_outputscale.data = inv_softplus(torch.as_tensor(value).reshape(())).to(self.raw_outputscale)
+
+    def forward(self, x1, x2, **params):
+        return self.base_kernel.forward(x1, x2, outputscale=self.outputscale, shard=self.shard, **params)
+
+
+class RBFKernel(Kernel):
+    """Plain (non-additive) RBF kernel for `kind: full` (training_routines.py:275-293; BASELINE config 1 = CPU
+    plumbing through the runner).  NOT the hot path: dense torch ops, any device."""
+
+    has_lengthscale = True
+
+    def dense(self, x1, x2):
+        a = x1 / self.lengthscale
+        b = x2 / self.lengthscale
+        d2 = (a.pow(2).sum(-1, keepdim=True) - 2.0 * a @ b.t() + b.pow(2).sum(-1).unsqueeze(0)).clamp_min(0.0)
+        return torch.exp(-0.5 * d2)
+
+    def forward(self, x1, x2, outputscale=None, **params):
+        from .dense_ops import DenseKernelOperator
+        return DenseKernelOperator(self, x1, x2, outputscale)

@@ -1,0 +1,146 @@
+"""Preconditioned batched conjugate gradients with Lanczos tridiagonalisation (mBCG).
+
+Re-implementation of the algorithm GPyTorch's `gpytorch.utils.linear_cg` runs for the reference (SURVEY.md §8(a)
+row a9, Appendix B.2; settings at gp_experiment_runner.py:324-329):
+  * right-hand-side columns are normalised to unit 2-norm, x0 = 0;
+  * per iteration  alpha = (r.z)/(p.Ap),  x += alpha p,  r -= alpha Ap,  z = M^-1 r,  beta = (r+.z+)/(r.z),  p = z + beta p;
+  * for the first `n_tridiag` columns and the first `max_tridiag_iter` iterations the Lanczos tridiagonal is
+    T[k,k] = 1/alpha_k + beta_{k-1}/alpha_{k-1},  T[k,k-1] = T[k-1,k] = sqrt(beta_{k-1})/alpha_{k-1};
+  * stop when the mean column residual norm < tolerance after >= 10 iterations (and the tridiagonal steps are done),
+    or at max_iter, in which case a NumericalWarning is issued (the reference counts these warnings,
+    training_routines.py:535,581).
+Every vector op is a torch op on the operator's device; the only host sync is the stopping test.
+"""
+import warnings
+
+import torch
+
+from . import settings
+
+
+class NumericalWarning(RuntimeWarning):
+    """Issued when CG stops at max_iter without reaching the tolerance."""
+
+
+def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_updating_after=1e-10, max_iter=None,
+              max_tridiag_iter=None, initial_guess=None, preconditioner=None, check_every=1):
+    """Solve A X = rhs for symmetric positive definite A given as `matmul_closure`.
+
+    rhs: (N x T).  Returns X, or (X, tridiag [n_tridiag x k x k]) when n_tridiag > 0.
+    """
+    if rhs.dim() == 1:
+        squeeze = True
+        rhs = rhs.unsqueeze(-1)
+    else:
+        squeeze = False
+    if tolerance is None:
+        tolerance = settings.cg_tolerance.value()
+    if max_iter is None:
+        max_iter = settings.max_cg_iterations.value()
+    if max_tridiag_iter is None:
+        max_tridiag_iter = settings.max_lanczos_quadrature_iterations.value()
+    if preconditioner is None:
+        def preconditioner(x):
+            return x
+
+    if eps is None:
+        # only guards divisions by exactly-vanished inner products; GPyTorch's fixed 1e-10 puts a floor of ~1e-5 on
+        # the reachable residual, which is too coarse for the 1e-4 parity gates
+        eps = 1e3 * torch.finfo(rhs.dtype).tiny
+    N, T = rhs.shape
+    n_iter = min(max_iter, N + 0)
+    n_tridiag_iter = min(max_tridiag_iter, n_iter)
+
+    rhs_norm = rhs.norm(2, dim=0, keepdim=True)
+    rhs_is_zero = rhs_norm.lt(1e-10)
+    rhs_norm = rhs_norm.masked_fill(rhs_is_zero, 1.0)
+    rhs = rhs / rhs_norm
+
+    if initial_guess is None:
+        result = torch.zeros_like(rhs)
+        residual = rhs.clone()
+    else:
+        result = initial_guess / rhs_norm
+        residual = rhs - matmul_closure(result)
+    if not torch.isfinite(residual).all():
+        raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
+
+    z = preconditioner(residual)
+    p = z.clone()
+    rz = (residual * z).sum(0, keepdim=True)
+
+    if n_tridiag:
+        t_mat = torch.zeros(n_tridiag, n_tridiag_iter, n_tridiag_iter, dtype=rhs.dtype, device=rhs.device)
+        inv_alpha_prev = torch.ones(1, n_tridiag, dtype=rhs.dtype, device=rhs.device)
+        beta_prev = torch.zeros(1, n_tridiag, dtype=rhs.dtype, device=rhs.device)
+    update_tridiag = bool(n_tridiag)
+    last_tridiag_iter = 0
+
+    tolerance_reached = False
+    residual_norm = None
+    min_iters = min(10, n_iter - 1)
+    k = 0
+    for k in range(n_iter):
+        Ap = matmul_closure(p)
+        pAp = (p * Ap).sum(0, keepdim=True)
+        safe = pAp.abs().gt(eps)
+        alpha = torch.where(safe, rz / torch.where(safe, pAp, torch.ones_like(pAp)), torch.zeros_like(pAp))
+        # columns that already converged stop moving (keeps alpha/beta finite)
+        if residual_norm is not None:
+            alpha = alpha.masked_fill(residual_norm.lt(stop_updating_after), 0.0)
+        result = result + alpha * p
+        residual = residual - alpha * Ap
+
+        residual_norm = residual.norm(2, dim=0, keepdim=True).masked_fill(rhs_is_zero, 0.0)
+
+        z = preconditioner(residual)
+        rz_new = (residual * z).sum(0, keepdim=True)
+        safe_rz = rz.abs().gt(eps)
+        beta = torch.where(safe_rz, rz_new / torch.where(safe_rz, rz, torch.ones_like(rz)), torch.zeros_like(rz))
+        rz = rz_new
+        p = z + beta * p
+
+        if update_tridiag and k < n_tridiag_iter:
+            a_t = alpha[:, :n_tridiag]
+            nz = a_t.abs().gt(eps)
+            # reciprocal -> 1 where alpha was masked to zero (converged column): keeps log(T) finite and the
+            # decoupled trailing block carries zero quadrature weight
+            inv_a = torch.where(nz, 1.0 / torch.where(nz, a_t, torch.ones_like(a_t)), torch.ones_like(a_t))
+            if k == 0:
+                t_mat[:, 0, 0] = inv_a[0]
+            else:
+                t_mat[:, k, k] = (inv_a + beta_prev * inv_alpha_prev)[0]
+                off = (beta_prev.clamp_min(0).sqrt() * inv_alpha_prev)[0]
+                t_mat[:, k, k - 1] = off
+                t_mat[:, k - 1, k] = off
+            inv_alpha_prev = inv_a
+            beta_prev = beta[:, :n_tridiag].clone()
+            last_tridiag_iter = k
+
+        if k >= min_iters and (k % check_every == 0 or k == n_iter - 1):
+            tridiag_pending = bool(n_tridiag) and k < min(n_tridiag_iter, n_iter) - 1
+            if not tridiag_pending:
+                mean_res = float(residual_norm.mean())  # host sync (the only one per iteration)
+                if mean_res != mean_res:
+                    raise RuntimeError("NaNs encountered in CG residuals")
+                if mean_res < tolerance:
+                    tolerance_reached = True
+                    break
+
+    if not tolerance_reached and n_iter > 0:
+        mean_res = float(residual_norm.mean()) if residual_norm is not None else 0.0
+        if mean_res >= tolerance:
+            warnings.warn(
+                "CG terminated in {} iterations with average residual norm {} which is larger than the tolerance of {} "
+                "specified by rpgp_amd.settings.cg_tolerance. If performance is affected, consider raising the maximum "
+                "number of CG iterations by running code in a rpgp_amd.settings.max_cg_iterations(value) context."
+                .format(k + 1, mean_res, tolerance), NumericalWarning)
+
+    result = result * rhs_norm
+    if squeeze:
+        result = result.squeeze(-1)
+    if n_tridiag:
+        m = last_tridiag_iter + 1
+        return result, t_mat[:, :m, :m]
+    return result
+

@@ -1,0 +1,147 @@
+"""Exact GP model, marginal log-likelihood and prediction strategy (counterparts of gp_models/models.py:10-20,
+gpytorch.models.ExactGP, gpytorch.mlls.ExactMarginalLogLikelihood and DefaultPredictionStrategy as the reference uses
+them from fitting/optimizing.py:65-73 and training_routines.py:545-579; semantics per SURVEY.md §3.3-3.4, A.3, B.7)."""
+import math
+import warnings
+
+import torch
+from torch import nn
+
+from . import settings
+from .dense_ops import DenseKernelOperator
+from .inv_quad_logdet import inv_quad_logdet, psd_safe_cholesky, use_cholesky
+from .likelihoods import ConstantMean, GaussianLikelihood, MultivariateNormal, LOG2PI
+from .linear_cg import linear_cg
+from .operators import AddedDiagOperator, AdditiveRPOperator, DenseOperator
+from .precond import build_preconditioner
+
+
+class PredictionStrategy:
+    """Caches alpha = Khat^-1 (y - c) (the `mean_cache`) and produces predictive mean / covariance:
+       mu* = K(X*,X) alpha + c ;  Sigma* = K(X*,X*) - K(X*,X) Khat^-1 K(X,X*)."""
+
+    def __init__(self, model):
+        self.model = model
+        x, y = model.train_inputs, model.train_targets
+        with torch.no_grad():
+            self.mean_const = model.mean_module(x)
+            self.op = model.covar_module(x)                        # train-train operator
+            self.noise = model.likelihood.noise.reshape(()).detach()
+            self.r = (y - self.mean_const).reshape(-1, 1)
+            N = x.shape[0]
+            self.dense_path = isinstance(self.op, DenseKernelOperator) or use_cholesky(N) or \
+                not settings.fast_computations.solves()
+            if self.dense_path:
+                Kd = self.op.to_dense()
+                Kd.diagonal().add_(self.noise)
+                self.chol = psd_safe_cholesky(Kd)
+                self.alpha = torch.cholesky_solve(self.r, self.chol)
+                self.khat = None
+            else:
+                self.chol = None
+                if settings.cache_kernel.on():
+                    self.khat = DenseOperator(self.op.to_dense(), float(self.noise))
+                else:
+                    self.khat = AddedDiagOperator(self.op, self.noise)
+                self.pre = build_preconditioner(self.op, float(self.noise), settings)
+                self.alpha = linear_cg(self.khat._matmul, self.r, tolerance=settings.eval_cg_tolerance.value(),
+                                       max_iter=settings.max_cg_iterations.value(), preconditioner=self.pre)
+
+    def solve(self, B):
+        if self.dense_path:
+            return torch.cholesky_solve(B, self.chol)
+        khat = self.khat
+        if B.shape[1] > 12 and not isinstance(khat, DenseOperator):
+            # wide right-hand sides (predictive covariance, T = N_test): materialise K once so every CG iteration is
+            # a library GEMM on the matrix cores instead of N_test/12 fused sweeps
+            N = B.shape[0]
+            if 4.0 * N * N <= 0.25 * torch.cuda.get_device_properties(B.device).total_memory if B.is_cuda else True:
+                khat = DenseOperator(self.op.to_dense(), float(self.noise))
+        return linear_cg(khat._matmul, B, tolerance=settings.eval_cg_tolerance.value(),
+                         max_iter=settings.max_cg_iterations.value(), preconditioner=getattr(self, "pre", None))
+
+    def predict(self, xs):
+        model = self.model
+        with torch.no_grad():
+            cross = model.covar_module(xs, model.train_inputs)      # K(X*, X) operator
+            mean = cross._matmul(self.alpha).reshape(-1) + model.mean_module(xs)
+            if settings.skip_posterior_variances.on():
+                return MultivariateNormal(mean, torch.zeros_like(mean), diagonal_only=True)
+            Kxs = cross._transpose_nonbatch().to_dense()            # N x N*
+            sol = self.solve(Kxs)                                   # Khat^-1 K(X, X*)
+            Kss = model.covar_module(xs).to_dense()
+            cov = Kss - Kxs.t() @ sol
+            cov = 0.5 * (cov + cov.t())
+        return MultivariateNormal(mean, cov)
+
+
+class ExactGP(nn.Module):
+    """Train mode: `model(train_x)` returns the prior MultivariateNormal(mean, K operator).
+    Eval mode: `model(x)` returns the posterior at x (prediction strategy cached across calls, B.7)."""
+
+    def __init__(self, train_inputs, train_targets, likelihood):
+        super().__init__()
+        self.train_inputs = train_inputs
+        self.train_targets = train_targets
+        self.likelihood = likelihood
+        self.prediction_strategy = None
+
+    def train(self, mode=True):
+        if mode:
+            self.prediction_strategy = None
+        return super().train(mode)
+
+    def forward(self, x):
+        raise NotImplementedError
+
+    def __call__(self, x):
+        if self.training:
+            if not (x is self.train_inputs or (x.shape == self.train_inputs.shape and torch.equal(x, self.train_inputs))):
+                raise RuntimeError("You must train on the training inputs!")
+            return self.forward(self.train_inputs)
+        if self.prediction_strategy is None:
+            self.prediction_strategy = PredictionStrategy(self)
+        return self.prediction_strategy.predict(x)
+
+
+class ExactGPModel(ExactGP):
+    """Basic exact GP with constant mean and a provided kernel (gp_models/models.py:10-20)."""
+
+    def __init__(self, train_x, train_y, likelihood, kernel):
+        super().__init__(train_x, train_y, likelihood)
+        self.mean_module = ConstantMean()
+        self.covar_module = kernel
+
+    def forward(self, x):
+        mean_x = self.mean_module(x)
+        covar_x = self.covar_module(x)
+        return MultivariateNormal(mean_x, covar_x)
+
+
+class ExactMarginalLogLikelihood(nn.Module):
+    """mll(output, target) = (1/N) [ log N(target | mean, K + sigma^2 I) + sum log-priors ]   (SURVEY.md A.3)."""
+
+    def __init__(self, likelihood, model):
+        super().__init__()
+        self.likelihood = likelihood
+        self.model = model
+
+    def forward(self, output, target):
+        n = target.shape[0]
+        cov = output.covariance
+        noise = self.likelihood.noise.reshape(())
+        if isinstance(cov, AdditiveRPOperator):
+            r = target - output.mean
+            inv_quad, logdet = inv_quad_logdet(cov, noise, r)
+            log_prob = -0.5 * (inv_quad + logdet + n * LOG2PI)
+        elif isinstance(cov, DenseKernelOperator):
+            K = cov.to_dense_autograd() + noise * torch.eye(n, dtype=target.dtype, device=target.device)
+            Lc = torch.linalg.cholesky(K)
+            r = (target - output.mean).unsqueeze(-1)
+            z = torch.linalg.solve_triangular(Lc, r, upper=False)
+            log_prob = -0.5 * (z * z).sum() - torch.log(Lc.diagonal()).sum() - 0.5 * n * LOG2PI
+        else:
+            # posterior (eval-mode) output: dense covariance or marginal variances
+            log_prob = self.likelihood(output).log_prob(target)
+        res = log_prob + self.likelihood.log_prior().to(log_prob.dtype)
+        return res / n

@@ -1,0 +1,302 @@
+"""LinearOperator-shaped classes for the additive randomly-projected kernel (drop-in boundary).
+
+Method names follow GPyTorch's LazyTensor / `linear_operator.LinearOperator` protocol (`_matmul`, `_size`,
+`_transpose_nonbatch`, `_diagonal`, `_bilinear_derivative`/`_quad_form_derivative`, `to_dense`/`evaluate`,
+`representation`) so the solver stack (linear_cg, pivoted Cholesky, prediction strategy) reads like the
+reference's dependency.  All arithmetic goes through the compute backend (HIP library); K is never stored unless
+`to_dense()` / the cached mode is requested.
+"""
+import torch
+
+from . import backend as _backend
+
+
+class LinearOperator:
+    """Minimal protocol base."""
+
+    def _size(self):
+        raise NotImplementedError
+
+    @property
+    def shape(self):
+        return self._size()
+
+    def size(self, dim=None):
+        s = self._size()
+        return s if dim is None else s[dim]
+
+    @property
+    def dtype(self):
+        raise NotImplementedError
+
+    @property
+    def device(self):
+        raise NotImplementedError
+
+    def _matmul(self, rhs):
+        raise NotImplementedError
+
+    def matmul(self, rhs):
+        if rhs.dim() == 1:
+            return self._matmul(rhs.unsqueeze(-1)).squeeze(-1)
+        return self._matmul(rhs)
+
+    __matmul__ = matmul
+
+    def _transpose_nonbatch(self):
+        raise NotImplementedError
+
+    def t(self):
+        return self._transpose_nonbatch()
+
+    def _diagonal(self):
+        raise NotImplementedError
+
+    def diagonal(self):
+        return self._diagonal()
+
+    diag = diagonal
+
+    def _get_rows(self, idx):
+        """Dense rows K[idx, :] (the `_getitem` use of pivoted Cholesky)."""
+        raise NotImplementedError
+
+    def to_dense(self):
+        raise NotImplementedError
+
+    evaluate = to_dense
+
+    def representation(self):
+        raise NotImplementedError
+
+    def _bilinear_derivative(self, left_vecs, right_vecs):
+        """Gradients of sum((left right^T) * self) w.r.t. each tensor of `representation()`."""
+        raise NotImplementedError
+
+    _quad_form_derivative = _bilinear_derivative
+
+    def add_diag(self, diag_value):
+        return AddedDiagOperator(self, diag_value)
+
+    add_diagonal = add_diag
+
+
+class AdditiveRPOperator(LinearOperator):
+    """K(Z1, Z2) = outputscale * weight * sum_j exp(-0.5 (Z1[:,j]-Z2[:,j]^T)^2)  (SURVEY.md A.1).
+
+    Z1, Z2: projected inputs (N x J), produced by `ScaledProjectionKernel` (scaled_projection_kernel.py:21-37).
+    `Z2 is None` means the symmetric train-train kernel: each unordered pair is evaluated once.
+    `shard` (rpgp_amd.distributed.JShard) splits the J terms across ranks with one all-reduce per MVM.
+    """
+
+    def __init__(self, Z1, Z2=None, outputscale=None, weight=1.0, shard=None):
+        self.Z1 = Z1
+        self.Z2 = Z2
+        self.symmetric = Z2 is None
+        if outputscale is None:
+            outputscale = torch.ones((), dtype=Z1.dtype, device=Z1.device)
+        self.outputscale = outputscale
+        self.weight = float(weight)
+        self.shard = shard
+        # one host sync per construction (= per optimiser step); kernels take the scale by value
+        self._scale = float(outputscale.detach()) * self.weight
+
+    # ---- protocol -------------------------------------------------------------------------------------------
+    def _size(self):
+        n2 = self.Z1.shape[0] if self.symmetric else self.Z2.shape[0]
+        return torch.Size((self.Z1.shape[0], n2))
+
+    @property
+    def dtype(self):
+        return self.Z1.dtype
+
+    @property
+    def device(self):
+        return self.Z1.device
+
+    @property
+    def num_projections(self):
+        return self.Z1.shape[1]
+
+    def _jrange(self):
+        if self.shard is None:
+            return 0, self.num_projections
+        return self.shard.j0, self.shard.j1
+
+    def _local_matmul(self, rhs, noise=0.0):
+        be = _backend.get_backend()
+        j0, j1 = self._jrange()
+        z1 = self.Z1.detach()
+        if self.symmetric:
+            return be.mvm_sym(z1, rhs, self._scale, noise, j0=j0, j1=j1)
+        return be.mvm_rect(z1, self.Z2.detach(), rhs, self._scale, j0=j0, j1=j1)
+
+    def _matmul(self, rhs, noise=0.0):
+        rhs = rhs.detach()
+        if self.shard is None or self.shard.world_size == 1:
+            out = self._local_matmul(rhs, noise if self.symmetric else 0.0)
+            if noise and not self.symmetric:
+                raise ValueError("a diagonal can only be added to the square symmetric operator")
+            return out
+        if noise and not self.symmetric:
+            raise ValueError("a diagonal can only be added to the square symmetric operator")
+        return self.shard.sharded_mvm(lambda j0, j1: self._local_matmul(rhs, 0.0), rhs, float(noise))
+
+    def _transpose_nonbatch(self):
+        if self.symmetric:
+            return self
+        return AdditiveRPOperator(self.Z2, self.Z1, self.outputscale, self.weight, self.shard)
+
+    def _diagonal(self):
+        if not self.symmetric:
+            raise RuntimeError("diagonal of a rectangular cross-covariance requested")
+        n = self.Z1.shape[0]
+        # k(x,x) = outputscale * weight * J  (diag(K) = s*w*J)
+        return torch.full((n,), self._scale * self.num_projections, dtype=self.dtype, device=self.device)
+
+    def _get_rows(self, idx):
+        be = _backend.get_backend()
+        z2 = self.Z1 if self.symmetric else self.Z2
+        return be.dense(self.Z1.detach().index_select(0, idx).contiguous(), z2.detach(), self._scale)
+
+    def to_dense(self):
+        be = _backend.get_backend()
+        z2 = self.Z1 if self.symmetric else self.Z2
+        return be.dense(self.Z1.detach(), z2.detach(), self._scale)
+
+    evaluate = to_dense
+
+    def representation(self):
+        if self.symmetric:
+            return (self.Z1, self.outputscale)
+        return (self.Z1, self.Z2, self.outputscale)
+
+    def _bilinear_derivative(self, left_vecs, right_vecs):
+        if not self.symmetric:
+            raise NotImplementedError("derivatives are only needed for the train-train kernel")
+        be = _backend.get_backend()
+        j0, j1 = self._jrange()
+        if j1 > j0:
+            gZ, gs = be.bilinear_grad(self.Z1.detach(), left_vecs.detach(), right_vecs.detach(), self._scale,
+                                      j0=j0, j1=j1)
+        else:
+            gZ = torch.zeros_like(self.Z1)
+            gs = torch.zeros((), dtype=self.dtype, device=self.device)
+        if self.shard is not None and self.shard.world_size > 1:
+            from .distributed import all_reduce_sum_
+            all_reduce_sum_(gZ, self.shard.group)
+            gs = gs.reshape(1)
+            all_reduce_sum_(gs, self.shard.group)
+            gs = gs.reshape(())
+        return gZ, gs * self.weight
+
+    _quad_form_derivative = _bilinear_derivative
+
+    def dense_weight_derivative(self, S):
+        """Gradients of 0.5*sum(S * self) for an explicit symmetric S (Cholesky regime)."""
+        be = _backend.get_backend()
+        gZ, gs = be.bilinear_grad_dense(self.Z1.detach(), S, self._scale)
+        return gZ, gs * self.weight
+
+
+class AddedDiagOperator(LinearOperator):
+    """base + noise * I  (the likelihood's AddedDiagLazyTensor); the noise term is fused into the MVM kernel."""
+
+    def __init__(self, base, noise):
+        if not isinstance(noise, torch.Tensor):
+            noise = torch.as_tensor(float(noise), dtype=base.dtype, device=base.device)
+        self.base = base
+        self.noise = noise
+        self._noise = float(noise.detach())
+
+    def _size(self):
+        return self.base._size()
+
+    @property
+    def dtype(self):
+        return self.base.dtype
+
+    @property
+    def device(self):
+        return self.base.device
+
+    def _matmul(self, rhs):
+        if isinstance(self.base, AdditiveRPOperator):
+            return self.base._matmul(rhs, noise=self._noise)
+        return self.base._matmul(rhs) + self._noise * rhs
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def _diagonal(self):
+        return self.base._diagonal() + self._noise
+
+    def _get_rows(self, idx):
+        rows = self.base._get_rows(idx)
+        rows[torch.arange(idx.numel(), device=rows.device), idx] += self._noise
+        return rows
+
+    def to_dense(self):
+        d = self.base.to_dense()
+        d.diagonal().add_(self._noise)
+        return d
+
+    evaluate = to_dense
+
+    def representation(self):
+        return self.base.representation() + (self.noise,)
+
+    def _bilinear_derivative(self, left_vecs, right_vecs):
+        g_noise = (left_vecs * right_vecs).sum()
+        return self.base._bilinear_derivative(left_vecs, right_vecs) + (g_noise,)
+
+    _quad_form_derivative = _bilinear_derivative
+
+
+class DenseOperator(LinearOperator):
+    """Cached-K mode: an explicit symmetric kernel matrix in HBM; every MVM is an HBM stream
+    (rpgp_dense_mvm for thin right-hand sides, a library GEMM for wide ones)."""
+
+    def __init__(self, Kd, noise=0.0):
+        self.Kd = Kd
+        self._noise = float(noise)
+
+    def _size(self):
+        return self.Kd.shape
+
+    @property
+    def dtype(self):
+        return self.Kd.dtype
+
+    @property
+    def device(self):
+        return self.Kd.device
+
+    def _matmul(self, rhs):
+        rhs = rhs.detach()
+        if rhs.shape[-1] <= 12:
+            return _backend.get_backend().dense_mvm(self.Kd, rhs, self._noise)
+        out = self.Kd @ rhs
+        if self._noise:
+            out.add_(rhs, alpha=self._noise)
+        return out
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def _diagonal(self):
+        return self.Kd.diagonal() + self._noise
+
+    def _get_rows(self, idx):
+        rows = self.Kd.index_select(0, idx).clone()
+        if self._noise:
+            rows[torch.arange(idx.numel(), device=rows.device), idx] += self._noise
+        return rows
+
+    def to_dense(self):
+        d = self.Kd.clone()
+        if self._noise:
+            d.diagonal().add_(self._noise)
+        return d
+
+    evaluate = to_dense

@@ -174,6 +174,26 @@ def bilinear_grad(Z, L, R, scale, j0=0, j1=None):
     return gZ, gs
 
 
+def bilinear_grad_dense(Z, S, scale, j0=0, j1=None):
+    """(gZ, gscale) = d/dZ, d/dscale of 0.5 * sum(S * K(Z,Z)) for an explicit symmetric N x N weight matrix S."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    S = _require(S, "S", 2)
+    N, J = Z.shape
+    if S.shape != (N, N):
+        raise ValueError("S must be %d x %d" % (N, N))
+    j1 = J if j1 is None else j1
+    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
+    gs = torch.zeros((), dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        nbytes = lib.rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)
+        ws = _workspace(Z.device, nbytes)
+        _lib.check(lib.rpgp_bilinear_grad_dense(Z.data_ptr(), S.data_ptr(), gZ.data_ptr(), gs.data_ptr(), N, J, J, N,
+                                                j0, j1, float(scale), ws.data_ptr(), ws.numel(), _stream()),
+                   "rpgp_bilinear_grad_dense")
+    return gZ, gs
+
+
 def dense_mvm(Kd, V, noise=0.0):
     """out = Kd @ V + noise * V for a cached dense symmetric kernel matrix."""
     lib = _lib.load()

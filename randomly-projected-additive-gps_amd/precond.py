@@ -1,0 +1,73 @@
+"""Pivoted-Cholesky preconditioner.
+
+Rank-k (k = settings.max_preconditioner_size = 15) partial Cholesky L of K with greedy max-diagonal pivots;
+M = L L^T + sigma^2 I is applied by Woodbury, log|M| corrects the SLQ log-det and probes are drawn from N(0, M).
+Used when N >= settings.min_preconditioning_size (2000).  Needs only diag(K) (constant s for this kernel) and k rows
+of K (rpgp_dense on k x N)."""
+import math
+
+import torch
+
+
+def pivoted_cholesky(diag, get_rows, max_iter):
+    """Returns L (N x k) with K ~= L L^T.  `get_rows(idx)` -> dense K[idx, :].  No host syncs: a fixed number of
+    steps is taken and exhausted pivots produce zero columns."""
+    N = diag.shape[0]
+    k = min(max_iter, N)
+    d = diag.clone()
+    L = torch.zeros(k, N, dtype=diag.dtype, device=diag.device)
+    tiny = torch.finfo(diag.dtype).tiny
+    for m in range(k):
+        piv = torch.argmax(d).reshape(1)
+        dp = d.index_select(0, piv)
+        ok = dp > 1e-10 * diag.max()
+        row = get_rows(piv)[0]
+        if m > 0:
+            row = row - L[:m].t() @ L[:m].index_select(1, piv).reshape(-1)
+        l = torch.where(ok, row / dp.clamp_min(tiny).sqrt(), torch.zeros_like(row))
+        L[m] = l
+        d = (d - l * l).clamp_min(0.0)
+        d.index_fill_(0, piv, 0.0)
+    return L.t().contiguous()
+
+
+class WoodburyPreconditioner:
+    """M = L L^T + noise I."""
+
+    def __init__(self, L, noise):
+        self.L = L
+        self.noise = float(noise)
+        k = L.shape[1]
+        cap = L.t() @ L
+        cap.diagonal().add_(self.noise)
+        self._cap_chol = torch.linalg.cholesky(cap.double())          # k x k, float64 for a stable capacitance solve
+        self.N, self.k = L.shape
+
+    def solve(self, r):
+        """M^-1 r = (r - L (noise I + L^T L)^-1 L^T r) / noise."""
+        t = (self.L.t() @ r).double()
+        t = torch.cholesky_solve(t, self._cap_chol).to(r.dtype)
+        return (r - self.L @ t) / self.noise
+
+    __call__ = solve
+
+    def logdet(self):
+        """log|M| = log|noise I_k + L^T L| + (N - k) log noise."""
+        ld_cap = 2.0 * torch.log(self._cap_chol.diagonal()).sum()
+        return float(ld_cap) + (self.N - self.k) * math.log(self.noise)
+
+    def sample(self, num, generator=None):
+        """z ~ N(0, M):  L eps1 + sqrt(noise) eps2."""
+        dev, dt = self.L.device, self.L.dtype
+        e1 = torch.randn(self.k, num, generator=generator, device=dev, dtype=dt)
+        e2 = torch.randn(self.N, num, generator=generator, device=dev, dtype=dt)
+        return self.L @ e1 + math.sqrt(self.noise) * e2
+
+
+def build_preconditioner(operator, noise, settings):
+    """operator: the noise-free kernel operator (LinearOperator protocol: _diagonal, _get_rows)."""
+    N = operator.shape[0]
+    if N < settings.min_preconditioning_size.value() or settings.max_preconditioner_size.value() <= 0:
+        return None
+    L = pivoted_cholesky(operator._diagonal(), operator._get_rows, settings.max_preconditioner_size.value())
+    return WoodburyPreconditioner(L, noise)

@@ -1,0 +1,104 @@
+"""Solver settings with the names the reference sets through `gpytorch.settings` (gp_experiment_runner.py:324-332),
+plus the GPyTorch defaults it relies on implicitly (SURVEY.md §5 "Config / flags", Appendix B).
+
+Each setting is a context manager class:  `with settings.cg_tolerance(0.01): ...` ;  `settings.cg_tolerance.value()`.
+"""
+
+
+class _Setting:
+    _default = None
+    _value = None
+
+    def __init__(self, value):
+        self._new = value
+        self._old = None
+
+    @classmethod
+    def value(cls):
+        return cls._default if cls._value is None else cls._value
+
+    @classmethod
+    def _set(cls, v):
+        cls._value = v
+
+    def __enter__(self):
+        self._old = type(self)._value
+        type(self)._set(self._new)
+        return self
+
+    def __exit__(self, *exc):
+        type(self)._set(self._old)
+        return False
+
+
+class _Flag(_Setting):
+    def __init__(self, state=True):
+        super().__init__(bool(state))
+
+    @classmethod
+    def on(cls):
+        return bool(cls.value())
+
+    @classmethod
+    def off(cls):
+        return not cls.on()
+
+
+def _setting(name, default, flag=False):
+    return type(name, (_Flag if flag else _Setting,), {"_default": default, "_value": None})
+
+
+cg_tolerance = _setting("cg_tolerance", 1.0)                 # gpytorch default 1; the runner sets 0.05 (--cg_tol)
+eval_cg_tolerance = _setting("eval_cg_tolerance", 0.01)
+max_cg_iterations = _setting("max_cg_iterations", 1000)     # the runner sets 10000
+max_cholesky_size = _setting("max_cholesky_size", 800)
+num_trace_samples = _setting("num_trace_samples", 10)
+max_lanczos_quadrature_iterations = _setting("max_lanczos_quadrature_iterations", 20)
+max_preconditioner_size = _setting("max_preconditioner_size", 15)
+min_preconditioning_size = _setting("min_preconditioning_size", 2000)
+max_root_decomposition_size = _setting("max_root_decomposition_size", 100)
+preconditioner_tolerance = _setting("preconditioner_tolerance", 1e-3)
+fast_pred_var = _setting("fast_pred_var", False, flag=True)
+use_toeplitz = _setting("use_toeplitz", True, flag=True)
+skip_logdet_forward = _setting("skip_logdet_forward", False, flag=True)
+memory_efficient = _setting("memory_efficient", False, flag=True)
+skip_posterior_variances = _setting("skip_posterior_variances", False, flag=True)
+deterministic_probes = _setting("deterministic_probes", False, flag=True)   # fixed probe vectors (reproducible SLQ)
+cache_kernel = _setting("cache_kernel", False, flag=True)                   # materialise K once per hyper-parameter step
+tridiagonal_jitter = _setting("tridiagonal_jitter", 1e-6)
+
+
+class fast_computations:
+    """fast_computations(covar_root_decomposition, log_prob, solves): False => dense Cholesky
+    (the runner passes `not use_chol` three times, gp_experiment_runner.py:326)."""
+    _state = {"covar_root_decomposition": True, "log_prob": True, "solves": True}
+
+    def __init__(self, covar_root_decomposition=True, log_prob=True, solves=True):
+        self._new = {"covar_root_decomposition": bool(covar_root_decomposition), "log_prob": bool(log_prob),
+                     "solves": bool(solves)}
+        self._old = None
+
+    @classmethod
+    def log_prob(cls):
+        return cls._state["log_prob"]
+
+    @classmethod
+    def solves(cls):
+        return cls._state["solves"]
+
+    @classmethod
+    def covar_root_decomposition(cls):
+        return cls._state["covar_root_decomposition"]
+
+    def __enter__(self):
+        self._old = dict(type(self)._state)
+        type(self)._state = dict(self._new)
+        return self
+
+    def __exit__(self, *exc):
+        type(self)._state = self._old
+        return False
+
+
+class beta_features:
+    checkpoint_kernel = _setting("checkpoint_kernel", 0)   # accepted for CLI parity; the fused kernel never stores K

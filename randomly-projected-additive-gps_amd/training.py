@@ -1,0 +1,297 @@
+"""Training routines: counterparts of training_routines.py (create_additive_rp_kernel :131-189, create_full_kernel
+:275-293, create_exact_gp :325-410, train_exact_gp :469-585) and fitting/optimizing.py (train_to_convergence :14-108,
+mean_squared_error :111-113) with the same argument names, defaults, return contract and error behaviour
+(SURVEY.md §3.2, Appendix D)."""
+import copy
+import os
+import warnings
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import rp
+from .distributed import JShard, is_distributed
+from .kernels import (AdditiveStructureRBFKernel, MemoryEfficientGamKernel, RBFKernel, ScaledProjectionKernel,
+                      ScaleKernel)
+from .likelihoods import GaussianLikelihood, SmoothedBoxPrior
+from .models import ExactGPModel, ExactMarginalLogLikelihood
+
+EXACT_GP_KINDS = ("full", "additive_rp")
+REFERENCE_ONLY_KINDS = ("rp", "strictly_additive", "additive", "rp_poly", "deep_rp_poly", "general_rp_poly",
+                        "multi_full", "duvenaud_additive", "sgpr")
+
+
+def _map_to_optim(optimizer):
+    """training_routines.py:24-34."""
+    table = {"adam": torch.optim.Adam, "sgd": torch.optim.SGD, "lbfgs": torch.optim.LBFGS}
+    if optimizer not in table:
+        raise ValueError("Unknown optimizer")
+    return table[optimizer]
+
+
+def _sample_from_range(num_samples, range_):
+    """training_routines.py:47-48 (always consumes `num_samples` uniforms, also for a degenerate range)."""
+    return torch.rand(num_samples) * (range_[1] - range_[0]) + range_[0]
+
+
+def mean_squared_error(y_pred, y_true):
+    return ((y_pred - y_true) ** 2).mean().item()
+
+
+def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_proj=False, prescale=False, ard=True,
+                              init_lengthscale_range=(1., 1.), ski=False, ski_options=None, proj_dist="gaussian",
+                              batch_kernel=True, mem_efficient=False, k=1, keops=False):
+    """Additive randomly-projected kernel (RPA-GP; DPA-GP when `space_proj`).  Same options and validation errors as
+    training_routines.py:131-189.  Sub-kernels other than 1-D RBF, k > 1 and SKI are outside the MI355X hot path
+     and raise NotImplementedError."""
+    if k > 1 and (mem_efficient or batch_kernel or space_proj):
+        raise ValueError("Can't have k > 1 with memory efficient GAM kernel or a batch kernel or spaced projections.")
+    if mem_efficient:
+        if ski:
+            raise ValueError("Not implemented yet")
+        if batch_kernel:
+            raise ValueError("Impossible to have batch kernel and memory efficient GAM")
+        if kernel_type != "RBF":
+            raise ValueError("Memory efficient GAM with alternative sub-kernels not implemented yet.")
+    if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+        raise ValueError("Unknown kernel type")
+    if kernel_type != "RBF":
+        raise NotImplementedError("only 1-D RBF sub-kernels are implemented on the fused MI355X path (SURVEY.md §8(f))")
+    if k != 1:
+        raise NotImplementedError("k > 1 sub-kernels are not implemented on the fused MI355X path (SURVEY.md §8(f))")
+    if ski:
+        raise NotImplementedError("the SKI grid-interpolation path is the next row of SURVEY.md §8(f), not built yet")
+    if keops:
+        warnings.warn("keops=True is ignored: the fused HIP kernel already is the matrix-free path")
+
+    projs = [rp.gen_rp(d, k, dist=proj_dist) for _ in range(J)]
+    if space_proj:
+        newW, _ = rp.space_equally(torch.cat(projs, dim=1).t(), lr=0.1, niter=5000)
+        newW.requires_grad = False
+        projs = [newW[i:i + k, :].t() for i in range(0, J * k, k)]
+    proj_module = torch.nn.Linear(d, J * k, bias=False)
+    proj_module.weight.data = torch.cat(projs, dim=1).t().contiguous()
+
+    if mem_efficient:
+        add_kernel = MemoryEfficientGamKernel(J)
+    else:
+        # batch_kernel (AdditiveStructureKernel) and the per-dimension AdditiveKernel variant are the same function:
+        # (1/J) sum_j RBF_1(z_j)  (training_routines.py:169-174)
+        add_kernel = AdditiveStructureRBFKernel(J)
+    if ard:
+        ard_num_dims = d if prescale else J * k
+        initial_ls = _sample_from_range(ard_num_dims, init_lengthscale_range)
+    else:
+        ard_num_dims = None
+        initial_ls = _sample_from_range(1, init_lengthscale_range)
+    proj_kernel = ScaledProjectionKernel(proj_module, add_kernel, prescale=prescale, ard_num_dims=ard_num_dims,
+                                         learn_proj=learn_proj)
+    proj_kernel.initialize(lengthscale=initial_ls)
+    return proj_kernel
+
+
+def create_full_kernel(d, ard=False, ski=False, grid_size=None, kernel_type="RBF", init_lengthscale_range=(1.0, 1.0),
+                       keops=False):
+    """Plain RBF kernel for `kind: full` (training_routines.py:275-293)."""
+    if kernel_type != "RBF":
+        raise NotImplementedError("only the RBF full kernel is provided (runner plumbing, BASELINE config 1)")
+    if ski:
+        raise NotImplementedError("SKI is not built (SURVEY.md §8(f))")
+    ard_num_dims = d if ard else None
+    kernel = RBFKernel(ard_num_dims=ard_num_dims)
+    kernel.initialize(lengthscale=_sample_from_range(d if ard else 1, init_lengthscale_range))
+    return kernel
+
+
+def create_exact_gp(trainX, trainY, kind, devices=("cpu",), **kwargs):
+    """Create an exact GP model with a specified kernel (training_routines.py:325-410).
+    More than one device means J-sharding over the ranks of the default torch.distributed process group."""
+    [n, d] = trainX.shape
+    if kind not in EXACT_GP_KINDS + REFERENCE_ONLY_KINDS:
+        raise ValueError("Unknown kernel structure type {}".format(kind))
+    if kind in REFERENCE_ONLY_KINDS:
+        raise NotImplementedError("kernel kind '%s' is outside the MI355X hot path (SURVEY.md §2.1, §8(f))" % kind)
+
+    if kwargs.pop("noise_prior"):
+        noise_prior_ = SmoothedBoxPrior(1e-4, 10, sigma=0.01)
+    else:
+        noise_prior_ = None
+    likelihood = GaussianLikelihood(noise_prior=noise_prior_)
+    likelihood.noise = _sample_from_range(1, kwargs.pop("init_noise_range", [1.0, 1.0]))
+    grid_size = kwargs.pop("grid_size", None)
+    kwargs.pop("grid_ratio", None)
+    if kind == "full":
+        kernel = create_full_kernel(d, grid_size=grid_size, **kwargs)
+    else:
+        kernel = create_additive_rp_kernel(d, **kwargs)
+    kernel = ScaleKernel(kernel)
+    if kind == "additive_rp" and is_distributed():
+        kernel.shard = JShard(kwargs["J"])
+    elif len(devices) > 1:
+        raise RuntimeError("multi-device runs are one process per GPU: launch with `python -m torch.distributed.run "
+                           "--nproc-per-node %d ...` (J terms are sharded over ranks, RCCL all-reduce per MVM)"
+                           % len(devices))
+    model = ExactGPModel(trainX, trainY, likelihood, kernel)
+    return model, likelihood
+
+
+def train_to_convergence(model, xs, ys, optimizer=None, lr=0.1, objective=None, max_iter=100, verbose=0, patience=20,
+                         conv_tol=1e-4, check_conv=True, smooth=True, isloss=False, batch_size=None, checkpoint=False,
+                         print_freq=1):
+    """Full-batch optimisation loop with moving-average early stopping (fitting/optimizing.py:14-108).
+
+    Returns the epoch index at which convergence was declared, or max_iter.  As in the reference the moving average
+    over `patience` epochs is undefined (NaN) for the first patience-1 epochs, so the earliest stop is epoch
+    2*patience-1.  Mini-batching (`batch_size`) is not meaningful for an exact GP and is rejected."""
+    if optimizer is None:
+        optimizer = torch.optim.LBFGS
+    verbose = int(verbose)
+    if batch_size is not None and batch_size != xs.shape[0]:
+        raise NotImplementedError("mini-batches are not supported for exact GPs (train inputs must be the full set)")
+    model.train()
+    optimizer_ = optimizer([p for p in model.parameters() if p.requires_grad], lr=lr)
+
+    best_model, best_loss = None, np.inf
+    losses = np.zeros((max_iter,))
+    ma = np.zeros((max_iter,))
+    for i in range(max_iter):
+        def closure():
+            optimizer_.zero_grad()
+            output = model(xs)
+            loss = objective(output, ys) if isloss else -objective(output, ys)
+            loss.backward()
+            return loss
+
+        loss = optimizer_.step(closure).item()
+        if verbose > 1:
+            print("epoch {}, iter {}, loss {}".format(i, 0, loss))
+        losses[i] = loss
+        lo = i - patience + 1
+        ma[i] = losses[lo:i + 1].mean() if lo >= 0 else np.nan
+        if i % print_freq == 0 and verbose >= 1:
+            print("epoch {}, loss {}, noise {}".format(i, loss, model.likelihood.noise.item()))
+        if checkpoint and loss < best_loss:
+            best_loss = loss
+            best_model = copy.deepcopy(model.state_dict())
+        if check_conv and i >= patience:
+            delta = (ma[i - patience] - ma[i]) if smooth else (losses[i - patience] - losses[i])
+            if delta < conv_tol:          # NaN compares False: no stop while the moving average is undefined
+                if verbose > 0:
+                    print("Reached convergence at {}, {} < {}".format(loss, delta, conv_tol))
+                if checkpoint:
+                    model.load_state_dict(best_model)
+                return i
+    if checkpoint:
+        model.load_state_dict(best_model)
+    return max_iter
+
+
+def _save_state_dict(model):
+    """training_routines.py:37-44: torch.save(state_dict) to <model_base_path>/models/model_state_dict_<hash>.pkl.
+    The base path comes from the environment (RPGP_MODEL_BASE_PATH) instead of a user-made config.py; without it
+    nothing is written and '' is returned."""
+    base = os.environ.get("RPGP_MODEL_BASE_PATH")
+    if not base:
+        return ""
+    d = model.state_dict()
+    fname = "model_state_dict_{}.pkl".format(hash(str(d)))
+    os.makedirs(os.path.join(base, "models"), exist_ok=True)
+    torch.save(d, os.path.join(base, "models", fname))
+    return fname
+
+
+def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwargs, devices=("cpu",),
+                   skip_posterior_variances=False, skip_random_restart=False, evaluate_on_train=True,
+                   output_device=None, record_pred_unc=False, double=False):
+    """Create and train an exact GP with the given options (training_routines.py:469-585).
+    Returns (model_metrics, pred_mean [cpu float32], model)."""
+    from . import settings
+    model_kwargs = copy.copy(model_kwargs)
+    train_kwargs = copy.copy(train_kwargs)
+    d = trainX.shape[-1]
+    devices = [torch.device(device) for device in devices]
+    output_device = devices[0] if output_device is None else torch.device(output_device)
+    if double and kind == "additive_rp":
+        raise NotImplementedError("--double is not available on the fused fp32 HIP path")
+    type_ = torch.double if double else torch.float
+    trainX = trainX.to(output_device, type_).contiguous()
+    trainY = trainY.to(output_device, type_).contiguous()
+    testX = testX.to(output_device, type_).contiguous()
+    testY = testY.to(output_device, type_).contiguous()
+
+    for k, v in list(model_kwargs.items()):
+        if isinstance(v, str) and v == "d":
+            model_kwargs[k] = d
+
+    random_restarts = train_kwargs.pop("random_restarts", 1)
+    init_iters = train_kwargs.pop("init_iters", 20)
+    optimizer_ = _map_to_optim(train_kwargs.pop("optimizer"))
+    rr_check_conv = train_kwargs.pop("rr_check_conv", False)
+    initial_train_kwargs = copy.copy(train_kwargs)
+    initial_train_kwargs["max_iter"] = init_iters
+    initial_train_kwargs["check_conv"] = rr_check_conv
+
+    def new_model():
+        model, likelihood = create_exact_gp(trainX, trainY, kind, devices=devices, **model_kwargs)
+        if is_distributed():
+            # every rank must start from identical parameters (projection draw, lengthscale / noise init)
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0)
+        model = model.to(output_device, type_)
+        return model, likelihood, ExactMarginalLogLikelihood(likelihood, model)
+
+    best_model, best_likelihood, best_mll, best_loss = None, None, None, np.inf
+    if not skip_random_restart:
+        for _ in range(random_restarts):
+            model, likelihood, mll = new_model()
+            train_to_convergence(model, trainX, trainY, optimizer=optimizer_, objective=mll, isloss=False,
+                                 **initial_train_kwargs)
+            model.train()
+            with torch.no_grad():
+                loss = -mll(model(trainX), trainY).item()
+            if loss < best_loss or best_model is None:
+                best_loss, best_model, best_likelihood, best_mll = loss, model, likelihood, mll
+        model, likelihood, mll = best_model, best_likelihood, best_mll
+    else:
+        model, likelihood, mll = new_model()
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        trained_epochs = train_to_convergence(model, trainX, trainY, optimizer=optimizer_, objective=mll,
+                                              isloss=False, **train_kwargs)
+
+    model.eval()
+    likelihood.eval()
+    mll.eval()
+    model_metrics = dict()
+    model_metrics["trained_epochs"] = trained_epochs
+    w2 = []
+    with torch.no_grad():
+        model.train()
+        likelihood.train()
+        model_metrics["prior_train_nmll"] = -mll(model(trainX), trainY).item()
+        with settings.skip_posterior_variances(skip_posterior_variances):
+            model.eval()
+            likelihood.eval()
+            if evaluate_on_train:
+                train_outputs = model(trainX)
+                model_metrics["train_mse"] = mean_squared_error(train_outputs.mean, trainY)
+            with warnings.catch_warnings(record=True) as w2:
+                warnings.simplefilter("always")
+                test_outputs = model(testX)
+                pred_mean = test_outputs.mean
+            if not skip_posterior_variances:
+                if evaluate_on_train:
+                    model_metrics["train_nll"] = -mll(train_outputs, trainY).item()
+                model_metrics["test_nll"] = -mll(test_outputs, testY).item()
+                distro = likelihood(test_outputs)
+                lower, upper = distro.confidence_region()
+                frac = ((testY > lower) * (testY < upper)).to(torch.float).mean().item()
+                model_metrics["test_pred_frac_in_cr"] = frac
+                if record_pred_unc:
+                    model_metrics["test_pred_z_score"] = (testY - distro.mean) / distro.stddev
+    model_metrics["training_warnings"] = len(w)
+    model_metrics["testing_warning"] = "" if len(w2) == 0 else w2[-1].message
+    model_metrics["state_dict_file"] = _save_state_dict(model)
+    return model_metrics, pred_mean.to("cpu", torch.float), model

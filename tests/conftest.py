@@ -18,3 +18,14 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def oracle_backend():
+    """Install the CPU test double for the duration of one test."""
+    from rpgp_amd import backend
+    from tests.oracle_backend import OracleBackend
+    ob = OracleBackend()
+    prev = backend.set_backend(ob)
+    yield ob
+    backend.set_backend(prev)

@@ -1,0 +1,318 @@
+"""Host-side solve stack on CPU with the oracle test double as compute backend: mBCG, SLQ, pivoted Cholesky,
+inv_quad_logdet autograd, MLL, predictions, training loop.  (The GPU versions of the same checks run in
+test_gp_gpu.py against the real HIP backend.)"""
+import math
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_gp as orc
+
+
+def _problem(N=120, d=5, J=7, seed=0, noise=0.3, s=0.9):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(N, d, generator=g)
+    P = torch.randn(d, J, generator=g)
+    ls = torch.rand(d, generator=g) * 1.5 + 1.0
+    y = torch.sin(X).sum(1) + 0.05 * torch.randn(N, generator=g)
+    return X, y, P, ls, noise, s
+
+
+def test_linear_cg_solves_spd_system_and_tridiag_gives_logdet():
+    from rpgp_amd.linear_cg import linear_cg
+    from rpgp_amd.inv_quad_logdet import slq_logdet
+    torch.manual_seed(0)
+    n = 200
+    A = torch.randn(n, n, dtype=torch.float64)
+    A = A @ A.t() / n + 0.5 * torch.eye(n, dtype=torch.float64)
+    B = torch.randn(n, 6, dtype=torch.float64)
+    X = linear_cg(lambda v: A @ v, B, tolerance=1e-10, max_iter=1000)
+    assert torch.allclose(A @ X, B, atol=1e-7)
+    # SLQ: many unit-norm Gaussian probes, full Lanczos depth -> log-det within a few percent
+    probes = torch.randn(n, 64, dtype=torch.float64)
+    probes = probes / probes.norm(dim=0, keepdim=True)
+    _, T = linear_cg(lambda v: A @ v, probes, n_tridiag=64, tolerance=1e-12, max_iter=60, max_tridiag_iter=60)
+    est = float(slq_logdet(T, n))
+    exact = float(torch.logdet(A))
+    assert abs(est - exact) < 0.05 * abs(exact) + 2.0
+
+
+def test_linear_cg_warns_when_not_converged_and_handles_zero_rhs():
+    from rpgp_amd.linear_cg import linear_cg, NumericalWarning
+    torch.manual_seed(1)
+    n = 300
+    A = torch.randn(n, n, dtype=torch.float64)
+    A = A @ A.t() + 1e-3 * torch.eye(n, dtype=torch.float64)
+    b = torch.randn(n, 2, dtype=torch.float64)
+    b[:, 1] = 0
+    with pytest.warns(NumericalWarning):
+        x = linear_cg(lambda v: A @ v, b, tolerance=1e-12, max_iter=12)
+    assert torch.isfinite(x).all() and float(x[:, 1].abs().max()) == 0.0
+    v = linear_cg(lambda z: A @ z, b[:, 0], tolerance=1e-8, max_iter=2000)   # vector rhs
+    assert v.shape == (n,)
+
+
+def test_pivoted_cholesky_and_woodbury(oracle_backend):
+    from rpgp_amd.operators import AdditiveRPOperator
+    from rpgp_amd.precond import pivoted_cholesky, WoodburyPreconditioner
+    torch.manual_seed(0)
+    Z = torch.randn(150, 3) * 0.5
+    op = AdditiveRPOperator(Z, None, torch.tensor(1.3), weight=1.0 / 3)
+    K = op.to_dense().double()
+    L = pivoted_cholesky(op._diagonal(), op._get_rows, 15).double()
+    assert L.shape == (150, 15)
+    resid = K - L @ L.t()
+    assert float(resid.diagonal().min()) > -1e-5                   # partial Cholesky never overshoots the diagonal
+    assert float(resid.abs().max()) < float(K.abs().max())          # and reduces the error
+    L40 = pivoted_cholesky(op._diagonal(), op._get_rows, 40).double()
+    assert float((K - L40 @ L40.t()).abs().max()) < float(resid.abs().max())
+    pre = WoodburyPreconditioner(L.float(), 0.2)
+    M = (L @ L.t() + 0.2 * torch.eye(150, dtype=torch.float64))
+    r = torch.randn(150, 4)
+    assert torch.allclose(pre.solve(r).double(), torch.linalg.solve(M, r.double()), atol=2e-4)
+    assert abs(pre.logdet() - float(torch.logdet(M))) < 1e-3 * abs(float(torch.logdet(M))) + 1e-3
+    z = pre.sample(20000, generator=torch.Generator().manual_seed(0)).double()
+    emp = z @ z.t() / 20000
+    assert float((emp - M).abs().max()) < 0.15
+
+
+def _build_model(X, y, P, ls, noise, s, prescale=True):
+    from rpgp_amd.kernels import AdditiveStructureRBFKernel, ScaledProjectionKernel, ScaleKernel
+    from rpgp_amd.likelihoods import GaussianLikelihood, SmoothedBoxPrior
+    from rpgp_amd.models import ExactGPModel, ExactMarginalLogLikelihood
+    d, J = P.shape
+    lin = torch.nn.Linear(d, J, bias=False)
+    lin.weight.data = P.t().contiguous()
+    k = ScaledProjectionKernel(lin, AdditiveStructureRBFKernel(J), prescale=prescale, ard_num_dims=d if prescale else J)
+    k.initialize(lengthscale=ls)
+    sk = ScaleKernel(k)
+    sk.outputscale = s
+    lik = GaussianLikelihood(noise_prior=SmoothedBoxPrior(1e-4, 10, sigma=0.01))
+    lik.noise = noise
+    model = ExactGPModel(X, y, lik, sk)
+    model.mean_module.constant.data.fill_(0.2)
+    return model, lik, ExactMarginalLogLikelihood(lik, model)
+
+
+def _oracle_gp(X, y, P, ls, noise, s, prescale=True):
+    return orc.DenseExactGP(X.numpy(), y.numpy(), P.numpy(), ls.numpy(), s, noise, mean=0.2, prescale=prescale)
+
+
+@pytest.mark.parametrize("prescale", [True, False])
+def test_mll_value_and_gradients_cholesky_regime(oracle_backend, prescale):
+    X, y, P, ls, noise, s = _problem()
+    if not prescale:
+        ls = torch.rand(P.shape[1], generator=torch.Generator().manual_seed(5)) + 1.0
+    model, lik, mll = _build_model(X, y, P, ls, noise, s, prescale)
+    model.train()
+    val = mll(model(X), y)
+    ref = _oracle_gp(X, y, P, ls, noise, s, prescale)
+    assert abs(val.item() - ref.mll()) < 1e-4 * abs(ref.mll())
+    val.backward()
+    # float64 autograd reference of the same objective
+    Xd, yd, Pd = X.double(), y.double(), P.double()
+    raw_ls = model.covar_module.base_kernel.raw_lengthscale.detach().double().clone().requires_grad_(True)
+    raw_s = model.covar_module.raw_outputscale.detach().double().clone().requires_grad_(True)
+    raw_n = lik.raw_noise.detach().double().clone().requires_grad_(True)
+    c = model.mean_module.constant.detach().double().clone().requires_grad_(True)
+    l = torch.nn.functional.softplus(raw_ls).reshape(-1)
+    Z = (Xd / l) @ Pd if prescale else (Xd @ Pd) / l
+    K = torch.zeros(X.shape[0], X.shape[0], dtype=torch.float64)
+    for j in range(P.shape[1]):
+        dd = Z[:, j:j + 1] - Z[:, j:j + 1].t()
+        K = K + torch.exp(-0.5 * dd * dd)
+    n = X.shape[0]
+    Kh = torch.nn.functional.softplus(raw_s) / P.shape[1] * K + (torch.nn.functional.softplus(raw_n) + 1e-4) * torch.eye(n, dtype=torch.float64)
+    r = yd - c
+    obj = (-0.5 * r @ torch.linalg.solve(Kh, r) - 0.5 * torch.logdet(Kh) - 0.5 * n * math.log(2 * math.pi)) / n
+    obj.backward()
+    got = model.covar_module.base_kernel.raw_lengthscale.grad.double()
+    assert torch.allclose(got, raw_ls.grad, rtol=2e-3, atol=1e-6)
+    assert torch.allclose(model.covar_module.raw_outputscale.grad.double(), raw_s.grad, rtol=2e-3, atol=1e-6)
+    assert torch.allclose(lik.raw_noise.grad.double(), raw_n.grad, rtol=2e-3, atol=1e-6)
+    assert torch.allclose(model.mean_module.constant.grad.double(), c.grad, rtol=2e-3, atol=1e-6)
+    # frozen parameters stay frozen (test.py:597-598)
+    assert model.covar_module.base_kernel.projection_module.weight.grad is None
+
+
+def test_mll_cg_regime_matches_exact_with_tight_tolerance(oracle_backend):
+    from rpgp_amd import settings
+    X, y, P, ls, noise, s = _problem(N=260, seed=3, noise=0.2)
+    model, lik, mll = _build_model(X, y, P, ls, noise, s)
+    ref = _oracle_gp(X, y, P, ls, noise, s)
+    model.train()
+    with settings.max_cholesky_size(0), settings.cg_tolerance(1e-7), settings.num_trace_samples(60), \
+            settings.max_lanczos_quadrature_iterations(60), settings.deterministic_probes(True), \
+            settings.min_preconditioning_size(100):
+        val = mll(model(X), y)
+        val.backward()
+    # inverse-quadratic part is deterministic: exact to CG tolerance; the SLQ log-det carries probe noise
+    n = X.shape[0]
+    exact = ref.mll()
+    assert abs(val.item() - exact) < 0.03 * abs(exact)
+    g_noise_cg = lik.raw_noise.grad.item()
+    lik.raw_noise.grad = None
+    model.zero_grad()
+    val2 = mll(model(X), y)      # Cholesky regime (N <= 800)
+    val2.backward()
+    assert abs(g_noise_cg - lik.raw_noise.grad.item()) < 0.15 * abs(lik.raw_noise.grad.item()) + 1e-4
+
+
+def test_skip_logdet_forward_and_preconditioner_off(oracle_backend):
+    from rpgp_amd import settings
+    X, y, P, ls, noise, s = _problem(N=150, seed=4)
+    model, lik, mll = _build_model(X, y, P, ls, noise, s)
+    ref = _oracle_gp(X, y, P, ls, noise, s)
+    model.train()
+    with settings.max_cholesky_size(0), settings.cg_tolerance(1e-8), settings.skip_logdet_forward(True), \
+            settings.deterministic_probes(True):
+        val = mll(model(X), y).item()
+    n = X.shape[0]
+    expect = (-0.5 * ref.inv_quad() - 0.5 * n * math.log(2 * math.pi) + orc.smoothed_box_log_prob(noise)) / n
+    assert abs(val - expect) < 1e-4 * abs(expect)
+
+
+def test_predictions_match_oracle(oracle_backend):
+    from rpgp_amd import settings
+    X, y, P, ls, noise, s = _problem(N=140, seed=7)
+    Xs = torch.randn(37, X.shape[1], generator=torch.Generator().manual_seed(9))
+    ys = torch.sin(Xs).sum(1)
+    model, lik, mll = _build_model(X, y, P, ls, noise, s)
+    ref = _oracle_gp(X, y, P, ls, noise, s)
+    mean_ref, cov_ref = ref.predict(Xs.numpy(), full_cov=True)
+    for chol in (True, False):
+        model.train()
+        model.eval()
+        ctx = settings.max_cholesky_size(800 if chol else 0)
+        with ctx, settings.eval_cg_tolerance(1e-8), torch.no_grad():
+            out = model(Xs)
+            np.testing.assert_allclose(out.mean.numpy(), mean_ref, rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(out.covariance_matrix.numpy(), cov_ref, rtol=1e-3, atol=2e-5)
+            nll = -mll(out, ys).item()
+            assert abs(nll - ref.test_nll(Xs.numpy(), ys.numpy())) < 1e-3 * abs(nll) + 1e-4
+            lower, upper = lik(out).confidence_region()
+            sd = np.sqrt(np.diag(cov_ref) + noise)
+            np.testing.assert_allclose(lower.numpy(), mean_ref - 2 * sd, rtol=1e-3, atol=1e-4)
+    model.train()
+    model.eval()
+    with settings.skip_posterior_variances(True), torch.no_grad():
+        out = model(Xs)
+        np.testing.assert_allclose(out.mean.numpy(), mean_ref, rtol=1e-4, atol=1e-5)
+        assert float(out.variance.abs().max()) == 0.0
+
+
+def test_train_mode_requires_train_inputs(oracle_backend):
+    X, y, P, ls, noise, s = _problem(N=30)
+    model, _, _ = _build_model(X, y, P, ls, noise, s)
+    model.train()
+    with pytest.raises(RuntimeError):
+        model(torch.randn(5, X.shape[1]))
+
+
+def test_gradient_step_moves_only_trainable_parameters(oracle_backend):
+    """test.py:575-621: after one Adam step the projection stays fixed unless learn_proj, the outer lengthscale moves."""
+    from rpgp_amd.kernels import AdditiveStructureRBFKernel, ScaledProjectionKernel
+    from rpgp_amd.likelihoods import GaussianLikelihood
+    from rpgp_amd.models import ExactGPModel, ExactMarginalLogLikelihood
+    x = torch.tensor([[1., 2., 3.], [1.1, 2.2, 3.3]])
+    y = torch.sin(x).sum(dim=1)
+    for learn in (False, True):
+        lin = torch.nn.Linear(3, 3, bias=False)
+        lin.weight.data = torch.eye(3)
+        k = ScaledProjectionKernel(lin, AdditiveStructureRBFKernel(3, weight=1.0), prescale=True, ard_num_dims=3,
+                                   learn_proj=learn)
+        k.initialize(lengthscale=torch.tensor([1., 2., 3.]))
+        np.testing.assert_allclose(k.lengthscale.detach().numpy().ravel(), [1., 2., 3.], rtol=1e-6)
+        model = ExactGPModel(x, y, GaussianLikelihood(), k)
+        mll = ExactMarginalLogLikelihood(model.likelihood, model)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.1)
+        opt.zero_grad()
+        model.train()
+        loss = -mll(model(x), y)
+        loss.backward()
+        opt.step()
+        moved_proj = not np.allclose(lin.weight.detach().numpy(), np.eye(3))
+        assert moved_proj == learn
+        assert not np.allclose(k.lengthscale.detach().numpy().ravel(), [1., 2., 3.])
+        assert float(k.base_kernel.inner_lengthscale) == 1.0
+
+
+def test_train_to_convergence_semantics(oracle_backend):
+    from rpgp_amd.training import train_to_convergence
+    X, y, P, ls, noise, s = _problem(N=40, seed=2)
+    model, lik, mll = _build_model(X, y, P, ls, noise, s)
+
+    class FlatObjective(torch.nn.Module):
+        def forward(self, output, target):
+            return 0.0 * sum(p.sum() for p in model.parameters() if p.requires_grad) + 1.0
+
+    # a flat loss converges at the earliest possible epoch 2*patience-1 (moving average undefined before that)
+    it = train_to_convergence(model, X, y, optimizer=torch.optim.Adam, objective=FlatObjective(), max_iter=100,
+                              patience=20, isloss=True)
+    assert it == 39
+    it = train_to_convergence(model, X, y, optimizer=torch.optim.Adam, objective=FlatObjective(), max_iter=30,
+                              patience=20, isloss=True, check_conv=False)
+    assert it == 30
+    it = train_to_convergence(model, X, y, optimizer=torch.optim.Adam, objective=FlatObjective(), max_iter=60,
+                              patience=5, isloss=True, smooth=False)
+    assert it == 5
+    # a real objective decreases the loss and `checkpoint` restores the best state
+    model.train()
+    before = -mll(model(X), y).item()
+    train_to_convergence(model, X, y, optimizer=torch.optim.Adam, objective=mll, max_iter=15, lr=0.1, checkpoint=True)
+    model.train()
+    after = -mll(model(X), y).item()
+    assert after < before
+
+
+def test_train_exact_gp_contract(oracle_backend):
+    from rpgp_amd.training import train_exact_gp
+    torch.manual_seed(0)
+    np.random.seed(0)
+    X, y, P, ls, noise, s = _problem(N=90, d=4, seed=11)
+    Xs = torch.randn(20, 4)
+    ys = torch.sin(Xs).sum(1)
+    mk = {"J": "d", "noise_prior": True, "kernel_type": "RBF", "learn_proj": False, "prescale": True,
+          "space_proj": True, "batch_kernel": False, "mem_efficient": True}
+    tk = {"verbose": False, "optimizer": "adam", "max_iter": 6, "lr": 0.1, "patience": 20, "smooth": True,
+          "init_iters": 2}
+    metrics, pred, model = train_exact_gp(X, y, Xs, ys, "additive_rp", mk, tk, record_pred_unc=True)
+    for key in ["trained_epochs", "prior_train_nmll", "train_mse", "train_nll", "test_nll", "test_pred_frac_in_cr",
+                "test_pred_z_score", "training_warnings", "testing_warning", "state_dict_file"]:
+        assert key in metrics
+    assert metrics["trained_epochs"] == 6
+    assert pred.shape == (20,) and pred.dtype == torch.float32 and pred.device.type == "cpu"
+    assert model.covar_module.base_kernel.projection_module.weight.shape == (4, 4)       # "J": "d" placeholder
+    assert abs(float(model.covar_module.base_kernel.base_kernel.inner_lengthscale) - math.log(2)) < 1e-6
+    m2, _, _ = train_exact_gp(X, y, Xs, ys, "additive_rp", mk, tk, skip_posterior_variances=True,
+                              skip_random_restart=True, evaluate_on_train=False)
+    assert "test_nll" not in m2 and "train_mse" not in m2
+    with pytest.raises(ValueError):
+        train_exact_gp(X, y, Xs, ys, "nonsense", mk, tk)
+    with pytest.raises(ValueError):
+        train_exact_gp(X, y, Xs, ys, "additive_rp", dict(mk, k=2), tk)
+
+
+def test_kernel_factory_validation_errors():
+    from rpgp_amd.training import create_additive_rp_kernel, _map_to_optim
+    with pytest.raises(ValueError):
+        create_additive_rp_kernel(5, 3, k=2)                                  # batch kernel with k > 1
+    with pytest.raises(ValueError):
+        create_additive_rp_kernel(5, 3, mem_efficient=True)                   # batch_kernel default True
+    with pytest.raises(ValueError):
+        create_additive_rp_kernel(5, 3, mem_efficient=True, batch_kernel=False, kernel_type="Matern")
+    with pytest.raises(ValueError):
+        create_additive_rp_kernel(5, 3, mem_efficient=True, batch_kernel=False, ski=True)
+    with pytest.raises(ValueError):
+        create_additive_rp_kernel(5, 3, kernel_type="bogus")
+    with pytest.raises(ValueError):
+        _map_to_optim("rmsprop")
+    k = create_additive_rp_kernel(6, 4, prescale=True)
+    assert k.raw_lengthscale.shape == (1, 6)
+    k = create_additive_rp_kernel(6, 4, prescale=False)
+    assert k.raw_lengthscale.shape == (1, 4)
+    k = create_additive_rp_kernel(6, 4, ard=False)
+    assert k.raw_lengthscale.shape == (1, 1)
+    assert not k.projection_module.weight.requires_grad

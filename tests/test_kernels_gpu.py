@@ -145,3 +145,25 @@ def test_errors_are_python_exceptions(gpu_device):
         ops.mvm_sym(Z.cpu(), torch.zeros((10, 1)), 1.0)
     with pytest.raises(TypeError):
         ops.mvm_sym(Z.double(), torch.zeros((10, 1), device=gpu_device).double(), 1.0)
+
+
+@pytest.mark.parametrize("N,J", [(277, 20), (700, 6), (64, 3)])
+def test_bilinear_grad_dense_matches_oracle(gpu_device, N, J):
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N)
+    Z = rng.standard_normal((N, J)).astype(np.float32)
+    A = rng.standard_normal((N, N)).astype(np.float32)
+    S = (A + A.T).astype(np.float32)
+    gZ, gs = ops.bilinear_grad_dense(torch.from_numpy(Z).to(gpu_device), torch.from_numpy(S).to(gpu_device), 0.3)
+    z = Z.astype(np.float64)
+    s = S.astype(np.float64)
+    g_ref = np.zeros_like(z)
+    ks = np.zeros((N, N))
+    for j in range(J):
+        d = z[:, j:j + 1] - z[:, j:j + 1].T
+        e = np.exp(-0.5 * d * d)
+        ks += e
+        g_ref[:, j] = -0.3 * (s * e * d).sum(axis=1)
+    assert _rel(gZ.cpu().numpy(), g_ref) < 2e-5
+    gs_ref = 0.5 * (s * ks).sum()
+    assert abs(gs.item() - gs_ref) < 2e-4 * np.abs(s * ks).sum() * 0.5 / N + 2e-5 * abs(gs_ref)

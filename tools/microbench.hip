@@ -107,6 +107,79 @@ __global__ __launch_bounds__(256) void bench_kernel(float *out, unsigned long lo
   if ((threadIdx.x & 63) == 0) cyc[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
+
+// The candidate restructuring of the fused MVM: the matrix pipe produces m = -(a-b)^2 for a 32x32 tile per
+// projection (one v_mfma_f32_32x32x16_bf16 on 3-way bf16 splits), VALU only does v_exp_f32 + accumulate.
+// B operands come from LDS (one ds_read_b128 per projection) like the real kernel's column stream.
+template <int NJ, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void mfma_mix_kernel(float *out, unsigned long long *cyc, float seed) {
+  __shared__ intx4 sB[NJ * 64];
+  const int lane = threadIdx.x & 63;
+  for (int e = threadIdx.x; e < NJ * 64; e += 64 * WAVES) sB[e] = intx4{(int)(e * 2654435761u) & 0x3f803f80, e, e * 3, e * 7} & 0x3fff3fff;
+  __syncthreads();
+  bf16x8 A[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    intx4 t = {(lane + j) * 0x01010101 & 0x3f7f3f7f, j * 0x00110011 & 0x3f7f3f7f, lane & 0x3f7f, 0x3c003c00};
+    A[j] = __builtin_bit_cast(bf16x8, t);
+  }
+  floatx16 kacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kacc[r] = 0.f;
+  const floatx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  // software pipeline with two statically named result tiles: the MFMA for projection j+1 is issued before the
+  // exps of projection j are consumed (no register copies)
+#define MM(jj, itv) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(jj) % NJ], __builtin_bit_cast(bf16x8, sB[((jj) % NJ) * 64 + ((lane + (itv)) & 63)]), zero, 0, 0, 0)
+  floatx16 c0 = MM(0, 0), c1;
+  for (int it = 0; it < ITERS / 16; ++it) {
+#pragma unroll
+    for (int j = 0; j < NJ; j += 2) {
+      c1 = MM(j + 1, it);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kacc[r] += __builtin_amdgcn_exp2f(-c0[r]);
+      c0 = MM(j + 2, it + (j + 2) / NJ);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kacc[r] += __builtin_amdgcn_exp2f(-c1[r]);
+    }
+  }
+#undef MM
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += kacc[r];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (lane == 0) cyc[(size_t)blockIdx.x * WAVES + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int NJ, int WAVES>
+int run_mfma_mix(int wgs_per_cu, int ncu, float *dout, unsigned long long *dcyc) {
+  const int blocks = ncu * wgs_per_cu;
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((mfma_mix_kernel<NJ, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, dout, dcyc, 0.5f);
+  CHK(hipDeviceSynchronize());
+  CHK(hipEventRecord(e0));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL((mfma_mix_kernel<NJ, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, dout, dcyc, 0.5f);
+  CHK(hipEventRecord(e1));
+  CHK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double terms = (double)blocks * WAVES * (ITERS / 16) * NJ * 1024.0;
+  printf("mfma32x32x16bf16 + 16 exp + 16 add  NJ=%d waves/WG=%d WG/CU=%d (waves/SIMD=%.1f)  time=%8.3f ms  pair-terms/s=%.3e\n",
+         NJ, WAVES, wgs_per_cu, wgs_per_cu * WAVES / 4.0, ms, terms / (ms * 1e-3));
+  CHK(hipEventDestroy(e0));
+  CHK(hipEventDestroy(e1));
+  return 0;
+}
+
 template <int MIX>
 int run_mix(int wgs_per_cu, int ncu, float *dout, unsigned long long *dcyc) {
   const int blocks = ncu * wgs_per_cu;  // 256-thread blocks: 1 wave per SIMD each
@@ -147,8 +220,13 @@ int main() {
          prop.clockRate, prop.memoryClockRate, prop.memoryBusWidth);
   float *dout;
   unsigned long long *dcyc;
-  CHK(hipMalloc(&dout, (size_t)ncu * 8 * 256 * sizeof(float)));
-  CHK(hipMalloc(&dcyc, (size_t)ncu * 8 * 4 * sizeof(unsigned long long)));
+  CHK(hipMalloc(&dout, (size_t)ncu * 8 * 512 * sizeof(float)));
+  CHK(hipMalloc(&dcyc, (size_t)ncu * 8 * 8 * sizeof(unsigned long long)));
+  for (int w : {1, 2, 3}) {
+    if (run_mfma_mix<20, 4>(w, ncu, dout, dcyc)) return 1;
+    if (run_mfma_mix<20, 8>(w, ncu, dout, dcyc)) return 1;
+  }
+  printf("\n");
   for (int w : {1, 2, 4, 8}) {
     if (run_mix<EXP>(w, ncu, dout, dcyc)) return 1;
     if (run_mix<FMA>(w, ncu, dout, dcyc)) return 1;

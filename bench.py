@@ -110,6 +110,16 @@ def main():
     # those of one dense-equivalent MVM, attributed to the slowest rank's kernel time
     achieved = b_alg / (kernel_ms * 1e-3)
 
+    # literal HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected live); reported only
+    # when the profile was taken on the same kernel + workload as this run
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters_current.json")))
+        if prof.get("N") == N and prof.get("J") == J and prof.get("T") == T and world == 1:
+            traffic = prof["hbm_bytes_high"]
+    except Exception:
+        traffic = None
+
     result = {
         "metric": "additive-RP kernel MVMs/sec at N=50k J=20; achieved HBM GB/s vs peak",
         "value": round(value, 3),
@@ -127,7 +137,7 @@ def main():
                    "N": N, "d": d, "J": J, "T": T, "parallelism": "j-shard x%d + all-reduce" % world if world > 1 else "single GPU",
                    "lengthscale": "sqrt(d)", "outputscale": outputscale, "noise": noise},
         "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": peak / 1e9, "unit": "GB/s",
-                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "frac": round(achieved / peak, 4), "traffic": traffic,
                      "kernel": "mvm_tile_kernel<20,1,2,sym>", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes": b_alg,
                      "pair_terms_per_s": round(0.5 * N * N * J / (kernel_ms * 1e-3), 1),

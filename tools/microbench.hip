@@ -114,39 +114,66 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 // The candidate restructuring of the fused MVM: the matrix pipe produces m = -(a-b)^2 for a 32x32 tile per
 // projection (one v_mfma_f32_32x32x16_bf16 on 3-way bf16 splits), VALU only does v_exp_f32 + accumulate.
 // B operands come from LDS (one ds_read_b128 per projection) like the real kernel's column stream.
-template <int NJ, int WAVES>
+template <int NJ, int WAVES, bool USE_MFMA>
 __global__ __launch_bounds__(64 * WAVES, 2) void mfma_mix_kernel(float *out, unsigned long long *cyc, float seed) {
   __shared__ intx4 sB[NJ * 64];
   const int lane = threadIdx.x & 63;
   for (int e = threadIdx.x; e < NJ * 64; e += 64 * WAVES) sB[e] = intx4{(int)(e * 2654435761u) & 0x3f803f80, e, e * 3, e * 7} & 0x3fff3fff;
   __syncthreads();
-  bf16x8 A[NJ];
+  intx4 A[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     intx4 t = {(lane + j) * 0x01010101 & 0x3f7f3f7f, j * 0x00110011 & 0x3f7f3f7f, lane & 0x3f7f, 0x3c003c00};
-    A[j] = __builtin_bit_cast(bf16x8, t);
+    A[j] = t;
   }
-  floatx16 kacc;
+  float kacc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) kacc[r] = 0.f;
   const floatx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  // software pipeline with two statically named result tiles: the MFMA for projection j+1 is issued before the
-  // exps of projection j are consumed (no register copies)
-#define MM(jj, itv) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(jj) % NJ], __builtin_bit_cast(bf16x8, sB[((jj) % NJ) * 64 + ((lane + (itv)) & 63)]), zero, 0, 0, 0)
-  floatx16 c0 = MM(0, 0), c1;
+  // software pipeline with two statically named result tiles.  The MFMA is an opaque asm statement and
+  // sched_barrier(0) fences keep "MFMA(j+1) | 16 exps + adds of j" in program order, so the matrix pipe works on
+  // projection j+1 while VALU consumes projection j (hipcc otherwise sinks the MFMA next to its consumer).
+#define MMASM(dst, jj, itv)                                                                         \
+  {                                                                                                 \
+    intx4 bq = sB[((jj) % NJ) * 64 + ((lane + (itv)) & 63)];                                        \
+    if constexpr (USE_MFMA)                                                                           \
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(dst) : "v"(A[(jj) % NJ]), "v"(bq)); \
+    else                                                                                              \
+      asm volatile("v_mov_b32 %0, %1" : "+v"(dst[0]) : "v"(bq[0]), "v"(A[(jj) % NJ]));                 \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+  }
+#define EXPADD8(cc, o)                                                                                         \
+  {                                                                                                            \
+    float t0, t1, t2, t3, t4, t5, t6, t7;                                                                      \
+    asm volatile(                                                                                              \
+        "v_exp_f32_e64 %8, -%16\n\tv_exp_f32_e64 %9, -%17\n\tv_exp_f32_e64 %10, -%18\n\tv_exp_f32_e64 %11, -%19\n\t" \
+        "v_exp_f32_e64 %12, -%20\n\tv_exp_f32_e64 %13, -%21\n\tv_exp_f32_e64 %14, -%22\n\tv_exp_f32_e64 %15, -%23\n\t" \
+        "v_add_f32 %0, %0, %8\n\tv_add_f32 %1, %1, %9\n\tv_add_f32 %2, %2, %10\n\tv_add_f32 %3, %3, %11\n\t"       \
+        "v_add_f32 %4, %4, %12\n\tv_add_f32 %5, %5, %13\n\tv_add_f32 %6, %6, %14\n\tv_add_f32 %7, %7, %15"        \
+        : "+v"(kacc[o + 0]), "+v"(kacc[o + 1]), "+v"(kacc[o + 2]), "+v"(kacc[o + 3]), "+v"(kacc[o + 4]),         \
+          "+v"(kacc[o + 5]), "+v"(kacc[o + 6]), "+v"(kacc[o + 7]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),   \
+          "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)                                                           \
+        : "v"(cc[o + 0]), "v"(cc[o + 1]), "v"(cc[o + 2]), "v"(cc[o + 3]), "v"(cc[o + 4]), "v"(cc[o + 5]),       \
+          "v"(cc[o + 6]), "v"(cc[o + 7]));                                                                     \
+  }
+#define CONSUME(cc)  \
+  EXPADD8(cc, 0)     \
+  EXPADD8(cc, 8)     \
+  __builtin_amdgcn_sched_barrier(0);
+  floatx16 c0 = zero, c1 = zero;
+  MMASM(c0, 0, 0)
   for (int it = 0; it < ITERS / 16; ++it) {
 #pragma unroll
     for (int j = 0; j < NJ; j += 2) {
-      c1 = MM(j + 1, it);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) kacc[r] += __builtin_amdgcn_exp2f(-c0[r]);
-      c0 = MM(j + 2, it + (j + 2) / NJ);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) kacc[r] += __builtin_amdgcn_exp2f(-c1[r]);
+      MMASM(c1, j + 1, it)
+      CONSUME(c0)
+      MMASM(c0, j + 2, it + (j + 2) / NJ)
+      CONSUME(c1)
     }
   }
-#undef MM
+#undef MMASM
+#undef CONSUME
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0.f;
 #pragma unroll
@@ -155,26 +182,34 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfma_mix_kernel(float *out, uns
   if (lane == 0) cyc[(size_t)blockIdx.x * WAVES + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int NJ, int WAVES>
+template <int NJ, int WAVES, bool USE_MFMA>
 int run_mfma_mix(int wgs_per_cu, int ncu, float *dout, unsigned long long *dcyc) {
   const int blocks = ncu * wgs_per_cu;
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((mfma_mix_kernel<NJ, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, dout, dcyc, 0.5f);
+  hipLaunchKernelGGL((mfma_mix_kernel<NJ, WAVES, USE_MFMA>), dim3(blocks), dim3(64 * WAVES), 0, 0, dout, dcyc, 0.5f);
   CHK(hipDeviceSynchronize());
   CHK(hipEventRecord(e0));
   const int reps = 5;
   for (int r = 0; r < reps; ++r)
-    hipLaunchKernelGGL((mfma_mix_kernel<NJ, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, dout, dcyc, 0.5f);
+    hipLaunchKernelGGL((mfma_mix_kernel<NJ, WAVES, USE_MFMA>), dim3(blocks), dim3(64 * WAVES), 0, 0, dout, dcyc, 0.5f);
   CHK(hipEventRecord(e1));
   CHK(hipEventSynchronize(e1));
   float ms = 0;
   CHK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
   const double terms = (double)blocks * WAVES * (ITERS / 16) * NJ * 1024.0;
-  printf("mfma32x32x16bf16 + 16 exp + 16 add  NJ=%d waves/WG=%d WG/CU=%d (waves/SIMD=%.1f)  time=%8.3f ms  pair-terms/s=%.3e\n",
-         NJ, WAVES, wgs_per_cu, wgs_per_cu * WAVES / 4.0, ms, terms / (ms * 1e-3));
+  std::vector<unsigned long long> h((size_t)blocks * WAVES);
+  CHK(hipMemcpy(h.data(), dcyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end());
+  const double med = (double)h[h.size() / 2];
+  const double wps = wgs_per_cu * WAVES / 4.0;
+  // SIMD cycles per (MFMA + 16 exp + 16 add) step, assuming the resident waves of a SIMD run concurrently
+  const double cyc_per_step = med / ((ITERS / 16) * (double)NJ * wps);
+  printf("%s + 16 exp + 16 add  NJ=%d waves/SIMD=%.1f  time=%8.3f ms  pair-terms/s=%.3e  SIMD-cycles/step=%.1f (=%.2f per 64 pair-terms)  clk~%.2f GHz\n",
+         USE_MFMA ? "mfma32x32x16bf16" : "(no mfma)       ", NJ, wps, ms, terms / (ms * 1e-3), cyc_per_step, cyc_per_step / 16.0,
+         med / (ms * 1e-3) * 1e-9);
   CHK(hipEventDestroy(e0));
   CHK(hipEventDestroy(e1));
   return 0;
@@ -223,8 +258,10 @@ int main() {
   CHK(hipMalloc(&dout, (size_t)ncu * 8 * 512 * sizeof(float)));
   CHK(hipMalloc(&dcyc, (size_t)ncu * 8 * 8 * sizeof(unsigned long long)));
   for (int w : {1, 2, 3}) {
-    if (run_mfma_mix<20, 4>(w, ncu, dout, dcyc)) return 1;
-    if (run_mfma_mix<20, 8>(w, ncu, dout, dcyc)) return 1;
+    if (run_mfma_mix<20, 4, true>(w, ncu, dout, dcyc)) return 1;
+    if (run_mfma_mix<20, 4, false>(w, ncu, dout, dcyc)) return 1;
+    if (run_mfma_mix<20, 8, true>(w, ncu, dout, dcyc)) return 1;
+    if (run_mfma_mix<20, 8, false>(w, ncu, dout, dcyc)) return 1;
   }
   printf("\n");
   for (int w : {1, 2, 4, 8}) {

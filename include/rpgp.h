@@ -71,6 +71,23 @@ int rpgp_mvm_sym(const float *Z, const float *V, float *out, int64_t N, int ldz,
                  void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Prepared (factorised) fast path for repeated symmetric MVMs with the same Z (every CG iteration of one
+ * hyper-parameter step).  exp(-(a-b)^2/2) is evaluated as exp2(-a'^2) * exp2(2a'b' - b'^2) on centred, pre-scaled
+ * coordinates: 3 VALU issues per pair-term instead of 4.  `rpgp_prepare` centres each projection at the midpoint of its
+ * range, writes the packed row/column tables into `prep` and records whether the exponent range is safe
+ * (max a'^2 < 100); `rpgp_prepare_status` copies that verdict to the host (synchronises the stream once).  Only call
+ * `rpgp_mvm_sym_prepared` when fast_ok == 1 — otherwise it fills `out` with NaN — and use rpgp_mvm_sym (exact direct
+ * form, any range) instead.  Same result contract, workspace and determinism as rpgp_mvm_sym; relative error per
+ * kernel entry <= ~1e-7 * (1 + a'^2).   J <= 64.
+ */
+size_t rpgp_prepare_bytes(int64_t N, int J);
+int rpgp_prepare(const float *Z, int64_t N, int ldz, int J, void *prep, size_t prep_bytes, void *stream);
+int rpgp_prepare_status(const void *prep, int *fast_ok_host, float *max_abs_host, void *stream);
+int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t N, int J, int T,
+                          int j0, int j1, float scale, float noise,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Rectangular fused MVM:  out = scale * sum_j K_j(Z1,Z2) @ V      (Z1: M x ., Z2: N x ., V: N x T, out: M x T)
  * Replaces K(X*,X) @ alpha and K(X,X*) blocks of the prediction strategy driven from training_routines.py:551-575.
  */

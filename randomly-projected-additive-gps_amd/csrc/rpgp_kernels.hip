@@ -26,7 +26,9 @@
 namespace {
 
 constexpr float kExp2Scale = 0.8493218002880191f;  // sqrt(0.5 * log2(e)):  exp(-d^2/2) = exp2(-(c d)^2)
-constexpr int kSC = 256;                           // columns staged in LDS per sub-chunk
+constexpr int kSC = 256;                           // columns staged in LDS per sub-chunk (T <= 4)
+// wide right-hand sides stage fewer columns so that LDS (sT = 4*SC*TT floats) still admits several workgroups per CU
+template <int TT> struct StageCols { static constexpr int v = (TT > 4) ? 64 : 256; };
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -128,10 +130,11 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
     float *__restrict__ slabR, float *__restrict__ slabT, int M, int N, int ldz1, int ldz2, int ldv,
     int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate) {
   constexpr int BR = 256 * R;
+  constexpr int SC = StageCols<TT>::v;
   constexpr int STR = ColStride<JT>::v;
-  __shared__ __attribute__((aligned(16))) float sB[kSC * STR];
-  __shared__ __attribute__((aligned(16))) float sV[kSC * TT];
-  __shared__ __attribute__((aligned(16))) float sT[SYM ? 4 * kSC * TT : 4];
+  __shared__ __attribute__((aligned(16))) float sB[SC * STR];
+  __shared__ __attribute__((aligned(16))) float sV[SC * TT];
+  __shared__ __attribute__((aligned(16))) float sT[SYM ? 4 * SC * TT : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -162,9 +165,9 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
     }
   }
 
-  for (int c0 = c_begin; c0 < c_end; c0 += kSC) {
+  for (int c0 = c_begin; c0 < c_end; c0 += SC) {
     __syncthreads();
-    {
+    if (tid < SC) {
       const int col = c0 + tid;
       const bool cv = col < c_end;
 #pragma unroll
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
     }
     __syncthreads();
     const int ncol = c_end - c0;
-    const int nsub = ncol >= kSC ? kSC / 64 : (ncol + 63) / 64;
+    const int nsub = ncol >= SC ? SC / 64 : (ncol + 63) / 64;
     for (int sub = 0; sub < nsub; ++sub) {
       const bool doT = SYM && (c0 + sub * 64 >= r0 + BR);
       float accT[TT];
@@ -221,18 +224,18 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
       }
       if constexpr (SYM) {
 #pragma unroll
-        for (int t = 0; t < TT; ++t) sT[(wave * kSC + sub * 64 + lane) * TT + t] = accT[t];
+        for (int t = 0; t < TT; ++t) sT[(wave * SC + sub * 64 + lane) * TT + t] = accT[t];
       }
     }
     if constexpr (SYM) {
       __syncthreads();
       const int col = c0 + tid;
-      if (col < c_end && col >= r0 + BR) {
+      if (tid < SC && col < c_end && col >= r0 + BR) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
           if (t < tcnt) {
-            float sum = sT[(0 * kSC + tid) * TT + t] + sT[(1 * kSC + tid) * TT + t] +
-                        sT[(2 * kSC + tid) * TT + t] + sT[(3 * kSC + tid) * TT + t];
+            float sum = sT[(0 * SC + tid) * TT + t] + sT[(1 * SC + tid) * TT + t] +
+                        sT[(2 * SC + tid) * TT + t] + sT[(3 * SC + tid) * TT + t];
             float *dst = slabT + ((size_t)rb * N + col) * ldv + t0 + t;
             *dst = accumulate ? *dst + sum : sum;
           }
@@ -256,12 +259,297 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Factorised fast path ("prepared" MVM).
+//   exp2(-(a-b)^2) = exp2(-a^2) * exp2(2ab - b^2)
+// so per pair-term the loop is  t = fma(a, 2b, -b^2);  e = v_exp_f32(t);  K = fma(e, exp2(-a^2), K)
+// (3 VALU issues instead of 4: the subtract disappears).  2ab - b^2 <= a^2 must stay below the fp32 exponent range,
+// so rpgp_prepare centres every projection at the midpoint of its range and records max|a|; the host only takes this
+// path when max a^2 < kFactMaxSq, otherwise the exact direct kernel above is used.
+// prep buffer: [header 256 B][mid J floats, padded to 256 B][rowdat N*J float2 {a, Ea}][coldat N*J float2 {2a, -a^2}]
+// ---------------------------------------------------------------------------------------------
+constexpr float kFactMaxSq = 100.0f;   // a^2 bound (|z - mid| < 11.8): exp2(100) is far inside fp32 range
+constexpr int kPrepHeaderFloats = 64;
+constexpr int kPrepMidFloats = 64;     // J <= 64 projections per prepared buffer
+
+struct PrepLayout {
+  float *header;
+  float *mid;
+  float2v *rowdat;
+  float2v *coldat;
+};
+
+__host__ __device__ inline PrepLayout prep_layout(void *prep, long long N, int J) {
+  PrepLayout L;
+  L.header = reinterpret_cast<float *>(prep);
+  L.mid = L.header + kPrepHeaderFloats;
+  L.rowdat = reinterpret_cast<float2v *>(L.mid + kPrepMidFloats);
+  L.coldat = L.rowdat + (size_t)N * J;
+  return L;
+}
+
+// NaN-propagating min / max so that non-finite inputs are caught by the range guard
+__device__ __forceinline__ float min_nan(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
+
+// per-block partial min/max of every projection
+__global__ __launch_bounds__(256) void prep_minmax_kernel(const float *__restrict__ Z, float *__restrict__ part,
+                                                          long long N, int ldz, int J, long long rows_per_block) {
+  __shared__ float smin[256], smax[256];
+  const long long n0 = (long long)blockIdx.x * rows_per_block;
+  const long long n1 = (n0 + rows_per_block < N) ? n0 + rows_per_block : N;
+  // thread t handles projection t % J of rows n0 + t / J, stepping by 256 / J rows
+  const int j = threadIdx.x % J;
+  const int rstep = 256 / J;
+  float mn = 3.4e38f, mx = -3.4e38f;
+  if ((int)threadIdx.x < rstep * J) {
+    for (long long n = n0 + threadIdx.x / J; n < n1; n += rstep) {
+      const float z = Z[n * ldz + j];
+      mn = min_nan(mn, z);
+      mx = max_nan(mx, z);
+    }
+  }
+  smin[threadIdx.x] = mn;
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  if ((int)threadIdx.x < J) {
+    for (int t = threadIdx.x + J; t < rstep * J; t += J) {
+      mn = min_nan(mn, smin[t]);
+      mx = max_nan(mx, smax[t]);
+    }
+    part[((size_t)blockIdx.x * J + threadIdx.x) * 2 + 0] = mn;
+    part[((size_t)blockIdx.x * J + threadIdx.x) * 2 + 1] = mx;
+  }
+}
+
+__global__ void prep_finish_kernel(const float *__restrict__ part, int nparts, int J, float *__restrict__ header,
+                                   float *__restrict__ mid) {
+  __shared__ float shalf[64];
+  const int j = threadIdx.x;
+  if (j < J) {
+    float mn = 3.4e38f, mx = -3.4e38f;
+    for (int p = 0; p < nparts; ++p) {
+      const float a = part[((size_t)p * J + j) * 2 + 0], b = part[((size_t)p * J + j) * 2 + 1];
+      mn = min_nan(mn, a);
+      mx = max_nan(mx, b);
+    }
+    mid[j] = 0.5f * (mn + mx);
+    shalf[j] = 0.5f * (mx - mn) * kExp2Scale;
+  }
+  __syncthreads();
+  if (j == 0) {
+    float m = 0.f;
+    bool finite = true;
+    for (int q = 0; q < J; ++q) {
+      finite = finite && (shalf[q] == shalf[q]) && (shalf[q] < 3.0e38f);
+      m = shalf[q] > m ? shalf[q] : m;
+    }
+    header[1] = m;                                             // max |a|
+    reinterpret_cast<int *>(header)[0] = (finite && m * m < kFactMaxSq) ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void prep_build_kernel(const float *__restrict__ Z, const float *__restrict__ mid,
+                                                         float2v *__restrict__ rowdat, float2v *__restrict__ coldat,
+                                                         long long N, int ldz, int J) {
+  const long long total = N * J;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+    const long long n = g / J;
+    const int j = (int)(g % J);
+    const float a = (Z[n * ldz + j] - mid[j]) * kExp2Scale;
+    const float na2 = -(a * a);
+    rowdat[g] = float2v{a, fast_exp2(na2)};
+    coldat[g] = float2v{2.0f * a, na2};
+  }
+}
+
+template <int JT> struct FactStride { static constexpr int v = ((2 * JT) % 8 == 0) ? 2 * JT + 4 : ((2 * JT) % 4 == 0 ? 2 * JT : 2 * JT); };
+
+// K(i, c) partial sum over JT projections in factorised form; q points at this column's packed LDS record
+// [pair p: b2_{2p}, b2_{2p+1}, nb2_{2p}, nb2_{2p+1}] (JT even) or [b2, nb2] (JT == 1)
+template <int JT>
+__device__ __forceinline__ float fact_pair_sum(const float2v (&ap)[(JT + 1) / 2], const float2v (&ea)[(JT + 1) / 2],
+                                               const float *q) {
+  if constexpr (JT % 2 == 0) {
+    float2v acc = {0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < JT / 2; ++p) {
+      const float4v c = *reinterpret_cast<const float4v *>(q + 4 * p);
+      const float2v b2 = {c.x, c.y};
+      const float2v nb2 = {c.z, c.w};
+      const float2v t = __builtin_elementwise_fma(ap[p], b2, nb2);
+      const float2v e = {fast_exp2(t.x), fast_exp2(t.y)};
+      acc = __builtin_elementwise_fma(e, ea[p], acc);
+    }
+    return acc.x + acc.y;
+  } else {
+    const float t = __builtin_fmaf(ap[0].x, q[0], q[1]);
+    return fast_exp2(t) * ea[0].x;
+  }
+}
+
+template <int JT, int TT, int R>
+__global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict__ rowdat,
+                                                       const float2v *__restrict__ coldat,
+                                                       const float *__restrict__ V, float *__restrict__ slabR,
+                                                       float *__restrict__ slabT, int N, int J, int ldv, int j0, int t0,
+                                                       int tcnt, int chunk_cols, int rotdir, int accumulate) {
+  constexpr int BR = 256 * R;
+  constexpr int SC = StageCols<TT>::v;
+  constexpr int NP = (JT + 1) / 2;
+  constexpr int STR = (JT == 1) ? 2 : FactStride<JT>::v;
+  __shared__ __attribute__((aligned(16))) float sB[SC * STR];
+  __shared__ __attribute__((aligned(16))) float sV[SC * TT];
+  __shared__ __attribute__((aligned(16))) float sT[4 * SC * TT];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int rb = blockIdx.y;
+  const int kchunk = blockIdx.x;
+  const int r0 = rb * BR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+
+  float2v ap[R][NP], ea[R][NP];
+  float vrow[R][TT], accR[R][TT];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+    const bool valid = row < N;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      float2v x0 = {0.f, 0.f}, x1 = {0.f, 0.f};
+      if (valid) {
+        x0 = rowdat[(size_t)row * J + j0 + 2 * p];
+        if (2 * p + 1 < JT) x1 = rowdat[(size_t)row * J + j0 + 2 * p + 1];
+      }
+      ap[r][p] = float2v{x0.x, x1.x};
+      ea[r][p] = float2v{x0.y, x1.y};     // invalid rows: Ea = 0 -> K = 0
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      vrow[r][t] = (valid && t < tcnt) ? V[(size_t)row * ldv + t0 + t] : 0.f;
+      accR[r][t] = 0.f;
+    }
+  }
+
+  for (int c0 = c_begin; c0 < c_end; c0 += SC) {
+    __syncthreads();
+    if (tid < SC) {
+      const int col = c0 + tid;
+      const bool cv = col < c_end;
+      if constexpr (JT == 1) {
+        float2v x = {0.f, -1.0e30f};
+        if (cv) x = coldat[(size_t)col * J + j0];
+        sB[tid * STR + 0] = x.x;
+        sB[tid * STR + 1] = x.y;
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          float2v x0 = {0.f, -1.0e30f}, x1 = {0.f, -1.0e30f};   // padded columns: exp2(-1e30) = 0
+          if (cv) {
+            x0 = coldat[(size_t)col * J + j0 + 2 * p];
+            x1 = coldat[(size_t)col * J + j0 + 2 * p + 1];
+          }
+          *reinterpret_cast<float4v *>(&sB[tid * STR + 4 * p]) = float4v{x0.x, x1.x, x0.y, x1.y};
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+        sV[tid * TT + t] = (cv && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+    }
+    __syncthreads();
+    const int ncol = c_end - c0;
+    const int nsub = ncol >= SC ? SC / 64 : (ncol + 63) / 64;
+    for (int sub = 0; sub < nsub; ++sub) {
+      const bool doT = (c0 + sub * 64 >= r0 + BR);
+      float accT[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) accT[t] = 0.f;
+      if (doT) {
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {
+          const int idx = sub * 64 + ((lane + rotdir * s) & 63);
+          float v[TT];
+          lds_load_vec<TT>(sV, idx, v);
+          float tsum[TT];
+#pragma unroll
+          for (int t = 0; t < TT; ++t) tsum[t] = accT[t];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float ks = fact_pair_sum<JT>(ap[r], ea[r], sB + idx * STR);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+              accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
+              tsum[t] = __builtin_fmaf(ks, vrow[r][t], tsum[t]);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < TT; ++t) accT[t] = wave_rotate1(tsum[t]);
+        }
+      } else {
+#pragma unroll 2
+        for (int s = 0; s < 64; ++s) {
+          const int idx = sub * 64 + ((lane + s) & 63);
+          float v[TT];
+          lds_load_vec<TT>(sV, idx, v);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float ks = fact_pair_sum<JT>(ap[r], ea[r], sB + idx * STR);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TT; ++t) sT[(wave * SC + sub * 64 + lane) * TT + t] = accT[t];
+    }
+    __syncthreads();
+    {
+      const int col = c0 + tid;
+      if (tid < SC && col < c_end && col >= r0 + BR) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          if (t < tcnt) {
+            float sum = sT[(0 * SC + tid) * TT + t] + sT[(1 * SC + tid) * TT + t] +
+                        sT[(2 * SC + tid) * TT + t] + sT[(3 * SC + tid) * TT + t];
+            float *dst = slabT + ((size_t)rb * N + col) * ldv + t0 + t;
+            *dst = accumulate ? *dst + sum : sum;
+          }
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+    if (row < N) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (t < tcnt) {
+          float *dst = slabR + ((size_t)kchunk * N + row) * ldv + t0 + t;
+          *dst = accumulate ? *dst + accR[r][t] : accR[r][t];
+        }
+      }
+    }
+  }
+}
+
 // out[row][t] = scale * (sum_k slabR[k][row][t] + sum_{rb < row/BR} slabT[rb][row][t]) + noise * V[row][t]
 __global__ void mvm_reduce_kernel(const float *__restrict__ slabR, const float *__restrict__ slabT,
                                   const float *__restrict__ V, float *__restrict__ out, int M, int N, int T,
-                                  int BR, int chunk_cols, int sym, float scale, float noise) {
+                                  int BR, int chunk_cols, int sym, float scale, float noise,
+                                  const int *__restrict__ guard) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (size_t)M * T) return;
+  if (guard && *guard == 0) {   // prepared (factorised) path used although rpgp_prepare flagged the range as unsafe
+    out[gid] = __builtin_nanf("");
+    return;
+  }
   const int row = (int)(gid / T);
   const int rb = row / BR;
   const int cbase = sym ? rb * BR : 0;
@@ -605,21 +893,25 @@ struct TilePlan {
   int R;           // rows per lane
   int BR;          // rows per workgroup
   int nrb;         // row blocks
-  int chunk_cols;  // columns per workgroup (multiple of BR and kSC)
+  int chunk_cols;  // columns per workgroup (multiple of 64)
   int maxchunks;   // grid.x
 };
 
-inline TilePlan make_plan(int64_t M, int64_t N, bool sym) {
+inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T) {
   TilePlan p;
+  // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
   p.R = (M >= 16384) ? 2 : 1;
+  (void)T;
   p.BR = 256 * p.R;
   p.nrb = (int)((M + p.BR - 1) / p.BR);
-  // aim for ~4096 workgroups so the hardware dispatcher can balance the triangular sweep
+  // aim for ~4600 workgroups (6 rounds of 3 workgroups per CU) so the dispatcher can balance the triangular sweep;
+  // chunks are multiples of 64 columns (one rotation subtile), at least 128 (64 for small problems)
   const double pairs = sym ? 0.5 * (double)M * (double)N : (double)M * (double)N;
-  double cc = pairs / ((double)p.BR * 4096.0);
-  int chunk = (int)((cc + p.BR - 1) / p.BR) * p.BR;
-  if (chunk < p.BR) chunk = p.BR;
-  if (chunk > 8192) chunk = 8192 / p.BR * p.BR;
+  double cc = pairs / ((double)p.BR * 4608.0);
+  int chunk = (int)((cc + 63.0) / 64.0) * 64;
+  const int min_chunk = (M >= 16384) ? 128 : 64;
+  if (chunk < min_chunk) chunk = min_chunk;
+  if (chunk > 8192) chunk = 8192;
   p.chunk_cols = chunk;
   p.maxchunks = (int)((N + chunk - 1) / chunk);
   return p;
@@ -664,7 +956,7 @@ int dispatch_jt(int jt, int tt, const TilePlan &p, const float *Z1, const float 
 }
 
 inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym) {
-  const TilePlan p = make_plan(M, N, sym);
+  const TilePlan p = make_plan(M, N, sym, T);
   size_t f = (size_t)p.maxchunks * M * T;
   if (sym) f += (size_t)p.nrb * N * T;
   return f;
@@ -681,7 +973,7 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
   const size_t need = mvm_workspace_floats(M, N, T, SYM) * sizeof(float);
   if (!ws || ws_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const TilePlan p = make_plan(M, N, SYM);
+  const TilePlan p = make_plan(M, N, SYM, T);
   float *slabR = reinterpret_cast<float *>(ws);
   float *slabT = slabR + (size_t)p.maxchunks * M * T;
   int first = 1;
@@ -706,8 +998,45 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
   }
   const size_t total = (size_t)M * T;
   hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V,
-                     out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise);
+                     out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise, (const int *)nullptr);
   return launch_status();
+}
+
+// ---- prepared (factorised) path -----------------------------------------------------------------
+template <int JT, int TT>
+int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *coldat, const float *V, float *slabR,
+                    float *slabT, int N, int J, int ldv, int j0, int t0, int tcnt, int accumulate, hipStream_t st) {
+  dim3 grid(p.maxchunks, p.nrb), block(256);
+  if (p.R == 2)
+    hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 2>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
+                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate);
+  else
+    hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 1>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
+                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate);
+  return launch_status();
+}
+
+template <int JT>
+int dispatch_fact_t(int tt, const TilePlan &p, const float2v *rowdat, const float2v *coldat, const float *V,
+                    float *slabR, float *slabT, int N, int J, int ldv, int j0, int t0, int tcnt, int accumulate,
+                    hipStream_t st) {
+  switch (tt) {
+    case 1: return launch_mvm_fact<JT, 1>(p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    case 4: return launch_mvm_fact<JT, 4>(p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    default: return launch_mvm_fact<JT, 12>(p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+  }
+}
+
+inline int dispatch_fact_jt(int jt, int tt, const TilePlan &p, const float2v *rowdat, const float2v *coldat,
+                            const float *V, float *slabR, float *slabT, int N, int J, int ldv, int j0, int t0,
+                            int tcnt, int accumulate, hipStream_t st) {
+  switch (jt) {
+    case 20: return dispatch_fact_t<20>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    case 8: return dispatch_fact_t<8>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    case 4: return dispatch_fact_t<4>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    case 2: return dispatch_fact_t<2>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    default: return dispatch_fact_t<1>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+  }
 }
 
 template <int JT>
@@ -844,6 +1173,81 @@ size_t rpgp_mvm_sym_workspace_bytes(int64_t N, int T) {
 int rpgp_mvm_sym(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1, float scale,
                  float noise, void *workspace, size_t workspace_bytes, void *stream) {
   return mvm_common<true>(Z, Z, V, out, N, N, ldz, ldz, T, j0, j1, scale, noise, workspace, workspace_bytes, stream);
+}
+
+size_t rpgp_prepare_bytes(int64_t N, int J) {
+  if (N <= 0 || J <= 0 || J > kPrepMidFloats) return 0;
+  // header + mid + rowdat + coldat + min/max partials (tail)
+  const size_t nblk = (size_t)((N + 2047) / 2048 < 1024 ? (N + 2047) / 2048 : 1024);
+  return (kPrepHeaderFloats + kPrepMidFloats) * sizeof(float) + 2 * (size_t)N * J * sizeof(float2v) +
+         nblk * J * 2 * sizeof(float);
+}
+
+int rpgp_prepare(const float *Z, int64_t N, int ldz, int J, void *prep, size_t prep_bytes, void *stream) {
+  if (!Z || !prep || N <= 0 || J <= 0 || J > kPrepMidFloats || ldz < J) return RPGP_EINVAL;
+  if (prep_bytes < rpgp_prepare_bytes(N, J)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  PrepLayout L = prep_layout(prep, N, J);
+  float *part = reinterpret_cast<float *>(L.coldat + (size_t)N * J);
+  const int nblk = (int)((N + 2047) / 2048 < 1024 ? (N + 2047) / 2048 : 1024);
+  const long long rows_per_block = (N + nblk - 1) / nblk;
+  hipLaunchKernelGGL(prep_minmax_kernel, dim3(nblk), dim3(256), 0, st, Z, part, (long long)N, ldz, J, rows_per_block);
+  hipLaunchKernelGGL(prep_finish_kernel, dim3(1), dim3(64), 0, st, part, nblk, J, L.header, L.mid);
+  const long long total = N * J;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(prep_build_kernel, dim3(blocks), dim3(256), 0, st, Z, L.mid, L.rowdat, L.coldat, (long long)N, ldz, J);
+  return launch_status();
+}
+
+int rpgp_prepare_status(const void *prep, int *fast_ok_host, float *max_abs_host, void *stream) {
+  if (!prep) return RPGP_EINVAL;
+  float h[2];
+  hipStream_t st = as_stream(stream);
+  RPGP_CHECK(hipMemcpyAsync(h, prep, sizeof(h), hipMemcpyDeviceToHost, st));
+  RPGP_CHECK(hipStreamSynchronize(st));
+  if (fast_ok_host) *fast_ok_host = *reinterpret_cast<int *>(&h[0]);
+  if (max_abs_host) *max_abs_host = h[1];
+  return 0;
+}
+
+int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t N, int J, int T, int j0, int j1,
+                          float scale, float noise, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!prep || !V || !out || N <= 0 || T <= 0 || J <= 0 || J > kPrepMidFloats || j0 < 0 || j1 <= j0 || j1 > J)
+    return RPGP_EINVAL;
+  if (N > 0x7fffffffLL) return RPGP_EINVAL;
+  int rc = rpgp_init();
+  if (rc) return rc;
+  const size_t need = mvm_workspace_floats(N, N, T, true) * sizeof(float);
+  if (!workspace || workspace_bytes < need) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const TilePlan p = make_plan(N, N, true, T);
+  PrepLayout L = prep_layout(const_cast<void *>(prep), N, J);
+  float *slabR = reinterpret_cast<float *>(workspace);
+  float *slabT = slabR + (size_t)p.maxchunks * N * T;
+  int first = 1;
+  const bool prof = g_prof_on && g_prof_n < kProfMax;
+  if (prof) RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
+  for (int j = j0; j < j1;) {
+    const int jt = next_j_piece(j1 - j);
+    for (int t0 = 0; t0 < T;) {
+      const int tt = next_t_piece(T - t0);
+      const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+      rc = dispatch_fact_jt(jt, tt, p, L.rowdat, L.coldat, V, slabR, slabT, (int)N, J, T, j, t0, tcnt, first ? 0 : 1, st);
+      if (rc) return rc;
+      t0 += tcnt;
+    }
+    first = 0;
+    j += jt;
+  }
+  if (prof) {
+    RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st));
+    ++g_prof_n;
+  }
+  const size_t total = (size_t)N * T;
+  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V, out,
+                     (int)N, (int)N, T, p.BR, p.chunk_cols, 1, scale, noise,
+                     reinterpret_cast<const int *>(L.header));
+  return launch_status();
 }
 
 size_t rpgp_mvm_rect_workspace_bytes(int64_t M, int64_t N, int T) {

@@ -100,6 +100,7 @@ class AdditiveRPOperator(LinearOperator):
         self.shard = shard
         # one host sync per construction (= per optimiser step); kernels take the scale by value
         self._scale = float(outputscale.detach()) * self.weight
+        self._prep = None          # rpgp_prepare tables for the factorised fast path (built on first use)
 
     # ---- protocol -------------------------------------------------------------------------------------------
     def _size(self):
@@ -128,6 +129,12 @@ class AdditiveRPOperator(LinearOperator):
         j0, j1 = self._jrange()
         z1 = self.Z1.detach()
         if self.symmetric:
+            prepare = getattr(be, "prepare", None)
+            if prepare is not None:
+                if self._prep is None:
+                    self._prep = prepare(z1)        # once per operator (= per hyper-parameter step), one host sync
+                if self._prep.fast_ok:
+                    return be.mvm_sym_prepared(self._prep, rhs, self._scale, noise, j0=j0, j1=j1)
             return be.mvm_sym(z1, rhs, self._scale, noise, j0=j0, j1=j1)
         return be.mvm_rect(z1, self.Z2.detach(), rhs, self._scale, j0=j0, j1=j1)
 

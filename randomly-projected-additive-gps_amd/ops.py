@@ -99,6 +99,53 @@ def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None):
     return out.squeeze(1) if squeeze else out
 
 
+class Prepared:
+    """Device-side tables of rpgp_prepare for one Z (centred, pre-scaled coordinates for the factorised fast path)."""
+
+    def __init__(self, Z):
+        import ctypes
+        lib = _lib.load()
+        Z = _require(Z, "Z", 2)
+        self.N, self.J = Z.shape
+        self.device = Z.device
+        self.fast_ok = False
+        self.max_abs = float("inf")
+        self.buf = None
+        if self.J > 64:
+            return
+        with torch.cuda.device(Z.device):
+            nbytes = lib.rpgp_prepare_bytes(self.N, self.J)
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=Z.device)
+            _lib.check(lib.rpgp_prepare(Z.data_ptr(), self.N, self.J, self.J, self.buf.data_ptr(), self.buf.numel(),
+                                        _stream()), "rpgp_prepare")
+            ok, mx = ctypes.c_int(0), ctypes.c_float(0)
+            _lib.check(lib.rpgp_prepare_status(self.buf.data_ptr(), ctypes.byref(ok), ctypes.byref(mx), _stream()),
+                       "rpgp_prepare_status")
+        self.fast_ok = bool(ok.value)
+        self.max_abs = float(mx.value)
+
+
+def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None):
+    """Factorised fast path: same result contract as mvm_sym for the Z that `prep` was built from."""
+    lib = _lib.load()
+    if not prep.fast_ok:
+        raise RuntimeError("rpgp_prepare flagged the coordinate range as unsafe for the factorised path "
+                           "(max|a| = %g): use mvm_sym" % prep.max_abs)
+    N, J = prep.N, prep.J
+    j1 = J if j1 is None else j1
+    V2, squeeze = _as_matrix(V, N, "V")
+    T = V2.shape[1]
+    if out is None:
+        out = torch.empty_like(V2)
+    with torch.cuda.device(prep.device):
+        nbytes = lib.rpgp_mvm_sym_workspace_bytes(N, T)
+        ws = _workspace(prep.device, nbytes)
+        _lib.check(lib.rpgp_mvm_sym_prepared(prep.buf.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1,
+                                             float(scale), float(noise), ws.data_ptr(), ws.numel(), _stream()),
+                   "rpgp_mvm_sym_prepared")
+    return out.squeeze(1) if squeeze else out
+
+
 def mvm_rect(Z1, Z2, V, scale, j0=0, j1=None):
     """out = scale * sum_j K_j(Z1,Z2) @ V   (M x T)."""
     lib = _lib.load()

@@ -167,3 +167,41 @@ def test_bilinear_grad_dense_matches_oracle(gpu_device, N, J):
     assert _rel(gZ.cpu().numpy(), g_ref) < 2e-5
     gs_ref = 0.5 * (s * ks).sum()
     assert abs(gs.item() - gs_ref) < 2e-4 * np.abs(s * ks).sum() * 0.5 / N + 2e-5 * abs(gs_ref)
+
+
+@pytest.mark.parametrize("N,J,T,shift", [(63, 20, 1, 0.0), (1000, 20, 1, 5.0), (777, 18, 4, -3.0), (2049, 8, 1, 100.0),
+                                         (1500, 7, 13, 0.0), (4096, 20, 11, 1.0), (300, 3, 1, 0.0), (16500, 20, 1, 0.5)])
+def test_mvm_sym_prepared_matches_oracle(gpu_device, N, J, T, shift):
+    """Factorised fast path (rpgp_prepare + rpgp_mvm_sym_prepared): same contract as rpgp_mvm_sym; the centring makes
+    it invariant to a common shift of the projected coordinates."""
+    from rpgp_amd import ops
+    Z, V = _data(N, J, T, seed=N + J + 1)
+    Z = (Z + np.float32(shift)).astype(np.float32)
+    scale, noise = 0.7 / J, 0.1
+    ref = orc.mvm(Z, Z, V, scale, noise)
+    Zt = torch.from_numpy(Z).to(gpu_device)
+    prep = ops.Prepared(Zt)
+    assert prep.fast_ok and prep.max_abs < 10.0
+    out = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), scale, noise)
+    assert _rel(out.cpu().numpy(), ref) < 1e-5
+    part = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), scale, 0.0, j0=1, j1=J)
+    ref_p = orc.mvm(Z[:, 1:], Z[:, 1:], V, scale) if J > 1 else None
+    if ref_p is not None:
+        assert _rel(part.cpu().numpy(), ref_p) < 1e-5
+
+
+def test_prepared_range_guard(gpu_device):
+    """Coordinates spread beyond the safe exponent range are flagged; the exact direct kernel still handles them."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(0)
+    Z = (rng.standard_normal((500, 6)) * 40.0).astype(np.float32)
+    V = rng.standard_normal((500, 1)).astype(np.float32)
+    Zt = torch.from_numpy(Z).to(gpu_device)
+    prep = ops.Prepared(Zt)
+    assert not prep.fast_ok and prep.max_abs > 10.0
+    with pytest.raises(RuntimeError):
+        ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), 1.0)
+    out = ops.mvm_sym(Zt, torch.from_numpy(V).to(gpu_device), 1.0, 0.0)
+    assert _rel(out.cpu().numpy(), orc.mvm(Z, Z, V, 1.0)) < 1e-5
+    bad = torch.from_numpy(np.full((10, 2), np.nan, dtype=np.float32)).to(gpu_device)
+    assert not ops.Prepared(bad).fast_ok

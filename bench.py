@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--J", type=int, default=20)
     ap.add_argument("--T", type=int, default=1)
     ap.add_argument("--direct", action="store_true", help="use the exact direct kernel instead of the factorised path")
+    ap.add_argument("--no-extras", action="store_true", help="skip the T=11 block / full-solve context numbers")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -155,6 +156,35 @@ def main():
                      "note": "dense-equivalent bytes (4N^2+4N(d+2T)); the fused kernel is VALU/transcendental-bound, "
                              "its literal HBM traffic is ~MBs (see DESIGN.md)"},
     }
+
+    if world == 1 and not args.no_extras:
+        # context numbers (not part of `value`): the T=11 block the training solve uses (10 probes + residual), and one
+        # full solve Khat^-1 y with the reference's eval tolerance (SURVEY.md §8(d) "unit of work")
+        from rpgp_amd import settings, linear_cg as lcg
+        from rpgp_amd.operators import AdditiveRPOperator, AddedDiagOperator
+        V11 = torch.randn(N, 11, generator=torch.Generator().manual_seed(4)).to(device)
+        blk = (lambda: ops.mvm_sym_prepared(prep, V11, scale, noise)) if fast else (lambda: ops.mvm_sym(Z, V11, scale, noise))
+        blk()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(5):
+            blk()
+        torch.cuda.synchronize()
+        t11 = (time.perf_counter() - tb) / 5
+        y = torch.sin(X).sum(1)
+        y = (y - y.mean()) / y.std()
+        khat = AddedDiagOperator(AdditiveRPOperator(Z, None, torch.tensor(outputscale, device=device), 1.0 / J),
+                                 torch.tensor(noise, device=device))
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        with settings.eval_cg_tolerance(0.01):
+            alpha = lcg.linear_cg(khat._matmul, y.reshape(-1, 1), tolerance=0.01, max_iter=1000)
+        torch.cuda.synchronize()
+        t_solve = time.perf_counter() - ts
+        resid = float((khat._matmul(alpha) - y.reshape(-1, 1)).norm() / y.norm())
+        result["extras"] = {"block_T11_ms": round(t11 * 1e3, 4), "block_T11_mvm_equiv_per_s": round(11.0 / t11, 1),
+                            "solve_Khat_inv_y": {"tolerance": 0.01, "cg_iterations": lcg.stats["last_iterations"],
+                                                 "seconds": round(t_solve, 4), "relative_residual": resid}}
 
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         from oracle import cpu_path

@@ -22,6 +22,10 @@ class NumericalWarning(RuntimeWarning):
     """Issued when CG stops at max_iter without reaching the tolerance."""
 
 
+# diagnostics of the most recent solves (iterations, number of right-hand sides); read by benchmarks / tests
+stats = {"calls": 0, "iterations": 0, "last_iterations": 0, "last_rhs": 0}
+
+
 def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_updating_after=1e-10, max_iter=None,
               max_tridiag_iter=None, initial_guess=None, preconditioner=None, check_every=1):
     """Solve A X = rhs for symmetric positive definite A given as `matmul_closure`.
@@ -136,6 +140,10 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
                 "number of CG iterations by running code in a rpgp_amd.settings.max_cg_iterations(value) context."
                 .format(k + 1, mean_res, tolerance), NumericalWarning)
 
+    stats["calls"] += 1
+    stats["iterations"] += k + 1
+    stats["last_iterations"] = k + 1
+    stats["last_rhs"] = T
     result = result * rhs_norm
     if squeeze:
         result = result.squeeze(-1)

@@ -147,8 +147,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mfma_mix_kernel(float *out, uns
   {                                                                                                            \
     float t0, t1, t2, t3, t4, t5, t6, t7;                                                                      \
     asm volatile(                                                                                              \
-        "v_exp_f32_e64 %8, -%16\n\tv_exp_f32_e64 %9, -%17\n\tv_exp_f32_e64 %10, -%18\n\tv_exp_f32_e64 %11, -%19\n\t" \
-        "v_exp_f32_e64 %12, -%20\n\tv_exp_f32_e64 %13, -%21\n\tv_exp_f32_e64 %14, -%22\n\tv_exp_f32_e64 %15, -%23\n\t" \
+        "v_exp_f32_e32 %8, %16\n\tv_exp_f32_e32 %9, %17\n\tv_exp_f32_e32 %10, %18\n\tv_exp_f32_e32 %11, %19\n\t" \
+        "v_exp_f32_e32 %12, %20\n\tv_exp_f32_e32 %13, %21\n\tv_exp_f32_e32 %14, %22\n\tv_exp_f32_e32 %15, %23\n\t" \
         "v_add_f32 %0, %0, %8\n\tv_add_f32 %1, %1, %9\n\tv_add_f32 %2, %2, %10\n\tv_add_f32 %3, %3, %11\n\t"       \
         "v_add_f32 %4, %4, %12\n\tv_add_f32 %5, %5, %13\n\tv_add_f32 %6, %6, %14\n\tv_add_f32 %7, %7, %15"        \
         : "+v"(kacc[o + 0]), "+v"(kacc[o + 1]), "+v"(kacc[o + 2]), "+v"(kacc[o + 3]), "+v"(kacc[o + 4]),         \

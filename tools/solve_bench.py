@@ -1,0 +1,68 @@
+"""End-to-end timing of the exact-GP solve path on one MI355X: optimiser steps (mBCG + SLQ forward, fused derivative
+backward) and the evaluation block (mean cache, predictive mean/variance) on synthetic stand-ins of the BASELINE
+configs.  Prints one JSON line per configuration."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rpgp_amd import settings, linear_cg as lcg
+from rpgp_amd.training import create_exact_gp
+from rpgp_amd.models import ExactMarginalLogLikelihood
+
+
+def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N + ntest, d, generator=g)
+    y = torch.sin(X).sum(1) + 0.05 * torch.randn(N + ntest, generator=g)
+    y = (y - y.mean()) / y.std()
+    Xtr, ytr, Xte, yte = X[:N].to(dev), y[:N].to(dev), X[N:].to(dev), y[N:].to(dev)
+    torch.manual_seed(0)
+    model, lik = create_exact_gp(Xtr, ytr, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                 prescale=True, space_proj=space_proj)
+    model = model.to(dev)
+    mll = ExactMarginalLogLikelihood(lik, model)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.1)
+    res = {"config": name, "N": N, "d": d, "J": J, "N_test": ntest}
+    with settings.cg_tolerance(cg_tol), settings.eval_cg_tolerance(eval_tol), settings.max_cg_iterations(10000):
+        model.train()
+        times, iters, losses = [], [], []
+        for it in range(steps + 1):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            lcg.stats["iterations"] = 0
+            opt.zero_grad()
+            loss = -mll(model(Xtr), ytr)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            if it > 0:
+                times.append(time.perf_counter() - t0); iters.append(lcg.stats["iterations"])
+            losses.append(loss.item())
+        res.update({"train_step_s": sum(times) / len(times), "cg_iters_per_step": sum(iters) / len(iters),
+                    "loss_first": losses[0], "loss_last": losses[-1]})
+        model.eval()
+        with torch.no_grad():
+            torch.cuda.synchronize(); t0 = time.perf_counter(); lcg.stats["iterations"] = 0
+            with settings.skip_posterior_variances(True):
+                out = model(Xte)
+                rmse = float(((out.mean - yte) ** 2).mean().sqrt())
+            torch.cuda.synchronize(); res["mean_pred_s"] = time.perf_counter() - t0
+            res["mean_cache_cg_iters"] = lcg.stats["iterations"]; res["test_rmse"] = rmse
+            model.train(); model.eval()
+            torch.cuda.synchronize(); t0 = time.perf_counter(); lcg.stats["iterations"] = 0
+            out = model(Xte)
+            nll = -mll(out, yte).item()
+            torch.cuda.synchronize(); res["full_pred_s"] = time.perf_counter() - t0
+            res["full_pred_cg_iters"] = lcg.stats["iterations"]; res["test_nll"] = nll
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="C2,C3")
+    ap.add_argument("--steps", type=int, default=5)
+    a = ap.parse_args()
+    table = {"C2": ("C2 kin8nm-shaped RPA-GP", 7372, 8, 20, 820, False), "C3": ("C3 elevators-shaped DPA-GP", 14939, 18, 20, 1660, True),
+             "C4": ("C4 synthetic 50k RPA-GP", 50000, 20, 20, 2000, False), "S": ("small", 3000, 8, 20, 300, False)}
+    for c in a.configs.split(","):
+        name, N, d, J, nt, sp = table[c]
+        run(name, N, d, J, nt, a.steps, sp, 0.05, 0.01)

@@ -137,6 +137,33 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
                    float noise, void *stream);
 
 /*
+ * SKI path (1-D grid interpolation per projection; replaces the `GridInterpolationKernel` wrap of
+ * training_routines.py:157-158 used by model_specs/additive_spread_prescale_Jd_ski.json):
+ *   K ~= scale * sum_j W_j Tm W_j^T,   W_j = cubic-convolution (Keys) interpolation weights of projection j onto ONE
+ *   shared regular grid of G points,  Tm[m,m'] = exp(-0.5 ((m-m') h)^2)  (symmetric Toeplitz).
+ * rpgp_ski_grid       : grid_params (device, 4 floats: g0, h, 1/h, 0) from the min/max of Z1 (and Z2 if given) so that all
+ *                       points lie in [g_2, g_{G-3}]  (h = range / (G-5)).
+ * rpgp_ski_mvm        : out = scale * sum_j W1_j Tm W2_j^T V (+ noise V when Z1 == Z2)    (out: M x T, V: N x T).
+ *                       scatter (LDS-privatised histogram + float atomics: sums are order-dependent in the last bits),
+ *                       Toeplitz matvec, gather.  HBM traffic ~ 4 (N (J + T) + M (J + T)) bytes.
+ * rpgp_ski_diag       : diag[i] = scale * sum_j w_i^T Tm[4x4] w_i.
+ * rpgp_ski_bilinear_grad : d/dZ and d/dscale of sum((L R^T) * K) for the square operator (T <= 12); `row_scratch`
+ *                       is N floats of device scratch.
+ * All need `rpgp_ski_workspace_bytes(J, G, T)` bytes of workspace; G*12*4 <= 64 KB (G <= 1365).
+ */
+size_t rpgp_ski_workspace_bytes(int J, int G, int T);
+int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t N2, int ld2, int J, int G,
+                  float *grid_params, void *workspace, size_t workspace_bytes, void *stream);
+int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, const float *V, float *out,
+                 int64_t M, int64_t N, int ldz1, int ldz2, int J, int G, int T, float scale, float noise,
+                 void *workspace, size_t workspace_bytes, void *stream);
+int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t N, int ldz, int J, int G,
+                  float scale, void *stream);
+int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
+                           float *gscale, int64_t N, int ldz, int ldg, int J, int G, int T, float scale,
+                           void *workspace, size_t workspace_bytes, float *row_scratch, void *stream);
+
+/*
  * Measurement hook used by bench.py (roofline.achieved): between begin/end every rpgp_mvm_sym / rpgp_mvm_rect call
  * records a HIP-event pair on its stream around the dominant fused tile kernel launch(es) (the small slab-reduce
  * launch is outside the pair).  `rpgp_profile_end` synchronises those events and returns the mean duration (ms)

@@ -1,0 +1,62 @@
+"""ORACLE — test infrastructure only.  Float64 dense restatement of the SKI path the reference enables with
+`ski=True` (training_routines.py:157-158: `GridInterpolationKernel(kernel, **ski_options)` around each 1-D sub-kernel;
+model_specs/additive_spread_prescale_Jd_ski.json: grid_size 1024, num_dims 1) — SURVEY.md Appendix E.
+
+K ~= scale * sum_j W_j Tm W_j^T with cubic-convolution interpolation (Keys 1981, the 4-tap kernel GPyTorch's
+`Interpolation` uses: u<=1: ((1.5u-2.5)u)u+1 ; 1<u<=2: ((-0.5u+2.5)u-4)u+2) onto one regular grid shared by all
+projections, and Tm[m,m'] = exp(-0.5 ((m-m')h)^2).  Grid rule of this build: h = (max-min)/(G-5), g0 = min - 2h, so that
+every stencil is interior.  **Parity unpinned**: GPyTorch is not installable and the reference has no SKI tests
+(SURVEY.md §4); this oracle pins the HIP kernels to the stated math and to the exact kernel (interpolation error)."""
+import numpy as np
+
+
+def grid_params(Z1, Z2=None, G=1024):
+    z = np.asarray(Z1, dtype=np.float64).ravel()
+    if Z2 is not None:
+        z = np.concatenate([z, np.asarray(Z2, dtype=np.float64).ravel()])
+    mn, mx = z.min(), z.max()
+    rng = max(mx - mn, 1e-12)
+    h = rng / (G - 5)
+    return mn - 2.0 * h, h
+
+
+def _cubic(U):
+    U = np.abs(U)
+    return np.where(U < 1.0, ((1.5 * U - 2.5) * U) * U + 1.0, ((-0.5 * U + 2.5) * U - 4.0) * U + 2.0)
+
+
+def interp_matrix(z, g0, h, G):
+    """Dense N x G interpolation matrix of one projection (4 non-zeros per row)."""
+    z = np.asarray(z, dtype=np.float64)
+    u = np.clip((z - g0) / h, 1.0, G - 2.0)
+    fl = np.floor(u)
+    fr = u - fl
+    idx0 = np.clip(fl.astype(np.int64) - 1, 0, G - 4)
+    W = np.zeros((z.shape[0], G))
+    rows = np.arange(z.shape[0])
+    for k, s in enumerate([fr + 1.0, fr, 1.0 - fr, 2.0 - fr]):
+        W[rows, idx0 + k] += _cubic(s)
+    return W
+
+
+def toeplitz(h, G):
+    m = np.arange(G)
+    d = (m[:, None] - m[None, :]) * h
+    return np.exp(-0.5 * d * d)
+
+
+def dense_kernel(Z1, Z2, scale, G=1024, grid=None):
+    Z1 = np.asarray(Z1, dtype=np.float64)
+    Z2 = np.asarray(Z2, dtype=np.float64)
+    g0, h = grid if grid is not None else grid_params(Z1, None if Z2 is Z1 else Z2, G)
+    Tm = toeplitz(h, G)
+    K = np.zeros((Z1.shape[0], Z2.shape[0]))
+    for j in range(Z1.shape[1]):
+        K += interp_matrix(Z1[:, j], g0, h, G) @ Tm @ interp_matrix(Z2[:, j], g0, h, G).T
+    return scale * K
+
+
+def bilinear_objective(Z, L, R, scale, G, grid):
+    """sum((L R^T) * K_ski(Z, Z)) with a FIXED grid (the grid is a buffer, not differentiated)."""
+    K = dense_kernel(Z, Z, scale, G, grid)
+    return float((np.asarray(L, dtype=np.float64) @ np.asarray(R, dtype=np.float64).T * K).sum())

@@ -41,6 +41,12 @@ SIGNATURES = {
     "rpgp_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "rpgp_bilinear_grad_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _int, _int, _f32, _vp, _sz, _vp]),
     "rpgp_dense_mvm": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _f32, _vp]),
+    "rpgp_ski_workspace_bytes": (_sz, [_int, _int, _int]),
+    "rpgp_ski_grid": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
+    "rpgp_ski_mvm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
+    "rpgp_ski_diag": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp]),
+    "rpgp_ski_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz,
+                                      _vp, _vp]),
     "rpgp_profile_begin": (_int, []),
     "rpgp_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
 }

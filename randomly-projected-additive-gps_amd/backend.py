@@ -18,6 +18,10 @@ class HipBackend:
     bilinear_grad = staticmethod(ops.bilinear_grad)
     bilinear_grad_dense = staticmethod(ops.bilinear_grad_dense)
     dense_mvm = staticmethod(ops.dense_mvm)
+    ski_grid = staticmethod(ops.ski_grid)
+    ski_mvm = staticmethod(ops.ski_mvm)
+    ski_diag = staticmethod(ops.ski_diag)
+    ski_bilinear_grad = staticmethod(ops.ski_bilinear_grad)
 
 
 _backend = HipBackend()

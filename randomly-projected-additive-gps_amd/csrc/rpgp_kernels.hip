@@ -853,6 +853,327 @@ __global__ __launch_bounds__(256) void dense_mvm_kernel(const float *__restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SKI path (spec additive_spread_prescale_Jd_ski.json):
+//   K_j ~= W_j Tm W_j^T,  W_j: cubic-convolution interpolation (Keys, 4 taps) of projection j onto ONE shared regular
+//   1-D grid of G points, Tm: symmetric Toeplitz with first column exp(-0.5 (k h)^2).
+// MVM = scatter (W^T v, LDS-privatised histogram + global float atomics) -> Toeplitz matvec (G x G, tiny) -> gather.
+// HBM traffic ~ N (J + 2T) floats: this path is bandwidth/latency bound, not exp bound.
+// grid params (device): gp[0] = g0 (first grid point), gp[1] = h (spacing), gp[2] = 1/h
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cubic_w(float U) {      // Keys cubic convolution kernel, U = |distance| / h in [0, 2]
+  return (U < 1.0f) ? ((1.5f * U - 2.5f) * U) * U + 1.0f : ((-0.5f * U + 2.5f) * U - 4.0f) * U + 2.0f;
+}
+__device__ __forceinline__ float cubic_dw(float U) {     // d/dU of the above
+  return (U < 1.0f) ? (4.5f * U - 5.0f) * U : (-1.5f * U + 5.0f) * U - 4.0f;
+}
+
+// taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
+template <bool DERIV>
+__device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, float (&w)[4], float (&dw)[4]) {
+  float u = (z - g0) * inv_h;
+  u = u < 1.0f ? 1.0f : (u > (float)(G - 2) ? (float)(G - 2) : u);   // clamp into the interior (extrapolation guard)
+  const float fl = __builtin_floorf(u);
+  const float fr = u - fl;
+  int idx0 = (int)fl - 1;
+  idx0 = idx0 < 0 ? 0 : (idx0 > G - 4 ? G - 4 : idx0);
+  const float s[4] = {fr + 1.0f, fr, 1.0f - fr, 2.0f - fr};          // |signed distance| of the 4 taps
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = cubic_w(s[k]);
+  if constexpr (DERIV) {
+    // signed distance s_k = fr + 1 - k: positive for k = 0,1; negative for k = 2,3;  dU/dz = sign / h
+    dw[0] = cubic_dw(s[0]) * inv_h;
+    dw[1] = cubic_dw(s[1]) * inv_h;
+    dw[2] = -cubic_dw(s[2]) * inv_h;
+    dw[3] = -cubic_dw(s[3]) * inv_h;
+  }
+  return idx0;
+}
+
+// global min / max of all N x J projected coordinates of up to two arrays -> grid parameters
+__global__ __launch_bounds__(256) void ski_minmax_kernel(const float *__restrict__ Z1, long long n1, int ld1,
+                                                         const float *__restrict__ Z2, long long n2, int ld2, int J,
+                                                         float *__restrict__ part) {
+  __shared__ float smin[256], smax[256];
+  float mn = 3.4e38f, mx = -3.4e38f;
+  const long long t1 = n1 * J, t2 = n2 * J;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < t1 + t2; g += (long long)gridDim.x * 256) {
+    float z;
+    if (g < t1) z = Z1[(g / J) * ld1 + (g % J)];
+    else { const long long q = g - t1; z = Z2[(q / J) * ld2 + (q % J)]; }
+    mn = min_nan(mn, z);
+    mx = max_nan(mx, z);
+  }
+  smin[threadIdx.x] = mn;
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      smin[threadIdx.x] = min_nan(smin[threadIdx.x], smin[threadIdx.x + w]);
+      smax[threadIdx.x] = max_nan(smax[threadIdx.x], smax[threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = smin[0];
+    part[2 * blockIdx.x + 1] = smax[0];
+  }
+}
+
+__global__ void ski_grid_finish_kernel(const float *__restrict__ part, int nparts, int G, float *__restrict__ gp) {
+  if (threadIdx.x != 0) return;
+  float mn = 3.4e38f, mx = -3.4e38f;
+  for (int p = 0; p < nparts; ++p) {
+    mn = min_nan(mn, part[2 * p]);
+    mx = max_nan(mx, part[2 * p + 1]);
+  }
+  float range = mx - mn;
+  if (!(range > 1e-12f)) range = 1e-12f;          // all points identical (or NaN -> propagates through h)
+  const float h = (mx - mn == mx - mn) ? range / (float)(G - 5) : (mx - mn);
+  gp[0] = mn - 2.0f * h;                          // data lie in [g_2, g_{G-3}]: every 4-tap stencil is interior
+  gp[1] = h;
+  gp[2] = 1.0f / h;
+  gp[3] = 0.f;
+}
+
+// hist[j][m][T] += sum_i w_k(z_ij) V[i][t]   for m = idx0+k.  LDS-privatised per workgroup, then global float atomics.
+template <int TT>
+__global__ __launch_bounds__(256) void ski_scatter2_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
+                                                           const float *__restrict__ V, float *__restrict__ hist,
+                                                           long long N, int ldz, int J, int G, int T, int HT, int hoff,
+                                                           int t0, int tcnt, long long pts_per_block) {
+  extern __shared__ float sh[];   // G * TT
+  const float g0 = gp[0], inv_h = gp[2];
+  const long long n0 = (long long)blockIdx.x * pts_per_block;
+  const long long n1 = (n0 + pts_per_block < N) ? n0 + pts_per_block : N;
+  for (int j = 0; j < J; ++j) {
+    for (int e = threadIdx.x; e < G * TT; e += 256) sh[e] = 0.f;
+    __syncthreads();
+    for (long long i = n0 + threadIdx.x; i < n1; i += 256) {
+      float w[4], dw[4];
+      const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+      float v[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) v[t] = t < tcnt ? V[i * T + t0 + t] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+          if (t < tcnt) atomicAdd(&sh[(idx0 + k) * TT + t], w[k] * v[t]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < G * TT; e += 256) {
+      const int m = e / TT, t = e % TT;
+      const float val = sh[e];
+      if (t < tcnt && val != 0.f) atomicAdd(&hist[((size_t)j * G + m) * HT + hoff + t0 + t], val);
+    }
+    __syncthreads();
+  }
+}
+
+// H[j][m][t] = sum_m' exp(-0.5 ((m - m') h)^2) hist[j][m'][t]
+__global__ __launch_bounds__(256) void ski_toeplitz_kernel(const float *__restrict__ hist, const float *__restrict__ gp,
+                                                           float *__restrict__ H, int G, int T) {
+  extern __shared__ float sc[];   // G toeplitz coefficients
+  const float hs = gp[1] * kExp2Scale;
+  for (int k = threadIdx.x; k < G; k += 256) {
+    const float d = (float)k * hs;
+    sc[k] = fast_exp2(-(d * d));
+  }
+  __syncthreads();
+  const int j = blockIdx.y;
+  // thread -> (m, t): 256 threads cover (256 / Tp) rows x Tp columns, Tp = T rounded up to a power of two <= 16
+  int Tp = 1;
+  while (Tp < T && Tp < 16) Tp <<= 1;
+  const int rows_per_block = 256 / Tp;
+  const int m = blockIdx.x * rows_per_block + threadIdx.x / Tp;
+  if (m >= G) return;
+  for (int t = threadIdx.x % Tp; t < T; t += Tp) {
+    const float *hj = hist + (size_t)j * G * T + t;
+    float acc = 0.f;
+    for (int mp = 0; mp < G; ++mp) {
+      const int k = m > mp ? m - mp : mp - m;
+      acc = __builtin_fmaf(sc[k], hj[(size_t)mp * T], acc);
+    }
+    H[((size_t)j * G + m) * T + t] = acc;
+  }
+}
+
+// out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0+k][t] + noise * V[i][t]
+template <int TT>
+__global__ __launch_bounds__(256) void ski_gather_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
+                                                         const float *__restrict__ H, const float *__restrict__ V,
+                                                         float *__restrict__ out, long long M, int ldz, int J, int G,
+                                                         int T, int t0, int tcnt, float scale, float noise) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const float g0 = gp[0], inv_h = gp[2];
+  float acc[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+  for (int j = 0; j < J; ++j) {
+    float w[4], dw[4];
+    const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float *hp = H + ((size_t)j * G + idx0 + k) * T + t0;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+        if (t < tcnt) acc[t] = __builtin_fmaf(w[k], hp[t], acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+    if (t < tcnt) {
+      float r = scale * acc[t];
+      if (noise != 0.f) r = __builtin_fmaf(noise, V[i * T + t0 + t], r);
+      out[i * T + t0 + t] = r;
+    }
+}
+
+// ---- wide right-hand sides (T > 12: predictive covariance blocks, dense evaluation): lane = column t, so every
+// histogram update / read is a 256-byte contiguous wave access (the efficient shape for float atomics) ------------
+__global__ __launch_bounds__(256) void ski_scatter_wide_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
+                                                               const float *__restrict__ V, float *__restrict__ hist,
+                                                               long long N, int ldz, int J, int G, int T, int HT,
+                                                               int hoff, long long pts_per_block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.y * 64 + lane;
+  const float g0 = gp[0], inv_h = gp[2];
+  const long long n0 = (long long)blockIdx.x * pts_per_block;
+  const long long n1 = (n0 + pts_per_block < N) ? n0 + pts_per_block : N;
+  if (t >= T) return;
+  for (long long i = n0 + wave; i < n1; i += 4) {
+    const float v = V[i * T + t];
+    for (int j = 0; j < J; ++j) {
+      float w[4], dw[4];
+      const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(&hist[((size_t)j * G + idx0 + k) * HT + hoff + t], w[k] * v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ski_toeplitz_wide_kernel(const float *__restrict__ hist,
+                                                                const float *__restrict__ gp, float *__restrict__ H,
+                                                                int G, int T) {
+  extern __shared__ float sc[];   // G toeplitz coefficients
+  const float hs = gp[1] * kExp2Scale;
+  for (int k = threadIdx.x; k < G; k += 256) {
+    const float d = (float)k * hs;
+    sc[k] = fast_exp2(-(d * d));
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  const int j = blockIdx.z;
+  const int m0 = (blockIdx.y * 4 + wave) * 4;     // 4 rows per wave, 16 per block
+  if (t >= T || m0 >= G) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float *hj = hist + (size_t)j * G * T + t;
+  for (int mp = 0; mp < G; ++mp) {
+    const float hv = hj[(size_t)mp * T];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + r;
+      const int k = m > mp ? m - mp : mp - m;
+      acc[r] = __builtin_fmaf(sc[k < G ? k : G - 1], hv, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (m0 + r < G) H[((size_t)j * G + m0 + r) * T + t] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void ski_gather_wide_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
+                                                              const float *__restrict__ H, const float *__restrict__ V,
+                                                              float *__restrict__ out, long long M, int ldz, int J,
+                                                              int G, int T, float scale, float noise,
+                                                              long long pts_per_block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.y * 64 + lane;
+  const float g0 = gp[0], inv_h = gp[2];
+  const long long n0 = (long long)blockIdx.x * pts_per_block;
+  const long long n1 = (n0 + pts_per_block < M) ? n0 + pts_per_block : M;
+  if (t >= T) return;
+  for (long long i = n0 + wave; i < n1; i += 4) {
+    float acc = 0.f;
+    for (int j = 0; j < J; ++j) {
+      float w[4], dw[4];
+      const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(w[k], H[((size_t)j * G + idx0 + k) * T + t], acc);
+    }
+    float r = scale * acc;
+    if (noise != 0.f) r = __builtin_fmaf(noise, V[i * T + t], r);
+    out[i * T + t] = r;
+  }
+}
+
+// Derivative gather.  H holds Toeplitz-smoothed histograms of the 2T columns [L | R]:
+//   gZ[i][j] = scale * sum_k dw_k(z_ij) * sum_t ( L[i,t] H_R[j][idx+k][t] + R[i,t] H_L[j][idx+k][t] )
+//   rowS[i]  = sum_t L[i,t] * sum_j sum_k w_k H_R[j][idx+k][t]          (= L[i,:] . (K R)[i,:] / scale)
+template <int TT>
+__global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
+                                                              const float *__restrict__ H, const float *__restrict__ L,
+                                                              const float *__restrict__ Rm, float *__restrict__ gZ,
+                                                              float *__restrict__ rowS, long long N, int ldz, int ldg,
+                                                              int J, int G, int T, float scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float g0 = gp[0], inv_h = gp[2];
+  float li[TT], ri[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    li[t] = t < T ? L[i * T + t] : 0.f;
+    ri[t] = t < T ? Rm[i * T + t] : 0.f;
+  }
+  float accS = 0.f;
+  const int T2 = 2 * T;
+  for (int j = 0; j < J; ++j) {
+    float w[4], dw[4];
+    const int idx0 = ski_taps<true>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+    float gz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float *hp = H + ((size_t)j * G + idx0 + k) * T2;   // [H_L (T) | H_R (T)]
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+        if (t < T) {
+          a = __builtin_fmaf(li[t], hp[T + t], a);      // L . H_R
+          b = __builtin_fmaf(ri[t], hp[t], b);          // R . H_L
+        }
+      gz = __builtin_fmaf(dw[k], a + b, gz);
+      accS = __builtin_fmaf(w[k], a, accS);
+    }
+    gZ[i * ldg + j] = scale * gz;
+  }
+  rowS[i] = accS;
+}
+
+// diag[i] = scale * sum_j sum_{k,k'} w_k w_k' exp(-0.5 ((k-k') h)^2)
+__global__ __launch_bounds__(256) void ski_diag_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
+                                                       float *__restrict__ diag, long long N, int ldz, int J, int G,
+                                                       float scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float g0 = gp[0], inv_h = gp[2], hs = gp[1] * kExp2Scale;
+  float c[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const float d = (float)k * hs; c[k] = fast_exp2(-(d * d)); }
+  float acc = 0.f;
+  for (int j = 0; j < J; ++j) {
+    float w[4], dw[4];
+    ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_fmaf(w[k] * w[kk], c[k > kk ? k - kk : kk - k], acc);
+  }
+  diag[i] = scale * acc;
+}
+
 // ------------------------------- host-side helpers -------------------------------------------
 
 int g_rotdir = 0;  // +1: wave_rotate1 delivers lane l+1's value to lane l; -1: lane l-1's.  0 = not probed.
@@ -1385,6 +1706,194 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
         hipLaunchKernelGGL((dense_mvm_kernel<12>), grid, block, 0, st, Kd, V, out, (int)N, (long long)ldk, T, t0, noise);
     }
   }
+  return launch_status();
+}
+
+}  // extern "C"
+
+// ------------------------------------ SKI entry points ----------------------------------------
+namespace {
+inline int ski_tpiece(int remaining) { return remaining > 4 ? 12 : (remaining > 1 ? 4 : 1); }
+constexpr int kSkiMaxParts = 512;
+
+template <int TT>
+int ski_launch_scatter(const float *Z, const float *gp, const float *V, float *hist, long long N, int ldz, int J, int G,
+                       int T, int t0, int tcnt, hipStream_t st) {
+  long long nblk = (N + 4095) / 4096;
+  if (nblk > 1024) nblk = 1024;
+  if (nblk < 1) nblk = 1;
+  const long long ppb = (N + nblk - 1) / nblk;
+  hipLaunchKernelGGL((ski_scatter2_kernel<TT>), dim3((unsigned)nblk), dim3(256), (size_t)G * TT * sizeof(float), st, Z,
+                     gp, V, hist, N, ldz, J, G, T, T, 0, t0, tcnt, ppb);
+  return launch_status();
+}
+
+int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist, long long N, int ldz, int J, int G,
+                    int T, hipStream_t st) {
+  RPGP_CHECK(hipMemsetAsync(hist, 0, (size_t)J * G * T * sizeof(float), st));
+  if (T > 12) {
+    long long nblk = (N + 255) / 256;
+    if (nblk > 2048) nblk = 2048;
+    const long long ppb = (N + nblk - 1) / nblk;
+    hipLaunchKernelGGL(ski_scatter_wide_kernel, dim3((unsigned)nblk, (unsigned)((T + 63) / 64)), dim3(256), 0, st, Z,
+                       gp, V, hist, N, ldz, J, G, T, T, 0, ppb);
+    return launch_status();
+  }
+  for (int t0 = 0; t0 < T;) {
+    const int tt = ski_tpiece(T - t0);
+    const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+    int rc;
+    if (tt == 1) rc = ski_launch_scatter<1>(Z, gp, V, hist, N, ldz, J, G, T, t0, tcnt, st);
+    else if (tt == 4) rc = ski_launch_scatter<4>(Z, gp, V, hist, N, ldz, J, G, T, t0, tcnt, st);
+    else rc = ski_launch_scatter<12>(Z, gp, V, hist, N, ldz, J, G, T, t0, tcnt, st);
+    if (rc) return rc;
+    t0 += tcnt;
+  }
+  return 0;
+}
+
+int ski_toeplitz(const float *hist, const float *gp, float *H, int J, int G, int T, hipStream_t st) {
+  if (T > 24) {
+    dim3 grid((T + 63) / 64, (G + 15) / 16, J);
+    hipLaunchKernelGGL(ski_toeplitz_wide_kernel, grid, dim3(256), (size_t)G * sizeof(float), st, hist, gp, H, G, T);
+    return launch_status();
+  }
+  int Tp = 1;
+  while (Tp < T && Tp < 16) Tp <<= 1;
+  const int rows_per_block = 256 / Tp;
+  dim3 grid((G + rows_per_block - 1) / rows_per_block, J);
+  hipLaunchKernelGGL(ski_toeplitz_kernel, grid, dim3(256), (size_t)G * sizeof(float), st, hist, gp, H, G, T);
+  return launch_status();
+}
+
+int ski_gather_all(const float *Z, const float *gp, const float *H, const float *V, float *out, long long M, int ldz,
+                   int J, int G, int T, float scale, float noise, hipStream_t st) {
+  if (T > 12) {
+    long long nblk = (M + 255) / 256;
+    if (nblk > 2048) nblk = 2048;
+    const long long ppb = (M + nblk - 1) / nblk;
+    hipLaunchKernelGGL(ski_gather_wide_kernel, dim3((unsigned)nblk, (unsigned)((T + 63) / 64)), dim3(256), 0, st, Z, gp,
+                       H, V, out, M, ldz, J, G, T, scale, noise, ppb);
+    return launch_status();
+  }
+  const unsigned nb = (unsigned)((M + 255) / 256);
+  for (int t0 = 0; t0 < T;) {
+    const int tt = ski_tpiece(T - t0);
+    const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+    if (tt == 1)
+      hipLaunchKernelGGL((ski_gather_kernel<1>), dim3(nb), dim3(256), 0, st, Z, gp, H, V, out, M, ldz, J, G, T, t0, tcnt, scale, noise);
+    else if (tt == 4)
+      hipLaunchKernelGGL((ski_gather_kernel<4>), dim3(nb), dim3(256), 0, st, Z, gp, H, V, out, M, ldz, J, G, T, t0, tcnt, scale, noise);
+    else
+      hipLaunchKernelGGL((ski_gather_kernel<12>), dim3(nb), dim3(256), 0, st, Z, gp, H, V, out, M, ldz, J, G, T, t0, tcnt, scale, noise);
+    int rc = launch_status();
+    if (rc) return rc;
+    t0 += tcnt;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+size_t rpgp_ski_workspace_bytes(int J, int G, int T) {
+  if (J <= 0 || G <= 0 || T <= 0) return 0;
+  // hist + H for up to 2T columns (the derivative uses [L | R]) + min/max partials
+  return (2 * (size_t)J * G * (2 * T) + 2 * kSkiMaxParts) * sizeof(float);
+}
+
+int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t N2, int ld2, int J, int G,
+                  float *grid_params, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!Z1 || N1 <= 0 || J <= 0 || G < 8 || !grid_params || ld1 < J || (Z2 && (N2 <= 0 || ld2 < J))) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < 2 * kSkiMaxParts * sizeof(float)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  float *part = reinterpret_cast<float *>(workspace);
+  const long long n2 = Z2 ? N2 : 0;
+  const long long total = (N1 + n2) * J;
+  int nblk = (int)((total + 4095) / 4096);
+  if (nblk > kSkiMaxParts) nblk = kSkiMaxParts;
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(ski_minmax_kernel, dim3(nblk), dim3(256), 0, st, Z1, (long long)N1, ld1, Z2 ? Z2 : Z1, n2,
+                     Z2 ? ld2 : ld1, J, part);
+  hipLaunchKernelGGL(ski_grid_finish_kernel, dim3(1), dim3(64), 0, st, part, nblk, G, grid_params);
+  return launch_status();
+}
+
+int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, const float *V, float *out, int64_t M,
+                 int64_t N, int ldz1, int ldz2, int J, int G, int T, float scale, float noise, void *workspace,
+                 size_t workspace_bytes, void *stream) {
+  if (!Z1 || !Z2 || !grid_params || !V || !out || M <= 0 || N <= 0 || J <= 0 || G < 8 || T <= 0 || ldz1 < J ||
+      ldz2 < J)
+    return RPGP_EINVAL;
+  if ((size_t)G * 12 * sizeof(float) > 64 * 1024) return RPGP_EINVAL;   // LDS histogram: G <= 1365
+  if (noise != 0.f && (M != N)) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  float *hist = reinterpret_cast<float *>(workspace);
+  float *H = hist + (size_t)J * G * (2 * T);
+  int rc = ski_scatter_all(Z2, grid_params, V, hist, N, ldz2, J, G, T, st);
+  if (rc) return rc;
+  rc = ski_toeplitz(hist, grid_params, H, J, G, T, st);
+  if (rc) return rc;
+  return ski_gather_all(Z1, grid_params, H, V, out, M, ldz1, J, G, T, scale, noise, st);
+}
+
+int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t N, int ldz, int J, int G, float scale,
+                  void *stream) {
+  if (!Z || !grid_params || !diag || N <= 0 || J <= 0 || G < 8 || ldz < J) return RPGP_EINVAL;
+  hipLaunchKernelGGL(ski_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), Z,
+                     grid_params, diag, (long long)N, ldz, J, G, scale);
+  return launch_status();
+}
+
+int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
+                           float *gscale, int64_t N, int ldz, int ldg, int J, int G, int T, float scale,
+                           void *workspace, size_t workspace_bytes, float *row_scratch, void *stream) {
+  if (!Z || !grid_params || !L || !R || !gZ || !gscale || !row_scratch || N <= 0 || J <= 0 || G < 8 || T <= 0 ||
+      T > 12 || ldz < J || ldg < J)
+    return RPGP_EINVAL;
+  if ((size_t)G * 12 * sizeof(float) > 64 * 1024) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int T2 = 2 * T;
+  float *hist = reinterpret_cast<float *>(workspace);
+  float *H = hist + (size_t)J * G * T2;
+  // scatter the 2T columns [L | R]: two passes writing into column offsets 0 and T of a [J][G][2T] histogram
+  RPGP_CHECK(hipMemsetAsync(hist, 0, (size_t)J * G * T2 * sizeof(float), st));
+  for (int half = 0; half < 2; ++half) {
+    const float *Vh = half == 0 ? L : R;
+    // the scatter kernel addresses V with row stride T and hist with row stride `T` argument: use a strided view by
+    // passing hist + half*T and stride T2 through the generic kernel's T parameter for hist only -> dedicated launch
+    long long nblk = (N + 4095) / 4096;
+    if (nblk > 1024) nblk = 1024;
+    const long long ppb = (N + nblk - 1) / nblk;
+    for (int t0 = 0; t0 < T;) {
+      const int tt = ski_tpiece(T - t0);
+      const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+      // V has stride T; hist has stride T2 and column offset half*T: handled by ski_scatter2_kernel
+      if (tt == 1)
+        hipLaunchKernelGGL((ski_scatter2_kernel<1>), dim3((unsigned)nblk), dim3(256), (size_t)G * 1 * sizeof(float), st, Z, grid_params, Vh, hist, (long long)N, ldz, J, G, T, T2, half * T, t0, tcnt, ppb);
+      else if (tt == 4)
+        hipLaunchKernelGGL((ski_scatter2_kernel<4>), dim3((unsigned)nblk), dim3(256), (size_t)G * 4 * sizeof(float), st, Z, grid_params, Vh, hist, (long long)N, ldz, J, G, T, T2, half * T, t0, tcnt, ppb);
+      else
+        hipLaunchKernelGGL((ski_scatter2_kernel<12>), dim3((unsigned)nblk), dim3(256), (size_t)G * 12 * sizeof(float), st, Z, grid_params, Vh, hist, (long long)N, ldz, J, G, T, T2, half * T, t0, tcnt, ppb);
+      int rc = launch_status();
+      if (rc) return rc;
+      t0 += tcnt;
+    }
+  }
+  int rc = ski_toeplitz(hist, grid_params, H, J, G, T2, st);
+  if (rc) return rc;
+  const unsigned nb = (unsigned)((N + 255) / 256);
+  if (T <= 1)
+    hipLaunchKernelGGL((ski_grad_gather_kernel<1>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale);
+  else if (T <= 4)
+    hipLaunchKernelGGL((ski_grad_gather_kernel<4>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale);
+  else
+    hipLaunchKernelGGL((ski_grad_gather_kernel<12>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale);
+  rc = launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, st, row_scratch, gscale, (int)N, 1.0f);
   return launch_status();
 }
 

@@ -11,7 +11,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import backend as _backend
-from .operators import AdditiveRPOperator
+from .operators import AdditiveRPOperator, SKIAdditiveOperator
 
 
 def inv_softplus(y):
@@ -80,17 +80,26 @@ class AdditiveStructureRBFKernel(Kernel):
     Its parameters (inner lengthscale 1, outputscale 1/J) are frozen by the wrapper
     (scaled_projection_kernel.py:15-17), so they are plain buffers here."""
 
-    def __init__(self, num_dims, weight=None, inner_lengthscale=1.0):
+    def __init__(self, num_dims, weight=None, inner_lengthscale=1.0, ski=False, ski_options=None):
         super().__init__()
         self.num_dims = num_dims
         self.register_buffer("weight", torch.tensor(1.0 / num_dims if weight is None else float(weight)))
         self.register_buffer("inner_lengthscale", torch.tensor(float(inner_lengthscale)))
+        # `GridInterpolationKernel(kernel, **ski_options)` wrap of training_routines.py:157-158
+        self.ski = bool(ski)
+        opts = dict(ski_options or {})
+        if self.ski and opts.get("num_dims", 1) != 1:
+            raise ValueError("only 1-D grid interpolation per projection is supported (ski_options.num_dims == 1)")
+        self.grid_size = int(opts.get("grid_size", 1024))
 
     def operator(self, Z1, Z2, outputscale=None, shard=None):
         il = float(self.inner_lengthscale)
         if il != 1.0:
             Z1 = Z1 / il
             Z2 = None if Z2 is None else Z2 / il
+        if self.ski:
+            return SKIAdditiveOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight),
+                                       grid_size=self.grid_size)
         return AdditiveRPOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight), shard=shard)
 
     def forward(self, z1, z2, **params):

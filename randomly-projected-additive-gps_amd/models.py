@@ -51,12 +51,15 @@ class PredictionStrategy:
         if self.dense_path:
             return torch.cholesky_solve(B, self.chol)
         khat = self.khat
-        if B.shape[1] > 12 and not isinstance(khat, DenseOperator):
-            # wide right-hand sides (predictive covariance, T = N_test): materialise K once so every CG iteration is
-            # a library GEMM on the matrix cores instead of N_test/12 fused sweeps
+        if B.shape[1] > 12 and type(self.op) is AdditiveRPOperator and not isinstance(khat, DenseOperator):
+            # wide right-hand sides (predictive covariance, T = N_test) on the exact fused operator: materialise K once
+            # so every CG iteration is a library GEMM on the matrix cores instead of N_test/12 fused sweeps
             N = B.shape[0]
-            if 4.0 * N * N <= 0.25 * torch.cuda.get_device_properties(B.device).total_memory if B.is_cuda else True:
-                khat = DenseOperator(self.op.to_dense(), float(self.noise))
+            fits = (4.0 * N * N <= 0.25 * torch.cuda.get_device_properties(B.device).total_memory) if B.is_cuda else True
+            if fits:
+                if getattr(self, "_dense_khat", None) is None:
+                    self._dense_khat = DenseOperator(self.op.to_dense(), float(self.noise))
+                khat = self._dense_khat
         return linear_cg(khat._matmul, B, tolerance=settings.eval_cg_tolerance.value(),
                          max_iter=settings.max_cg_iterations.value(), preconditioner=getattr(self, "pre", None))
 
@@ -67,10 +70,37 @@ class PredictionStrategy:
             mean = cross._matmul(self.alpha).reshape(-1) + model.mean_module(xs)
             if settings.skip_posterior_variances.on():
                 return MultivariateNormal(mean, torch.zeros_like(mean), diagonal_only=True)
-            Kxs = cross._transpose_nonbatch().to_dense()            # N x N*
-            sol = self.solve(Kxs)                                   # Khat^-1 K(X, X*)
-            Kss = model.covar_module(xs).to_dense()
-            cov = Kss - Kxs.t() @ sol
+            # Sigma* = K** - K*x Khat^-1 Kx*.  With an iterative solve S ~= Khat^-1 Kx* the plain product K*x S is
+            # neither symmetric nor bounded by the exact quadratic form; the variational form
+            #     Kx*^T Khat^-1 Kx*  >=  2 Kx*^T S - S^T Khat S          (equality at the exact solve)
+            # is symmetric and keeps Sigma* positive semi-definite for ANY S (slightly conservative variances at loose
+            # CG tolerances; the plain product has a FIRST-order error amplified by ||K|| / sigma^2).  The solves run in
+            # column blocks of test points; S and Khat S are kept (2 x N x N* floats).
+            n_train, n_test = model.train_inputs.shape[0], xs.shape[0]
+            cov = model.covar_module(xs).to_dense()                 # K(X*, X*)
+            budget = 1 << 28                                        # floats per N x c block of CG state (1 GiB)
+            c = max(32, min(n_test, budget // max(n_train, 1)))
+            if self.dense_path:
+                Kx = cross._get_rows(torch.arange(n_test, device=xs.device)).t().contiguous()   # K(X, X*)
+                cov -= Kx.t() @ torch.cholesky_solve(Kx, self.chol)
+            else:
+                khat = self.khat
+                total_mem = torch.cuda.get_device_properties(xs.device).total_memory if xs.is_cuda else float("inf")
+                if 8.0 * n_train * n_test > 0.35 * total_mem:
+                    raise RuntimeError("the full %d x %d predictive covariance needs two %d x %d work arrays (%.0f GB): "
+                                       "use --skip_posterior_variances" % (n_test, n_test, n_train, n_test,
+                                                                          8e-9 * n_train * n_test))
+                S = torch.empty(n_train, n_test, dtype=cov.dtype, device=cov.device)
+                KS = torch.empty_like(S)
+                BtS = torch.empty(n_test, n_test, dtype=cov.dtype, device=cov.device)
+                for c0 in range(0, n_test, c):
+                    idx = torch.arange(c0, min(c0 + c, n_test), device=xs.device)
+                    Kx_blk = cross._get_rows(idx).t().contiguous()      # K(X, X*[idx])  (N x c)
+                    sol = self.solve(Kx_blk)                            # ~ Khat^-1 K(X, X*[idx])
+                    S[:, idx] = sol
+                    KS[:, idx] = khat._matmul(sol)
+                    BtS[:, idx] = cross._matmul(sol)                    # K(X*, X) sol
+                cov -= BtS + BtS.t() - S.t() @ KS
             cov = 0.5 * (cov + cov.t())
         return MultivariateNormal(mean, cov)
 

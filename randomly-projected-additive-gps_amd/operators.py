@@ -206,6 +206,77 @@ class AdditiveRPOperator(LinearOperator):
         return gZ, gs * self.weight
 
 
+class SKIAdditiveOperator(AdditiveRPOperator):
+    """K ~= outputscale * weight * sum_j W_j Tm W_j^T  — the `ski=True` variant (training_routines.py:157-158;
+    SURVEY.md Appendix E): cubic interpolation of every projection onto one shared regular grid of `grid_size` points
+    and a Toeplitz RBF on the grid.  O(N) per MVM (scatter / Toeplitz / gather kernels); same protocol as the exact
+    operator so the whole solve stack is unchanged.  The grid is recomputed from the data range at construction
+    (once per hyper-parameter step) and is not differentiated (it is a buffer in GPyTorch as well)."""
+
+    def __init__(self, Z1, Z2=None, outputscale=None, weight=1.0, shard=None, grid_size=1024):
+        super().__init__(Z1, Z2, outputscale, weight, shard=None)     # SKI runs replicated (no J-sharding)
+        self.grid_size = int(grid_size)
+        be = _backend.get_backend()
+        self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size)
+
+    def _local_matmul(self, rhs, noise=0.0):
+        be = _backend.get_backend()
+        z1 = self.Z1.detach()
+        z2 = z1 if self.symmetric else self.Z2.detach()
+        return be.ski_mvm(z1, z2, self.gp, rhs, self._scale, noise if self.symmetric else 0.0, self.grid_size)
+
+    def _matmul(self, rhs, noise=0.0):
+        if noise and not self.symmetric:
+            raise ValueError("a diagonal can only be added to the square symmetric operator")
+        return self._local_matmul(rhs.detach(), noise)
+
+    def _transpose_nonbatch(self):
+        if self.symmetric:
+            return self
+        t = SKIAdditiveOperator.__new__(SKIAdditiveOperator)
+        AdditiveRPOperator.__init__(t, self.Z2, self.Z1, self.outputscale, self.weight, None)
+        t.grid_size, t.gp = self.grid_size, self.gp
+        return t
+
+    def _diagonal(self):
+        if not self.symmetric:
+            raise RuntimeError("diagonal of a rectangular cross-covariance requested")
+        return _backend.get_backend().ski_diag(self.Z1.detach(), self.gp, self._scale, self.grid_size)
+
+    def _get_rows(self, idx):
+        be = _backend.get_backend()
+        z1 = self.Z1.detach()
+        z2 = z1 if self.symmetric else self.Z2.detach()
+        k = idx.numel()
+        eye = torch.eye(k, dtype=self.dtype, device=self.device)
+        # K[idx, :] = (K(Z2, Z1[idx]))^T : interpolate the k selected points, gather at all columns
+        cols = be.ski_mvm(z2, z1.index_select(0, idx).contiguous(), self.gp, eye, self._scale, 0.0, self.grid_size)
+        return cols.t().contiguous()
+
+    def to_dense(self):
+        be = _backend.get_backend()
+        z1 = self.Z1.detach()
+        z2 = z1 if self.symmetric else self.Z2.detach()
+        eye = torch.eye(z2.shape[0], dtype=self.dtype, device=self.device)
+        return be.ski_mvm(z1, z2, self.gp, eye, self._scale, 0.0, self.grid_size)
+
+    evaluate = to_dense
+
+    def _bilinear_derivative(self, left_vecs, right_vecs):
+        if not self.symmetric:
+            raise NotImplementedError("derivatives are only needed for the train-train kernel")
+        gZ, gs = _backend.get_backend().ski_bilinear_grad(self.Z1.detach(), self.gp, left_vecs.detach(),
+                                                          right_vecs.detach(), self._scale, self.grid_size)
+        return gZ, gs * self.weight
+
+    _quad_form_derivative = _bilinear_derivative
+
+    def dense_weight_derivative(self, S):
+        """Gradients of 0.5*sum(S * self) for an explicit symmetric S: bilinear form with L = S/2, R = I."""
+        eye = torch.eye(S.shape[0], dtype=self.dtype, device=self.device)
+        return self._bilinear_derivative((0.5 * S).contiguous(), eye)
+
+
 class AddedDiagOperator(LinearOperator):
     """base + noise * I  (the likelihood's AddedDiagLazyTensor); the noise term is fused into the MVM kernel."""
 

@@ -253,3 +253,80 @@ def dense_mvm(Kd, V, noise=0.0):
         _lib.check(lib.rpgp_dense_mvm(Kd.data_ptr(), V2.data_ptr(), out.data_ptr(), N, Kd.shape[1], T, float(noise),
                                       _stream()), "rpgp_dense_mvm")
     return out.squeeze(1) if squeeze else out
+
+
+# ------------------------------------------------------------------------------------------------ SKI path
+
+def ski_grid(Z1, Z2=None, grid_size=1024):
+    """Device tensor [g0, h, 1/h, 0] of the shared 1-D interpolation grid covering Z1 (and Z2)."""
+    lib = _lib.load()
+    Z1 = _require(Z1, "Z1", 2)
+    N1, J = Z1.shape
+    gp = torch.empty(4, dtype=torch.float32, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, 1))
+        if Z2 is None:
+            rc = lib.rpgp_ski_grid(Z1.data_ptr(), N1, J, None, 0, 0, J, grid_size, gp.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), _stream())
+        else:
+            Z2 = _require(Z2, "Z2", 2)
+            rc = lib.rpgp_ski_grid(Z1.data_ptr(), N1, J, Z2.data_ptr(), Z2.shape[0], Z2.shape[1], J, grid_size,
+                                   gp.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        _lib.check(rc, "rpgp_ski_grid")
+    return gp
+
+
+def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
+    """out = scale * sum_j W1_j Tm W2_j^T V (+ noise V);  Z2 may be Z1 (square operator)."""
+    lib = _lib.load()
+    Z1 = _require(Z1, "Z1", 2)
+    Z2 = _require(Z2, "Z2", 2)
+    M, J = Z1.shape
+    N = Z2.shape[0]
+    V2, squeeze = _as_matrix(V, N, "V")
+    T = V2.shape[1]
+    out = torch.empty((M, T), dtype=torch.float32, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
+        _lib.check(lib.rpgp_ski_mvm(Z1.data_ptr(), Z2.data_ptr(), gp.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N,
+                                    J, J, J, grid_size, T, float(scale), float(noise), ws.data_ptr(), ws.numel(),
+                                    _stream()), "rpgp_ski_mvm")
+    return out.squeeze(1) if squeeze else out
+
+
+def ski_diag(Z, gp, scale, grid_size=1024):
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    N, J = Z.shape
+    out = torch.empty(N, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        _lib.check(lib.rpgp_ski_diag(Z.data_ptr(), gp.data_ptr(), out.data_ptr(), N, J, J, grid_size, float(scale),
+                                     _stream()), "rpgp_ski_diag")
+    return out
+
+
+def ski_bilinear_grad(Z, gp, L, R, scale, grid_size=1024):
+    """(gZ, gscale) of sum((L R^T) * K_ski(Z,Z)); wide blocks are processed 12 columns at a time."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    N, J = Z.shape
+    L2, _ = _as_matrix(L, N, "L")
+    R2, _ = _as_matrix(R, N, "R")
+    T = L2.shape[1]
+    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
+    gs = torch.zeros((), dtype=torch.float32, device=Z.device)
+    scratch = torch.empty(N, dtype=torch.float32, device=Z.device)
+    gZp = torch.empty_like(gZ)
+    gsp = torch.empty_like(gs)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, min(T, 12)))
+        for t0 in range(0, T, 12):
+            Lc = L2[:, t0:t0 + 12].contiguous()
+            Rc = R2[:, t0:t0 + 12].contiguous()
+            _lib.check(lib.rpgp_ski_bilinear_grad(Z.data_ptr(), gp.data_ptr(), Lc.data_ptr(), Rc.data_ptr(),
+                                                  gZp.data_ptr(), gsp.data_ptr(), N, J, J, J, grid_size, Lc.shape[1],
+                                                  float(scale), ws.data_ptr(), ws.numel(), scratch.data_ptr(),
+                                                  _stream()), "rpgp_ski_bilinear_grad")
+            gZ += gZp
+            gs += gsp
+    return gZ, gs

@@ -43,8 +43,9 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
                               init_lengthscale_range=(1., 1.), ski=False, ski_options=None, proj_dist="gaussian",
                               batch_kernel=True, mem_efficient=False, k=1, keops=False):
     """Additive randomly-projected kernel (RPA-GP; DPA-GP when `space_proj`).  Same options and validation errors as
-    training_routines.py:131-189.  Sub-kernels other than 1-D RBF, k > 1 and SKI are outside the MI355X hot path
-     and raise NotImplementedError."""
+    training_routines.py:131-189.  `ski=True` selects the 1-D grid-interpolation operator.
+    Sub-kernels other than 1-D RBF and k > 1 are outside the MI355X hot path and raise
+    NotImplementedError."""
     if k > 1 and (mem_efficient or batch_kernel or space_proj):
         raise ValueError("Can't have k > 1 with memory efficient GAM kernel or a batch kernel or spaced projections.")
     if mem_efficient:
@@ -60,8 +61,6 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
         raise NotImplementedError("only 1-D RBF sub-kernels are implemented on the fused MI355X path (SURVEY.md §8(f))")
     if k != 1:
         raise NotImplementedError("k > 1 sub-kernels are not implemented on the fused MI355X path (SURVEY.md §8(f))")
-    if ski:
-        raise NotImplementedError("the SKI grid-interpolation path is the next row of SURVEY.md §8(f), not built yet")
     if keops:
         warnings.warn("keops=True is ignored: the fused HIP kernel already is the matrix-free path")
 
@@ -78,7 +77,7 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
     else:
         # batch_kernel (AdditiveStructureKernel) and the per-dimension AdditiveKernel variant are the same function:
         # (1/J) sum_j RBF_1(z_j)  (training_routines.py:169-174)
-        add_kernel = AdditiveStructureRBFKernel(J)
+        add_kernel = AdditiveStructureRBFKernel(J, ski=ski, ski_options=ski_options)
     if ard:
         ard_num_dims = d if prescale else J * k
         initial_ls = _sample_from_range(ard_num_dims, init_lengthscale_range)
@@ -106,7 +105,8 @@ def create_full_kernel(d, ard=False, ski=False, grid_size=None, kernel_type="RBF
 
 def create_exact_gp(trainX, trainY, kind, devices=("cpu",), **kwargs):
     """Create an exact GP model with a specified kernel (training_routines.py:325-410).
-    More than one device means J-sharding over the ranks of the default torch.distributed process group."""
+    More than one device means J-sharding over the ranks of the default torch.distributed process group
+    (the SKI variant runs replicated: its MVM is O(N) and latency-bound)."""
     [n, d] = trainX.shape
     if kind not in EXACT_GP_KINDS + REFERENCE_ONLY_KINDS:
         raise ValueError("Unknown kernel structure type {}".format(kind))

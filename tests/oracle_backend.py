@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 from oracle import dense_gp as orc
+from oracle import ski as sko
 
 
 def _np(t):
@@ -73,3 +74,52 @@ class OracleBackend:
         v = _np(V).reshape(Kd.shape[0], -1)
         r = _t(_np(Kd) @ v + noise * v, V)
         return r.squeeze(1) if squeeze else r
+
+    # ---- SKI path -------------------------------------------------------------------------------------------
+    def ski_grid(self, Z1, Z2=None, grid_size=1024):
+        g0, h = sko.grid_params(_np(Z1), None if Z2 is None else _np(Z2), grid_size)
+        return torch.tensor([g0, h, 1.0 / h, 0.0], dtype=Z1.dtype)
+
+    def _grid(self, gp):
+        g = gp.double()
+        return float(g[0]), float(g[1])
+
+    def ski_mvm(self, Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
+        squeeze = V.dim() == 1
+        v = _np(V).reshape(Z2.shape[0], -1)
+        K = sko.dense_kernel(_np(Z1), _np(Z2), scale, grid_size, self._grid(gp))
+        out = K @ v
+        if noise:
+            out = out + noise * v
+        r = _t(out, V)
+        return r.squeeze(1) if squeeze else r
+
+    def ski_diag(self, Z, gp, scale, grid_size=1024):
+        return _t(np.diag(sko.dense_kernel(_np(Z), _np(Z), scale, grid_size, self._grid(gp))).copy(), Z)
+
+    def ski_bilinear_grad(self, Z, gp, L, R, scale, grid_size=1024):
+        """Analytic derivative of sum((L R^T) * K_ski) in float64 (same formulas as the HIP kernel, dense)."""
+        z = _np(Z)
+        Ld, Rd = _np(L).reshape(z.shape[0], -1), _np(R).reshape(z.shape[0], -1)
+        g0, h = self._grid(gp)
+        G = grid_size
+        Tm = sko.toeplitz(h, G)
+        gZ = np.zeros_like(z)
+        gs = 0.0
+        for j in range(z.shape[1]):
+            u = np.clip((z[:, j] - g0) / h, 1.0, G - 2.0)
+            fl = np.floor(u)
+            fr = u - fl
+            idx0 = np.clip(fl.astype(np.int64) - 1, 0, G - 4)
+            W = sko.interp_matrix(z[:, j], g0, h, G)
+            HR = Tm @ (W.T @ Rd)
+            HL = Tm @ (W.T @ Ld)
+            gs += (Ld * (W @ HR)).sum()
+            s = [fr + 1.0, fr, 1.0 - fr, 2.0 - fr]
+            sign = [1.0, 1.0, -1.0, -1.0]
+            for k in range(4):
+                U = s[k]
+                d = np.where(U < 1.0, (4.5 * U - 5.0) * U, (-1.5 * U + 5.0) * U - 4.0) * sign[k] / h
+                rows = idx0 + k
+                gZ[:, j] += scale * d * ((Ld * HR[rows]).sum(1) + (Rd * HL[rows]).sum(1))
+        return _t(gZ, Z), _t(np.array(gs), Z)

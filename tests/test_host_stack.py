@@ -316,3 +316,54 @@ def test_kernel_factory_validation_errors():
     k = create_additive_rp_kernel(6, 4, ard=False)
     assert k.raw_lengthscale.shape == (1, 1)
     assert not k.projection_module.weight.requires_grad
+
+
+def test_ski_model_matches_dense_ski_oracle(oracle_backend):
+    """`ski: true` spec path end to end on the host stack: MLL (Cholesky and CG regimes) against a dense float64
+    evaluation of the same SKI kernel, and closeness to the exact-kernel MLL."""
+    from rpgp_amd import settings
+    from rpgp_amd.kernels import AdditiveStructureRBFKernel, ScaledProjectionKernel, ScaleKernel
+    from rpgp_amd.likelihoods import GaussianLikelihood, SmoothedBoxPrior
+    from rpgp_amd.models import ExactGPModel, ExactMarginalLogLikelihood
+    from oracle import ski as sko
+    X, y, P, ls, noise, s = _problem(N=150, d=3, J=3, seed=21)
+    lin = torch.nn.Linear(3, 3, bias=False)
+    lin.weight.data = P.t().contiguous()
+    k = ScaledProjectionKernel(lin, AdditiveStructureRBFKernel(3, ski=True, ski_options={"grid_size": 256, "num_dims": 1}),
+                               prescale=True, ard_num_dims=3)
+    k.initialize(lengthscale=ls)
+    sk = ScaleKernel(k)
+    sk.outputscale = s
+    lik = GaussianLikelihood(noise_prior=SmoothedBoxPrior(1e-4, 10, sigma=0.01))
+    lik.noise = noise
+    model = ExactGPModel(X, y, lik, sk)
+    mll = ExactMarginalLogLikelihood(lik, model)
+    model.train()
+    val = mll(model(X), y)
+    val.backward()
+    Z = orc.project(X.numpy(), P.numpy(), ls.numpy())
+    Kd = sko.dense_kernel(Z, Z, s / 3, 256) + noise * np.eye(150)
+    r = y.numpy().astype(np.float64)
+    ref = (-0.5 * r @ np.linalg.solve(Kd, r) - 0.5 * np.linalg.slogdet(Kd)[1] - 75 * math.log(2 * math.pi)
+           + orc.smoothed_box_log_prob(noise)) / 150
+    assert abs(val.item() - ref) < 1e-4 * abs(ref)
+    exact = orc.DenseExactGP(X.numpy(), y.numpy(), P.numpy(), ls.numpy(), s, noise).mll()
+    assert abs(val.item() - exact) < 1e-3 * abs(exact)
+    assert model.covar_module.base_kernel.raw_lengthscale.grad is not None
+    g_chol = model.covar_module.base_kernel.raw_lengthscale.grad.clone()
+    model.zero_grad()
+    with settings.max_cholesky_size(0), settings.cg_tolerance(1e-7), settings.num_trace_samples(80), \
+            settings.max_lanczos_quadrature_iterations(60), settings.deterministic_probes(True):
+        v2 = mll(model(X), y)
+        v2.backward()
+    assert abs(v2.item() - ref) < 0.03 * abs(ref)
+    g_cg = model.covar_module.base_kernel.raw_lengthscale.grad
+    assert torch.allclose(g_cg, g_chol, rtol=0.3, atol=5e-3)
+    # predictions through the SKI cross operator
+    Xs = torch.randn(20, 3, generator=torch.Generator().manual_seed(3))
+    model.eval()
+    with torch.no_grad():
+        out = model(Xs)
+    ex_mean, ex_var = orc.DenseExactGP(X.numpy(), y.numpy(), P.numpy(), ls.numpy(), s, noise).predict(Xs.numpy())
+    np.testing.assert_allclose(out.mean.numpy(), ex_mean, rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(out.variance.numpy(), ex_var, rtol=2e-2, atol=1e-3)

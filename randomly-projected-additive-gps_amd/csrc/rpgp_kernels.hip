@@ -602,19 +602,42 @@ __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ Z1
 // ---------------------------------------------------------------------------------------------
 // Projection Z = X @ Peff and its backward dPeff = X^T @ G (thin GEMMs; plain VALU version).
 // ---------------------------------------------------------------------------------------------
+typedef float floatx4m __attribute__((ext_vector_type(4)));
+
+// Z = X @ Peff on the matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, MI355X_MICROARCH.md "FP32-input
+// MFMA").  One wave64 owns a 16-row stripe of Z and walks the column tiles; the K dimension (d) advances 4 per MFMA.
+//   A (16x4): lane l holds X[row0 + l%16][k0 + l/16]        B (4x16): lane l holds Peff[k0 + l/16][col0 + l%16]
+//   D (16x16): lane l holds Z[row0 + 4*(l/16) + r][col0 + l%16], r = 0..3
 __global__ __launch_bounds__(256) void project_kernel(const float *__restrict__ X, const float *__restrict__ Peff,
                                                       float *__restrict__ Z, long long N, int d, int J) {
-  extern __shared__ float sP[];  // d*J
-  for (int e = threadIdx.x; e < d * J; e += 256) sP[e] = Peff[e];
+  extern __shared__ float sP[];  // d4 x J16 zero-padded copy of Peff (d4 = d rounded up to 4, J16 = J rounded up to 16)
+  const int d4 = (d + 3) & ~3, J16 = (J + 15) & ~15;
+  for (int e = threadIdx.x; e < d4 * J16; e += 256) {
+    const int k = e / J16, j = e % J16;
+    sP[e] = (k < d && j < J) ? Peff[k * J + j] : 0.f;
+  }
   __syncthreads();
-  const long long total = N * J;
-  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-    const long long n = g / J;
-    const int j = (int)(g % J);
-    const float *x = X + n * d;
-    float acc = 0.f;
-    for (int k = 0; k < d; ++k) acc = __builtin_fmaf(x[k], sP[k * J + j], acc);
-    Z[g] = acc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const long long stripes = (N + 15) / 16;
+  for (long long sidx = (long long)blockIdx.x * 4 + wave; sidx < stripes; sidx += (long long)gridDim.x * 4) {
+    const long long row = sidx * 16 + m;
+    const bool rv = row < N;
+    for (int col0 = 0; col0 < J16; col0 += 16) {
+      floatx4m acc = {0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < d4; k0 += 4) {
+        const int k = k0 + q;
+        const float a = (rv && k < d) ? X[row * d + k] : 0.f;
+        const float b = sP[k * J16 + col0 + m];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long orow = sidx * 16 + 4 * q + r;
+        const int ocol = col0 + m;
+        if (orow < N && ocol < J) Z[orow * J + ocol] = acc[r];
+      }
+    }
   }
 }
 
@@ -1461,11 +1484,11 @@ int rpgp_profile_end(float *avg_ms_host, int *count_host) {
 }
 
 int rpgp_project(const float *X, const float *Peff, float *Z, int64_t N, int d, int J, void *stream) {
-  if (!X || !Peff || !Z || N <= 0 || d <= 0 || J <= 0 || (size_t)d * J * 4 > 64 * 1024) return RPGP_EINVAL;
-  const long long total = N * J;
-  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(project_kernel, dim3(blocks), dim3(256), (size_t)d * J * sizeof(float), as_stream(stream), X,
-                     Peff, Z, (long long)N, d, J);
+  if (!X || !Peff || !Z || N <= 0 || d <= 0 || J <= 0 || (size_t)(d + 3) * (J + 15) * 4 > 64 * 1024) return RPGP_EINVAL;
+  const long long stripes = (N + 15) / 16;
+  int blocks = (int)((stripes + 3) / 4 < 4096 ? (stripes + 3) / 4 : 4096);
+  const size_t lds = (size_t)((d + 3) & ~3) * ((J + 15) & ~15) * sizeof(float);
+  hipLaunchKernelGGL(project_kernel, dim3(blocks), dim3(256), lds, as_stream(stream), X, Peff, Z, (long long)N, d, J);
   return launch_status();
 }
 

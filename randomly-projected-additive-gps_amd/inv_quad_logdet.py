@@ -12,7 +12,7 @@ import torch
 
 from . import settings
 from .linear_cg import linear_cg
-from .operators import AddedDiagOperator
+from .operators import AddedDiagOperator, DenseOperator, SKIAdditiveOperator
 from .precond import build_preconditioner
 
 
@@ -94,7 +94,15 @@ class InvQuadLogDet(torch.autograd.Function):
         probe_norms = probes.norm(2, dim=0, keepdim=True)
         probes_n = probes / probe_norms
         full_rhs = torch.cat([probes_n, r], dim=1)
-        solves, t_mat = linear_cg(khat._matmul, full_rhs, n_tridiag=num_probes,
+        matmul = khat._matmul
+        if settings.cache_kernel.on() and not isinstance(op, SKIAdditiveOperator) and \
+                (op.shard is None or op.shard.world_size == 1):
+            # cached-K mode: materialise K once per hyper-parameter step (rpgp_dense) so each
+            # CG iteration on the T = 11 block is one HBM-bound library GEMM; the backward pass stays fused
+            total = torch.cuda.get_device_properties(Z.device).total_memory if Z.is_cuda else float("inf")
+            if 4.0 * N * N <= 0.25 * total:
+                matmul = DenseOperator(op.to_dense(), float(noise.detach()))._matmul
+        solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes,
                                   tolerance=settings.cg_tolerance.value(),
                                   max_iter=settings.max_cg_iterations.value(),
                                   max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),

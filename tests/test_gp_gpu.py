@@ -161,3 +161,20 @@ def test_full_size_properties_n50k(gpu_device):
     # rectangular kernel agrees with the symmetric one on the same points
     Kr = ops.mvm_rect(Z[:4096].contiguous(), Z, u, 1.0 / J) + 0.1 * u[:4096]
     assert float((Kr - Ku[:4096]).norm() / Ku[:4096].norm()) < 1e-5
+
+
+def test_cached_kernel_mode_matches_fused(gpu_device):
+    """settings.cache_kernel: K materialised once per step (rpgp_dense) + library GEMM per CG iteration gives the same
+    MLL and gradients as the fused path (same probes)."""
+    from rpgp_amd import settings
+    vals = []
+    for cached in (False, True):
+        prob, model, lik, mll = _gpu_model(gpu_device, 2500, 8, 20, 6, 0.3)
+        model.train()
+        with settings.cg_tolerance(1e-6), settings.deterministic_probes(True), settings.cache_kernel(cached):
+            v = mll(model(model.train_inputs), model.train_targets)
+            v.backward()
+        vals.append((v.item(), model.covar_module.base_kernel.raw_lengthscale.grad.cpu().clone(), lik.raw_noise.grad.item()))
+    assert abs(vals[0][0] - vals[1][0]) < 1e-5 * abs(vals[0][0])
+    assert torch.allclose(vals[0][1], vals[1][1], rtol=1e-3, atol=1e-6)
+    assert abs(vals[0][2] - vals[1][2]) < 1e-4 * abs(vals[0][2])

@@ -9,7 +9,7 @@ from rpgp_amd.training import create_exact_gp
 from rpgp_amd.models import ExactMarginalLogLikelihood
 
 
-def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol):
+def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol, ski=False, full_cov=True):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     X = torch.randn(N + ntest, d, generator=g)
@@ -18,11 +18,12 @@ def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol):
     Xtr, ytr, Xte, yte = X[:N].to(dev), y[:N].to(dev), X[N:].to(dev), y[N:].to(dev)
     torch.manual_seed(0)
     model, lik = create_exact_gp(Xtr, ytr, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
-                                 prescale=True, space_proj=space_proj)
+                                 prescale=True, space_proj=space_proj, ski=ski,
+                                 ski_options={"grid_size": 1024, "num_dims": 1} if ski else None)
     model = model.to(dev)
     mll = ExactMarginalLogLikelihood(lik, model)
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.1)
-    res = {"config": name, "N": N, "d": d, "J": J, "N_test": ntest}
+    res = {"config": name, "N": N, "d": d, "J": J, "N_test": ntest, "ski": ski}
     with settings.cg_tolerance(cg_tol), settings.eval_cg_tolerance(eval_tol), settings.max_cg_iterations(10000):
         model.train()
         times, iters, losses = [], [], []
@@ -47,12 +48,13 @@ def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol):
                 rmse = float(((out.mean - yte) ** 2).mean().sqrt())
             torch.cuda.synchronize(); res["mean_pred_s"] = time.perf_counter() - t0
             res["mean_cache_cg_iters"] = lcg.stats["iterations"]; res["test_rmse"] = rmse
-            model.train(); model.eval()
-            torch.cuda.synchronize(); t0 = time.perf_counter(); lcg.stats["iterations"] = 0
-            out = model(Xte)
-            nll = -mll(out, yte).item()
-            torch.cuda.synchronize(); res["full_pred_s"] = time.perf_counter() - t0
-            res["full_pred_cg_iters"] = lcg.stats["iterations"]; res["test_nll"] = nll
+            if full_cov:
+                model.train(); model.eval()
+                torch.cuda.synchronize(); t0 = time.perf_counter(); lcg.stats["iterations"] = 0
+                out = model(Xte)
+                nll = -mll(out, yte).item()
+                torch.cuda.synchronize(); res["full_pred_s"] = time.perf_counter() - t0
+                res["full_pred_cg_iters"] = lcg.stats["iterations"]; res["test_nll"] = nll
     print(json.dumps(res))
 
 
@@ -60,9 +62,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="C2,C3")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--cache_kernel", action="store_true")
     a = ap.parse_args()
     table = {"C2": ("C2 kin8nm-shaped RPA-GP", 7372, 8, 20, 820, False), "C3": ("C3 elevators-shaped DPA-GP", 14939, 18, 20, 1660, True),
-             "C4": ("C4 synthetic 50k RPA-GP", 50000, 20, 20, 2000, False), "S": ("small", 3000, 8, 20, 300, False)}
+             "C4": ("C4 synthetic 50k RPA-GP", 50000, 20, 20, 2000, False), "S": ("small", 3000, 8, 20, 300, False),
+             "C5": ("C5 3droad-shaped DPA-GP + SKI (J=d=3, grid 1024)", 391386, 3, 3, 43488, True)}
     for c in a.configs.split(","):
         name, N, d, J, nt, sp = table[c]
-        run(name, N, d, J, nt, a.steps, sp, 0.05, 0.01)
+        with settings.cache_kernel(a.cache_kernel):
+            run(name + (" [cached-K]" if a.cache_kernel else ""), N, d, J, nt, a.steps, sp, 0.05, 0.01, ski=(c == "C5"),
+                full_cov=(c != "C5"))

@@ -34,6 +34,7 @@ extern "C" {
 #define RPGP_EINVAL     10001 /* bad argument (shape, range, null pointer) */
 #define RPGP_EWORKSPACE 10002 /* workspace too small: call the matching *_workspace_bytes */
 #define RPGP_ENODEVICE  10003 /* no gfx950 device visible */
+#define RPGP_ENUMERIC   10004 /* NaNs encountered in an iterative solve */
 
 /* ABI version of the loaded library. */
 int rpgp_version(void);
@@ -162,6 +163,34 @@ int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t
 int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
                            float *gscale, int64_t N, int ldz, int ldg, int J, int G, int T, float scale,
                            void *workspace, size_t workspace_bytes, float *row_scratch, void *stream);
+
+/*
+ * Native mBCG executor (replaces gpytorch.utils.linear_cg as configured at gp_experiment_runner.py:324-329; algorithm in
+ * SURVEY.md Appendix B.2).  Solves (A) X = rhs for T <= 16 right-hand sides with A described by `rpgp_operator`
+ * (noise included), optional Woodbury preconditioner M = L L^T + sigma2 I given as L (N x k, k <= 16) and
+ * Cinv = (sigma2 I + L^T L)^-1 (k x k, FLOAT64: the capacitance system is ill-conditioned).  Right-hand-side columns are normalised internally; the loop stops when the mean
+ * column residual norm < tolerance after >= min_iter iterations (tested every `check_every` iterations — the only host
+ * synchronisations) or at max_iter.  The first `hist_len` (<= 64) iterations' alpha / beta coefficients are returned in
+ * HOST arrays laid out [hist_len][16] for the Lanczos tridiagonals.  Returns RPGP_ENUMERIC on NaNs.
+ */
+#define RPGP_OP_FUSED 0           /* rpgp_mvm_sym on Z */
+#define RPGP_OP_FUSED_PREPARED 1  /* rpgp_mvm_sym_prepared on prep */
+#define RPGP_OP_SKI 2             /* rpgp_ski_mvm on Z + grid_params */
+typedef struct rpgp_operator {
+  int kind;
+  int64_t N;
+  int J, ldz, j0, j1, G;
+  float scale, noise;
+  const float *Z;
+  const void *prep;
+  const float *grid_params;
+} rpgp_operator;
+size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank);
+int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,
+                    int hist_len, int check_every, float tolerance, int precond_rank, const float *L,
+                    const double *Cinv, float precond_sigma2, float *alpha_hist_host, float *beta_hist_host,
+                    int *iterations_host, float *mean_resid_host, void *workspace, size_t workspace_bytes,
+                    void *stream);
 
 /*
  * Measurement hook used by bench.py (roofline.achieved): between begin/end every rpgp_mvm_sym / rpgp_mvm_rect call

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(CSRC_DIR, "librpgp.so")
 RPGP_EINVAL = 10001
 RPGP_EWORKSPACE = 10002
 RPGP_ENODEVICE = 10003
+RPGP_ENUMERIC = 10004
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _vp = ctypes.c_void_p
@@ -47,9 +48,22 @@ SIGNATURES = {
     "rpgp_ski_diag": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp]),
     "rpgp_ski_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz,
                                       _vp, _vp]),
+    "rpgp_mbcg_workspace_bytes": (_sz, [_vp, _int, _int]),
+    "rpgp_mbcg_solve": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _f32, _int, _vp, _vp, _f32, _vp, _vp, _vp,
+                               _vp, _vp, _sz, _vp]),
     "rpgp_profile_begin": (_int, []),
     "rpgp_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
 }
+
+class RpgpOperator(ctypes.Structure):
+    """struct rpgp_operator of include/rpgp.h."""
+    _fields_ = [("kind", ctypes.c_int), ("N", ctypes.c_int64), ("J", ctypes.c_int), ("ldz", ctypes.c_int),
+                ("j0", ctypes.c_int), ("j1", ctypes.c_int), ("G", ctypes.c_int), ("scale", ctypes.c_float),
+                ("noise", ctypes.c_float), ("Z", ctypes.c_void_p), ("prep", ctypes.c_void_p),
+                ("grid_params", ctypes.c_void_p)]
+
+
+RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI = 0, 1, 2
 
 _lib = None
 

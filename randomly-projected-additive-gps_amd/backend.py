@@ -22,6 +22,8 @@ class HipBackend:
     ski_mvm = staticmethod(ops.ski_mvm)
     ski_diag = staticmethod(ops.ski_diag)
     ski_bilinear_grad = staticmethod(ops.ski_bilinear_grad)
+    make_operator_desc = staticmethod(ops.make_operator_desc)
+    mbcg_solve = staticmethod(ops.mbcg_solve)
 
 
 _backend = HipBackend()

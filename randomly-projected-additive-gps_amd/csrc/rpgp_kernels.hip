@@ -1437,6 +1437,7 @@ const char *rpgp_error_string(int code) {
     case RPGP_EINVAL: return "rpgp: invalid argument";
     case RPGP_EWORKSPACE: return "rpgp: workspace too small";
     case RPGP_ENODEVICE: return "rpgp: no usable gfx950 device";
+    case RPGP_ENUMERIC: return "rpgp: NaNs encountered in an iterative solve";
     default: return hipGetErrorString((hipError_t)code);
   }
 }

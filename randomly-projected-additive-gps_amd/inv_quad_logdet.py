@@ -95,6 +95,7 @@ class InvQuadLogDet(torch.autograd.Function):
         probes_n = probes / probe_norms
         full_rhs = torch.cat([probes_n, r], dim=1)
         matmul = khat._matmul
+        native_op = khat
         if settings.cache_kernel.on() and not isinstance(op, SKIAdditiveOperator) and \
                 (op.shard is None or op.shard.world_size == 1):
             # cached-K mode: materialise K once per hyper-parameter step (rpgp_dense) so each
@@ -102,7 +103,8 @@ class InvQuadLogDet(torch.autograd.Function):
             total = torch.cuda.get_device_properties(Z.device).total_memory if Z.is_cuda else float("inf")
             if 4.0 * N * N <= 0.25 * total:
                 matmul = DenseOperator(op.to_dense(), float(noise.detach()))._matmul
-        solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes,
+                native_op = None
+        solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes, operator=native_op,
                                   tolerance=settings.cg_tolerance.value(),
                                   max_iter=settings.max_cg_iterations.value(),
                                   max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),

@@ -26,11 +26,74 @@ class NumericalWarning(RuntimeWarning):
 stats = {"calls": 0, "iterations": 0, "last_iterations": 0, "last_rhs": 0}
 
 
+def _tridiag_from_history(alpha, beta, n_tridiag, dtype, device):
+    """Lanczos tridiagonals from the CG coefficient history (same formulas as the loop below, incl. the
+    reciprocal -> 1 rule for masked alphas)."""
+    import numpy as np
+    m = alpha.shape[0]
+    a = alpha[:, :n_tridiag].astype(np.float64)
+    b = beta[:, :n_tridiag].astype(np.float64)
+    inv_a = np.where(np.abs(a) > 1e-30, 1.0 / np.where(np.abs(a) > 1e-30, a, 1.0), 1.0)
+    t = np.zeros((n_tridiag, m, m))
+    for k in range(m):
+        if k == 0:
+            t[:, 0, 0] = inv_a[0]
+        else:
+            t[:, k, k] = inv_a[k] + b[k - 1] * inv_a[k - 1]
+            off = np.sqrt(np.clip(b[k - 1], 0.0, None)) * inv_a[k - 1]
+            t[:, k, k - 1] = off
+            t[:, k - 1, k] = off
+    return torch.from_numpy(t).to(device=device, dtype=dtype)
+
+
+def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner, check_every):
+    """Route the solve through the native mBCG executor (rpgp_mbcg_solve) when everything it needs is available;
+    returns None to fall through to the torch-op loop."""
+    from . import backend as _backend
+    be = _backend.get_backend()
+    if operator is None or not hasattr(be, "mbcg_solve") or not rhs.is_cuda or rhs.dtype != torch.float32 or \
+            rhs.shape[1] > 16 or max_tridiag_iter > 64:
+        return None
+    fn = getattr(operator, "native_descriptor", None)
+    made = fn() if fn is not None else None
+    if made is None:
+        return None
+    desc, keep = made
+    L = Cinv = None
+    sigma2 = 1.0
+    if preconditioner is not None:
+        if not (hasattr(preconditioner, "L") and hasattr(preconditioner, "cinv")) or preconditioner.L.shape[1] > 16:
+            return None
+        L, Cinv, sigma2 = preconditioner.L.contiguous(), preconditioner.cinv(), preconditioner.noise
+    N, T = rhs.shape
+    n_iter = min(max_iter, N)
+    hist = min(max_tridiag_iter, n_iter) if n_tridiag else 0
+    x, ah, bh, iters, mres = be.mbcg_solve(desc, rhs.contiguous(), tolerance, n_iter, min_iter=10, hist_len=hist,
+                                           check_every=check_every, L=L, Cinv=Cinv, sigma2=sigma2)
+    del keep
+    stats["calls"] += 1
+    stats["iterations"] += iters
+    stats["last_iterations"] = iters
+    stats["last_rhs"] = T
+    stats["native_calls"] = stats.get("native_calls", 0) + 1
+    if mres >= tolerance and iters >= n_iter:
+        warnings.warn(
+            "CG terminated in {} iterations with average residual norm {} which is larger than the tolerance of {} "
+            "specified by rpgp_amd.settings.cg_tolerance. If performance is affected, consider raising the maximum "
+            "number of CG iterations by running code in a rpgp_amd.settings.max_cg_iterations(value) context."
+            .format(iters, mres, tolerance), NumericalWarning)
+    if n_tridiag:
+        return x, _tridiag_from_history(ah, bh, n_tridiag, rhs.dtype, rhs.device)
+    return x
+
+
 def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_updating_after=1e-10, max_iter=None,
-              max_tridiag_iter=None, initial_guess=None, preconditioner=None, check_every=1):
+              max_tridiag_iter=None, initial_guess=None, preconditioner=None, check_every=1, operator=None):
     """Solve A X = rhs for symmetric positive definite A given as `matmul_closure`.
 
     rhs: (N x T).  Returns X, or (X, tridiag [n_tridiag x k x k]) when n_tridiag > 0.
+    `operator` (optional): the LinearOperator behind `matmul_closure`; when it exposes `native_descriptor()` and
+    T <= 16 the whole loop runs in the native executor (fused vector kernels, device-resident scalars).
     """
     if rhs.dim() == 1:
         squeeze = True
@@ -43,6 +106,13 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
         max_iter = settings.max_cg_iterations.value()
     if max_tridiag_iter is None:
         max_tridiag_iter = settings.max_lanczos_quadrature_iterations.value()
+    if initial_guess is None and rhs.dim() == 2:
+        res = _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner,
+                                check_every)
+        if res is not None:
+            if squeeze:
+                return (res[0].squeeze(-1), res[1]) if n_tridiag else res.squeeze(-1)
+            return res
     if preconditioner is None:
         def preconditioner(x):
             return x

@@ -45,7 +45,8 @@ class PredictionStrategy:
                     self.khat = AddedDiagOperator(self.op, self.noise)
                 self.pre = build_preconditioner(self.op, float(self.noise), settings)
                 self.alpha = linear_cg(self.khat._matmul, self.r, tolerance=settings.eval_cg_tolerance.value(),
-                                       max_iter=settings.max_cg_iterations.value(), preconditioner=self.pre)
+                                       max_iter=settings.max_cg_iterations.value(), preconditioner=self.pre,
+                                       operator=self.khat)
 
     def solve(self, B):
         if self.dense_path:
@@ -61,7 +62,8 @@ class PredictionStrategy:
                     self._dense_khat = DenseOperator(self.op.to_dense(), float(self.noise))
                 khat = self._dense_khat
         return linear_cg(khat._matmul, B, tolerance=settings.eval_cg_tolerance.value(),
-                         max_iter=settings.max_cg_iterations.value(), preconditioner=getattr(self, "pre", None))
+                         max_iter=settings.max_cg_iterations.value(), preconditioner=getattr(self, "pre", None),
+                         operator=khat)
 
     def predict(self, xs):
         model = self.model

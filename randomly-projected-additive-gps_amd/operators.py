@@ -149,6 +149,25 @@ class AdditiveRPOperator(LinearOperator):
             raise ValueError("a diagonal can only be added to the square symmetric operator")
         return self.shard.sharded_mvm(lambda j0, j1: self._local_matmul(rhs, 0.0), rhs, float(noise))
 
+    def native_descriptor(self, noise=0.0):
+        """`struct rpgp_operator` for the native mBCG executor, or None when the operator must stay on the Python path
+        (rectangular, J-sharded over several ranks, or a backend without the executor)."""
+        be = _backend.get_backend()
+        if not self.symmetric or not hasattr(be, "mbcg_solve") or (self.shard is not None and self.shard.world_size > 1):
+            return None
+        from . import _lib
+        z1 = self.Z1.detach()
+        j0, j1 = self._jrange()
+        prepare = getattr(be, "prepare", None)
+        if prepare is not None:
+            if self._prep is None:
+                self._prep = prepare(z1)
+            if self._prep.fast_ok:
+                return be.make_operator_desc(_lib.RPGP_OP_FUSED_PREPARED, z1.shape[0], z1.shape[1], self._scale, noise,
+                                             prep=self._prep, j0=j0, j1=j1)
+        return be.make_operator_desc(_lib.RPGP_OP_FUSED, z1.shape[0], z1.shape[1], self._scale, noise, Z=z1.contiguous(),
+                                     j0=j0, j1=j1)
+
     def _transpose_nonbatch(self):
         if self.symmetric:
             return self
@@ -224,6 +243,15 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         z1 = self.Z1.detach()
         z2 = z1 if self.symmetric else self.Z2.detach()
         return be.ski_mvm(z1, z2, self.gp, rhs, self._scale, noise if self.symmetric else 0.0, self.grid_size)
+
+    def native_descriptor(self, noise=0.0):
+        be = _backend.get_backend()
+        if not self.symmetric or not hasattr(be, "mbcg_solve"):
+            return None
+        from . import _lib
+        z1 = self.Z1.detach().contiguous()
+        return be.make_operator_desc(_lib.RPGP_OP_SKI, z1.shape[0], z1.shape[1], self._scale, noise, Z=z1, gp=self.gp,
+                                     G=self.grid_size)
 
     def _matmul(self, rhs, noise=0.0):
         if noise and not self.symmetric:
@@ -302,6 +330,10 @@ class AddedDiagOperator(LinearOperator):
         if isinstance(self.base, AdditiveRPOperator):
             return self.base._matmul(rhs, noise=self._noise)
         return self.base._matmul(rhs) + self._noise * rhs
+
+    def native_descriptor(self):
+        fn = getattr(self.base, "native_descriptor", None)
+        return fn(self._noise) if fn is not None else None
 
     def _transpose_nonbatch(self):
         return self

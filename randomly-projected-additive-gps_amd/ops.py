@@ -330,3 +330,54 @@ def ski_bilinear_grad(Z, gp, L, R, scale, grid_size=1024):
             gZ += gZp
             gs += gsp
     return gZ, gs
+
+
+# ------------------------------------------------------------------------------------------------ native mBCG
+
+def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=0, j1=None, G=0):
+    """Fill a `struct rpgp_operator`; returns (struct, keepalive) — keep both referenced while the solve runs."""
+    d = _lib.RpgpOperator()
+    d.kind, d.N, d.J, d.ldz = kind, N, J, J
+    d.j0, d.j1, d.G = j0, J if j1 is None else j1, G
+    d.scale, d.noise = float(scale), float(noise)
+    d.Z = Z.data_ptr() if Z is not None else None
+    d.prep = prep.buf.data_ptr() if prep is not None else None
+    d.grid_params = gp.data_ptr() if gp is not None else None
+    return d, (Z, prep, gp)
+
+
+def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_every=1, L=None, Cinv=None, sigma2=1.0):
+    """Native preconditioned batched CG (rpgp_mbcg_solve).  rhs: N x T (T <= 16).
+    Returns (x, alpha_hist [h x T], beta_hist [h x T], iterations, mean_residual)."""
+    import ctypes
+    import numpy as np
+    lib = _lib.load()
+    rhs = _require(rhs, "rhs", 2)
+    N, T = rhs.shape
+    if T > 16:
+        raise ValueError("the native mBCG executor handles at most 16 right-hand sides")
+    k = 0
+    Lp = Cp = None
+    if L is not None:
+        L = _require(L, "L", 2)
+        if Cinv.dtype != torch.float64 or not Cinv.is_cuda:
+            raise TypeError("Cinv must be a float64 device tensor")
+        Cinv = Cinv.contiguous()
+        k = L.shape[1]
+        Lp, Cp = L.data_ptr(), Cinv.data_ptr()
+    x = torch.empty_like(rhs)
+    ah = np.zeros((max(hist_len, 1), 16), dtype=np.float32)
+    bh = np.zeros((max(hist_len, 1), 16), dtype=np.float32)
+    iters, mres = ctypes.c_int(0), ctypes.c_float(0)
+    with torch.cuda.device(rhs.device):
+        nbytes = lib.rpgp_mbcg_workspace_bytes(ctypes.byref(desc), T, k)
+        ws = _workspace(rhs.device, nbytes)
+        rc = lib.rpgp_mbcg_solve(ctypes.byref(desc), rhs.data_ptr(), x.data_ptr(), T, int(max_iter), int(min_iter),
+                                 int(hist_len), int(check_every), float(tolerance), k, Lp, Cp, float(sigma2),
+                                 ah.ctypes.data, bh.ctypes.data, ctypes.byref(iters), ctypes.byref(mres),
+                                 ws.data_ptr(), ws.numel(), _stream())
+    if rc == _lib.RPGP_ENUMERIC:
+        raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
+    _lib.check(rc, "rpgp_mbcg_solve")
+    h = min(hist_len, iters.value)
+    return x, ah[:h, :T].copy(), bh[:h, :T].copy(), iters.value, mres.value

@@ -51,6 +51,10 @@ class WoodburyPreconditioner:
 
     __call__ = solve
 
+    def cinv(self):
+        """(noise I + L^T L)^-1 in float64 (k x k) for the native mBCG executor."""
+        return torch.cholesky_inverse(self._cap_chol).contiguous()
+
     def logdet(self):
         """log|M| = log|noise I_k + L^T L| + (N - k) log noise."""
         ld_cap = 2.0 * torch.log(self._cap_chol.diagonal()).sum()

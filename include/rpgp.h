@@ -131,8 +131,16 @@ int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *g
                              void *workspace, size_t workspace_bytes, void *stream);
 
 /*
- * Dense symmetric-matrix MVM for the cached-K mode:  out = Kd @ V + noise * V   (Kd: N x N fp32 in HBM).
- * HBM-bound stream of Kd.
+ * Rank-`rank` pivoted Cholesky of K(Z,Z) (greedy max-diagonal pivots): L (N x rank, row-major) with K ~= L L^T, for the
+ * Woodbury preconditioner M = L L^T + sigma^2 I (GPyTorch `pivoted_cholesky`, max_preconditioner_size = 15,
+ * SURVEY.md Appendix B.3).  One single-workgroup launch; `diag_work` is N floats of device scratch.  J, rank <= 64.
+ */
+int rpgp_pivoted_cholesky(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int J, int rank,
+                          float scale, void *stream);
+
+/*
+ * Dense-matrix MVM for the cached-K mode:  out = Kd @ V + noise * V   (Kd: N x N fp32 in HBM, row stride ldk).
+ * HBM-bound stream of Kd with the thin GEMM on the matrix cores (v_mfma_f32_16x16x4_f32) — SURVEY.md §8(f) rank 2.
  */
 int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64_t ldk, int T,
                    float noise, void *stream);
@@ -176,6 +184,7 @@ int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float
 #define RPGP_OP_FUSED 0           /* rpgp_mvm_sym on Z */
 #define RPGP_OP_FUSED_PREPARED 1  /* rpgp_mvm_sym_prepared on prep */
 #define RPGP_OP_SKI 2             /* rpgp_ski_mvm on Z + grid_params */
+#define RPGP_OP_DENSE 3           /* cached-K: symmetric Kd (N x N, row stride ldk) in HBM, applied by rpgp_dense_mvm */
 typedef struct rpgp_operator {
   int kind;
   int64_t N;
@@ -184,6 +193,8 @@ typedef struct rpgp_operator {
   const float *Z;
   const void *prep;
   const float *grid_params;
+  const float *Kd;
+  int64_t ldk;
 } rpgp_operator;
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank);
 int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "rpgp_bilinear_grad_workspace_bytes": (_sz, [_i64, _int]),
     "rpgp_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "rpgp_bilinear_grad_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _int, _int, _f32, _vp, _sz, _vp]),
+    "rpgp_pivoted_cholesky": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp]),
     "rpgp_dense_mvm": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _f32, _vp]),
     "rpgp_ski_workspace_bytes": (_sz, [_int, _int, _int]),
     "rpgp_ski_grid": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
@@ -60,10 +61,10 @@ class RpgpOperator(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("N", ctypes.c_int64), ("J", ctypes.c_int), ("ldz", ctypes.c_int),
                 ("j0", ctypes.c_int), ("j1", ctypes.c_int), ("G", ctypes.c_int), ("scale", ctypes.c_float),
                 ("noise", ctypes.c_float), ("Z", ctypes.c_void_p), ("prep", ctypes.c_void_p),
-                ("grid_params", ctypes.c_void_p)]
+                ("grid_params", ctypes.c_void_p), ("Kd", ctypes.c_void_p), ("ldk", ctypes.c_int64)]
 
 
-RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI = 0, 1, 2
+RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI, RPGP_OP_DENSE = 0, 1, 2, 3
 
 _lib = None
 

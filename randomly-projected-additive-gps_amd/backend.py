@@ -18,6 +18,7 @@ class HipBackend:
     bilinear_grad = staticmethod(ops.bilinear_grad)
     bilinear_grad_dense = staticmethod(ops.bilinear_grad_dense)
     dense_mvm = staticmethod(ops.dense_mvm)
+    pivoted_cholesky = staticmethod(ops.pivoted_cholesky)
     ski_grid = staticmethod(ops.ski_grid)
     ski_mvm = staticmethod(ops.ski_mvm)
     ski_diag = staticmethod(ops.ski_diag)

@@ -297,6 +297,8 @@ int apply_operator(const rpgp_operator *op, const float *V, float *out, int T, v
     case RPGP_OP_SKI:
       return rpgp_ski_mvm(op->Z, op->Z, op->grid_params, V, out, op->N, op->N, op->ldz, op->ldz, op->J, op->G, T,
                           op->scale, op->noise, ws, ws_bytes, stream);
+    case RPGP_OP_DENSE:
+      return rpgp_dense_mvm(op->Kd, V, out, op->N, op->ldk, T, op->noise, stream);
     default:
       return RPGP_EINVAL;
   }
@@ -309,6 +311,8 @@ size_t operator_workspace(const rpgp_operator *op, int T) {
       return rpgp_mvm_sym_workspace_bytes(op->N, T);
     case RPGP_OP_SKI:
       return rpgp_ski_workspace_bytes(op->J, op->G, T);
+    case RPGP_OP_DENSE:
+      return 256;
     default:
       return 0;
   }

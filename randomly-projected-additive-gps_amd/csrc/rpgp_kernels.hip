@@ -32,6 +32,7 @@ template <int TT> struct StageCols { static constexpr int v = (TT > 4) ? 64 : 25
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float floatx4m __attribute__((ext_vector_type(4)));
 
 // LDS row stride (floats) for a column's JT coordinates: (stride/4) odd keeps the per-lane
 // ds_read_b128 of 16 consecutive columns on 16 distinct 4-bank slots (MI355X_MICROARCH.md §LDS).
@@ -602,8 +603,6 @@ __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ Z1
 // ---------------------------------------------------------------------------------------------
 // Projection Z = X @ Peff and its backward dPeff = X^T @ G (thin GEMMs; plain VALU version).
 // ---------------------------------------------------------------------------------------------
-typedef float floatx4m __attribute__((ext_vector_type(4)));
-
 // Z = X @ Peff on the matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, MI355X_MICROARCH.md "FP32-input
 // MFMA").  One wave64 owns a 16-row stripe of Z and walks the column tiles; the K dimension (d) advances 4 per MFMA.
 //   A (16x4): lane l holds X[row0 + l%16][k0 + l/16]        B (4x16): lane l holds Peff[k0 + l/16][col0 + l%16]
@@ -826,54 +825,87 @@ __global__ __launch_bounds__(1024) void sum_vector_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// Cached-K mode: out = Kd @ V + noise V, Kd dense N x N fp32 (HBM stream).  One wave per row,
-// float4 loads; V (N x T) comes from L2.
+// Cached-K mode: out = Kd @ V + noise V for a dense N x N fp32 matrix in HBM and a thin block V (T <= 16 columns per
+// pass).  HBM-bound stream of Kd; the multiply-accumulate runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact
+// fp32) so the VALU only issues loads.  A 256-thread workgroup owns 128 rows (32 per wave = two 16-row MFMA tiles);
+// V is staged 256 rows at a time in LDS and shared by the four waves.
+//   A tile: lane (m = l%16, q = l/16) loads float4 Kd[row0+m][c + 4q .. 4q+3]; MFMA i uses component i with
+//   B_i[q][n] = V[c + 4q + i][n]  (any consistent ordering of the K dimension is valid);
+//   D: lane holds out[row0 + 4*(l/16) + r][l%16], r = 0..3.
 // ---------------------------------------------------------------------------------------------
-template <int TT>
-__global__ __launch_bounds__(256) void dense_mvm_kernel(const float *__restrict__ Kd, const float *__restrict__ V,
-                                                        float *__restrict__ out, int N, long long ldk, int T,
-                                                        int t0, float noise) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= N) return;
-  const float *kr = Kd + (size_t)row * ldk;
-  float acc[TT];
+__global__ __launch_bounds__(256) void dense_gemm_kernel(const float *__restrict__ Kd, const float *__restrict__ V,
+                                                         float *__restrict__ slab, int N, long long ldk, int T, int t0,
+                                                         int tcnt, int rows_per_split) {
+  // Kd is symmetric, so out[c][t] = sum_r Kd[r][c] V[r][t]: every wave owns 64 consecutive OUTPUT indices c and
+  // streams down the rows r of Kd, 4 rows per step.  Lane (k = l/16, n = l%16) loads float4 Kd[r+k][c0 + 4n .. 4n+3]
+  // (256 contiguous bytes per row per wave-instruction) and feeds its 4 components to 4 MFMAs:
+  //   D_i[t][n] += sum_k V[r+k][t] * Kd[r+k][c0 + 4n + i]        (A: lane (t = l%16, k = l/16) holds V[r+k][t])
+  constexpr int VC = 256;                        // V rows staged per step
+  __shared__ float sV[VC * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, k = lane >> 4;
+  const int c0 = blockIdx.x * 256 + wave * 64;   // first output index of this wave
+  const int cl = c0 + 4 * n;                     // this lane's 4 columns
+  const bool vec_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0) && (cl + 3 < N);
+  floatx4m acc[4];
 #pragma unroll
-  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
-  const bool vec_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0);
-  int c = 0;
-  if (vec_ok) {
-    const int n4 = N & ~255;
-    for (c = lane * 4; c < n4; c += 256) {
-      const float4v q = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kr + c));
+  for (int i = 0; i < 4; ++i) acc[i] = floatx4m{0.f, 0.f, 0.f, 0.f};
+  const int rs = blockIdx.y * rows_per_split;
+  const int re = (rs + rows_per_split < N) ? rs + rows_per_split : N;
+  for (int rb = rs; rb < re; rb += VC) {
+    __syncthreads();
+    for (int e = tid; e < VC * 16; e += 256) {
+      const int rr = e >> 4, t = e & 15;
+      const int row = rb + rr;
+      sV[e] = (row < re && t < tcnt) ? V[(size_t)row * T + t0 + t] : 0.f;
+    }
+    __syncthreads();
+    const int rend = (rb + VC < re) ? VC : re - rb;
+#pragma unroll 4
+    for (int rr = 0; rr < rend; rr += 4) {
+      const int row = rb + rr + k;
+      float4v a = {0.f, 0.f, 0.f, 0.f};
+      if (row < re) {
+        const float *kp = Kd + (size_t)row * ldk + cl;
+        if (vec_ok) {
+          a = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kp));
+        } else {
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        if (TT == 1 || t0 + t < T) {
-          acc[t] = __builtin_fmaf(q.x, V[(size_t)(c + 0) * T + t0 + t], acc[t]);
-          acc[t] = __builtin_fmaf(q.y, V[(size_t)(c + 1) * T + t0 + t], acc[t]);
-          acc[t] = __builtin_fmaf(q.z, V[(size_t)(c + 2) * T + t0 + t], acc[t]);
-          acc[t] = __builtin_fmaf(q.w, V[(size_t)(c + 3) * T + t0 + t], acc[t]);
+          for (int i = 0; i < 4; ++i)
+            if (cl + i < N) a[i] = kp[i];
         }
       }
-    }
-    c = n4;
-  }
-  for (int cc = c + lane; cc < N; cc += 64) {
-    const float q = kr[cc];
-#pragma unroll
-    for (int t = 0; t < TT; ++t)
-      if (TT == 1 || t0 + t < T) acc[t] = __builtin_fmaf(q, V[(size_t)cc * T + t0 + t], acc[t]);
-  }
-#pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    float s = acc[t];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0 && t0 + t < T) {
-      const size_t o = (size_t)row * T + t0 + t;
-      out[o] = __builtin_fmaf(noise, V[o], s);
+      const float v = sV[(rr + k) * 16 + n];     // A operand: V[row][t = n] for k = l/16 (zero beyond the split)
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, a.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, a.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, a.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, a.w, acc[3], 0, 0, 0);
     }
   }
+  // D_i: lane holds out^T[t = 4k + r][c = c0 + 4n + i]
+  float *sl = slab + (size_t)blockIdx.y * N * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = cl + i;
+    if (c < N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sl[(size_t)c * 16 + 4 * k + r] = acc[i][r];
+    }
+  }
+}
+
+// out[row][t0+n] = sum_split slab[split][row][n] + noise * V[row][t0+n]   (fixed order: deterministic)
+__global__ void dense_gemm_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ V,
+                                         float *__restrict__ out, int N, int T, int t0, int tcnt, int nsplit,
+                                         float noise) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)N * 16) return;
+  const int row = (int)(gid >> 4), n = (int)(gid & 15);
+  if (n >= tcnt) return;
+  float acc = 0.f;
+  for (int sidx = 0; sidx < nsplit; ++sidx) acc += slab[(size_t)sidx * N * 16 + gid];
+  const size_t o = (size_t)row * T + t0 + n;
+  out[o] = __builtin_fmaf(noise, V[o], acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1195,6 +1227,79 @@ __global__ __launch_bounds__(256) void ski_diag_kernel(const float *__restrict__
       for (int kk = 0; kk < 4; ++kk) acc = __builtin_fmaf(w[k] * w[kk], c[k > kk ? k - kk : kk - k], acc);
   }
   diag[i] = scale * acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rank-k pivoted Cholesky of K = scale * sum_j exp(-0.5 (z_ij - z_i'j)^2) (preconditioner) as ONE
+// single-workgroup launch: k greedy steps of {argmax of the residual diagonal, one kernel row, rank-1 downdate}.
+// L is N x k row-major (what the native mBCG executor consumes).  Work per step is O(N (J + k)): negligible next to
+// one MVM, so a single CU is enough and no host round-trips are needed (the torch version costs ~10 launches/step).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void pivchol_kernel(const float *__restrict__ Z, float *__restrict__ L,
+                                                       float *__restrict__ dwork, int N, int ldz, int J, int k,
+                                                       float scale) {
+  __shared__ float sval[16];
+  __shared__ int sidx[16];
+  __shared__ float szp[64];
+  __shared__ float slp[64];
+  __shared__ float sdp;
+  __shared__ int spiv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float d0 = scale * (float)J;
+  for (int i = tid; i < N; i += 1024) dwork[i] = d0;
+  __syncthreads();
+  for (int m = 0; m < k; ++m) {
+    // argmax of the residual diagonal (ties -> smallest index: deterministic)
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < N; i += 1024) {
+      const float v = dwork[i];
+      if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sval[wave] = bv; sidx[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = sval[0];
+      int ix = sidx[0];
+      for (int w = 1; w < 16; ++w)
+        if (sval[w] > v || (sval[w] == v && sidx[w] < ix)) { v = sval[w]; ix = sidx[w]; }
+      sdp = v;
+      spiv = ix;
+    }
+    __syncthreads();
+    const int piv = spiv;
+    const float dp = sdp;
+    const bool ok = dp > 1e-10f * d0;
+    if (tid < J) szp[tid] = Z[(size_t)piv * ldz + tid] * kExp2Scale;
+    if (tid < m) slp[tid] = L[(size_t)piv * k + tid];
+    __syncthreads();
+    const float inv_sq = ok ? 1.0f / sqrtf(dp) : 0.f;
+    for (int i = tid; i < N; i += 1024) {
+      float l = 0.f;
+      if (ok) {
+        float row = 0.f;
+        for (int j = 0; j < J; ++j) {
+          const float dd = Z[(size_t)i * ldz + j] * kExp2Scale - szp[j];
+          row += fast_exp2(-(dd * dd));
+        }
+        row *= scale;
+        float corr = 0.f;
+        for (int q = 0; q < m; ++q) corr = __builtin_fmaf(L[(size_t)i * k + q], slp[q], corr);
+        l = (row - corr) * inv_sq;
+      }
+      L[(size_t)i * k + m] = l;
+      float nd = dwork[i] - l * l;
+      nd = nd < 0.f ? 0.f : nd;
+      dwork[i] = (i == piv) ? 0.f : nd;
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------- host-side helpers -------------------------------------------
@@ -1715,22 +1820,42 @@ int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *g
   return launch_status();
 }
 
+int rpgp_pivoted_cholesky(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int J, int rank, float scale,
+                          void *stream) {
+  if (!Z || !L || !diag_work || N <= 0 || J <= 0 || J > 64 || rank <= 0 || rank > 64 || ldz < J || N > 0x7fffffffLL)
+    return RPGP_EINVAL;
+  hipLaunchKernelGGL(pivchol_kernel, dim3(1), dim3(1024), 0, as_stream(stream), Z, L, diag_work, (int)N, ldz, J, rank,
+                     scale);
+  return launch_status();
+}
+
 int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64_t ldk, int T, float noise,
                    void *stream) {
   if (!Kd || !V || !out || N <= 0 || T <= 0 || ldk < N || N > 0x7fffffffLL) return RPGP_EINVAL;
   hipStream_t st = as_stream(stream);
-  dim3 grid((unsigned)((N + 3) / 4)), block(256);
-  if (T == 1) {
-    hipLaunchKernelGGL((dense_mvm_kernel<1>), grid, block, 0, st, Kd, V, out, (int)N, (long long)ldk, T, 0, noise);
-  } else {
-    for (int t0 = 0; t0 < T; t0 += 12) {
-      if (T - t0 <= 4)
-        hipLaunchKernelGGL((dense_mvm_kernel<4>), grid, block, 0, st, Kd, V, out, (int)N, (long long)ldk, T, t0, noise);
-      else
-        hipLaunchKernelGGL((dense_mvm_kernel<12>), grid, block, 0, st, Kd, V, out, (int)N, (long long)ldk, T, t0, noise);
-    }
+  const int nrb = (int)((N + 255) / 256);
+  int nsplit = (3072 + nrb - 1) / nrb;            // ~3000 workgroups keep enough loads in flight to stream HBM
+  const int max_split = (int)((N + 1023) / 1024);
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit > 32) nsplit = 32;
+  if (nsplit < 1) nsplit = 1;
+  int cps = (int)((N + nsplit - 1) / nsplit);
+  cps = (cps + 255) / 256 * 256;
+  nsplit = (int)((N + cps - 1) / cps);
+  float *slab = nullptr;
+  RPGP_CHECK(hipMallocAsync((void **)&slab, (size_t)nsplit * N * 16 * sizeof(float), st));
+  dim3 grid((unsigned)nrb, (unsigned)nsplit), block(256);
+  int rc = 0;
+  for (int t0 = 0; t0 < T && rc == 0; t0 += 16) {
+    const int tcnt = (T - t0 < 16) ? T - t0 : 16;
+    hipLaunchKernelGGL(dense_gemm_kernel, grid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, t0, tcnt, cps);
+    const size_t total = (size_t)N * 16;
+    hipLaunchKernelGGL(dense_gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, V, out,
+                       (int)N, T, t0, tcnt, nsplit, noise);
+    rc = launch_status();
   }
-  return launch_status();
+  (void)hipFreeAsync(slab, st);
+  return rc;
 }
 
 }  // extern "C"

@@ -102,8 +102,8 @@ class InvQuadLogDet(torch.autograd.Function):
             # CG iteration on the T = 11 block is one HBM-bound library GEMM; the backward pass stays fused
             total = torch.cuda.get_device_properties(Z.device).total_memory if Z.is_cuda else float("inf")
             if 4.0 * N * N <= 0.25 * total:
-                matmul = DenseOperator(op.to_dense(), float(noise.detach()))._matmul
-                native_op = None
+                native_op = DenseOperator(op.to_dense(), float(noise.detach()))
+                matmul = native_op._matmul
         solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes, operator=native_op,
                                   tolerance=settings.cg_tolerance.value(),
                                   max_iter=settings.max_cg_iterations.value(),
@@ -114,7 +114,7 @@ class InvQuadLogDet(torch.autograd.Function):
         if settings.skip_logdet_forward.on():
             logdet = torch.zeros((), dtype=Z.dtype, device=Z.device)
         else:
-            logdet = (slq_logdet(t_mat, N) + logdet_correction).to(Z.dtype)
+            logdet = torch.as_tensor(float(slq_logdet(t_mat, N)) + logdet_correction, dtype=Z.dtype, device=Z.device)
         ctx.mode = "cg"
         ctx.pre = pre
         ctx.num_probes = num_probes

@@ -43,7 +43,9 @@ def _tridiag_from_history(alpha, beta, n_tridiag, dtype, device):
             off = np.sqrt(np.clip(b[k - 1], 0.0, None)) * inv_a[k - 1]
             t[:, k, k - 1] = off
             t[:, k - 1, k] = off
-    return torch.from_numpy(t).to(device=device, dtype=dtype)
+    # the tridiagonals stay on the HOST: they are only eigendecomposed (10 matrices of 20 x 20), which costs ~1 ms
+    # as GPU eigh launches and microseconds on the CPU
+    return torch.from_numpy(t)
 
 
 def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner, check_every):

@@ -149,6 +149,15 @@ class AdditiveRPOperator(LinearOperator):
             raise ValueError("a diagonal can only be added to the square symmetric operator")
         return self.shard.sharded_mvm(lambda j0, j1: self._local_matmul(rhs, 0.0), rhs, float(noise))
 
+    def fused_pivoted_cholesky(self, rank):
+        """Single-launch pivoted Cholesky (rpgp_pivoted_cholesky) when the backend has it and the kernel is not sharded;
+        None otherwise (callers fall back to the generic row-by-row version)."""
+        be = _backend.get_backend()
+        if type(self) is not AdditiveRPOperator or not self.symmetric or not hasattr(be, "pivoted_cholesky") or \
+                (self.shard is not None and self.shard.world_size > 1) or self.num_projections > 64 or rank > 64:
+            return None
+        return be.pivoted_cholesky(self.Z1.detach().contiguous(), self._scale, min(rank, self.Z1.shape[0]))
+
     def native_descriptor(self, noise=0.0):
         """`struct rpgp_operator` for the native mBCG executor, or None when the operator must stay on the Python path
         (rectangular, J-sharded over several ranks, or a backend without the executor)."""
@@ -383,12 +392,21 @@ class DenseOperator(LinearOperator):
         return self.Kd.device
 
     def _matmul(self, rhs):
-        # a plain library GEMM / GEMV (rocBLAS): measured 6.2 TB/s of K at T = 11 and 5.1 TB/s at T = 1 on MI355X
         rhs = rhs.detach()
-        out = self.Kd @ rhs
+        if rhs.shape[-1] <= 32 and rhs.is_cuda:
+            return _backend.get_backend().dense_mvm(self.Kd, rhs, self._noise)      # HBM-bound MFMA thin GEMM
+        out = self.Kd @ rhs                                                        # wide blocks: library GEMM
         if self._noise:
             out.add_(rhs, alpha=self._noise)
         return out
+
+    def native_descriptor(self):
+        be = _backend.get_backend()
+        if not hasattr(be, "mbcg_solve") or not self.Kd.is_cuda or self.Kd.dtype != torch.float32 or \
+                self.Kd.stride(1) != 1 or self.Kd.shape[0] >= 2 ** 31:
+            return None
+        from . import _lib
+        return be.make_operator_desc(_lib.RPGP_OP_DENSE, self.Kd.shape[0], 0, 1.0, self._noise, Kd=self.Kd)
 
     def _transpose_nonbatch(self):
         return self

@@ -241,6 +241,19 @@ def bilinear_grad_dense(Z, S, scale, j0=0, j1=None):
     return gZ, gs
 
 
+def pivoted_cholesky(Z, scale, rank):
+    """L (N x rank) with K(Z,Z) ~= L L^T (greedy pivots), one launch."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    N, J = Z.shape
+    L = torch.empty((N, rank), dtype=torch.float32, device=Z.device)
+    work = torch.empty(N, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        _lib.check(lib.rpgp_pivoted_cholesky(Z.data_ptr(), L.data_ptr(), work.data_ptr(), N, J, J, int(rank),
+                                             float(scale), _stream()), "rpgp_pivoted_cholesky")
+    return L
+
+
 def dense_mvm(Kd, V, noise=0.0):
     """out = Kd @ V + noise * V for a cached dense symmetric kernel matrix."""
     lib = _lib.load()
@@ -334,7 +347,7 @@ def ski_bilinear_grad(Z, gp, L, R, scale, grid_size=1024):
 
 # ------------------------------------------------------------------------------------------------ native mBCG
 
-def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=0, j1=None, G=0):
+def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=0, j1=None, G=0, Kd=None):
     """Fill a `struct rpgp_operator`; returns (struct, keepalive) — keep both referenced while the solve runs."""
     d = _lib.RpgpOperator()
     d.kind, d.N, d.J, d.ldz = kind, N, J, J
@@ -343,7 +356,9 @@ def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=
     d.Z = Z.data_ptr() if Z is not None else None
     d.prep = prep.buf.data_ptr() if prep is not None else None
     d.grid_params = gp.data_ptr() if gp is not None else None
-    return d, (Z, prep, gp)
+    d.Kd = Kd.data_ptr() if Kd is not None else None
+    d.ldk = Kd.stride(0) if Kd is not None else 0
+    return d, (Z, prep, gp, Kd)
 
 
 def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_every=1, L=None, Cinv=None, sigma2=1.0):

@@ -73,5 +73,9 @@ def build_preconditioner(operator, noise, settings):
     N = operator.shape[0]
     if N < settings.min_preconditioning_size.value() or settings.max_preconditioner_size.value() <= 0:
         return None
-    L = pivoted_cholesky(operator._diagonal(), operator._get_rows, settings.max_preconditioner_size.value())
+    rank = settings.max_preconditioner_size.value()
+    fused = getattr(operator, "fused_pivoted_cholesky", None)
+    L = fused(rank) if fused is not None else None
+    if L is None:
+        L = pivoted_cholesky(operator._diagonal(), operator._get_rows, rank)
     return WoodburyPreconditioner(L, noise)

@@ -205,3 +205,21 @@ def test_prepared_range_guard(gpu_device):
     assert _rel(out.cpu().numpy(), orc.mvm(Z, Z, V, 1.0)) < 1e-5
     bad = torch.from_numpy(np.full((10, 2), np.nan, dtype=np.float32)).to(gpu_device)
     assert not ops.Prepared(bad).fast_ok
+
+
+@pytest.mark.parametrize("N,J,rank", [(500, 20, 15), (3000, 3, 15), (64, 8, 10)])
+def test_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, rank):
+    """rpgp_pivoted_cholesky (one launch) against the generic row-by-row implementation on the same operator."""
+    from rpgp_amd import ops
+    from rpgp_amd.operators import AdditiveRPOperator
+    from rpgp_amd.precond import pivoted_cholesky
+    rng = np.random.default_rng(N)
+    Z = torch.from_numpy((rng.standard_normal((N, J)) * 0.7).astype(np.float32)).to(gpu_device)
+    op = AdditiveRPOperator(Z, None, torch.tensor(0.8, device=gpu_device), 1.0 / J)
+    Lf = ops.pivoted_cholesky(Z, 0.8 / J, rank)
+    Lg = pivoted_cholesky(op._diagonal(), op._get_rows, rank)
+    K = op.to_dense().double()
+    ef = (K - Lf.double() @ Lf.double().t()).abs().max().item()
+    eg = (K - Lg.double() @ Lg.double().t()).abs().max().item()
+    assert ef <= eg * 1.05 + 1e-5
+    assert torch.allclose(Lf, Lg, rtol=1e-3, atol=2e-4)

@@ -182,7 +182,28 @@ def main():
         torch.cuda.synchronize()
         t_solve = time.perf_counter() - ts
         resid = float((khat._matmul(alpha) - y.reshape(-1, 1)).norm() / y.norm())
-        result["extras"] = {"block_T11_ms": round(t11 * 1e3, 4), "block_T11_mvm_equiv_per_s": round(11.0 / t11, 1),
+        # cached-K mode (K materialised once per hyper-parameter step, then a genuinely HBM-bound MFMA thin GEMM)
+        cached = None
+        if 4.0 * N * N < 0.3 * torch.cuda.get_device_properties(device).total_memory:
+            torch.cuda.synchronize()
+            tk = time.perf_counter()
+            Kd = ops.dense(Z, Z, scale)
+            torch.cuda.synchronize()
+            t_build = time.perf_counter() - tk
+            ops.dense_mvm(Kd, V, noise)
+            torch.cuda.synchronize()
+            tk = time.perf_counter()
+            for _ in range(10):
+                oc = ops.dense_mvm(Kd, V, noise)
+            torch.cuda.synchronize()
+            t_c = (time.perf_counter() - tk) / 10
+            cached = {"mvm_ms": round(t_c * 1e3, 4), "mvm_per_s": round(1.0 / t_c, 1), "build_ms": round(t_build * 1e3, 3),
+                      "hbm_GBps": round(4.0 * N * N / t_c / 1e9, 1), "hbm_frac_of_8TBps": round(4.0 * N * N / t_c / 8e12, 4),
+                      "rel_diff_vs_fused": float((oc - res).norm() / res.norm()),
+                      "note": "literal HBM stream of the 4N^2-byte matrix (rpgp_dense_mvm, MFMA fp32); not the headline"}
+            del Kd
+        result["extras"] = {"cached_k": cached,
+                            "block_T11_ms": round(t11 * 1e3, 4), "block_T11_mvm_equiv_per_s": round(11.0 / t11, 1),
                             "solve_Khat_inv_y": {"tolerance": 0.01, "cg_iterations": lcg.stats["last_iterations"],
                                                  "seconds": round(t_solve, 4), "relative_residual": resid}}
 

@@ -89,6 +89,26 @@ int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t 
                           void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Pair-sharding of the symmetric MVM across ranks (multi-GPU): the (row block, column chunk) tile pairs are split by
+ * contiguous row-block ranges with equal pair counts; rank r computes out_r = partial product of its tiles (row AND
+ * transposed contributions) over ALL J projections at the full per-term efficiency, and the partial N x T outputs are
+ * summed with one all-reduce — the same message as J-sharding (training_routines.py:407-408 `MultiDeviceKernel`
+ * counterpart), without the per-pair overhead of thin J-slices.  Pass noise = 0 and add noise*V after the reduce.
+ *   rpgp_mvm_sym_blocks : number of row blocks of the plan for (N, T)
+ *   rpgp_mvm_sym_shard  : balanced [rb0, rb1) of `rank` out of `world`
+ *   *_range variants    : same contracts as rpgp_mvm_sym / rpgp_mvm_sym_prepared restricted to row blocks [rb0, rb1)
+ *                         (rb1 = -1 means all).
+ */
+int rpgp_mvm_sym_blocks(int64_t N, int T);
+int rpgp_mvm_sym_shard(int64_t N, int T, int world, int rank, int *rb0_host, int *rb1_host);
+int rpgp_mvm_sym_range(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1,
+                       int rb0, int rb1, float scale, float noise,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, int64_t N, int J, int T,
+                                int j0, int j1, int rb0, int rb1, float scale, float noise,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Rectangular fused MVM:  out = scale * sum_j K_j(Z1,Z2) @ V      (Z1: M x ., Z2: N x ., V: N x T, out: M x T)
  * Replaces K(X*,X) @ alpha and K(X,X*) blocks of the prediction strategy driven from training_routines.py:551-575.
  */

@@ -129,7 +129,7 @@ template <int JT, int TT, int R, bool SYM>
 __global__ __launch_bounds__(256) void mvm_tile_kernel(
     const float *__restrict__ Z1, const float *__restrict__ Z2, const float *__restrict__ V,
     float *__restrict__ slabR, float *__restrict__ slabT, int M, int N, int ldz1, int ldz2, int ldv,
-    int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate) {
+    int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate, int rb_off) {
   constexpr int BR = 256 * R;
   constexpr int SC = StageCols<TT>::v;
   constexpr int STR = ColStride<JT>::v;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int rb = blockIdx.y;
+  const int rb = blockIdx.y + rb_off;   // row-block range [rb_off, rb_off + gridDim.y): pair-sharding across ranks
   const int kchunk = blockIdx.x;
   const int r0 = rb * BR;
   const int cbase = SYM ? r0 : 0;
@@ -364,17 +364,23 @@ __global__ __launch_bounds__(256) void prep_build_kernel(const float *__restrict
   }
 }
 
-template <int JT> struct FactStride { static constexpr int v = ((2 * JT) % 8 == 0) ? 2 * JT + 4 : ((2 * JT) % 4 == 0 ? 2 * JT : 2 * JT); };
+// LDS record of one column: NP = ceil(JT/2) float4 {b2_even, b2_odd, nb2_even, nb2_odd}; stride padded so that
+// (stride/4) is odd (conflict-free per-lane ds_read_b128)
+template <int JT> struct FactStride {
+  static constexpr int np = (JT + 1) / 2;
+  static constexpr int v = (np % 2 == 0) ? 4 * np + 4 : 4 * np;
+};
 
 // K(i, c) partial sum over JT projections in factorised form; q points at this column's packed LDS record
 // [pair p: b2_{2p}, b2_{2p+1}, nb2_{2p}, nb2_{2p+1}] (JT even) or [b2, nb2] (JT == 1)
 template <int JT>
 __device__ __forceinline__ float fact_pair_sum(const float2v (&ap)[(JT + 1) / 2], const float2v (&ea)[(JT + 1) / 2],
                                                const float *q) {
-  if constexpr (JT % 2 == 0) {
+  if constexpr (JT != 1) {
+    // odd JT: the last record's second slot is padding (b2 = 0, nb2 = -1e30 -> e = 0, and Ea = 0 on the row side)
     float2v acc = {0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < JT / 2; ++p) {
+    for (int p = 0; p < (JT + 1) / 2; ++p) {
       const float4v c = *reinterpret_cast<const float4v *>(q + 4 * p);
       const float2v b2 = {c.x, c.y};
       const float2v nb2 = {c.z, c.w};
@@ -394,7 +400,8 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
                                                        const float2v *__restrict__ coldat,
                                                        const float *__restrict__ V, float *__restrict__ slabR,
                                                        float *__restrict__ slabT, int N, int J, int ldv, int j0, int t0,
-                                                       int tcnt, int chunk_cols, int rotdir, int accumulate) {
+                                                       int tcnt, int chunk_cols, int rotdir, int accumulate,
+                                                       int rb_off) {
   constexpr int BR = 256 * R;
   constexpr int SC = StageCols<TT>::v;
   constexpr int NP = (JT + 1) / 2;
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int rb = blockIdx.y;
+  const int rb = blockIdx.y + rb_off;   // row-block range [rb_off, rb_off + gridDim.y): pair-sharding across ranks
   const int kchunk = blockIdx.x;
   const int r0 = rb * BR;
   const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
           float2v x0 = {0.f, -1.0e30f}, x1 = {0.f, -1.0e30f};   // padded columns: exp2(-1e30) = 0
           if (cv) {
             x0 = coldat[(size_t)col * J + j0 + 2 * p];
-            x1 = coldat[(size_t)col * J + j0 + 2 * p + 1];
+            if (2 * p + 1 < JT) x1 = coldat[(size_t)col * J + j0 + 2 * p + 1];
           }
           *reinterpret_cast<float4v *>(&sB[tid * STR + 4 * p]) = float4v{x0.x, x1.x, x0.y, x1.y};
         }
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
 __global__ void mvm_reduce_kernel(const float *__restrict__ slabR, const float *__restrict__ slabT,
                                   const float *__restrict__ V, float *__restrict__ out, int M, int N, int T,
                                   int BR, int chunk_cols, int sym, float scale, float noise,
-                                  const int *__restrict__ guard) {
+                                  const int *__restrict__ guard, int rb0, int rb1) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (size_t)M * T) return;
   if (guard && *guard == 0) {   // prepared (factorised) path used although rpgp_prepare flagged the range as unsafe
@@ -556,9 +563,12 @@ __global__ void mvm_reduce_kernel(const float *__restrict__ slabR, const float *
   const int cbase = sym ? rb * BR : 0;
   const int nk = (N - cbase + chunk_cols - 1) / chunk_cols;
   float acc = 0.f;
-  for (int k = 0; k < nk; ++k) acc += slabR[(size_t)k * M * T + gid];
-  if (sym)
-    for (int b = 0; b < rb; ++b) acc += slabT[(size_t)b * N * T + gid];
+  if (rb >= rb0 && rb < rb1)                      // row products exist only for this call's row blocks
+    for (int k = 0; k < nk; ++k) acc += slabR[(size_t)k * M * T + gid];
+  if (sym) {
+    const int bend = rb < rb1 ? rb : rb1;         // transposed products written by row blocks rb0 <= b < min(rb, rb1)
+    for (int b = rb0; b < bend; ++b) acc += slabT[(size_t)b * N * T + gid];
+  }
   float r = scale * acc;
   if (noise != 0.f) r = __builtin_fmaf(noise, V[gid], r);
   out[gid] = r;
@@ -1323,7 +1333,8 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 inline int launch_status() { return (int)hipGetLastError(); }
 
 // decomposition of a j-range into the compiled JT pieces
-const int kJPieces[] = {20, 8, 4, 2, 1};
+// 10 / 5 / 3 make the J-shards of 2 / 4 / 8 ranks (J = 20) a single sweep per MVM
+const int kJPieces[] = {20, 10, 8, 5, 4, 3, 2, 1};
 inline int next_j_piece(int remaining) {
   for (int p : kJPieces)
     if (p <= remaining) return p;
@@ -1339,6 +1350,7 @@ inline int next_t_piece(int remaining) {
 }
 
 struct TilePlan {
+  int rb0, rb1;    // row-block range handled by this call (pair-sharding); default = all
   int R;           // rows per lane
   int BR;          // rows per workgroup
   int nrb;         // row blocks
@@ -1363,6 +1375,8 @@ inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T) {
   if (chunk > 8192) chunk = 8192;
   p.chunk_cols = chunk;
   p.maxchunks = (int)((N + chunk - 1) / chunk);
+  p.rb0 = 0;
+  p.rb1 = p.nrb;
   return p;
 }
 
@@ -1370,13 +1384,13 @@ template <int JT, int TT, bool SYM>
 int launch_mvm_tile(const TilePlan &p, const float *Z1, const float *Z2, const float *V, float *slabR, float *slabT,
                     int M, int N, int ldz1, int ldz2, int ldv, int j0, int t0, int tcnt, int accumulate,
                     hipStream_t st) {
-  dim3 grid(p.maxchunks, p.nrb), block(256);
+  dim3 grid(p.maxchunks, p.rb1 - p.rb0), block(256);
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 2, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
-                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate);
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0);
   else
     hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 1, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
-                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate);
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0);
   return launch_status();
 }
 
@@ -1397,7 +1411,10 @@ int dispatch_jt(int jt, int tt, const TilePlan &p, const float *Z1, const float 
                 hipStream_t st) {
   switch (jt) {
     case 20: return dispatch_t<20, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    case 10: return dispatch_t<10, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
     case 8: return dispatch_t<8, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    case 5: return dispatch_t<5, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
+    case 3: return dispatch_t<3, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
     case 4: return dispatch_t<4, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
     case 2: return dispatch_t<2, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
     default: return dispatch_t<1, SYM>(tt, p, Z1, Z2, V, slabR, slabT, M, N, ldz1, ldz2, ldv, j0, t0, tcnt, accumulate, st);
@@ -1413,7 +1430,8 @@ inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym) {
 
 template <bool SYM>
 int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int64_t M, int64_t N, int ldz1,
-               int ldz2, int T, int j0, int j1, float scale, float noise, void *ws, size_t ws_bytes, void *stream) {
+               int ldz2, int T, int j0, int j1, float scale, float noise, void *ws, size_t ws_bytes, void *stream,
+               int rb0 = 0, int rb1 = -1) {
   if (!Z1 || !Z2 || !V || !out || M <= 0 || N <= 0 || T <= 0 || j0 < 0 || j1 <= j0 || ldz1 < j1 || ldz2 < j1)
     return RPGP_EINVAL;
   if (M > 0x7fffffffLL || N > 0x7fffffffLL) return RPGP_EINVAL;
@@ -1422,13 +1440,18 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
   const size_t need = mvm_workspace_floats(M, N, T, SYM) * sizeof(float);
   if (!ws || ws_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const TilePlan p = make_plan(M, N, SYM, T);
+  TilePlan p = make_plan(M, N, SYM, T);
+  if (rb1 >= 0) {
+    if (rb0 < 0 || rb1 > p.nrb || rb0 > rb1) return RPGP_EINVAL;
+    p.rb0 = rb0;
+    p.rb1 = rb1;
+  }
   float *slabR = reinterpret_cast<float *>(ws);
   float *slabT = slabR + (size_t)p.maxchunks * M * T;
   int first = 1;
   const bool prof = g_prof_on && g_prof_n < kProfMax;
   if (prof) RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
-  for (int j = j0; j < j1;) {
+  for (int j = j0; j < j1 && p.rb1 > p.rb0;) {
     const int jt = next_j_piece(j1 - j);
     for (int t0 = 0; t0 < T;) {
       const int tt = next_t_piece(T - t0);
@@ -1447,7 +1470,8 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
   }
   const size_t total = (size_t)M * T;
   hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V,
-                     out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise, (const int *)nullptr);
+                     out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise, (const int *)nullptr, p.rb0,
+                     p.rb1);
   return launch_status();
 }
 
@@ -1455,13 +1479,13 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
 template <int JT, int TT>
 int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *coldat, const float *V, float *slabR,
                     float *slabT, int N, int J, int ldv, int j0, int t0, int tcnt, int accumulate, hipStream_t st) {
-  dim3 grid(p.maxchunks, p.nrb), block(256);
+  dim3 grid(p.maxchunks, p.rb1 - p.rb0), block(256);
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 2>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
-                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate);
+                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0);
   else
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 1>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
-                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate);
+                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0);
   return launch_status();
 }
 
@@ -1481,7 +1505,10 @@ inline int dispatch_fact_jt(int jt, int tt, const TilePlan &p, const float2v *ro
                             int tcnt, int accumulate, hipStream_t st) {
   switch (jt) {
     case 20: return dispatch_fact_t<20>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    case 10: return dispatch_fact_t<10>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
     case 8: return dispatch_fact_t<8>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    case 5: return dispatch_fact_t<5>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
+    case 3: return dispatch_fact_t<3>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
     case 4: return dispatch_fact_t<4>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
     case 2: return dispatch_fact_t<2>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
     default: return dispatch_fact_t<1>(tt, p, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0, tcnt, accumulate, st);
@@ -1662,6 +1689,51 @@ int rpgp_prepare_status(const void *prep, int *fast_ok_host, float *max_abs_host
 
 int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t N, int J, int T, int j0, int j1,
                           float scale, float noise, void *workspace, size_t workspace_bytes, void *stream) {
+  return rpgp_mvm_sym_prepared_range(prep, V, out, N, J, T, j0, j1, 0, -1, scale, noise, workspace, workspace_bytes,
+                                     stream);
+}
+
+int rpgp_mvm_sym_blocks(int64_t N, int T) {
+  if (N <= 0 || T <= 0) return 0;
+  return make_plan(N, N, true, T).nrb;
+}
+
+int rpgp_mvm_sym_shard(int64_t N, int T, int world, int rank, int *rb0_host, int *rb1_host) {
+  if (N <= 0 || T <= 0 || world <= 0 || rank < 0 || rank >= world || !rb0_host || !rb1_host) return RPGP_EINVAL;
+  const TilePlan p = make_plan(N, N, true, T);
+  // contiguous ranges of row blocks with equal numbers of (row, column) pairs: block b sweeps columns [b*BR, N)
+  double total = 0.0;
+  for (int b = 0; b < p.nrb; ++b) {
+    const double rows = (double)((b + 1) * (long long)p.BR < N ? p.BR : N - (long long)b * p.BR);
+    total += rows * (double)(N - (long long)b * p.BR);
+  }
+  int bounds[2] = {0, p.nrb};
+  double acc = 0.0;
+  int b = 0;
+  for (int side = 0; side < 2; ++side) {
+    const double target = total * (double)(rank + side) / (double)world;
+    while (b < p.nrb && acc < target - 1e-9) {
+      const double rows = (double)((b + 1) * (long long)p.BR < N ? p.BR : N - (long long)b * p.BR);
+      acc += rows * (double)(N - (long long)b * p.BR);
+      ++b;
+    }
+    bounds[side] = b;
+  }
+  if (rank == world - 1) bounds[1] = p.nrb;
+  *rb0_host = bounds[0];
+  *rb1_host = bounds[1];
+  return 0;
+}
+
+int rpgp_mvm_sym_range(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1, int rb0,
+                       int rb1, float scale, float noise, void *workspace, size_t workspace_bytes, void *stream) {
+  return mvm_common<true>(Z, Z, V, out, N, N, ldz, ldz, T, j0, j1, scale, noise, workspace, workspace_bytes, stream, rb0,
+                          rb1);
+}
+
+int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, int64_t N, int J, int T, int j0, int j1,
+                                int rb0, int rb1, float scale, float noise, void *workspace, size_t workspace_bytes,
+                                void *stream) {
   if (!prep || !V || !out || N <= 0 || T <= 0 || J <= 0 || J > kPrepMidFloats || j0 < 0 || j1 <= j0 || j1 > J)
     return RPGP_EINVAL;
   if (N > 0x7fffffffLL) return RPGP_EINVAL;
@@ -1670,14 +1742,19 @@ int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t 
   const size_t need = mvm_workspace_floats(N, N, T, true) * sizeof(float);
   if (!workspace || workspace_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const TilePlan p = make_plan(N, N, true, T);
+  TilePlan p = make_plan(N, N, true, T);
+  if (rb1 >= 0) {
+    if (rb0 < 0 || rb1 > p.nrb || rb0 > rb1) return RPGP_EINVAL;
+    p.rb0 = rb0;
+    p.rb1 = rb1;
+  }
   PrepLayout L = prep_layout(const_cast<void *>(prep), N, J);
   float *slabR = reinterpret_cast<float *>(workspace);
   float *slabT = slabR + (size_t)p.maxchunks * N * T;
   int first = 1;
   const bool prof = g_prof_on && g_prof_n < kProfMax;
   if (prof) RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
-  for (int j = j0; j < j1;) {
+  for (int j = j0; j < j1 && p.rb1 > p.rb0;) {
     const int jt = next_j_piece(j1 - j);
     for (int t0 = 0; t0 < T;) {
       const int tt = next_t_piece(T - t0);
@@ -1696,7 +1773,7 @@ int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t 
   const size_t total = (size_t)N * T;
   hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V, out,
                      (int)N, (int)N, T, p.BR, p.chunk_cols, 1, scale, noise,
-                     reinterpret_cast<const int *>(L.header));
+                     reinterpret_cast<const int *>(L.header), p.rb0, p.rb1);
   return launch_status();
 }
 
@@ -1724,7 +1801,10 @@ int rpgp_dense(const float *Z1, const float *Z2, float *out, int64_t M, int64_t 
     int rc;
     switch (jt) {
       case 20: rc = launch_dense<20>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
+      case 10: rc = launch_dense<10>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
       case 8: rc = launch_dense<8>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
+      case 5: rc = launch_dense<5>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
+      case 3: rc = launch_dense<3>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
       case 4: rc = launch_dense<4>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
       case 2: rc = launch_dense<2>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
       default: rc = launch_dense<1>(Z1, Z2, out, (int)M, (int)N, ldz1, ldz2, ldo, j, scale, !first, st); break;
@@ -1763,7 +1843,10 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
     int rc;
     switch (jt) {
       case 20: rc = launch_bilinear<20>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
+      case 10: rc = launch_bilinear<10>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
       case 8: rc = launch_bilinear<8>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
+      case 5: rc = launch_bilinear<5>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
+      case 3: rc = launch_bilinear<3>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
       case 4: rc = launch_bilinear<4>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
       case 2: rc = launch_bilinear<2>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
       default: rc = launch_bilinear<1>(T, Z, L, R, slabG, slabS, (int)N, ldz, T, j, cps, ns, st); break;
@@ -1802,7 +1885,10 @@ int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *g
     int rc;
     switch (jt) {
       case 20: rc = launch_bilinear_dense<20>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
+      case 10: rc = launch_bilinear_dense<10>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
       case 8: rc = launch_bilinear_dense<8>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
+      case 5: rc = launch_bilinear_dense<5>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
+      case 3: rc = launch_bilinear_dense<3>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
       case 4: rc = launch_bilinear_dense<4>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
       case 2: rc = launch_bilinear_dense<2>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;
       default: rc = launch_bilinear_dense<1>(Z, S, slabG, slabS, (int)N, ldz, lds_, j, cps, ns, st); break;

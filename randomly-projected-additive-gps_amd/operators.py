@@ -129,13 +129,21 @@ class AdditiveRPOperator(LinearOperator):
         j0, j1 = self._jrange()
         z1 = self.Z1.detach()
         if self.symmetric:
+            kw = {}
+            if self.shard is not None and self.shard.world_size > 1:
+                rng = self.shard.row_block_range(be, z1.shape[0], rhs.shape[-1])
+                if rng is not None:                 # pair-sharding: all projections on this rank's row blocks
+                    j0, j1 = 0, self.num_projections
+                    kw = {"rb0": rng[0], "rb1": rng[1]}
+                elif j1 <= j0:                      # J-sharding with more ranks than projections: nothing to do here
+                    return torch.zeros_like(rhs)
             prepare = getattr(be, "prepare", None)
             if prepare is not None:
                 if self._prep is None:
                     self._prep = prepare(z1)        # once per operator (= per hyper-parameter step), one host sync
                 if self._prep.fast_ok:
-                    return be.mvm_sym_prepared(self._prep, rhs, self._scale, noise, j0=j0, j1=j1)
-            return be.mvm_sym(z1, rhs, self._scale, noise, j0=j0, j1=j1)
+                    return be.mvm_sym_prepared(self._prep, rhs, self._scale, noise, j0=j0, j1=j1, **kw)
+            return be.mvm_sym(z1, rhs, self._scale, noise, j0=j0, j1=j1, **kw)
         return be.mvm_rect(z1, self.Z2.detach(), rhs, self._scale, j0=j0, j1=j1)
 
     def _matmul(self, rhs, noise=0.0):

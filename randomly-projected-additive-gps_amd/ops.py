@@ -81,8 +81,17 @@ def _as_matrix(V, N, name):
     return V2, squeeze
 
 
-def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None):
-    """out = scale * sum_{j in [j0,j1)} K_j(Z,Z) @ V + noise * V."""
+def mvm_shard(N, T, world, rank):
+    """Balanced row-block range [rb0, rb1) of `rank` for pair-sharding the symmetric MVM (host-only computation)."""
+    import ctypes
+    lib = _lib.load()
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.rpgp_mvm_sym_shard(N, T, world, rank, ctypes.byref(a), ctypes.byref(b)), "rpgp_mvm_sym_shard")
+    return a.value, b.value
+
+
+def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, rb1=-1):
+    """out = scale * sum_{j in [j0,j1)} K_j(Z,Z) @ V + noise * V   (restricted to row blocks [rb0, rb1) if rb1 >= 0)."""
     lib = _lib.load()
     Z = _require(Z, "Z", 2)
     N, J = Z.shape
@@ -94,8 +103,9 @@ def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None):
     with torch.cuda.device(Z.device):
         nbytes = lib.rpgp_mvm_sym_workspace_bytes(N, T)
         ws = _workspace(Z.device, nbytes)
-        _lib.check(lib.rpgp_mvm_sym(Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1, float(scale),
-                                    float(noise), ws.data_ptr(), ws.numel(), _stream()), "rpgp_mvm_sym")
+        _lib.check(lib.rpgp_mvm_sym_range(Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1, rb0, rb1,
+                                          float(scale), float(noise), ws.data_ptr(), ws.numel(), _stream()),
+                   "rpgp_mvm_sym")
     return out.squeeze(1) if squeeze else out
 
 
@@ -125,7 +135,7 @@ class Prepared:
         self.max_abs = float(mx.value)
 
 
-def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None):
+def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, rb1=-1):
     """Factorised fast path: same result contract as mvm_sym for the Z that `prep` was built from."""
     lib = _lib.load()
     if not prep.fast_ok:
@@ -140,9 +150,9 @@ def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None):
     with torch.cuda.device(prep.device):
         nbytes = lib.rpgp_mvm_sym_workspace_bytes(N, T)
         ws = _workspace(prep.device, nbytes)
-        _lib.check(lib.rpgp_mvm_sym_prepared(prep.buf.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1,
-                                             float(scale), float(noise), ws.data_ptr(), ws.numel(), _stream()),
-                   "rpgp_mvm_sym_prepared")
+        _lib.check(lib.rpgp_mvm_sym_prepared_range(prep.buf.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1,
+                                                   rb0, rb1, float(scale), float(noise), ws.data_ptr(), ws.numel(),
+                                                   _stream()), "rpgp_mvm_sym_prepared")
     return out.squeeze(1) if squeeze else out
 
 

@@ -223,3 +223,22 @@ def test_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, rank):
     eg = (K - Lg.double() @ Lg.double().t()).abs().max().item()
     assert ef <= eg * 1.05 + 1e-5
     assert torch.allclose(Lf, Lg, rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("N,T,world", [(3000, 1, 3), (20000, 1, 8), (5000, 11, 4), (700, 4, 2)])
+def test_pair_sharded_mvm_sums_to_full(gpu_device, N, T, world):
+    """Pair-sharding (rpgp_mvm_sym_shard + *_range): the per-rank partial products sum to the full MVM, for the direct
+    and the prepared kernels; the ranges are contiguous, disjoint and cover all row blocks."""
+    from rpgp_amd import ops, _lib
+    Z, V = _data(N, 20, T, seed=N)
+    Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
+    full = ops.mvm_sym(Zt, Vt, 0.05, 0.0)
+    prep = ops.Prepared(Zt)
+    nblk = _lib.load().rpgp_mvm_sym_blocks(N, T)
+    ranges = [ops.mvm_shard(N, T, world, r) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == nblk
+    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    acc_d = sum(ops.mvm_sym(Zt, Vt, 0.05, 0.0, rb0=a, rb1=b) for a, b in ranges)
+    acc_p = sum(ops.mvm_sym_prepared(prep, Vt, 0.05, 0.0, rb0=a, rb1=b) for a, b in ranges)
+    assert _rel(acc_d.cpu().numpy(), full.cpu().numpy()) < 2e-6
+    assert _rel(acc_p.cpu().numpy(), full.cpu().numpy()) < 2e-6

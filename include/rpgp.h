@@ -99,6 +99,7 @@ int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t 
  *   *_range variants    : same contracts as rpgp_mvm_sym / rpgp_mvm_sym_prepared restricted to row blocks [rb0, rb1)
  *                         (rb1 = -1 means all).
  */
+size_t rpgp_mvm_sym_range_workspace_bytes(int64_t N, int T, int rb0, int rb1);  /* workspace of a *_range call */
 int rpgp_mvm_sym_blocks(int64_t N, int T);
 int rpgp_mvm_sym_shard(int64_t N, int T, int world, int rank, int *rb0_host, int *rb1_host);
 int rpgp_mvm_sym_range(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1,

@@ -129,7 +129,7 @@ template <int JT, int TT, int R, bool SYM>
 __global__ __launch_bounds__(256) void mvm_tile_kernel(
     const float *__restrict__ Z1, const float *__restrict__ Z2, const float *__restrict__ V,
     float *__restrict__ slabR, float *__restrict__ slabT, int M, int N, int ldz1, int ldz2, int ldv,
-    int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate, int rb_off) {
+    int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate, int rb_off, int slab_row0, int slab_rows) {
   constexpr int BR = 256 * R;
   constexpr int SC = StageCols<TT>::v;
   constexpr int STR = ColStride<JT>::v;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
           if (t < tcnt) {
             float sum = sT[(0 * SC + tid) * TT + t] + sT[(1 * SC + tid) * TT + t] +
                         sT[(2 * SC + tid) * TT + t] + sT[(3 * SC + tid) * TT + t];
-            float *dst = slabT + ((size_t)rb * N + col) * ldv + t0 + t;
+            float *dst = slabT + ((size_t)blockIdx.y * N + col) * ldv + t0 + t;
             *dst = accumulate ? *dst + sum : sum;
           }
         }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         if (t < tcnt) {
-          float *dst = slabR + ((size_t)kchunk * M + row) * ldv + t0 + t;
+          float *dst = slabR + ((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0 + t;
           *dst = accumulate ? *dst + accR[r][t] : accR[r][t];
         }
       }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
                                                        const float *__restrict__ V, float *__restrict__ slabR,
                                                        float *__restrict__ slabT, int N, int J, int ldv, int j0, int t0,
                                                        int tcnt, int chunk_cols, int rotdir, int accumulate,
-                                                       int rb_off) {
+                                                       int rb_off, int slab_row0, int slab_rows) {
   constexpr int BR = 256 * R;
   constexpr int SC = StageCols<TT>::v;
   constexpr int NP = (JT + 1) / 2;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
           if (t < tcnt) {
             float sum = sT[(0 * SC + tid) * TT + t] + sT[(1 * SC + tid) * TT + t] +
                         sT[(2 * SC + tid) * TT + t] + sT[(3 * SC + tid) * TT + t];
-            float *dst = slabT + ((size_t)rb * N + col) * ldv + t0 + t;
+            float *dst = slabT + ((size_t)blockIdx.y * N + col) * ldv + t0 + t;
             *dst = accumulate ? *dst + sum : sum;
           }
         }
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         if (t < tcnt) {
-          float *dst = slabR + ((size_t)kchunk * N + row) * ldv + t0 + t;
+          float *dst = slabR + ((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0 + t;
           *dst = accumulate ? *dst + accR[r][t] : accR[r][t];
         }
       }
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
 __global__ void mvm_reduce_kernel(const float *__restrict__ slabR, const float *__restrict__ slabT,
                                   const float *__restrict__ V, float *__restrict__ out, int M, int N, int T,
                                   int BR, int chunk_cols, int sym, float scale, float noise,
-                                  const int *__restrict__ guard, int rb0, int rb1) {
+                                  const int *__restrict__ guard, int rb0, int rb1, int slab_row0, int slab_rows) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (size_t)M * T) return;
   if (guard && *guard == 0) {   // prepared (factorised) path used although rpgp_prepare flagged the range as unsafe
@@ -563,11 +563,13 @@ __global__ void mvm_reduce_kernel(const float *__restrict__ slabR, const float *
   const int cbase = sym ? rb * BR : 0;
   const int nk = (N - cbase + chunk_cols - 1) / chunk_cols;
   float acc = 0.f;
-  if (rb >= rb0 && rb < rb1)                      // row products exist only for this call's row blocks
-    for (int k = 0; k < nk; ++k) acc += slabR[(size_t)k * M * T + gid];
+  if (rb >= rb0 && rb < rb1) {                    // row products exist only for this call's row blocks
+    const size_t lid = gid - (size_t)slab_row0 * T;
+    for (int k = 0; k < nk; ++k) acc += slabR[(size_t)k * slab_rows * T + lid];
+  }
   if (sym) {
     const int bend = rb < rb1 ? rb : rb1;         // transposed products written by row blocks rb0 <= b < min(rb, rb1)
-    for (int b = rb0; b < bend; ++b) acc += slabT[(size_t)b * N * T + gid];
+    for (int b = rb0; b < bend; ++b) acc += slabT[(size_t)(b - rb0) * N * T + gid];
   }
   float r = scale * acc;
   if (noise != 0.f) r = __builtin_fmaf(noise, V[gid], r);
@@ -1351,6 +1353,7 @@ inline int next_t_piece(int remaining) {
 
 struct TilePlan {
   int rb0, rb1;    // row-block range handled by this call (pair-sharding); default = all
+  int row0, rows;  // first row / number of rows of that range (slab addressing)
   int R;           // rows per lane
   int BR;          // rows per workgroup
   int nrb;         // row blocks
@@ -1358,25 +1361,43 @@ struct TilePlan {
   int maxchunks;   // grid.x
 };
 
-inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T) {
+inline int plan_chunk(double pairs, int BR, bool big) {
+  // aim for ~4600 workgroups (6 rounds of 3 workgroups per CU) so the dispatcher can balance the triangular sweep;
+  // chunks are multiples of 64 columns (one rotation subtile), at least 128 (64 for small problems)
+  double cc = pairs / ((double)BR * 4608.0);
+  int chunk = (int)((cc + 63.0) / 64.0) * 64;
+  const int min_chunk = big ? 128 : 64;
+  if (chunk < min_chunk) chunk = min_chunk;
+  if (chunk > 8192) chunk = 8192;
+  return chunk;
+}
+
+inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int rb0 = 0, int rb1 = -1) {
   TilePlan p;
   // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
   p.R = (M >= 16384) ? 2 : 1;
   (void)T;
   p.BR = 256 * p.R;
   p.nrb = (int)((M + p.BR - 1) / p.BR);
-  // aim for ~4600 workgroups (6 rounds of 3 workgroups per CU) so the dispatcher can balance the triangular sweep;
-  // chunks are multiples of 64 columns (one rotation subtile), at least 128 (64 for small problems)
-  const double pairs = sym ? 0.5 * (double)M * (double)N : (double)M * (double)N;
-  double cc = pairs / ((double)p.BR * 4608.0);
-  int chunk = (int)((cc + 63.0) / 64.0) * 64;
-  const int min_chunk = (M >= 16384) ? 128 : 64;
-  if (chunk < min_chunk) chunk = min_chunk;
-  if (chunk > 8192) chunk = 8192;
-  p.chunk_cols = chunk;
-  p.maxchunks = (int)((N + chunk - 1) / chunk);
   p.rb0 = 0;
   p.rb1 = p.nrb;
+  if (rb1 >= 0) {
+    p.rb0 = rb0 < 0 ? 0 : (rb0 > p.nrb ? p.nrb : rb0);
+    p.rb1 = rb1 > p.nrb ? p.nrb : (rb1 < p.rb0 ? p.rb0 : rb1);
+  }
+  p.row0 = p.rb0 * p.BR;
+  const long long rend = (long long)p.rb1 * p.BR < M ? (long long)p.rb1 * p.BR : M;
+  p.rows = (int)(rend - p.row0 > 0 ? rend - p.row0 : 0);
+  // pairs handled by this call: row block b sweeps columns [b*BR, N) (symmetric) or all N columns
+  double pairs = 0.0;
+  for (int b = p.rb0; b < p.rb1; ++b) {
+    const double rows = (double)(((long long)(b + 1) * p.BR < M) ? p.BR : M - (long long)b * p.BR);
+    pairs += rows * (sym ? (double)(N - (long long)b * p.BR) : (double)N);
+  }
+  p.chunk_cols = plan_chunk(pairs, p.BR, M >= 16384);
+  const long long first_col = sym ? (long long)p.row0 : 0;
+  p.maxchunks = (int)((N - first_col + p.chunk_cols - 1) / p.chunk_cols);
+  if (p.maxchunks < 1) p.maxchunks = 1;
   return p;
 }
 
@@ -1387,10 +1408,10 @@ int launch_mvm_tile(const TilePlan &p, const float *Z1, const float *Z2, const f
   dim3 grid(p.maxchunks, p.rb1 - p.rb0), block(256);
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 2, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
-                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0);
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0, p.row0, p.rows);
   else
     hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 1, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
-                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0);
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0, p.row0, p.rows);
   return launch_status();
 }
 
@@ -1421,10 +1442,10 @@ int dispatch_jt(int jt, int tt, const TilePlan &p, const float *Z1, const float 
   }
 }
 
-inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym) {
-  const TilePlan p = make_plan(M, N, sym, T);
-  size_t f = (size_t)p.maxchunks * M * T;
-  if (sym) f += (size_t)p.nrb * N * T;
+inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int rb0 = 0, int rb1 = -1) {
+  const TilePlan p = make_plan(M, N, sym, T, rb0, rb1);
+  size_t f = (size_t)p.maxchunks * p.rows * T;
+  if (sym) f += (size_t)(p.rb1 - p.rb0) * N * T;
   return f;
 }
 
@@ -1437,17 +1458,13 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
   if (M > 0x7fffffffLL || N > 0x7fffffffLL) return RPGP_EINVAL;
   int rc = rpgp_init();
   if (rc) return rc;
-  const size_t need = mvm_workspace_floats(M, N, T, SYM) * sizeof(float);
+  if (rb1 >= 0 && (rb0 < 0 || rb0 > rb1)) return RPGP_EINVAL;
+  const size_t need = mvm_workspace_floats(M, N, T, SYM, rb0, rb1) * sizeof(float);
   if (!ws || ws_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  TilePlan p = make_plan(M, N, SYM, T);
-  if (rb1 >= 0) {
-    if (rb0 < 0 || rb1 > p.nrb || rb0 > rb1) return RPGP_EINVAL;
-    p.rb0 = rb0;
-    p.rb1 = rb1;
-  }
+  const TilePlan p = make_plan(M, N, SYM, T, rb0, rb1);
   float *slabR = reinterpret_cast<float *>(ws);
-  float *slabT = slabR + (size_t)p.maxchunks * M * T;
+  float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
   int first = 1;
   const bool prof = g_prof_on && g_prof_n < kProfMax;
   if (prof) RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
@@ -1471,7 +1488,7 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
   const size_t total = (size_t)M * T;
   hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V,
                      out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise, (const int *)nullptr, p.rb0,
-                     p.rb1);
+                     p.rb1, p.row0, p.rows);
   return launch_status();
 }
 
@@ -1482,10 +1499,10 @@ int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *col
   dim3 grid(p.maxchunks, p.rb1 - p.rb0), block(256);
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 2>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
-                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0);
+                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0, p.row0, p.rows);
   else
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 1>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
-                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0);
+                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0, p.row0, p.rows);
   return launch_status();
 }
 
@@ -1693,6 +1710,11 @@ int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t 
                                      stream);
 }
 
+size_t rpgp_mvm_sym_range_workspace_bytes(int64_t N, int T, int rb0, int rb1) {
+  if (N <= 0 || T <= 0) return 0;
+  return mvm_workspace_floats(N, N, T, true, rb0, rb1) * sizeof(float);
+}
+
 int rpgp_mvm_sym_blocks(int64_t N, int T) {
   if (N <= 0 || T <= 0) return 0;
   return make_plan(N, N, true, T).nrb;
@@ -1739,18 +1761,14 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
   if (N > 0x7fffffffLL) return RPGP_EINVAL;
   int rc = rpgp_init();
   if (rc) return rc;
-  const size_t need = mvm_workspace_floats(N, N, T, true) * sizeof(float);
+  if (rb1 >= 0 && (rb0 < 0 || rb0 > rb1)) return RPGP_EINVAL;
+  const size_t need = mvm_workspace_floats(N, N, T, true, rb0, rb1) * sizeof(float);
   if (!workspace || workspace_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  TilePlan p = make_plan(N, N, true, T);
-  if (rb1 >= 0) {
-    if (rb0 < 0 || rb1 > p.nrb || rb0 > rb1) return RPGP_EINVAL;
-    p.rb0 = rb0;
-    p.rb1 = rb1;
-  }
+  const TilePlan p = make_plan(N, N, true, T, rb0, rb1);
   PrepLayout L = prep_layout(const_cast<void *>(prep), N, J);
   float *slabR = reinterpret_cast<float *>(workspace);
-  float *slabT = slabR + (size_t)p.maxchunks * N * T;
+  float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
   int first = 1;
   const bool prof = g_prof_on && g_prof_n < kProfMax;
   if (prof) RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
@@ -1773,7 +1791,7 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
   const size_t total = (size_t)N * T;
   hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V, out,
                      (int)N, (int)N, T, p.BR, p.chunk_cols, 1, scale, noise,
-                     reinterpret_cast<const int *>(L.header), p.rb0, p.rb1);
+                     reinterpret_cast<const int *>(L.header), p.rb0, p.rb1, p.row0, p.rows);
   return launch_status();
 }
 

@@ -101,7 +101,7 @@ def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, rb1=-1):
     if out is None:
         out = torch.empty_like(V2)
     with torch.cuda.device(Z.device):
-        nbytes = lib.rpgp_mvm_sym_workspace_bytes(N, T)
+        nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, rb0, rb1)
         ws = _workspace(Z.device, nbytes)
         _lib.check(lib.rpgp_mvm_sym_range(Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1, rb0, rb1,
                                           float(scale), float(noise), ws.data_ptr(), ws.numel(), _stream()),
@@ -148,7 +148,7 @@ def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, 
     if out is None:
         out = torch.empty_like(V2)
     with torch.cuda.device(prep.device):
-        nbytes = lib.rpgp_mvm_sym_workspace_bytes(N, T)
+        nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, rb0, rb1)
         ws = _workspace(prep.device, nbytes)
         _lib.check(lib.rpgp_mvm_sym_prepared_range(prep.buf.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1,
                                                    rb0, rb1, float(scale), float(noise), ws.data_ptr(), ws.numel(),

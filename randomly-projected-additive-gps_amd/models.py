@@ -16,6 +16,37 @@ from .operators import AddedDiagOperator, AdditiveRPOperator, DenseOperator
 from .precond import build_preconditioner
 
 
+def lanczos_inverse_root(matmul, init_vec, rank):
+    """LOVE cache (GPyTorch `fast_pred_var`, `--fast_pred`, gp_experiment_runner.py:235,327): R (N x k) with
+    Khat^-1 ~= R R^T from k = `max_root_decomposition_size` Lanczos steps with full re-orthogonalisation started at
+    `init_vec`; k operator applications with T = 1."""
+    N = init_vec.shape[0]
+    k = min(rank, N)
+    Q = torch.zeros(N, k, dtype=init_vec.dtype, device=init_vec.device)
+    alpha = torch.zeros(k, dtype=torch.float64)
+    beta = torch.zeros(k, dtype=torch.float64)
+    q = init_vec / init_vec.norm()
+    m = 0
+    for i in range(k):
+        Q[:, i] = q
+        w = matmul(q.reshape(-1, 1)).reshape(-1)
+        a = torch.dot(w, q)
+        w = w - a * q - (beta[i - 1].to(w.dtype) * Q[:, i - 1] if i > 0 else 0.0)
+        for _ in range(2):                                   # full re-orthogonalisation (twice is enough)
+            w = w - Q[:, :i + 1] @ (Q[:, :i + 1].t() @ w)
+        b = w.norm()
+        alpha[i] = float(a)
+        m = i + 1
+        if float(b) < 1e-6 * abs(float(a)) or i == k - 1:
+            break
+        beta[i] = float(b)
+        q = w / b
+    Tm = torch.diag(alpha[:m]) + torch.diag(beta[:m - 1], 1) + torch.diag(beta[:m - 1], -1)
+    evals, evecs = torch.linalg.eigh(Tm)
+    evals = evals.clamp_min(1e-10)
+    return Q[:, :m] @ (evecs / evals.sqrt()).to(Q.dtype).to(Q.device)
+
+
 class PredictionStrategy:
     """Caches alpha = Khat^-1 (y - c) (the `mean_cache`) and produces predictive mean / covariance:
        mu* = K(X*,X) alpha + c ;  Sigma* = K(X*,X*) - K(X*,X) Khat^-1 K(X,X*)."""
@@ -85,6 +116,14 @@ class PredictionStrategy:
             if self.dense_path:
                 Kx = cross._get_rows(torch.arange(n_test, device=xs.device)).t().contiguous()   # K(X, X*)
                 cov -= Kx.t() @ torch.cholesky_solve(Kx, self.chol)
+            elif settings.fast_pred_var.on():
+                # LOVE: Sigma* ~= K** - (K*x R)(K*x R)^T with the cached rank-k Lanczos inverse root R
+                if getattr(self, "_love_root", None) is None:
+                    init = cross._transpose_nonbatch()._matmul(torch.ones(n_test, 1, dtype=cov.dtype, device=cov.device))
+                    self._love_root = lanczos_inverse_root(self.khat._matmul, init.reshape(-1),
+                                                           settings.max_root_decomposition_size.value())
+                KR = cross._matmul(self._love_root)                  # (N* x k)
+                cov -= KR @ KR.t()
             else:
                 khat = self.khat
                 total_mem = torch.cuda.get_device_properties(xs.device).total_memory if xs.is_cuda else float("inf")

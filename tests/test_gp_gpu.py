@@ -178,3 +178,20 @@ def test_cached_kernel_mode_matches_fused(gpu_device):
     assert abs(vals[0][0] - vals[1][0]) < 1e-5 * abs(vals[0][0])
     assert torch.allclose(vals[0][1], vals[1][1], rtol=1e-3, atol=1e-6)
     assert abs(vals[0][2] - vals[1][2]) < 1e-4 * abs(vals[0][2])
+
+
+def test_fast_pred_var_love_on_gpu(gpu_device):
+    """--fast_pred (LOVE, rank-100 Lanczos inverse root through the fused MVM): conservative variances close to exact."""
+    from rpgp_amd import settings
+    prob, model, lik, mll = _gpu_model(gpu_device, 2600, 8, 20, 2, 0.15)
+    X, y, P, ls, noise, s = prob
+    ref = _oracle_gp(X, y, P, ls, noise, s)
+    Xs = torch.randn(64, 8, generator=torch.Generator().manual_seed(5))
+    mean_ref, var_ref = ref.predict(Xs.numpy())
+    model.eval()
+    with torch.no_grad(), settings.eval_cg_tolerance(1e-6), settings.fast_pred_var(True):
+        out = model(Xs.to(gpu_device))
+    assert np.linalg.norm(out.mean.cpu().numpy() - mean_ref) / np.linalg.norm(mean_ref) < 1e-4
+    var = out.variance.cpu().numpy()
+    assert (var - var_ref).min() > -1e-4
+    assert np.abs(var - var_ref).mean() / var_ref.mean() < 0.25

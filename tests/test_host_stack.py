@@ -367,3 +367,26 @@ def test_ski_model_matches_dense_ski_oracle(oracle_backend):
     ex_mean, ex_var = orc.DenseExactGP(X.numpy(), y.numpy(), P.numpy(), ls.numpy(), s, noise).predict(Xs.numpy())
     np.testing.assert_allclose(out.mean.numpy(), ex_mean, rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(out.variance.numpy(), ex_var, rtol=2e-2, atol=1e-3)
+
+
+def test_fast_pred_var_love(oracle_backend):
+    """`--fast_pred` (LOVE): with a full-rank Lanczos root the predictive covariance equals the exact one; with a low
+    rank it is a conservative (larger-variance) approximation that improves with the rank."""
+    from rpgp_amd import settings
+    X, y, P, ls, noise, s = _problem(N=120, seed=13)
+    Xs = torch.randn(25, X.shape[1], generator=torch.Generator().manual_seed(4))
+    model, lik, mll = _build_model(X, y, P, ls, noise, s)
+    ref = _oracle_gp(X, y, P, ls, noise, s)
+    mean_ref, cov_ref = ref.predict(Xs.numpy(), full_cov=True)
+    errs = []
+    for rank in (120, 40, 10):
+        model.train()
+        model.eval()
+        with settings.max_cholesky_size(0), settings.eval_cg_tolerance(1e-8), settings.fast_pred_var(True), \
+                settings.max_root_decomposition_size(rank), torch.no_grad():
+            out = model(Xs)
+        np.testing.assert_allclose(out.mean.numpy(), mean_ref, rtol=1e-4, atol=1e-5)
+        cov = out.covariance_matrix.numpy()
+        errs.append(np.abs(cov - cov_ref).max())
+        assert (np.diag(cov) - np.diag(cov_ref)).min() > -1e-4          # never under-estimates the variance
+    assert errs[0] < 1e-4 and errs[0] <= errs[1] + 1e-6 <= errs[2] + 2e-6

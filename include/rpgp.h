@@ -225,6 +225,24 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
                     void *stream);
 
 /*
+ * Float64 variants for `--double` (training_routines.py:481).  Same contracts as the fp32 entry points of the same
+ * name; parity path (software exp, no symmetry exploitation, no workspace).  rpgp_mvm_f64 covers both the square
+ * (Z1 == Z2, optional noise) and the rectangular product; `row_scratch` is N doubles of device scratch.
+ */
+int rpgp_project_f64(const double *X, const double *Peff, double *Z, int64_t N, int d, int J, void *stream);
+int rpgp_project_grad_f64(const double *X, const double *G, double *dPeff, int64_t N, int d, int J, void *stream);
+int rpgp_mvm_f64(const double *Z1, const double *Z2, const double *V, double *out, int64_t M, int64_t N,
+                 int ldz1, int ldz2, int T, int j0, int j1, double scale, double noise, void *stream);
+int rpgp_dense_f64(const double *Z1, const double *Z2, double *out, int64_t M, int64_t N, int ldz1, int ldz2,
+                   int64_t ldo, int j0, int j1, double scale, void *stream);
+int rpgp_bilinear_grad_f64(const double *Z, const double *L, const double *R, double *gZ, double *gscale,
+                           int64_t N, int ldz, int ldg, int T, int j0, int j1, double scale,
+                           double *row_scratch, void *stream);
+int rpgp_bilinear_grad_dense_f64(const double *Z, const double *S, double *gZ, double *gscale, int64_t N,
+                                 int ldz, int ldg, int64_t lds, int j0, int j1, double scale,
+                                 double *row_scratch, void *stream);
+
+/*
  * Measurement hook used by bench.py (roofline.achieved): between begin/end every rpgp_mvm_sym / rpgp_mvm_rect call
  * records a HIP-event pair on its stream around the dominant fused tile kernel launch(es) (the small slab-reduce
  * launch is outside the pair).  `rpgp_profile_end` synchronises those events and returns the mean duration (ms)

@@ -20,6 +20,7 @@ _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
 _int = ctypes.c_int
 _f32 = ctypes.c_float
+_f64 = ctypes.c_double
 _sz = ctypes.c_size_t
 
 # name -> (restype, argtypes); mirrors include/rpgp.h one to one
@@ -58,6 +59,12 @@ SIGNATURES = {
     "rpgp_mbcg_workspace_bytes": (_sz, [_vp, _int, _int]),
     "rpgp_mbcg_solve": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _f32, _int, _vp, _vp, _f32, _vp, _vp, _vp,
                                _vp, _vp, _sz, _vp]),
+    "rpgp_project_f64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "rpgp_project_grad_f64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "rpgp_mvm_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f64, _f64, _vp]),
+    "rpgp_dense_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f64, _vp]),
+    "rpgp_bilinear_grad_f64": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f64, _vp, _vp]),
+    "rpgp_bilinear_grad_dense_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _int, _int, _f64, _vp, _vp]),
     "rpgp_profile_begin": (_int, []),
     "rpgp_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
 }

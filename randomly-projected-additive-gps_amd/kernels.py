@@ -15,8 +15,9 @@ from .operators import AdditiveRPOperator, SKIAdditiveOperator
 
 
 def inv_softplus(y):
+    """float64 inverse softplus; callers cast to the parameter's dtype (so `--double` models keep full precision)."""
     y = torch.as_tensor(y, dtype=torch.float64)
-    return (y + torch.log(-torch.expm1(-y))).to(torch.get_default_dtype())
+    return y + torch.log(-torch.expm1(-y))
 
 
 class _Project(torch.autograd.Function):
@@ -83,8 +84,10 @@ class AdditiveStructureRBFKernel(Kernel):
     def __init__(self, num_dims, weight=None, inner_lengthscale=1.0, ski=False, ski_options=None):
         super().__init__()
         self.num_dims = num_dims
-        self.register_buffer("weight", torch.tensor(1.0 / num_dims if weight is None else float(weight)))
-        self.register_buffer("inner_lengthscale", torch.tensor(float(inner_lengthscale)))
+        # float64 buffers: `model.to(torch.double)` (--double) must see 1/J, not float32(1/J)
+        self.register_buffer("weight", torch.tensor(1.0 / num_dims if weight is None else float(weight),
+                                                    dtype=torch.float64))
+        self.register_buffer("inner_lengthscale", torch.tensor(float(inner_lengthscale), dtype=torch.float64))
         # `GridInterpolationKernel(kernel, **ski_options)` wrap of training_routines.py:157-158
         self.ski = bool(ski)
         opts = dict(ski_options or {})

@@ -132,13 +132,13 @@ class AdditiveRPOperator(LinearOperator):
             kw = {}
             if self.shard is not None and self.shard.world_size > 1:
                 rng = self.shard.row_block_range(be, z1.shape[0], rhs.shape[-1])
-                if rng is not None:                 # pair-sharding: all projections on this rank's row blocks
+                if rng is not None and z1.dtype == torch.float32:   # pair-sharding: all projections on own row blocks
                     j0, j1 = 0, self.num_projections
                     kw = {"rb0": rng[0], "rb1": rng[1]}
                 elif j1 <= j0:                      # J-sharding with more ranks than projections: nothing to do here
                     return torch.zeros_like(rhs)
             prepare = getattr(be, "prepare", None)
-            if prepare is not None:
+            if prepare is not None and z1.dtype == torch.float32:
                 if self._prep is None:
                     self._prep = prepare(z1)        # once per operator (= per hyper-parameter step), one host sync
                 if self._prep.fast_ok:
@@ -162,6 +162,7 @@ class AdditiveRPOperator(LinearOperator):
         None otherwise (callers fall back to the generic row-by-row version)."""
         be = _backend.get_backend()
         if type(self) is not AdditiveRPOperator or not self.symmetric or not hasattr(be, "pivoted_cholesky") or \
+                self.Z1.dtype != torch.float32 or \
                 (self.shard is not None and self.shard.world_size > 1) or self.num_projections > 64 or rank > 64:
             return None
         return be.pivoted_cholesky(self.Z1.detach().contiguous(), self._scale, min(rank, self.Z1.shape[0]))
@@ -170,7 +171,8 @@ class AdditiveRPOperator(LinearOperator):
         """`struct rpgp_operator` for the native mBCG executor, or None when the operator must stay on the Python path
         (rectangular, J-sharded over several ranks, or a backend without the executor)."""
         be = _backend.get_backend()
-        if not self.symmetric or not hasattr(be, "mbcg_solve") or (self.shard is not None and self.shard.world_size > 1):
+        if not self.symmetric or not hasattr(be, "mbcg_solve") or (self.shard is not None and self.shard.world_size > 1) \
+                or self.Z1.dtype != torch.float32:
             return None
         from . import _lib
         z1 = self.Z1.detach()
@@ -401,7 +403,7 @@ class DenseOperator(LinearOperator):
 
     def _matmul(self, rhs):
         rhs = rhs.detach()
-        if rhs.shape[-1] <= 32 and rhs.is_cuda:
+        if rhs.shape[-1] <= 32 and rhs.is_cuda and rhs.dtype == torch.float32:
             return _backend.get_backend().dense_mvm(self.Kd, rhs, self._noise)      # HBM-bound MFMA thin GEMM
         out = self.Kd @ rhs                                                        # wide blocks: library GEMM
         if self._noise:

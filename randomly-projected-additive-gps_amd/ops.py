@@ -9,14 +9,14 @@ from . import _lib
 _workspaces = {}
 
 
-def _require(t, name, ndim=None):
+def _require(t, name, ndim=None, allow64=False):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
     if not t.is_cuda:
         raise RuntimeError("%s must live on a HIP device (got %s): the rpgp kernels have no CPU fallback"
                            % (name, t.device))
-    if t.dtype != torch.float32:
-        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if t.dtype != torch.float32 and not (allow64 and t.dtype == torch.float64):
+        raise TypeError("%s must be float32%s (got %s)" % (name, " or float64" if allow64 else "", t.dtype))
     if ndim is not None and t.dim() != ndim:
         raise ValueError("%s must be %d-dimensional (got shape %s)" % (name, ndim, tuple(t.shape)))
     return t.contiguous()
@@ -44,38 +44,39 @@ def init():
 def project(X, Peff):
     """Z = X @ Peff  (N x d)(d x J) -> N x J."""
     lib = _lib.load()
-    X = _require(X, "X", 2)
-    Peff = _require(Peff, "Peff", 2)
+    X = _require(X, "X", 2, allow64=True)
+    Peff = _require(Peff, "Peff", 2, allow64=True)
     N, d = X.shape
-    if Peff.shape[0] != d:
-        raise ValueError("Peff must be d x J with d=%d (got %s)" % (d, tuple(Peff.shape)))
+    if Peff.shape[0] != d or Peff.dtype != X.dtype:
+        raise ValueError("Peff must be d x J with d=%d and the dtype of X (got %s)" % (d, tuple(Peff.shape)))
     J = Peff.shape[1]
-    Z = torch.empty((N, J), dtype=torch.float32, device=X.device)
+    Z = torch.empty((N, J), dtype=X.dtype, device=X.device)
+    fn = lib.rpgp_project_f64 if X.dtype == torch.float64 else lib.rpgp_project
     with torch.cuda.device(X.device):
-        _lib.check(lib.rpgp_project(X.data_ptr(), Peff.data_ptr(), Z.data_ptr(), N, d, J, _stream()), "rpgp_project")
+        _lib.check(fn(X.data_ptr(), Peff.data_ptr(), Z.data_ptr(), N, d, J, _stream()), "rpgp_project")
     return Z
 
 
 def project_grad(X, G):
     """dPeff = X^T @ G  (d x J)."""
     lib = _lib.load()
-    X = _require(X, "X", 2)
-    G = _require(G, "G", 2)
+    X = _require(X, "X", 2, allow64=True)
+    G = _require(G, "G", 2, allow64=True)
     N, d = X.shape
-    if G.shape[0] != N:
-        raise ValueError("G must have N=%d rows" % N)
+    if G.shape[0] != N or G.dtype != X.dtype:
+        raise ValueError("G must have N=%d rows and the dtype of X" % N)
     J = G.shape[1]
-    out = torch.empty((d, J), dtype=torch.float32, device=X.device)
+    out = torch.empty((d, J), dtype=X.dtype, device=X.device)
+    fn = lib.rpgp_project_grad_f64 if X.dtype == torch.float64 else lib.rpgp_project_grad
     with torch.cuda.device(X.device):
-        _lib.check(lib.rpgp_project_grad(X.data_ptr(), G.data_ptr(), out.data_ptr(), N, d, J, _stream()),
-                   "rpgp_project_grad")
+        _lib.check(fn(X.data_ptr(), G.data_ptr(), out.data_ptr(), N, d, J, _stream()), "rpgp_project_grad")
     return out
 
 
-def _as_matrix(V, N, name):
+def _as_matrix(V, N, name, allow64=False):
     squeeze = V.dim() == 1
     V2 = V.unsqueeze(1) if squeeze else V
-    V2 = _require(V2, name, 2)
+    V2 = _require(V2, name, 2, allow64=allow64)
     if V2.shape[0] != N:
         raise ValueError("%s must have %d rows (got %s)" % (name, N, tuple(V.shape)))
     return V2, squeeze
@@ -93,13 +94,20 @@ def mvm_shard(N, T, world, rank):
 def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, rb1=-1):
     """out = scale * sum_{j in [j0,j1)} K_j(Z,Z) @ V + noise * V   (restricted to row blocks [rb0, rb1) if rb1 >= 0)."""
     lib = _lib.load()
-    Z = _require(Z, "Z", 2)
+    Z = _require(Z, "Z", 2, allow64=True)
     N, J = Z.shape
     j1 = J if j1 is None else j1
-    V2, squeeze = _as_matrix(V, N, "V")
+    V2, squeeze = _as_matrix(V, N, "V", allow64=True)
     T = V2.shape[1]
     if out is None:
         out = torch.empty_like(V2)
+    if Z.dtype == torch.float64:
+        if V2.dtype != torch.float64 or rb1 >= 0:
+            raise TypeError("float64 MVM needs float64 V (and does not support row-block ranges)")
+        with torch.cuda.device(Z.device):
+            _lib.check(lib.rpgp_mvm_f64(Z.data_ptr(), Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, N, J, J, T, j0, j1,
+                                        float(scale), float(noise), _stream()), "rpgp_mvm_f64")
+        return out.squeeze(1) if squeeze else out
     with torch.cuda.device(Z.device):
         nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, rb0, rb1)
         ws = _workspace(Z.device, nbytes)
@@ -159,16 +167,21 @@ def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, 
 def mvm_rect(Z1, Z2, V, scale, j0=0, j1=None):
     """out = scale * sum_j K_j(Z1,Z2) @ V   (M x T)."""
     lib = _lib.load()
-    Z1 = _require(Z1, "Z1", 2)
-    Z2 = _require(Z2, "Z2", 2)
+    Z1 = _require(Z1, "Z1", 2, allow64=True)
+    Z2 = _require(Z2, "Z2", 2, allow64=True)
     M, J = Z1.shape
     N = Z2.shape[0]
     if Z2.shape[1] != J:
         raise ValueError("Z1 and Z2 must have the same number of projections")
     j1 = J if j1 is None else j1
-    V2, squeeze = _as_matrix(V, N, "V")
+    V2, squeeze = _as_matrix(V, N, "V", allow64=True)
     T = V2.shape[1]
-    out = torch.empty((M, T), dtype=torch.float32, device=Z1.device)
+    out = torch.empty((M, T), dtype=Z1.dtype, device=Z1.device)
+    if Z1.dtype == torch.float64:
+        with torch.cuda.device(Z1.device):
+            _lib.check(lib.rpgp_mvm_f64(Z1.data_ptr(), Z2.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N, J, J, T, j0,
+                                        j1, float(scale), 0.0, _stream()), "rpgp_mvm_f64")
+        return out.squeeze(1) if squeeze else out
     with torch.cuda.device(Z1.device):
         nbytes = lib.rpgp_mvm_rect_workspace_bytes(M, N, T)
         ws = _workspace(Z1.device, nbytes)
@@ -180,14 +193,19 @@ def mvm_rect(Z1, Z2, V, scale, j0=0, j1=None):
 def dense(Z1, Z2, scale, j0=0, j1=None):
     """Dense block K(Z1,Z2) (M x N)."""
     lib = _lib.load()
-    Z1 = _require(Z1, "Z1", 2)
-    Z2 = _require(Z2, "Z2", 2)
+    Z1 = _require(Z1, "Z1", 2, allow64=True)
+    Z2 = _require(Z2, "Z2", 2, allow64=True)
     M, J = Z1.shape
     N = Z2.shape[0]
     if Z2.shape[1] != J:
         raise ValueError("Z1 and Z2 must have the same number of projections")
     j1 = J if j1 is None else j1
-    out = torch.empty((M, N), dtype=torch.float32, device=Z1.device)
+    out = torch.empty((M, N), dtype=Z1.dtype, device=Z1.device)
+    if Z1.dtype == torch.float64:
+        with torch.cuda.device(Z1.device):
+            _lib.check(lib.rpgp_dense_f64(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, j0, j1,
+                                          float(scale), _stream()), "rpgp_dense_f64")
+        return out
     with torch.cuda.device(Z1.device):
         _lib.check(lib.rpgp_dense(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, j0, j1, float(scale),
                                   _stream()), "rpgp_dense")
@@ -197,16 +215,23 @@ def dense(Z1, Z2, scale, j0=0, j1=None):
 def bilinear_grad(Z, L, R, scale, j0=0, j1=None):
     """(gZ [N x J], gscale [scalar tensor]) = d/dZ, d/dscale of sum((L R^T) * K(Z,Z))."""
     lib = _lib.load()
-    Z = _require(Z, "Z", 2)
+    Z = _require(Z, "Z", 2, allow64=True)
     N, J = Z.shape
     j1 = J if j1 is None else j1
-    L2, _ = _as_matrix(L, N, "L")
-    R2, _ = _as_matrix(R, N, "R")
+    L2, _ = _as_matrix(L, N, "L", allow64=True)
+    R2, _ = _as_matrix(R, N, "R", allow64=True)
     if L2.shape != R2.shape:
         raise ValueError("L and R must have the same shape")
     T = L2.shape[1]
-    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
-    gs = torch.zeros((), dtype=torch.float32, device=Z.device)
+    gZ = torch.zeros((N, J), dtype=Z.dtype, device=Z.device)
+    gs = torch.zeros((), dtype=Z.dtype, device=Z.device)
+    if Z.dtype == torch.float64:
+        scratch = torch.empty(N, dtype=torch.float64, device=Z.device)
+        with torch.cuda.device(Z.device):
+            _lib.check(lib.rpgp_bilinear_grad_f64(Z.data_ptr(), L2.data_ptr(), R2.data_ptr(), gZ.data_ptr(), gs.data_ptr(),
+                                                  N, J, J, T, j0, j1, float(scale), scratch.data_ptr(), _stream()),
+                       "rpgp_bilinear_grad_f64")
+        return gZ, gs
     with torch.cuda.device(Z.device):
         if T <= 12:
             nbytes = lib.rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)
@@ -234,14 +259,21 @@ def bilinear_grad(Z, L, R, scale, j0=0, j1=None):
 def bilinear_grad_dense(Z, S, scale, j0=0, j1=None):
     """(gZ, gscale) = d/dZ, d/dscale of 0.5 * sum(S * K(Z,Z)) for an explicit symmetric N x N weight matrix S."""
     lib = _lib.load()
-    Z = _require(Z, "Z", 2)
-    S = _require(S, "S", 2)
+    Z = _require(Z, "Z", 2, allow64=True)
+    S = _require(S, "S", 2, allow64=True)
     N, J = Z.shape
     if S.shape != (N, N):
         raise ValueError("S must be %d x %d" % (N, N))
     j1 = J if j1 is None else j1
-    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
-    gs = torch.zeros((), dtype=torch.float32, device=Z.device)
+    gZ = torch.zeros((N, J), dtype=Z.dtype, device=Z.device)
+    gs = torch.zeros((), dtype=Z.dtype, device=Z.device)
+    if Z.dtype == torch.float64:
+        scratch = torch.empty(N, dtype=torch.float64, device=Z.device)
+        with torch.cuda.device(Z.device):
+            _lib.check(lib.rpgp_bilinear_grad_dense_f64(Z.data_ptr(), S.data_ptr(), gZ.data_ptr(), gs.data_ptr(), N, J, J,
+                                                        N, j0, j1, float(scale), scratch.data_ptr(), _stream()),
+                       "rpgp_bilinear_grad_dense_f64")
+        return gZ, gs
     with torch.cuda.device(Z.device):
         nbytes = lib.rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)
         ws = _workspace(Z.device, nbytes)

@@ -212,8 +212,8 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
     d = trainX.shape[-1]
     devices = [torch.device(device) for device in devices]
     output_device = devices[0] if output_device is None else torch.device(output_device)
-    if double and kind == "additive_rp":
-        raise NotImplementedError("--double is not available on the fused fp32 HIP path")
+    if double and kind == "additive_rp" and model_kwargs.get("ski", False):
+        raise NotImplementedError("--double is not available for the SKI operator (fp32 kernels only)")
     type_ = torch.double if double else torch.float
     trainX = trainX.to(output_device, type_).contiguous()
     trainY = trainY.to(output_device, type_).contiguous()

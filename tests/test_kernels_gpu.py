@@ -144,7 +144,9 @@ def test_errors_are_python_exceptions(gpu_device):
     with pytest.raises(RuntimeError):
         ops.mvm_sym(Z.cpu(), torch.zeros((10, 1)), 1.0)
     with pytest.raises(TypeError):
-        ops.mvm_sym(Z.double(), torch.zeros((10, 1), device=gpu_device).double(), 1.0)
+        ops.mvm_sym(Z.half(), torch.zeros((10, 1), device=gpu_device).half(), 1.0)
+    with pytest.raises(TypeError):
+        ops.Prepared(Z.double())                          # the factorised fast path is fp32 only
 
 
 @pytest.mark.parametrize("N,J", [(277, 20), (700, 6), (64, 3)])

@@ -244,3 +244,31 @@ def test_pair_sharded_mvm_sums_to_full(gpu_device, N, T, world):
     acc_p = sum(ops.mvm_sym_prepared(prep, Vt, 0.05, 0.0, rb0=a, rb1=b) for a, b in ranges)
     assert _rel(acc_d.cpu().numpy(), full.cpu().numpy()) < 2e-6
     assert _rel(acc_p.cpu().numpy(), full.cpu().numpy()) < 2e-6
+
+
+def test_edge_shapes(gpu_device):
+    """Ragged / extreme shapes: N = 2, J = 70 (> the prepared path's 64-projection limit, pieces 20+20+20+10), a zero
+    right-hand side, T = 33, duplicate points."""
+    from rpgp_amd import ops
+    from rpgp_amd.operators import AdditiveRPOperator
+    rng = np.random.default_rng(0)
+    Z = rng.standard_normal((2, 3)).astype(np.float32)
+    V = rng.standard_normal((2, 1)).astype(np.float32)
+    out = ops.mvm_sym(torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device), 1.0, 0.5)
+    assert _rel(out.cpu().numpy(), orc.mvm(Z, Z, V, 1.0, 0.5)) < 1e-6
+    Z = rng.standard_normal((600, 70)).astype(np.float32)
+    V = rng.standard_normal((600, 33)).astype(np.float32)
+    Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
+    ref = orc.mvm(Z, Z, V, 0.01, 0.1)
+    assert _rel(ops.mvm_sym(Zt, Vt, 0.01, 0.1).cpu().numpy(), ref) < 1e-5
+    op = AdditiveRPOperator(Zt, None, torch.tensor(0.7, device=gpu_device), 1.0 / 70)
+    assert _rel(op._matmul(Vt, noise=0.1).cpu().numpy(), orc.mvm(Z, Z, V, 0.01, 0.1)) < 1e-5      # J > 64: direct kernel
+    assert op._prep is not None and not op._prep.fast_ok
+    zero = torch.zeros(600, 2, device=gpu_device)
+    assert float(ops.mvm_sym(Zt, zero, 0.01, 0.1).abs().max()) == 0.0
+    Zd = np.repeat(rng.standard_normal((1, 5)).astype(np.float32), 300, axis=0)       # all points identical: K = s*J*11^T
+    Vd = rng.standard_normal((300, 1)).astype(np.float32)
+    Zdt = torch.from_numpy(Zd).to(gpu_device)
+    for fn in (lambda: ops.mvm_sym(Zdt, torch.from_numpy(Vd).to(gpu_device), 0.2, 0.0),
+               lambda: ops.mvm_sym_prepared(ops.Prepared(Zdt), torch.from_numpy(Vd).to(gpu_device), 0.2, 0.0)):
+        np.testing.assert_allclose(fn().cpu().numpy().ravel(), np.full(300, 0.2 * 5 * Vd.sum()), rtol=2e-5, atol=2e-4)

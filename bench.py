@@ -80,14 +80,14 @@ def main():
 
     # multi-GPU split: "pairs" (default) gives every rank an equal share of the (i,i') tile pairs with all J terms;
     # "j" is north_star's J-slice split.  Both end in ONE all-reduce of the length-N partial result per step.
-    rb = ops.mvm_shard(N, T, world, rank) if (world > 1 and args.shard == "pairs") else (0, -1)
+    ps = (world, rank) if (world > 1 and args.shard == "pairs") else None
 
     def local(j0, j1, nz, o=None):
         if world > 1 and args.shard == "pairs":
             j0, j1 = 0, J
         if fast:
-            return ops.mvm_sym_prepared(prep, V, scale, nz, j0=j0, j1=j1, out=o, rb0=rb[0], rb1=rb[1])
-        return ops.mvm_sym(Z, V, scale, nz, j0=j0, j1=j1, out=o, rb0=rb[0], rb1=rb[1])
+            return ops.mvm_sym_prepared(prep, V, scale, nz, j0=j0, j1=j1, out=o, shard=ps)
+        return ops.mvm_sym(Z, V, scale, nz, j0=j0, j1=j1, out=o, shard=ps)
 
     def step():
         if world == 1:

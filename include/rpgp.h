@@ -89,24 +89,21 @@ int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t 
                           void *workspace, size_t workspace_bytes, void *stream);
 
 /*
- * Pair-sharding of the symmetric MVM across ranks (multi-GPU): the (row block, column chunk) tile pairs are split by
- * contiguous row-block ranges with equal pair counts; rank r computes out_r = partial product of its tiles (row AND
- * transposed contributions) over ALL J projections at the full per-term efficiency, and the partial N x T outputs are
- * summed with one all-reduce — the same message as J-sharding (training_routines.py:407-408 `MultiDeviceKernel`
- * counterpart), without the per-pair overhead of thin J-slices.  Pass noise = 0 and add noise*V after the reduce.
- *   rpgp_mvm_sym_blocks : number of row blocks of the plan for (N, T)
- *   rpgp_mvm_sym_shard  : balanced [rb0, rb1) of `rank` out of `world`
- *   *_range variants    : same contracts as rpgp_mvm_sym / rpgp_mvm_sym_prepared restricted to row blocks [rb0, rb1)
- *                         (rb1 = -1 means all).
+ * Pair-sharding of the symmetric MVM across ranks (multi-GPU).  The (row block, column chunk) workgroups of the tile
+ * decomposition are numbered row block by row block; rank r of `world` executes the contiguous range
+ * [total*r/world, total*(r+1)/world) (the chunk size is chosen for the per-rank share, so every rank still launches a
+ * few thousand workgroups of equal size).  Each rank therefore evaluates ALL J projections on 1/world of the (i,i')
+ * pairs at the full per-term efficiency and produces a partial N x T output (row AND transposed contributions);
+ * the partials are summed with one all-reduce — the same message as J-sharding (`MultiDeviceKernel` counterpart,
+ * training_routines.py:407-408) without the per-pair overhead of thin J-slices.  Pass noise = 0 and add noise*V after
+ * the reduce.  world = 1, rank = 0 is the plain call.  Workspace: rpgp_mvm_sym_range_workspace_bytes.
  */
-size_t rpgp_mvm_sym_range_workspace_bytes(int64_t N, int T, int rb0, int rb1);  /* workspace of a *_range call */
-int rpgp_mvm_sym_blocks(int64_t N, int T);
-int rpgp_mvm_sym_shard(int64_t N, int T, int world, int rank, int *rb0_host, int *rb1_host);
+size_t rpgp_mvm_sym_range_workspace_bytes(int64_t N, int T, int world, int rank);
 int rpgp_mvm_sym_range(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1,
-                       int rb0, int rb1, float scale, float noise,
+                       int world, int rank, float scale, float noise,
                        void *workspace, size_t workspace_bytes, void *stream);
 int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, int64_t N, int J, int T,
-                                int j0, int j1, int rb0, int rb1, float scale, float noise,
+                                int j0, int j1, int world, int rank, float scale, float noise,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /*

@@ -37,8 +37,6 @@ SIGNATURES = {
     "rpgp_prepare_status": (_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float), _vp]),
     "rpgp_mvm_sym_prepared": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
     "rpgp_mvm_sym_range_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
-    "rpgp_mvm_sym_blocks": (_int, [_i64, _int]),
-    "rpgp_mvm_sym_shard": (_int, [_i64, _int, _int, _int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "rpgp_mvm_sym_range": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
     "rpgp_mvm_sym_prepared_range": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _f32, _f32, _vp, _sz,
                                            _vp]),

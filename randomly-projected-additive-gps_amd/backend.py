@@ -11,7 +11,7 @@ class HipBackend:
     project = staticmethod(ops.project)
     project_grad = staticmethod(ops.project_grad)
     mvm_sym = staticmethod(ops.mvm_sym)
-    mvm_shard = staticmethod(ops.mvm_shard)
+    supports_pair_shard = True
     prepare = staticmethod(ops.Prepared)
     mvm_sym_prepared = staticmethod(ops.mvm_sym_prepared)
     mvm_rect = staticmethod(ops.mvm_rect)

@@ -125,11 +125,28 @@ __device__ __forceinline__ void lds_load_vec(const float *sV, int idx, float (&v
 // slabR[k][row][T]  : partial row products of chunk k           (k < chunks of that row block)
 // slabT[rb][col][T] : partial transposed products of row block rb (only col >= (rb+1)*BR written)
 // ---------------------------------------------------------------------------------------------
+// Linear workgroup index -> (row block, column chunk).  Row block b owns ceil((N - cbase(b)) / chunk) chunks (cbase = its
+// own first row for the symmetric sweep, 0 otherwise); workgroups are numbered row block by row block.  A rank's
+// launch covers the contiguous range [w0, w0 + gridDim.x) of that numbering (pair-sharding at workgroup granularity).
+__device__ __forceinline__ void wg_to_tile(int lin, int N, int BR, int chunk, bool sym, int &rb, int &kchunk) {
+  int b = 0, acc = 0;
+  for (;;) {
+    const int cbase = sym ? b * BR : 0;
+    const int cb = (N - cbase + chunk - 1) / chunk;
+    if (lin < acc + cb) break;
+    acc += cb;
+    ++b;
+  }
+  rb = b;
+  kchunk = lin - acc;
+}
+
 template <int JT, int TT, int R, bool SYM>
 __global__ __launch_bounds__(256) void mvm_tile_kernel(
     const float *__restrict__ Z1, const float *__restrict__ Z2, const float *__restrict__ V,
     float *__restrict__ slabR, float *__restrict__ slabT, int M, int N, int ldz1, int ldz2, int ldv,
-    int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate, int rb_off, int slab_row0, int slab_rows) {
+    int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate, int w0, int rb_first, int slab_row0,
+    int slab_rows) {
   constexpr int BR = 256 * R;
   constexpr int SC = StageCols<TT>::v;
   constexpr int STR = ColStride<JT>::v;
@@ -140,8 +157,8 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int rb = blockIdx.y + rb_off;   // row-block range [rb_off, rb_off + gridDim.y): pair-sharding across ranks
-  const int kchunk = blockIdx.x;
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, SYM ? N : N, BR, chunk_cols, SYM, rb, kchunk);
   const int r0 = rb * BR;
   const int cbase = SYM ? r0 : 0;
   const long long cb = (long long)cbase + (long long)kchunk * chunk_cols;
@@ -237,7 +254,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
           if (t < tcnt) {
             float sum = sT[(0 * SC + tid) * TT + t] + sT[(1 * SC + tid) * TT + t] +
                         sT[(2 * SC + tid) * TT + t] + sT[(3 * SC + tid) * TT + t];
-            float *dst = slabT + ((size_t)blockIdx.y * N + col) * ldv + t0 + t;
+            float *dst = slabT + ((size_t)(rb - rb_first) * N + col) * ldv + t0 + t;
             *dst = accumulate ? *dst + sum : sum;
           }
         }
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
                                                        const float *__restrict__ V, float *__restrict__ slabR,
                                                        float *__restrict__ slabT, int N, int J, int ldv, int j0, int t0,
                                                        int tcnt, int chunk_cols, int rotdir, int accumulate,
-                                                       int rb_off, int slab_row0, int slab_rows) {
+                                                       int w0, int rb_first, int slab_row0, int slab_rows) {
   constexpr int BR = 256 * R;
   constexpr int SC = StageCols<TT>::v;
   constexpr int NP = (JT + 1) / 2;
@@ -413,8 +430,8 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int rb = blockIdx.y + rb_off;   // row-block range [rb_off, rb_off + gridDim.y): pair-sharding across ranks
-  const int kchunk = blockIdx.x;
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
   const int r0 = rb * BR;
   const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
   if (cb >= N) return;
@@ -524,7 +541,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
           if (t < tcnt) {
             float sum = sT[(0 * SC + tid) * TT + t] + sT[(1 * SC + tid) * TT + t] +
                         sT[(2 * SC + tid) * TT + t] + sT[(3 * SC + tid) * TT + t];
-            float *dst = slabT + ((size_t)blockIdx.y * N + col) * ldv + t0 + t;
+            float *dst = slabT + ((size_t)(rb - rb_first) * N + col) * ldv + t0 + t;
             *dst = accumulate ? *dst + sum : sum;
           }
         }
@@ -1352,13 +1369,16 @@ inline int next_t_piece(int remaining) {
 }
 
 struct TilePlan {
-  int rb0, rb1;    // row-block range handled by this call (pair-sharding); default = all
-  int row0, rows;  // first row / number of rows of that range (slab addressing)
   int R;           // rows per lane
   int BR;          // rows per workgroup
   int nrb;         // row blocks
   int chunk_cols;  // columns per workgroup (multiple of 64)
-  int maxchunks;   // grid.x
+  int total_wg;    // workgroups of the whole problem (row block by row block)
+  int w0, w1;      // workgroup range of this call (pair-sharding); default = all
+  int rb0, rb1;    // row blocks touched by that range
+  int row0, rows;  // first row / number of rows of those row blocks (slab addressing)
+  int maxchunks;   // chunk slabs per row (chunks of the first touched row block)
+  bool partial;    // the range is a strict subset: slabs are zero-initialised before the sweep
 };
 
 inline int plan_chunk(double pairs, int BR, bool big) {
@@ -1372,32 +1392,49 @@ inline int plan_chunk(double pairs, int BR, bool big) {
   return chunk;
 }
 
-inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int rb0 = 0, int rb1 = -1) {
+inline int chunks_of(const TilePlan &p, int64_t N, bool sym, int b) {
+  const long long cbase = sym ? (long long)b * p.BR : 0;
+  return (int)((N - cbase + p.chunk_cols - 1) / p.chunk_cols);
+}
+
+// `world`-way split: the chunk size is chosen for the per-rank share of the pairs so that every rank still launches
+// a few thousand workgroups; rank r gets workgroups [total*r/world, total*(r+1)/world).
+inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0) {
   TilePlan p;
   // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
   p.R = (M >= 16384) ? 2 : 1;
   (void)T;
   p.BR = 256 * p.R;
   p.nrb = (int)((M + p.BR - 1) / p.BR);
-  p.rb0 = 0;
-  p.rb1 = p.nrb;
-  if (rb1 >= 0) {
-    p.rb0 = rb0 < 0 ? 0 : (rb0 > p.nrb ? p.nrb : rb0);
-    p.rb1 = rb1 > p.nrb ? p.nrb : (rb1 < p.rb0 ? p.rb0 : rb1);
+  const double pairs = (sym ? 0.5 * (double)M * (double)N : (double)M * (double)N) / (double)(world > 0 ? world : 1);
+  p.chunk_cols = plan_chunk(pairs, p.BR, M >= 16384);
+  long long total = 0;
+  for (int b = 0; b < p.nrb; ++b) total += chunks_of(p, N, sym, b);
+  p.total_wg = (int)total;
+  if (world <= 1) {
+    p.w0 = 0;
+    p.w1 = p.total_wg;
+  } else {
+    p.w0 = (int)(total * rank / world);
+    p.w1 = (int)(total * (rank + 1) / world);
   }
+  p.partial = !(p.w0 == 0 && p.w1 == p.total_wg);
+  // row blocks touched by [w0, w1)
+  p.rb0 = 0;
+  p.rb1 = 0;
+  long long acc = 0;
+  bool started = false;
+  for (int b = 0; b < p.nrb; ++b) {
+    const int cb = chunks_of(p, N, sym, b);
+    if (!started && p.w0 < acc + cb) { p.rb0 = b; started = true; }
+    if (p.w1 > acc) p.rb1 = b + 1;
+    acc += cb;
+  }
+  if (p.w1 <= p.w0) { p.rb0 = 0; p.rb1 = 0; }
   p.row0 = p.rb0 * p.BR;
   const long long rend = (long long)p.rb1 * p.BR < M ? (long long)p.rb1 * p.BR : M;
   p.rows = (int)(rend - p.row0 > 0 ? rend - p.row0 : 0);
-  // pairs handled by this call: row block b sweeps columns [b*BR, N) (symmetric) or all N columns
-  double pairs = 0.0;
-  for (int b = p.rb0; b < p.rb1; ++b) {
-    const double rows = (double)(((long long)(b + 1) * p.BR < M) ? p.BR : M - (long long)b * p.BR);
-    pairs += rows * (sym ? (double)(N - (long long)b * p.BR) : (double)N);
-  }
-  p.chunk_cols = plan_chunk(pairs, p.BR, M >= 16384);
-  const long long first_col = sym ? (long long)p.row0 : 0;
-  p.maxchunks = (int)((N - first_col + p.chunk_cols - 1) / p.chunk_cols);
-  if (p.maxchunks < 1) p.maxchunks = 1;
+  p.maxchunks = p.rb1 > p.rb0 ? chunks_of(p, N, sym, sym ? p.rb0 : 0) : 1;
   return p;
 }
 
@@ -1405,13 +1442,13 @@ template <int JT, int TT, bool SYM>
 int launch_mvm_tile(const TilePlan &p, const float *Z1, const float *Z2, const float *V, float *slabR, float *slabT,
                     int M, int N, int ldz1, int ldz2, int ldv, int j0, int t0, int tcnt, int accumulate,
                     hipStream_t st) {
-  dim3 grid(p.maxchunks, p.rb1 - p.rb0), block(256);
+  dim3 grid(p.w1 - p.w0), block(256);
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 2, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
-                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0, p.row0, p.rows);
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);
   else
     hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 1, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
-                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0, p.row0, p.rows);
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);
   return launch_status();
 }
 
@@ -1442,8 +1479,8 @@ int dispatch_jt(int jt, int tt, const TilePlan &p, const float *Z1, const float 
   }
 }
 
-inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int rb0 = 0, int rb1 = -1) {
-  const TilePlan p = make_plan(M, N, sym, T, rb0, rb1);
+inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int world = 1, int rank = 0) {
+  const TilePlan p = make_plan(M, N, sym, T, world, rank);
   size_t f = (size_t)p.maxchunks * p.rows * T;
   if (sym) f += (size_t)(p.rb1 - p.rb0) * N * T;
   return f;
@@ -1452,23 +1489,24 @@ inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int rb
 template <bool SYM>
 int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int64_t M, int64_t N, int ldz1,
                int ldz2, int T, int j0, int j1, float scale, float noise, void *ws, size_t ws_bytes, void *stream,
-               int rb0 = 0, int rb1 = -1) {
+               int world = 1, int rank = 0) {
   if (!Z1 || !Z2 || !V || !out || M <= 0 || N <= 0 || T <= 0 || j0 < 0 || j1 <= j0 || ldz1 < j1 || ldz2 < j1)
     return RPGP_EINVAL;
   if (M > 0x7fffffffLL || N > 0x7fffffffLL) return RPGP_EINVAL;
   int rc = rpgp_init();
   if (rc) return rc;
-  if (rb1 >= 0 && (rb0 < 0 || rb0 > rb1)) return RPGP_EINVAL;
-  const size_t need = mvm_workspace_floats(M, N, T, SYM, rb0, rb1) * sizeof(float);
+  if (world < 1 || rank < 0 || rank >= world) return RPGP_EINVAL;
+  const size_t need = mvm_workspace_floats(M, N, T, SYM, world, rank) * sizeof(float);
   if (!ws || ws_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const TilePlan p = make_plan(M, N, SYM, T, rb0, rb1);
+  const TilePlan p = make_plan(M, N, SYM, T, world, rank);
   float *slabR = reinterpret_cast<float *>(ws);
   float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
+  if (p.partial && need) RPGP_CHECK(hipMemsetAsync(ws, 0, need, st));   // row blocks shared with a neighbour rank
   int first = 1;
   const bool prof = g_prof_on && g_prof_n < kProfMax;
   if (prof) RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
-  for (int j = j0; j < j1 && p.rb1 > p.rb0;) {
+  for (int j = j0; j < j1 && p.w1 > p.w0;) {
     const int jt = next_j_piece(j1 - j);
     for (int t0 = 0; t0 < T;) {
       const int tt = next_t_piece(T - t0);
@@ -1496,13 +1534,13 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
 template <int JT, int TT>
 int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *coldat, const float *V, float *slabR,
                     float *slabT, int N, int J, int ldv, int j0, int t0, int tcnt, int accumulate, hipStream_t st) {
-  dim3 grid(p.maxchunks, p.rb1 - p.rb0), block(256);
+  dim3 grid(p.w1 - p.w0), block(256);
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 2>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
-                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0, p.row0, p.rows);
+                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);
   else
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 1>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
-                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.rb0, p.row0, p.rows);
+                       j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);
   return launch_status();
 }
 
@@ -1706,73 +1744,42 @@ int rpgp_prepare_status(const void *prep, int *fast_ok_host, float *max_abs_host
 
 int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t N, int J, int T, int j0, int j1,
                           float scale, float noise, void *workspace, size_t workspace_bytes, void *stream) {
-  return rpgp_mvm_sym_prepared_range(prep, V, out, N, J, T, j0, j1, 0, -1, scale, noise, workspace, workspace_bytes,
+  return rpgp_mvm_sym_prepared_range(prep, V, out, N, J, T, j0, j1, 1, 0, scale, noise, workspace, workspace_bytes,
                                      stream);
 }
 
-size_t rpgp_mvm_sym_range_workspace_bytes(int64_t N, int T, int rb0, int rb1) {
-  if (N <= 0 || T <= 0) return 0;
-  return mvm_workspace_floats(N, N, T, true, rb0, rb1) * sizeof(float);
+size_t rpgp_mvm_sym_range_workspace_bytes(int64_t N, int T, int world, int rank) {
+  if (N <= 0 || T <= 0 || world < 1 || rank < 0 || rank >= world) return 0;
+  return mvm_workspace_floats(N, N, T, true, world, rank) * sizeof(float);
 }
 
-int rpgp_mvm_sym_blocks(int64_t N, int T) {
-  if (N <= 0 || T <= 0) return 0;
-  return make_plan(N, N, true, T).nrb;
-}
-
-int rpgp_mvm_sym_shard(int64_t N, int T, int world, int rank, int *rb0_host, int *rb1_host) {
-  if (N <= 0 || T <= 0 || world <= 0 || rank < 0 || rank >= world || !rb0_host || !rb1_host) return RPGP_EINVAL;
-  const TilePlan p = make_plan(N, N, true, T);
-  // contiguous ranges of row blocks with equal numbers of (row, column) pairs: block b sweeps columns [b*BR, N)
-  double total = 0.0;
-  for (int b = 0; b < p.nrb; ++b) {
-    const double rows = (double)((b + 1) * (long long)p.BR < N ? p.BR : N - (long long)b * p.BR);
-    total += rows * (double)(N - (long long)b * p.BR);
-  }
-  int bounds[2] = {0, p.nrb};
-  double acc = 0.0;
-  int b = 0;
-  for (int side = 0; side < 2; ++side) {
-    const double target = total * (double)(rank + side) / (double)world;
-    while (b < p.nrb && acc < target - 1e-9) {
-      const double rows = (double)((b + 1) * (long long)p.BR < N ? p.BR : N - (long long)b * p.BR);
-      acc += rows * (double)(N - (long long)b * p.BR);
-      ++b;
-    }
-    bounds[side] = b;
-  }
-  if (rank == world - 1) bounds[1] = p.nrb;
-  *rb0_host = bounds[0];
-  *rb1_host = bounds[1];
-  return 0;
-}
-
-int rpgp_mvm_sym_range(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1, int rb0,
-                       int rb1, float scale, float noise, void *workspace, size_t workspace_bytes, void *stream) {
-  return mvm_common<true>(Z, Z, V, out, N, N, ldz, ldz, T, j0, j1, scale, noise, workspace, workspace_bytes, stream, rb0,
-                          rb1);
+int rpgp_mvm_sym_range(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1, int world,
+                       int rank, float scale, float noise, void *workspace, size_t workspace_bytes, void *stream) {
+  return mvm_common<true>(Z, Z, V, out, N, N, ldz, ldz, T, j0, j1, scale, noise, workspace, workspace_bytes, stream,
+                          world, rank);
 }
 
 int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, int64_t N, int J, int T, int j0, int j1,
-                                int rb0, int rb1, float scale, float noise, void *workspace, size_t workspace_bytes,
+                                int world, int rank, float scale, float noise, void *workspace, size_t workspace_bytes,
                                 void *stream) {
   if (!prep || !V || !out || N <= 0 || T <= 0 || J <= 0 || J > kPrepMidFloats || j0 < 0 || j1 <= j0 || j1 > J)
     return RPGP_EINVAL;
   if (N > 0x7fffffffLL) return RPGP_EINVAL;
   int rc = rpgp_init();
   if (rc) return rc;
-  if (rb1 >= 0 && (rb0 < 0 || rb0 > rb1)) return RPGP_EINVAL;
-  const size_t need = mvm_workspace_floats(N, N, T, true, rb0, rb1) * sizeof(float);
+  if (world < 1 || rank < 0 || rank >= world) return RPGP_EINVAL;
+  const size_t need = mvm_workspace_floats(N, N, T, true, world, rank) * sizeof(float);
   if (!workspace || workspace_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const TilePlan p = make_plan(N, N, true, T, rb0, rb1);
+  const TilePlan p = make_plan(N, N, true, T, world, rank);
   PrepLayout L = prep_layout(const_cast<void *>(prep), N, J);
   float *slabR = reinterpret_cast<float *>(workspace);
   float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
+  if (p.partial && need) RPGP_CHECK(hipMemsetAsync(workspace, 0, need, st));
   int first = 1;
   const bool prof = g_prof_on && g_prof_n < kProfMax;
   if (prof) RPGP_CHECK(hipEventRecord(g_prof_ev[2 * g_prof_n], st));
-  for (int j = j0; j < j1 && p.rb1 > p.rb0;) {
+  for (int j = j0; j < j1 && p.w1 > p.w0;) {
     const int jt = next_j_piece(j1 - j);
     for (int t0 = 0; t0 < T;) {
       const int tt = next_t_piece(T - t0);

@@ -3,9 +3,9 @@ ONE all-reduce of the N x T partial result per MVM (RCCL over xGMI on MI355X: `t
 on CPU in tests); the noise term is added once, after the reduce, so every rank holds the identical result and runs
 the identical CG recurrences:
   * mode "j"     — K = sum_j K_j: rank r owns a contiguous slice of the J projections and sweeps the full N x N index
-                   space (north_star's split; the only one available to backends without `mvm_shard`);
-  * mode "pairs" — rank r owns a contiguous range of row blocks of the symmetric tile decomposition with an equal share
-                   of the (i, i') pairs and evaluates ALL J projections on them.  Same message, but every rank runs the
+                   space (north_star's split; the only one available to backends without `supports_pair_shard`);
+  * mode "pairs" — rank r owns a contiguous 1/world range of the (row block, column chunk) workgroups of the symmetric
+                   tile decomposition, i.e. an equal share of the (i, i') pairs, and evaluates ALL J projections on them.  Same message, but every rank runs the
                    JT = 20 kernel at full per-term efficiency (thin J-slices pay the per-pair overhead J/J_r times):
                    measured per-rank kernel time at N = 50k: 8 ranks 0.66 ms (j) vs ~0.33 ms (pairs).
 Gradients (bilinear derivative) are always J-sharded.
@@ -59,12 +59,11 @@ class JShard:
     def empty(self):
         return self.j1 <= self.j0
 
-    def row_block_range(self, backend, N, T):
-        """[rb0, rb1) of this rank for pair-sharding, or None when the backend cannot do it (then mode "j" is used)."""
-        fn = getattr(backend, "mvm_shard", None)
-        if self.mode != "pairs" or fn is None:
+    def pair_shard(self, backend):
+        """(world, rank) for pair-sharding, or None when mode is "j" or the backend cannot do it (then J-slices)."""
+        if self.mode != "pairs" or not getattr(backend, "supports_pair_shard", False):
             return None
-        return fn(N, T, self.world_size, self.rank)
+        return (self.world_size, self.rank)
 
     def sharded_mvm(self, local_mvm, V, noise):
         """local_mvm(j0, j1) -> partial product of this rank's projections (no noise term).

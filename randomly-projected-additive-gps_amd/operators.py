@@ -131,10 +131,10 @@ class AdditiveRPOperator(LinearOperator):
         if self.symmetric:
             kw = {}
             if self.shard is not None and self.shard.world_size > 1:
-                rng = self.shard.row_block_range(be, z1.shape[0], rhs.shape[-1])
-                if rng is not None and z1.dtype == torch.float32:   # pair-sharding: all projections on own row blocks
+                ps = self.shard.pair_shard(be)
+                if ps is not None and z1.dtype == torch.float32:    # pair-sharding: all projections, 1/world of the pairs
                     j0, j1 = 0, self.num_projections
-                    kw = {"rb0": rng[0], "rb1": rng[1]}
+                    kw = {"shard": ps}
                 elif j1 <= j0:                      # J-sharding with more ranks than projections: nothing to do here
                     return torch.zeros_like(rhs)
             prepare = getattr(be, "prepare", None)

@@ -82,17 +82,10 @@ def _as_matrix(V, N, name, allow64=False):
     return V2, squeeze
 
 
-def mvm_shard(N, T, world, rank):
-    """Balanced row-block range [rb0, rb1) of `rank` for pair-sharding the symmetric MVM (host-only computation)."""
-    import ctypes
-    lib = _lib.load()
-    a, b = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(lib.rpgp_mvm_sym_shard(N, T, world, rank, ctypes.byref(a), ctypes.byref(b)), "rpgp_mvm_sym_shard")
-    return a.value, b.value
-
-
-def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, rb1=-1):
-    """out = scale * sum_{j in [j0,j1)} K_j(Z,Z) @ V + noise * V   (restricted to row blocks [rb0, rb1) if rb1 >= 0)."""
+def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None, shard=None):
+    """out = scale * sum_{j in [j0,j1)} K_j(Z,Z) @ V + noise * V.
+    shard = (world, rank): only this rank's 1/world share of the (i,i') tile pairs (pair-sharding; partial output)."""
+    world, rank = shard if shard is not None else (1, 0)
     lib = _lib.load()
     Z = _require(Z, "Z", 2, allow64=True)
     N, J = Z.shape
@@ -102,16 +95,16 @@ def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, rb1=-1):
     if out is None:
         out = torch.empty_like(V2)
     if Z.dtype == torch.float64:
-        if V2.dtype != torch.float64 or rb1 >= 0:
-            raise TypeError("float64 MVM needs float64 V (and does not support row-block ranges)")
+        if V2.dtype != torch.float64 or world != 1:
+            raise TypeError("float64 MVM needs float64 V (and does not support pair-sharding)")
         with torch.cuda.device(Z.device):
             _lib.check(lib.rpgp_mvm_f64(Z.data_ptr(), Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, N, J, J, T, j0, j1,
                                         float(scale), float(noise), _stream()), "rpgp_mvm_f64")
         return out.squeeze(1) if squeeze else out
     with torch.cuda.device(Z.device):
-        nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, rb0, rb1)
+        nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, world, rank)
         ws = _workspace(Z.device, nbytes)
-        _lib.check(lib.rpgp_mvm_sym_range(Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1, rb0, rb1,
+        _lib.check(lib.rpgp_mvm_sym_range(Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1, world, rank,
                                           float(scale), float(noise), ws.data_ptr(), ws.numel(), _stream()),
                    "rpgp_mvm_sym")
     return out.squeeze(1) if squeeze else out
@@ -143,8 +136,9 @@ class Prepared:
         self.max_abs = float(mx.value)
 
 
-def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, rb1=-1):
+def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None, shard=None):
     """Factorised fast path: same result contract as mvm_sym for the Z that `prep` was built from."""
+    world, rank = shard if shard is not None else (1, 0)
     lib = _lib.load()
     if not prep.fast_ok:
         raise RuntimeError("rpgp_prepare flagged the coordinate range as unsafe for the factorised path "
@@ -156,10 +150,10 @@ def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None, rb0=0, 
     if out is None:
         out = torch.empty_like(V2)
     with torch.cuda.device(prep.device):
-        nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, rb0, rb1)
+        nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, world, rank)
         ws = _workspace(prep.device, nbytes)
         _lib.check(lib.rpgp_mvm_sym_prepared_range(prep.buf.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1,
-                                                   rb0, rb1, float(scale), float(noise), ws.data_ptr(), ws.numel(),
+                                                   world, rank, float(scale), float(noise), ws.data_ptr(), ws.numel(),
                                                    _stream()), "rpgp_mvm_sym_prepared")
     return out.squeeze(1) if squeeze else out
 

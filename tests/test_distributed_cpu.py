@@ -76,20 +76,3 @@ def test_sharded_operator_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / ("ok%d" % r))
-
-
-def test_pair_shard_partition_is_balanced():
-    """rpgp_mvm_sym_shard is host-only arithmetic: contiguous cover of the row blocks with near-equal pair counts."""
-    from rpgp_amd import ops, _lib
-    lib = _lib.load()
-    for N, T in [(50000, 1), (16599, 11), (1000, 1)]:
-        nblk = lib.rpgp_mvm_sym_blocks(N, T)
-        BR = -(-N // nblk) if nblk else N
-        for world in (1, 2, 4, 8):
-            rng = [ops.mvm_shard(N, T, world, r) for r in range(world)]
-            assert rng[0][0] == 0 and rng[-1][1] == nblk
-            assert all(rng[i][1] == rng[i + 1][0] for i in range(world - 1))
-            if N == 50000:
-                br = 512
-                work = [sum(min(br, N - b * br) * (N - b * br) for b in range(a, e)) for a, e in rng]
-                assert max(work) / (sum(work) / world) < 1.15

@@ -227,23 +227,21 @@ def test_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, rank):
     assert torch.allclose(Lf, Lg, rtol=1e-3, atol=2e-4)
 
 
-@pytest.mark.parametrize("N,T,world", [(3000, 1, 3), (20000, 1, 8), (5000, 11, 4), (700, 4, 2)])
+@pytest.mark.parametrize("N,T,world", [(3000, 1, 3), (20000, 1, 8), (5000, 11, 4), (700, 4, 2), (300, 1, 8)])
 def test_pair_sharded_mvm_sums_to_full(gpu_device, N, T, world):
-    """Pair-sharding (rpgp_mvm_sym_shard + *_range): the per-rank partial products sum to the full MVM, for the direct
-    and the prepared kernels; the ranges are contiguous, disjoint and cover all row blocks."""
-    from rpgp_amd import ops, _lib
+    """Pair-sharding (rpgp_mvm_sym[_prepared]_range): the per-rank partial products sum to the full MVM, for the
+    direct and the prepared kernels, including j-ranges."""
+    from rpgp_amd import ops
     Z, V = _data(N, 20, T, seed=N)
     Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
     full = ops.mvm_sym(Zt, Vt, 0.05, 0.0)
     prep = ops.Prepared(Zt)
-    nblk = _lib.load().rpgp_mvm_sym_blocks(N, T)
-    ranges = [ops.mvm_shard(N, T, world, r) for r in range(world)]
-    assert ranges[0][0] == 0 and ranges[-1][1] == nblk
-    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
-    acc_d = sum(ops.mvm_sym(Zt, Vt, 0.05, 0.0, rb0=a, rb1=b) for a, b in ranges)
-    acc_p = sum(ops.mvm_sym_prepared(prep, Vt, 0.05, 0.0, rb0=a, rb1=b) for a, b in ranges)
+    acc_d = sum(ops.mvm_sym(Zt, Vt, 0.05, 0.0, shard=(world, r)) for r in range(world))
+    acc_p = sum(ops.mvm_sym_prepared(prep, Vt, 0.05, 0.0, shard=(world, r)) for r in range(world))
     assert _rel(acc_d.cpu().numpy(), full.cpu().numpy()) < 2e-6
     assert _rel(acc_p.cpu().numpy(), full.cpu().numpy()) < 2e-6
+    part = sum(ops.mvm_sym_prepared(prep, Vt, 0.05, 0.0, j0=3, j1=11, shard=(world, r)) for r in range(world))
+    assert _rel(part.cpu().numpy(), ops.mvm_sym(Zt, Vt, 0.05, 0.0, j0=3, j1=11).cpu().numpy()) < 2e-6
 
 
 def test_edge_shapes(gpu_device):

@@ -29,11 +29,10 @@ base = None
 for world in (1, 2, 4, 8):
     worst = 0.0
     for r in range(world):
-        a, b = ops.mvm_shard(N, 1, world, r)
-        ops.mvm_sym_prepared(prep, V, 1.0 / J, 0.0, rb0=a, rb1=b); torch.cuda.synchronize()
+        ops.mvm_sym_prepared(prep, V, 1.0 / J, 0.0, shard=(world, r)); torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10): ops.mvm_sym_prepared(prep, V, 1.0 / J, 0.0, rb0=a, rb1=b)
+        for _ in range(10): ops.mvm_sym_prepared(prep, V, 1.0 / J, 0.0, shard=(world, r))
         e1.record(); torch.cuda.synchronize()
         worst = max(worst, e0.elapsed_time(e1) / 10)
     base = base or worst

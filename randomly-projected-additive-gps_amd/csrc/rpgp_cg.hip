@@ -5,10 +5,12 @@
 //
 // Per iteration (T <= 16 right-hand sides, row-major N x T):
 //   Ap = A p                                            rpgp_mvm_sym[_prepared] / rpgp_ski_mvm
-//   k_pAp    : partial sums of p.Ap per column
+//   k_coldot : partial sums of p.Ap per column
 //   k_update : alpha = rz / pAp ; x += alpha p ; r -= alpha Ap ; partial |r|^2 ; partial L^T r (preconditioner)
 //   k_precond: w = Cinv (L^T r) ; z = (r - L w) / sigma^2 ; partial r.z            (identity preconditioner: z = r)
-//   k_direct : beta = rz' / rz ; p = z + beta p ; records alpha/beta history ; mean residual norm
+//   k_direction: beta = rz' / rz ; p = z + beta p ; alpha/beta history ; mean residual norm ; convergence decision
+// The convergence flag lives on the device; the host polls it one iteration late through pinned memory, so the queue
+// never drains on the round trip (the one iteration queued past convergence is a no-op on x).
 // Partial sums are per-workgroup slabs reduced in a fixed order by the consuming kernel's prologue (deterministic).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,12 +33,17 @@ constexpr int kMaxHist = 64;        // Lanczos coefficients kept for at most thi
   } while (0)
 
 // device-resident scalar state
+struct CgPoll {             // copied to pinned host memory after the iterations that test convergence
+  float mean_resid;
+  int done;                 // 0 running, 1 tolerance reached (later iterations are no-ops), 2 non-finite residual
+  int iters;                // iterations performed when `done` was set
+};
 struct CgState {
   float rz[2][kMaxT];       // r.z of the current iterate, ping-pong by iteration parity (no intra-kernel race)
   float rhs_norm[kMaxT];
   float resid[kMaxT];       // residual norms of the current iterate
-  float mean_resid;
   int rhs_zero[kMaxT];
+  CgPoll poll;
 };
 
 __device__ __forceinline__ float block_sum(float v, float *sh) {
@@ -48,6 +55,25 @@ __device__ __forceinline__ float block_sum(float v, float *sh) {
   if (lane == 0) sh[wave] = v;
   __syncthreads();
   return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// dst[t] = sum_q partial[q][t] for t < T with all 256 threads: 16 lanes per column take every 16th slab, then the 16
+// lane sums are added in a fixed order (deterministic).  `scratch` holds 256 floats.  Ends with a barrier.
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nparts, int T,
+                                                float *__restrict__ dst, float *__restrict__ scratch) {
+  const int t = threadIdx.x & (kMaxT - 1), q0 = threadIdx.x / kMaxT;
+  float s = 0.f;
+  if (t < T)
+    for (int q = q0; q < nparts; q += 256 / kMaxT) s += partial[(size_t)q * T + t];
+  scratch[q0 * kMaxT + t] = s;
+  __syncthreads();
+  if ((int)threadIdx.x < T) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 256 / kMaxT; ++q) tot += scratch[q * kMaxT + threadIdx.x];
+    dst[threadIdx.x] = tot;
+  }
+  __syncthreads();
 }
 
 // partial[blk][t] = sum over the block's rows of a[i][t] * b[i][t]
@@ -75,11 +101,12 @@ __global__ __launch_bounds__(256) void k_coldot(const float *__restrict__ a, con
 __global__ __launch_bounds__(256) void k_normalise(const float *__restrict__ rhs, const float *__restrict__ partial,
                                                    int nparts, float *__restrict__ r, float *__restrict__ x,
                                                    CgState *__restrict__ st, long long N, int T) {
+  __shared__ float ssum[kMaxT];
   __shared__ float snorm[kMaxT];
+  __shared__ float scratch[256];
+  reduce_partials(partial, nparts, T, ssum, scratch);
   if ((int)threadIdx.x < T) {
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * T + threadIdx.x];
-    float nrm = sqrtf(s);
+    float nrm = sqrtf(ssum[threadIdx.x]);
     const int zero = nrm < 1e-10f;
     if (zero) nrm = 1.0f;
     snorm[threadIdx.x] = nrm;
@@ -87,6 +114,11 @@ __global__ __launch_bounds__(256) void k_normalise(const float *__restrict__ rhs
       st->rhs_norm[threadIdx.x] = nrm;
       st->rhs_zero[threadIdx.x] = zero;
     }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->poll.mean_resid = 1.0f;
+    st->poll.done = 0;
+    st->poll.iters = 0;
   }
   __syncthreads();
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
@@ -96,31 +128,41 @@ __global__ __launch_bounds__(256) void k_normalise(const float *__restrict__ rhs
     }
 }
 
-// partial_w[blk][kk][t] = sum_i L[i][kk] r[i][t]       (L: N x K row-major)
-__global__ __launch_bounds__(256) void k_Ltr(const float *__restrict__ L, const float *__restrict__ r,
-                                             float *__restrict__ partial_w, long long N, int T, int K,
-                                             long long rows_per_block) {
-  __shared__ float sL[64 * kMaxK];
-  __shared__ float sR[64 * kMaxT];
-  const long long n0 = (long long)blockIdx.x * rows_per_block;
-  const long long n1 = (n0 + rows_per_block < N) ? n0 + rows_per_block : N;
-  const int kk = threadIdx.x / kMaxT, t = threadIdx.x % kMaxT;   // 16 x 16 threads
-  float acc = 0.f;
-  for (long long c0 = n0; c0 < n1; c0 += 64) {
-    const int nr = (int)((n1 - c0 < 64) ? n1 - c0 : 64);
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * K; e += 256) {
-      const int rr = e / K;
-      sL[rr * kMaxK + e % K] = rr < nr ? L[(c0 + rr) * K + e % K] : 0.f;
-    }
-    for (int e = threadIdx.x; e < 64 * T; e += 256) {
-      const int rr = e / T;
-      sR[rr * kMaxT + e % T] = rr < nr ? r[(c0 + rr) * T + e % T] : 0.f;
-    }
-    __syncthreads();
-    if (kk < K && t < T)
-      for (int rr = 0; rr < nr; ++rr) acc = __builtin_fmaf(sL[rr * kMaxK + kk], sR[rr * kMaxT + t], acc);
+// One 256-row tile of w += L^T r: the tile's r (kMaxT-wide rows in sR) and L rows (sL) are in LDS; thread (kk, t)
+// accumulates its entry over the tile's rows.  Callers bracket it with barriers.
+__device__ __forceinline__ float ltr_tile(const float *__restrict__ sL, const float *__restrict__ sR, float acc) {
+  const int kk = threadIdx.x / kMaxT, t = threadIdx.x % kMaxT;
+#pragma unroll 8
+  for (int rr = 0; rr < 256; ++rr) acc = __builtin_fmaf(sL[rr * kMaxK + kk], sR[rr * kMaxT + t], acc);
+  return acc;
+}
+
+__device__ __forceinline__ void load_L_tile(const float *__restrict__ L, float *__restrict__ sL, long long row0,
+                                            long long N, int K) {
+  for (int e = threadIdx.x; e < 256 * kMaxK; e += 256) {
+    const int rr = e / kMaxK, kk = e % kMaxK;
+    sL[e] = (kk < K && row0 + rr < N) ? L[(row0 + rr) * K + kk] : 0.f;
   }
+}
+
+// partial_w[blk][kk][t] = sum over the block's rows of L[i][kk] r[i][t]       (L: N x K row-major); first iterate only
+__global__ __launch_bounds__(256) void k_Ltr(const float *__restrict__ L, const float *__restrict__ r,
+                                             float *__restrict__ partial_w, long long N, int T, int K) {
+  __shared__ float sL[256 * kMaxK];
+  __shared__ float sR[256 * kMaxT];
+  float acc = 0.f;
+  for (long long tile = blockIdx.x, nt = (N + 255) / 256; tile < nt; tile += gridDim.x) {
+    const long long row0 = tile * 256;
+    __syncthreads();
+    load_L_tile(L, sL, row0, N, K);
+    for (int e = threadIdx.x; e < 256 * kMaxT; e += 256) {
+      const int rr = e / kMaxT, t = e % kMaxT;
+      sR[e] = (t < T && row0 + rr < N) ? r[(row0 + rr) * T + t] : 0.f;
+    }
+    __syncthreads();
+    acc = ltr_tile(sL, sR, acc);
+  }
+  const int kk = threadIdx.x / kMaxT, t = threadIdx.x % kMaxT;
   if (kk < K && t < T) partial_w[((size_t)blockIdx.x * K + kk) * T + t] = acc;
 }
 
@@ -186,29 +228,37 @@ __global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, co
 __global__ __launch_bounds__(256) void k_first_dir(const float *__restrict__ z, float *__restrict__ p,
                                                    const float *__restrict__ partial_rz, int nparts,
                                                    CgState *__restrict__ st, long long N, int T) {
-  if (blockIdx.x == 0 && (int)threadIdx.x < T) {
-    float s = 0.f;
-    for (int q = 0; q < nparts; ++q) s += partial_rz[(size_t)q * T + threadIdx.x];
-    st->rz[0][threadIdx.x] = s;
-    st->resid[threadIdx.x] = 1.0f;
+  __shared__ float srz[kMaxT];
+  __shared__ float scratch[256];
+  if (blockIdx.x == 0) {
+    reduce_partials(partial_rz, nparts, T, srz, scratch);
+    if ((int)threadIdx.x < T) {
+      st->rz[0][threadIdx.x] = srz[threadIdx.x];
+      st->resid[threadIdx.x] = 1.0f;
+    }
   }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N * T; i += (long long)gridDim.x * 256) p[i] = z[i];
 }
 
-// alpha = rz / pAp (guarded); x += alpha p; r -= alpha Ap; partial |r|^2
+// alpha = rz / pAp (guarded); x += alpha p; r -= alpha Ap; partial |r|^2; partial L^T r for the preconditioner.
+// After convergence (st->poll.done) alpha = 0: iterations the host had already enqueued leave x and r untouched.
 __global__ __launch_bounds__(256) void k_update(const float *__restrict__ p, const float *__restrict__ Ap,
                                                 const float *__restrict__ partial_pAp, int nparts,
                                                 float *__restrict__ x, float *__restrict__ r,
                                                 float *__restrict__ partial_rr, const CgState *__restrict__ st,
-                                                float *__restrict__ alpha_out, long long N, int T, float eps,
+                                                float *__restrict__ alpha_out, const float *__restrict__ L,
+                                                float *__restrict__ partial_w, long long N, int T, int K, float eps,
                                                 float stop_after, int cur) {
+  __shared__ float spAp[kMaxT];
   __shared__ float salpha[kMaxT];
   __shared__ float sh[4];
+  __shared__ float sR[256 * kMaxT];      // doubles as the reduce_partials scratch before the first tile
+  __shared__ float sL[256 * kMaxK];
+  reduce_partials(partial_pAp, nparts, T, spAp, sR);
   if ((int)threadIdx.x < T) {
-    float s = 0.f;
-    for (int q = 0; q < nparts; ++q) s += partial_pAp[(size_t)q * T + threadIdx.x];
+    const float s = spAp[threadIdx.x];
     float a = (fabsf(s) > eps) ? st->rz[cur][threadIdx.x] / s : 0.f;
-    if (st->resid[threadIdx.x] < stop_after || st->rhs_zero[threadIdx.x]) a = 0.f;
+    if (st->resid[threadIdx.x] < stop_after || st->rhs_zero[threadIdx.x] || st->poll.done) a = 0.f;
     salpha[threadIdx.x] = a;
     if (blockIdx.x == 0) alpha_out[threadIdx.x] = a;
   }
@@ -216,16 +266,29 @@ __global__ __launch_bounds__(256) void k_update(const float *__restrict__ p, con
   float acc[kMaxT];
 #pragma unroll
   for (int t = 0; t < kMaxT; ++t) acc[t] = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+  float accw = 0.f;
+  for (long long tile = blockIdx.x, nt = (N + 255) / 256; tile < nt; tile += gridDim.x) {
+    const long long row0 = tile * 256;
+    const long long i = row0 + threadIdx.x;
+    if (K > 0) {
+      __syncthreads();                     // previous tile's ltr_tile is done with sL / sR
+      load_L_tile(L, sL, row0, N, K);
+    }
 #pragma unroll
     for (int t = 0; t < kMaxT; ++t) {
-      if (t < T) {
+      float rv = 0.f;
+      if (t < T && i < N) {
         const float a = salpha[t];
         x[i * T + t] = __builtin_fmaf(a, p[i * T + t], x[i * T + t]);
-        const float rv = __builtin_fmaf(-a, Ap[i * T + t], r[i * T + t]);
+        rv = __builtin_fmaf(-a, Ap[i * T + t], r[i * T + t]);
         r[i * T + t] = rv;
         acc[t] = __builtin_fmaf(rv, rv, acc[t]);
       }
+      if (K > 0) sR[threadIdx.x * kMaxT + t] = rv;
+    }
+    if (K > 0) {
+      __syncthreads();
+      accw = ltr_tile(sL, sR, accw);
     }
   }
 #pragma unroll
@@ -235,41 +298,56 @@ __global__ __launch_bounds__(256) void k_update(const float *__restrict__ p, con
       if (threadIdx.x == 0) partial_rr[(size_t)blockIdx.x * T + t] = s;
     }
   }
+  if (K > 0) {
+    const int kk = threadIdx.x / kMaxT, t = threadIdx.x % kMaxT;
+    if (kk < K && t < T) partial_w[((size_t)blockIdx.x * K + kk) * T + t] = accw;
+  }
 }
 
-// beta = rz' / rz; p = z + beta p; bookkeeping (block 0): rz <- rz', resid, mean residual, beta history
+// beta = rz' / rz; p = z + beta p; bookkeeping (block 0): rz <- rz', resid, mean residual, beta history, and — on the
+// iterations the host marks with check_now — the convergence decision (st->poll.done), which freezes later iterations.
 __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, float *__restrict__ p,
                                                    const float *__restrict__ partial_rz, const float *__restrict__ partial_rr,
                                                    int nparts, CgState *__restrict__ st, float *__restrict__ beta_out,
-                                                   long long N, int T, float eps, int cur) {
+                                                   long long N, int T, float eps, int cur, int check_now,
+                                                   float tolerance, int iter_count) {
+  __shared__ float srzn[kMaxT];
+  __shared__ float srr[kMaxT];
   __shared__ float sbeta[kMaxT];
   __shared__ float sres[kMaxT];
+  __shared__ float scratch[256];
+  const int was_done = st->poll.done;
+  reduce_partials(partial_rz, nparts, T, srzn, scratch);
+  reduce_partials(partial_rr, nparts, T, srr, scratch);
   if ((int)threadIdx.x < T) {
-    float rzn = 0.f, rr = 0.f;
-    for (int q = 0; q < nparts; ++q) {
-      rzn += partial_rz[(size_t)q * T + threadIdx.x];
-      rr += partial_rr[(size_t)q * T + threadIdx.x];
-    }
     const float rz = st->rz[cur][threadIdx.x];
-    sbeta[threadIdx.x] = (fabsf(rz) > eps) ? rzn / rz : 0.f;
-    sres[threadIdx.x] = st->rhs_zero[threadIdx.x] ? 0.f : sqrtf(rr);
+    sbeta[threadIdx.x] = (fabsf(rz) > eps) ? srzn[threadIdx.x] / rz : 0.f;
+    sres[threadIdx.x] = st->rhs_zero[threadIdx.x] ? 0.f : sqrtf(srr[threadIdx.x]);
   }
   __syncthreads();
+  if (was_done) return;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
     for (int t = 0; t < T; ++t) p[i * T + t] = __builtin_fmaf(sbeta[t], p[i * T + t], z[i * T + t]);
   if (blockIdx.x == 0) {
-    __syncthreads();
     if ((int)threadIdx.x < T) {
-      float rzn = 0.f;
-      for (int q = 0; q < nparts; ++q) rzn += partial_rz[(size_t)q * T + threadIdx.x];
-      st->rz[cur ^ 1][threadIdx.x] = rzn;
+      st->rz[cur ^ 1][threadIdx.x] = srzn[threadIdx.x];
       st->resid[threadIdx.x] = sres[threadIdx.x];
       beta_out[threadIdx.x] = sbeta[threadIdx.x];
     }
     if (threadIdx.x == 0) {
       float m = 0.f;
       for (int t = 0; t < T; ++t) m += sres[t];
-      st->mean_resid = m / (float)T;
+      m /= (float)T;
+      st->poll.mean_resid = m;
+      if (check_now) {
+        if (m != m) {
+          st->poll.done = 2;
+          st->poll.iters = iter_count;
+        } else if (m < tolerance) {
+          st->poll.done = 1;
+          st->poll.iters = iter_count;
+        }
+      }
     }
   }
 }
@@ -281,11 +359,32 @@ __global__ __launch_bounds__(256) void k_unnormalise(float *__restrict__ x, cons
 }
 
 inline int nblocks_for(long long N) {
-  long long b = (N + 1023) / 1024;
+  long long b = (N + 255) / 256;      // one 256-row tile per workgroup until the partial-sum slabs are full
   if (b > kMaxBlocks) b = kMaxBlocks;
   if (b < 1) b = 1;
   return (int)b;
 }
+
+// Pinned host landing zone for the lagged convergence polls (one per host thread; the executor keeps no other
+// state between calls).
+constexpr int kPollRing = 4;
+struct PollCtx {
+  CgPoll *host = nullptr;
+  hipEvent_t ev[kPollRing];
+  bool ok = false;
+  int init() {
+    if (ok) return 0;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), (kPollRing + 1) * sizeof(CgPoll), hipHostMallocDefault);
+    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < kPollRing; ++i) {
+      e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+      if (e != hipSuccess) return (int)e;
+    }
+    ok = true;
+    return 0;
+  }
+};
+thread_local PollCtx g_poll;
 
 int apply_operator(const rpgp_operator *op, const float *V, float *out, int T, void *ws, size_t ws_bytes, void *stream) {
   switch (op->kind) {
@@ -366,63 +465,73 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   const size_t op_ws_bytes = operator_workspace(op, T);
 
   const int nb = nblocks_for(N);
-  const long long rows_per_block = (N + nb - 1) / nb;
   const float eps = 1e-30f, stop_after = 1e-10f;
+  {
+    const int prc = g_poll.init();
+    if (prc) return prc;
+  }
+  CgPoll *hpoll = g_poll.host;
 
   // normalise right-hand sides, x = 0
   hipLaunchKernelGGL(k_coldot, dim3(nb), dim3(256), 0, st, rhs, rhs, part_a, N, T);
   hipLaunchKernelGGL(k_normalise, dim3(nb), dim3(256), 0, st, rhs, part_a, nb, r, x, state, N, T);
   // z0 = M^-1 r0, p0 = z0, rz0
-  if (K > 0) hipLaunchKernelGGL(k_Ltr, dim3(nb), dim3(256), 0, st, L, r, part_w, N, T, K, rows_per_block);
+  if (K > 0) hipLaunchKernelGGL(k_Ltr, dim3(nb), dim3(256), 0, st, L, r, part_w, N, T, K);
   hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, Cinv, part_w, nb, r, z, part_rz, N, T, K, precond_sigma2);
   hipLaunchKernelGGL(k_first_dir, dim3(nb), dim3(256), 0, st, z, p, part_rz, nb, state, N, T);
   CG_CHECK(hipGetLastError());
 
   int it = 0;
-  float mean_resid = 1.0f;
-  bool converged = false;
   const int n_iter = max_iter < N ? max_iter : (int)N;
-  // device-side history ring: alpha/beta of iteration k are copied to the host arrays asynchronously
+  const int min_it = min_iter < n_iter - 1 ? min_iter : n_iter - 1;
+  const int n_hist = hist_len < n_iter ? hist_len : n_iter;
+  // The convergence decision is taken on the device (k_direction); the host reads it one iteration late from pinned
+  // memory, so the next iteration is already queued while it waits and the GPU never idles on the round trip.  The
+  // iteration queued past convergence is a no-op on x (alpha = 0).
+  int polled_it = -1;                     // iteration whose poll is in flight (-1: none)
+  CgPoll last = {1.0f, 0, 0};
   for (it = 0; it < n_iter; ++it) {
     int rc = apply_operator(op, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(k_coldot, dim3(nb), dim3(256), 0, st, p, Ap, part_a, N, T);
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
     hipLaunchKernelGGL(k_update, dim3(nb), dim3(256), 0, st, p, Ap, part_a, nb, x, r, part_rr, state,
-                       alpha_d + (size_t)slot * kMaxT, N, T, eps, stop_after, it & 1);
-    if (K > 0) hipLaunchKernelGGL(k_Ltr, dim3(nb), dim3(256), 0, st, L, r, part_w, N, T, K, rows_per_block);
+                       alpha_d + (size_t)slot * kMaxT, L, part_w, N, T, K, eps, stop_after, it & 1);
     hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, Cinv, part_w, nb, r, z, part_rz, N, T, K,
                        precond_sigma2);
+    const bool hist_pending = it < n_hist - 1;
+    const bool check_now = it >= min_it && !hist_pending && ((it - min_it) % check_every == 0 || it == n_iter - 1);
     hipLaunchKernelGGL(k_direction, dim3(nb), dim3(256), 0, st, z, p, part_rz, part_rr, nb, state,
-                       beta_d + (size_t)slot * kMaxT, N, T, eps, it & 1);
-    const bool hist_pending = it < (hist_len < n_iter ? hist_len : n_iter) - 1;
-    const int min_it = min_iter < n_iter - 1 ? min_iter : n_iter - 1;
-    if (it >= min_it && !hist_pending && ((it - min_it) % check_every == 0 || it == n_iter - 1)) {
-      CG_CHECK(hipMemcpyAsync(&mean_resid, &state->mean_resid, sizeof(float), hipMemcpyDeviceToHost, st));
-      CG_CHECK(hipStreamSynchronize(st));
-      if (mean_resid != mean_resid) {
-        if (iterations_host) *iterations_host = it + 1;
-        if (mean_resid_host) *mean_resid_host = mean_resid;
-        return RPGP_ENUMERIC;
-      }
-      if (mean_resid < tolerance) {
-        converged = true;
+                       beta_d + (size_t)slot * kMaxT, N, T, eps, it & 1, check_now ? 1 : 0, tolerance, it + 1);
+    if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
+      CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
+      last = hpoll[polled_it % kPollRing];
+      polled_it = -1;
+      if (last.done) {
         ++it;
         break;
       }
     }
+    if (check_now) {
+      CG_CHECK(hipMemcpyAsync(&hpoll[it % kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
+      CG_CHECK(hipEventRecord(g_poll.ev[it % kPollRing], st));
+      polled_it = it;
+    }
   }
   hipLaunchKernelGGL(k_unnormalise, dim3(nb), dim3(256), 0, st, x, state, N, T);
-  const int nh = it < hist_len ? it : hist_len;
+  CG_CHECK(hipMemcpyAsync(&hpoll[kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
+  CG_CHECK(hipStreamSynchronize(st));
+  last = hpoll[kPollRing];
+  const int iters_done = last.done ? last.iters : it;
+  const int nh = iters_done < hist_len ? iters_done : hist_len;
   if (nh > 0) {   // history rows are kMaxT wide on the device, [hist_len][kMaxT] on the host
     CG_CHECK(hipMemcpyAsync(alpha_hist_host, alpha_d, (size_t)nh * kMaxT * sizeof(float), hipMemcpyDeviceToHost, st));
     CG_CHECK(hipMemcpyAsync(beta_hist_host, beta_d, (size_t)nh * kMaxT * sizeof(float), hipMemcpyDeviceToHost, st));
+    CG_CHECK(hipStreamSynchronize(st));
   }
-  CG_CHECK(hipMemcpyAsync(&mean_resid, &state->mean_resid, sizeof(float), hipMemcpyDeviceToHost, st));
-  CG_CHECK(hipStreamSynchronize(st));
-  if (iterations_host) *iterations_host = it;
-  if (mean_resid_host) *mean_resid_host = mean_resid;
-  (void)converged;
+  if (iterations_host) *iterations_host = iters_done;
+  if (mean_resid_host) *mean_resid_host = last.mean_resid;
+  if (last.done == 2 || last.mean_resid != last.mean_resid) return RPGP_ENUMERIC;
   return 0;
 }
 

@@ -565,30 +565,45 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
 }
 
 // out[row][t] = scale * (sum_k slabR[k][row][t] + sum_{rb < row/BR} slabT[rb][row][t]) + noise * V[row][t]
-__global__ void mvm_reduce_kernel(const float *__restrict__ slabR, const float *__restrict__ slabT,
+// A workgroup owns 32 consecutive outputs; its 8 half-waves split the slab entries (entry k goes to group k % 8, each
+// read is a 128-byte contiguous segment) and the 8 group sums are added in a fixed order: deterministic, and short
+// enough for the small problems (N < 10k) where a one-thread-per-output loop over ~150 slabs was latency-bound.
+constexpr int kRedGroups = 8;
+constexpr int kRedOutputs = 32;
+__global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict__ slabR, const float *__restrict__ slabT,
                                   const float *__restrict__ V, float *__restrict__ out, int M, int N, int T,
                                   int BR, int chunk_cols, int sym, float scale, float noise,
                                   const int *__restrict__ guard, int rb0, int rb1, int slab_row0, int slab_rows) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (size_t)M * T) return;
+  __shared__ float sacc[kRedGroups][kRedOutputs];
+  const int o = threadIdx.x & (kRedOutputs - 1), g = threadIdx.x / kRedOutputs;
+  const size_t gid = (size_t)blockIdx.x * kRedOutputs + o;
+  const bool valid = gid < (size_t)M * T;
+  float acc = 0.f;
+  if (valid) {
+    const int row = (int)(gid / T);
+    const int rb = row / BR;
+    const int cbase = sym ? rb * BR : 0;
+    const int nk = (N - cbase + chunk_cols - 1) / chunk_cols;
+    if (rb >= rb0 && rb < rb1) {                    // row products exist only for this call's row blocks
+      const size_t lid = gid - (size_t)slab_row0 * T;
+      for (int k = g; k < nk; k += kRedGroups) acc += slabR[(size_t)k * slab_rows * T + lid];
+    }
+    if (sym) {
+      const int bend = rb < rb1 ? rb : rb1;         // transposed products written by row blocks rb0 <= b < min(rb, rb1)
+      for (int b = rb0 + g; b < bend; b += kRedGroups) acc += slabT[(size_t)(b - rb0) * N * T + gid];
+    }
+  }
+  sacc[g][o] = acc;
+  __syncthreads();
+  if (g != 0 || !valid) return;
   if (guard && *guard == 0) {   // prepared (factorised) path used although rpgp_prepare flagged the range as unsafe
     out[gid] = __builtin_nanf("");
     return;
   }
-  const int row = (int)(gid / T);
-  const int rb = row / BR;
-  const int cbase = sym ? rb * BR : 0;
-  const int nk = (N - cbase + chunk_cols - 1) / chunk_cols;
-  float acc = 0.f;
-  if (rb >= rb0 && rb < rb1) {                    // row products exist only for this call's row blocks
-    const size_t lid = gid - (size_t)slab_row0 * T;
-    for (int k = 0; k < nk; ++k) acc += slabR[(size_t)k * slab_rows * T + lid];
-  }
-  if (sym) {
-    const int bend = rb < rb1 ? rb : rb1;         // transposed products written by row blocks rb0 <= b < min(rb, rb1)
-    for (int b = rb0; b < bend; ++b) acc += slabT[(size_t)(b - rb0) * N * T + gid];
-  }
-  float r = scale * acc;
+  float tot = sacc[0][o];
+#pragma unroll
+  for (int q = 1; q < kRedGroups; ++q) tot += sacc[q][o];
+  float r = scale * tot;
   if (noise != 0.f) r = __builtin_fmaf(noise, V[gid], r);
   out[gid] = r;
 }
@@ -1524,7 +1539,7 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
     ++g_prof_n;
   }
   const size_t total = (size_t)M * T;
-  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V,
+  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st, slabR, slabT, V,
                      out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise, (const int *)nullptr, p.rb0,
                      p.rb1, p.row0, p.rows);
   return launch_status();
@@ -1796,7 +1811,7 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
     ++g_prof_n;
   }
   const size_t total = (size_t)N * T;
-  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR, slabT, V, out,
+  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st, slabR, slabT, V, out,
                      (int)N, (int)N, T, p.BR, p.chunk_cols, 1, scale, noise,
                      reinterpret_cast<const int *>(L.header), p.rb0, p.rb1, p.row0, p.rows);
   return launch_status();

@@ -6,7 +6,7 @@ from rpgp_amd.operators import AdditiveRPOperator, AddedDiagOperator
 from rpgp_amd.precond import build_preconditioner
 warnings.simplefilter("ignore")
 dev = torch.device("cuda:0")
-N, d, J = 50000, 20, 20
+N, d, J = (int(sys.argv[1]) if len(sys.argv) > 1 else 50000), 20, 20
 X = torch.randn(N, d, generator=torch.Generator().manual_seed(0)).to(dev)
 P = torch.randn(d, J, generator=torch.Generator().manual_seed(1)).to(dev)
 Z = ops.project(X, (P / math.sqrt(d)).contiguous())

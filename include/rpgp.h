@@ -191,6 +191,44 @@ int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float
                            void *workspace, size_t workspace_bytes, float *row_scratch, void *stream);
 
 /*
+ * Generalised additive family — the other members behind the same operator:
+ *     K[i,i'] = scale * sum_{c < ncomp} weights[c] * phi_kind( columns [c*group, (c+1)*group) of Z )
+ *   kind RBF      exp(-r^2/2), r^2 summed over the group's columns   (k > 1 sub-kernels of training_routines.py:172-174,
+ *                 the product groups of polynomial_projection_kernels.py:70-86; group in {1,2,3,4,5,8,10,20})
+ *   kind MATERN15 (1 + sqrt3 r) exp(-sqrt3 r)     kind IMQ  (1 + r^2)^(-1/2)     kind COSINE  cos(pi r)
+ *                 (`kernel_type` of training_routines.py:47-88, imq_kernel.py:8-9; group must be 1)
+ * `weights` (DEVICE, ncomp floats, required) are the per-component output scales (the `weighted` ScaleKernels of
+ * polynomial_projection_kernels.py:88-98; all 1/J for additive_rp).  Z holds ncomp*group columns, already divided by
+ * the lengthscales.  Same tile / dense kernels as the hot path with a different kernel-function policy; no factorised
+ * fast path, no float64 variant.
+ * rpgp_family_bilinear_grad*: gZ as rpgp_bilinear_grad; gcomp[c] (DEVICE, ncomp) = 0.5 sum_ii' S_ii' phi_c(i,i'), the
+ * unweighted per-component sums (d/d weights[c] = scale * gcomp[c]; d/d scale = sum_c weights[c] gcomp[c]).
+ */
+#define RPGP_KIND_RBF 0
+#define RPGP_KIND_MATERN15 1
+#define RPGP_KIND_IMQ 2
+#define RPGP_KIND_COSINE 3
+typedef struct rpgp_family {
+  int kind, group, ncomp;
+  const float *weights;
+} rpgp_family;
+size_t rpgp_family_mvm_workspace_bytes(int64_t M, int64_t N, int T, int sym);
+int rpgp_family_mvm_sym(const rpgp_family *fam, const float *Z, const float *V, float *out, int64_t N, int ldz, int T,
+                        float scale, float noise, void *workspace, size_t workspace_bytes, void *stream);
+int rpgp_family_mvm_rect(const rpgp_family *fam, const float *Z1, const float *Z2, const float *V, float *out,
+                         int64_t M, int64_t N, int ldz1, int ldz2, int T, float scale, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int rpgp_family_dense(const rpgp_family *fam, const float *Z1, const float *Z2, float *out, int64_t M, int64_t N,
+                      int ldz1, int ldz2, int64_t ldo, float scale, void *stream);
+size_t rpgp_family_bilinear_grad_workspace_bytes(int64_t N, int ncols, int ncomp);
+int rpgp_family_bilinear_grad(const rpgp_family *fam, const float *Z, const float *L, const float *R, float *gZ,
+                              float *gcomp, int64_t N, int ldz, int ldg, int T, float scale, void *workspace,
+                              size_t workspace_bytes, void *stream);
+int rpgp_family_bilinear_grad_dense(const rpgp_family *fam, const float *Z, const float *S, float *gZ, float *gcomp,
+                                    int64_t N, int ldz, int ldg, int64_t lds, float scale, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+
+/*
  * Native mBCG executor (replaces gpytorch.utils.linear_cg as configured at gp_experiment_runner.py:324-329; algorithm in
  * SURVEY.md Appendix B.2).  Solves (A) X = rhs for T <= 16 right-hand sides with A described by `rpgp_operator`
  * (noise included), optional Woodbury preconditioner M = L L^T + sigma2 I given as L (N x k, k <= 16) and
@@ -203,6 +241,7 @@ int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float
 #define RPGP_OP_FUSED_PREPARED 1  /* rpgp_mvm_sym_prepared on prep */
 #define RPGP_OP_SKI 2             /* rpgp_ski_mvm on Z + grid_params */
 #define RPGP_OP_DENSE 3           /* cached-K: symmetric Kd (N x N, row stride ldk) in HBM, applied by rpgp_dense_mvm */
+#define RPGP_OP_FAMILY 4          /* rpgp_family_mvm_sym on Z + family */
 typedef struct rpgp_operator {
   int kind;
   int64_t N;
@@ -213,6 +252,7 @@ typedef struct rpgp_operator {
   const float *grid_params;
   const float *Kd;
   int64_t ldk;
+  const rpgp_family *family;
 } rpgp_operator;
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank);
 int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,

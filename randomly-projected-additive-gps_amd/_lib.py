@@ -54,6 +54,13 @@ SIGNATURES = {
     "rpgp_ski_diag": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp]),
     "rpgp_ski_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz,
                                       _vp, _vp]),
+    "rpgp_family_mvm_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "rpgp_family_mvm_sym": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _f32, _vp, _sz, _vp]),
+    "rpgp_family_mvm_rect": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _f32, _vp, _sz, _vp]),
+    "rpgp_family_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _f32, _vp]),
+    "rpgp_family_bilinear_grad_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "rpgp_family_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp, _sz, _vp]),
+    "rpgp_family_bilinear_grad_dense": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _f32, _vp, _sz, _vp]),
     "rpgp_mbcg_workspace_bytes": (_sz, [_vp, _int, _int]),
     "rpgp_mbcg_solve": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _f32, _int, _vp, _vp, _f32, _vp, _vp, _vp,
                                _vp, _vp, _sz, _vp]),
@@ -72,10 +79,17 @@ class RpgpOperator(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("N", ctypes.c_int64), ("J", ctypes.c_int), ("ldz", ctypes.c_int),
                 ("j0", ctypes.c_int), ("j1", ctypes.c_int), ("G", ctypes.c_int), ("scale", ctypes.c_float),
                 ("noise", ctypes.c_float), ("Z", ctypes.c_void_p), ("prep", ctypes.c_void_p),
-                ("grid_params", ctypes.c_void_p), ("Kd", ctypes.c_void_p), ("ldk", ctypes.c_int64)]
+                ("grid_params", ctypes.c_void_p), ("Kd", ctypes.c_void_p), ("ldk", ctypes.c_int64),
+                ("family", ctypes.c_void_p)]
 
 
-RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI, RPGP_OP_DENSE = 0, 1, 2, 3
+class RpgpFamily(ctypes.Structure):
+    """struct rpgp_family of include/rpgp.h."""
+    _fields_ = [("kind", ctypes.c_int), ("group", ctypes.c_int), ("ncomp", ctypes.c_int), ("weights", ctypes.c_void_p)]
+
+
+RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI, RPGP_OP_DENSE, RPGP_OP_FAMILY = 0, 1, 2, 3, 4
+RPGP_KIND_RBF, RPGP_KIND_MATERN15, RPGP_KIND_IMQ, RPGP_KIND_COSINE = 0, 1, 2, 3
 
 _lib = None
 

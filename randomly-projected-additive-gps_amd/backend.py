@@ -24,6 +24,12 @@ class HipBackend:
     ski_mvm = staticmethod(ops.ski_mvm)
     ski_diag = staticmethod(ops.ski_diag)
     ski_bilinear_grad = staticmethod(ops.ski_bilinear_grad)
+    make_family = staticmethod(ops.Family)
+    family_mvm_sym = staticmethod(ops.family_mvm_sym)
+    family_mvm_rect = staticmethod(ops.family_mvm_rect)
+    family_dense = staticmethod(ops.family_dense)
+    family_bilinear_grad = staticmethod(ops.family_bilinear_grad)
+    family_bilinear_grad_dense = staticmethod(ops.family_bilinear_grad_dense)
     make_operator_desc = staticmethod(ops.make_operator_desc)
     mbcg_solve = staticmethod(ops.mbcg_solve)
 

@@ -80,6 +80,139 @@ __device__ __forceinline__ float pair_kernel_sum(const float (&a)[JT], const flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel-function policies.  The hot path is KfBase (unweighted sum of 1-D RBFs).  The other members of the
+// reference's additive family (`kernel_type` of training_routines.py:47-88, k > 1 sub-kernels of
+// :172-174, per-component weights of polynomial_projection_kernels.py:88-98) run through the SAME tile / dense kernels
+// with a different policy:
+//     K[i,i'] = scale * sum_c w[c] * phi(columns [c*G, (c+1)*G) of Z)
+// `pre` is the factor applied to Z when it is loaded (so the inner loop works on prescaled differences dd), `val` the
+// 1-D function of dd, `val_grad` additionally returns g with  d phi / d z_i = mulG * g.
+// ---------------------------------------------------------------------------------------------
+template <int KIND> struct Phi;
+template <> struct Phi<RPGP_KIND_RBF> {                 // exp(-d^2 / 2) = exp2(-(c d)^2)
+  static constexpr float pre = kExp2Scale;
+  static constexpr float mulG = -1.0f / kExp2Scale;
+  static __device__ __forceinline__ float val(float dd) { return fast_exp2(-(dd * dd)); }
+  static __device__ __forceinline__ void val_grad(float dd, float &phi, float &g) {
+    phi = fast_exp2(-(dd * dd));
+    g = phi * dd;
+  }
+};
+template <> struct Phi<RPGP_KIND_MATERN15> {            // (1 + sqrt3 r) exp(-sqrt3 r), dd = sqrt3 (z - z')
+  static constexpr float pre = 1.7320508075688772f;
+  static constexpr float mulG = -1.7320508075688772f;
+  static __device__ __forceinline__ float val(float dd) {
+    const float u = __builtin_fabsf(dd);
+    return (1.0f + u) * fast_exp2(-1.4426950408889634f * u);
+  }
+  static __device__ __forceinline__ void val_grad(float dd, float &phi, float &g) {
+    const float u = __builtin_fabsf(dd);
+    const float e = fast_exp2(-1.4426950408889634f * u);
+    phi = (1.0f + u) * e;
+    g = dd * e;                                         // d phi / d dd = -dd e
+  }
+};
+template <> struct Phi<RPGP_KIND_IMQ> {                 // (1 + r^2)^(-1/2)   (imq_kernel.py:8-9)
+  static constexpr float pre = 1.0f;
+  static constexpr float mulG = -1.0f;
+  static __device__ __forceinline__ float val(float dd) { return __builtin_amdgcn_rsqf(__builtin_fmaf(dd, dd, 1.0f)); }
+  static __device__ __forceinline__ void val_grad(float dd, float &phi, float &g) {
+    phi = __builtin_amdgcn_rsqf(__builtin_fmaf(dd, dd, 1.0f));
+    g = dd * phi * phi * phi;
+  }
+};
+template <> struct Phi<RPGP_KIND_COSINE> {              // cos(pi r) (period 1); v_cos/v_sin take revolutions: dd = (z - z') / 2
+  static constexpr float pre = 0.5f;
+  static constexpr float mulG = -3.14159265358979323846f;
+  static __device__ __forceinline__ float val(float dd) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(dd)); }
+  static __device__ __forceinline__ void val_grad(float dd, float &phi, float &g) {
+    const float f = __builtin_amdgcn_fractf(dd);
+    phi = __builtin_amdgcn_cosf(f);
+    g = __builtin_amdgcn_sinf(f);
+  }
+};
+
+struct KfBase {                                         // the hot path: sum_j exp2(-(a_j - b_j)^2), weights folded in `scale`
+  static constexpr float pre = kExp2Scale;
+  static constexpr int group = 1;
+  static constexpr bool weighted = false;
+  template <int JT>
+  static __device__ __forceinline__ float pair_sum(const float (&a)[JT], const float (&b)[JT], const float *) {
+    return pair_kernel_sum<JT>(a, b);
+  }
+};
+
+template <int KIND>
+struct KfPhi {                                          // weighted sum of 1-D functions
+  static constexpr float pre = Phi<KIND>::pre;
+  static constexpr float mulG = Phi<KIND>::mulG;
+  static constexpr int group = 1;
+  static constexpr bool weighted = true;
+  template <int JT>
+  static __device__ __forceinline__ float pair_sum(const float (&a)[JT], const float (&b)[JT], const float *w) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc = __builtin_fmaf(w[j], Phi<KIND>::val(a[j] - b[j]), acc);
+    return acc;
+  }
+  // per-column gradient factors and per-component values for the bilinear derivative
+  template <int JT>
+  static __device__ __forceinline__ void pair_grad(const float (&a)[JT], const float *b, const float *w, float S,
+                                                   float (&accG)[JT], float (&accC)[JT]) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      float phi, g;
+      Phi<KIND>::val_grad(a[j] - b[j], phi, g);
+      accG[j] = __builtin_fmaf(S * w[j], g, accG[j]);
+      accC[j] = __builtin_fmaf(S, phi, accC[j]);
+    }
+  }
+};
+
+template <int G>
+struct KfGroupRbf {                                     // weighted sum of G-dimensional RBFs (products of G 1-D RBFs)
+  static constexpr float pre = kExp2Scale;
+  static constexpr float mulG = -1.0f / kExp2Scale;
+  static constexpr int group = G;
+  static constexpr bool weighted = true;
+  template <int JT>
+  static __device__ __forceinline__ float pair_sum(const float (&a)[JT], const float (&b)[JT], const float *w) {
+    static_assert(JT % G == 0, "column pieces must hold whole groups");
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < JT / G; ++c) {
+      float r2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < G; ++m) {
+        const float dd = a[c * G + m] - b[c * G + m];
+        r2 = __builtin_fmaf(dd, dd, r2);
+      }
+      acc = __builtin_fmaf(w[c], fast_exp2(-r2), acc);
+    }
+    return acc;
+  }
+  template <int JT>
+  static __device__ __forceinline__ void pair_grad(const float (&a)[JT], const float *b, const float *w, float S,
+                                                   float (&accG)[JT], float (&accC)[JT / G]) {
+#pragma unroll
+    for (int c = 0; c < JT / G; ++c) {
+      float dd[G];
+      float r2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < G; ++m) {
+        dd[m] = a[c * G + m] - b[c * G + m];
+        r2 = __builtin_fmaf(dd[m], dd[m], r2);
+      }
+      const float phi = fast_exp2(-r2);
+      const float sw = S * w[c] * phi;
+#pragma unroll
+      for (int m = 0; m < G; ++m) accG[c * G + m] = __builtin_fmaf(sw, dd[m], accG[c * G + m]);
+      accC[c] = __builtin_fmaf(S, phi, accC[c]);
+    }
+  }
+};
+
 template <int JT>
 __device__ __forceinline__ void lds_load_cols(const float *sB, int idx, float (&b)[JT]) {
   constexpr int STR = ColStride<JT>::v;
@@ -141,12 +274,12 @@ __device__ __forceinline__ void wg_to_tile(int lin, int N, int BR, int chunk, bo
   kchunk = lin - acc;
 }
 
-template <int JT, int TT, int R, bool SYM>
+template <int JT, int TT, int R, bool SYM, class KF = KfBase>
 __global__ __launch_bounds__(256) void mvm_tile_kernel(
     const float *__restrict__ Z1, const float *__restrict__ Z2, const float *__restrict__ V,
     float *__restrict__ slabR, float *__restrict__ slabT, int M, int N, int ldz1, int ldz2, int ldv,
     int j0, int t0, int tcnt, int chunk_cols, int rotdir, int accumulate, int w0, int rb_first, int slab_row0,
-    int slab_rows) {
+    int slab_rows, const float *__restrict__ wts) {
   constexpr int BR = 256 * R;
   constexpr int SC = StageCols<TT>::v;
   constexpr int STR = ColStride<JT>::v;
@@ -166,6 +299,15 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
   const int c_begin = (int)cb;
   const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
 
+  // component weights of this column piece (uniform; unused by the hot-path policy)
+  float wreg[KF::weighted ? JT / KF::group : 1];
+  if constexpr (KF::weighted) {
+#pragma unroll
+    for (int c = 0; c < JT / KF::group; ++c) wreg[c] = wts[j0 / KF::group + c];
+  } else {
+    wreg[0] = 0.f;
+  }
+
   float a[R][JT];
   float vrow[R][TT];
   float accR[R][TT];
@@ -175,7 +317,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
     const bool valid = row < M;
 #pragma unroll
     for (int j = 0; j < JT; ++j)
-      a[r][j] = valid ? Z1[(size_t)row * ldz1 + j0 + j] * kExp2Scale : 0.f;
+      a[r][j] = valid ? Z1[(size_t)row * ldz1 + j0 + j] * KF::pre : 0.f;
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       vrow[r][t] = (SYM && valid && t < tcnt) ? V[(size_t)row * ldv + t0 + t] : 0.f;
@@ -190,7 +332,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
       const bool cv = col < c_end;
 #pragma unroll
       for (int j = 0; j < JT; ++j)
-        sB[tid * STR + j] = cv ? Z2[(size_t)col * ldz2 + j0 + j] * kExp2Scale : 0.f;
+        sB[tid * STR + j] = cv ? Z2[(size_t)col * ldz2 + j0 + j] * KF::pre : 0.f;
 #pragma unroll
       for (int t = 0; t < TT; ++t)
         sV[tid * TT + t] = (cv && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
@@ -215,7 +357,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
           for (int t = 0; t < TT; ++t) tsum[t] = accT[t];
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const float ks = pair_kernel_sum<JT>(a[r], b);
+            const float ks = KF::template pair_sum<JT>(a[r], b, wreg);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
               accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
@@ -234,7 +376,7 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
           lds_load_vec<TT>(sV, idx, v);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const float ks = pair_kernel_sum<JT>(a[r], b);
+            const float ks = KF::template pair_sum<JT>(a[r], b, wreg);
 #pragma unroll
             for (int t = 0; t < TT; ++t) accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
           }
@@ -612,33 +754,36 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
 // Dense block: out[m][n] = scale * sum_j exp(-0.5 (Z1[m,j]-Z2[n,j])^2).  One thread per output column
 // (coalesced stores), RT rows per workgroup held in LDS.
 // ---------------------------------------------------------------------------------------------
-template <int JT>
+template <int JT, class KF = KfBase>
 __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ Z1, const float *__restrict__ Z2,
                                                     float *__restrict__ out, int M, int N, int ldz1, int ldz2,
-                                                    long long ldo, int j0, float scale, int accumulate) {
+                                                    long long ldo, int j0, float scale, int accumulate,
+                                                    const float *__restrict__ wts) {
   constexpr int RT = 16;
   __shared__ float sA[RT][JT];
+  float wreg[KF::weighted ? JT / KF::group : 1];
+  if constexpr (KF::weighted) {
+#pragma unroll
+    for (int c = 0; c < JT / KF::group; ++c) wreg[c] = wts[j0 / KF::group + c];
+  } else {
+    wreg[0] = 0.f;
+  }
   const int tid = threadIdx.x;
   const int col = blockIdx.x * 256 + tid;
   const int m0 = blockIdx.y * RT;
   for (int e = tid; e < RT * JT; e += 256) {
     const int r = e / JT, j = e % JT;
-    sA[r][j] = (m0 + r < M) ? Z1[(size_t)(m0 + r) * ldz1 + j0 + j] * kExp2Scale : 0.f;
+    sA[r][j] = (m0 + r < M) ? Z1[(size_t)(m0 + r) * ldz1 + j0 + j] * KF::pre : 0.f;
   }
   __syncthreads();
   if (col >= N) return;
   float b[JT];
 #pragma unroll
-  for (int j = 0; j < JT; ++j) b[j] = Z2[(size_t)col * ldz2 + j0 + j] * kExp2Scale;
+  for (int j = 0; j < JT; ++j) b[j] = Z2[(size_t)col * ldz2 + j0 + j] * KF::pre;
 #pragma unroll 4
   for (int r = 0; r < RT; ++r) {
     if (m0 + r >= M) break;
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      float d = sA[r][j] - b[j];
-      acc += fast_exp2(-(d * d));
-    }
+    const float acc = KF::template pair_sum<JT>(sA[r], b, wreg);
     float *dst = out + (size_t)(m0 + r) * ldo + col;
     *dst = accumulate ? __builtin_fmaf(scale, acc, *dst) : scale * acc;
   }
@@ -851,6 +996,159 @@ __global__ void bilinear_reduce_kernel(const float *__restrict__ slabG, const fl
     for (int s = 0; s < nsplit; ++s) acc += slabS[(size_t)s * N + row];
     rowS[row] = accumulate ? rowS[row] + acc : acc;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear derivative for the generalised family (weighted policies): same sweep as bilinear_kernel, but the
+// per-row by-products are the UNWEIGHTED per-component sums  rowC[i][c] = sum_i' S_ii' phi_c(i,i')  (the gradients of
+// the component weights and of the outer scale follow from them on the host).
+// ---------------------------------------------------------------------------------------------
+template <int JT, int TT, class KF>
+__global__ __launch_bounds__(256) void family_bilinear_kernel(const float *__restrict__ Z, const float *__restrict__ L,
+                                                              const float *__restrict__ Rm, float *__restrict__ slabG,
+                                                              float *__restrict__ slabC, int N, int ldz, int T, int j0,
+                                                              int cols_per_split, const float *__restrict__ wts) {
+  constexpr int STR = JT + 2 * TT;
+  constexpr int NC = JT / KF::group;
+  __shared__ __attribute__((aligned(16))) float sC[64 * STR];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.y * 256 + tid;
+  const bool valid = row < N;
+  const int c_begin = blockIdx.x * cols_per_split;
+  if (c_begin >= N) return;
+  const int c_end = (c_begin + cols_per_split < N) ? c_begin + cols_per_split : N;
+
+  float wreg[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) wreg[c] = wts[j0 / KF::group + c];
+  float a[JT], li[TT], ri[TT], accG[JT], accC[NC];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    a[j] = valid ? Z[(size_t)row * ldz + j0 + j] * KF::pre : 0.f;
+    accG[j] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) accC[c] = 0.f;
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    li[t] = (valid && t < T) ? L[(size_t)row * T + t] : 0.f;
+    ri[t] = (valid && t < T) ? Rm[(size_t)row * T + t] : 0.f;
+  }
+  for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * STR; e += 256) {
+      const int c = e / STR, q = e % STR;
+      const int col = c0 + c;
+      float val = 0.f;
+      if (col < c_end) {
+        if (q < JT) val = Z[(size_t)col * ldz + j0 + q] * KF::pre;
+        else if (q < JT + TT) { const int t = q - JT; val = t < T ? L[(size_t)col * T + t] : 0.f; }
+        else { const int t = q - JT - TT; val = t < T ? Rm[(size_t)col * T + t] : 0.f; }
+      }
+      sC[e] = val;
+    }
+    __syncthreads();
+    const int nc = (c_end - c0 < 64) ? c_end - c0 : 64;
+    for (int c = 0; c < nc; ++c) {
+      const float *p = sC + c * STR;
+      float S = 0.f;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        S = __builtin_fmaf(li[t], p[JT + TT + t], S);
+        S = __builtin_fmaf(ri[t], p[JT + t], S);
+      }
+      KF::template pair_grad<JT>(a, p, wreg, S, accG, accC);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) slabG[((size_t)blockIdx.x * N + row) * JT + j] = accG[j];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) slabC[((size_t)blockIdx.x * N + row) * NC + c] = accC[c];
+  }
+}
+
+// explicit symmetric weight matrix S (Cholesky regime), cf. bilinear_dense_kernel
+template <int JT, class KF>
+__global__ __launch_bounds__(256) void family_bilinear_dense_kernel(const float *__restrict__ Z,
+                                                                    const float *__restrict__ S,
+                                                                    float *__restrict__ slabG, float *__restrict__ slabC,
+                                                                    int N, int ldz, long long lds_, int j0,
+                                                                    int cols_per_split, const float *__restrict__ wts) {
+  constexpr int NC = JT / KF::group;
+  __shared__ __attribute__((aligned(16))) float sC[64 * JT];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.y * 256 + tid;
+  const bool valid = row < N;
+  const int c_begin = blockIdx.x * cols_per_split;
+  if (c_begin >= N) return;
+  const int c_end = (c_begin + cols_per_split < N) ? c_begin + cols_per_split : N;
+  float wreg[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) wreg[c] = wts[j0 / KF::group + c];
+  float a[JT], accG[JT], accC[NC];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    a[j] = valid ? Z[(size_t)row * ldz + j0 + j] * KF::pre : 0.f;
+    accG[j] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) accC[c] = 0.f;
+  for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * JT; e += 256) {
+      const int c = e / JT, q = e % JT;
+      const int col = c0 + c;
+      sC[e] = (col < c_end) ? Z[(size_t)col * ldz + j0 + q] * KF::pre : 0.f;
+    }
+    __syncthreads();
+    const int nc = (c_end - c0 < 64) ? c_end - c0 : 64;
+    for (int c = 0; c < nc; ++c) {
+      const float Sv = valid ? S[(size_t)(c0 + c) * lds_ + row] : 0.f;
+      KF::template pair_grad<JT>(a, sC + c * JT, wreg, Sv, accG, accC);
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) slabG[((size_t)blockIdx.x * N + row) * JT + j] = accG[j];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) slabC[((size_t)blockIdx.x * N + row) * NC + c] = accC[c];
+  }
+}
+
+// gZ[row][j0+j] = mulG * sum_split slabG ; rowC[row][c0 + c] = sum_split slabC
+__global__ void family_bilinear_reduce_kernel(const float *__restrict__ slabG, const float *__restrict__ slabC,
+                                              float *__restrict__ gZ, float *__restrict__ rowC, int N, int JT, int NC,
+                                              int ldg, int j0, int c0, int ncomp, int nsplit, float mulG) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)N * (JT + NC)) return;
+  const int row = (int)(gid / (JT + NC));
+  const int q = (int)(gid % (JT + NC));
+  float acc = 0.f;
+  if (q < JT) {
+    for (int s = 0; s < nsplit; ++s) acc += slabG[((size_t)s * N + row) * JT + q];
+    gZ[(size_t)row * ldg + j0 + q] = mulG * acc;
+  } else {
+    const int c = q - JT;
+    for (int s = 0; s < nsplit; ++s) acc += slabC[((size_t)s * N + row) * NC + c];
+    rowC[(size_t)row * ncomp + c0 + c] = acc;
+  }
+}
+
+// out[c] = mul * sum_row x[row][c]  (one workgroup per column, fixed order)
+__global__ __launch_bounds__(1024) void sum_columns_kernel(const float *__restrict__ x, float *__restrict__ out, int n,
+                                                           int ncols, float mul) {
+  __shared__ float sh[1024];
+  const int c = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += x[(size_t)i * ncols + c];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = sh[0] * mul;
 }
 
 // deterministic single-block sum: out[0] = mul * sum_i x[i]
@@ -1414,10 +1712,10 @@ inline int chunks_of(const TilePlan &p, int64_t N, bool sym, int b) {
 
 // `world`-way split: the chunk size is chosen for the per-rank share of the pairs so that every rank still launches
 // a few thousand workgroups; rank r gets workgroups [total*r/world, total*(r+1)/world).
-inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0) {
+inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0, bool r1 = false) {
   TilePlan p;
   // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
-  p.R = (M >= 16384) ? 2 : 1;
+  p.R = (M >= 16384 && !r1) ? 2 : 1;   // r1: the family policies are instantiated with one row per lane only
   (void)T;
   p.BR = 256 * p.R;
   p.nrb = (int)((M + p.BR - 1) / p.BR);
@@ -1460,10 +1758,12 @@ int launch_mvm_tile(const TilePlan &p, const float *Z1, const float *Z2, const f
   dim3 grid(p.w1 - p.w0), block(256);
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 2, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
-                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows,
+                       (const float *)nullptr);
   else
     hipLaunchKernelGGL((mvm_tile_kernel<JT, TT, 1, SYM>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
-                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);
+                       ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows,
+                       (const float *)nullptr);
   return launch_status();
 }
 
@@ -1494,8 +1794,8 @@ int dispatch_jt(int jt, int tt, const TilePlan &p, const float *Z1, const float 
   }
 }
 
-inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int world = 1, int rank = 0) {
-  const TilePlan p = make_plan(M, N, sym, T, world, rank);
+inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int world = 1, int rank = 0, bool r1 = false) {
+  const TilePlan p = make_plan(M, N, sym, T, world, rank, r1);
   size_t f = (size_t)p.maxchunks * p.rows * T;
   if (sym) f += (size_t)(p.rb1 - p.rb0) * N * T;
   return f;
@@ -1590,7 +1890,7 @@ int launch_dense(const float *Z1, const float *Z2, float *out, int M, int N, int
                  int j0, float scale, int accumulate, hipStream_t st) {
   dim3 grid((N + 255) / 256, (M + 15) / 16);
   hipLaunchKernelGGL((dense_kernel<JT>), grid, dim3(256), 0, st, Z1, Z2, out, M, N, ldz1, ldz2, ldo, j0, scale,
-                     accumulate);
+                     accumulate, (const float *)nullptr);
   return launch_status();
 }
 
@@ -1613,6 +1913,128 @@ int launch_bilinear_dense(const float *Z, const float *S, float *slabG, float *s
   dim3 grid(nsplit, (N + 255) / 256);
   hipLaunchKernelGGL((bilinear_dense_kernel<JT>), grid, dim3(256), 0, st, Z, S, slabG, slabS, N, ldz, lds_, j0,
                      cols_per_split);
+  return launch_status();
+}
+
+// ---- generalised family dispatch ---------------------------------------------------------------
+#include <type_traits>
+template <int V> using IntC = std::integral_constant<int, V>;
+
+// calls f(policy object) for the (kind, group) pair; RPGP_EINVAL for combinations that are not instantiated
+template <class F>
+int with_family_policy(int kind, int group, F &&f) {
+  switch (kind) {
+    case RPGP_KIND_RBF:
+      switch (group) {
+        case 1: return f(KfGroupRbf<1>{});
+        case 2: return f(KfGroupRbf<2>{});
+        case 3: return f(KfGroupRbf<3>{});
+        case 4: return f(KfGroupRbf<4>{});
+        case 5: return f(KfGroupRbf<5>{});
+        case 8: return f(KfGroupRbf<8>{});
+        case 10: return f(KfGroupRbf<10>{});
+        case 20: return f(KfGroupRbf<20>{});
+        default: return RPGP_EINVAL;
+      }
+    case RPGP_KIND_MATERN15: return group == 1 ? f(KfPhi<RPGP_KIND_MATERN15>{}) : RPGP_EINVAL;
+    case RPGP_KIND_IMQ: return group == 1 ? f(KfPhi<RPGP_KIND_IMQ>{}) : RPGP_EINVAL;
+    case RPGP_KIND_COSINE: return group == 1 ? f(KfPhi<RPGP_KIND_COSINE>{}) : RPGP_EINVAL;
+    default: return RPGP_EINVAL;
+  }
+}
+
+// column pieces: whole groups for grouped policies, {10, 4, 2, 1} columns otherwise
+template <class KF>
+inline int family_piece(int remaining) {
+  if (KF::group > 1) return KF::group;
+  return remaining >= 10 ? 10 : (remaining >= 4 ? 4 : (remaining >= 2 ? 2 : 1));
+}
+template <class KF, class F>
+int with_family_piece(int jt, F &&f) {
+  if constexpr (KF::group > 1) {
+    return f(IntC<KF::group>{});
+  } else {
+    switch (jt) {
+      case 10: return f(IntC<10>{});
+      case 4: return f(IntC<4>{});
+      case 2: return f(IntC<2>{});
+      default: return f(IntC<1>{});
+    }
+  }
+}
+
+inline int family_check(const rpgp_family *fam, int ld_a, int ld_b) {
+  if (!fam || !fam->weights || fam->ncomp <= 0 || fam->group <= 0) return RPGP_EINVAL;
+  const long long cols = (long long)fam->ncomp * fam->group;
+  if (cols > ld_a || cols > ld_b) return RPGP_EINVAL;
+  return with_family_policy(fam->kind, fam->group, [](auto) { return 0; });
+}
+
+template <class KF, int JT, bool SYM>
+int launch_family_tile(int tt, const TilePlan &p, const float *Z1, const float *Z2, const float *V, float *slabR,
+                       float *slabT, int M, int N, int ldz1, int ldz2, int ldv, int j0, int t0, int tcnt,
+                       int accumulate, const float *wts, hipStream_t st) {
+  dim3 grid(p.w1 - p.w0), block(256);
+  switch (tt) {
+    case 1:
+      hipLaunchKernelGGL((mvm_tile_kernel<JT, 1, 1, SYM, KF>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
+                         ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows, wts);
+      break;
+    case 4:
+      hipLaunchKernelGGL((mvm_tile_kernel<JT, 4, 1, SYM, KF>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
+                         ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows, wts);
+      break;
+    default:
+      hipLaunchKernelGGL((mvm_tile_kernel<JT, 12, 1, SYM, KF>), grid, block, 0, st, Z1, Z2, V, slabR, slabT, M, N, ldz1,
+                         ldz2, ldv, j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows, wts);
+      break;
+  }
+  return launch_status();
+}
+
+template <bool SYM>
+int family_mvm_common(const rpgp_family *fam, const float *Z1, const float *Z2, const float *V, float *out, int64_t M,
+                      int64_t N, int ldz1, int ldz2, int T, float scale, float noise, void *ws, size_t ws_bytes,
+                      void *stream) {
+  if (!Z1 || !Z2 || !V || !out || M <= 0 || N <= 0 || T <= 0) return RPGP_EINVAL;
+  if (M > 0x7fffffffLL || N > 0x7fffffffLL) return RPGP_EINVAL;
+  int rc = family_check(fam, ldz1, ldz2);
+  if (rc) return rc;
+  rc = rpgp_init();
+  if (rc) return rc;
+  const size_t need = mvm_workspace_floats(M, N, T, SYM, 1, 0, true) * sizeof(float);
+  if (!ws || ws_bytes < need) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const TilePlan p = make_plan(M, N, SYM, T, 1, 0, true);
+  float *slabR = reinterpret_cast<float *>(ws);
+  float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
+  const int J = fam->ncomp * fam->group;
+  const float *wts = fam->weights;
+  rc = with_family_policy(fam->kind, fam->group, [&](auto kf) -> int {
+    using KF = decltype(kf);
+    int first = 1;
+    for (int j = 0; j < J;) {
+      const int jt = family_piece<KF>(J - j);
+      for (int t0 = 0; t0 < T;) {
+        const int tt = next_t_piece(T - t0);
+        const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+        const int r2 = with_family_piece<KF>(jt, [&](auto jc) -> int {
+          return launch_family_tile<KF, decltype(jc)::value, SYM>(tt, p, Z1, Z2, V, slabR, slabT, (int)M, (int)N, ldz1,
+                                                                  ldz2, T, j, t0, tcnt, first ? 0 : 1, wts, st);
+        });
+        if (r2) return r2;
+        t0 += tcnt;
+      }
+      first = 0;
+      j += jt;
+    }
+    return 0;
+  });
+  if (rc) return rc;
+  const size_t total = (size_t)M * T;
+  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st,
+                     slabR, slabT, V, out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise,
+                     (const int *)nullptr, p.rb0, p.rb1, p.row0, p.rows);
   return launch_status();
 }
 
@@ -1944,6 +2366,131 @@ int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *g
   }
   hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, st, rowS, gscale, (int)N, 0.5f);
   return launch_status();
+}
+
+// ---- generalised family: C-ABI -------------------------------------------------------------------
+size_t rpgp_family_mvm_workspace_bytes(int64_t M, int64_t N, int T, int sym) {
+  if (M <= 0 || N <= 0 || T <= 0) return 0;
+  return mvm_workspace_floats(M, N, T, sym != 0, 1, 0, true) * sizeof(float);
+}
+
+int rpgp_family_mvm_sym(const rpgp_family *fam, const float *Z, const float *V, float *out, int64_t N, int ldz, int T,
+                        float scale, float noise, void *workspace, size_t workspace_bytes, void *stream) {
+  return family_mvm_common<true>(fam, Z, Z, V, out, N, N, ldz, ldz, T, scale, noise, workspace, workspace_bytes,
+                                 stream);
+}
+
+int rpgp_family_mvm_rect(const rpgp_family *fam, const float *Z1, const float *Z2, const float *V, float *out,
+                         int64_t M, int64_t N, int ldz1, int ldz2, int T, float scale, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+  return family_mvm_common<false>(fam, Z1, Z2, V, out, M, N, ldz1, ldz2, T, scale, 0.f, workspace, workspace_bytes,
+                                  stream);
+}
+
+int rpgp_family_dense(const rpgp_family *fam, const float *Z1, const float *Z2, float *out, int64_t M, int64_t N,
+                      int ldz1, int ldz2, int64_t ldo, float scale, void *stream) {
+  if (!Z1 || !Z2 || !out || M <= 0 || N <= 0 || ldo < N || M > 0x7fffffffLL || N > 0x7fffffffLL) return RPGP_EINVAL;
+  int rc = family_check(fam, ldz1, ldz2);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const int J = fam->ncomp * fam->group;
+  const float *wts = fam->weights;
+  return with_family_policy(fam->kind, fam->group, [&](auto kf) -> int {
+    using KF = decltype(kf);
+    int first = 1;
+    for (int j = 0; j < J;) {
+      const int jt = family_piece<KF>(J - j);
+      const int r2 = with_family_piece<KF>(jt, [&](auto jc) -> int {
+        constexpr int JT = decltype(jc)::value;
+        dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + 15) / 16));
+        hipLaunchKernelGGL((dense_kernel<JT, KF>), grid, dim3(256), 0, st, Z1, Z2, out, (int)M, (int)N, ldz1, ldz2,
+                           (long long)ldo, j, scale, first ? 0 : 1, wts);
+        return launch_status();
+      });
+      if (r2) return r2;
+      first = 0;
+      j += jt;
+    }
+    return 0;
+  });
+}
+
+size_t rpgp_family_bilinear_grad_workspace_bytes(int64_t N, int ncols, int ncomp) {
+  if (N <= 0 || ncols <= 0 || ncomp <= 0) return 0;
+  const int ns = bilinear_nsplit(N);
+  // slabG [ns][N][<=20] + slabC [ns][N][<=10] + rowC [N][ncomp]
+  return ((size_t)ns * N * 30 + (size_t)N * ncomp) * sizeof(float);
+}
+
+// mode 0: S = L R^T + R L^T from N x T factors; mode 1: explicit symmetric S (N x N, row stride lds)
+static int family_bilinear_common(const rpgp_family *fam, const float *Z, const float *L, const float *R,
+                                  const float *S, int64_t lds_, float *gZ, float *gcomp, int64_t N, int ldz, int ldg,
+                                  int T, float scale, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!Z || !gZ || !gcomp || N <= 0 || N > 0x7fffffffLL) return RPGP_EINVAL;
+  int rc = family_check(fam, ldz, ldg);
+  if (rc) return rc;
+  const int J = fam->ncomp * fam->group, C = fam->ncomp;
+  if (!workspace || workspace_bytes < rpgp_family_bilinear_grad_workspace_bytes(N, J, C)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int ns = bilinear_nsplit(N);
+  int cps = (int)((N + ns - 1) / ns);
+  cps = (cps + 63) / 64 * 64;
+  float *slabG = reinterpret_cast<float *>(workspace);
+  float *slabC = slabG + (size_t)ns * N * 20;
+  float *rowC = slabC + (size_t)ns * N * 10;
+  const float *wts = fam->weights;
+  rc = with_family_policy(fam->kind, fam->group, [&](auto kf) -> int {
+    using KF = decltype(kf);
+    for (int j = 0; j < J;) {
+      const int jt = family_piece<KF>(J - j);
+      const int r2 = with_family_piece<KF>(jt, [&](auto jc) -> int {
+        constexpr int JT = decltype(jc)::value;
+        constexpr int NC = JT / KF::group;
+        dim3 grid(ns, (unsigned)((N + 255) / 256));
+        if (S) {
+          hipLaunchKernelGGL((family_bilinear_dense_kernel<JT, KF>), grid, dim3(256), 0, st, Z, S, slabG, slabC, (int)N,
+                             ldz, (long long)lds_, j, cps, wts);
+        } else if (T <= 1) {
+          hipLaunchKernelGGL((family_bilinear_kernel<JT, 1, KF>), grid, dim3(256), 0, st, Z, L, R, slabG, slabC, (int)N,
+                             ldz, T, j, cps, wts);
+        } else if (T <= 4) {
+          hipLaunchKernelGGL((family_bilinear_kernel<JT, 4, KF>), grid, dim3(256), 0, st, Z, L, R, slabG, slabC, (int)N,
+                             ldz, T, j, cps, wts);
+        } else {
+          hipLaunchKernelGGL((family_bilinear_kernel<JT, 12, KF>), grid, dim3(256), 0, st, Z, L, R, slabG, slabC, (int)N,
+                             ldz, T, j, cps, wts);
+        }
+        int r3 = launch_status();
+        if (r3) return r3;
+        const size_t total = (size_t)N * (JT + NC);
+        hipLaunchKernelGGL(family_bilinear_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabG,
+                           slabC, gZ, rowC, (int)N, JT, NC, ldg, j, j / KF::group, C, ns, scale * KF::mulG);
+        return launch_status();
+      });
+      if (r2) return r2;
+      j += jt;
+    }
+    return 0;
+  });
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum_columns_kernel, dim3(C), dim3(1024), 0, st, rowC, gcomp, (int)N, C, 0.5f);
+  return launch_status();
+}
+
+int rpgp_family_bilinear_grad(const rpgp_family *fam, const float *Z, const float *L, const float *R, float *gZ,
+                              float *gcomp, int64_t N, int ldz, int ldg, int T, float scale, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+  if (!L || !R || T <= 0 || T > 12) return RPGP_EINVAL;
+  return family_bilinear_common(fam, Z, L, R, nullptr, 0, gZ, gcomp, N, ldz, ldg, T, scale, workspace, workspace_bytes,
+                                stream);
+}
+
+int rpgp_family_bilinear_grad_dense(const rpgp_family *fam, const float *Z, const float *S, float *gZ, float *gcomp,
+                                    int64_t N, int ldz, int ldg, int64_t lds_, float scale, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+  if (!S || lds_ < N) return RPGP_EINVAL;
+  return family_bilinear_common(fam, Z, nullptr, nullptr, S, lds_, gZ, gcomp, N, ldz, ldg, 0, scale, workspace,
+                                workspace_bytes, stream);
 }
 
 int rpgp_pivoted_cholesky(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int J, int rank, float scale,

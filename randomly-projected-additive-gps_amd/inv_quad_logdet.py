@@ -61,7 +61,7 @@ class InvQuadLogDet(torch.autograd.Function):
     """(inv_quad, logdet) = (r^T Khat^-1 r, log|Khat|) for Khat = K(Z) * outputscale + noise I."""
 
     @staticmethod
-    def forward(ctx, Z, outputscale, noise, rhs, op):
+    def forward(ctx, Z, outputscale, noise, rhs, op, comp_weights=None):
         # `op` is the AdditiveRPOperator built on (Z, outputscale); passed as a non-tensor argument
         N = Z.shape[0]
         khat = AddedDiagOperator(op, noise.detach())
@@ -126,14 +126,15 @@ class InvQuadLogDet(torch.autograd.Function):
     def backward(ctx, g_inv_quad, g_logdet):
         op = ctx.op
         need = ctx.needs_input_grad
-        gZ = gs = gn = gr = None
+        gZ = gs = gn = gr = gw = None
         if ctx.mode == "chol":
             Lc, alpha = ctx.saved_tensors
             Kinv = torch.cholesky_inverse(Lc)
             # d(g_iq * inv_quad + g_ld * logdet) = sum_{ii'} (g_ld Kinv - g_iq alpha alpha^T)[i,i'] dKhat[i,i']
             S = g_logdet * Kinv - g_inv_quad * (alpha @ alpha.t())
-            if need[0] or need[1]:
-                gZ, gs = op.dense_weight_derivative((2.0 * S).contiguous())
+            if need[0] or need[1] or need[5]:
+                gZ, gs, *rest = op.dense_weight_derivative((2.0 * S).contiguous())
+                gw = rest[0] if rest else None
             if need[2]:
                 gn = S.diagonal().sum()
             if need[3]:
@@ -144,8 +145,9 @@ class InvQuadLogDet(torch.autograd.Function):
             pre_probes = ctx.pre.solve(probes) if ctx.pre is not None else probes
             left = torch.cat([probe_solves * (g_logdet / p), -g_inv_quad * alpha], dim=1).contiguous()
             right = torch.cat([pre_probes, alpha], dim=1).contiguous()
-            if need[0] or need[1]:
-                gZ, gs = op._bilinear_derivative(left, right)
+            if need[0] or need[1] or need[5]:
+                gZ, gs, *rest = op._bilinear_derivative(left, right)
+                gw = rest[0] if rest else None
             if need[2]:
                 gn = (left * right).sum()
             if need[3]:
@@ -154,11 +156,13 @@ class InvQuadLogDet(torch.autograd.Function):
             gs = gs.reshape(ctx.op.outputscale.shape)
         if gn is not None:
             gn = gn.reshape(())
-        return gZ, gs, gn, gr, None
+        if gw is not None:
+            gw = gw.reshape(ctx.op.comp_weights.shape).to(ctx.op.comp_weights.dtype)
+        return gZ, gs, gn, gr, None, gw
 
 
 def inv_quad_logdet(op, noise, rhs):
     """op: symmetric AdditiveRPOperator on (Z, outputscale) (both may require grad); noise: 0-dim tensor; rhs: (N,)."""
     noise_t = noise.reshape(())
-    gr = InvQuadLogDet.apply(op.Z1, op.outputscale, noise_t, rhs, op)
+    gr = InvQuadLogDet.apply(op.Z1, op.outputscale, noise_t, rhs, op, getattr(op, "comp_weights", None))
     return gr

@@ -11,7 +11,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import backend as _backend
-from .operators import AdditiveRPOperator, SKIAdditiveOperator
+from .operators import AdditiveRPOperator, FamilyAdditiveOperator, SKIAdditiveOperator
 
 
 def inv_softplus(y):
@@ -81,9 +81,17 @@ class AdditiveStructureRBFKernel(Kernel):
     Its parameters (inner lengthscale 1, outputscale 1/J) are frozen by the wrapper
     (scaled_projection_kernel.py:15-17), so they are plain buffers here."""
 
-    def __init__(self, num_dims, weight=None, inner_lengthscale=1.0, ski=False, ski_options=None):
+    def __init__(self, num_dims, weight=None, inner_lengthscale=1.0, ski=False, ski_options=None, kernel_type="RBF",
+                 group=1):
         super().__init__()
         self.num_dims = num_dims
+        # `kernel_type` of training_routines.py:47-88 (Matern nu=1.5 / InverseMQ / Cosine sub-kernels) and k-dimensional
+        # RBF sub-kernels on consecutive column groups (`AdditiveKernel` of training_routines.py:172-174): the same
+        # operator with another kernel-function policy (operators.FamilyAdditiveOperator)
+        if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+            raise ValueError("Unknown kernel type")
+        self.kernel_type = kernel_type
+        self.group = int(group)
         # float64 buffers: `model.to(torch.double)` (--double) must see 1/J, not float32(1/J)
         self.register_buffer("weight", torch.tensor(1.0 / num_dims if weight is None else float(weight),
                                                     dtype=torch.float64))
@@ -100,6 +108,13 @@ class AdditiveStructureRBFKernel(Kernel):
         if il != 1.0:
             Z1 = Z1 / il
             Z2 = None if Z2 is None else Z2 / il
+        if self.kernel_type != "RBF" or self.group != 1:
+            if self.ski:
+                raise NotImplementedError("grid interpolation is built for the 1-D RBF sub-kernels only")
+            ncomp = Z1.shape[1] // self.group
+            w = torch.full((ncomp,), float(self.weight), dtype=Z1.dtype, device=Z1.device)
+            return FamilyAdditiveOperator(Z1, Z2, outputscale=outputscale, comp_weights=w, kind=self.kernel_type,
+                                          group=self.group)
         if self.ski:
             return SKIAdditiveOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight),
                                        grid_size=self.grid_size)
@@ -110,11 +125,26 @@ class AdditiveStructureRBFKernel(Kernel):
 
 
 class MemoryEfficientGamKernel(AdditiveStructureRBFKernel):
-    """gp_models/kernels/memory_efficient_gam_kernel.py:62-69 as constructed bare at training_routines.py:168:
-    sum of 1-D RBFs with the DEFAULT lengthscale softplus(0) = ln 2 and no 1/J weight."""
+    """gp_models/kernels/memory_efficient_gam_kernel.py:62-69: sum of 1-D RBFs, no 1/J weight.
+    Constructed bare at training_routines.py:168 (inside ScaledProjectionKernel: the DEFAULT lengthscale
+    softplus(0) = ln 2, frozen) or with `ard_num_dims=d` and a trainable lengthscale as the `strictly_additive`
+    GAM of training_routines.py:214-218 (then it is called on the raw inputs: Z = X / lengthscale)."""
 
-    def __init__(self, num_dims=None):
-        super().__init__(num_dims if num_dims else 1, weight=1.0, inner_lengthscale=math.log(2.0))
+    has_lengthscale = True
+
+    def __init__(self, num_dims=None, ard_num_dims=None):
+        n = ard_num_dims if ard_num_dims else (num_dims if num_dims else 1)
+        super().__init__(n, weight=1.0, inner_lengthscale=1.0)
+        self.ard_num_dims = ard_num_dims
+        self.raw_lengthscale = nn.Parameter(torch.zeros(1, ard_num_dims if ard_num_dims else 1))
+
+    def operator(self, Z1, Z2, outputscale=None, shard=None):
+        ls = self.lengthscale
+        return super().operator(Z1 / ls, None if Z2 is None else Z2 / ls, outputscale=outputscale, shard=shard)
+
+    def forward(self, x1, x2, outputscale=None, shard=None, **params):
+        same = x2 is None or x2 is x1 or (x1.shape == x2.shape and x1.data_ptr() == x2.data_ptr())
+        return self.operator(x1, None if same else x2, outputscale=outputscale, shard=shard)
 
 
 class ScaledProjectionKernel(Kernel):
@@ -157,6 +187,115 @@ class ScaledProjectionKernel(Kernel):
         z1 = self.project(x1)
         z2 = None if same else self.project(x2)
         return self.base_kernel.operator(z1, z2, outputscale=outputscale, shard=shard)
+
+
+class GeneralizedProjectionKernel(Kernel):
+    """The older projection family (gp_models/kernels/polynomial_projection_kernels.py:19-160):
+        k(x, x') = sum_c s_c prod_{m in group c} k1((p_m(x) - p_m(x')) / l_m)
+    with one base-kernel type, a projection module, equally sized multiplicative groups (`component_degrees`), one
+    lengthscale per projected dimension and one output scale per additive component (trainable iff `weighted`,
+    :88-98).  For the RBF the product over a group is the group's multi-dimensional RBF; for the other base kernels
+    only 1-D groups are built.  `forward` returns operators.FamilyAdditiveOperator."""
+
+    def __init__(self, component_degrees, d, kernel_type, projection_module, learn_proj=False, weighted=False,
+                 ski=False, ski_options=None, X=None, **kernel_kwargs):
+        super().__init__()
+        if ski:
+            raise NotImplementedError("grid interpolation is built for the additive_rp kernel only")
+        degrees = list(component_degrees)
+        if len(set(degrees)) != 1:
+            raise NotImplementedError("multiplicative groups of different sizes are not built (general_rp_poly)")
+        if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+            raise ValueError("Unknown kernel type")
+        if degrees[0] > 1 and kernel_type != "RBF":
+            raise NotImplementedError("products of non-RBF sub-kernels are not built")
+        self.component_degrees = degrees
+        self.J, self.k, self.d = len(degrees), degrees[0], d
+        self.kernel_type = kernel_type
+        self.weighted = weighted
+        self.learn_proj = learn_proj
+        self.projection_module = projection_module
+        for p in self.projection_module.parameters():
+            p.requires_grad = bool(learn_proj)
+        self.raw_lengthscales = nn.Parameter(torch.zeros(1, sum(degrees)))
+        self.raw_outputscales = nn.Parameter(inv_softplus(torch.full((self.J,), 1.0 / self.J)).float(),
+                                             requires_grad=bool(weighted))
+
+    @property
+    def lengthscales(self):
+        return F.softplus(self.raw_lengthscales)
+
+    @property
+    def outputscales(self):
+        return F.softplus(self.raw_outputscales)
+
+    def initialize(self, mixin_range, lengthscale_range):
+        """polynomial_projection_kernels.py:139-156: normalised mixing weights, one lengthscale draw per sub-kernel
+        (same order of torch.rand calls)."""
+        mixins = torch.rand(self.J) * (mixin_range[1] - mixin_range[0]) + mixin_range[0]
+        mixins = mixins / mixins.sum()
+        self.raw_outputscales.data = inv_softplus(mixins).to(self.raw_outputscales)
+        ls = torch.cat([torch.rand(1) * (lengthscale_range[1] - lengthscale_range[0]) + lengthscale_range[0]
+                        for _ in range(sum(self.component_degrees))])
+        self.raw_lengthscales.data = inv_softplus(ls).to(self.raw_lengthscales).reshape(1, -1)
+        return self
+
+    def effective_projection(self):
+        """(d x J*k) projection with the per-dimension lengthscales folded in (a bias cancels in z - z')."""
+        return self.projection_module.weight.t() / self.lengthscales.reshape(1, -1)
+
+    def project(self, x):
+        return _Project.apply(x.contiguous(), self.effective_projection())
+
+    def forward(self, x1, x2, outputscale=None, shard=None, **params):
+        same = x2 is None or x2 is x1 or (x1.shape == x2.shape and x1.data_ptr() == x2.data_ptr())
+        z1 = self.project(x1)
+        z2 = None if same else self.project(x2)
+        return FamilyAdditiveOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
+                                      kind=self.kernel_type, group=self.k)
+
+
+class PolynomialProjectionKernel(GeneralizedProjectionKernel):
+    """J groups of k projections given as column blocks Ws (polynomial_projection_kernels.py:208-237)."""
+
+    def __init__(self, J, k, d, kernel_type, Ws, bs=None, activation=None, learn_proj=False, weighted=False, ski=False,
+                 ski_options=None, X=None, **kernel_kwargs):
+        if activation is not None:
+            raise ValueError("activation not supported through the normal projection interface. "
+                             "Use the GeneralPolynomialProjectionKernel instead.")
+        projection_module = nn.Linear(d, J * k, bias=False)
+        projection_module.weight = nn.Parameter(torch.cat(Ws, dim=1).t().contiguous())
+        super().__init__([k] * J, d, kernel_type, projection_module, learn_proj, weighted, ski, ski_options, X=X,
+                         **kernel_kwargs)
+
+
+class _GroupFeatures(nn.Module):
+    """Column selection as a (frozen) projection: weight[i, g_i] = 1 (polynomial_projection_kernels.py:243-262)."""
+
+    def __init__(self, order, d):
+        super().__init__()
+        W = torch.zeros(len(order), d)
+        for i, g in enumerate(order):
+            W[i, g] = 1.0
+        self.register_buffer("weight", W)
+
+
+class CustomAdditiveKernel(GeneralizedProjectionKernel):
+    """Additive kernel over explicit feature groups (polynomial_projection_kernels.py:240-270)."""
+
+    def __init__(self, groups, d, kernel_type, weighted=False, ski=False, ski_options=None, X=None, **kernel_kwargs):
+        order = [i for g in groups for i in g]
+        super().__init__([len(g) for g in groups], d, kernel_type, _GroupFeatures(order, d), learn_proj=False,
+                         weighted=weighted, ski=ski, ski_options=ski_options, X=X, **kernel_kwargs)
+        self.groups = groups
+
+
+class StrictlyAdditiveKernel(CustomAdditiveKernel):
+    """One 1-D sub-kernel per input dimension (polynomial_projection_kernels.py:273-281)."""
+
+    def __init__(self, d, kernel_type, weighted=False, ski=False, ski_options=None, X=None, **kernel_kwargs):
+        super().__init__([[i] for i in range(d)], d, kernel_type, weighted=weighted, ski=ski, ski_options=ski_options,
+                         X=X, **kernel_kwargs)
 
 
 class ScaleKernel(Kernel):

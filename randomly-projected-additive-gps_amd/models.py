@@ -12,7 +12,7 @@ from .dense_ops import DenseKernelOperator
 from .inv_quad_logdet import inv_quad_logdet, psd_safe_cholesky, use_cholesky
 from .likelihoods import ConstantMean, GaussianLikelihood, MultivariateNormal, LOG2PI
 from .linear_cg import linear_cg
-from .operators import AddedDiagOperator, AdditiveRPOperator, DenseOperator
+from .operators import AddedDiagOperator, AdditiveRPOperator, DenseOperator, SKIAdditiveOperator
 from .precond import build_preconditioner
 
 
@@ -83,7 +83,8 @@ class PredictionStrategy:
         if self.dense_path:
             return torch.cholesky_solve(B, self.chol)
         khat = self.khat
-        if B.shape[1] > 12 and type(self.op) is AdditiveRPOperator and not isinstance(khat, DenseOperator):
+        if B.shape[1] > 12 and isinstance(self.op, AdditiveRPOperator) and \
+                not isinstance(self.op, SKIAdditiveOperator) and not isinstance(khat, DenseOperator):
             # wide right-hand sides (predictive covariance, T = N_test) on the exact fused operator: materialise K once
             # so every CG iteration is a library GEMM on the matrix cores instead of N_test/12 fused sweeps
             N = B.shape[0]

@@ -324,6 +324,93 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         return self._bilinear_derivative((0.5 * S).contiguous(), eye)
 
 
+class FamilyAdditiveOperator(AdditiveRPOperator):
+    """K = outputscale * sum_c w_c phi_kind(group c of Z's columns) — the other members of the family behind the same
+    operator: `kernel_type` Matern / InverseMQ / Cosine sub-kernels (training_routines.py:47-88),
+    k > 1 RBF sub-kernels (:172-174) and per-component output scales (polynomial_projection_kernels.py:88-98).
+    Z is already divided by the lengthscales.  Same fused tile kernels with a different kernel-function policy
+    (rpgp_family_*); runs replicated (no J-sharding), fp32 only."""
+
+    def __init__(self, Z1, Z2=None, outputscale=None, comp_weights=None, kind="RBF", group=1):
+        super().__init__(Z1, Z2, outputscale, 1.0, shard=None)
+        self.kind, self.group = kind, int(group)
+        if Z1.shape[1] % self.group:
+            raise ValueError("the number of columns must be a multiple of the sub-kernel dimension")
+        ncomp = Z1.shape[1] // self.group
+        if comp_weights is None:
+            comp_weights = torch.full((ncomp,), 1.0 / ncomp, dtype=Z1.dtype, device=Z1.device)
+        self.comp_weights = comp_weights
+        w = comp_weights.detach().to(device=Z1.device, dtype=torch.float32).reshape(-1).contiguous()
+        self.fam = _backend.get_backend().make_family(kind, self.group, w)
+        self._wsum = float(w.sum())                 # one host sync per construction (= per optimiser step)
+
+    def _local_matmul(self, rhs, noise=0.0):
+        be = _backend.get_backend()
+        z1 = self.Z1.detach()
+        if self.symmetric:
+            return be.family_mvm_sym(self.fam, z1, rhs, self._scale, noise)
+        return be.family_mvm_rect(self.fam, z1, self.Z2.detach(), rhs, self._scale)
+
+    def _matmul(self, rhs, noise=0.0):
+        if noise and not self.symmetric:
+            raise ValueError("a diagonal can only be added to the square symmetric operator")
+        return self._local_matmul(rhs.detach(), noise if self.symmetric else 0.0)
+
+    def native_descriptor(self, noise=0.0):
+        be = _backend.get_backend()
+        if not self.symmetric or not hasattr(be, "mbcg_solve"):
+            return None
+        from . import _lib
+        z1 = self.Z1.detach().contiguous()
+        return be.make_operator_desc(_lib.RPGP_OP_FAMILY, z1.shape[0], z1.shape[1], self._scale, noise, Z=z1,
+                                     family=self.fam)
+
+    def _transpose_nonbatch(self):
+        if self.symmetric:
+            return self
+        return FamilyAdditiveOperator(self.Z2, self.Z1, self.outputscale, self.comp_weights, self.kind, self.group)
+
+    def _diagonal(self):
+        if not self.symmetric:
+            raise RuntimeError("diagonal of a rectangular cross-covariance requested")
+        # phi(0) = 1 for every member: k(x,x) = outputscale * sum_c w_c
+        return torch.full((self.Z1.shape[0],), self._scale * self._wsum, dtype=self.dtype, device=self.device)
+
+    def _get_rows(self, idx):
+        be = _backend.get_backend()
+        z2 = self.Z1 if self.symmetric else self.Z2
+        return be.family_dense(self.fam, self.Z1.detach().index_select(0, idx).contiguous(), z2.detach(), self._scale)
+
+    def to_dense(self):
+        be = _backend.get_backend()
+        z2 = self.Z1 if self.symmetric else self.Z2
+        return be.family_dense(self.fam, self.Z1.detach(), z2.detach(), self._scale)
+
+    evaluate = to_dense
+
+    def representation(self):
+        if self.symmetric:
+            return (self.Z1, self.outputscale, self.comp_weights)
+        return (self.Z1, self.Z2, self.outputscale, self.comp_weights)
+
+    def _finish_grads(self, gZ, gcomp):
+        w = self.comp_weights.detach().to(gcomp)
+        return gZ, (w * gcomp).sum(), self._scale * gcomp          # d/dZ, d/d outputscale, d/d comp_weights
+
+    def _bilinear_derivative(self, left_vecs, right_vecs):
+        if not self.symmetric:
+            raise NotImplementedError("derivatives are only needed for the train-train kernel")
+        gZ, gc = _backend.get_backend().family_bilinear_grad(self.fam, self.Z1.detach(), left_vecs.detach(),
+                                                            right_vecs.detach(), self._scale)
+        return self._finish_grads(gZ, gc)
+
+    _quad_form_derivative = _bilinear_derivative
+
+    def dense_weight_derivative(self, S):
+        gZ, gc = _backend.get_backend().family_bilinear_grad_dense(self.fam, self.Z1.detach(), S, self._scale)
+        return self._finish_grads(gZ, gc)
+
+
 class AddedDiagOperator(LinearOperator):
     """base + noise * I  (the likelihood's AddedDiagLazyTensor); the noise term is fused into the MVM kernel."""
 

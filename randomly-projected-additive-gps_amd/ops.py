@@ -383,8 +383,134 @@ def ski_bilinear_grad(Z, gp, L, R, scale, grid_size=1024):
 
 # ------------------------------------------------------------------------------------------------ native mBCG
 
-def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=0, j1=None, G=0, Kd=None):
+# ------------------------------------------------------------------------------------ generalised family
+
+KINDS = {"RBF": _lib.RPGP_KIND_RBF, "Matern": _lib.RPGP_KIND_MATERN15, "InverseMQ": _lib.RPGP_KIND_IMQ,
+         "Cosine": _lib.RPGP_KIND_COSINE}
+FAMILY_GROUPS = (1, 2, 3, 4, 5, 8, 10, 20)
+
+
+class Family:
+    """`struct rpgp_family`: kind (name of training_routines.py:47-88 or RPGP_KIND_*), group size, per-component
+    weights (device float32 tensor, kept alive here)."""
+
+    def __init__(self, kind, group, weights):
+        import ctypes
+        self.kind = KINDS[kind] if isinstance(kind, str) else int(kind)
+        self.group = int(group)
+        self.weights = _require(weights.detach().reshape(-1), "weights", 1)
+        self.ncomp = self.weights.numel()
+        if self.group not in FAMILY_GROUPS or (self.group > 1 and self.kind != _lib.RPGP_KIND_RBF):
+            raise ValueError("unsupported family member: kind %s with %d-dimensional sub-kernels (RBF groups of %s; "
+                             "other kernel types with 1-D sub-kernels)" % (kind, self.group, FAMILY_GROUPS))
+        self.struct = _lib.RpgpFamily(self.kind, self.group, self.ncomp, self.weights.data_ptr())
+        self.ref = ctypes.byref(self.struct)
+
+    @property
+    def ncols(self):
+        return self.ncomp * self.group
+
+
+def _family_cols(fam, Z, name):
+    Z = _require(Z, name, 2)
+    if Z.shape[1] != fam.ncols:
+        raise ValueError("%s must have ncomp * group = %d columns (got %d)" % (name, fam.ncols, Z.shape[1]))
+    return Z
+
+
+def family_mvm_sym(fam, Z, V, scale, noise=0.0):
+    """out = scale * sum_c w_c K_c(Z,Z) @ V + noise * V for a member of the generalised family."""
+    lib = _lib.load()
+    Z = _family_cols(fam, Z, "Z")
+    N, J = Z.shape
+    V2, squeeze = _as_matrix(V, N, "V")
+    T = V2.shape[1]
+    out = torch.empty_like(V2)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_family_mvm_workspace_bytes(N, N, T, 1))
+        _lib.check(lib.rpgp_family_mvm_sym(fam.ref, Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, float(scale),
+                                           float(noise), ws.data_ptr(), ws.numel(), _stream()), "rpgp_family_mvm_sym")
+    return out.squeeze(1) if squeeze else out
+
+
+def family_mvm_rect(fam, Z1, Z2, V, scale):
+    """out (M x T) = scale * sum_c w_c K_c(Z1, Z2) @ V."""
+    lib = _lib.load()
+    Z1 = _family_cols(fam, Z1, "Z1")
+    Z2 = _family_cols(fam, Z2, "Z2")
+    M, J = Z1.shape
+    N = Z2.shape[0]
+    V2, squeeze = _as_matrix(V, N, "V")
+    T = V2.shape[1]
+    out = torch.empty((M, T), dtype=torch.float32, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        ws = _workspace(Z1.device, lib.rpgp_family_mvm_workspace_bytes(M, N, T, 0))
+        _lib.check(lib.rpgp_family_mvm_rect(fam.ref, Z1.data_ptr(), Z2.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N,
+                                            J, J, T, float(scale), ws.data_ptr(), ws.numel(), _stream()),
+                   "rpgp_family_mvm_rect")
+    return out.squeeze(1) if squeeze else out
+
+
+def family_dense(fam, Z1, Z2, scale):
+    """Dense block K(Z1, Z2) (M x N) of a family member."""
+    lib = _lib.load()
+    Z1 = _family_cols(fam, Z1, "Z1")
+    Z2 = _family_cols(fam, Z2, "Z2")
+    M, J = Z1.shape
+    N = Z2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        _lib.check(lib.rpgp_family_dense(fam.ref, Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N,
+                                         float(scale), _stream()), "rpgp_family_dense")
+    return out
+
+
+def family_bilinear_grad(fam, Z, L, R, scale):
+    """(gZ [N x cols], gcomp [ncomp]) for sum((L R^T) * K): gcomp are the unweighted per-component sums."""
+    lib = _lib.load()
+    Z = _family_cols(fam, Z, "Z")
+    N, J = Z.shape
+    L2, _ = _as_matrix(L, N, "L")
+    R2, _ = _as_matrix(R, N, "R")
+    if L2.shape != R2.shape:
+        raise ValueError("L and R must have the same shape")
+    T = L2.shape[1]
+    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
+    gc = torch.zeros(fam.ncomp, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_family_bilinear_grad_workspace_bytes(N, J, fam.ncomp))
+        gZp, gcp = torch.empty_like(gZ), torch.empty_like(gc)
+        for t0 in range(0, T, 12):      # the derivative is additive over the columns of L, R
+            Lc, Rc = L2[:, t0:t0 + 12].contiguous(), R2[:, t0:t0 + 12].contiguous()
+            _lib.check(lib.rpgp_family_bilinear_grad(fam.ref, Z.data_ptr(), Lc.data_ptr(), Rc.data_ptr(), gZp.data_ptr(),
+                                                     gcp.data_ptr(), N, J, J, Lc.shape[1], float(scale), ws.data_ptr(),
+                                                     ws.numel(), _stream()), "rpgp_family_bilinear_grad")
+            gZ += gZp
+            gc += gcp
+    return gZ, gc
+
+
+def family_bilinear_grad_dense(fam, Z, S, scale):
+    """(gZ, gcomp) for 0.5 * sum(S * K) with an explicit symmetric N x N weight matrix S."""
+    lib = _lib.load()
+    Z = _family_cols(fam, Z, "Z")
+    S = _require(S, "S", 2)
+    N, J = Z.shape
+    if S.shape != (N, N):
+        raise ValueError("S must be %d x %d" % (N, N))
+    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
+    gc = torch.zeros(fam.ncomp, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_family_bilinear_grad_workspace_bytes(N, J, fam.ncomp))
+        _lib.check(lib.rpgp_family_bilinear_grad_dense(fam.ref, Z.data_ptr(), S.data_ptr(), gZ.data_ptr(), gc.data_ptr(),
+                                                       N, J, J, N, float(scale), ws.data_ptr(), ws.numel(), _stream()),
+                   "rpgp_family_bilinear_grad_dense")
+    return gZ, gc
+
+
+def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=0, j1=None, G=0, Kd=None, family=None):
     """Fill a `struct rpgp_operator`; returns (struct, keepalive) — keep both referenced while the solve runs."""
+    import ctypes
     d = _lib.RpgpOperator()
     d.kind, d.N, d.J, d.ldz = kind, N, J, J
     d.j0, d.j1, d.G = j0, J if j1 is None else j1, G
@@ -394,7 +520,8 @@ def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=
     d.grid_params = gp.data_ptr() if gp is not None else None
     d.Kd = Kd.data_ptr() if Kd is not None else None
     d.ldk = Kd.stride(0) if Kd is not None else 0
-    return d, (Z, prep, gp, Kd)
+    d.family = ctypes.addressof(family.struct) if family is not None else None
+    return d, (Z, prep, gp, Kd, family)
 
 
 def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_every=1, L=None, Cinv=None, sigma2=1.0):

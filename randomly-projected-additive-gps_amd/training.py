@@ -12,14 +12,13 @@ import torch.distributed as dist
 
 from . import rp
 from .distributed import JShard, is_distributed
-from .kernels import (AdditiveStructureRBFKernel, MemoryEfficientGamKernel, RBFKernel, ScaledProjectionKernel,
-                      ScaleKernel)
+from .kernels import (AdditiveStructureRBFKernel, CustomAdditiveKernel, MemoryEfficientGamKernel,
+                      PolynomialProjectionKernel, RBFKernel, ScaledProjectionKernel, ScaleKernel, StrictlyAdditiveKernel)
 from .likelihoods import GaussianLikelihood, SmoothedBoxPrior
 from .models import ExactGPModel, ExactMarginalLogLikelihood
 
-EXACT_GP_KINDS = ("full", "additive_rp")
-REFERENCE_ONLY_KINDS = ("rp", "strictly_additive", "additive", "rp_poly", "deep_rp_poly", "general_rp_poly",
-                        "multi_full", "duvenaud_additive", "sgpr")
+EXACT_GP_KINDS = ("full", "additive_rp", "strictly_additive", "additive", "rp_poly")
+REFERENCE_ONLY_KINDS = ("rp", "deep_rp_poly", "general_rp_poly", "multi_full", "duvenaud_additive", "sgpr")
 
 
 def _map_to_optim(optimizer):
@@ -57,10 +56,12 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
             raise ValueError("Memory efficient GAM with alternative sub-kernels not implemented yet.")
     if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
         raise ValueError("Unknown kernel type")
-    if kernel_type != "RBF":
-        raise NotImplementedError("only 1-D RBF sub-kernels are implemented on the fused MI355X path (SURVEY.md §8(f))")
-    if k != 1:
-        raise NotImplementedError("k > 1 sub-kernels are not implemented on the fused MI355X path (SURVEY.md §8(f))")
+    if k > 1 and kernel_type != "RBF":
+        raise NotImplementedError("k > 1 sub-kernels are built for the RBF only")
+    if k > 1 and k not in (2, 3, 4, 5, 8, 10, 20):
+        raise NotImplementedError("k-dimensional sub-kernels are instantiated for k in (2, 3, 4, 5, 8, 10, 20)")
+    if ski and (k > 1 or kernel_type != "RBF"):
+        raise NotImplementedError("grid interpolation is built for the 1-D RBF sub-kernels only")
     if keops:
         warnings.warn("keops=True is ignored: the fused HIP kernel already is the matrix-free path")
 
@@ -77,7 +78,7 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
     else:
         # batch_kernel (AdditiveStructureKernel) and the per-dimension AdditiveKernel variant are the same function:
         # (1/J) sum_j RBF_1(z_j)  (training_routines.py:169-174)
-        add_kernel = AdditiveStructureRBFKernel(J, ski=ski, ski_options=ski_options)
+        add_kernel = AdditiveStructureRBFKernel(J, ski=ski, ski_options=ski_options, kernel_type=kernel_type, group=k)
     if ard:
         ard_num_dims = d if prescale else J * k
         initial_ls = _sample_from_range(ard_num_dims, init_lengthscale_range)
@@ -88,6 +89,49 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
                                          learn_proj=learn_proj)
     proj_kernel.initialize(lengthscale=initial_ls)
     return proj_kernel
+
+
+def create_rp_poly_kernel(d, k, J, activation=None, learn_proj=False, weighted=False, kernel_type="RBF",
+                          space_proj=False, init_mixin_range=(1.0, 1.0), init_lengthscale_range=(1.0, 1.0), ski=False,
+                          ski_options=None, X=None, proj_dist="gaussian", keops=False):
+    """training_routines.py:107-128: J groups of k random projections, product of 1-D sub-kernels inside a group,
+    per-component output scales."""
+    projs = [rp.gen_rp(d, k, dist=proj_dist) for _ in range(J)]
+    if space_proj:
+        newW, _ = rp.space_equally(torch.cat(projs, dim=1).t(), lr=0.1, niter=5000)
+        newW.requires_grad = False
+        projs = [newW[i:i + 1, :].t() for i in range(J)]
+    if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+        raise ValueError("Unknown kernel type")
+    kernel = PolynomialProjectionKernel(J, k, d, kernel_type, projs, None, activation=activation, learn_proj=learn_proj,
+                                        weighted=weighted, ski=ski, ski_options=ski_options, X=X)
+    kernel.initialize(init_mixin_range, init_lengthscale_range)
+    return kernel
+
+
+def create_strictly_additive_kernel(d, weighted=False, kernel_type="RBF", init_lengthscale_range=(1.0, 1.0),
+                                    init_mixin_range=(1.0, 1.0), ski=False, ski_options=None, X=None,
+                                    memory_efficient=False, keops=False):
+    """training_routines.py:210-225: one sub-kernel per input dimension (GAM)."""
+    if kernel_type == "RBF" and memory_efficient:
+        kernel = MemoryEfficientGamKernel(ard_num_dims=d)
+        kernel.initialize(lengthscale=_sample_from_range(d, init_lengthscale_range))
+        return kernel
+    if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+        raise ValueError("Unknown kernel type")
+    kernel = StrictlyAdditiveKernel(d, kernel_type, weighted, ski=ski, ski_options=ski_options, X=X)
+    kernel.initialize(init_mixin_range, init_lengthscale_range)
+    return kernel
+
+
+def create_additive_kernel(d, groups, weighted=False, kernel_type="RBF", init_lengthscale_range=(1.0, 1.0),
+                           init_mixin_range=(1.0, 1.0), ski=False, ski_options=None, X=None, keops=False):
+    """training_routines.py:228-235: additive kernel over explicit (equally sized) feature groups."""
+    if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+        raise ValueError("Unknown kernel type")
+    kernel = CustomAdditiveKernel(groups, d, kernel_type, weighted=weighted, ski=ski, ski_options=ski_options, X=X)
+    kernel.initialize(init_mixin_range, init_lengthscale_range)
+    return kernel
 
 
 def create_full_kernel(d, ard=False, ski=False, grid_size=None, kernel_type="RBF", init_lengthscale_range=(1.0, 1.0),
@@ -123,6 +167,12 @@ def create_exact_gp(trainX, trainY, kind, devices=("cpu",), **kwargs):
     kwargs.pop("grid_ratio", None)
     if kind == "full":
         kernel = create_full_kernel(d, grid_size=grid_size, **kwargs)
+    elif kind == "strictly_additive":
+        kernel = create_strictly_additive_kernel(d, X=trainX, **kwargs)
+    elif kind == "additive":
+        kernel = create_additive_kernel(d, X=trainX, **kwargs)
+    elif kind == "rp_poly":
+        kernel = create_rp_poly_kernel(d, X=trainX, **kwargs)
     else:
         kernel = create_additive_rp_kernel(d, **kwargs)
     kernel = ScaleKernel(kernel)

@@ -6,6 +6,7 @@ import torch
 
 from oracle import dense_gp as orc
 from oracle import ski as sko
+from oracle import family as fmo
 
 
 def _np(t):
@@ -74,6 +75,40 @@ class OracleBackend:
         v = _np(V).reshape(Kd.shape[0], -1)
         r = _t(_np(Kd) @ v + noise * v, V)
         return r.squeeze(1) if squeeze else r
+
+    # ---- generalised family ----------------------------------------------------------------------------------
+    class _Fam:
+        def __init__(self, kind, group, weights):
+            self.kind, self.group, self.w = kind, int(group), _np(weights).reshape(-1)
+            self.ncomp = self.w.size
+
+    def make_family(self, kind, group, weights):
+        if group > 1 and kind != "RBF":
+            raise ValueError("unsupported family member")
+        return OracleBackend._Fam(kind, group, weights)
+
+    def family_mvm_sym(self, fam, Z, V, scale, noise=0.0):
+        squeeze = V.dim() == 1
+        v = _np(V).reshape(Z.shape[0], -1)
+        r = _t(fmo.mvm(_np(Z), _np(Z), v, fam.kind, fam.group, fam.w, scale, noise), V)
+        return r.squeeze(1) if squeeze else r
+
+    def family_mvm_rect(self, fam, Z1, Z2, V, scale):
+        squeeze = V.dim() == 1
+        v = _np(V).reshape(Z2.shape[0], -1)
+        r = _t(fmo.mvm(_np(Z1), _np(Z2), v, fam.kind, fam.group, fam.w, scale), V)
+        return r.squeeze(1) if squeeze else r
+
+    def family_dense(self, fam, Z1, Z2, scale):
+        return _t(fmo.kernel_matrix(_np(Z1), _np(Z2), fam.kind, fam.group, fam.w, scale), Z1)
+
+    def family_bilinear_grad(self, fam, Z, L, R, scale):
+        g, gc = fmo.bilinear_grad(_np(Z), _np(L), _np(R), fam.kind, fam.group, fam.w, scale)
+        return _t(g, Z), _t(gc, Z)
+
+    def family_bilinear_grad_dense(self, fam, Z, S, scale):
+        g, gc = fmo.bilinear_grad_dense(_np(Z), _np(S), fam.kind, fam.group, fam.w, scale)
+        return _t(g, Z), _t(gc, Z)
 
     # ---- SKI path -------------------------------------------------------------------------------------------
     def ski_grid(self, Z1, Z2=None, grid_size=1024):

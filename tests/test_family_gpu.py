@@ -1,0 +1,181 @@
+"""GPU parity tests (through the C-ABI) for the other members of the kernel family behind the same operator
+(rpgp_family_*) against the float64 oracle (oracle/family.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import family as fmo
+
+pytestmark = pytest.mark.gpu
+
+MEMBERS = [("RBF", 1, 20), ("RBF", 1, 7), ("RBF", 2, 6), ("RBF", 3, 6), ("RBF", 4, 8), ("RBF", 5, 10), ("RBF", 8, 8),
+           ("RBF", 10, 20), ("RBF", 20, 20), ("Matern", 1, 20), ("Matern", 1, 3), ("InverseMQ", 1, 18),
+           ("Cosine", 1, 9)]
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _setup(kind, group, cols, N, T, dev, seed=0, M=None):
+    rng = np.random.default_rng(seed)
+    scale_z = 0.5 if group >= 8 else 1.0          # keep multi-dimensional RBFs from collapsing to the identity
+    Z = (rng.normal(size=(N, cols)) * scale_z).astype(np.float32)
+    V = rng.normal(size=(N, T)).astype(np.float32)
+    w = rng.uniform(0.3, 1.2, size=cols // group).astype(np.float32)
+    from rpgp_amd import ops
+    fam = ops.Family(kind, group, torch.from_numpy(w).to(dev))
+    out = [fam, Z, V, w]
+    if M:
+        out.append((rng.normal(size=(M, cols)) * scale_z).astype(np.float32))
+    return out
+
+
+@pytest.mark.parametrize("kind,group,cols", MEMBERS)
+@pytest.mark.parametrize("T", [1, 11])
+def test_family_mvm_matches_oracle(gpu_device, kind, group, cols, T):
+    from rpgp_amd import ops
+    N, M = 1237, 301
+    fam, Z, V, w, Z1 = _setup(kind, group, cols, N, T, gpu_device, seed=cols + T, M=M)
+    Zt, Vt, Z1t = (torch.from_numpy(a).to(gpu_device) for a in (Z, V, Z1))
+    got = ops.family_mvm_sym(fam, Zt, Vt, 0.7, 0.13).cpu().numpy()
+    ref = fmo.mvm(Z, Z, V, kind, group, w, 0.7, 0.13)
+    assert _rel(got, ref) < 5e-6
+    got_r = ops.family_mvm_rect(fam, Z1t, Zt, Vt, 0.7).cpu().numpy()
+    ref_r = fmo.mvm(Z1, Z, V, kind, group, w, 0.7)
+    assert _rel(got_r, ref_r) < 5e-6
+
+
+@pytest.mark.parametrize("kind,group,cols", MEMBERS)
+def test_family_dense_and_bilinear_match_oracle(gpu_device, kind, group, cols):
+    from rpgp_amd import ops
+    N, M, T = 523, 77, 3
+    fam, Z, V, w, Z1 = _setup(kind, group, cols, N, T, gpu_device, seed=3 * cols, M=M)
+    Zt, Z1t = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(Z1).to(gpu_device)
+    Kd = ops.family_dense(fam, Z1t, Zt, 1.3).cpu().numpy()
+    assert np.abs(Kd - fmo.kernel_matrix(Z1, Z, kind, group, w, 1.3)).max() < 2e-5
+    rng = np.random.default_rng(5)
+    L, R = rng.normal(size=(N, T)).astype(np.float32), rng.normal(size=(N, T)).astype(np.float32)
+    gZ, gc = ops.family_bilinear_grad(fam, Zt, torch.from_numpy(L).to(gpu_device), torch.from_numpy(R).to(gpu_device), 1.3)
+    rZ, rc = fmo.bilinear_grad(Z.astype(np.float64), L, R, kind, group, w, 1.3)
+    assert _rel(gZ.cpu().numpy(), rZ) < 2e-5
+    assert _rel(gc.cpu().numpy(), rc) < 2e-5
+    S = rng.normal(size=(N, N)).astype(np.float32)
+    S = (S + S.T) / 2
+    gZ2, gc2 = ops.family_bilinear_grad_dense(fam, Zt, torch.from_numpy(S).to(gpu_device), 1.3)
+    rZ2, rc2 = fmo.bilinear_grad_dense(Z.astype(np.float64), S, kind, group, w, 1.3)
+    assert _rel(gZ2.cpu().numpy(), rZ2) < 2e-5
+    assert _rel(gc2.cpu().numpy(), rc2) < 2e-5
+
+
+def test_family_large_n_symmetric_equals_rectangular_and_is_linear(gpu_device):
+    """Size-independent properties at a size the dense oracle cannot reach: the symmetric sweep (each pair once, DPP
+    rotation for the transposed product) equals the rectangular sweep, and the operator is linear."""
+    from rpgp_amd import ops
+    N = 20011
+    for kind, group, cols in (("Matern", 1, 20), ("RBF", 2, 10), ("InverseMQ", 1, 5)):
+        fam, Z, V, w = _setup(kind, group, cols, N, 2, gpu_device, seed=1)
+        Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
+        a = ops.family_mvm_sym(fam, Zt, Vt, 0.5, 0.0)
+        b = ops.family_mvm_rect(fam, Zt, Zt, Vt, 0.5)
+        assert float((a - b).norm() / b.norm()) < 3e-6
+        c = ops.family_mvm_sym(fam, Zt, 2.0 * Vt[:, :1] - 3.0 * Vt[:, 1:], 0.5, 0.0)
+        assert float((c - (2.0 * a[:, :1] - 3.0 * a[:, 1:])).norm() / c.norm()) < 3e-6
+
+
+def test_family_group1_rbf_equals_hot_path(gpu_device):
+    from rpgp_amd import ops
+    N, J = 3000, 20
+    Z = torch.randn(N, J, generator=torch.Generator().manual_seed(0)).to(gpu_device)
+    V = torch.randn(N, 4, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    fam = ops.Family("RBF", 1, torch.full((J,), 1.0 / J, device=gpu_device))
+    a = ops.family_mvm_sym(fam, Z, V, 1.0, 0.1)
+    b = ops.mvm_sym(Z, V, 1.0 / J, 0.1)
+    assert float((a - b).norm() / b.norm()) < 2e-6
+
+
+def test_family_errors(gpu_device):
+    from rpgp_amd import ops
+    w = torch.ones(3, device=gpu_device)
+    with pytest.raises(ValueError):
+        ops.Family("Matern", 2, w)
+    with pytest.raises(ValueError):
+        ops.Family("RBF", 7, w)
+    fam = ops.Family("RBF", 2, w)
+    with pytest.raises(ValueError):
+        ops.family_mvm_sym(fam, torch.zeros(10, 5, device=gpu_device), torch.zeros(10, 1, device=gpu_device), 1.0)
+    with pytest.raises(TypeError):
+        ops.family_mvm_sym(fam, torch.zeros(10, 6, device=gpu_device, dtype=torch.float64),
+                           torch.zeros(10, 1, device=gpu_device), 1.0)
+
+
+@pytest.mark.parametrize("kind,model_kwargs", [
+    ("additive_rp", dict(J=20, kernel_type="Matern", prescale=True)),
+    ("additive_rp", dict(J=4, k=5, batch_kernel=False, prescale=True)),
+    ("rp_poly", dict(J=8, k=1, weighted=True, kernel_type="RBF")),
+    ("strictly_additive", dict(weighted=True, kernel_type="InverseMQ")),
+])
+@pytest.mark.parametrize("regime", ["chol", "cg"])
+def test_family_model_mll_and_prediction(gpu_device, kind, model_kwargs, regime):
+    """End to end through the kernel modules, the native mBCG executor (RPGP_OP_FAMILY) and the prediction strategy,
+    against a dense float64 computation with the model's own hyper-parameters."""
+    from rpgp_amd import settings
+    from rpgp_amd import kernels as km
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    from rpgp_amd.training import create_exact_gp
+    N, d = 1500, 6
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N, d, generator=g)
+    y = torch.sin(X).sum(1) + 0.05 * torch.randn(N, generator=g)
+    y = (y - y.mean()) / y.std()
+    Xs = torch.randn(40, d, generator=g)
+    torch.manual_seed(1)
+    if kind in ("additive_rp", "rp_poly"):
+        model, lik = create_exact_gp(X, y, kind, noise_prior=True, learn_proj=False, **model_kwargs)
+    else:
+        model, lik = create_exact_gp(X, y, kind, noise_prior=True, **model_kwargs)
+    lik.noise = 0.05
+    model, lik = model.to(gpu_device), lik.to(gpu_device)
+    model.train_inputs, model.train_targets = X.to(gpu_device), y.to(gpu_device)
+    mll = ExactMarginalLogLikelihood(lik, model)
+    base = model.covar_module.base_kernel
+    if isinstance(base, km.ScaledProjectionKernel):
+        P = base.projection_module.weight.detach().double().cpu().t()
+        ls = base.lengthscale.detach().double().cpu().reshape(-1)
+        tr = lambda A: (((A.double() / ls) @ P) if base.prescale else ((A.double() @ P) / ls)).numpy()
+        ktype, group = base.base_kernel.kernel_type, base.base_kernel.group
+        w = np.full(P.shape[1] // group, float(base.base_kernel.weight))
+    else:
+        P = base.projection_module.weight.detach().double().cpu().t()
+        ls = base.lengthscales.detach().double().cpu().reshape(-1)
+        tr = lambda A: ((A.double() @ P) / ls).numpy()
+        ktype, group = base.kernel_type, base.k
+        w = base.outputscales.detach().double().cpu().numpy()
+    s, noise, c = float(model.covar_module.outputscale), float(lik.noise), float(model.mean_module.constant)
+    Z, Zs = tr(X), tr(Xs)
+    K = fmo.kernel_matrix(Z, Z, ktype, group, w, s) + noise * np.eye(N)
+    r = y.double().numpy() - c
+    alpha = np.linalg.solve(K, r)
+    ref_mll = (-0.5 * r @ alpha - 0.5 * np.linalg.slogdet(K)[1] - 0.5 * N * math.log(2 * math.pi)
+               + float(lik.log_prior().detach())) / N
+    ctx = settings.max_cholesky_size(4000 if regime == "chol" else 100)
+    with ctx, settings.cg_tolerance(1e-4), settings.eval_cg_tolerance(1e-5), settings.num_trace_samples(30), \
+            settings.max_lanczos_quadrature_iterations(60), settings.max_cg_iterations(2000):
+        model.train()
+        val = mll(model(model.train_inputs), model.train_targets)
+        val.backward()
+        tol = 1e-4 if regime == "chol" else 2e-2                # SLQ log-det is stochastic in the CG regime
+        assert abs(val.item() - ref_mll) < tol * max(1.0, abs(ref_mll))
+        for p in model.parameters():
+            if p.requires_grad:
+                assert p.grad is not None and torch.isfinite(p.grad).all()
+        model.eval()
+        with torch.no_grad():
+            out = model(Xs.to(gpu_device))
+        Ks = fmo.kernel_matrix(Zs, Z, ktype, group, w, s)
+        mean = Ks @ alpha + c
+        cov = fmo.kernel_matrix(Zs, Zs, ktype, group, w, s) - Ks @ np.linalg.solve(K, Ks.T)
+        assert _rel(out.mean.cpu().numpy(), mean) < 1e-4
+        assert np.abs(out.variance.cpu().numpy() - np.diag(cov)).max() < 1e-4 * s + 1e-5

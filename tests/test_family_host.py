@@ -1,0 +1,205 @@
+"""Host-side tests (CPU, oracle test double) for the other members of the kernel family behind the same operator
+(SURVEY.md §8(f) rank 4): `kernel_type` sub-kernels, k > 1 RBF sub-kernels, the weighted rp_poly / strictly_additive /
+additive kinds.  The float64 reference of every check is a dense torch-autograd restatement written out in the test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import family as fmo
+from oracle import dense_gp as orc
+
+
+def _phi_t(kind, d2):
+    if kind == "RBF":
+        return torch.exp(-0.5 * d2)
+    r = torch.sqrt(d2 + 1e-300)
+    if kind == "Matern":
+        return (1 + math.sqrt(3) * r) * torch.exp(-math.sqrt(3) * r)
+    if kind == "InverseMQ":
+        return (d2 + 1) ** -0.5
+    return torch.cos(math.pi * r)
+
+
+def _dense_family(Z, kind, group, w):
+    n = Z.shape[0]
+    K = torch.zeros(n, n, dtype=torch.float64)
+    for c in range(Z.shape[1] // group):
+        d2 = sum((Z[:, c * group + m:c * group + m + 1] - Z[:, c * group + m:c * group + m + 1].t()) ** 2
+                 for m in range(group))
+        K = K + w[c] * _phi_t(kind, d2)
+    return K
+
+
+def test_family_oracle_pinned_to_rbf_oracle_and_reference_formulas():
+    rng = np.random.default_rng(0)
+    Z1, Z2 = rng.normal(size=(30, 6)), rng.normal(size=(17, 6))
+    # group 1, weights 1/J: the hot-path kernel (oracle/dense_gp.py, itself pinned to the reference's GAMFunction)
+    assert np.allclose(fmo.kernel_matrix(Z1, Z2, "RBF", 1, np.full(6, 1 / 6)), orc.additive_rbf(Z1, Z2) / 6, atol=1e-14)
+    # k-dimensional RBF = product of the 1-D RBFs of its group
+    comps1 = fmo.component_matrices(Z1, Z2, "RBF", 1)
+    comps3 = fmo.component_matrices(Z1, Z2, "RBF", 3)
+    assert np.allclose(comps3[0], comps1[0] * comps1[1] * comps1[2])
+    # InverseMQ: dist.add_(1).pow_(-1/2) on the squared distance (imq_kernel.py:8-9)
+    d2 = (Z1[:, :1] - Z2[:, :1].T) ** 2
+    assert np.allclose(fmo.component_matrices(Z1, Z2, "InverseMQ", 1)[0], (d2 + 1) ** -0.5)
+    with pytest.raises(ValueError):
+        fmo.component_matrices(Z1, Z2, "Matern", 2)
+
+
+def _problem(n=60, d=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(n, d, generator=g)
+    y = torch.sin(X).sum(1) + 0.05 * torch.randn(n, generator=g)
+    return X, (y - y.mean()) / y.std()
+
+
+@pytest.mark.parametrize("kind,model_kwargs", [
+    ("additive_rp", dict(J=6, kernel_type="Matern", prescale=True)),
+    ("additive_rp", dict(J=4, kernel_type="InverseMQ", prescale=False)),
+    ("additive_rp", dict(J=4, kernel_type="Cosine", prescale=True, init_lengthscale_range=(3.0, 3.0))),
+    ("additive_rp", dict(J=3, k=2, batch_kernel=False, prescale=True)),
+    ("rp_poly", dict(J=5, k=1, weighted=True, kernel_type="RBF")),
+    ("rp_poly", dict(J=3, k=2, weighted=True, kernel_type="RBF")),
+    ("rp_poly", dict(J=4, k=1, weighted=False, kernel_type="Matern")),
+    ("strictly_additive", dict(weighted=True, kernel_type="RBF")),
+    ("strictly_additive", dict(weighted=False, kernel_type="RBF", memory_efficient=True)),
+    ("additive", dict(groups=[[0, 3], [1, 4]], weighted=True)),
+])
+def test_family_mll_and_gradients_match_dense_autograd(oracle_backend, kind, model_kwargs):
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    from rpgp_amd import kernels as km
+    X, y = _problem()
+    torch.manual_seed(3)
+    model, lik = create_exact_gp(X, y, kind, noise_prior=True, learn_proj=False, **model_kwargs) \
+        if kind in ("additive_rp", "rp_poly") else create_exact_gp(X, y, kind, noise_prior=True, **model_kwargs)
+    mll = ExactMarginalLogLikelihood(lik, model)
+    model.train()
+    val = mll(model(X), y)
+    val.backward()
+
+    # dense float64 autograd restatement of the same objective from the model's own parameters
+    base = model.covar_module.base_kernel
+    Xd, yd = X.double(), y.double()
+    leaves = {}
+
+    def leaf(name, p):
+        leaves[name] = p.detach().double().clone().requires_grad_(True)
+        return leaves[name]
+
+    raw_s = leaf("outputscale", model.covar_module.raw_outputscale)
+    raw_n = leaf("noise", lik.raw_noise)
+    c = leaf("mean", model.mean_module.constant)
+    if isinstance(base, km.ScaledProjectionKernel):
+        raw_ls = leaf("ls", base.raw_lengthscale)
+        ls = F.softplus(raw_ls).reshape(-1)
+        P = base.projection_module.weight.detach().double().t()
+        Z = (Xd / ls) @ P if base.prescale else (Xd @ P) / ls
+        inner = base.base_kernel
+        group, ktype = inner.group, inner.kernel_type
+        w = torch.full((Z.shape[1] // group,), float(inner.weight), dtype=torch.float64)
+    elif isinstance(base, km.MemoryEfficientGamKernel):
+        raw_ls = leaf("ls", base.raw_lengthscale)
+        Z = Xd / F.softplus(raw_ls).reshape(-1)
+        group, ktype = 1, "RBF"
+        w = torch.ones(Z.shape[1], dtype=torch.float64)
+    else:
+        raw_ls = leaf("ls", base.raw_lengthscales)
+        raw_w = leaf("w", base.raw_outputscales)
+        P = base.projection_module.weight.detach().double().t()
+        Z = (Xd @ P) / F.softplus(raw_ls).reshape(-1)
+        group, ktype = base.k, base.kernel_type
+        w = F.softplus(raw_w)
+    n = X.shape[0]
+    Kh = F.softplus(raw_s) * _dense_family(Z, ktype, group, w) + (F.softplus(raw_n) + 1e-4) * torch.eye(n, dtype=torch.float64)
+    r = yd - c
+    obj = (-0.5 * r @ torch.linalg.solve(Kh, r) - 0.5 * torch.logdet(Kh) - 0.5 * n * math.log(2 * math.pi)) / n
+    # the noise-prior term comes from the model's own code on both sides; its gradient w.r.t. raw_noise is not compared
+    prior = float(lik.log_prior().detach())
+    assert abs(val.item() - (obj.item() + prior / n)) < 2e-4 * max(1.0, abs(val.item()))
+    obj.backward()
+
+    def close(a, b):
+        return torch.allclose(a.double().reshape(-1), b.reshape(-1), rtol=3e-3, atol=2e-6)
+
+    assert close(model.covar_module.raw_outputscale.grad, leaves["outputscale"].grad)
+    assert close(model.mean_module.constant.grad, leaves["mean"].grad)
+    ls_param = base.raw_lengthscale if hasattr(base, "raw_lengthscale") and "w" not in leaves else base.raw_lengthscales
+    assert close(ls_param.grad, leaves["ls"].grad)
+    if "w" in leaves:
+        if base.weighted:
+            assert close(base.raw_outputscales.grad, leaves["w"].grad)
+        else:
+            assert base.raw_outputscales.grad is None            # frozen mixing weights (polynomial_projection_kernels.py:94-98)
+    proj = getattr(base, "projection_module", None)
+    if proj is not None and isinstance(getattr(proj, "weight", None), torch.nn.Parameter):
+        assert proj.weight.grad is None
+
+
+def test_family_initialisation_follows_reference_order():
+    """polynomial_projection_kernels.py:139-156: mixing weights first (normalised), then one draw per sub-kernel."""
+    from rpgp_amd.training import create_rp_poly_kernel, create_strictly_additive_kernel
+    torch.manual_seed(11)
+    k = create_rp_poly_kernel(6, 1, 4, weighted=True, init_mixin_range=(0.5, 1.5), init_lengthscale_range=(0.5, 2.0))
+    torch.manual_seed(11)
+    from rpgp_amd import rp
+    [rp.gen_rp(6, 1) for _ in range(4)]
+    torch.nn.Linear(6, 4, bias=False)            # the projection module's default init draws from the same stream
+    mix = torch.rand(4) * 1.0 + 0.5
+    mix = mix / mix.sum()
+    ls = torch.cat([torch.rand(1) * 1.5 + 0.5 for _ in range(4)])
+    assert torch.allclose(k.outputscales.detach(), mix, atol=1e-6)
+    assert torch.allclose(k.lengthscales.detach().reshape(-1), ls, atol=1e-6)
+    assert abs(float(k.outputscales.sum()) - 1.0) < 1e-6
+    g = create_strictly_additive_kernel(5, weighted=False)
+    assert not g.raw_outputscales.requires_grad and g.raw_lengthscales.shape == (1, 5)
+    assert torch.allclose(g.outputscales.detach(), torch.full((5,), 0.2), atol=1e-6)
+    m = create_strictly_additive_kernel(5, memory_efficient=True, init_lengthscale_range=(2.0, 2.0))
+    assert torch.allclose(m.lengthscale.detach(), torch.full((1, 5), 2.0), atol=1e-6)
+
+
+def test_family_validation_errors():
+    from rpgp_amd.training import create_additive_rp_kernel, create_rp_poly_kernel, create_exact_gp
+    with pytest.raises(NotImplementedError):
+        create_additive_rp_kernel(6, 3, k=2, batch_kernel=False, kernel_type="Matern")
+    with pytest.raises(NotImplementedError):
+        create_additive_rp_kernel(6, 3, k=7, batch_kernel=False)
+    with pytest.raises(NotImplementedError):
+        create_additive_rp_kernel(6, 3, kernel_type="Matern", ski=True, ski_options={"grid_size": 64})
+    with pytest.raises(ValueError):
+        create_rp_poly_kernel(6, 1, 3, kernel_type="bogus")
+    with pytest.raises(ValueError):
+        create_rp_poly_kernel(6, 1, 3, activation="relu")
+    X, y = _problem(20, 4)
+    with pytest.raises(NotImplementedError):
+        create_exact_gp(X, y, "general_rp_poly", noise_prior=False, degrees=[1, 2])
+    with pytest.raises(ValueError):
+        create_exact_gp(X, y, "nonsense", noise_prior=False)
+
+
+def test_family_predictions_match_dense(oracle_backend):
+    from rpgp_amd.training import create_exact_gp
+    X, y = _problem(50, 4, seed=4)
+    Xs = torch.randn(9, 4, generator=torch.Generator().manual_seed(8))
+    torch.manual_seed(0)
+    model, lik = create_exact_gp(X, y, "rp_poly", noise_prior=False, J=4, k=1, weighted=True, kernel_type="InverseMQ")
+    model.eval(); lik.eval()
+    out = model(Xs)
+    base = model.covar_module.base_kernel
+    P = base.projection_module.weight.detach().double().t()
+    ls = base.lengthscales.detach().double().reshape(-1)
+    w = base.outputscales.detach().double().numpy()
+    s = float(model.covar_module.outputscale)
+    noise = float(lik.noise)
+    Z, Zs = ((X.double() @ P) / ls).numpy(), ((Xs.double() @ P) / ls).numpy()
+    K = fmo.kernel_matrix(Z, Z, "InverseMQ", 1, w, s) + noise * np.eye(50)
+    Ks = fmo.kernel_matrix(Zs, Z, "InverseMQ", 1, w, s)
+    Kss = fmo.kernel_matrix(Zs, Zs, "InverseMQ", 1, w, s)
+    c = float(model.mean_module.constant)
+    mean = Ks @ np.linalg.solve(K, y.double().numpy() - c) + c
+    cov = Kss - Ks @ np.linalg.solve(K, Ks.T)
+    assert np.allclose(out.mean.numpy(), mean, rtol=1e-4, atol=1e-5)
+    assert np.allclose(out.covariance.numpy(), cov, rtol=1e-3, atol=1e-5)

@@ -285,7 +285,8 @@ def test_train_exact_gp_contract(oracle_backend):
     assert metrics["trained_epochs"] == 6
     assert pred.shape == (20,) and pred.dtype == torch.float32 and pred.device.type == "cpu"
     assert model.covar_module.base_kernel.projection_module.weight.shape == (4, 4)       # "J": "d" placeholder
-    assert abs(float(model.covar_module.base_kernel.base_kernel.inner_lengthscale) - math.log(2)) < 1e-6
+    gam = model.covar_module.base_kernel.base_kernel
+    assert abs(float(gam.lengthscale) - math.log(2)) < 1e-6 and not gam.raw_lengthscale.requires_grad
     m2, _, _ = train_exact_gp(X, y, Xs, ys, "additive_rp", mk, tk, skip_posterior_variances=True,
                               skip_random_restart=True, evaluate_on_train=False)
     assert "test_nll" not in m2 and "train_mse" not in m2

@@ -105,6 +105,25 @@ def test_cli_additive_spec_through_oracle_backend(tmp_path, oracle_backend):
     assert oracle_backend.calls["dense"] > 0
 
 
+@pytest.mark.parametrize("name", ["GAM_spec.json", "additive_rp_J20_K1.json", "additive_rp_prescale_J1_K20.json",
+                                  "additive_rp_postscale_J20.json", "additive_rp_prescale_J20_matern.json"])
+def test_cli_family_specs_through_oracle_backend(tmp_path, oracle_backend, name):
+    """The other family members' spec files run end to end through the same CLI."""
+    from rpgp_amd import runner
+    spec = json.load(open(os.path.join(ROOT, "model_specs", name)))
+    spec["train_kwargs"]["max_iter"] = 2
+    spec["train_kwargs"]["init_iters"] = 1
+    if spec["model_kwargs"].get("J") == 20:
+        spec["model_kwargs"]["J"] = 5
+    if spec["model_kwargs"].get("k") == 20:
+        spec["model_kwargs"]["k"] = 2
+    sp = tmp_path / "spec.json"
+    json.dump(spec, open(sp, "w"))
+    df = runner.main(["-m", str(sp), "-d", "synthetic:tiny", "-o", str(tmp_path / "res.csv"), "--no_cv",
+                      "--skip_random_restart"])
+    assert np.isfinite(df.iloc[0]["rmse"]) and "error" not in df.columns
+
+
 def test_run_experiment_records_errors_and_retries():
     from rpgp_amd import runner
     calls = {"n": 0}

@@ -1943,15 +1943,18 @@ int with_family_policy(int kind, int group, F &&f) {
   }
 }
 
-// column pieces: whole groups for grouped policies, {10, 4, 2, 1} columns otherwise
+// column pieces: {10, 4, 2, 1} columns for 1-D sub-kernels; for G-dimensional groups as many whole groups as fit in
+// ~10 columns (fewer passes over the pair space), then single groups
+template <int G> struct GroupBig { static constexpr int v = (G <= 5) ? G * (10 / G) : G; };
 template <class KF>
 inline int family_piece(int remaining) {
-  if (KF::group > 1) return KF::group;
+  if (KF::group > 1) return remaining >= GroupBig<KF::group>::v ? GroupBig<KF::group>::v : KF::group;
   return remaining >= 10 ? 10 : (remaining >= 4 ? 4 : (remaining >= 2 ? 2 : 1));
 }
 template <class KF, class F>
 int with_family_piece(int jt, F &&f) {
   if constexpr (KF::group > 1) {
+    if (jt == GroupBig<KF::group>::v) return f(IntC<GroupBig<KF::group>::v>{});
     return f(IntC<KF::group>{});
   } else {
     switch (jt) {

@@ -1368,6 +1368,98 @@ __global__ __launch_bounds__(256) void ski_scatter2_kernel(const float *__restri
   }
 }
 
+// Scatter for T <= 12, parallel over projections AND point chunks: workgroup (chunk, j) accumulates its chunk's
+// contributions to projection j's histogram in LDS and stores it as a slab; ski_slab_sum_kernel adds the slabs.
+// Lanes are laid out (point, t): LPP = 1 / 4 / 16 lanes per point, so one LDS atomic instruction updates the TT
+// consecutive words of a grid cell for 256 / LPP points (conflict-free across t, V read coalesced).
+// The LDS accumulation is INTEGER: gfx950 executes ds_add_f32 at ~80 ns per wave-instruction per CU against 2.6 ns for
+// ds_add_u32 (tools/lds_atomic_bench.hip, profiles/r1_lds_atomic_bench.txt).  Each column gets a power-of-two
+// fixed-point scale from the chunk's own max|v| (sum of |w v| over the chunk stays below 2^30, so no overflow); the
+// rounding error per update is <= 2^-31 of that bound — about the fp32 rounding of the float sum it replaces — and
+// integer addition commutes, so the SKI product is bitwise reproducible.
+template <int TT>
+__global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
+                                                           const float *__restrict__ V, float *__restrict__ slab,
+                                                           long long N, int ldz, int J, int G, int T, int tcnt,
+                                                           long long pts_per_chunk) {
+  extern __shared__ int shi[];    // G * TT fixed-point accumulators
+  __shared__ float smax[256];
+  __shared__ float sscale[16], sinv[16];
+  constexpr int LPP = TT == 1 ? 1 : (TT == 4 ? 4 : 16);
+  constexpr int PPI = 256 / LPP;
+  const float g0 = gp[0], inv_h = gp[2];
+  const int j = blockIdx.y;
+  const long long n0 = (long long)blockIdx.x * pts_per_chunk;
+  const long long n1 = (n0 + pts_per_chunk < N) ? n0 + pts_per_chunk : N;
+  for (int e = threadIdx.x; e < G * TT; e += 256) shi[e] = 0;
+  const int t = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+  // pass 1: max |v| of the chunk per column -> fixed-point scale
+  float vm = 0.f;
+  if (t < tcnt)
+    for (long long i = n0 + pl; i < n1; i += PPI) vm = fmaxf(vm, __builtin_fabsf(V[i * T + t]));
+  smax[threadIdx.x] = vm;
+  __syncthreads();
+  if ((int)threadIdx.x < LPP) {
+    float m = 0.f;
+    for (int q = 0; q < PPI; ++q) m = fmaxf(m, smax[q * LPP + threadIdx.x]);
+    // |sum| <= 1.2 * points * max|v| (cubic-convolution weights: |w| <= 1, negative lobes add < 0.2)
+    const float bound = 1.2f * (float)(n1 - n0) * m;
+    float sc = 1.0f, inv = 1.0f;
+    if (bound > 0.f && bound < 3.0e38f) {
+      int ex;
+      (void)frexpf(bound, &ex);                       // bound < 2^ex
+      sc = ldexpf(1.0f, 30 - ex);
+      inv = ldexpf(1.0f, ex - 30);
+    }
+    sscale[threadIdx.x] = sc;
+    sinv[threadIdx.x] = inv;
+  }
+  __syncthreads();
+  if (t < tcnt) {
+    const float sc = sscale[t];
+    constexpr int U = 4;                   // points in flight per thread (hides the Z / V load latency)
+    for (long long i0 = n0 + pl; i0 < n1; i0 += (long long)PPI * U) {
+      float zv[U], vv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long i = i0 + (long long)u * PPI;
+        const bool ok = i < n1;
+        zv[u] = ok ? Z[i * ldz + j] : 0.f;
+        vv[u] = ok ? V[i * T + t] * sc : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (i0 + (long long)u * PPI < n1) {
+          float w[4], dw[4];
+          const int idx0 = ski_taps<false>(zv[u], g0, inv_h, G, w, dw);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) atomicAdd(&shi[(idx0 + k) * TT + t], __float2int_rn(w[k] * vv[u]));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float *dst = slab + ((size_t)blockIdx.x * J + j) * G * TT;
+  for (int e = threadIdx.x; e < G * TT; e += 256) {
+    const int tt = e % TT;
+    dst[e] = tt < tcnt ? (float)shi[e] * sinv[tt] : 0.f;
+  }
+}
+
+// hist[j][g][hoff + t] = sum_c slab[c][j][g][t]   (t < tcnt; hist row stride HT)
+__global__ __launch_bounds__(256) void ski_slab_sum_kernel(const float *__restrict__ slab, float *__restrict__ hist,
+                                                           int nchunks, int J, int G, int TT, int tcnt, int HT,
+                                                           int hoff) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;        // over J * G * TT
+  const size_t per = (size_t)J * G * TT;
+  if (e >= per) return;
+  const int t = (int)(e % TT);
+  if (t >= tcnt) return;
+  float acc = 0.f;
+  for (int c = 0; c < nchunks; ++c) acc += slab[(size_t)c * per + e];
+  hist[(e / TT) * HT + hoff + t] = acc;
+}
+
 // H[j][m][t] = sum_m' exp(-0.5 ((m - m') h)^2) hist[j][m'][t]
 __global__ __launch_bounds__(256) void ski_toeplitz_kernel(const float *__restrict__ hist, const float *__restrict__ gp,
                                                            float *__restrict__ H, int G, int T) {
@@ -1396,36 +1488,90 @@ __global__ __launch_bounds__(256) void ski_toeplitz_kernel(const float *__restri
   }
 }
 
+// Toeplitz product on the matrix cores for T <= 16: H_j (G x T) = Toep(G x G) @ hist_j (G x T) as 16 x 16 output tiles,
+// v_mfma_f32_16x16x4_f32 over the G grid points (K = 4 per issue).  One wave per 16-row tile, four tiles per workgroup;
+// hist_j is staged once per workgroup in LDS; the Toeplitz entry sc[|m - k|] is read from LDS.
+//   A (16x4): lane l holds Toep[m0 + l%16][k0 + l/16]     B (4x16): lane l holds hist_j[k0 + l/16][l%16]
+//   D (16x16): lane l holds H_j[m0 + 4*(l/16) + r][l%16], r = 0..3
+__global__ __launch_bounds__(256) void ski_toeplitz_mfma_kernel(const float *__restrict__ hist,
+                                                                const float *__restrict__ gp, float *__restrict__ H,
+                                                                int G, int T) {
+  extern __shared__ float smem[];           // sc[G16] | sh[G16 * T]   (G16 = G rounded up to 16, zero-filled tails)
+  const int G16 = (G + 15) & ~15;
+  float *sc = smem;
+  float *shh = smem + G16;
+  const int j = blockIdx.y;
+  const float hs = gp[1] * kExp2Scale;
+  for (int k = threadIdx.x; k < G16; k += 256) {
+    const float d = (float)k * hs;
+    sc[k] = k < G ? fast_exp2(-(d * d)) : 0.f;
+  }
+  for (int e = threadIdx.x; e < G16 * T; e += 256) shh[e] = e < G * T ? hist[(size_t)j * G * T + e] : 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = (blockIdx.x * 4 + wave) * 16;
+  if (m0 >= G) return;
+  const int mrow = m0 + (lane & 15), q = lane >> 4;
+  const int nb = lane & 15;
+  const int nbc = nb < T ? nb : T - 1;               // clamped column: every LDS read below is unconditional
+  const float bmask = nb < T ? 1.0f : 0.0f;
+  const float amask = mrow < G ? 1.0f : 0.0f;        // (rows >= G are never stored; sc[] is zero beyond G)
+  // four independent accumulators: consecutive K-steps do not wait on each other's MFMA latency
+  floatx4m acc4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc4[u] = floatx4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int k0 = 0; k0 < G16; k0 += 16) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 4 * u + q;
+      int dist = mrow > k ? mrow - k : k - mrow;
+      dist = dist < G16 ? dist : G16 - 1;             // only rows >= G can exceed it; they carry amask = 0
+      a[u] = sc[dist] * amask;
+      b[u] = shh[k * T + nbc] * bmask;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc4[u], 0, 0, 0);
+  }
+  floatx4m acc = acc4[0] + acc4[1] + acc4[2] + acc4[3];
+  if (nb < T) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * q + r;
+      if (m < G) H[((size_t)j * G + m) * T + nb] = acc[r];
+    }
+  }
+}
+
 // out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0+k][t] + noise * V[i][t]
+// Lanes are laid out (point, t) with LPP = 1 / 4 / 16 lanes per point: a tap's T values are one contiguous segment for
+// the point's lanes (a lane-per-point layout touched 64 cache lines per load instruction and was bound by the L1
+// transaction rate: 85 us at N = 50k, J = 20, T = 11).
 template <int TT>
 __global__ __launch_bounds__(256) void ski_gather_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
                                                          const float *__restrict__ H, const float *__restrict__ V,
                                                          float *__restrict__ out, long long M, int ldz, int J, int G,
                                                          int T, int t0, int tcnt, float scale, float noise) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= M) return;
+  constexpr int LPP = TT == 1 ? 1 : (TT == 4 ? 4 : 16);
+  constexpr int PPB = 256 / LPP;
+  const int t = threadIdx.x % LPP;
+  const long long i = (long long)blockIdx.x * PPB + threadIdx.x / LPP;
+  if (i >= M || t >= tcnt) return;
   const float g0 = gp[0], inv_h = gp[2];
-  float acc[TT];
-#pragma unroll
-  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+  const float *zrow = Z + i * ldz;
+  float acc = 0.f;
+#pragma unroll 4
   for (int j = 0; j < J; ++j) {
     float w[4], dw[4];
-    const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+    const int idx0 = ski_taps<false>(zrow[j], g0, inv_h, G, w, dw);
+    const float *hp = H + ((size_t)j * G + idx0) * T + t0 + t;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float *hp = H + ((size_t)j * G + idx0 + k) * T + t0;
-#pragma unroll
-      for (int t = 0; t < TT; ++t)
-        if (t < tcnt) acc[t] = __builtin_fmaf(w[k], hp[t], acc[t]);
-    }
+    for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(w[k], hp[(size_t)k * T], acc);
   }
-#pragma unroll
-  for (int t = 0; t < TT; ++t)
-    if (t < tcnt) {
-      float r = scale * acc[t];
-      if (noise != 0.f) r = __builtin_fmaf(noise, V[i * T + t0 + t], r);
-      out[i * T + t0 + t] = r;
-    }
+  float r = scale * acc;
+  if (noise != 0.f) r = __builtin_fmaf(noise, V[i * T + t0 + t], r);
+  out[i * T + t0 + t] = r;
 }
 
 // ---- wide right-hand sides (T > 12: predictive covariance blocks, dense evaluation): lane = column t, so every
@@ -2541,22 +2687,43 @@ namespace {
 inline int ski_tpiece(int remaining) { return remaining > 4 ? 12 : (remaining > 1 ? 4 : 1); }
 constexpr int kSkiMaxParts = 512;
 
-template <int TT>
-int ski_launch_scatter(const float *Z, const float *gp, const float *V, float *hist, long long N, int ldz, int J, int G,
-                       int T, int t0, int tcnt, hipStream_t st) {
-  long long nblk = (N + 4095) / 4096;
-  if (nblk > 1024) nblk = 1024;
-  if (nblk < 1) nblk = 1;
-  const long long ppb = (N + nblk - 1) / nblk;
-  hipLaunchKernelGGL((ski_scatter2_kernel<TT>), dim3((unsigned)nblk), dim3(256), (size_t)G * TT * sizeof(float), st, Z,
-                     gp, V, hist, N, ldz, J, G, T, T, 0, t0, tcnt, ppb);
+// chunks of points per projection for ski_scatter3_kernel: ~1024 workgroups in total, at least 256 points each
+inline int ski_max_chunks(int J) { return (1024 + J - 1) / J; }
+inline int ski_chunks(long long N, int J) {
+  long long c = ski_max_chunks(J);
+  const long long by_pts = (N + 255) / 256;
+  if (c > by_pts) c = by_pts;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+inline size_t ski_slab_floats(int J, int G) { return (size_t)ski_max_chunks(J) * J * G * 12; }
+
+// hist[j][g][hoff + t] (row stride HT) = sum_i w(z_ij)[g] V[i][t], T <= 12 columns of V (row stride T); no atomics on hist
+int ski_scatter_narrow(const float *Z, const float *gp, const float *V, float *hist, float *slab, long long N, int ldz,
+                       int J, int G, int T, int HT, int hoff, hipStream_t st) {
+  const int tt = ski_tpiece(T);
+  const int nch = ski_chunks(N, J);
+  const long long ppc = (N + nch - 1) / nch;
+  dim3 grid((unsigned)nch, (unsigned)J);
+  const size_t lds = (size_t)G * tt * sizeof(float);
+  if (tt == 1)
+    hipLaunchKernelGGL((ski_scatter3_kernel<1>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
+  else if (tt == 4)
+    hipLaunchKernelGGL((ski_scatter3_kernel<4>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
+  else
+    hipLaunchKernelGGL((ski_scatter3_kernel<12>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
+  int rc = launch_status();
+  if (rc) return rc;
+  const size_t per = (size_t)J * G * tt;
+  hipLaunchKernelGGL(ski_slab_sum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, slab, hist, nch, J, G,
+                     tt, T, HT, hoff);
   return launch_status();
 }
 
-int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist, long long N, int ldz, int J, int G,
-                    int T, hipStream_t st) {
-  RPGP_CHECK(hipMemsetAsync(hist, 0, (size_t)J * G * T * sizeof(float), st));
+int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist, float *slab, long long N, int ldz,
+                    int J, int G, int T, hipStream_t st) {
   if (T > 12) {
+    RPGP_CHECK(hipMemsetAsync(hist, 0, (size_t)J * G * T * sizeof(float), st));
     long long nblk = (N + 255) / 256;
     if (nblk > 2048) nblk = 2048;
     const long long ppb = (N + nblk - 1) / nblk;
@@ -2564,23 +2731,19 @@ int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist
                        gp, V, hist, N, ldz, J, G, T, T, 0, ppb);
     return launch_status();
   }
-  for (int t0 = 0; t0 < T;) {
-    const int tt = ski_tpiece(T - t0);
-    const int tcnt = (T - t0 < tt) ? T - t0 : tt;
-    int rc;
-    if (tt == 1) rc = ski_launch_scatter<1>(Z, gp, V, hist, N, ldz, J, G, T, t0, tcnt, st);
-    else if (tt == 4) rc = ski_launch_scatter<4>(Z, gp, V, hist, N, ldz, J, G, T, t0, tcnt, st);
-    else rc = ski_launch_scatter<12>(Z, gp, V, hist, N, ldz, J, G, T, t0, tcnt, st);
-    if (rc) return rc;
-    t0 += tcnt;
-  }
-  return 0;
+  return ski_scatter_narrow(Z, gp, V, hist, slab, N, ldz, J, G, T, T, 0, st);
 }
 
 int ski_toeplitz(const float *hist, const float *gp, float *H, int J, int G, int T, hipStream_t st) {
   if (T > 24) {
     dim3 grid((T + 63) / 64, (G + 15) / 16, J);
     hipLaunchKernelGGL(ski_toeplitz_wide_kernel, grid, dim3(256), (size_t)G * sizeof(float), st, hist, gp, H, G, T);
+    return launch_status();
+  }
+  const int G16 = (G + 15) & ~15;
+  if (T <= 16 && (size_t)G16 * (T + 1) * sizeof(float) <= 64 * 1024) {   // matrix-core path (LDS: sc + hist_j)
+    dim3 grid((G + 63) / 64, J);
+    hipLaunchKernelGGL(ski_toeplitz_mfma_kernel, grid, dim3(256), (size_t)G16 * (T + 1) * sizeof(float), st, hist, gp, H, G, T);
     return launch_status();
   }
   int Tp = 1;
@@ -2601,10 +2764,11 @@ int ski_gather_all(const float *Z, const float *gp, const float *H, const float 
                        H, V, out, M, ldz, J, G, T, scale, noise, ppb);
     return launch_status();
   }
-  const unsigned nb = (unsigned)((M + 255) / 256);
   for (int t0 = 0; t0 < T;) {
     const int tt = ski_tpiece(T - t0);
     const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+    const int lpp = tt == 1 ? 1 : (tt == 4 ? 4 : 16);
+    const unsigned nb = (unsigned)((M * lpp + 255) / 256);
     if (tt == 1)
       hipLaunchKernelGGL((ski_gather_kernel<1>), dim3(nb), dim3(256), 0, st, Z, gp, H, V, out, M, ldz, J, G, T, t0, tcnt, scale, noise);
     else if (tt == 4)
@@ -2623,8 +2787,8 @@ extern "C" {
 
 size_t rpgp_ski_workspace_bytes(int J, int G, int T) {
   if (J <= 0 || G <= 0 || T <= 0) return 0;
-  // hist + H for up to 2T columns (the derivative uses [L | R]) + min/max partials
-  return (2 * (size_t)J * G * (2 * T) + 2 * kSkiMaxParts) * sizeof(float);
+  // hist + H for up to 2T columns (the derivative uses [L | R]) + min/max partials + per-chunk scatter slabs
+  return (2 * (size_t)J * G * (2 * T) + 2 * kSkiMaxParts + ski_slab_floats(J, G)) * sizeof(float);
 }
 
 int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t N2, int ld2, int J, int G,
@@ -2656,7 +2820,8 @@ int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, con
   hipStream_t st = as_stream(stream);
   float *hist = reinterpret_cast<float *>(workspace);
   float *H = hist + (size_t)J * G * (2 * T);
-  int rc = ski_scatter_all(Z2, grid_params, V, hist, N, ldz2, J, G, T, st);
+  float *slab = H + (size_t)J * G * (2 * T) + 2 * kSkiMaxParts;
+  int rc = ski_scatter_all(Z2, grid_params, V, hist, slab, N, ldz2, J, G, T, st);
   if (rc) return rc;
   rc = ski_toeplitz(hist, grid_params, H, J, G, T, st);
   if (rc) return rc;
@@ -2684,28 +2849,11 @@ int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float
   float *hist = reinterpret_cast<float *>(workspace);
   float *H = hist + (size_t)J * G * T2;
   // scatter the 2T columns [L | R]: two passes writing into column offsets 0 and T of a [J][G][2T] histogram
-  RPGP_CHECK(hipMemsetAsync(hist, 0, (size_t)J * G * T2 * sizeof(float), st));
+  float *slab = H + (size_t)J * G * T2 + 2 * kSkiMaxParts;
   for (int half = 0; half < 2; ++half) {
-    const float *Vh = half == 0 ? L : R;
-    // the scatter kernel addresses V with row stride T and hist with row stride `T` argument: use a strided view by
-    // passing hist + half*T and stride T2 through the generic kernel's T parameter for hist only -> dedicated launch
-    long long nblk = (N + 4095) / 4096;
-    if (nblk > 1024) nblk = 1024;
-    const long long ppb = (N + nblk - 1) / nblk;
-    for (int t0 = 0; t0 < T;) {
-      const int tt = ski_tpiece(T - t0);
-      const int tcnt = (T - t0 < tt) ? T - t0 : tt;
-      // V has stride T; hist has stride T2 and column offset half*T: handled by ski_scatter2_kernel
-      if (tt == 1)
-        hipLaunchKernelGGL((ski_scatter2_kernel<1>), dim3((unsigned)nblk), dim3(256), (size_t)G * 1 * sizeof(float), st, Z, grid_params, Vh, hist, (long long)N, ldz, J, G, T, T2, half * T, t0, tcnt, ppb);
-      else if (tt == 4)
-        hipLaunchKernelGGL((ski_scatter2_kernel<4>), dim3((unsigned)nblk), dim3(256), (size_t)G * 4 * sizeof(float), st, Z, grid_params, Vh, hist, (long long)N, ldz, J, G, T, T2, half * T, t0, tcnt, ppb);
-      else
-        hipLaunchKernelGGL((ski_scatter2_kernel<12>), dim3((unsigned)nblk), dim3(256), (size_t)G * 12 * sizeof(float), st, Z, grid_params, Vh, hist, (long long)N, ldz, J, G, T, T2, half * T, t0, tcnt, ppb);
-      int rc = launch_status();
-      if (rc) return rc;
-      t0 += tcnt;
-    }
+    const int rcs = ski_scatter_narrow(Z, grid_params, half == 0 ? L : R, hist, slab, (long long)N, ldz, J, G, T, T2,
+                                       half * T, st);
+    if (rcs) return rcs;
   }
   int rc = ski_toeplitz(hist, grid_params, H, J, G, T2, st);
   if (rc) return rc;

@@ -211,7 +211,27 @@ def main():
                       "rel_diff_vs_fused": float((oc - res).norm() / res.norm()),
                       "note": "literal HBM stream of the 4N^2-byte matrix (rpgp_dense_mvm, MFMA fp32); not the headline"}
             del Kd
-        result["extras"] = {"cached_k": cached,
+        # SKI mode (the reference's `ski: true` specs, e.g. additive_spread_prescale_J20_ski.json): grid interpolation of
+        # the same operator, O(N (J + T)) per MVM; an approximation (difference reported), never the headline
+        gp = ops.ski_grid(Z, None, 1024)
+        ops.ski_mvm(Z, Z, gp, V, scale, noise, 1024)
+        torch.cuda.synchronize()
+        tk = time.perf_counter()
+        for _ in range(20):
+            osk = ops.ski_mvm(Z, Z, gp, V, scale, noise, 1024)
+        torch.cuda.synchronize()
+        t_ski = (time.perf_counter() - tk) / 20
+        ops.ski_mvm(Z, Z, gp, V11, scale, noise, 1024)
+        torch.cuda.synchronize()
+        tk = time.perf_counter()
+        for _ in range(20):
+            ops.ski_mvm(Z, Z, gp, V11, scale, noise, 1024)
+        torch.cuda.synchronize()
+        t_ski11 = (time.perf_counter() - tk) / 20
+        ski = {"grid_size": 1024, "mvm_ms": round(t_ski * 1e3, 4), "mvm_per_s": round(1.0 / t_ski, 1),
+               "block_T11_ms": round(t_ski11 * 1e3, 4), "rel_diff_vs_fused": float((osk - res).norm() / res.norm()),
+               "note": "cubic interpolation onto a 1024-point grid + Toeplitz RBF (rpgp_ski_mvm); approximate, not the headline"}
+        result["extras"] = {"cached_k": cached, "ski": ski,
                             "block_T11_ms": round(t11 * 1e3, 4), "block_T11_mvm_equiv_per_s": round(11.0 / t11, 1),
                             "solve_Khat_inv_y": {"what": "mean-cache solve, rank-15 pivoted-Cholesky preconditioner, native mBCG, fused MVM",
                                                  "tolerance": 0.01, "cg_iterations": lcg.stats["last_iterations"],

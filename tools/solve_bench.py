@@ -66,9 +66,12 @@ if __name__ == "__main__":
     a = ap.parse_args()
     table = {"C2": ("C2 kin8nm-shaped RPA-GP", 7372, 8, 20, 820, False), "C3": ("C3 elevators-shaped DPA-GP", 14939, 18, 20, 1660, True),
              "C4": ("C4 synthetic 50k RPA-GP", 50000, 20, 20, 2000, False), "S": ("small", 3000, 8, 20, 300, False),
-             "C5": ("C5 3droad-shaped DPA-GP + SKI (J=d=3, grid 1024)", 391386, 3, 3, 43488, True)}
+             "C5": ("C5 3droad-shaped DPA-GP + SKI (J=d=3, grid 1024)", 391386, 3, 3, 43488, True),
+             # the reference's J = 20 SKI specs (additive_spread_prescale_J20_ski.json) at the C3 / C4 shapes
+             "C3S": ("C3 elevators-shaped DPA-GP + SKI (J=20, grid 1024)", 14939, 18, 20, 1660, True),
+             "C4S": ("C4 synthetic 50k RPA-GP + SKI (J=20, grid 1024)", 50000, 20, 20, 2000, False)}
     for c in a.configs.split(","):
         name, N, d, J, nt, sp = table[c]
         with settings.cache_kernel(a.cache_kernel):
-            run(name + (" [cached-K]" if a.cache_kernel else ""), N, d, J, nt, a.steps, sp, 0.05, 0.01, ski=(c == "C5"),
+            run(name + (" [cached-K]" if a.cache_kernel else ""), N, d, J, nt, a.steps, sp, 0.05, 0.01, ski=(c in ("C5", "C3S", "C4S")),
                 full_cov=(c != "C5"))

@@ -151,8 +151,12 @@ int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *g
 /*
  * Rank-`rank` pivoted Cholesky of K(Z,Z) (greedy max-diagonal pivots): L (N x rank, row-major) with K ~= L L^T, for the
  * Woodbury preconditioner M = L L^T + sigma^2 I (GPyTorch `pivoted_cholesky`, max_preconditioner_size = 15,
- * SURVEY.md Appendix B.3).  One single-workgroup launch; `diag_work` is N floats of device scratch.  J, rank <= 64.
+ * SURVEY.md Appendix B.3).  One single-workgroup launch for N <= 2048, otherwise rank + 1 chip-wide launches (one per
+ * greedy step; pivots identical: ties go to the smallest index).  `diag_work` is N + RPGP_PIVCHOL_SCRATCH floats of
+ * device scratch.  J, rank <= 64.  The family variant takes weight_sum = sum_c weights[c] (the kernel's diagonal is
+ * scale * weight_sum).
  */
+#define RPGP_PIVCHOL_SCRATCH 2048
 int rpgp_pivoted_cholesky(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int J, int rank,
                           float scale, void *stream);
 
@@ -227,6 +231,8 @@ int rpgp_family_bilinear_grad(const rpgp_family *fam, const float *Z, const floa
 int rpgp_family_bilinear_grad_dense(const rpgp_family *fam, const float *Z, const float *S, float *gZ, float *gcomp,
                                     int64_t N, int ldz, int ldg, int64_t lds, float scale, void *workspace,
                                     size_t workspace_bytes, void *stream);
+int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *L, float *diag_work, int64_t N,
+                                 int ldz, int rank, float scale, float weight_sum, void *stream);
 
 /*
  * Native mBCG executor (replaces gpytorch.utils.linear_cg as configured at gp_experiment_runner.py:324-329; algorithm in

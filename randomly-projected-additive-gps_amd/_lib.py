@@ -61,6 +61,7 @@ SIGNATURES = {
     "rpgp_family_bilinear_grad_workspace_bytes": (_sz, [_i64, _int, _int]),
     "rpgp_family_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "rpgp_family_bilinear_grad_dense": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _f32, _vp, _sz, _vp]),
+    "rpgp_family_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _f32, _vp]),
     "rpgp_mbcg_workspace_bytes": (_sz, [_vp, _int, _int]),
     "rpgp_mbcg_solve": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _f32, _int, _vp, _vp, _f32, _vp, _vp, _vp,
                                _vp, _vp, _sz, _vp]),
@@ -90,6 +91,7 @@ class RpgpFamily(ctypes.Structure):
 
 RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI, RPGP_OP_DENSE, RPGP_OP_FAMILY = 0, 1, 2, 3, 4
 RPGP_KIND_RBF, RPGP_KIND_MATERN15, RPGP_KIND_IMQ, RPGP_KIND_COSINE = 0, 1, 2, 3
+RPGP_PIVCHOL_SCRATCH = 2048
 
 _lib = None
 

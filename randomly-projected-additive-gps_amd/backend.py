@@ -30,6 +30,7 @@ class HipBackend:
     family_dense = staticmethod(ops.family_dense)
     family_bilinear_grad = staticmethod(ops.family_bilinear_grad)
     family_bilinear_grad_dense = staticmethod(ops.family_bilinear_grad_dense)
+    family_pivoted_cholesky = staticmethod(ops.family_pivoted_cholesky)
     make_operator_desc = staticmethod(ops.make_operator_desc)
     mbcg_solve = staticmethod(ops.mbcg_solve)
 

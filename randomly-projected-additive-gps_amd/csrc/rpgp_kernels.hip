@@ -1790,6 +1790,127 @@ __global__ __launch_bounds__(1024) void pivchol_kernel(const float *__restrict__
   }
 }
 
+// Multi-workgroup form for N > 2048: one launch per greedy step.  The launch of step m first reduces the per-workgroup
+// argmax partials left by step m-1 (every workgroup redundantly, same fixed order -> same pivot everywhere), then
+// evaluates the pivot's kernel row on its own rows, writes column m of L, downdates the residual diagonal and leaves
+// its argmax partial for step m+1 (ping-pong buffers).  k + 1 launches spread over the whole chip instead of one CU:
+// 6.5 ms -> ~0.3 ms at N = 50k.  The entry K(i, piv) is evaluated by a runtime-shaped routine that also covers the other
+// family members (kind / group / per-component weights; the hot path is kind RBF, group 1, unit weights).
+__device__ __forceinline__ float pivchol_entry(const float *__restrict__ zi, const float *__restrict__ szp, int kind,
+                                               int group, int ncomp, const float *__restrict__ wts) {
+  float acc = 0.f;
+  for (int c = 0; c < ncomp; ++c) {
+    float phi;
+    if (kind == RPGP_KIND_RBF) {
+      float r2 = 0.f;
+      for (int q = 0; q < group; ++q) {
+        const float dd = zi[c * group + q] * kExp2Scale - szp[c * group + q];
+        r2 = __builtin_fmaf(dd, dd, r2);
+      }
+      phi = fast_exp2(-r2);
+    } else if (kind == RPGP_KIND_MATERN15) {
+      phi = Phi<RPGP_KIND_MATERN15>::val(zi[c] * Phi<RPGP_KIND_MATERN15>::pre - szp[c]);
+    } else if (kind == RPGP_KIND_IMQ) {
+      phi = Phi<RPGP_KIND_IMQ>::val(zi[c] * Phi<RPGP_KIND_IMQ>::pre - szp[c]);
+    } else {
+      phi = Phi<RPGP_KIND_COSINE>::val(zi[c] * Phi<RPGP_KIND_COSINE>::pre - szp[c]);
+    }
+    acc = wts ? __builtin_fmaf(wts[c], phi, acc) : acc + phi;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float pivchol_pre(int kind) {
+  return kind == RPGP_KIND_RBF ? kExp2Scale
+                               : (kind == RPGP_KIND_MATERN15 ? Phi<RPGP_KIND_MATERN15>::pre
+                                                             : (kind == RPGP_KIND_IMQ ? Phi<RPGP_KIND_IMQ>::pre
+                                                                                      : Phi<RPGP_KIND_COSINE>::pre));
+}
+
+// block-wide argmax (ties -> smallest index); result valid in thread 0
+__device__ __forceinline__ void block_argmax(float &bv, int &bi, float *sval, int *sidx) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sval[wave] = bv; sidx[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+      if (sval[w] > bv || (sval[w] == bv && sidx[w] < bi)) { bv = sval[w]; bi = sidx[w]; }
+  }
+}
+
+// residual diagonal d = d0 everywhere; argmax partials of that (pivot 0)
+__global__ __launch_bounds__(256) void pivchol_init_kernel(float *__restrict__ dwork, float *__restrict__ pval,
+                                                           int *__restrict__ pidx, int N, float d0) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) dwork[i] = d0;
+  if (threadIdx.x == 0) {
+    const int first = blockIdx.x * 256;
+    pval[blockIdx.x] = first < N ? d0 : -1.f;
+    pidx[blockIdx.x] = first < N ? first : 0x7fffffff;
+  }
+}
+
+__global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restrict__ Z, float *__restrict__ L,
+                                                           float *__restrict__ dwork, const float *__restrict__ pval_in,
+                                                           const int *__restrict__ pidx_in, float *__restrict__ pval_out,
+                                                           int *__restrict__ pidx_out, int nparts, int N, int ldz,
+                                                           int ncols, int k, int m, float scale, float d0, int kind,
+                                                           int group, int ncomp, const float *__restrict__ wts) {
+  __shared__ float sval[4];
+  __shared__ int sidx[4];
+  __shared__ float szp[64];
+  __shared__ float slp[64];
+  __shared__ float sdp;
+  __shared__ int spiv;
+  // pivot of this step from the previous launch's partials
+  float bv = -1.f;
+  int bi = 0x7fffffff;
+  for (int q = threadIdx.x; q < nparts; q += 256) {
+    const float v = pval_in[q];
+    const int ix = pidx_in[q];
+    if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+  }
+  block_argmax(bv, bi, sval, sidx);
+  if (threadIdx.x == 0) { sdp = bv; spiv = bi; }
+  __syncthreads();
+  const int piv = spiv;
+  const float dp = sdp;
+  const bool ok = dp > 1e-10f * d0;
+  const float pre = pivchol_pre(kind);
+  if ((int)threadIdx.x < ncols) szp[threadIdx.x] = Z[(size_t)piv * ldz + threadIdx.x] * pre;
+  if ((int)threadIdx.x < m) slp[threadIdx.x] = L[(size_t)piv * k + threadIdx.x];
+  __syncthreads();
+  const float inv_sq = ok ? 1.0f / sqrtf(dp) : 0.f;
+  bv = -1.f;
+  bi = 0x7fffffff;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    float l = 0.f;
+    if (ok) {
+      const float row = scale * pivchol_entry(Z + (size_t)i * ldz, szp, kind, group, ncomp, wts);
+      float corr = 0.f;
+      for (int q = 0; q < m; ++q) corr = __builtin_fmaf(L[(size_t)i * k + q], slp[q], corr);
+      l = (row - corr) * inv_sq;
+    }
+    L[(size_t)i * k + m] = l;
+    float nd = dwork[i] - l * l;
+    nd = nd < 0.f ? 0.f : nd;
+    nd = (i == piv) ? 0.f : nd;
+    dwork[i] = nd;
+    if (nd > bv || (nd == bv && i < bi)) { bv = nd; bi = i; }
+  }
+  __syncthreads();
+  block_argmax(bv, bi, sval, sidx);
+  if (threadIdx.x == 0) {
+    pval_out[blockIdx.x] = bv;
+    pidx_out[blockIdx.x] = bi;
+  }
+}
+
 // ------------------------------- host-side helpers -------------------------------------------
 
 int g_rotdir = 0;  // +1: wave_rotate1 delivers lane l+1's value to lane l; -1: lane l-1's.  0 = not probed.
@@ -2642,13 +2763,43 @@ int rpgp_family_bilinear_grad_dense(const rpgp_family *fam, const float *Z, cons
                                 workspace_bytes, stream);
 }
 
+// diag_work: N + kPivcholScratch floats (residual diagonal + argmax partials of the multi-workgroup form)
+static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int ncols, int rank,
+                          float scale, float d0, int kind, int group, int ncomp, const float *wts, void *stream) {
+  hipStream_t st = as_stream(stream);
+  if (N <= 2048 && kind == RPGP_KIND_RBF && group == 1 && !wts) {      // launch-latency regime: one workgroup
+    hipLaunchKernelGGL(pivchol_kernel, dim3(1), dim3(1024), 0, st, Z, L, diag_work, (int)N, ldz, ncols, rank, scale);
+    return launch_status();
+  }
+  int nb = (int)((N + 255) / 256);
+  if (nb > 512) nb = 512;
+  float *pval[2] = {diag_work + N, diag_work + N + 512};
+  int *pidx[2] = {reinterpret_cast<int *>(diag_work + N + 1024), reinterpret_cast<int *>(diag_work + N + 1536)};
+  hipLaunchKernelGGL(pivchol_init_kernel, dim3(nb), dim3(256), 0, st, diag_work, pval[0], pidx[0], (int)N, d0);
+  for (int m = 0; m < rank; ++m) {
+    hipLaunchKernelGGL(pivchol_step_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
+                       pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, kind, group,
+                       ncomp, wts);
+  }
+  return launch_status();
+}
+
 int rpgp_pivoted_cholesky(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int J, int rank, float scale,
                           void *stream) {
   if (!Z || !L || !diag_work || N <= 0 || J <= 0 || J > 64 || rank <= 0 || rank > 64 || ldz < J || N > 0x7fffffffLL)
     return RPGP_EINVAL;
-  hipLaunchKernelGGL(pivchol_kernel, dim3(1), dim3(1024), 0, as_stream(stream), Z, L, diag_work, (int)N, ldz, J, rank,
-                     scale);
-  return launch_status();
+  return pivchol_common(Z, L, diag_work, N, ldz, J, rank, scale, scale * (float)J, RPGP_KIND_RBF, 1, J, nullptr, stream);
+}
+
+int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *L, float *diag_work, int64_t N,
+                                 int ldz, int rank, float scale, float weight_sum, void *stream) {
+  if (!Z || !L || !diag_work || N <= 0 || rank <= 0 || rank > 64 || N > 0x7fffffffLL) return RPGP_EINVAL;
+  const int rc = family_check(fam, ldz, ldz);
+  if (rc) return rc;
+  const int ncols = fam->ncomp * fam->group;
+  if (ncols > 64) return RPGP_EINVAL;
+  return pivchol_common(Z, L, diag_work, N, ldz, ncols, rank, scale, scale * weight_sum, fam->kind, fam->group,
+                        fam->ncomp, fam->weights, stream);
 }
 
 int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64_t ldk, int T, float noise,

@@ -356,6 +356,13 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
             raise ValueError("a diagonal can only be added to the square symmetric operator")
         return self._local_matmul(rhs.detach(), noise if self.symmetric else 0.0)
 
+    def fused_pivoted_cholesky(self, rank):
+        be = _backend.get_backend()
+        if not self.symmetric or not hasattr(be, "family_pivoted_cholesky") or self.Z1.shape[1] > 64 or rank > 64:
+            return None
+        return be.family_pivoted_cholesky(self.fam, self.Z1.detach().contiguous(), self._scale,
+                                          min(rank, self.Z1.shape[0]), self._wsum)
+
     def native_descriptor(self, noise=0.0):
         be = _backend.get_backend()
         if not self.symmetric or not hasattr(be, "mbcg_solve"):

@@ -283,10 +283,24 @@ def pivoted_cholesky(Z, scale, rank):
     Z = _require(Z, "Z", 2)
     N, J = Z.shape
     L = torch.empty((N, rank), dtype=torch.float32, device=Z.device)
-    work = torch.empty(N, dtype=torch.float32, device=Z.device)
+    work = torch.empty(N + _lib.RPGP_PIVCHOL_SCRATCH, dtype=torch.float32, device=Z.device)
     with torch.cuda.device(Z.device):
         _lib.check(lib.rpgp_pivoted_cholesky(Z.data_ptr(), L.data_ptr(), work.data_ptr(), N, J, J, int(rank),
                                              float(scale), _stream()), "rpgp_pivoted_cholesky")
+    return L
+
+
+def family_pivoted_cholesky(fam, Z, scale, rank, weight_sum):
+    """Pivoted Cholesky of a family member's kernel matrix (diagonal = scale * weight_sum)."""
+    lib = _lib.load()
+    Z = _family_cols(fam, Z, "Z")
+    N, J = Z.shape
+    L = torch.empty((N, rank), dtype=torch.float32, device=Z.device)
+    work = torch.empty(N + _lib.RPGP_PIVCHOL_SCRATCH, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        _lib.check(lib.rpgp_family_pivoted_cholesky(fam.ref, Z.data_ptr(), L.data_ptr(), work.data_ptr(), N, J, int(rank),
+                                                    float(scale), float(weight_sum), _stream()),
+                   "rpgp_family_pivoted_cholesky")
     return L
 
 

@@ -1236,6 +1236,61 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const float *__restrict
   }
 }
 
+// VALU form for T <= 12: the padded 16-column MFMA above spends 128 matrix-pipe cycles per KB of Kd per SIMD — as much
+// as HBM allows a SIMD to receive (1 KB / 132 clk at 8 TB/s), so it cannot overlap its way to the HBM roofline.  Here a
+// wave owns 256 output columns (lane = 4 consecutive columns) and streams down the rows of the symmetric Kd: every
+// wave-instruction loads ONE contiguous KB of a row (perfectly coalesced), V[row][0..T) is wave-uniform (scalar loads,
+// SGPR multiplier), and the update is 4 T v_fma_f32 per lane (8.8 T cycles per KB).  Split-K slabs + the same
+// fixed-order reduce as the MFMA form.
+template <int TT>
+__global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__restrict__ Kd, const float *__restrict__ V,
+                                                              float *__restrict__ slab, int N, long long ldk, int T,
+                                                              int rows_per_split) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cl = blockIdx.x * 1024 + wave * 256 + 4 * lane;      // this lane's 4 output columns
+  const bool vec_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0) && (cl + 3 < N);
+  float acc[4][TT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[i][t] = 0.f;
+  const int rs = blockIdx.y * rows_per_split;
+  const int re = (rs + rows_per_split < N) ? rs + rows_per_split : N;
+  if (cl < N) {
+#pragma unroll (TT <= 4 ? 8 : 4)
+    for (int row = rs; row < re; ++row) {
+      const float *kp = Kd + (size_t)row * ldk + cl;
+      float4v a = {0.f, 0.f, 0.f, 0.f};
+      if (vec_ok) {
+        a = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kp));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (cl + i < N) a[i] = kp[i];
+      }
+      const float *vp = V + (size_t)row * T;      // wave-uniform address: scalar loads
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const float v = t < T ? vp[t] : 0.f;
+        acc[0][t] = __builtin_fmaf(a.x, v, acc[0][t]);
+        acc[1][t] = __builtin_fmaf(a.y, v, acc[1][t]);
+        acc[2][t] = __builtin_fmaf(a.z, v, acc[2][t]);
+        acc[3][t] = __builtin_fmaf(a.w, v, acc[3][t]);
+      }
+    }
+  }
+  float *sl = slab + (size_t)blockIdx.y * N * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = cl + i;
+    if (c < N) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+        if (t < T) sl[(size_t)c * 16 + t] = acc[i][t];
+    }
+  }
+}
+
 // out[row][t0+n] = sum_split slab[split][row][n] + noise * V[row][t0+n]   (fixed order: deterministic)
 __global__ void dense_gemm_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ V,
                                          float *__restrict__ out, int N, int T, int t0, int tcnt, int nsplit,
@@ -2807,10 +2862,12 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
   if (!Kd || !V || !out || N <= 0 || T <= 0 || ldk < N || N > 0x7fffffffLL) return RPGP_EINVAL;
   hipStream_t st = as_stream(stream);
   const int nrb = (int)((N + 255) / 256);
-  int nsplit = (3072 + nrb - 1) / nrb;            // ~3000 workgroups keep enough loads in flight to stream HBM
-  const int max_split = (int)((N + 1023) / 1024);
+  const int ncols_wg = T <= 12 ? 1024 : 256;      // output columns per workgroup (VALU / MFMA form)
+  const int ncb_ = (int)((N + ncols_wg - 1) / ncols_wg);
+  int nsplit = (3072 + ncb_ - 1) / ncb_;          // ~3000 workgroups keep enough loads in flight to stream HBM
+  const int max_split = (int)((N + 255) / 256);
   if (nsplit > max_split) nsplit = max_split;
-  if (nsplit > 32) nsplit = 32;
+  if (nsplit > (T <= 12 ? 64 : 32)) nsplit = T <= 12 ? 64 : 32;
   if (nsplit < 1) nsplit = 1;
   int cps = (int)((N + nsplit - 1) / nsplit);
   cps = (cps + 255) / 256 * 256;
@@ -2819,6 +2876,25 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
   RPGP_CHECK(hipMallocAsync((void **)&slab, (size_t)nsplit * N * 16 * sizeof(float), st));
   dim3 grid((unsigned)nrb, (unsigned)nsplit), block(256);
   int rc = 0;
+  if (T <= 12) {
+    // VALU form: 1024 output columns per workgroup, rows split so that ~3000 workgroups stream concurrently
+    const unsigned ncb = (unsigned)((N + 1023) / 1024);
+    dim3 vgrid(ncb, (unsigned)nsplit);
+    if (T == 1)
+      hipLaunchKernelGGL((dense_gemv_valu_kernel<1>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, cps);
+    else if (T <= 4)
+      hipLaunchKernelGGL((dense_gemv_valu_kernel<4>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, cps);
+    else if (T <= 8)
+      hipLaunchKernelGGL((dense_gemv_valu_kernel<8>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, cps);
+    else
+      hipLaunchKernelGGL((dense_gemv_valu_kernel<12>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, cps);
+    const size_t total = (size_t)N * 16;
+    hipLaunchKernelGGL(dense_gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, V, out,
+                       (int)N, T, 0, T, nsplit, noise);
+    rc = launch_status();
+    (void)hipFreeAsync(slab, st);
+    return rc;
+  }
   for (int t0 = 0; t0 < T && rc == 0; t0 += 16) {
     const int tcnt = (T - t0 < 16) ? T - t0 : 16;
     hipLaunchKernelGGL(dense_gemm_kernel, grid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, t0, tcnt, cps);

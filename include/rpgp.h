@@ -188,6 +188,9 @@ int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t
 int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, const float *V, float *out,
                  int64_t M, int64_t N, int ldz1, int ldz2, int J, int G, int T, float scale, float noise,
                  void *workspace, size_t workspace_bytes, void *stream);
+/* Pivoted Cholesky of the SKI operator (same contract as rpgp_pivoted_cholesky; diag_work: N + RPGP_PIVCHOL_SCRATCH). */
+int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
+                              int J, int G, int rank, float scale, void *stream);
 int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t N, int ldz, int J, int G,
                   float scale, void *stream);
 int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,

@@ -23,6 +23,7 @@ class HipBackend:
     ski_grid = staticmethod(ops.ski_grid)
     ski_mvm = staticmethod(ops.ski_mvm)
     ski_diag = staticmethod(ops.ski_diag)
+    ski_pivoted_cholesky = staticmethod(ops.ski_pivoted_cholesky)
     ski_bilinear_grad = staticmethod(ops.ski_bilinear_grad)
     make_family = staticmethod(ops.Family)
     family_mvm_sym = staticmethod(ops.family_mvm_sym)

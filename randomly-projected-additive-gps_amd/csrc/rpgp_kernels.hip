@@ -1910,16 +1910,38 @@ __global__ __launch_bounds__(256) void pivchol_init_kernel(float *__restrict__ d
   }
 }
 
+// argmax partials of an already filled residual diagonal (SKI: the diagonal is not constant)
+__global__ __launch_bounds__(256) void pivchol_init_from_diag_kernel(const float *__restrict__ dwork,
+                                                                     float *__restrict__ pval, int *__restrict__ pidx,
+                                                                     int N) {
+  __shared__ float sval[4];
+  __shared__ int sidx[4];
+  float bv = -1.f;
+  int bi = 0x7fffffff;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const float v = dwork[i];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  block_argmax(bv, bi, sval, sidx);
+  if (threadIdx.x == 0) {
+    pval[blockIdx.x] = bv;
+    pidx[blockIdx.x] = bi;
+  }
+}
+
 __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restrict__ Z, float *__restrict__ L,
                                                            float *__restrict__ dwork, const float *__restrict__ pval_in,
                                                            const int *__restrict__ pidx_in, float *__restrict__ pval_out,
                                                            int *__restrict__ pidx_out, int nparts, int N, int ldz,
                                                            int ncols, int k, int m, float scale, float d0, int kind,
-                                                           int group, int ncomp, const float *__restrict__ wts) {
+                                                           int group, int ncomp, const float *__restrict__ wts,
+                                                           const float *__restrict__ gp, int G) {
   __shared__ float sval[4];
   __shared__ int sidx[4];
   __shared__ float szp[64];
   __shared__ float slp[64];
+  __shared__ float spw[64][4];     // SKI mode (gp != nullptr): the pivot's interpolation weights / first tap per column
+  __shared__ int spidx[64];
   __shared__ float sdp;
   __shared__ int spiv;
   // pivot of this step from the previous launch's partials
@@ -1937,7 +1959,16 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
   const float dp = sdp;
   const bool ok = dp > 1e-10f * d0;
   const float pre = pivchol_pre(kind);
-  if ((int)threadIdx.x < ncols) szp[threadIdx.x] = Z[(size_t)piv * ldz + threadIdx.x] * pre;
+  if ((int)threadIdx.x < ncols) {
+    const float zp = Z[(size_t)piv * ldz + threadIdx.x];
+    szp[threadIdx.x] = zp * pre;
+    if (gp) {
+      float w[4], dw[4];
+      spidx[threadIdx.x] = ski_taps<false>(zp, gp[0], gp[2], G, w, dw);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) spw[threadIdx.x][q] = w[q];
+    }
+  }
   if ((int)threadIdx.x < m) slp[threadIdx.x] = L[(size_t)piv * k + threadIdx.x];
   __syncthreads();
   const float inv_sq = ok ? 1.0f / sqrtf(dp) : 0.f;
@@ -1946,7 +1977,30 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
     float l = 0.f;
     if (ok) {
-      const float row = scale * pivchol_entry(Z + (size_t)i * ldz, szp, kind, group, ncomp, wts);
+      float row;
+      if (gp) {
+        // K_ski(i, piv) = sum_j sum_{q,q'} w_q(z_ij) w_q'(z_pj) Toep[(idx_i + q) - (idx_p + q')]: 7 distinct lags per column
+        const float g0 = gp[0], inv_h = gp[2], hs = gp[1] * kExp2Scale;
+        float acc = 0.f;
+        for (int j = 0; j < ncols; ++j) {
+          float w[4], dw[4];
+          const int idx = ski_taps<false>(Z[(size_t)i * ldz + j], g0, inv_h, G, w, dw);
+          const int delta = idx - spidx[j];
+          float tl[7];
+#pragma unroll
+          for (int u = 0; u < 7; ++u) {
+            const float dd = (float)(delta + u - 3) * hs;
+            tl[u] = fast_exp2(-(dd * dd));
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) acc = __builtin_fmaf(w[q] * spw[j][qq], tl[q - qq + 3], acc);
+        }
+        row = scale * acc;
+      } else {
+        row = scale * pivchol_entry(Z + (size_t)i * ldz, szp, kind, group, ncomp, wts);
+      }
       float corr = 0.f;
       for (int q = 0; q < m; ++q) corr = __builtin_fmaf(L[(size_t)i * k + q], slp[q], corr);
       l = (row - corr) * inv_sq;
@@ -2820,9 +2874,10 @@ int rpgp_family_bilinear_grad_dense(const rpgp_family *fam, const float *Z, cons
 
 // diag_work: N + kPivcholScratch floats (residual diagonal + argmax partials of the multi-workgroup form)
 static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int ncols, int rank,
-                          float scale, float d0, int kind, int group, int ncomp, const float *wts, void *stream) {
+                          float scale, float d0, int kind, int group, int ncomp, const float *wts, void *stream,
+                          const float *gp = nullptr, int G = 0) {
   hipStream_t st = as_stream(stream);
-  if (N <= 2048 && kind == RPGP_KIND_RBF && group == 1 && !wts) {      // launch-latency regime: one workgroup
+  if (N <= 2048 && kind == RPGP_KIND_RBF && group == 1 && !wts && !gp) {      // launch-latency regime: one workgroup
     hipLaunchKernelGGL(pivchol_kernel, dim3(1), dim3(1024), 0, st, Z, L, diag_work, (int)N, ldz, ncols, rank, scale);
     return launch_status();
   }
@@ -2830,11 +2885,17 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
   if (nb > 512) nb = 512;
   float *pval[2] = {diag_work + N, diag_work + N + 512};
   int *pidx[2] = {reinterpret_cast<int *>(diag_work + N + 1024), reinterpret_cast<int *>(diag_work + N + 1536)};
-  hipLaunchKernelGGL(pivchol_init_kernel, dim3(nb), dim3(256), 0, st, diag_work, pval[0], pidx[0], (int)N, d0);
+  if (gp) {    // SKI: the residual diagonal starts at diag(K_ski), which depends on the point
+    hipLaunchKernelGGL(ski_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, Z, gp, diag_work,
+                       (long long)N, ldz, ncols, G, scale);
+    hipLaunchKernelGGL(pivchol_init_from_diag_kernel, dim3(nb), dim3(256), 0, st, diag_work, pval[0], pidx[0], (int)N);
+  } else {
+    hipLaunchKernelGGL(pivchol_init_kernel, dim3(nb), dim3(256), 0, st, diag_work, pval[0], pidx[0], (int)N, d0);
+  }
   for (int m = 0; m < rank; ++m) {
     hipLaunchKernelGGL(pivchol_step_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
                        pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, kind, group,
-                       ncomp, wts);
+                       ncomp, wts, gp, G);
   }
   return launch_status();
 }
@@ -2844,6 +2905,15 @@ int rpgp_pivoted_cholesky(const float *Z, float *L, float *diag_work, int64_t N,
   if (!Z || !L || !diag_work || N <= 0 || J <= 0 || J > 64 || rank <= 0 || rank > 64 || ldz < J || N > 0x7fffffffLL)
     return RPGP_EINVAL;
   return pivchol_common(Z, L, diag_work, N, ldz, J, rank, scale, scale * (float)J, RPGP_KIND_RBF, 1, J, nullptr, stream);
+}
+
+int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
+                              int J, int G, int rank, float scale, void *stream) {
+  if (!Z || !grid_params || !L || !diag_work || N <= 0 || J <= 0 || J > 64 || G < 8 || rank <= 0 || rank > 64 ||
+      ldz < J || N > 0x7fffffffLL)
+    return RPGP_EINVAL;
+  return pivchol_common(Z, L, diag_work, N, ldz, J, rank, scale, scale * (float)J, RPGP_KIND_RBF, 1, J, nullptr, stream,
+                        grid_params, G);
 }
 
 int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *L, float *diag_work, int64_t N,

@@ -257,6 +257,13 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         be = _backend.get_backend()
         self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size)
 
+    def fused_pivoted_cholesky(self, rank):
+        be = _backend.get_backend()
+        if not self.symmetric or not hasattr(be, "ski_pivoted_cholesky") or self.Z1.shape[1] > 64 or rank > 64:
+            return None
+        return be.ski_pivoted_cholesky(self.Z1.detach().contiguous(), self.gp, self._scale,
+                                       min(rank, self.Z1.shape[0]), self.grid_size)
+
     def _local_matmul(self, rhs, noise=0.0):
         be = _backend.get_backend()
         z1 = self.Z1.detach()

@@ -357,6 +357,20 @@ def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
     return out.squeeze(1) if squeeze else out
 
 
+def ski_pivoted_cholesky(Z, gp, scale, rank, grid_size=1024):
+    """Pivoted Cholesky of the SKI operator: L (N x rank)."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    N, J = Z.shape
+    L = torch.empty((N, rank), dtype=torch.float32, device=Z.device)
+    work = torch.empty(N + _lib.RPGP_PIVCHOL_SCRATCH, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        _lib.check(lib.rpgp_ski_pivoted_cholesky(Z.data_ptr(), gp.data_ptr(), L.data_ptr(), work.data_ptr(), N, J, J,
+                                                 int(grid_size), int(rank), float(scale), _stream()),
+                   "rpgp_ski_pivoted_cholesky")
+    return L
+
+
 def ski_diag(Z, gp, scale, grid_size=1024):
     lib = _lib.load()
     Z = _require(Z, "Z", 2)

@@ -142,3 +142,17 @@ def test_ski_mll_matches_exact_operator_on_gpu(gpu_device):
         assert abs(res[(ski, False)][0] - res[(ski, True)][0]) < 2e-3 * abs(res[(ski, True)][0])
         assert torch.allclose(res[(ski, False)][1], res[(ski, True)][1], rtol=0.1, atol=4e-3)
         assert abs(res[(ski, False)][2] - res[(ski, True)][2]) < 2e-2 * abs(res[(ski, True)][2])
+
+
+@pytest.mark.parametrize("N,J,G", [(3000, 3, 256), (20000, 20, 1024)])
+def test_ski_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, G):
+    """rpgp_ski_pivoted_cholesky (one chip-wide launch per greedy step, entries from the interpolation weights and the
+    Toeplitz lags) against the generic row-by-row version that asks the operator for rows."""
+    from rpgp_amd.operators import SKIAdditiveOperator
+    from rpgp_amd.precond import pivoted_cholesky
+    rng = np.random.default_rng(N)
+    Z = torch.from_numpy((rng.standard_normal((N, J)) * 0.8).astype(np.float32)).to(gpu_device)
+    op = SKIAdditiveOperator(Z, None, torch.tensor(0.9, device=gpu_device), 1.0 / J, grid_size=G)
+    Lf = op.fused_pivoted_cholesky(10)
+    Lg = pivoted_cholesky(op._diagonal(), op._get_rows, 10)
+    assert Lf is not None and torch.allclose(Lf, Lg, rtol=2e-3, atol=3e-4)

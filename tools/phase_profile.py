@@ -1,5 +1,5 @@
 """Host-side phase timing of one training step (synchronising between phases) to see where small-N steps spend time.
-usage: phase_profile.py [N] [d]"""
+usage: phase_profile.py [N] [d] [ski]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
@@ -13,11 +13,13 @@ dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 7372
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 J = 20
+SKI = len(sys.argv) > 3 and sys.argv[3] == "ski"
 g = torch.Generator().manual_seed(0)
 X = torch.randn(N, d, generator=g); y = torch.sin(X).sum(1); y = (y - y.mean()) / y.std()
 X, y = X.to(dev), y.to(dev)
 torch.manual_seed(0)
-model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False, prescale=True)
+model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False, prescale=True,
+                             ski=SKI, ski_options={"grid_size": 1024, "num_dims": 1} if SKI else None)
 model = model.to(dev); mll = ExactMarginalLogLikelihood(lik, model)
 T = {}
 def timed(name, fn):

@@ -19,6 +19,7 @@
 //     reduce kernel sums them in a fixed order: deterministic, no float atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stddef.h>
 
 #include "../../include/rpgp.h"
@@ -2091,8 +2092,10 @@ inline int chunks_of(const TilePlan &p, int64_t N, bool sym, int b) {
 inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0, bool r1 = false) {
   TilePlan p;
   // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
-  p.R = (M >= 16384 && !r1) ? 2 : 1;   // r1: the family policies are instantiated with one row per lane only
-  (void)T;
+  // measured (tools/time_small.py): with T > 4 right-hand sides two rows per lane win from N ~ 4k up (362 vs 429 us at
+  // N = 14939, T = 11); with T <= 4 only once there are enough 512-row workgroups to fill the chip (N >~ 10k)
+  const long long r2_min = T > 4 ? 4096 : 10240;
+  p.R = (M >= r2_min && !r1) ? 2 : 1;   // r1: the family policies are instantiated with one row per lane only
   p.BR = 256 * p.R;
   p.nrb = (int)((M + p.BR - 1) / p.BR);
   const double pairs = (sym ? 0.5 * (double)M * (double)N : (double)M * (double)N) / (double)(world > 0 ? world : 1);

@@ -45,7 +45,9 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // (rpgp_init) and passed to kernels as `rotdir`, so correctness does not rest on the mnemonic.
 __device__ __forceinline__ float wave_rotate1(float x) {
   int xi = __builtin_bit_cast(int, x);
-  int r = __builtin_amdgcn_update_dpp(0, xi, 0x134, 0xf, 0xf, false);
+  // bound_ctrl = true: every lane of a wave rotate has a valid source, and the compiler no longer has to materialise the
+  // `old` operand with an extra v_mov_b32 per rotation (24 per two steps in the T = 12 kernel)
+  int r = __builtin_amdgcn_update_dpp(0, xi, 0x134, 0xf, 0xf, true);
   return __builtin_bit_cast(float, r);
 }
 

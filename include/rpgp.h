@@ -245,6 +245,8 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
  * column residual norm < tolerance after >= min_iter iterations (tested every `check_every` iterations — the only host
  * synchronisations) or at max_iter.  The first `hist_len` (<= 64) iterations' alpha / beta coefficients are returned in
  * HOST arrays laid out [hist_len][16] for the Lanczos tridiagonals.  Returns RPGP_ENUMERIC on NaNs.
+ * stagnation_window > 0: also stop (without convergence: *mean_resid_host stays >= tolerance) when the best mean
+ * residual has not improved by 1 % over that many consecutive tests — the fp32 floor of a badly conditioned system.
  */
 #define RPGP_OP_FUSED 0           /* rpgp_mvm_sym on Z */
 #define RPGP_OP_FUSED_PREPARED 1  /* rpgp_mvm_sym_prepared on prep */
@@ -265,7 +267,8 @@ typedef struct rpgp_operator {
 } rpgp_operator;
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank);
 int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,
-                    int hist_len, int check_every, float tolerance, int precond_rank, const float *L,
+                    int hist_len, int check_every, int stagnation_window, float tolerance, int precond_rank,
+                    const float *L,
                     const double *Cinv, float precond_sigma2, float *alpha_hist_host, float *beta_hist_host,
                     int *iterations_host, float *mean_resid_host, void *workspace, size_t workspace_bytes,
                     void *stream);

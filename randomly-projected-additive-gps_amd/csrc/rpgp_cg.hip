@@ -35,8 +35,11 @@ constexpr int kMaxHist = 64;        // Lanczos coefficients kept for at most thi
 // device-resident scalar state
 struct CgPoll {             // copied to pinned host memory after the iterations that test convergence
   float mean_resid;
-  int done;                 // 0 running, 1 tolerance reached (later iterations are no-ops), 2 non-finite residual
+  int done;                 // 0 running, 1 tolerance reached (later iterations are no-ops), 2 non-finite residual,
+                            // 3 stagnated (no 1 % improvement of the best residual over `stagnation_window` tests)
   int iters;                // iterations performed when `done` was set
+  float best_resid;         // stagnation bookkeeping
+  int since_best;
 };
 struct CgState {
   float rz[2][kMaxT];       // r.z of the current iterate, ping-pong by iteration parity (no intra-kernel race)
@@ -119,6 +122,8 @@ __global__ __launch_bounds__(256) void k_normalise(const float *__restrict__ rhs
     st->poll.mean_resid = 1.0f;
     st->poll.done = 0;
     st->poll.iters = 0;
+    st->poll.best_resid = 3.0e38f;
+    st->poll.since_best = 0;
   }
   __syncthreads();
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, 
                                                    const float *__restrict__ partial_rz, const float *__restrict__ partial_rr,
                                                    int nparts, CgState *__restrict__ st, float *__restrict__ beta_out,
                                                    long long N, int T, float eps, int cur, int check_now,
-                                                   float tolerance, int iter_count) {
+                                                   float tolerance, int iter_count, int stagnation_window) {
   __shared__ float srzn[kMaxT];
   __shared__ float srr[kMaxT];
   __shared__ float sbeta[kMaxT];
@@ -346,6 +351,14 @@ __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, 
         } else if (m < tolerance) {
           st->poll.done = 1;
           st->poll.iters = iter_count;
+        } else if (stagnation_window > 0) {
+          if (m < 0.99f * st->poll.best_resid) {
+            st->poll.best_resid = m;
+            st->poll.since_best = 0;
+          } else if (++st->poll.since_best >= stagnation_window) {
+            st->poll.done = 3;
+            st->poll.iters = iter_count;
+          }
         }
       }
     }
@@ -441,7 +454,8 @@ size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_ran
 }
 
 int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,
-                    int hist_len, int check_every, float tolerance, int precond_rank, const float *L,
+                    int hist_len, int check_every, int stagnation_window, float tolerance, int precond_rank,
+                    const float *L,
                     const double *Cinv, float precond_sigma2, float *alpha_hist_host, float *beta_hist_host,
                     int *iterations_host, float *mean_resid_host, void *workspace, size_t workspace_bytes, void *stream) {
   if (!op || !rhs || !x || T <= 0 || T > kMaxT || max_iter < 0 || hist_len < 0 || check_every <= 0 ||
@@ -494,7 +508,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   // memory, so the next iteration is already queued while it waits and the GPU never idles on the round trip.  The
   // iteration queued past convergence is a no-op on x (alpha = 0).
   int polled_it = -1;                     // iteration whose poll is in flight (-1: none)
-  CgPoll last = {1.0f, 0, 0};
+  CgPoll last = {1.0f, 0, 0, 0.f, 0};
   for (it = 0; it < n_iter; ++it) {
     int rc = apply_operator(op, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
@@ -507,7 +521,8 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && ((it - min_it) % check_every == 0 || it == n_iter - 1);
     hipLaunchKernelGGL(k_direction, dim3(nb), dim3(256), 0, st, z, p, part_rz, part_rr, nb, state,
-                       beta_d + (size_t)slot * kMaxT, N, T, eps, it & 1, check_now ? 1 : 0, tolerance, it + 1);
+                       beta_d + (size_t)slot * kMaxT, N, T, eps, it & 1, check_now ? 1 : 0, tolerance, it + 1,
+                       stagnation_window);
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
       CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
       last = hpoll[polled_it % kPollRing];

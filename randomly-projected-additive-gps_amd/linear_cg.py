@@ -71,14 +71,15 @@ def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag
     n_iter = min(max_iter, N)
     hist = min(max_tridiag_iter, n_iter) if n_tridiag else 0
     x, ah, bh, iters, mres = be.mbcg_solve(desc, rhs.contiguous(), tolerance, n_iter, min_iter=10, hist_len=hist,
-                                           check_every=check_every, L=L, Cinv=Cinv, sigma2=sigma2)
+                                           check_every=check_every, L=L, Cinv=Cinv, sigma2=sigma2,
+                                           stagnation_window=settings.cg_stagnation_window.value())
     del keep
     stats["calls"] += 1
     stats["iterations"] += iters
     stats["last_iterations"] = iters
     stats["last_rhs"] = T
     stats["native_calls"] = stats.get("native_calls", 0) + 1
-    if mres >= tolerance and iters >= n_iter:
+    if mres >= tolerance:                       # ran out of iterations, or stagnated at the fp32 floor
         warnings.warn(
             "CG terminated in {} iterations with average residual norm {} which is larger than the tolerance of {} "
             "specified by rpgp_amd.settings.cg_tolerance. If performance is affected, consider raising the maximum "
@@ -153,6 +154,8 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     last_tridiag_iter = 0
 
     tolerance_reached = False
+    best_res, since_best = float("inf"), 0
+    stagnation_window = settings.cg_stagnation_window.value()
     residual_norm = None
     min_iters = min(10, n_iter - 1)
     k = 0
@@ -202,6 +205,16 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
                 if mean_res < tolerance:
                     tolerance_reached = True
                     break
+                # fp32 floor: on a badly conditioned system the recurrence stops making progress long before
+                # max_cg_iterations (10 000 in the runner); give up once the best residual has not improved by 1 %
+                # over `cg_stagnation_window` consecutive tests (the non-convergence warning below still fires)
+                if mean_res < 0.99 * best_res:
+                    best_res, since_best = mean_res, 0
+                else:
+                    since_best += 1
+                    if stagnation_window and since_best >= stagnation_window:
+                        stats["stagnated"] = stats.get("stagnated", 0) + 1
+                        break
 
     if not tolerance_reached and n_iter > 0:
         mean_res = float(residual_norm.mean()) if residual_norm is not None else 0.0

@@ -552,7 +552,8 @@ def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=
     return d, (Z, prep, gp, Kd, family)
 
 
-def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_every=1, L=None, Cinv=None, sigma2=1.0):
+def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_every=1, L=None, Cinv=None, sigma2=1.0,
+               stagnation_window=0):
     """Native preconditioned batched CG (rpgp_mbcg_solve).  rhs: N x T (T <= 16).
     Returns (x, alpha_hist [h x T], beta_hist [h x T], iterations, mean_residual)."""
     import ctypes
@@ -579,7 +580,8 @@ def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_ev
         nbytes = lib.rpgp_mbcg_workspace_bytes(ctypes.byref(desc), T, k)
         ws = _workspace(rhs.device, nbytes)
         rc = lib.rpgp_mbcg_solve(ctypes.byref(desc), rhs.data_ptr(), x.data_ptr(), T, int(max_iter), int(min_iter),
-                                 int(hist_len), int(check_every), float(tolerance), k, Lp, Cp, float(sigma2),
+                                 int(hist_len), int(check_every), int(stagnation_window), float(tolerance), k, Lp, Cp,
+                                 float(sigma2),
                                  ah.ctypes.data, bh.ctypes.data, ctypes.byref(iters), ctypes.byref(mres),
                                  ws.data_ptr(), ws.numel(), _stream())
     if rc == _lib.RPGP_ENUMERIC:

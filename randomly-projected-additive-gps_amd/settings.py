@@ -66,6 +66,9 @@ skip_posterior_variances = _setting("skip_posterior_variances", False, flag=True
 deterministic_probes = _setting("deterministic_probes", False, flag=True)   # fixed probe vectors (reproducible SLQ)
 cache_kernel = _setting("cache_kernel", False, flag=True)                   # materialise K once per hyper-parameter step
 tridiagonal_jitter = _setting("tridiagonal_jitter", 1e-6)
+# wide-block CG (torch-op loop): stop when the best mean residual has not improved by 1 % over this many consecutive
+# convergence tests (fp32 floor on badly conditioned systems); 0 disables (GPyTorch's behaviour: run to max_cg_iterations)
+cg_stagnation_window = _setting("cg_stagnation_window", 200)
 
 
 class fast_computations:

@@ -391,3 +391,19 @@ def test_fast_pred_var_love(oracle_backend):
         errs.append(np.abs(cov - cov_ref).max())
         assert (np.diag(cov) - np.diag(cov_ref)).min() > -1e-4          # never under-estimates the variance
     assert errs[0] < 1e-4 and errs[0] <= errs[1] + 1e-6 <= errs[2] + 2e-6
+
+
+def test_linear_cg_gives_up_on_stagnation_instead_of_running_to_max_iter():
+    """A system whose fp32 residual floor lies above the tolerance: the torch-op loop stops after
+    `cg_stagnation_window` tests without progress and still warns about non-convergence."""
+    from rpgp_amd import linear_cg as lcg, settings
+    g = torch.Generator().manual_seed(0)
+    Q, _ = torch.linalg.qr(torch.randn(200, 200, generator=g, dtype=torch.float64))
+    A = ((Q * torch.logspace(0, 9, 200, dtype=torch.float64)) @ Q.t()).float()      # condition number 1e9 in fp32
+    b = torch.randn(200, 3, generator=g)
+    with settings.cg_stagnation_window(25), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lcg.stats["stagnated"] = 0
+        lcg.linear_cg(lambda v: A @ v, b, tolerance=1e-7, max_iter=100000)
+    assert lcg.stats["stagnated"] == 1 and lcg.stats["last_iterations"] < 20000
+    assert any("CG terminated" in str(x.message) for x in w)

@@ -97,3 +97,21 @@ def test_native_cached_k_operator(gpu_device):
     assert float((xd - xf).norm() / xf.norm()) < 1e-3
     resid = (dense._matmul(xd) - rhs).norm(dim=0) / rhs.norm(dim=0)
     assert float(resid.max()) < 1e-3
+
+
+def test_native_cg_stops_on_stagnation(gpu_device):
+    """Badly conditioned system (noise 1e-7 on a smooth kernel): fp32 CG cannot reach the tolerance; the device-side
+    stagnation rule stops the executor long before max_iter and the non-convergence warning is raised."""
+    import warnings
+    from rpgp_amd import linear_cg as lcg, settings
+    from rpgp_amd.operators import AdditiveRPOperator, AddedDiagOperator
+    N, J = 3000, 4
+    Z = (torch.randn(N, J, generator=torch.Generator().manual_seed(0)) * 0.3).to(gpu_device)
+    khat = AddedDiagOperator(AdditiveRPOperator(Z, None, torch.tensor(1.0, device=gpu_device), 1.0 / J),
+                             torch.tensor(1e-7, device=gpu_device))
+    rhs = torch.randn(N, 2, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    with settings.cg_stagnation_window(50), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lcg.linear_cg(khat._matmul, rhs, tolerance=1e-6, max_iter=100000, operator=khat)
+    assert lcg.stats["last_iterations"] < 2500          # n_iter = min(max_iter, N) = 3000 without the rule
+    assert any("CG terminated" in str(x.message) for x in w)

@@ -1312,7 +1312,7 @@ __global__ void dense_gemm_reduce_kernel(const float *__restrict__ slab, const f
 // SKI path (spec additive_spread_prescale_Jd_ski.json):
 //   K_j ~= W_j Tm W_j^T,  W_j: cubic-convolution interpolation (Keys, 4 taps) of projection j onto ONE shared regular
 //   1-D grid of G points, Tm: symmetric Toeplitz with first column exp(-0.5 (k h)^2).
-// MVM = scatter (W^T v, LDS-privatised histogram + global float atomics) -> Toeplitz matvec (G x G, tiny) -> gather.
+// MVM = scatter (W^T v: per-(chunk, projection) LDS histograms in fixed point, slabs) -> Toeplitz product (MFMA) -> gather.
 // HBM traffic ~ N (J + 2T) floats: this path is bandwidth/latency bound, not exp bound.
 // grid params (device): gp[0] = g0 (first grid point), gp[1] = h (spacing), gp[2] = 1/h
 // ---------------------------------------------------------------------------------------------
@@ -1389,41 +1389,6 @@ __global__ void ski_grid_finish_kernel(const float *__restrict__ part, int npart
   gp[1] = h;
   gp[2] = 1.0f / h;
   gp[3] = 0.f;
-}
-
-// hist[j][m][T] += sum_i w_k(z_ij) V[i][t]   for m = idx0+k.  LDS-privatised per workgroup, then global float atomics.
-template <int TT>
-__global__ __launch_bounds__(256) void ski_scatter2_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
-                                                           const float *__restrict__ V, float *__restrict__ hist,
-                                                           long long N, int ldz, int J, int G, int T, int HT, int hoff,
-                                                           int t0, int tcnt, long long pts_per_block) {
-  extern __shared__ float sh[];   // G * TT
-  const float g0 = gp[0], inv_h = gp[2];
-  const long long n0 = (long long)blockIdx.x * pts_per_block;
-  const long long n1 = (n0 + pts_per_block < N) ? n0 + pts_per_block : N;
-  for (int j = 0; j < J; ++j) {
-    for (int e = threadIdx.x; e < G * TT; e += 256) sh[e] = 0.f;
-    __syncthreads();
-    for (long long i = n0 + threadIdx.x; i < n1; i += 256) {
-      float w[4], dw[4];
-      const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
-      float v[TT];
-#pragma unroll
-      for (int t = 0; t < TT; ++t) v[t] = t < tcnt ? V[i * T + t0 + t] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int t = 0; t < TT; ++t)
-          if (t < tcnt) atomicAdd(&sh[(idx0 + k) * TT + t], w[k] * v[t]);
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < G * TT; e += 256) {
-      const int m = e / TT, t = e % TT;
-      const float val = sh[e];
-      if (t < tcnt && val != 0.f) atomicAdd(&hist[((size_t)j * G + m) * HT + hoff + t0 + t], val);
-    }
-    __syncthreads();
-  }
 }
 
 // Scatter for T <= 12, parallel over projections AND point chunks: workgroup (chunk, j) accumulates its chunk's

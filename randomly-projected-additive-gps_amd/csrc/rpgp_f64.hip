@@ -53,7 +53,9 @@ template <int JT, int TT>
 __global__ __launch_bounds__(256) void mvm_f64_kernel(const double *__restrict__ Z1, const double *__restrict__ Z2,
                                                       const double *__restrict__ V, double *__restrict__ out, int M,
                                                       int N, int ldz1, int ldz2, int T, int j0, int t0, int tcnt,
-                                                      double scale, double noise, int accumulate) {
+                                                      double scale, int cols_per_split) {
+  // out must be initialised (noise * V or the running sum): every (row block, column split) workgroup ADDS its part
+  // atomically.  The column split is what fills the chip: a row-only grid is N / 256 workgroups (29 at N = 7k).
   __shared__ double sB[64 * JT];
   __shared__ double sV[64 * TT];
   const int row = blockIdx.x * 256 + threadIdx.x;
@@ -63,18 +65,20 @@ __global__ __launch_bounds__(256) void mvm_f64_kernel(const double *__restrict__
   for (int j = 0; j < JT; ++j) a[j] = valid ? Z1[(size_t)row * ldz1 + j0 + j] : 0.0;
 #pragma unroll
   for (int t = 0; t < TT; ++t) acc[t] = 0.0;
-  for (int c0 = 0; c0 < N; c0 += 64) {
+  const int cbeg = blockIdx.y * cols_per_split;
+  const int cend = (cbeg + cols_per_split < N) ? cbeg + cols_per_split : N;
+  for (int c0 = cbeg; c0 < cend; c0 += 64) {
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * JT; e += 256) {
       const int c = e / JT, j = e % JT;
-      sB[e] = (c0 + c < N) ? Z2[(size_t)(c0 + c) * ldz2 + j0 + j] : 0.0;
+      sB[e] = (c0 + c < cend) ? Z2[(size_t)(c0 + c) * ldz2 + j0 + j] : 0.0;
     }
     for (int e = threadIdx.x; e < 64 * TT; e += 256) {
       const int c = e / TT, t = e % TT;
-      sV[e] = (c0 + c < N && t < tcnt) ? V[(size_t)(c0 + c) * T + t0 + t] : 0.0;
+      sV[e] = (c0 + c < cend && t < tcnt) ? V[(size_t)(c0 + c) * T + t0 + t] : 0.0;
     }
     __syncthreads();
-    const int nc = (N - c0 < 64) ? N - c0 : 64;
+    const int nc = (cend - c0 < 64) ? cend - c0 : 64;
     for (int c = 0; c < nc; ++c) {
       double ks = 0.0;
 #pragma unroll
@@ -90,14 +94,17 @@ __global__ __launch_bounds__(256) void mvm_f64_kernel(const double *__restrict__
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       if (t < tcnt) {
-        const size_t o = (size_t)row * T + t0 + t;
-        double r = scale * acc[t];
-        if (accumulate) r += out[o];
-        else if (noise != 0.0) r = fma(noise, V[o], r);
-        out[o] = r;
+        atomicAdd(out + (size_t)row * T + t0 + t, scale * acc[t]);
       }
     }
   }
+}
+
+// out = noise * V  (noise may be 0): the base value the split MVM workgroups add to
+__global__ __launch_bounds__(256) void mvm_init_f64_kernel(const double *__restrict__ V, double *__restrict__ out,
+                                                           long long total, double noise) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) out[i] = noise != 0.0 ? noise * V[i] : 0.0;
 }
 
 template <int JT>
@@ -136,7 +143,8 @@ __global__ __launch_bounds__(256) void bilinear_f64_kernel(const double *__restr
                                                            const double *__restrict__ Rm, const double *__restrict__ S,
                                                            double *__restrict__ gZ, double *__restrict__ rowS, int N,
                                                            int ldz, int ldg, long long lds_, int T, int j0, int t0,
-                                                           int tcnt, double scale, int first_piece, int first_t) {
+                                                           int tcnt, double scale, int cols_per_split) {
+  // gZ[:, j0 : j0 + JT) and rowS are zero-initialised by the host; (row block, column split) workgroups add atomically
   __shared__ double sC[64 * (JT + 2 * TT)];
   constexpr int STR = JT + 2 * TT;
   const int row = blockIdx.x * 256 + threadIdx.x;
@@ -153,13 +161,15 @@ __global__ __launch_bounds__(256) void bilinear_f64_kernel(const double *__restr
     li[t] = (!DENSE && valid && t < tcnt) ? L[(size_t)row * T + t0 + t] : 0.0;
     ri[t] = (!DENSE && valid && t < tcnt) ? Rm[(size_t)row * T + t0 + t] : 0.0;
   }
-  for (int c0 = 0; c0 < N; c0 += 64) {
+  const int cbeg = blockIdx.y * cols_per_split;
+  const int cend = (cbeg + cols_per_split < N) ? cbeg + cols_per_split : N;
+  for (int c0 = cbeg; c0 < cend; c0 += 64) {
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * STR; e += 256) {
       const int c = e / STR, q = e % STR;
       const int col = c0 + c;
       double val = 0.0;
-      if (col < N) {
+      if (col < cend) {
         if (q < JT) val = Z[(size_t)col * ldz + j0 + q];
         else if (!DENSE && q < JT + TT) { const int t = q - JT; val = t < tcnt ? L[(size_t)col * T + t0 + t] : 0.0; }
         else if (!DENSE) { const int t = q - JT - TT; val = t < tcnt ? Rm[(size_t)col * T + t0 + t] : 0.0; }
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256) void bilinear_f64_kernel(const double *__restr
       sC[e] = val;
     }
     __syncthreads();
-    const int nc = (N - c0 < 64) ? N - c0 : 64;
+    const int nc = (cend - c0 < 64) ? cend - c0 : 64;
     for (int c = 0; c < nc; ++c) {
       const double *p = sC + c * STR;
       double Sv = 0.0;
@@ -193,11 +203,8 @@ __global__ __launch_bounds__(256) void bilinear_f64_kernel(const double *__restr
   }
   if (valid) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      double *dst = gZ + (size_t)row * ldg + j0 + j;
-      *dst = first_t ? -scale * accG[j] : *dst - scale * accG[j];
-    }
-    rowS[row] = (first_piece && first_t) ? accS : rowS[row] + accS;
+    for (int j = 0; j < JT; ++j) atomicAdd(gZ + (size_t)row * ldg + j0 + j, -scale * accG[j]);
+    atomicAdd(rowS + row, accS);
   }
 }
 
@@ -215,24 +222,43 @@ __global__ __launch_bounds__(1024) void sum_f64_kernel(const double *__restrict_
   if (threadIdx.x == 0) out[0] = sh[0] * mul;
 }
 
+inline int mvm64_splits(int M, int N) {
+  const int nrb = (M + 255) / 256;
+  int ns = (1024 + nrb - 1) / nrb;
+  const int maxs = (N + 63) / 64;
+  if (ns > maxs) ns = maxs;
+  return ns < 1 ? 1 : ns;
+}
+
 template <int JT>
 int launch_mvm64(int tt, const double *Z1, const double *Z2, const double *V, double *out, int M, int N, int ldz1,
-                 int ldz2, int T, int j0, int t0, int tcnt, double scale, double noise, int accumulate, hipStream_t st) {
-  dim3 grid((M + 255) / 256), block(256);
+                 int ldz2, int T, int j0, int t0, int tcnt, double scale, hipStream_t st) {
+  const int ns = mvm64_splits(M, N);
+  int cps = (N + ns - 1) / ns;
+  cps = (cps + 63) / 64 * 64;
+  dim3 grid((M + 255) / 256, (N + cps - 1) / cps), block(256);
   if (tt == 1)
-    hipLaunchKernelGGL((mvm_f64_kernel<JT, 1>), grid, block, 0, st, Z1, Z2, V, out, M, N, ldz1, ldz2, T, j0, t0, tcnt, scale, noise, accumulate);
+    hipLaunchKernelGGL((mvm_f64_kernel<JT, 1>), grid, block, 0, st, Z1, Z2, V, out, M, N, ldz1, ldz2, T, j0, t0, tcnt, scale, cps);
+  else if (tt == 4)
+    hipLaunchKernelGGL((mvm_f64_kernel<JT, 4>), grid, block, 0, st, Z1, Z2, V, out, M, N, ldz1, ldz2, T, j0, t0, tcnt, scale, cps);
   else
-    hipLaunchKernelGGL((mvm_f64_kernel<JT, 4>), grid, block, 0, st, Z1, Z2, V, out, M, N, ldz1, ldz2, T, j0, t0, tcnt, scale, noise, accumulate);
+    hipLaunchKernelGGL((mvm_f64_kernel<JT, 12>), grid, block, 0, st, Z1, Z2, V, out, M, N, ldz1, ldz2, T, j0, t0, tcnt, scale, cps);
   return F64_CHECK_LAUNCH();
 }
 
 template <int JT, bool DENSE>
-int launch_bil64(const double *Z, const double *L, const double *R, const double *S, double *gZ, double *rowS, int N,
-                 int ldz, int ldg, long long lds_, int T, int j0, int t0, int tcnt, double scale, int first_piece,
-                 int first_t, hipStream_t st) {
-  dim3 grid((N + 255) / 256), block(256);
-  hipLaunchKernelGGL((bilinear_f64_kernel<JT, 4, DENSE>), grid, block, 0, st, Z, L, R, S, gZ, rowS, N, ldz, ldg, lds_, T,
-                     j0, t0, tcnt, scale, first_piece, first_t);
+int launch_bil64(int tt, const double *Z, const double *L, const double *R, const double *S, double *gZ, double *rowS,
+                 int N, int ldz, int ldg, long long lds_, int T, int j0, int t0, int tcnt, double scale, hipStream_t st) {
+  const int ns = mvm64_splits(N, N);
+  int cps = (N + ns - 1) / ns;
+  cps = (cps + 63) / 64 * 64;
+  dim3 grid((N + 255) / 256, (N + cps - 1) / cps), block(256);
+  if (DENSE || tt <= 4)
+    hipLaunchKernelGGL((bilinear_f64_kernel<JT, 4, DENSE>), grid, block, 0, st, Z, L, R, S, gZ, rowS, N, ldz, ldg, lds_, T,
+                       j0, t0, tcnt, scale, cps);
+  else
+    hipLaunchKernelGGL((bilinear_f64_kernel<JT, 12, DENSE>), grid, block, 0, st, Z, L, R, S, gZ, rowS, N, ldz, ldg, lds_,
+                       T, j0, t0, tcnt, scale, cps);
   return F64_CHECK_LAUNCH();
 }
 
@@ -259,21 +285,23 @@ int bilinear64_common(const double *Z, const double *L, const double *R, const d
                       int64_t N, int ldz, int ldg, int64_t lds_, int T, int j0, int j1, double scale, double *rowS,
                       double gmul, void *stream) {
   hipStream_t st = as_stream64(stream);
-  int first_piece = 1;
+  if (hipMemsetAsync(rowS, 0, (size_t)N * sizeof(double), st) != hipSuccess) return (int)hipGetLastError();
+  if (hipMemset2DAsync(gZ + j0, (size_t)ldg * sizeof(double), 0, (size_t)(j1 - j0) * sizeof(double), (size_t)N, st) !=
+      hipSuccess)
+    return (int)hipGetLastError();
   for (int j = j0; j < j1;) {
     const int jt = next_piece64(j1 - j);
     const int nT = DENSE ? 1 : T;
-    int first_t = 1;
-    for (int t0 = 0; t0 < nT; t0 += 4) {
-      const int tcnt = DENSE ? 0 : ((T - t0 < 4) ? T - t0 : 4);
+    for (int t0 = 0; t0 < nT;) {
+      const int tt = DENSE ? 4 : ((T - t0 > 4) ? 12 : 4);
+      const int tcnt = DENSE ? 0 : ((T - t0 < tt) ? T - t0 : tt);
       int rc;
-#define CALL_BIL(JTV) launch_bil64<JTV, DENSE>(Z, L, R, S, gZ, rowS, (int)N, ldz, ldg, lds_, T, j, t0, tcnt, scale, first_piece, first_t, st)
+#define CALL_BIL(JTV) launch_bil64<JTV, DENSE>(tt, Z, L, R, S, gZ, rowS, (int)N, ldz, ldg, lds_, T, j, t0, tcnt, scale, st)
       DISPATCH_JT(jt, CALL_BIL)
 #undef CALL_BIL
       if (rc) return rc;
-      first_t = 0;
+      t0 += DENSE ? 1 : tcnt;
     }
-    first_piece = 0;
     j += jt;
   }
   hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(1024), 0, st, rowS, gscale, (int)N, gmul);
@@ -305,20 +333,20 @@ int rpgp_mvm_f64(const double *Z1, const double *Z2, const double *V, double *ou
       M > 0x7fffffffLL || N > 0x7fffffffLL || (noise != 0.0 && M != N))
     return RPGP_EINVAL;
   hipStream_t st = as_stream64(stream);
-  int first = 1;
+  const long long total = (long long)M * T;
+  hipLaunchKernelGGL(mvm_init_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, V, out, total, noise);
   for (int j = j0; j < j1;) {
     const int jt = next_piece64(j1 - j);
     for (int t0 = 0; t0 < T;) {
-      const int tt = (T - t0 > 1) ? 4 : 1;
+      const int tt = (T - t0 > 4) ? 12 : ((T - t0 > 1) ? 4 : 1);
       const int tcnt = (T - t0 < tt) ? T - t0 : tt;
       int rc;
-#define CALL_MVM(JTV) launch_mvm64<JTV>(tt, Z1, Z2, V, out, (int)M, (int)N, ldz1, ldz2, T, j, t0, tcnt, scale, noise, first ? 0 : 1, st)
+#define CALL_MVM(JTV) launch_mvm64<JTV>(tt, Z1, Z2, V, out, (int)M, (int)N, ldz1, ldz2, T, j, t0, tcnt, scale, st)
       DISPATCH_JT(jt, CALL_MVM)
 #undef CALL_MVM
       if (rc) return rc;
       t0 += tcnt;
     }
-    first = 0;
     j += jt;
   }
   return 0;

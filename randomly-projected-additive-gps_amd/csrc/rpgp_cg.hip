@@ -519,7 +519,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, Cinv, part_w, nb, r, z, part_rz, N, T, K,
                        precond_sigma2);
     const bool hist_pending = it < n_hist - 1;
-    const bool check_now = it >= min_it && !hist_pending && ((it - min_it) % check_every == 0 || it == n_iter - 1);
+    const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
     hipLaunchKernelGGL(k_direction, dim3(nb), dim3(256), 0, st, z, p, part_rz, part_rr, nb, state,
                        beta_d + (size_t)slot * kMaxT, N, T, eps, it & 1, check_now ? 1 : 0, tolerance, it + 1,
                        stagnation_window);

@@ -115,3 +115,29 @@ def test_native_cg_stops_on_stagnation(gpu_device):
         lcg.linear_cg(khat._matmul, rhs, tolerance=1e-6, max_iter=100000, operator=khat)
     assert lcg.stats["last_iterations"] < 2500          # n_iter = min(max_iter, N) = 3000 without the rule
     assert any("CG terminated" in str(x.message) for x in w)
+
+
+@pytest.mark.parametrize("tol,max_iter,check_every,nt", [(1e-2, 500, 1, 0), (1e-3, 500, 3, 0), (1e-30, 7, 1, 0),
+                                                         (1e-30, 1, 1, 0), (0.5, 500, 1, 0), (1e-2, 500, 1, 4),
+                                                         (1e-30, 25, 1, 4), (1e-3, 12, 5, 0)])
+def test_native_stopping_rule_edge_cases(gpu_device, tol, max_iter, check_every, nt):
+    """The device-side convergence flag + lagged host polling must reproduce the torch loop's stopping rule exactly:
+    same iteration count (>= 10 iterations, after the Lanczos window, every `check_every`-th test, max_iter caps) and
+    the same iterate, including when convergence is detected on the last allowed iteration."""
+    from rpgp_amd import linear_cg as lcg
+    base, khat = _ops_pair(gpu_device, 2048, 20, 0.5, seed=3)
+    rhs = torch.randn(2048, 5, generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    kw = dict(n_tridiag=nt, tolerance=tol, max_iter=max_iter, max_tridiag_iter=20, check_every=check_every)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out_n = lcg.linear_cg(khat._matmul, rhs, operator=khat, **kw)
+        it_n = lcg.stats["last_iterations"]
+        out_t = lcg.linear_cg(khat._matmul, rhs, **kw)
+        it_t = lcg.stats["last_iterations"]
+    xn, xt = (out_n[0], out_t[0]) if nt else (out_n, out_t)
+    # the two loops round differently, so a residual sitting on the tolerance may be accepted one test apart
+    assert abs(it_n - it_t) <= check_every and (it_n - it_t) % check_every == 0 or it_n == it_t, (it_n, it_t)
+    assert float((xn - xt).norm() / xt.norm()) < 2e-3
+    if nt:
+        assert out_n[1].shape == out_t[1].shape

@@ -172,11 +172,14 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
  * training_routines.py:157-158 used by model_specs/additive_spread_prescale_Jd_ski.json):
  *   K ~= scale * sum_j W_j Tm W_j^T,   W_j = cubic-convolution (Keys) interpolation weights of projection j onto ONE
  *   shared regular grid of G points,  Tm[m,m'] = exp(-0.5 ((m-m') h)^2)  (symmetric Toeplitz).
- * rpgp_ski_grid       : grid_params (device, 4 floats: g0, h, 1/h, 0) from the min/max of Z1 (and Z2 if given) so that all
- *                       points lie in [g_2, g_{G-3}]  (h = range / (G-5)).
+ * rpgp_ski_grid       : grid_params (device: g0, h, 1/h, has_weights = 0) from the min/max of Z1 (and Z2 if given) so that
+ *                       all points lie in [g_2, g_{G-3}]  (h = range / (G-5)).  The block may be 4 + J floats long: a caller
+ *                       that sets has_weights = 1 and appends w_0 .. w_{J-1} gets K ~= scale * sum_j w_j W_j Tm W_j^T
+ *                       from every SKI entry point (the `weighted` components of polynomial_projection_kernels.py:88-98).
  * rpgp_ski_mvm        : out = scale * sum_j W1_j Tm W2_j^T V (+ noise V when Z1 == Z2)    (out: M x T, V: N x T).
- *                       scatter (LDS-privatised histogram + float atomics: sums are order-dependent in the last bits),
- *                       Toeplitz matvec, gather.  HBM traffic ~ 4 (N (J + T) + M (J + T)) bytes.
+ *                       scatter (per-(chunk, projection) fixed-point LDS histograms + slabs for T <= 12: bitwise
+ *                       reproducible; float atomics for wider blocks), Toeplitz product (MFMA), gather.
+ *                       HBM traffic ~ 4 (N (J + T) + M (J + T)) bytes.
  * rpgp_ski_diag       : diag[i] = scale * sum_j w_i^T Tm[4x4] w_i.
  * rpgp_ski_bilinear_grad : d/dZ and d/dscale of sum((L R^T) * K) for the square operator (T <= 12); `row_scratch`
  *                       is N floats of device scratch.
@@ -196,6 +199,13 @@ int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t
 int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
                            float *gscale, int64_t N, int ldz, int ldg, int J, int G, int T, float scale,
                            void *workspace, size_t workspace_bytes, float *row_scratch, void *stream);
+/* Same with per-projection output scales in the grid parameter block (see rpgp_ski_grid): additionally gcomp[j] (DEVICE,
+ * J floats) = the part of gscale contributed by projection j (it carries w_j; divide by w_j for the unweighted component
+ * sum); row_scratch: N * (J + 1) floats. */
+int rpgp_ski_bilinear_grad_comp(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
+                                float *gscale, float *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
+                                float scale, void *workspace, size_t workspace_bytes, float *row_scratch,
+                                void *stream);
 
 /*
  * Generalised additive family — the other members behind the same operator:

@@ -45,18 +45,21 @@ def toeplitz(h, G):
     return np.exp(-0.5 * d * d)
 
 
-def dense_kernel(Z1, Z2, scale, G=1024, grid=None):
+def dense_kernel(Z1, Z2, scale, G=1024, grid=None, weights=None):
+    """scale * sum_j w_j W_j(Z1) Tm W_j(Z2)^T; `weights` = per-projection output scales (the `weighted` components of
+    polynomial_projection_kernels.py:88-98), default all one."""
     Z1 = np.asarray(Z1, dtype=np.float64)
     Z2 = np.asarray(Z2, dtype=np.float64)
     g0, h = grid if grid is not None else grid_params(Z1, None if Z2 is Z1 else Z2, G)
     Tm = toeplitz(h, G)
     K = np.zeros((Z1.shape[0], Z2.shape[0]))
+    w = np.ones(Z1.shape[1]) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)
     for j in range(Z1.shape[1]):
-        K += interp_matrix(Z1[:, j], g0, h, G) @ Tm @ interp_matrix(Z2[:, j], g0, h, G).T
+        K += w[j] * (interp_matrix(Z1[:, j], g0, h, G) @ Tm @ interp_matrix(Z2[:, j], g0, h, G).T)
     return scale * K
 
 
-def bilinear_objective(Z, L, R, scale, G, grid):
+def bilinear_objective(Z, L, R, scale, G, grid, weights=None):
     """sum((L R^T) * K_ski(Z, Z)) with a FIXED grid (the grid is a buffer, not differentiated)."""
-    K = dense_kernel(Z, Z, scale, G, grid)
+    K = dense_kernel(Z, Z, scale, G, grid, weights)
     return float((np.asarray(L, dtype=np.float64) @ np.asarray(R, dtype=np.float64).T * K).sum())

@@ -63,6 +63,8 @@ SIGNATURES = {
     "rpgp_family_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "rpgp_family_bilinear_grad_dense": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _f32, _vp, _sz, _vp]),
     "rpgp_family_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _f32, _vp]),
+    "rpgp_ski_bilinear_grad_comp": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp,
+                                           _sz, _vp, _vp]),
     "rpgp_mbcg_workspace_bytes": (_sz, [_vp, _int, _int]),
     "rpgp_mbcg_solve": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _f32, _int, _vp, _vp, _f32, _vp, _vp, _vp,
                                _vp, _vp, _sz, _vp]),

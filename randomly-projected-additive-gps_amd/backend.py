@@ -25,6 +25,7 @@ class HipBackend:
     ski_diag = staticmethod(ops.ski_diag)
     ski_pivoted_cholesky = staticmethod(ops.ski_pivoted_cholesky)
     ski_bilinear_grad = staticmethod(ops.ski_bilinear_grad)
+    ski_bilinear_grad_comp = staticmethod(ops.ski_bilinear_grad_comp)
     make_family = staticmethod(ops.Family)
     family_mvm_sym = staticmethod(ops.family_mvm_sym)
     family_mvm_rect = staticmethod(ops.family_mvm_rect)

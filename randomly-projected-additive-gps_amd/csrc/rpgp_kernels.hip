@@ -1324,6 +1324,11 @@ __device__ __forceinline__ float cubic_dw(float U) {     // d/dU of the above
 }
 
 // taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
+// Per-projection output scales (the `weighted` components of polynomial_projection_kernels.py:88-98 under SKI): the grid
+// parameter block is [g0, h, 1/h, has_weights, w_0 .. w_{J-1}]; rpgp_ski_grid writes has_weights = 0 and the host may then
+// set it to 1 and append the weights.  K = scale * sum_j w_j W_j Tm W_j^T: the weight rides on the Toeplitz stage.
+__device__ __forceinline__ float ski_wj(const float *__restrict__ gp, int j) { return gp[3] != 0.f ? gp[4 + j] : 1.0f; }
+
 template <bool DERIV>
 __device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, float (&w)[4], float (&dw)[4]) {
   float u = (z - g0) * inv_h;
@@ -1507,7 +1512,7 @@ __global__ __launch_bounds__(256) void ski_toeplitz_kernel(const float *__restri
       const int k = m > mp ? m - mp : mp - m;
       acc = __builtin_fmaf(sc[k], hj[(size_t)mp * T], acc);
     }
-    H[((size_t)j * G + m) * T + t] = acc;
+    H[((size_t)j * G + m) * T + t] = acc * ski_wj(gp, j);
   }
 }
 
@@ -1558,11 +1563,12 @@ __global__ __launch_bounds__(256) void ski_toeplitz_mfma_kernel(const float *__r
     for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc4[u], 0, 0, 0);
   }
   floatx4m acc = acc4[0] + acc4[1] + acc4[2] + acc4[3];
+  const float wj = ski_wj(gp, j);
   if (nb < T) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + 4 * q + r;
-      if (m < G) H[((size_t)j * G + m) * T + nb] = acc[r];
+      if (m < G) H[((size_t)j * G + m) * T + nb] = acc[r] * wj;
     }
   }
 }
@@ -1648,7 +1654,7 @@ __global__ __launch_bounds__(256) void ski_toeplitz_wide_kernel(const float *__r
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    if (m0 + r < G) H[((size_t)j * G + m0 + r) * T + t] = acc[r];
+    if (m0 + r < G) H[((size_t)j * G + m0 + r) * T + t] = acc[r] * ski_wj(gp, j);
 }
 
 __global__ __launch_bounds__(256) void ski_gather_wide_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
@@ -1684,7 +1690,7 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
                                                               const float *__restrict__ H, const float *__restrict__ L,
                                                               const float *__restrict__ Rm, float *__restrict__ gZ,
                                                               float *__restrict__ rowS, long long N, int ldz, int ldg,
-                                                              int J, int G, int T, float scale) {
+                                                              int J, int G, int T, float scale, float *__restrict__ rowC) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   const float g0 = gp[0], inv_h = gp[2];
@@ -1699,7 +1705,7 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
   for (int j = 0; j < J; ++j) {
     float w[4], dw[4];
     const int idx0 = ski_taps<true>(Z[i * ldz + j], g0, inv_h, G, w, dw);
-    float gz = 0.f;
+    float gz = 0.f, accj = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float *hp = H + ((size_t)j * G + idx0 + k) * T2;   // [H_L (T) | H_R (T)]
@@ -1711,9 +1717,11 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
           b = __builtin_fmaf(ri[t], hp[t], b);          // R . H_L
         }
       gz = __builtin_fmaf(dw[k], a + b, gz);
-      accS = __builtin_fmaf(w[k], a, accS);
+      accj = __builtin_fmaf(w[k], a, accj);
     }
     gZ[i * ldg + j] = scale * gz;
+    accS += accj;
+    if (rowC) rowC[i * J + j] = accj;      // per-projection part (H already carries the projection's weight)
   }
   rowS[i] = accS;
 }
@@ -1732,10 +1740,12 @@ __global__ __launch_bounds__(256) void ski_diag_kernel(const float *__restrict__
   for (int j = 0; j < J; ++j) {
     float w[4], dw[4];
     ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+    float aj = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = __builtin_fmaf(w[k] * w[kk], c[k > kk ? k - kk : kk - k], acc);
+      for (int kk = 0; kk < 4; ++kk) aj = __builtin_fmaf(w[k] * w[kk], c[k > kk ? k - kk : kk - k], aj);
+    acc = __builtin_fmaf(ski_wj(gp, j), aj, acc);
   }
   diag[i] = scale * acc;
 }
@@ -1960,10 +1970,12 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
             const float dd = (float)(delta + u - 3) * hs;
             tl[u] = fast_exp2(-(dd * dd));
           }
+          float aj = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) acc = __builtin_fmaf(w[q] * spw[j][qq], tl[q - qq + 3], acc);
+            for (int qq = 0; qq < 4; ++qq) aj = __builtin_fmaf(w[q] * spw[j][qq], tl[q - qq + 3], aj);
+          acc = __builtin_fmaf(ski_wj(gp, j), aj, acc);
         }
         row = scale * acc;
       } else {
@@ -3103,9 +3115,11 @@ int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t
   return launch_status();
 }
 
-int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
-                           float *gscale, int64_t N, int ldz, int ldg, int J, int G, int T, float scale,
-                           void *workspace, size_t workspace_bytes, float *row_scratch, void *stream) {
+// gcomp == nullptr: plain form.  Otherwise gcomp[j] (J floats) = sum_i of the per-projection parts of gscale (they
+// carry the projection's weight: divide by w_j for the unweighted component sums) and row_scratch holds N * (J + 1) floats.
+static int ski_bilinear_common(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
+                               float *gscale, float *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
+                               float scale, void *workspace, size_t workspace_bytes, float *row_scratch, void *stream) {
   if (!Z || !grid_params || !L || !R || !gZ || !gscale || !row_scratch || N <= 0 || J <= 0 || G < 8 || T <= 0 ||
       T > 12 || ldz < J || ldg < J)
     return RPGP_EINVAL;
@@ -3125,16 +3139,34 @@ int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float
   int rc = ski_toeplitz(hist, grid_params, H, J, G, T2, st);
   if (rc) return rc;
   const unsigned nb = (unsigned)((N + 255) / 256);
+  float *rowC = gcomp ? row_scratch + N : nullptr;
   if (T <= 1)
-    hipLaunchKernelGGL((ski_grad_gather_kernel<1>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale);
+    hipLaunchKernelGGL((ski_grad_gather_kernel<1>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale, rowC);
   else if (T <= 4)
-    hipLaunchKernelGGL((ski_grad_gather_kernel<4>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale);
+    hipLaunchKernelGGL((ski_grad_gather_kernel<4>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale, rowC);
   else
-    hipLaunchKernelGGL((ski_grad_gather_kernel<12>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale);
+    hipLaunchKernelGGL((ski_grad_gather_kernel<12>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale, rowC);
   rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, st, row_scratch, gscale, (int)N, 1.0f);
+  if (gcomp) hipLaunchKernelGGL(sum_columns_kernel, dim3(J), dim3(1024), 0, st, rowC, gcomp, (int)N, J, 1.0f);
   return launch_status();
+}
+
+int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
+                           float *gscale, int64_t N, int ldz, int ldg, int J, int G, int T, float scale,
+                           void *workspace, size_t workspace_bytes, float *row_scratch, void *stream) {
+  return ski_bilinear_common(Z, grid_params, L, R, gZ, gscale, nullptr, N, ldz, ldg, J, G, T, scale, workspace,
+                             workspace_bytes, row_scratch, stream);
+}
+
+int rpgp_ski_bilinear_grad_comp(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
+                                float *gscale, float *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
+                                float scale, void *workspace, size_t workspace_bytes, float *row_scratch,
+                                void *stream) {
+  if (!gcomp) return RPGP_EINVAL;
+  return ski_bilinear_common(Z, grid_params, L, R, gZ, gscale, gcomp, N, ldz, ldg, J, G, T, scale, workspace,
+                             workspace_bytes, row_scratch, stream);
 }
 
 }  // extern "C"

@@ -200,9 +200,13 @@ class GeneralizedProjectionKernel(Kernel):
     def __init__(self, component_degrees, d, kernel_type, projection_module, learn_proj=False, weighted=False,
                  ski=False, ski_options=None, X=None, **kernel_kwargs):
         super().__init__()
-        if ski:
-            raise NotImplementedError("grid interpolation is built for the additive_rp kernel only")
         degrees = list(component_degrees)
+        if ski and (kernel_type != "RBF" or any(dg != 1 for dg in degrees)):
+            raise NotImplementedError("grid interpolation is built for 1-D RBF sub-kernels only")
+        if ski and dict(ski_options or {}).get("num_dims", 1) != 1:
+            raise ValueError("only 1-D grid interpolation per projection is supported (ski_options.num_dims == 1)")
+        self.ski = bool(ski)
+        self.grid_size = int(dict(ski_options or {}).get("grid_size", 1024))
         if len(set(degrees)) != 1:
             raise NotImplementedError("multiplicative groups of different sizes are not built (general_rp_poly)")
         if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
@@ -251,6 +255,11 @@ class GeneralizedProjectionKernel(Kernel):
         same = x2 is None or x2 is x1 or (x1.shape == x2.shape and x1.data_ptr() == x2.data_ptr())
         z1 = self.project(x1)
         z2 = None if same else self.project(x2)
+        if self.ski:
+            # one shared dynamic grid over the current projections (the reference fixes per-projection bounds from X at
+            # construction, polynomial_projection_kernels.py:52-61); per-component output scales ride in the grid block
+            return SKIAdditiveOperator(z1, z2, outputscale=outputscale, weight=1.0, grid_size=self.grid_size,
+                                       comp_weights=self.outputscales)
         return FamilyAdditiveOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
                                       kind=self.kernel_type, group=self.k)
 

@@ -251,11 +251,18 @@ class SKIAdditiveOperator(AdditiveRPOperator):
     operator so the whole solve stack is unchanged.  The grid is recomputed from the data range at construction
     (once per hyper-parameter step) and is not differentiated (it is a buffer in GPyTorch as well)."""
 
-    def __init__(self, Z1, Z2=None, outputscale=None, weight=1.0, shard=None, grid_size=1024):
+    def __init__(self, Z1, Z2=None, outputscale=None, weight=1.0, shard=None, grid_size=1024, comp_weights=None):
         super().__init__(Z1, Z2, outputscale, weight, shard=None)     # SKI runs replicated (no J-sharding)
         self.grid_size = int(grid_size)
+        # per-projection output scales (weighted rp_poly / strictly_additive kinds with `ski: true`): they ride in the
+        # grid parameter block and every SKI kernel applies them on the Toeplitz stage
+        self.comp_weights = comp_weights
         be = _backend.get_backend()
-        self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size)
+        if comp_weights is None:
+            self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size)
+        else:
+            self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size,
+                                  weights=comp_weights.detach())
 
     def fused_pivoted_cholesky(self, rank):
         be = _backend.get_backend()
@@ -289,13 +296,17 @@ class SKIAdditiveOperator(AdditiveRPOperator):
             return self
         t = SKIAdditiveOperator.__new__(SKIAdditiveOperator)
         AdditiveRPOperator.__init__(t, self.Z2, self.Z1, self.outputscale, self.weight, None)
-        t.grid_size, t.gp = self.grid_size, self.gp
+        t.grid_size, t.gp, t.comp_weights = self.grid_size, self.gp, self.comp_weights
         return t
 
     def _diagonal(self):
         if not self.symmetric:
             raise RuntimeError("diagonal of a rectangular cross-covariance requested")
         return _backend.get_backend().ski_diag(self.Z1.detach(), self.gp, self._scale, self.grid_size)
+
+    def representation(self):
+        base = super().representation()
+        return base if self.comp_weights is None else base + (self.comp_weights,)
 
     def _get_rows(self, idx):
         be = _backend.get_backend()
@@ -319,8 +330,14 @@ class SKIAdditiveOperator(AdditiveRPOperator):
     def _bilinear_derivative(self, left_vecs, right_vecs):
         if not self.symmetric:
             raise NotImplementedError("derivatives are only needed for the train-train kernel")
-        gZ, gs = _backend.get_backend().ski_bilinear_grad(self.Z1.detach(), self.gp, left_vecs.detach(),
-                                                          right_vecs.detach(), self._scale, self.grid_size)
+        be = _backend.get_backend()
+        if self.comp_weights is not None:
+            gZ, gs, gc = be.ski_bilinear_grad_comp(self.Z1.detach(), self.gp, left_vecs.detach(), right_vecs.detach(),
+                                                   self._scale, self.grid_size)
+            w = self.comp_weights.detach().to(gc)
+            return gZ, gs * self.weight, self._scale * gc / w       # d/dZ, d/d outputscale, d/d comp_weights
+        gZ, gs = be.ski_bilinear_grad(self.Z1.detach(), self.gp, left_vecs.detach(), right_vecs.detach(), self._scale,
+                                      self.grid_size)
         return gZ, gs * self.weight
 
     _quad_form_derivative = _bilinear_derivative

@@ -320,12 +320,13 @@ def dense_mvm(Kd, V, noise=0.0):
 
 # ------------------------------------------------------------------------------------------------ SKI path
 
-def ski_grid(Z1, Z2=None, grid_size=1024):
-    """Device tensor [g0, h, 1/h, 0] of the shared 1-D interpolation grid covering Z1 (and Z2)."""
+def ski_grid(Z1, Z2=None, grid_size=1024, weights=None):
+    """Device tensor [g0, h, 1/h, has_weights, (w_0 .. w_{J-1})] of the shared 1-D interpolation grid covering Z1 (and
+    Z2); `weights` (J per-projection output scales) switches every SKI entry point to the weighted sum."""
     lib = _lib.load()
     Z1 = _require(Z1, "Z1", 2)
     N1, J = Z1.shape
-    gp = torch.empty(4, dtype=torch.float32, device=Z1.device)
+    gp = torch.empty(4 if weights is None else 4 + J, dtype=torch.float32, device=Z1.device)
     with torch.cuda.device(Z1.device):
         ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, 1))
         if Z2 is None:
@@ -336,6 +337,12 @@ def ski_grid(Z1, Z2=None, grid_size=1024):
             rc = lib.rpgp_ski_grid(Z1.data_ptr(), N1, J, Z2.data_ptr(), Z2.shape[0], Z2.shape[1], J, grid_size,
                                    gp.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         _lib.check(rc, "rpgp_ski_grid")
+    if weights is not None:
+        w = weights.detach().to(device=Z1.device, dtype=torch.float32).reshape(-1)
+        if w.numel() != J:
+            raise ValueError("weights must have one entry per projection (%d)" % J)
+        gp[3] = 1.0
+        gp[4:] = w
     return gp
 
 
@@ -407,6 +414,34 @@ def ski_bilinear_grad(Z, gp, L, R, scale, grid_size=1024):
             gZ += gZp
             gs += gsp
     return gZ, gs
+
+
+def ski_bilinear_grad_comp(Z, gp, L, R, scale, grid_size=1024):
+    """(gZ, gscale, gcomp [J]) for the weighted SKI operator: gcomp[j] is projection j's part of gscale (it carries w_j)."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    N, J = Z.shape
+    L2, _ = _as_matrix(L, N, "L")
+    R2, _ = _as_matrix(R, N, "R")
+    T = L2.shape[1]
+    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
+    gs = torch.zeros((), dtype=torch.float32, device=Z.device)
+    gc = torch.zeros(J, dtype=torch.float32, device=Z.device)
+    scratch = torch.empty(N * (J + 1), dtype=torch.float32, device=Z.device)
+    gZp, gsp, gcp = torch.empty_like(gZ), torch.empty_like(gs), torch.empty_like(gc)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, min(T, 12)))
+        for t0 in range(0, T, 12):
+            Lc = L2[:, t0:t0 + 12].contiguous()
+            Rc = R2[:, t0:t0 + 12].contiguous()
+            _lib.check(lib.rpgp_ski_bilinear_grad_comp(Z.data_ptr(), gp.data_ptr(), Lc.data_ptr(), Rc.data_ptr(),
+                                                       gZp.data_ptr(), gsp.data_ptr(), gcp.data_ptr(), N, J, J, J,
+                                                       grid_size, Lc.shape[1], float(scale), ws.data_ptr(), ws.numel(),
+                                                       scratch.data_ptr(), _stream()), "rpgp_ski_bilinear_grad_comp")
+            gZ += gZp
+            gs += gsp
+            gc += gcp
+    return gZ, gs, gc
 
 
 # ------------------------------------------------------------------------------------------------ native mBCG

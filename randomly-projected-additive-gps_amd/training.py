@@ -114,6 +114,8 @@ def create_strictly_additive_kernel(d, weighted=False, kernel_type="RBF", init_l
                                     memory_efficient=False, keops=False):
     """training_routines.py:210-225: one sub-kernel per input dimension (GAM)."""
     if kernel_type == "RBF" and memory_efficient:
+        if ski:
+            raise NotImplementedError("the memory-efficient GAM has no grid-interpolation form (use memory_efficient=False)")
         kernel = MemoryEfficientGamKernel(ard_num_dims=d)
         kernel.initialize(lengthscale=_sample_from_range(d, init_lengthscale_range))
         return kernel

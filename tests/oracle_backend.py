@@ -111,18 +111,23 @@ class OracleBackend:
         return _t(g, Z), _t(gc, Z)
 
     # ---- SKI path -------------------------------------------------------------------------------------------
-    def ski_grid(self, Z1, Z2=None, grid_size=1024):
+    def ski_grid(self, Z1, Z2=None, grid_size=1024, weights=None):
         g0, h = sko.grid_params(_np(Z1), None if Z2 is None else _np(Z2), grid_size)
-        return torch.tensor([g0, h, 1.0 / h, 0.0], dtype=Z1.dtype)
+        head = [g0, h, 1.0 / h, 0.0 if weights is None else 1.0]
+        tail = [] if weights is None else [float(x) for x in weights.detach().reshape(-1)]
+        return torch.tensor(head + tail, dtype=Z1.dtype)
 
     def _grid(self, gp):
         g = gp.double()
         return float(g[0]), float(g[1])
 
+    def _w(self, gp):
+        return None if float(gp[3]) == 0.0 else gp[4:].double().numpy()
+
     def ski_mvm(self, Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
         squeeze = V.dim() == 1
         v = _np(V).reshape(Z2.shape[0], -1)
-        K = sko.dense_kernel(_np(Z1), _np(Z2), scale, grid_size, self._grid(gp))
+        K = sko.dense_kernel(_np(Z1), _np(Z2), scale, grid_size, self._grid(gp), self._w(gp))
         out = K @ v
         if noise:
             out = out + noise * v
@@ -130,7 +135,7 @@ class OracleBackend:
         return r.squeeze(1) if squeeze else r
 
     def ski_diag(self, Z, gp, scale, grid_size=1024):
-        return _t(np.diag(sko.dense_kernel(_np(Z), _np(Z), scale, grid_size, self._grid(gp))).copy(), Z)
+        return _t(np.diag(sko.dense_kernel(_np(Z), _np(Z), scale, grid_size, self._grid(gp), self._w(gp))).copy(), Z)
 
     def ski_bilinear_grad(self, Z, gp, L, R, scale, grid_size=1024):
         """Analytic derivative of sum((L R^T) * K_ski) in float64 (same formulas as the HIP kernel, dense)."""
@@ -141,7 +146,10 @@ class OracleBackend:
         Tm = sko.toeplitz(h, G)
         gZ = np.zeros_like(z)
         gs = 0.0
+        wts = self._w(gp)
+        self._last_comp = np.zeros(z.shape[1])
         for j in range(z.shape[1]):
+            wj = 1.0 if wts is None else wts[j]
             u = np.clip((z[:, j] - g0) / h, 1.0, G - 2.0)
             fl = np.floor(u)
             fr = u - fl
@@ -149,12 +157,17 @@ class OracleBackend:
             W = sko.interp_matrix(z[:, j], g0, h, G)
             HR = Tm @ (W.T @ Rd)
             HL = Tm @ (W.T @ Ld)
-            gs += (Ld * (W @ HR)).sum()
+            self._last_comp[j] = wj * (Ld * (W @ HR)).sum()
+            gs += self._last_comp[j]
             s = [fr + 1.0, fr, 1.0 - fr, 2.0 - fr]
             sign = [1.0, 1.0, -1.0, -1.0]
             for k in range(4):
                 U = s[k]
                 d = np.where(U < 1.0, (4.5 * U - 5.0) * U, (-1.5 * U + 5.0) * U - 4.0) * sign[k] / h
                 rows = idx0 + k
-                gZ[:, j] += scale * d * ((Ld * HR[rows]).sum(1) + (Rd * HL[rows]).sum(1))
+                gZ[:, j] += wj * scale * d * ((Ld * HR[rows]).sum(1) + (Rd * HL[rows]).sum(1))
         return _t(gZ, Z), _t(np.array(gs), Z)
+
+    def ski_bilinear_grad_comp(self, Z, gp, L, R, scale, grid_size=1024):
+        gZ, gs = self.ski_bilinear_grad(Z, gp, L, R, scale, grid_size)
+        return gZ, gs, _t(self._last_comp.copy(), Z)

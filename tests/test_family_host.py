@@ -203,3 +203,43 @@ def test_family_predictions_match_dense(oracle_backend):
     cov = Kss - Ks @ np.linalg.solve(K, Ks.T)
     assert np.allclose(out.mean.numpy(), mean, rtol=1e-4, atol=1e-5)
     assert np.allclose(out.covariance.numpy(), cov, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind,model_kwargs", [
+    ("rp_poly", dict(J=5, k=1, weighted=True, kernel_type="RBF")),
+    ("strictly_additive", dict(weighted=False, kernel_type="RBF")),
+])
+def test_weighted_ski_kinds_track_the_exact_kernel(oracle_backend, kind, model_kwargs):
+    """`ski: true` on the weighted kinds (additive_rp_J20_K1_ski.json, additive_deterministic_spec_unweighted_ski.json):
+    with a 1024-point grid the interpolated operator reproduces the exact family operator's MLL and gradients, including
+    the gradient of the per-component output scales (which ride in the SKI grid-parameter block)."""
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    from rpgp_amd.operators import SKIAdditiveOperator
+    X, y = _problem(70, 4, seed=5)
+    grads = {}
+    for ski in (False, True):
+        torch.manual_seed(7)
+        kw = dict(model_kwargs, ski=ski, ski_options={"grid_size": 1024, "num_dims": 1} if ski else None,
+                  init_mixin_range=(0.5, 1.5), init_lengthscale_range=(1.0, 2.0))
+        if kind == "rp_poly":
+            kw["learn_proj"] = False
+        model, lik = create_exact_gp(X, y, kind, noise_prior=True, **kw)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        model.train()
+        out = model(X)
+        assert isinstance(out.covariance, SKIAdditiveOperator) == ski
+        val = mll(out, y)
+        val.backward()
+        base = model.covar_module.base_kernel
+        grads[ski] = (val.item(), base.raw_lengthscales.grad.clone(),
+                      None if base.raw_outputscales.grad is None else base.raw_outputscales.grad.clone(),
+                      model.covar_module.raw_outputscale.grad.clone())
+    (v0, gl0, gw0, gs0), (v1, gl1, gw1, gs1) = grads[False], grads[True]
+    assert abs(v0 - v1) < 2e-4 * max(1.0, abs(v0))
+    assert torch.allclose(gl0, gl1, rtol=3e-2, atol=2e-4)
+    assert torch.allclose(gs0, gs1, rtol=3e-2, atol=2e-4)
+    if model_kwargs["weighted"]:
+        assert torch.allclose(gw0, gw1, rtol=3e-2, atol=2e-4)
+    else:
+        assert gw0 is None and gw1 is None

@@ -106,7 +106,9 @@ def test_cli_additive_spec_through_oracle_backend(tmp_path, oracle_backend):
 
 
 @pytest.mark.parametrize("name", ["GAM_spec.json", "additive_rp_J20_K1.json", "additive_rp_prescale_J1_K20.json",
-                                  "additive_rp_postscale_J20.json", "additive_rp_prescale_J20_matern.json"])
+                                  "additive_rp_postscale_J20.json", "additive_rp_prescale_J20_matern.json",
+                                  "additive_rp_J20_K1_ski.json", "additive_deterministic_spec_unweighted_ski.json",
+                                  "additive_spread_prescale_J20_ski.json", "additive_rp_postscale_J20_ski.json"])
 def test_cli_family_specs_through_oracle_backend(tmp_path, oracle_backend, name):
     """The other family members' spec files run end to end through the same CLI."""
     from rpgp_amd import runner
@@ -117,6 +119,9 @@ def test_cli_family_specs_through_oracle_backend(tmp_path, oracle_backend, name)
         spec["model_kwargs"]["J"] = 5
     if spec["model_kwargs"].get("k") == 20:
         spec["model_kwargs"]["k"] = 2
+    if spec["model_kwargs"].get("ski"):
+        spec["model_kwargs"]["ski_options"]["grid_size"] = 64        # keep the dense float64 test double small
+    spec["train_kwargs"]["verbose"] = False
     sp = tmp_path / "spec.json"
     json.dump(spec, open(sp, "w"))
     df = runner.main(["-m", str(sp), "-d", "synthetic:tiny", "-o", str(tmp_path / "res.csv"), "--no_cv",

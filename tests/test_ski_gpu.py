@@ -156,3 +156,38 @@ def test_ski_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, G):
     Lf = op.fused_pivoted_cholesky(10)
     Lg = pivoted_cholesky(op._diagonal(), op._get_rows, 10)
     assert Lf is not None and torch.allclose(Lf, Lg, rtol=2e-3, atol=3e-4)
+
+
+@pytest.mark.parametrize("N,J,T,G", [(2500, 5, 3, 256), (3000, 20, 11, 1024)])
+def test_weighted_ski_kernels_match_oracle(gpu_device, N, J, T, G):
+    """Per-projection output scales in the grid-parameter block: MVM, diagonal, pivoted Cholesky rows and the bilinear
+    derivative (incl. the per-component parts) against the float64 dense SKI oracle / its analytic derivative."""
+    from rpgp_amd import ops
+    from tests.oracle_backend import OracleBackend
+    rng = np.random.default_rng(N)
+    Z = (rng.standard_normal((N, J)) * 0.9).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    w = rng.uniform(0.2, 1.5, size=J).astype(np.float32)
+    Zt, Vt, wt = (torch.from_numpy(a).to(gpu_device) for a in (Z, V, w))
+    gp = ops.ski_grid(Zt, None, G, weights=wt)
+    grid = (float(gp[0]), float(gp[1]))
+    M = 400
+    Kd = sko.dense_kernel(Z[:M], Z, 0.7, G, grid, w)
+    got = ops.ski_mvm(Zt[:M].contiguous(), Zt, gp, Vt, 0.7, 0.0, G).cpu().numpy()
+    assert np.linalg.norm(got - Kd @ V) / np.linalg.norm(Kd @ V) < 2e-5
+    full = ops.ski_mvm(Zt, Zt, gp, Vt, 0.7, 0.1, G).cpu().numpy()
+    assert np.linalg.norm(full[:M] - (Kd @ V + 0.1 * V[:M])) / np.linalg.norm(Kd @ V) < 2e-5
+    dg = ops.ski_diag(Zt, gp, 0.7, G).cpu().numpy()[:M]
+    assert np.abs(dg - np.diag(Kd[:, :M])).max() < 2e-5
+    # derivative: the CPU test double restates the analytic formulas in float64
+    ob = OracleBackend()
+    L = rng.standard_normal((N, T)).astype(np.float32)
+    R = rng.standard_normal((N, T)).astype(np.float32)
+    sub = slice(0, 1500)                     # dense float64 reference on a subset (its own grid = the same block)
+    Zs, Ls, Rs = (torch.from_numpy(a[sub].copy()) for a in (Z, L, R))
+    gps = torch.cat([gp[:4].cpu(), torch.from_numpy(w)])
+    rZ, rs, rc = ob.ski_bilinear_grad_comp(Zs, gps, Ls, Rs, 0.7, G)
+    gZ, gs, gc = ops.ski_bilinear_grad_comp(Zs.to(gpu_device), gp, Ls.to(gpu_device), Rs.to(gpu_device), 0.7, G)
+    assert float((gZ.cpu() - rZ).norm() / rZ.norm()) < 2e-4
+    assert abs(float(gs) - float(rs)) < 2e-4 * abs(float(rs)) + 1e-3
+    assert float((gc.cpu() - rc).norm() / rc.norm()) < 2e-4

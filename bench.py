@@ -92,7 +92,7 @@ def main():
     def step():
         if world == 1:
             return local(0, J, noise, out)
-        return shard.sharded_mvm(lambda j0, j1: local(j0, j1, 0.0), V, noise)
+        return shard.sharded_mvm(lambda j0, j1, nz: local(j0, j1, nz), V, noise)
 
     for _ in range(args.warmup):
         res = step()

@@ -95,8 +95,8 @@ int rpgp_mvm_sym_prepared(const void *prep, const float *V, float *out, int64_t 
  * few thousand workgroups of equal size).  Each rank therefore evaluates ALL J projections on 1/world of the (i,i')
  * pairs at the full per-term efficiency and produces a partial N x T output (row AND transposed contributions);
  * the partials are summed with one all-reduce — the same message as J-sharding (`MultiDeviceKernel` counterpart,
- * training_routines.py:407-408) without the per-pair overhead of thin J-slices.  Pass noise = 0 and add noise*V after
- * the reduce.  world = 1, rank = 0 is the plain call.  Workspace: rpgp_mvm_sym_range_workspace_bytes.
+ * training_routines.py:407-408) without the per-pair overhead of thin J-slices.  Pass the noise on exactly ONE rank
+ * (its slab reduce adds noise*V for every row) and 0 on the others.  world = 1, rank = 0 is the plain call.  Workspace: rpgp_mvm_sym_range_workspace_bytes.
  */
 size_t rpgp_mvm_sym_range_workspace_bytes(int64_t N, int T, int world, int rank);
 int rpgp_mvm_sym_range(const float *Z, const float *V, float *out, int64_t N, int ldz, int T, int j0, int j1,

@@ -1,6 +1,6 @@
 """Sharding of the additive kernel MVM across ranks.  Two splits of the same work, both ending in
 ONE all-reduce of the N x T partial result per MVM (RCCL over xGMI on MI355X: `torch.distributed` backend "nccl"; gloo
-on CPU in tests); the noise term is added once, after the reduce, so every rank holds the identical result and runs
+on CPU in tests); the noise term is added once (by rank 0's kernel), so every rank holds the identical result and runs
 the identical CG recurrences:
   * mode "j"     — K = sum_j K_j: rank r owns a contiguous slice of the J projections and sweeps the full N x N index
                    space (north_star's split; the only one available to backends without `supports_pair_shard`);
@@ -66,11 +66,9 @@ class JShard:
         return (self.world_size, self.rank)
 
     def sharded_mvm(self, local_mvm, V, noise):
-        """local_mvm(j0, j1) -> partial product of this rank's projections (no noise term).
-        Returns sum over ranks + noise * V, identical on every rank."""
-        # `local_mvm` decides itself what this rank owns (a J-slice, or a row-block range in "pairs" mode)
-        partial = local_mvm(self.j0, self.j1)
+        """local_mvm(j0, j1, noise) -> partial product of what this rank owns (a J-slice, or its share of the tile pairs in
+        "pairs" mode) + noise * V.  The noise term is handed to rank 0's kernel only (fused into its slab reduce), so
+        the single all-reduce yields sum over ranks + noise * V, identical on every rank, with no extra pass over V."""
+        partial = local_mvm(self.j0, self.j1, noise if self.rank == 0 else 0.0)
         all_reduce_sum_(partial, self.group)
-        if noise != 0.0:
-            partial = partial.add_(V, alpha=noise)
         return partial

@@ -136,7 +136,7 @@ class AdditiveRPOperator(LinearOperator):
                     j0, j1 = 0, self.num_projections
                     kw = {"shard": ps}
                 elif j1 <= j0:                      # J-sharding with more ranks than projections: nothing to do here
-                    return torch.zeros_like(rhs)
+                    return torch.zeros_like(rhs) if not noise else rhs * noise
             prepare = getattr(be, "prepare", None)
             if prepare is not None and z1.dtype == torch.float32:
                 if self._prep is None:
@@ -155,7 +155,7 @@ class AdditiveRPOperator(LinearOperator):
             return out
         if noise and not self.symmetric:
             raise ValueError("a diagonal can only be added to the square symmetric operator")
-        return self.shard.sharded_mvm(lambda j0, j1: self._local_matmul(rhs, 0.0), rhs, float(noise))
+        return self.shard.sharded_mvm(lambda j0, j1, nz: self._local_matmul(rhs, nz), rhs, float(noise))
 
     def fused_pivoted_cholesky(self, rank):
         """Single-launch pivoted Cholesky (rpgp_pivoted_cholesky) when the backend has it and the kernel is not sharded;

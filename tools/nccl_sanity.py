@@ -15,6 +15,6 @@ from rpgp_amd.distributed import JShard
 Z = torch.randn(3000, 20, device="cuda"); V = torch.randn(3000, 2, device="cuda")
 sh = JShard(20)
 full = ops.mvm_sym(Z, V, 0.05, 0.1)
-got = sh.sharded_mvm(lambda j0, j1: ops.mvm_sym(Z, V, 0.05, 0.0, shard=(dist.get_world_size(), dist.get_rank())), V, 0.1)
+got = sh.sharded_mvm(lambda j0, j1, nz: ops.mvm_sym(Z, V, 0.05, nz, shard=(dist.get_world_size(), dist.get_rank())), V, 0.1)
 print("world", dist.get_world_size(), "allreduce ok", float(t[0]), "sharded rel diff", float((got - full).norm() / full.norm()))
 dist.barrier(); dist.destroy_process_group()

@@ -47,6 +47,14 @@ const char *rpgp_error_string(int code);
 int rpgp_init(void);
 
 /*
+ * DPA-GP diversification of the projection directions (replaces the gradient loop of rp.space_equally, rp.py:241-266, for
+ * d < J): `niter` plain gradient steps of size `lr` on sum_{a != b} cos^4(angle(P_a, P_b)), then row normalisation, in
+ * ONE single-workgroup launch.  P: J x d row-major DEVICE array, updated in place (J, d <= 64); final_loss (DEVICE, 1
+ * float, may be NULL) receives the energy before the normalisation, as the reference returns it.
+ */
+int rpgp_space_equally(float *P, int J, int d, float lr, int niter, float *final_loss, void *stream);
+
+/*
  * Projection  Z = X @ Peff   (X: N x d, Peff: d x J, Z: N x J).
  * Replaces gp_models/kernels/scaled_projection_kernel.py:21-27 (`x1.div(lengthscale)` + `projection_module(x1)`);
  * the caller folds the ARD lengthscale into Peff (prescale: diag(1/l) P; postscale: P diag(1/l)).

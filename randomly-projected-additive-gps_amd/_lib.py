@@ -28,6 +28,7 @@ SIGNATURES = {
     "rpgp_version": (_int, []),
     "rpgp_error_string": (ctypes.c_char_p, [_int]),
     "rpgp_init": (_int, []),
+    "rpgp_space_equally": (_int, [_vp, _int, _int, _f32, _int, _vp, _vp]),
     "rpgp_project": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "rpgp_project_grad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "rpgp_mvm_sym_workspace_bytes": (_sz, [_i64, _int]),

@@ -2000,6 +2000,70 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// DPA-GP diversification (rp.space_equally, rp.py:241-266) as ONE single-workgroup launch:
+// `niter` plain gradient steps of size lr on  L(P) = sum_{a != b} cos^4(angle(P_a, P_b)),  then row normalisation.
+//   c_ab = P_a.P_b / (n_a n_b);   dL/dP_a = sum_{b != a} 8 c_ab^3 ( P_b / (n_a n_b) - c_ab P_a / n_a^2 )
+// J x d <= 64 x 64 lives in LDS for the whole optimisation (5000 steps ~ 10 ms instead of seconds of autograd steps on
+// the host, which dominated the wall time of a DPA-GP experiment on the GPU box).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void space_equally_kernel(float *__restrict__ P, int J, int d, float lr, int niter,
+                                                            float *__restrict__ final_loss) {
+  __shared__ float sA[64 * 65];
+  __shared__ float sB[64 * 65];      // ping-pong copies of P
+  __shared__ float sC[64 * 65];      // cos_ab (diagonal zeroed)
+  __shared__ float sN[64];
+  __shared__ float sred[256];
+  const int tid = threadIdx.x;
+  float *cur = sA, *nxt = sB;
+  for (int e = tid; e < J * d; e += 256) cur[(e / d) * 65 + e % d] = P[e];
+  __syncthreads();
+  for (int it = 0; it <= niter; ++it) {
+    if (tid < J) {
+      float s2 = 0.f;
+      for (int q = 0; q < d; ++q) s2 = __builtin_fmaf(cur[tid * 65 + q], cur[tid * 65 + q], s2);
+      sN[tid] = sqrtf(s2);
+    }
+    __syncthreads();
+    for (int e = tid; e < J * J; e += 256) {
+      const int a = e / J, b = e % J;
+      float dot = 0.f;
+      for (int q = 0; q < d; ++q) dot = __builtin_fmaf(cur[a * 65 + q], cur[b * 65 + q], dot);
+      sC[a * 65 + b] = a == b ? 0.f : dot / (sN[a] * sN[b]);
+    }
+    __syncthreads();
+    if (it == niter) break;          // the last pass only refreshes norms and cosines for the loss / normalisation
+    for (int e = tid; e < J * d; e += 256) {
+      const int a = e / d, q = e % d;
+      const float na = sN[a], pa = cur[a * 65 + q];
+      float g = 0.f;
+      for (int b = 0; b < J; ++b) {
+        const float c = sC[a * 65 + b];
+        const float c3 = c * c * c;
+        g = __builtin_fmaf(8.0f * c3, cur[b * 65 + q] / (na * sN[b]) - c * pa / (na * na), g);
+      }
+      nxt[a * 65 + q] = pa - lr * g;
+    }
+    __syncthreads();
+    float *tmp = cur;
+    cur = nxt;
+    nxt = tmp;
+  }
+  float part = 0.f;
+  for (int e = tid; e < J * J; e += 256) {
+    const float c = sC[(e / J) * 65 + e % J];
+    part += c * c * c * c;
+  }
+  sred[tid] = part;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) sred[tid] += sred[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0 && final_loss) final_loss[0] = sred[0];
+  for (int e = tid; e < J * d; e += 256) P[e] = cur[(e / d) * 65 + e % d] / sN[e / d];
+}
+
 // ------------------------------- host-side helpers -------------------------------------------
 
 int g_rotdir = 0;  // +1: wave_rotate1 delivers lane l+1's value to lane l; -1: lane l-1's.  0 = not probed.
@@ -2467,6 +2531,12 @@ int rpgp_profile_end(float *avg_ms_host, int *count_host) {
   if (count_host) *count_host = g_prof_n;
   g_prof_n = 0;
   return 0;
+}
+
+int rpgp_space_equally(float *P, int J, int d, float lr, int niter, float *final_loss, void *stream) {
+  if (!P || J <= 0 || d <= 0 || J > 64 || d > 64 || niter < 0) return RPGP_EINVAL;
+  hipLaunchKernelGGL(space_equally_kernel, dim3(1), dim3(256), 0, as_stream(stream), P, J, d, lr, niter, final_loss);
+  return launch_status();
 }
 
 int rpgp_project(const float *X, const float *Peff, float *Z, int64_t N, int d, int J, void *stream) {

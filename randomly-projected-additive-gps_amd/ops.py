@@ -41,6 +41,18 @@ def init():
     _lib.check(lib.rpgp_init(), "rpgp_init")
 
 
+def space_equally(P, lr, niter):
+    """DPA-GP diversification on the device (rpgp_space_equally): returns (P_new [J x d, unit rows], final_loss [1 x 1])."""
+    lib = _lib.load()
+    Q = _require(P.detach().clone(), "P", 2)
+    J, d = Q.shape
+    loss = torch.empty(1, dtype=torch.float32, device=Q.device)
+    with torch.cuda.device(Q.device):
+        _lib.check(lib.rpgp_space_equally(Q.data_ptr(), J, d, float(lr), int(niter), loss.data_ptr(), _stream()),
+                   "rpgp_space_equally")
+    return Q, loss.reshape(1, 1)
+
+
 def project(X, Peff):
     """Z = X @ Peff  (N x d)(d x J) -> N x J."""
     lib = _lib.load()

@@ -58,6 +58,15 @@ def space_equally(P, lr, niter):
         out = torch.from_numpy(np.vstack(rows)).to(P)
         out.requires_grad = False
         return out, None
+    if n <= 64 and d <= 64 and P.dtype == torch.float32 and torch.cuda.is_available():
+        # one single-workgroup launch instead of `niter` autograd steps on the host (seconds per model build, more than
+        # a whole kin8nm-sized fit on the GPU); same recurrence, fp32 summation order differs (~1e-6 on the result)
+        from . import ops
+        dev = P.device if P.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        out, final = ops.space_equally(P.to(dev), lr, niter)
+        out = out.to(P.device)
+        out.requires_grad = False
+        return out, final.to(P.device)
     Q = P.detach().clone().requires_grad_(True)
     for _ in range(niter):
         loss = _cos4_loss(Q)

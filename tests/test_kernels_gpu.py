@@ -288,3 +288,23 @@ def test_edge_shapes(gpu_device):
     for fn in (lambda: ops.mvm_sym(Zdt, torch.from_numpy(Vd).to(gpu_device), 0.2, 0.0),
                lambda: ops.mvm_sym_prepared(ops.Prepared(Zdt), torch.from_numpy(Vd).to(gpu_device), 0.2, 0.0)):
         np.testing.assert_allclose(fn().cpu().numpy().ravel(), np.full(300, 0.2 * 5 * Vd.sum()), rtol=2e-5, atol=2e-4)
+
+
+def test_space_equally_on_device_matches_reference_golden(gpu_device):
+    """rpgp_space_equally (one launch) against the golden outputs captured from the reference's rp.space_equally (5000
+    autograd steps on the host), same tolerance as the CPU restatement's golden test, plus the reference's own
+    properties (test.py:460-491): unit rows, non-trivial final energy."""
+    import os
+    from rpgp_amd import rp, ops
+    s = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "space_equally.npz"))
+    for (J, d, seed) in [(20, 18, 0), (20, 8, 1), (4, 2, 3)]:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        P0 = torch.cat([rp.gen_rp(d, 1, "gaussian") for _ in range(J)], dim=1).t().contiguous()
+        out, loss = ops.space_equally(P0.to(gpu_device), 0.1, 5000)
+        ref = s["J%d_d%d_s%d_out" % (J, d, seed)]
+        np.testing.assert_allclose(out.cpu().numpy(), ref, atol=5e-5)
+        np.testing.assert_allclose(np.linalg.norm(out.cpu().numpy(), axis=1), 1.0, atol=1e-5)
+        assert float(loss) > 1e-3
+        out2, _ = rp.space_equally(P0.clone(), 0.1, 5000)          # the module-level entry takes the device path here
+        assert out2.device.type == "cpu" and np.allclose(out2.numpy(), ref, atol=5e-5)

@@ -332,16 +332,30 @@ class ScaleKernel(Kernel):
 
 
 class RBFKernel(Kernel):
-    """Plain (non-additive) RBF kernel for `kind: full` (training_routines.py:275-293; BASELINE config 1 = CPU
-    plumbing through the runner).  NOT the hot path: dense torch ops, any device."""
+    """Plain (non-additive) stationary kernel for `kind: full` (training_routines.py:275-293; BASELINE config 1 = CPU
+    plumbing through the runner).  NOT the hot path: dense torch ops, any device.  `kernel_type` selects the reference's
+    other full kernels (training_routines.py:47-88): Matern (nu = 1.5), InverseMQ (imq_kernel.py:8-9), Cosine."""
 
     has_lengthscale = True
+
+    def __init__(self, ard_num_dims=None, kernel_type="RBF", **kwargs):
+        super().__init__(ard_num_dims=ard_num_dims, **kwargs)
+        if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+            raise ValueError("Unknown kernel type")
+        self.kernel_type = kernel_type
 
     def dense(self, x1, x2):
         a = x1 / self.lengthscale
         b = x2 / self.lengthscale
         d2 = (a.pow(2).sum(-1, keepdim=True) - 2.0 * a @ b.t() + b.pow(2).sum(-1).unsqueeze(0)).clamp_min(0.0)
-        return torch.exp(-0.5 * d2)
+        if self.kernel_type == "RBF":
+            return torch.exp(-0.5 * d2)
+        if self.kernel_type == "InverseMQ":
+            return (d2 + 1.0).rsqrt()
+        r = (d2 + 1e-30).sqrt()
+        if self.kernel_type == "Matern":
+            return (1.0 + math.sqrt(3.0) * r) * torch.exp(-math.sqrt(3.0) * r)
+        return torch.cos(math.pi * r)
 
     def forward(self, x1, x2, outputscale=None, **params):
         from .dense_ops import DenseKernelOperator

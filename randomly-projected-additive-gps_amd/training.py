@@ -138,13 +138,13 @@ def create_additive_kernel(d, groups, weighted=False, kernel_type="RBF", init_le
 
 def create_full_kernel(d, ard=False, ski=False, grid_size=None, kernel_type="RBF", init_lengthscale_range=(1.0, 1.0),
                        keops=False):
-    """Plain RBF kernel for `kind: full` (training_routines.py:275-293)."""
-    if kernel_type != "RBF":
-        raise NotImplementedError("only the RBF full kernel is provided (runner plumbing, BASELINE config 1)")
+    """Plain stationary kernel for `kind: full` (training_routines.py:275-293): dense torch ops, not the hot path."""
+    if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+        raise ValueError("Unknown kernel type")
     if ski:
-        raise NotImplementedError("SKI is not built (SURVEY.md §8(f))")
+        raise NotImplementedError("d-dimensional grid interpolation is not built (only the 1-D per-projection SKI)")
     ard_num_dims = d if ard else None
-    kernel = RBFKernel(ard_num_dims=ard_num_dims)
+    kernel = RBFKernel(ard_num_dims=ard_num_dims, kernel_type=kernel_type)
     kernel.initialize(lengthscale=_sample_from_range(d if ard else 1, init_lengthscale_range))
     return kernel
 

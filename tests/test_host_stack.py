@@ -407,3 +407,34 @@ def test_linear_cg_gives_up_on_stagnation_instead_of_running_to_max_iter():
         lcg.linear_cg(lambda v: A @ v, b, tolerance=1e-7, max_iter=100000)
     assert lcg.stats["stagnated"] == 1 and lcg.stats["last_iterations"] < 20000
     assert any("CG terminated" in str(x.message) for x in w)
+
+
+@pytest.mark.parametrize("kernel_type", ["RBF", "Matern", "InverseMQ"])
+def test_full_kernel_types_match_dense_formulas(kernel_type):
+    """`kind: full` (ARD_model_spec.json, Inverse_MQ_ARD_model_spec.json; training_routines.py:275-293): the dense torch path
+    with the reference's other full kernels against the float64 formulas of oracle/family.py."""
+    from oracle import family as fmo
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(60, 3, generator=g)
+    y = torch.sin(X).sum(1)
+    torch.manual_seed(0)
+    model, lik = create_exact_gp(X, y, "full", noise_prior=False, kernel_type=kernel_type, ard=True,
+                                 init_lengthscale_range=(0.7, 1.5))
+    mll = ExactMarginalLogLikelihood(lik, model)
+    model.train()
+    val = float(mll(model(X), y).detach())
+    ls = model.covar_module.base_kernel.lengthscale.detach().double().reshape(-1).numpy()
+    s, noise, c = float(model.covar_module.outputscale.detach()), float(lik.noise.detach()), float(model.mean_module.constant.detach())
+    Z = X.double().numpy() / ls
+    K = fmo.kernel_matrix(Z, Z, "RBF", 3, [1.0], s) if kernel_type == "RBF" else None
+    if K is None:
+        d2 = ((Z[:, None, :] - Z[None, :, :]) ** 2).sum(-1)
+        K = s * fmo._phi(kernel_type, d2)
+    K = K + noise * np.eye(60)
+    r = y.double().numpy() - c
+    ref = (-0.5 * r @ np.linalg.solve(K, r) - 0.5 * np.linalg.slogdet(K)[1] - 30 * math.log(2 * math.pi)) / 60
+    assert abs(val - ref) < 1e-4 * max(1.0, abs(ref))
+    with pytest.raises(ValueError):
+        create_exact_gp(X, y, "full", noise_prior=False, kernel_type="bogus")

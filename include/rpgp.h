@@ -204,6 +204,9 @@ int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L
                               int J, int G, int rank, float scale, void *stream);
 int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t N, int ldz, int J, int G,
                   float scale, void *stream);
+/* Dense block K_ski(Z1, Z2) (M x N, row stride ldo) straight from the interpolation weights and the Toeplitz lags (J <= 64). */
+int rpgp_ski_dense(const float *Z1, const float *Z2, const float *grid_params, float *out, int64_t M, int64_t N,
+                   int ldz1, int ldz2, int64_t ldo, int J, int G, float scale, void *stream);
 int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
                            float *gscale, int64_t N, int ldz, int ldg, int J, int G, int T, float scale,
                            void *workspace, size_t workspace_bytes, float *row_scratch, void *stream);

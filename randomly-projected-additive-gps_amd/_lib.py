@@ -53,6 +53,7 @@ SIGNATURES = {
     "rpgp_ski_grid": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "rpgp_ski_mvm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
     "rpgp_ski_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp]),
+    "rpgp_ski_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f32, _vp]),
     "rpgp_ski_diag": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp]),
     "rpgp_ski_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz,
                                       _vp, _vp]),

@@ -23,6 +23,7 @@ class HipBackend:
     ski_grid = staticmethod(ops.ski_grid)
     ski_mvm = staticmethod(ops.ski_mvm)
     ski_diag = staticmethod(ops.ski_diag)
+    ski_dense = staticmethod(ops.ski_dense)
     ski_pivoted_cholesky = staticmethod(ops.ski_pivoted_cholesky)
     ski_bilinear_grad = staticmethod(ops.ski_bilinear_grad)
     ski_bilinear_grad_comp = staticmethod(ops.ski_bilinear_grad_comp)

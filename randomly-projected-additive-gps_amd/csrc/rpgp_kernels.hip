@@ -1726,6 +1726,69 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
   rowS[i] = accS;
 }
 
+// Dense block of the SKI operator: out[m][n] = scale * sum_j w_j sum_{q,q'} w_q(z1_mj) w_q'(z2_nj) Toep[(idx_m + q) - (idx_n + q')]
+// (7 distinct lags per column, looked up in an LDS copy of the Toeplitz column).  One thread per output column, 16
+// rows per workgroup with their taps in LDS.  Used for `to_dense`, row gathers and — below N ~ 32k, where a library
+// GEMM on the dense matrix beats the wide scatter/gather — the wide solves of the predictive covariance.
+__global__ __launch_bounds__(256) void ski_dense_kernel(const float *__restrict__ Z1, const float *__restrict__ Z2,
+                                                        const float *__restrict__ gp, float *__restrict__ out, int M,
+                                                        int N, int ldz1, int ldz2, long long ldo, int J, int G,
+                                                        float scale) {
+  constexpr int RT = 16;
+  extern __shared__ float smem[];           // sc[G] | sW[RT][J][4] | sI[RT][J] (ints)
+  float *sc = smem;
+  float *sW = smem + G;
+  int *sI = reinterpret_cast<int *>(sW + RT * J * 4);
+  const float g0 = gp[0], inv_h = gp[2], hs = gp[1] * kExp2Scale;
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * RT;
+  for (int q = tid; q < G; q += 256) {
+    const float dd = (float)q * hs;
+    sc[q] = fast_exp2(-(dd * dd));
+  }
+  for (int e = tid; e < RT * J; e += 256) {
+    const int r = e / J, j = e % J;
+    float w[4] = {0.f, 0.f, 0.f, 0.f}, dw[4];
+    int idx = 0;
+    if (m0 + r < M) idx = ski_taps<false>(Z1[(size_t)(m0 + r) * ldz1 + j], g0, inv_h, G, w, dw);
+    sI[e] = idx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sW[e * 4 + q] = w[q];
+  }
+  __syncthreads();
+  const int col = blockIdx.x * 256 + tid;
+  if (col >= N) return;
+  float acc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+  for (int j = 0; j < J; ++j) {
+    float wc[4], dw[4];
+    const int idc = ski_taps<false>(Z2[(size_t)col * ldz2 + j], g0, inv_h, G, wc, dw);
+    const float wj = ski_wj(gp, j);
+#pragma unroll 4
+    for (int r = 0; r < RT; ++r) {
+      const int delta = sI[r * J + j] - idc;
+      const float *wr = sW + (r * J + j) * 4;
+      float tl[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        int lag = delta + u - 3;
+        lag = lag < 0 ? -lag : lag;
+        tl[u] = lag < G ? sc[lag] : 0.f;
+      }
+      float aj = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) aj = __builtin_fmaf(wr[q] * wc[qq], tl[q - qq + 3], aj);
+      acc[r] = __builtin_fmaf(wj, aj, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+    if (m0 + r < M) out[(size_t)(m0 + r) * ldo + col] = scale * acc[r];
+}
+
 // diag[i] = scale * sum_j sum_{k,k'} w_k w_k' exp(-0.5 ((k-k') h)^2)
 __global__ __launch_bounds__(256) void ski_diag_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
                                                        float *__restrict__ diag, long long N, int ldz, int J, int G,
@@ -3175,6 +3238,19 @@ int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, con
   rc = ski_toeplitz(hist, grid_params, H, J, G, T, st);
   if (rc) return rc;
   return ski_gather_all(Z1, grid_params, H, V, out, M, ldz1, J, G, T, scale, noise, st);
+}
+
+int rpgp_ski_dense(const float *Z1, const float *Z2, const float *grid_params, float *out, int64_t M, int64_t N,
+                   int ldz1, int ldz2, int64_t ldo, int J, int G, float scale, void *stream) {
+  if (!Z1 || !Z2 || !grid_params || !out || M <= 0 || N <= 0 || J <= 0 || J > 64 || G < 8 || ldz1 < J || ldz2 < J ||
+      ldo < N || M > 0x7fffffffLL || N > 0x7fffffffLL)
+    return RPGP_EINVAL;
+  const size_t lds = ((size_t)G + 16 * J * 5) * sizeof(float);
+  if (lds > 64 * 1024) return RPGP_EINVAL;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + 15) / 16));
+  hipLaunchKernelGGL(ski_dense_kernel, grid, dim3(256), lds, as_stream(stream), Z1, Z2, grid_params, out, (int)M, (int)N,
+                     ldz1, ldz2, (long long)ldo, J, G, scale);
+  return launch_status();
 }
 
 int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t N, int ldz, int J, int G, float scale,

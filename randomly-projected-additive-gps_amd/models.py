@@ -83,12 +83,15 @@ class PredictionStrategy:
         if self.dense_path:
             return torch.cholesky_solve(B, self.chol)
         khat = self.khat
-        if B.shape[1] > 12 and isinstance(self.op, AdditiveRPOperator) and \
-                not isinstance(self.op, SKIAdditiveOperator) and not isinstance(khat, DenseOperator):
+        if B.shape[1] > 12 and isinstance(self.op, AdditiveRPOperator) and not isinstance(khat, DenseOperator):
             # wide right-hand sides (predictive covariance, T = N_test) on the exact fused operator: materialise K once
-            # so every CG iteration is a library GEMM on the matrix cores instead of N_test/12 fused sweeps
+            # so every CG iteration is a library GEMM on the matrix cores instead of N_test/12 fused sweeps.  The SKI
+            # operator's own wide scatter/gather is O(N J T) and wins above N ~ 32k (measured: 35 vs 88 ms per product
+            # at N = 50k, T = 2000; 115 vs 45 ms at N = T = 14 939), so it is densified only below that.
             N = B.shape[0]
             fits = (4.0 * N * N <= 0.25 * torch.cuda.get_device_properties(B.device).total_memory) if B.is_cuda else True
+            if isinstance(self.op, SKIAdditiveOperator) and N > 32768:
+                fits = False
             if fits:
                 if getattr(self, "_dense_khat", None) is None:
                     self._dense_khat = DenseOperator(self.op.to_dense(), float(self.noise))

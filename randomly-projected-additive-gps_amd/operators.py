@@ -312,6 +312,8 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         be = _backend.get_backend()
         z1 = self.Z1.detach()
         z2 = z1 if self.symmetric else self.Z2.detach()
+        if hasattr(be, "ski_dense") and z1.shape[1] <= 64:
+            return be.ski_dense(z1.index_select(0, idx).contiguous(), z2, self.gp, self._scale, self.grid_size)
         k = idx.numel()
         eye = torch.eye(k, dtype=self.dtype, device=self.device)
         # K[idx, :] = (K(Z2, Z1[idx]))^T : interpolate the k selected points, gather at all columns
@@ -322,6 +324,9 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         be = _backend.get_backend()
         z1 = self.Z1.detach()
         z2 = z1 if self.symmetric else self.Z2.detach()
+        if hasattr(be, "ski_dense") and z1.shape[1] <= 64:
+            # straight from the interpolation weights and the Toeplitz lags (no N x N identity through the MVM)
+            return be.ski_dense(z1, z2, self.gp, self._scale, self.grid_size)
         eye = torch.eye(z2.shape[0], dtype=self.dtype, device=self.device)
         return be.ski_mvm(z1, z2, self.gp, eye, self._scale, 0.0, self.grid_size)
 

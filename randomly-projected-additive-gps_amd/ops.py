@@ -390,6 +390,20 @@ def ski_pivoted_cholesky(Z, gp, scale, rank, grid_size=1024):
     return L
 
 
+def ski_dense(Z1, Z2, gp, scale, grid_size=1024):
+    """Dense block K_ski(Z1, Z2) (M x N) of the SKI operator."""
+    lib = _lib.load()
+    Z1 = _require(Z1, "Z1", 2)
+    Z2 = _require(Z2, "Z2", 2)
+    M, J = Z1.shape
+    N = Z2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        _lib.check(lib.rpgp_ski_dense(Z1.data_ptr(), Z2.data_ptr(), gp.data_ptr(), out.data_ptr(), M, N, J, J, N, J,
+                                      int(grid_size), float(scale), _stream()), "rpgp_ski_dense")
+    return out
+
+
 def ski_diag(Z, gp, scale, grid_size=1024):
     lib = _lib.load()
     Z = _require(Z, "Z", 2)

@@ -191,3 +191,24 @@ def test_weighted_ski_kernels_match_oracle(gpu_device, N, J, T, G):
     assert float((gZ.cpu() - rZ).norm() / rZ.norm()) < 2e-4
     assert abs(float(gs) - float(rs)) < 2e-4 * abs(float(rs)) + 1e-3
     assert float((gc.cpu() - rc).norm() / rc.norm()) < 2e-4
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_ski_dense_block_matches_oracle_and_mvm(gpu_device, weighted):
+    """rpgp_ski_dense (entries from the interpolation weights and the Toeplitz lags) against the dense float64 SKI oracle
+    and against the operator's own MVM."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(7)
+    N, M, J, G = 1500, 333, 7, 512
+    Z = (rng.standard_normal((N, J)) * 0.8).astype(np.float32)
+    Z1 = (rng.standard_normal((M, J)) * 0.8).astype(np.float32)
+    w = rng.uniform(0.3, 1.4, size=J).astype(np.float32) if weighted else None
+    Zt, Z1t = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(Z1).to(gpu_device)
+    gp = ops.ski_grid(Zt, Z1t, G, weights=None if w is None else torch.from_numpy(w).to(gpu_device))
+    grid = (float(gp[0]), float(gp[1]))
+    Kd = ops.ski_dense(Z1t, Zt, gp, 0.6, G)
+    ref = sko.dense_kernel(Z1, Z, 0.6, G, grid, w)
+    assert np.abs(Kd.cpu().numpy() - ref).max() < 2e-5
+    V = torch.randn(N, 5, generator=torch.Generator().manual_seed(0)).to(gpu_device)
+    mv = ops.ski_mvm(Z1t, Zt, gp, V, 0.6, 0.0, G)
+    assert float((Kd @ V - mv).norm() / mv.norm()) < 1e-5

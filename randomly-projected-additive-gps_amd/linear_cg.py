@@ -144,7 +144,14 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
 
     z = preconditioner(residual)
     p = z.clone()
-    rz = (residual * z).sum(0, keepdim=True)
+    # wide blocks (predictive covariance: N x N_test) make every N x T temporary a GB-sized allocation; the loop below
+    # updates result / residual / p in place and routes the column-wise inner products through ONE scratch buffer
+    scratch = torch.empty_like(rhs)
+
+    def coldot(a, b):
+        return torch.mul(a, b, out=scratch).sum(0, keepdim=True)
+
+    rz = coldot(residual, z)
 
     if n_tridiag:
         t_mat = torch.zeros(n_tridiag, n_tridiag_iter, n_tridiag_iter, dtype=rhs.dtype, device=rhs.device)
@@ -161,23 +168,24 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     k = 0
     for k in range(n_iter):
         Ap = matmul_closure(p)
-        pAp = (p * Ap).sum(0, keepdim=True)
+        pAp = coldot(p, Ap)
         safe = pAp.abs().gt(eps)
         alpha = torch.where(safe, rz / torch.where(safe, pAp, torch.ones_like(pAp)), torch.zeros_like(pAp))
         # columns that already converged stop moving (keeps alpha/beta finite)
         if residual_norm is not None:
             alpha = alpha.masked_fill(residual_norm.lt(stop_updating_after), 0.0)
-        result = result + alpha * p
-        residual = residual - alpha * Ap
+        result.addcmul_(p, alpha)
+        residual.addcmul_(Ap, alpha, value=-1.0)
+        del Ap
 
         residual_norm = residual.norm(2, dim=0, keepdim=True).masked_fill(rhs_is_zero, 0.0)
 
         z = preconditioner(residual)
-        rz_new = (residual * z).sum(0, keepdim=True)
+        rz_new = coldot(residual, z)
         safe_rz = rz.abs().gt(eps)
         beta = torch.where(safe_rz, rz_new / torch.where(safe_rz, rz, torch.ones_like(rz)), torch.zeros_like(rz))
         rz = rz_new
-        p = z + beta * p
+        p.mul_(beta).add_(z)
 
         if update_tridiag and k < n_tridiag_iter:
             a_t = alpha[:, :n_tridiag]
@@ -229,7 +237,7 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     stats["iterations"] += k + 1
     stats["last_iterations"] = k + 1
     stats["last_rhs"] = T
-    result = result * rhs_norm
+    result.mul_(rhs_norm)
     if squeeze:
         result = result.squeeze(-1)
     if n_tridiag:

@@ -96,6 +96,17 @@ class PredictionStrategy:
                 if getattr(self, "_dense_khat", None) is None:
                     self._dense_khat = DenseOperator(self.op.to_dense(), float(self.noise))
                 khat = self._dense_khat
+                if N <= settings.dense_solve_size.value():
+                    # with Khat in HBM anyway, a float64 Cholesky (rocSOLVER) solves the N_test-wide block exactly and
+                    # faster than ~50 CG iterations of N x N x N_test GEMMs (N = 15k: 0.6 s against 3 s)
+                    if getattr(self, "_chol64", None) is None:
+                        self._chol64 = psd_safe_cholesky(khat.to_dense().double())
+                    # column panels of 1024: hipSOLVER potrs / rocBLAS trsm run out of workspace on N x N right-hand sides
+                    out = torch.empty_like(B)
+                    for c0 in range(0, B.shape[1], 1024):
+                        blk = B[:, c0:c0 + 1024].double().contiguous()
+                        out[:, c0:c0 + 1024] = torch.cholesky_solve(blk, self._chol64).to(B.dtype)
+                    return out
         return linear_cg(khat._matmul, B, tolerance=settings.eval_cg_tolerance.value(),
                          max_iter=settings.max_cg_iterations.value(), preconditioner=getattr(self, "pre", None),
                          operator=khat)
@@ -143,8 +154,12 @@ class PredictionStrategy:
                     Kx_blk = cross._get_rows(idx).t().contiguous()      # K(X, X*[idx])  (N x c)
                     sol = self.solve(Kx_blk)                            # ~ Khat^-1 K(X, X*[idx])
                     S[:, idx] = sol
-                    KS[:, idx] = khat._matmul(sol)
-                    BtS[:, idx] = cross._matmul(sol)                    # K(X*, X) sol
+                    # Khat sol through the matrix the solve used (a library GEMM when it was densified)
+                    KS[:, idx] = (getattr(self, "_dense_khat", None) or khat)._matmul(sol)
+                    if idx.numel() == n_test and sol.shape[1] > 12:
+                        BtS[:, idx] = Kx_blk.t() @ sol                  # single block: K(X*, X) is Kx_blk^T, already dense
+                    else:
+                        BtS[:, idx] = cross._matmul(sol)                # K(X*, X) sol
                 cov -= BtS + BtS.t() - S.t() @ KS
             cov = 0.5 * (cov + cov.t())
         return MultivariateNormal(mean, cov)

@@ -47,6 +47,8 @@ class WoodburyPreconditioner:
         """M^-1 r = (r - L (noise I + L^T L)^-1 L^T r) / noise."""
         t = (self.L.t() @ r).double()
         t = torch.cholesky_solve(t, self._cap_chol).to(r.dtype)
+        if r.dim() == 2 and t.dim() == 2:
+            return torch.addmm(r, self.L, t, alpha=-1.0).div_(self.noise)      # one N x T temporary instead of three
         return (r - self.L @ t) / self.noise
 
     __call__ = solve

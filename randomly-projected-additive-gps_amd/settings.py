@@ -69,6 +69,9 @@ tridiagonal_jitter = _setting("tridiagonal_jitter", 1e-6)
 # wide-block CG (torch-op loop): stop when the best mean residual has not improved by 1 % over this many consecutive
 # convergence tests (fp32 floor on badly conditioned systems); 0 disables (GPyTorch's behaviour: run to max_cg_iterations)
 cg_stagnation_window = _setting("cg_stagnation_window", 200)
+# wide (N_test-column) solves of the predictive covariance: when Khat has been materialised in HBM and N is at most this,
+# factorise it once in float64 instead of running CG on the wide block (0 keeps CG, GPyTorch's behaviour)
+dense_solve_size = _setting("dense_solve_size", 20000)
 
 
 class fast_computations:

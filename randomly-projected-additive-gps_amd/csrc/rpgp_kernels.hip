@@ -2787,12 +2787,15 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
   if (N > 0x7fffffffLL) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const int ns = bilinear_nsplit(N);
-  int cps = (int)((N + ns - 1) / ns);
+  const int ns_max = bilinear_nsplit(N);          // the slab layout (and the workspace size) uses the upper bound
+  int cps = (int)((N + ns_max - 1) / ns_max);
   cps = (cps + 63) / 64 * 64;
+  // splits that actually own columns: rounding cps up to 64 can leave trailing splits empty, and an empty split's
+  // workgroups return without writing their slab — the reduce must not read them
+  const int ns = (int)((N + cps - 1) / cps);
   float *slabG = reinterpret_cast<float *>(workspace);
-  float *slabS = slabG + (size_t)ns * N * 20;
-  float *rowS = slabS + (size_t)ns * N;
+  float *slabS = slabG + (size_t)ns_max * N * 20;
+  float *rowS = slabS + (size_t)ns_max * N;
   int first = 1;
   for (int j = j0; j < j1;) {
     const int jt = next_j_piece(j1 - j);
@@ -2829,12 +2832,15 @@ int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *g
   if (N > 0x7fffffffLL) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const int ns = bilinear_nsplit(N);
-  int cps = (int)((N + ns - 1) / ns);
+  const int ns_max = bilinear_nsplit(N);          // the slab layout (and the workspace size) uses the upper bound
+  int cps = (int)((N + ns_max - 1) / ns_max);
   cps = (cps + 63) / 64 * 64;
+  // splits that actually own columns: rounding cps up to 64 can leave trailing splits empty, and an empty split's
+  // workgroups return without writing their slab — the reduce must not read them
+  const int ns = (int)((N + cps - 1) / cps);
   float *slabG = reinterpret_cast<float *>(workspace);
-  float *slabS = slabG + (size_t)ns * N * 20;
-  float *rowS = slabS + (size_t)ns * N;
+  float *slabS = slabG + (size_t)ns_max * N * 20;
+  float *rowS = slabS + (size_t)ns_max * N;
   int first = 1;
   for (int j = j0; j < j1;) {
     const int jt = next_j_piece(j1 - j);
@@ -2926,12 +2932,15 @@ static int family_bilinear_common(const rpgp_family *fam, const float *Z, const 
   const int J = fam->ncomp * fam->group, C = fam->ncomp;
   if (!workspace || workspace_bytes < rpgp_family_bilinear_grad_workspace_bytes(N, J, C)) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const int ns = bilinear_nsplit(N);
-  int cps = (int)((N + ns - 1) / ns);
+  const int ns_max = bilinear_nsplit(N);          // the slab layout (and the workspace size) uses the upper bound
+  int cps = (int)((N + ns_max - 1) / ns_max);
   cps = (cps + 63) / 64 * 64;
+  // splits that actually own columns: rounding cps up to 64 can leave trailing splits empty, and an empty split's
+  // workgroups return without writing their slab — the reduce must not read them
+  const int ns = (int)((N + cps - 1) / cps);
   float *slabG = reinterpret_cast<float *>(workspace);
-  float *slabC = slabG + (size_t)ns * N * 20;
-  float *rowC = slabC + (size_t)ns * N * 10;
+  float *slabC = slabG + (size_t)ns_max * N * 20;
+  float *rowC = slabC + (size_t)ns_max * N * 10;
   const float *wts = fam->weights;
   rc = with_family_policy(fam->kind, fam->group, [&](auto kf) -> int {
     using KF = decltype(kf);

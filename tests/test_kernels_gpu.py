@@ -308,3 +308,30 @@ def test_space_equally_on_device_matches_reference_golden(gpu_device):
         assert float(loss) > 1e-3
         out2, _ = rp.space_equally(P0.clone(), 0.1, 5000)          # the module-level entry takes the device path here
         assert out2.device.type == "cpu" and np.allclose(out2.numpy(), ref, atol=5e-5)
+
+
+@pytest.mark.parametrize("N", [14939, 7372, 5000])
+def test_workspace_contents_never_leak_into_results(gpu_device, N):
+    """Regression: with a NaN-poisoned (re-used) workspace every op must return what it returns on a fresh one.  The
+    bilinear derivative used to read the slabs of column splits that own no columns (rounding of the split width)."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N)
+    Z = torch.from_numpy(rng.standard_normal((N, 20)).astype(np.float32)).to(gpu_device)
+    L = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32)).to(gpu_device)
+    R = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32)).to(gpu_device)
+    fam = ops.Family("Matern", 1, torch.full((20,), 0.05, device=gpu_device))
+
+    def run():
+        gp = ops.ski_grid(Z, None, 256)
+        return [ops.mvm_sym(Z, L, 0.05, 0.1), ops.mvm_sym_prepared(ops.Prepared(Z), L, 0.05, 0.1),
+                *ops.bilinear_grad(Z, L, R, 0.05), *ops.family_bilinear_grad(fam, Z, L, R, 0.9),
+                ops.family_mvm_sym(fam, Z, L, 0.9, 0.1), ops.ski_mvm(Z, Z, gp, L, 0.05, 0.1, 256),
+                *ops.ski_bilinear_grad(Z, gp, L, R, 0.05, 256), ops.dense_mvm(ops.dense(Z[:4096], Z[:4096], 0.05), L[:4096])]
+
+    ref = run()
+    for buf in ops._workspaces.values():
+        buf.view(torch.float32).fill_(float("nan"))
+    got = run()
+    for a, b in zip(ref, got):
+        assert torch.isfinite(b).all()
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)

@@ -335,3 +335,55 @@ def test_workspace_contents_never_leak_into_results(gpu_device, N):
     for a, b in zip(ref, got):
         assert torch.isfinite(b).all()
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_no_op_reads_uninitialised_scratch(gpu_device, monkeypatch):
+    """Every scratch / output tensor the wrappers allocate with torch.empty is NaN-filled here: results must not change
+    (an op that reads memory it has not written shows up as NaN or as a difference)."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(3)
+    N = 14939
+    Z = torch.from_numpy(rng.standard_normal((N, 20)).astype(np.float32)).to(gpu_device)
+    Zs = torch.from_numpy(rng.standard_normal((700, 20)).astype(np.float32)).to(gpu_device)
+    X = torch.from_numpy(rng.standard_normal((N, 18)).astype(np.float32)).to(gpu_device)
+    Pm = torch.from_numpy(rng.standard_normal((18, 20)).astype(np.float32)).to(gpu_device)
+    L = torch.from_numpy(rng.standard_normal((N, 11)).astype(np.float32)).to(gpu_device)
+    R = torch.from_numpy(rng.standard_normal((N, 11)).astype(np.float32)).to(gpu_device)
+    w = torch.from_numpy(rng.uniform(0.3, 1.0, 20).astype(np.float32)).to(gpu_device)
+
+    def run():
+        fam = ops.Family("InverseMQ", 1, w)
+        famg = ops.Family("RBF", 4, w[:5])
+        gp = ops.ski_grid(Z, Zs, 512, weights=w)
+        prep = ops.Prepared(Z)
+        desc, keep = ops.make_operator_desc(1, N, 20, 0.05, 0.3, prep=prep)
+        x, ah, bh, it, mres = ops.mbcg_solve(desc, L, 1e-3, 200, hist_len=5)
+        return [ops.project(X, Pm), ops.project_grad(X, Z), ops.mvm_sym(Z, L, 0.05, 0.1), ops.mvm_sym_prepared(prep, L, 0.05, 0.1),
+                ops.mvm_sym_prepared(prep, L, 0.05, 0.0, shard=(3, 1)), ops.mvm_rect(Zs, Z, L, 0.05), ops.dense(Zs, Z, 0.05),
+                *ops.bilinear_grad(Z, L, R, 0.05), ops.pivoted_cholesky(Z, 0.05, 15), ops.family_mvm_sym(fam, Z, L, 0.9, 0.1),
+                ops.family_mvm_sym(famg, Z, L, 0.9, 0.1), ops.family_mvm_rect(fam, Zs, Z, L, 0.9), ops.family_dense(fam, Zs, Z, 0.9),
+                *ops.family_bilinear_grad(famg, Z, L, R, 0.9), ops.family_pivoted_cholesky(fam, Z, 0.9, 8, float(w.sum())),
+                ops.ski_mvm(Z, Z, gp, L, 0.05, 0.1, 512), ops.ski_mvm(Zs, Z, gp, L, 0.05, 0.0, 512), ops.ski_diag(Z, gp, 0.05, 512),
+                ops.ski_dense(Zs, Z, gp, 0.05, 512), *ops.ski_bilinear_grad_comp(Z, gp, L, R, 0.05, 512),
+                ops.ski_pivoted_cholesky(Z, gp, 0.05, 8, 512), x, torch.from_numpy(ah), torch.from_numpy(bh),
+                ops.space_equally(Pm.t().contiguous(), 0.1, 50)[0]]
+
+    ref = [t.clone() for t in run()]
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+
+    def nan_empty(*a, **k):
+        t = real_empty(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+
+    def nan_empty_like(*a, **k):
+        t = real_empty_like(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+
+    monkeypatch.setattr(ops.torch, "empty", nan_empty)
+    monkeypatch.setattr(ops.torch, "empty_like", nan_empty_like)
+    for buf in ops._workspaces.values():
+        buf.view(real_empty(0).dtype if False else torch.float32).fill_(float("nan"))
+    got = run()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.isfinite(b).all(), "output %d has non-finite entries" % i
+        assert torch.allclose(a.cpu(), b.cpu(), rtol=1e-5, atol=1e-6), "output %d changed" % i

@@ -3,7 +3,8 @@ run_experiment :105-219, CLI :222-381).  Same flags, same model-spec JSON schema
 (SURVEY.md §5, Appendix D).  UCI `.mat` files are not shipped with the reference and cannot be downloaded here, so
 `synthetic:<name>` datasets with the standard (N, d) of the BASELINE configs are provided as stand-ins.
 
-    python -m rpgp_amd.runner -m model_specs/additive_rp_prescale_J20.json -d synthetic:kin8nm -o out.csv --device cuda:0
+    python -m rpgp_amd.runner -m additive_rp_prescale_J20 -d synthetic:kin8nm -o out.csv --device cuda:0
+    (-m takes the path of a reference model_specs/*.json file, or the name of a built-in spec: rpgp_amd.specs)
 """
 import argparse
 import datetime
@@ -195,7 +196,8 @@ def run_experiment(training_routine, training_options, dataset, split, cv, addl_
 def build_parser():
     p = argparse.ArgumentParser(description="Utility to run a suite of experiments with a GP model on UCI regression "
                                             "datasets (MI355X-native counterpart of gp_experiment_runner.py).")
-    p.add_argument("-m", "--model_spec", type=str, required=True, help="path to model specification json file")
+    p.add_argument("-m", "--model_spec", type=str, required=True,
+                   help="path to model specification json file (or the name of a built-in spec, see rpgp_amd.specs)")
     p.add_argument("-d", "--datasets", type=str, nargs="+", required=True,
                    help="UCI dataset name(s), a predefined set (all|small|small-med|med|large|<int>) or synthetic:<name>")
     p.add_argument("-o", "--output", type=str, required=True, help="path to output csv file")
@@ -253,8 +255,16 @@ def resolve_datasets(names):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print("Parser arguments", args)
-    with open(args.model_spec, "r") as f:
-        options = json.load(f)
+    if os.path.exists(args.model_spec):
+        with open(args.model_spec, "r") as f:
+            options = json.load(f)
+    else:
+        # a bare spec name (or a path whose file does not exist) resolves against the built-in table of rpgp_amd.specs
+        from . import specs
+        try:
+            options = specs.get(args.model_spec)
+        except KeyError:
+            raise FileNotFoundError("no such model specification file, and not a built-in spec name: %s" % args.model_spec)
     print("Loaded options", options)
     devices = args.device.split(",")
     print("Using device(s) {}".format(devices))

@@ -16,6 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _spec(name):
+    from rpgp_amd import specs
+    return specs.get(name)
+
+
 def _to(dev, *ts):
     return [t.to(dev) for t in ts]
 
@@ -106,7 +111,7 @@ def test_predictive_mean_and_variance(gpu_device, N, chol):
 
 def test_train_exact_gp_and_runner_on_gpu(gpu_device, tmp_path):
     from rpgp_amd import runner
-    spec = json.load(open(os.path.join(ROOT, "model_specs", "additive_rp_prescale_J20.json")))
+    spec = _spec("additive_rp_prescale_J20.json")
     spec["train_kwargs"]["max_iter"] = 8
     spec["train_kwargs"]["init_iters"] = 2
     sp = tmp_path / "spec.json"

@@ -11,6 +11,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _spec(name):
+    from rpgp_amd import specs
+    return specs.get(name)
+
+
 def test_normalize_by_train_literal():
     from rpgp_amd.runner import _normalize_by_train
     df = pd.DataFrame({"index": [0, 1, 2], "0": [1, 2, 2], "target": [0, 0, 1]})
@@ -72,7 +77,7 @@ def test_mat_loader_layout(tmp_path, monkeypatch):
 def test_cli_full_rbf_on_cpu(tmp_path):
     """BASELINE config 1 plumbing: spec JSON -> settings -> folds -> fit -> metrics -> CSV, on CPU."""
     from rpgp_amd import runner
-    spec = json.load(open(os.path.join(ROOT, "model_specs", "RBF_model_spec.json")))
+    spec = _spec("RBF_model_spec.json")
     spec["train_kwargs"]["max_iter"] = 5
     spec["train_kwargs"]["init_iters"] = 2
     sp = tmp_path / "spec.json"
@@ -93,7 +98,7 @@ def test_cli_full_rbf_on_cpu(tmp_path):
 
 def test_cli_additive_spec_through_oracle_backend(tmp_path, oracle_backend):
     from rpgp_amd import runner
-    spec = json.load(open(os.path.join(ROOT, "model_specs", "additive_spread_prescale_J20.json")))
+    spec = _spec("additive_spread_prescale_J20.json")
     spec["train_kwargs"]["max_iter"] = 3
     spec["train_kwargs"]["init_iters"] = 1
     spec["model_kwargs"]["J"] = 6
@@ -112,7 +117,7 @@ def test_cli_additive_spec_through_oracle_backend(tmp_path, oracle_backend):
 def test_cli_family_specs_through_oracle_backend(tmp_path, oracle_backend, name):
     """The other family members' spec files run end to end through the same CLI."""
     from rpgp_amd import runner
-    spec = json.load(open(os.path.join(ROOT, "model_specs", name)))
+    spec = _spec(name)
     spec["train_kwargs"]["max_iter"] = 2
     spec["train_kwargs"]["init_iters"] = 1
     if spec["model_kwargs"].get("J") == 20:
@@ -150,9 +155,30 @@ def test_specs_match_reference_keys():
     """The five in-scope spec files carry the reference's keys/values."""
     for name, J in [("additive_rp_prescale_J20.json", 20), ("additive_spread_prescale_J20.json", 20),
                     ("additive_spread_prescale_Jd.json", "d"), ("additive_spread_prescale_Jd_ski.json", "d")]:
-        spec = json.load(open(os.path.join(ROOT, "model_specs", name)))
+        spec = _spec(name)
         assert spec["kind"] == "additive_rp" and spec["model_kwargs"]["J"] == J
         assert spec["model_kwargs"]["prescale"] is True and spec["model_kwargs"]["noise_prior"] is True
         assert spec["train_kwargs"] == {"verbose": False, "optimizer": "adam", "max_iter": 1000, "lr": 0.1,
                                         "patience": 20, "smooth": True}
-    assert json.load(open(os.path.join(ROOT, "model_specs", "RBF_model_spec.json")))["kind"] == "full"
+    assert _spec("RBF_model_spec.json")["kind"] == "full"
+
+
+def test_spec_table_files_and_names(tmp_path, oracle_backend):
+    """`-m` takes the path of a spec file (a user's copy of the reference's model_specs/*.json) or a built-in name;
+    `specs.write_all` materialises the table as files that round-trip."""
+    from rpgp_amd import runner, specs
+    paths = specs.write_all(str(tmp_path / "model_specs"))
+    assert len(paths) == len(specs.names()) >= 16
+    for pth in paths:
+        assert json.load(open(pth)) == specs.get(os.path.basename(pth))
+    spec = specs.get("additive_rp_prescale_J20")
+    spec["train_kwargs"].update(max_iter=2, init_iters=1)
+    spec["model_kwargs"]["J"] = 4
+    f = tmp_path / "mine.json"
+    json.dump(spec, open(f, "w"))
+    df = runner.main(["-m", str(f), "-d", "synthetic:tiny", "-o", str(tmp_path / "a.csv"), "--no_cv", "--skip_random_restart"])
+    assert np.isfinite(df.iloc[0]["rmse"])
+    with pytest.raises(FileNotFoundError):
+        runner.main(["-m", "no_such_spec", "-d", "synthetic:tiny", "-o", str(tmp_path / "b.csv"), "--no_cv"])
+    with pytest.raises(KeyError):
+        specs.get("nope")

@@ -10,6 +10,11 @@ from oracle import ski as sko
 pytestmark = pytest.mark.gpu
 
 
+def _spec(name):
+    from rpgp_amd import specs
+    return specs.get(name)
+
+
 def _rel(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -86,7 +91,7 @@ def test_ski_spec_trains_and_predicts_on_gpu(gpu_device, tmp_path):
     import os
     from rpgp_amd import runner
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = json.load(open(os.path.join(root, "model_specs", "additive_spread_prescale_Jd_ski.json")))
+    spec = _spec("additive_spread_prescale_Jd_ski.json")
     spec["train_kwargs"]["max_iter"] = 6
     spec["train_kwargs"]["init_iters"] = 2
     sp = tmp_path / "spec.json"

@@ -9,7 +9,7 @@ specs = sys.argv[2:] or ["additive_rp_prescale_J20", "additive_spread_prescale_J
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for spec in specs:
     t0 = time.perf_counter()
-    df = runner.main(["-m", os.path.join(root, "model_specs", spec + ".json"), "-d", dataset, "-o",
+    df = runner.main(["-m", spec, "-d", dataset, "-o",
                       os.path.join(root, "gpurun_out", "run_%s.csv" % spec), "--device", "cuda:0", "--no_cv",
                       "--skip_random_restart"])
     dt = time.perf_counter() - t0

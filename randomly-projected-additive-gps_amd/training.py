@@ -264,8 +264,12 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
     d = trainX.shape[-1]
     devices = [torch.device(device) for device in devices]
     output_device = devices[0] if output_device is None else torch.device(output_device)
-    if double and kind == "additive_rp" and model_kwargs.get("ski", False):
+    if double and model_kwargs.get("ski", False):
         raise NotImplementedError("--double is not available for the SKI operator (fp32 kernels only)")
+    if double and (kind in ("rp_poly", "additive") or (kind == "strictly_additive" and not model_kwargs.get("memory_efficient"))
+                   or (kind == "additive_rp" and (model_kwargs.get("kernel_type", "RBF") != "RBF" or model_kwargs.get("k", 1) > 1))):
+        raise NotImplementedError("--double is served by the float64 parity kernels of the RBF hot path only "
+                                  "(additive_rp with 1-D RBF sub-kernels, the memory-efficient GAM, kind full)")
     type_ = torch.double if double else torch.float
     trainX = trainX.to(output_device, type_).contiguous()
     trainY = trainY.to(output_device, type_).contiguous()

@@ -243,3 +243,15 @@ def test_weighted_ski_kinds_track_the_exact_kernel(oracle_backend, kind, model_k
         assert torch.allclose(gw0, gw1, rtol=3e-2, atol=2e-4)
     else:
         assert gw0 is None and gw1 is None
+
+
+def test_double_is_refused_for_family_kinds(oracle_backend):
+    from rpgp_amd.training import train_exact_gp
+    X, y = _problem(30, 4)
+    tk = {"verbose": False, "optimizer": "adam", "max_iter": 2, "lr": 0.1, "patience": 20, "smooth": True}
+    for kind, mk in (("rp_poly", dict(J=3, k=1, noise_prior=True, weighted=True)),
+                     ("additive_rp", dict(J=3, noise_prior=True, kernel_type="Matern", learn_proj=False, prescale=True)),
+                     ("additive_rp", dict(J=3, noise_prior=True, learn_proj=False, prescale=True, ski=True,
+                                          ski_options={"grid_size": 64, "num_dims": 1}))):
+        with pytest.raises(NotImplementedError):
+            train_exact_gp(X, y, X, y, kind, mk, tk, double=True)

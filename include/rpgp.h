@@ -191,7 +191,7 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
  * rpgp_ski_diag       : diag[i] = scale * sum_j w_i^T Tm[4x4] w_i.
  * rpgp_ski_bilinear_grad : d/dZ and d/dscale of sum((L R^T) * K) for the square operator (T <= 12); `row_scratch`
  *                       is N floats of device scratch.
- * All need `rpgp_ski_workspace_bytes(J, G, T)` bytes of workspace; G*12*4 <= 64 KB (G <= 1365).
+ * All need `rpgp_ski_workspace_bytes(J, G, T)` bytes of workspace; G*13*4 <= 64 KB (G <= 1260).
  */
 size_t rpgp_ski_workspace_bytes(int J, int G, int T);
 int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t N2, int ld2, int J, int G,

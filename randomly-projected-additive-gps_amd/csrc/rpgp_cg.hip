@@ -40,12 +40,15 @@ struct CgPoll {             // copied to pinned host memory after the iterations
   int iters;                // iterations performed when `done` was set
   float best_resid;         // stagnation bookkeeping
   int since_best;
+  int snap_slot;            // which snap_resid entry is current
+  float snap_cur;           // its value (mean residual of the iterate saved in x_best)
 };
 struct CgState {
   float rz[2][kMaxT];       // r.z of the current iterate, ping-pong by iteration parity (no intra-kernel race)
   float rhs_norm[kMaxT];
   float resid[kMaxT];       // residual norms of the current iterate
   int rhs_zero[kMaxT];
+  float snap_resid[2];      // mean residual of the iterate saved in x_best (ping-pong by iteration parity)
   CgPoll poll;
 };
 
@@ -124,6 +127,10 @@ __global__ __launch_bounds__(256) void k_normalise(const float *__restrict__ rhs
     st->poll.iters = 0;
     st->poll.best_resid = 3.0e38f;
     st->poll.since_best = 0;
+    st->poll.snap_slot = 0;
+    st->poll.snap_cur = 3.0e38f;
+    st->snap_resid[0] = 3.0e38f;
+    st->snap_resid[1] = 3.0e38f;
   }
   __syncthreads();
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
@@ -315,7 +322,11 @@ __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, 
                                                    const float *__restrict__ partial_rz, const float *__restrict__ partial_rr,
                                                    int nparts, CgState *__restrict__ st, float *__restrict__ beta_out,
                                                    long long N, int T, float eps, int cur, int check_now,
-                                                   float tolerance, int iter_count, int stagnation_window) {
+                                                   float tolerance, int iter_count, int stagnation_window,
+                                                   const float *__restrict__ x, float *__restrict__ x_best) {
+  // Best-iterate safeguard: fp32 CG on a system with cond(Khat) * 1e-6 >~ 1 (N s / sigma^2 beyond a few million) does not
+  // merely stall, its recurrence residual can GROW; the iterate with the smallest tested residual is kept in x_best (every
+  // workgroup takes the same decision from the same reduced numbers) and returned when the tolerance is never reached.
   __shared__ float srzn[kMaxT];
   __shared__ float srr[kMaxT];
   __shared__ float sbeta[kMaxT];
@@ -331,9 +342,22 @@ __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, 
   }
   __syncthreads();
   if (was_done) return;
+  float mres = 0.f;
+  for (int t = 0; t < T; ++t) mres += sres[t];
+  mres /= (float)T;
+  const float snap_prev = st->snap_resid[cur];
+  const bool improved = check_now && mres == mres && mres < snap_prev;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
-    for (int t = 0; t < T; ++t) p[i * T + t] = __builtin_fmaf(sbeta[t], p[i * T + t], z[i * T + t]);
+    for (int t = 0; t < T; ++t) {
+      p[i * T + t] = __builtin_fmaf(sbeta[t], p[i * T + t], z[i * T + t]);
+      if (improved) x_best[i * T + t] = x[i * T + t];
+    }
   if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      st->snap_resid[cur ^ 1] = improved ? mres : snap_prev;
+      st->poll.snap_slot = cur ^ 1;
+      st->poll.snap_cur = improved ? mres : snap_prev;
+    }
     if ((int)threadIdx.x < T) {
       st->rz[cur ^ 1][threadIdx.x] = srzn[threadIdx.x];
       st->resid[threadIdx.x] = sres[threadIdx.x];
@@ -351,6 +375,9 @@ __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, 
         } else if (m < tolerance) {
           st->poll.done = 1;
           st->poll.iters = iter_count;
+        } else if (snap_prev < 1.0f && m > 100.0f * snap_prev) {
+          st->poll.done = 3;                      // diverging: give up, the saved iterate is returned
+          st->poll.iters = iter_count;
         } else if (stagnation_window > 0) {
           if (m < 0.99f * st->poll.best_resid) {
             st->poll.best_resid = m;
@@ -365,10 +392,14 @@ __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, 
   }
 }
 
-__global__ __launch_bounds__(256) void k_unnormalise(float *__restrict__ x, const CgState *__restrict__ st, long long N,
-                                                     int T) {
+// x *= |rhs| per column; when the tolerance was never reached and a better tested iterate was saved, return that one
+// (the reported mean residual is updated by the host from the same two numbers)
+__global__ __launch_bounds__(256) void k_unnormalise(float *__restrict__ x, const float *__restrict__ x_best,
+                                                     const CgState *__restrict__ st, long long N, int T) {
+  const float snap = st->snap_resid[st->poll.snap_slot];
+  const bool use_best = st->poll.done != 1 && snap < st->poll.mean_resid;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
-    for (int t = 0; t < T; ++t) x[i * T + t] *= st->rhs_norm[t];
+    for (int t = 0; t < T; ++t) x[i * T + t] = (use_best ? x_best[i * T + t] : x[i * T + t]) * st->rhs_norm[t];
 }
 
 inline int nblocks_for(long long N) {
@@ -444,7 +475,7 @@ extern "C" {
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank) {
   if (!op || T <= 0 || T > kMaxT || precond_rank < 0 || precond_rank > kMaxK) return 0;
   const size_t nt = (size_t)op->N * T * sizeof(float);
-  size_t total = 4 * align256(nt);                                             // r, p, z, Ap
+  size_t total = 5 * align256(nt);                                             // r, p, z, Ap, x_best
   total += align256(sizeof(CgState));
   total += 3 * align256((size_t)kMaxBlocks * kMaxT * sizeof(float));           // partial pAp / rr / rz
   total += align256((size_t)kMaxBlocks * kMaxK * kMaxT * sizeof(float));       // partial L^T r
@@ -473,6 +504,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   float *p = reinterpret_cast<float *>(w); w += align256(nt);
   float *z = reinterpret_cast<float *>(w); w += align256(nt);
   float *Ap = reinterpret_cast<float *>(w); w += align256(nt);
+  float *x_best = reinterpret_cast<float *>(w); w += align256(nt);
   CgState *state = reinterpret_cast<CgState *>(w); w += align256(sizeof(CgState));
   float *part_a = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxT * sizeof(float));
   float *part_rr = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxT * sizeof(float));
@@ -508,7 +540,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   // memory, so the next iteration is already queued while it waits and the GPU never idles on the round trip.  The
   // iteration queued past convergence is a no-op on x (alpha = 0).
   int polled_it = -1;                     // iteration whose poll is in flight (-1: none)
-  CgPoll last = {1.0f, 0, 0, 0.f, 0};
+  CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f};
   for (it = 0; it < n_iter; ++it) {
     int rc = apply_operator(op, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
@@ -522,7 +554,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
     hipLaunchKernelGGL(k_direction, dim3(nb), dim3(256), 0, st, z, p, part_rz, part_rr, nb, state,
                        beta_d + (size_t)slot * kMaxT, N, T, eps, it & 1, check_now ? 1 : 0, tolerance, it + 1,
-                       stagnation_window);
+                       stagnation_window, x, x_best);
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
       CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
       last = hpoll[polled_it % kPollRing];
@@ -538,7 +570,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
       polled_it = it;
     }
   }
-  hipLaunchKernelGGL(k_unnormalise, dim3(nb), dim3(256), 0, st, x, state, N, T);
+  hipLaunchKernelGGL(k_unnormalise, dim3(nb), dim3(256), 0, st, x, x_best, state, N, T);
   CG_CHECK(hipMemcpyAsync(&hpoll[kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
   CG_CHECK(hipStreamSynchronize(st));
   last = hpoll[kPollRing];
@@ -550,6 +582,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     CG_CHECK(hipStreamSynchronize(st));
   }
   if (iterations_host) *iterations_host = iters_done;
+  if (last.done != 1 && last.snap_cur < last.mean_resid) last.mean_resid = last.snap_cur;   // the saved iterate was returned
   if (mean_resid_host) *mean_resid_host = last.mean_resid;
   if (last.done == 2 || last.mean_resid != last.mean_resid) return RPGP_ENUMERIC;
   return 0;

@@ -1402,16 +1402,17 @@ __global__ void ski_grid_finish_kernel(const float *__restrict__ part, int npart
 // consecutive words of a grid cell for 256 / LPP points (conflict-free across t, V read coalesced).
 // The LDS accumulation is INTEGER: gfx950 executes ds_add_f32 at ~80 ns per wave-instruction per CU against 2.6 ns for
 // ds_add_u32 (tools/lds_atomic_bench.hip, profiles/r1_lds_atomic_bench.txt).  Each column gets a power-of-two
-// fixed-point scale from the chunk's own max|v| (sum of |w v| over the chunk stays below 2^30, so no overflow); the
-// rounding error per update is <= 2^-31 of that bound — about the fp32 rounding of the float sum it replaces — and
-// integer addition commutes, so the SKI product is bitwise reproducible.
+// fixed-point scale from the chunk's own max|v| and its densest 4-cell neighbourhood (so no cell sum can overflow 2^30);
+// the rounding error per update is <= 2^-31 of that bound — at the fp32 rounding level of the float sum it replaces —
+// and integer addition commutes, so the SKI product is bitwise reproducible.
 template <int TT>
 __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
                                                            const float *__restrict__ V, float *__restrict__ slab,
                                                            long long N, int ldz, int J, int G, int T, int tcnt,
                                                            long long pts_per_chunk) {
-  extern __shared__ int shi[];    // G * TT fixed-point accumulators
+  extern __shared__ int shi[];    // G * TT fixed-point accumulators | G ints: points per first-tap cell (scale bound)
   __shared__ float smax[256];
+  __shared__ int scmax[256];
   __shared__ float sscale[16], sinv[16];
   constexpr int LPP = TT == 1 ? 1 : (TT == 4 ? 4 : 16);
   constexpr int PPI = 256 / LPP;
@@ -1419,19 +1420,39 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
   const int j = blockIdx.y;
   const long long n0 = (long long)blockIdx.x * pts_per_chunk;
   const long long n1 = (n0 + pts_per_chunk < N) ? n0 + pts_per_chunk : N;
-  for (int e = threadIdx.x; e < G * TT; e += 256) shi[e] = 0;
+  int *scnt = shi + G * TT;
+  for (int e = threadIdx.x; e < G * TT + G; e += 256) shi[e] = 0;
+  __syncthreads();
   const int t = threadIdx.x % LPP, pl = threadIdx.x / LPP;
-  // pass 1: max |v| of the chunk per column -> fixed-point scale
+  // pass 1: max |v| of the chunk per column, and how many points start their 4-tap stencil at each grid cell: a cell
+  // receives at most one tap (|w| <= 1) from every point whose stencil starts in [cell - 3, cell], so
+  //   |cell sum| <= (max over cells of that 4-cell count) * max|v|
+  // — a bound ~100x tighter than points * max|v|, i.e. a fixed-point quantum at the fp32 rounding level
   float vm = 0.f;
   if (t < tcnt)
     for (long long i = n0 + pl; i < n1; i += PPI) vm = fmaxf(vm, __builtin_fabsf(V[i * T + t]));
   smax[threadIdx.x] = vm;
+  for (long long i = n0 + threadIdx.x; i < n1; i += 256) {
+    float w[4], dw[4];
+    atomicAdd(&scnt[ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw)], 1);
+  }
+  __syncthreads();
+  int cm = 0;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    int c4 = scnt[g];
+    if (g >= 1) c4 += scnt[g - 1];
+    if (g >= 2) c4 += scnt[g - 2];
+    if (g >= 3) c4 += scnt[g - 3];
+    cm = c4 > cm ? c4 : cm;
+  }
+  scmax[threadIdx.x] = cm;
   __syncthreads();
   if ((int)threadIdx.x < LPP) {
     float m = 0.f;
     for (int q = 0; q < PPI; ++q) m = fmaxf(m, smax[q * LPP + threadIdx.x]);
-    // |sum| <= 1.2 * points * max|v| (cubic-convolution weights: |w| <= 1, negative lobes add < 0.2)
-    const float bound = 1.2f * (float)(n1 - n0) * m;
+    int cmax = 1;
+    for (int q = 0; q < 256; ++q) cmax = scmax[q] > cmax ? scmax[q] : cmax;
+    const float bound = 1.05f * (float)cmax * m;
     float sc = 1.0f, inv = 1.0f;
     if (bound > 0.f && bound < 3.0e38f) {
       int ex;
@@ -1474,8 +1495,11 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
   }
 }
 
-// hist[j][g][hoff + t] = sum_c slab[c][j][g][t]   (t < tcnt; hist row stride HT)
-__global__ __launch_bounds__(256) void ski_slab_sum_kernel(const float *__restrict__ slab, float *__restrict__ hist,
+// hist[j][g][hoff + t] = sum_c slab[c][j][g][t]   (t < tcnt; hist row stride HT).  The grid histogram and the Toeplitz
+// product below are carried in FLOAT64: they cost nothing (J G T values), and with |K| ~ s N the fp32 rounding of these
+// two small stages alone (~1e-6 |K v|) exceeds sigma^2 |v| once N s / sigma^2 reaches a few million — at N = 391k the
+// operator then stops being numerically positive definite and CG diverges.
+__global__ __launch_bounds__(256) void ski_slab_sum_kernel(const float *__restrict__ slab, double *__restrict__ hist,
                                                            int nchunks, int J, int G, int TT, int tcnt, int HT,
                                                            int hoff) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;        // over J * G * TT
@@ -1483,19 +1507,21 @@ __global__ __launch_bounds__(256) void ski_slab_sum_kernel(const float *__restri
   if (e >= per) return;
   const int t = (int)(e % TT);
   if (t >= tcnt) return;
-  float acc = 0.f;
-  for (int c = 0; c < nchunks; ++c) acc += slab[(size_t)c * per + e];
+  double acc = 0.0;
+  for (int c = 0; c < nchunks; ++c) acc += (double)slab[(size_t)c * per + e];
   hist[(e / TT) * HT + hoff + t] = acc;
 }
 
 // H[j][m][t] = sum_m' exp(-0.5 ((m - m') h)^2) hist[j][m'][t]
-__global__ __launch_bounds__(256) void ski_toeplitz_kernel(const float *__restrict__ hist, const float *__restrict__ gp,
+template <class HT_>
+__global__ __launch_bounds__(256) void ski_toeplitz_kernel(const HT_ *__restrict__ hist, const float *__restrict__ gp,
                                                            float *__restrict__ H, int G, int T) {
-  extern __shared__ float sc[];   // G toeplitz coefficients
-  const float hs = gp[1] * kExp2Scale;
+  extern __shared__ double scd[];   // G toeplitz coefficients (float64)
+  double *sc = scd;
+  const double hd = (double)gp[1];
   for (int k = threadIdx.x; k < G; k += 256) {
-    const float d = (float)k * hs;
-    sc[k] = fast_exp2(-(d * d));
+    const double d = (double)k * hd;
+    sc[k] = exp(-0.5 * d * d);
   }
   __syncthreads();
   const int j = blockIdx.y;
@@ -1506,69 +1532,78 @@ __global__ __launch_bounds__(256) void ski_toeplitz_kernel(const float *__restri
   const int m = blockIdx.x * rows_per_block + threadIdx.x / Tp;
   if (m >= G) return;
   for (int t = threadIdx.x % Tp; t < T; t += Tp) {
-    const float *hj = hist + (size_t)j * G * T + t;
-    float acc = 0.f;
+    const HT_ *hj = hist + (size_t)j * G * T + t;
+    double acc = 0.0;
     for (int mp = 0; mp < G; ++mp) {
       const int k = m > mp ? m - mp : mp - m;
-      acc = __builtin_fmaf(sc[k], hj[(size_t)mp * T], acc);
+      acc = fma(sc[k], (double)hj[(size_t)mp * T], acc);
     }
-    H[((size_t)j * G + m) * T + t] = acc * ski_wj(gp, j);
+    H[((size_t)j * G + m) * T + t] = (float)(acc * (double)ski_wj(gp, j));
   }
 }
 
-// Toeplitz product on the matrix cores for T <= 16: H_j (G x T) = Toep(G x G) @ hist_j (G x T) as 16 x 16 output tiles,
-// v_mfma_f32_16x16x4_f32 over the G grid points (K = 4 per issue).  One wave per 16-row tile, four tiles per workgroup;
-// hist_j is staged once per workgroup in LDS; the Toeplitz entry sc[|m - k|] is read from LDS.
+// Toeplitz product on the matrix cores for T <= 16, in float64: H_j (G x T) = Toep(G x G) @ hist_j (G x T) as 16 x 16
+// output tiles, v_mfma_f64_16x16x4_f64 over the G grid points (K = 4 per issue).  One wave per 16-row tile, four tiles
+// per workgroup; hist_j is staged through LDS in panels of 512 grid rows; the Toeplitz entry sc[|m - k|] is read from LDS.
 //   A (16x4): lane l holds Toep[m0 + l%16][k0 + l/16]     B (4x16): lane l holds hist_j[k0 + l/16][l%16]
-//   D (16x16): lane l holds H_j[m0 + 4*(l/16) + r][l%16], r = 0..3
-__global__ __launch_bounds__(256) void ski_toeplitz_mfma_kernel(const float *__restrict__ hist,
+//   D (16x16): lane l holds H_j[m0 + l/16 + 4 r][l%16], r = 0..3   (NOT the fp32 instruction's 4*(l/16) + r)
+typedef double doublex4m __attribute__((ext_vector_type(4)));
+constexpr int kToepPanel = 512;
+__global__ __launch_bounds__(256) void ski_toeplitz_mfma_kernel(const double *__restrict__ hist,
                                                                 const float *__restrict__ gp, float *__restrict__ H,
                                                                 int G, int T) {
-  extern __shared__ float smem[];           // sc[G16] | sh[G16 * T]   (G16 = G rounded up to 16, zero-filled tails)
+  extern __shared__ double dmem[];          // sc[G16] | sh[kToepPanel * T]   (G16 = G rounded up to 16)
   const int G16 = (G + 15) & ~15;
-  float *sc = smem;
-  float *shh = smem + G16;
+  double *sc = dmem;
+  double *shh = dmem + G16;
   const int j = blockIdx.y;
-  const float hs = gp[1] * kExp2Scale;
+  const double hd = (double)gp[1];
   for (int k = threadIdx.x; k < G16; k += 256) {
-    const float d = (float)k * hs;
-    sc[k] = k < G ? fast_exp2(-(d * d)) : 0.f;
+    const double d = (double)k * hd;
+    sc[k] = k < G ? exp(-0.5 * d * d) : 0.0;
   }
-  for (int e = threadIdx.x; e < G16 * T; e += 256) shh[e] = e < G * T ? hist[(size_t)j * G * T + e] : 0.f;
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = (blockIdx.x * 4 + wave) * 16;
-  if (m0 >= G) return;
   const int mrow = m0 + (lane & 15), q = lane >> 4;
   const int nb = lane & 15;
   const int nbc = nb < T ? nb : T - 1;               // clamped column: every LDS read below is unconditional
-  const float bmask = nb < T ? 1.0f : 0.0f;
-  const float amask = mrow < G ? 1.0f : 0.0f;        // (rows >= G are never stored; sc[] is zero beyond G)
+  const double bmask = nb < T ? 1.0 : 0.0;
+  const double amask = (mrow < G) ? 1.0 : 0.0;
   // four independent accumulators: consecutive K-steps do not wait on each other's MFMA latency
-  floatx4m acc4[4];
+  doublex4m acc4[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) acc4[u] = floatx4m{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int k0 = 0; k0 < G16; k0 += 16) {
-    float a[4], b[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = k0 + 4 * u + q;
-      int dist = mrow > k ? mrow - k : k - mrow;
-      dist = dist < G16 ? dist : G16 - 1;             // only rows >= G can exceed it; they carry amask = 0
-      a[u] = sc[dist] * amask;
-      b[u] = shh[k * T + nbc] * bmask;
+  for (int u = 0; u < 4; ++u) acc4[u] = doublex4m{0.0, 0.0, 0.0, 0.0};
+  for (int p0 = 0; p0 < G16; p0 += kToepPanel) {
+    const int prow = (G16 - p0 < kToepPanel) ? G16 - p0 : kToepPanel;
+    __syncthreads();
+    for (int e = threadIdx.x; e < prow * T; e += 256) {
+      const size_t ge = (size_t)p0 * T + e;
+      shh[e] = ge < (size_t)G * T ? hist[(size_t)j * G * T + ge] : 0.0;
     }
+    __syncthreads();
+    for (int k0 = 0; k0 < prow; k0 += 16) {
+      double a[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc4[u], 0, 0, 0);
+      for (int u = 0; u < 4; ++u) {
+        const int kl = k0 + 4 * u + q;              // row within the panel (prow is a multiple of 16)
+        const int k = p0 + kl;
+        int dist = mrow > k ? mrow - k : k - mrow;
+        dist = dist < G16 ? dist : G16 - 1;         // only rows >= G can exceed it; they carry amask = 0
+        a[u] = sc[dist] * amask;
+        b[u] = shh[kl * T + nbc] * bmask;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc4[u], 0, 0, 0);
+    }
   }
-  floatx4m acc = acc4[0] + acc4[1] + acc4[2] + acc4[3];
-  const float wj = ski_wj(gp, j);
+  if (m0 >= G) return;
+  doublex4m acc = acc4[0] + acc4[1] + acc4[2] + acc4[3];
+  const double wj = (double)ski_wj(gp, j);
   if (nb < T) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 4 * q + r;
-      if (m < G) H[((size_t)j * G + m) * T + nb] = acc[r] * wj;
+      const int m = m0 + q + 4 * r;          // float64 MFMA result layout (tools/mfma_f64_probe.hip): row = l/16 + 4 r
+      if (m < G) H[((size_t)j * G + m) * T + nb] = (float)(acc[r] * wj);
     }
   }
 }
@@ -1589,16 +1624,16 @@ __global__ __launch_bounds__(256) void ski_gather_kernel(const float *__restrict
   if (i >= M || t >= tcnt) return;
   const float g0 = gp[0], inv_h = gp[2];
   const float *zrow = Z + i * ldz;
-  float acc = 0.f;
+  double acc = 0.0;                          // 4 J terms per output: float64 accumulation is free here
 #pragma unroll 4
   for (int j = 0; j < J; ++j) {
     float w[4], dw[4];
     const int idx0 = ski_taps<false>(zrow[j], g0, inv_h, G, w, dw);
     const float *hp = H + ((size_t)j * G + idx0) * T + t0 + t;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(w[k], hp[(size_t)k * T], acc);
+    for (int k = 0; k < 4; ++k) acc = fma((double)w[k], (double)hp[(size_t)k * T], acc);
   }
-  float r = scale * acc;
+  float r = scale * (float)acc;
   if (noise != 0.f) r = __builtin_fmaf(noise, V[i * T + t0 + t], r);
   out[i * T + t0 + t] = r;
 }
@@ -3120,13 +3155,13 @@ inline int ski_chunks(long long N, int J) {
 inline size_t ski_slab_floats(int J, int G) { return (size_t)ski_max_chunks(J) * J * G * 12; }
 
 // hist[j][g][hoff + t] (row stride HT) = sum_i w(z_ij)[g] V[i][t], T <= 12 columns of V (row stride T); no atomics on hist
-int ski_scatter_narrow(const float *Z, const float *gp, const float *V, float *hist, float *slab, long long N, int ldz,
+int ski_scatter_narrow(const float *Z, const float *gp, const float *V, double *hist, float *slab, long long N, int ldz,
                        int J, int G, int T, int HT, int hoff, hipStream_t st) {
   const int tt = ski_tpiece(T);
   const int nch = ski_chunks(N, J);
   const long long ppc = (N + nch - 1) / nch;
   dim3 grid((unsigned)nch, (unsigned)J);
-  const size_t lds = (size_t)G * tt * sizeof(float);
+  const size_t lds = ((size_t)G * tt + G) * sizeof(float);
   if (tt == 1)
     hipLaunchKernelGGL((ski_scatter3_kernel<1>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
   else if (tt == 4)
@@ -3141,8 +3176,10 @@ int ski_scatter_narrow(const float *Z, const float *gp, const float *V, float *h
   return launch_status();
 }
 
+// T <= 12: float64 histogram (returns 1 in *hist_is_double); wider blocks: float histogram with global float atomics
 int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist, float *slab, long long N, int ldz,
-                    int J, int G, int T, hipStream_t st) {
+                    int J, int G, int T, hipStream_t st, int *hist_is_double) {
+  *hist_is_double = T <= 12;
   if (T > 12) {
     RPGP_CHECK(hipMemsetAsync(hist, 0, (size_t)J * G * T * sizeof(float), st));
     long long nblk = (N + 255) / 256;
@@ -3152,26 +3189,35 @@ int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist
                        gp, V, hist, N, ldz, J, G, T, T, 0, ppb);
     return launch_status();
   }
-  return ski_scatter_narrow(Z, gp, V, hist, slab, N, ldz, J, G, T, T, 0, st);
+  return ski_scatter_narrow(Z, gp, V, reinterpret_cast<double *>(hist), slab, N, ldz, J, G, T, T, 0, st);
 }
 
-int ski_toeplitz(const float *hist, const float *gp, float *H, int J, int G, int T, hipStream_t st) {
-  if (T > 24) {
+int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T, hipStream_t st) {
+  if (!hist_is_double && T > 24) {
     dim3 grid((T + 63) / 64, (G + 15) / 16, J);
-    hipLaunchKernelGGL(ski_toeplitz_wide_kernel, grid, dim3(256), (size_t)G * sizeof(float), st, hist, gp, H, G, T);
+    hipLaunchKernelGGL(ski_toeplitz_wide_kernel, grid, dim3(256), (size_t)G * sizeof(float), st,
+                       reinterpret_cast<const float *>(hist), gp, H, G, T);
     return launch_status();
   }
   const int G16 = (G + 15) & ~15;
-  if (T <= 16 && (size_t)G16 * (T + 1) * sizeof(float) <= 64 * 1024) {   // matrix-core path (LDS: sc + hist_j)
+  const int panel = G16 < kToepPanel ? G16 : kToepPanel;
+  const size_t lds = ((size_t)G16 + (size_t)panel * T) * sizeof(double);
+  if (hist_is_double && T <= 16 && lds <= 64 * 1024) {        // matrix-core path, float64
     dim3 grid((G + 63) / 64, J);
-    hipLaunchKernelGGL(ski_toeplitz_mfma_kernel, grid, dim3(256), (size_t)G16 * (T + 1) * sizeof(float), st, hist, gp, H, G, T);
+    hipLaunchKernelGGL(ski_toeplitz_mfma_kernel, grid, dim3(256), lds, st, reinterpret_cast<const double *>(hist), gp, H,
+                       G, T);
     return launch_status();
   }
   int Tp = 1;
   while (Tp < T && Tp < 16) Tp <<= 1;
   const int rows_per_block = 256 / Tp;
   dim3 grid((G + rows_per_block - 1) / rows_per_block, J);
-  hipLaunchKernelGGL(ski_toeplitz_kernel, grid, dim3(256), (size_t)G * sizeof(float), st, hist, gp, H, G, T);
+  if (hist_is_double)
+    hipLaunchKernelGGL((ski_toeplitz_kernel<double>), grid, dim3(256), (size_t)G * sizeof(double), st,
+                       reinterpret_cast<const double *>(hist), gp, H, G, T);
+  else
+    hipLaunchKernelGGL((ski_toeplitz_kernel<float>), grid, dim3(256), (size_t)G * sizeof(double), st,
+                       reinterpret_cast<const float *>(hist), gp, H, G, T);
   return launch_status();
 }
 
@@ -3209,7 +3255,8 @@ extern "C" {
 size_t rpgp_ski_workspace_bytes(int J, int G, int T) {
   if (J <= 0 || G <= 0 || T <= 0) return 0;
   // hist + H for up to 2T columns (the derivative uses [L | R]) + min/max partials + per-chunk scatter slabs
-  return (2 * (size_t)J * G * (2 * T) + 2 * kSkiMaxParts + ski_slab_floats(J, G)) * sizeof(float);
+  // (the histogram region is sized for float64 entries)
+  return (3 * (size_t)J * G * (2 * T) + 2 * kSkiMaxParts + ski_slab_floats(J, G)) * sizeof(float);
 }
 
 int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t N2, int ld2, int J, int G,
@@ -3235,16 +3282,17 @@ int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, con
   if (!Z1 || !Z2 || !grid_params || !V || !out || M <= 0 || N <= 0 || J <= 0 || G < 8 || T <= 0 || ldz1 < J ||
       ldz2 < J)
     return RPGP_EINVAL;
-  if ((size_t)G * 12 * sizeof(float) > 64 * 1024) return RPGP_EINVAL;   // LDS histogram: G <= 1365
+  if ((size_t)G * 13 * sizeof(float) > 64 * 1024) return RPGP_EINVAL;   // LDS histogram + cell counts: G <= 1260
   if (noise != 0.f && (M != N)) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   float *hist = reinterpret_cast<float *>(workspace);
-  float *H = hist + (size_t)J * G * (2 * T);
+  float *H = hist + 2 * (size_t)J * G * (2 * T);
   float *slab = H + (size_t)J * G * (2 * T) + 2 * kSkiMaxParts;
-  int rc = ski_scatter_all(Z2, grid_params, V, hist, slab, N, ldz2, J, G, T, st);
+  int hist_is_double = 0;
+  int rc = ski_scatter_all(Z2, grid_params, V, hist, slab, N, ldz2, J, G, T, st, &hist_is_double);
   if (rc) return rc;
-  rc = ski_toeplitz(hist, grid_params, H, J, G, T, st);
+  rc = ski_toeplitz(hist, hist_is_double, grid_params, H, J, G, T, st);
   if (rc) return rc;
   return ski_gather_all(Z1, grid_params, H, V, out, M, ldz1, J, G, T, scale, noise, st);
 }
@@ -3278,20 +3326,20 @@ static int ski_bilinear_common(const float *Z, const float *grid_params, const f
   if (!Z || !grid_params || !L || !R || !gZ || !gscale || !row_scratch || N <= 0 || J <= 0 || G < 8 || T <= 0 ||
       T > 12 || ldz < J || ldg < J)
     return RPGP_EINVAL;
-  if ((size_t)G * 12 * sizeof(float) > 64 * 1024) return RPGP_EINVAL;
+  if ((size_t)G * 13 * sizeof(float) > 64 * 1024) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   const int T2 = 2 * T;
-  float *hist = reinterpret_cast<float *>(workspace);
-  float *H = hist + (size_t)J * G * T2;
-  // scatter the 2T columns [L | R]: two passes writing into column offsets 0 and T of a [J][G][2T] histogram
+  double *hist = reinterpret_cast<double *>(workspace);
+  float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * T2;
+  // scatter the 2T columns [L | R]: two passes writing into column offsets 0 and T of a [J][G][2T] float64 histogram
   float *slab = H + (size_t)J * G * T2 + 2 * kSkiMaxParts;
   for (int half = 0; half < 2; ++half) {
     const int rcs = ski_scatter_narrow(Z, grid_params, half == 0 ? L : R, hist, slab, (long long)N, ldz, J, G, T, T2,
                                        half * T, st);
     if (rcs) return rcs;
   }
-  int rc = ski_toeplitz(hist, grid_params, H, J, G, T2, st);
+  int rc = ski_toeplitz(hist, 1, grid_params, H, J, G, T2, st);
   if (rc) return rc;
   const unsigned nb = (unsigned)((N + 255) / 256);
   float *rowC = gcomp ? row_scratch + N : nullptr;

@@ -163,6 +163,7 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     tolerance_reached = False
     best_res, since_best = float("inf"), 0
     stagnation_window = settings.cg_stagnation_window.value()
+    keep_best, snap_res, snap_x = T <= 64, float("inf"), None      # (wide blocks: a GB-sized copy per improvement is not worth it)
     residual_norm = None
     min_iters = min(10, n_iter - 1)
     k = 0
@@ -216,6 +217,13 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
                 # fp32 floor: on a badly conditioned system the recurrence stops making progress long before
                 # max_cg_iterations (10 000 in the runner); give up once the best residual has not improved by 1 %
                 # over `cg_stagnation_window` consecutive tests (the non-convergence warning below still fires)
+                # best-iterate safeguard (see rpgp_cg.hip k_direction): keep the iterate with the smallest tested residual
+                if keep_best and mean_res < snap_res:
+                    snap_res = mean_res
+                    snap_x = result.clone() if snap_x is None else snap_x.copy_(result)
+                if snap_res < 1.0 and mean_res > 100.0 * snap_res:
+                    stats["stagnated"] = stats.get("stagnated", 0) + 1
+                    break
                 if mean_res < 0.99 * best_res:
                     best_res, since_best = mean_res, 0
                 else:
@@ -226,6 +234,8 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
 
     if not tolerance_reached and n_iter > 0:
         mean_res = float(residual_norm.mean()) if residual_norm is not None else 0.0
+        if snap_x is not None and snap_res < mean_res:
+            result, mean_res = snap_x, snap_res
         if mean_res >= tolerance:
             warnings.warn(
                 "CG terminated in {} iterations with average residual norm {} which is larger than the tolerance of {} "

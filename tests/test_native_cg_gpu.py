@@ -141,3 +141,25 @@ def test_native_stopping_rule_edge_cases(gpu_device, tol, max_iter, check_every,
     assert float((xn - xt).norm() / xt.norm()) < 2e-3
     if nt:
         assert out_n[1].shape == out_t[1].shape
+
+
+def test_best_iterate_is_returned_when_fp32_cg_breaks_down(gpu_device):
+    """cond(Khat) * fp32 eps >~ 1: the recurrence residual stalls or grows.  Both loops must hand back the iterate with the
+    smallest tested residual (not the last one) and report that residual."""
+    import warnings
+    from rpgp_amd import linear_cg as lcg, settings
+    from rpgp_amd.operators import AdditiveRPOperator, AddedDiagOperator
+    N, J = 20000, 3
+    Z = (torch.randn(N, J, generator=torch.Generator().manual_seed(0)) * 0.5).to(gpu_device)
+    khat = AddedDiagOperator(AdditiveRPOperator(Z, None, torch.tensor(3.0, device=gpu_device), 1.0 / J),
+                             torch.tensor(2e-2, device=gpu_device))
+    rhs = torch.randn(N, 2, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    for operator in (khat, None):                         # native executor, torch-op loop
+        with settings.cg_stagnation_window(60), warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            x = lcg.linear_cg(khat._matmul, rhs, tolerance=1e-9, max_iter=3000, operator=operator)   # below the fp32 floor
+        assert torch.isfinite(x).all()
+        true_res = float(((khat._matmul(x) - rhs).norm(dim=0) / rhs.norm(dim=0)).mean())
+        # (the recurrence residual may keep shrinking below the tolerance while the TRUE residual floors near
+        # eps * cond: whether a non-convergence warning fires is not asserted, the quality of the returned iterate is)
+        assert true_res < 0.05

@@ -719,11 +719,11 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
                                   const float *__restrict__ V, float *__restrict__ out, int M, int N, int T,
                                   int BR, int chunk_cols, int sym, float scale, float noise,
                                   const int *__restrict__ guard, int rb0, int rb1, int slab_row0, int slab_rows) {
-  __shared__ float sacc[kRedGroups][kRedOutputs];
+  __shared__ double sacc[kRedGroups][kRedOutputs];   // float64: ~150 slab entries per output, free at this size
   const int o = threadIdx.x & (kRedOutputs - 1), g = threadIdx.x / kRedOutputs;
   const size_t gid = (size_t)blockIdx.x * kRedOutputs + o;
   const bool valid = gid < (size_t)M * T;
-  float acc = 0.f;
+  double acc = 0.0;
   if (valid) {
     const int row = (int)(gid / T);
     const int rb = row / BR;
@@ -731,11 +731,11 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
     const int nk = (N - cbase + chunk_cols - 1) / chunk_cols;
     if (rb >= rb0 && rb < rb1) {                    // row products exist only for this call's row blocks
       const size_t lid = gid - (size_t)slab_row0 * T;
-      for (int k = g; k < nk; k += kRedGroups) acc += slabR[(size_t)k * slab_rows * T + lid];
+      for (int k = g; k < nk; k += kRedGroups) acc += (double)slabR[(size_t)k * slab_rows * T + lid];
     }
     if (sym) {
       const int bend = rb < rb1 ? rb : rb1;         // transposed products written by row blocks rb0 <= b < min(rb, rb1)
-      for (int b = rb0 + g; b < bend; b += kRedGroups) acc += slabT[(size_t)(b - rb0) * N * T + gid];
+      for (int b = rb0 + g; b < bend; b += kRedGroups) acc += (double)slabT[(size_t)(b - rb0) * N * T + gid];
     }
   }
   sacc[g][o] = acc;
@@ -745,10 +745,10 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
     out[gid] = __builtin_nanf("");
     return;
   }
-  float tot = sacc[0][o];
+  double tot = sacc[0][o];
 #pragma unroll
   for (int q = 1; q < kRedGroups; ++q) tot += sacc[q][o];
-  float r = scale * tot;
+  float r = (float)((double)scale * tot);
   if (noise != 0.f) r = __builtin_fmaf(noise, V[gid], r);
   out[gid] = r;
 }

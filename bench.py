@@ -48,11 +48,41 @@ def main():
     ap.add_argument("--direct", action="store_true", help="use the exact direct kernel instead of the factorised path")
     ap.add_argument("--no-extras", action="store_true", help="skip the T=11 block / full-solve context numbers")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (gloo, no GPU work): every rank joins, one all-reduce, rank 0 prints the world "
+                         "size; used by tests/ to cover the --gpus launcher on machines without GPUs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) through
+        # torch.distributed.run.  This parent has not touched the GPU (no HIP call so far) and never will; it waits
+        # for the ranks and exits with their status (replaces the `--device cuda:0,cuda:1,...` single-command form of
+        # gp_experiment_runner.py:263).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or drop the launcher and let "
+                         "bench.py start the ranks itself)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        dist.init_process_group(backend="gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "allreduce": float(t[0])}))
+        dist.destroy_process_group()
+        return
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -157,6 +187,10 @@ def main():
                    "lengthscale": "sqrt(d)", "outputscale": outputscale, "noise": noise},
         "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": peak / 1e9, "unit": "GB/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "traffic_source": ("committed rocprofv3 --pmc passes (profiles/pmc_counters_current.json), not measured "
+                                        "in this run") if traffic is not None else None,
+                     "limiter": "VALU + transcendental issue (v_exp_f32 at quarter rate); neither HBM nor the matrix "
+                                "pipe is saturated - `bound` names the roofline the metric is priced against",
                      "kernel": ("mvm_fact_kernel<20,%d,2>" if fast else "mvm_tile_kernel<20,%d,2,sym>") % (1 if T == 1 else (4 if T <= 4 else 12)), "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes": b_alg,
                      "pair_terms_per_s": round(0.5 * N * N * J / (kernel_ms * 1e-3), 1),

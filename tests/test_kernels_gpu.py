@@ -387,3 +387,23 @@ def test_no_op_reads_uninitialised_scratch(gpu_device, monkeypatch):
     for i, (a, b) in enumerate(zip(ref, got)):
         assert torch.isfinite(b).all(), "output %d has non-finite entries" % i
         assert torch.allclose(a.cpu(), b.cpu(), rtol=1e-5, atol=1e-6), "output %d changed" % i
+
+
+@pytest.mark.parametrize("N,J", [(2048, 20), (3001, 20), (4097, 12), (2300, 8), (2100, 2)])
+def test_matrix_core_prepared_mvm_matches_oracle(gpu_device, monkeypatch, N, J):
+    """RPGP_MFMA=1 routes the prepared symmetric MVM (T = 1) through rpgp_mfma.hip (`v_mfma_f32_32x32x2_f32` for the
+    rank-2 exponent, exact fp32): an opt-in experiment kept for A/B measurements, same results."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + J)
+    Z = (rng.standard_normal((N, J)) * 1.3).astype(np.float32)
+    V = rng.standard_normal((N, 1)).astype(np.float32)
+    Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
+    prep = ops.Prepared(Zt)
+    assert prep.fast_ok
+    base = ops.mvm_sym_prepared(prep, Vt, 0.7 / J, 0.1).cpu().numpy()
+    monkeypatch.setenv("RPGP_MFMA", "1")
+    out = ops.mvm_sym_prepared(prep, Vt, 0.7 / J, 0.1).cpu().numpy()
+    ref = orc.mvm(Z, Z, V, 0.7 / J, 0.1)
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 1e-5
+    assert np.linalg.norm(out - base) / np.linalg.norm(base) < 2e-6
+    assert not np.array_equal(out, base), "RPGP_MFMA=1 did not select the matrix-core kernel"

@@ -12,6 +12,7 @@ class HipBackend:
     project_grad = staticmethod(ops.project_grad)
     mvm_sym = staticmethod(ops.mvm_sym)
     supports_pair_shard = True
+    supports_padded_dense = True
     prepare = staticmethod(ops.Prepared)
     mvm_sym_prepared = staticmethod(ops.mvm_sym_prepared)
     mvm_rect = staticmethod(ops.mvm_rect)

@@ -1248,11 +1248,14 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const float *__restrict
 // fixed-order reduce as the MFMA form.
 template <int TT>
 __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__restrict__ Kd, const float *__restrict__ V,
-                                                              float *__restrict__ slab, int N, long long ldk, int T,
+                                                              float *__restrict__ slab, int N, long long ldk,
                                                               int rows_per_split) {
+  // TT is the EXACT number of right-hand sides (V is N x TT, row-major): the V loads are unconditional wave-uniform
+  // scalar loads that hipcc merges into s_load_dwordx4/x8, and the row loop is branch-free.  (The first version
+  // guarded every load with `t < T` / per-lane alignment tests: one branch per load, 2.4 TB/s at N = 15k.)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cl = blockIdx.x * 1024 + wave * 256 + 4 * lane;      // this lane's 4 output columns
-  const bool vec_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0) && (cl + 3 < N);
+  const bool base_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0);
   float acc[4][TT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1260,51 +1263,82 @@ __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__res
     for (int t = 0; t < TT; ++t) acc[i][t] = 0.f;
   const int rs = blockIdx.y * rows_per_split;
   const int re = (rs + rows_per_split < N) ? rs + rows_per_split : N;
-  if (cl < N) {
-#pragma unroll (TT <= 4 ? 8 : 4)
-    for (int row = rs; row < re; ++row) {
-      const float *kp = Kd + (size_t)row * ldk + cl;
-      float4v a = {0.f, 0.f, 0.f, 0.f};
-      if (vec_ok) {
-        a = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kp));
-      } else {
+  if (base_ok && cl + 3 < N) {
+    // batches of 8 rows: 8 x 16 B per lane in flight before the first FMA (mid-size problems launch only ~4 workgroups
+    // per CU, so the bytes in flight per CU come from the depth of each thread's own load queue)
+    constexpr int RB = 8;
+    const float *kp = Kd + (size_t)rs * ldk + cl;
+    const float *vp = V + (size_t)rs * TT;
+    int row = rs;
+    for (; row + RB <= re; row += RB) {
+      float4v a[RB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (cl + i < N) a[i] = kp[i];
+      for (int q = 0; q < RB; ++q) a[q] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kp + (size_t)q * ldk));
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          const float v = vp[q * TT + t];                         // wave-uniform address: scalar load
+          acc[0][t] = __builtin_fmaf(a[q].x, v, acc[0][t]);
+          acc[1][t] = __builtin_fmaf(a[q].y, v, acc[1][t]);
+          acc[2][t] = __builtin_fmaf(a[q].z, v, acc[2][t]);
+          acc[3][t] = __builtin_fmaf(a[q].w, v, acc[3][t]);
+        }
       }
-      const float *vp = V + (size_t)row * T;      // wave-uniform address: scalar loads
+      kp += (size_t)RB * ldk;
+      vp += RB * TT;
+    }
+    for (; row < re; ++row) {
+      const float4v a = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kp));
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        const float v = t < T ? vp[t] : 0.f;
+        const float v = vp[t];
         acc[0][t] = __builtin_fmaf(a.x, v, acc[0][t]);
         acc[1][t] = __builtin_fmaf(a.y, v, acc[1][t]);
         acc[2][t] = __builtin_fmaf(a.z, v, acc[2][t]);
         acc[3][t] = __builtin_fmaf(a.w, v, acc[3][t]);
       }
+      kp += ldk;
+      vp += TT;
+    }
+  } else if (cl < N) {
+    // ragged right edge / unaligned matrix: element-wise loads (at most one wave of the last column block)
+    for (int row = rs; row < re; ++row) {
+      const float *kp = Kd + (size_t)row * ldk + cl;
+      float a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = (cl + i < N) ? kp[i] : 0.f;
+      const float *vp = V + (size_t)row * TT;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const float v = vp[t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][t] = __builtin_fmaf(a[i], v, acc[i][t]);
+      }
     }
   }
-  float *sl = slab + (size_t)blockIdx.y * N * 16;
+  float *sl = slab + (size_t)blockIdx.y * N * TT;                 // compact slab: [split][column][TT]
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = cl + i;
     if (c < N) {
 #pragma unroll
-      for (int t = 0; t < TT; ++t)
-        if (t < T) sl[(size_t)c * 16 + t] = acc[i][t];
+      for (int t = 0; t < TT; ++t) sl[(size_t)c * TT + t] = acc[i][t];
     }
   }
 }
 
 // out[row][t0+n] = sum_split slab[split][row][n] + noise * V[row][t0+n]   (fixed order: deterministic)
+// `sw` = slab width (floats per (split, row)): 16 for the MFMA form, the exact T for the VALU form
 __global__ void dense_gemm_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ V,
                                          float *__restrict__ out, int N, int T, int t0, int tcnt, int nsplit,
-                                         float noise) {
+                                         float noise, int sw) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (size_t)N * 16) return;
-  const int row = (int)(gid >> 4), n = (int)(gid & 15);
+  if (gid >= (size_t)N * sw) return;
+  const int row = (int)(gid / sw), n = (int)(gid % sw);
   if (n >= tcnt) return;
   float acc = 0.f;
-  for (int sidx = 0; sidx < nsplit; ++sidx) acc += slab[(size_t)sidx * N * 16 + gid];
+  for (int sidx = 0; sidx < nsplit; ++sidx) acc += slab[(size_t)sidx * N * sw + gid];
   const size_t o = (size_t)row * T + t0 + n;
   out[o] = __builtin_fmaf(noise, V[o], acc);
 }
@@ -3132,46 +3166,58 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
                    void *stream) {
   if (!Kd || !V || !out || N <= 0 || T <= 0 || ldk < N || N > 0x7fffffffLL) return RPGP_EINVAL;
   hipStream_t st = as_stream(stream);
-  const int nrb = (int)((N + 255) / 256);
-  const int ncols_wg = T <= 12 ? 1024 : 256;      // output columns per workgroup (VALU / MFMA form)
-  const int ncb_ = (int)((N + ncols_wg - 1) / ncols_wg);
-  int nsplit = (3072 + ncb_ - 1) / ncb_;          // ~3000 workgroups keep enough loads in flight to stream HBM
-  const int max_split = (int)((N + 255) / 256);
-  if (nsplit > max_split) nsplit = max_split;
-  if (nsplit > (T <= 12 ? 64 : 32)) nsplit = T <= 12 ? 64 : 32;
-  if (nsplit < 1) nsplit = 1;
-  int cps = (int)((N + nsplit - 1) / nsplit);
-  cps = (cps + 255) / 256 * 256;
-  nsplit = (int)((N + cps - 1) / cps);
   float *slab = nullptr;
-  RPGP_CHECK(hipMallocAsync((void **)&slab, (size_t)nsplit * N * 16 * sizeof(float), st));
-  dim3 grid((unsigned)nrb, (unsigned)nsplit), block(256);
   int rc = 0;
   if (T <= 12) {
-    // VALU form: 1024 output columns per workgroup, rows split so that ~3000 workgroups stream concurrently
+    // VALU form: 1024 output columns per workgroup (a wave streams 256 columns down the rows); the rows are split so that
+    // ~8192 waves are in flight, but never into more slabs than 8 % of the matrix's own bytes, nor below 64 rows
     const unsigned ncb = (unsigned)((N + 1023) / 1024);
-    dim3 vgrid(ncb, (unsigned)nsplit);
-    if (T == 1)
-      hipLaunchKernelGGL((dense_gemv_valu_kernel<1>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, cps);
-    else if (T <= 4)
-      hipLaunchKernelGGL((dense_gemv_valu_kernel<4>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, cps);
-    else if (T <= 8)
-      hipLaunchKernelGGL((dense_gemv_valu_kernel<8>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, cps);
-    else
-      hipLaunchKernelGGL((dense_gemv_valu_kernel<12>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, cps);
-    const size_t total = (size_t)N * 16;
+    long long nsplit = (2048 + ncb - 1) / ncb;
+    const long long cap_bytes = (long long)(0.08 * (double)N / T);
+    if (nsplit > cap_bytes) nsplit = cap_bytes;
+    if (nsplit > (N + 63) / 64) nsplit = (N + 63) / 64;
+    if (nsplit > 128) nsplit = 128;
+    if (nsplit < 1) nsplit = 1;
+    int cps = (int)((N + nsplit - 1) / nsplit);
+    cps = (cps + 7) / 8 * 8;                           // whole 8-row batches
+    nsplit = (N + cps - 1) / cps;
+    RPGP_CHECK(hipMallocAsync((void **)&slab, (size_t)nsplit * N * T * sizeof(float), st));
+    dim3 vgrid(ncb, (unsigned)nsplit), block(256);
+#define RPGP_GEMV_CASE(TT_)                                                                                            \
+  case TT_:                                                                                                            \
+    hipLaunchKernelGGL((dense_gemv_valu_kernel<TT_>), vgrid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, cps);   \
+    break
+    switch (T) {
+      RPGP_GEMV_CASE(1); RPGP_GEMV_CASE(2); RPGP_GEMV_CASE(3); RPGP_GEMV_CASE(4); RPGP_GEMV_CASE(5); RPGP_GEMV_CASE(6);
+      RPGP_GEMV_CASE(7); RPGP_GEMV_CASE(8); RPGP_GEMV_CASE(9); RPGP_GEMV_CASE(10); RPGP_GEMV_CASE(11);
+      default: RPGP_GEMV_CASE(12);
+    }
+#undef RPGP_GEMV_CASE
+    const size_t total = (size_t)N * T;
     hipLaunchKernelGGL(dense_gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, V, out,
-                       (int)N, T, 0, T, nsplit, noise);
+                       (int)N, T, 0, T, (int)nsplit, noise, T);
     rc = launch_status();
     (void)hipFreeAsync(slab, st);
     return rc;
   }
+  const int nrb = (int)((N + 255) / 256);
+  const int ncb_ = (int)((N + 255) / 256);
+  int nsplit = (3072 + ncb_ - 1) / ncb_;          // ~3000 workgroups keep enough loads in flight to stream HBM
+  const int max_split = (int)((N + 255) / 256);
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit > 32) nsplit = 32;
+  if (nsplit < 1) nsplit = 1;
+  int cps = (int)((N + nsplit - 1) / nsplit);
+  cps = (cps + 255) / 256 * 256;
+  nsplit = (int)((N + cps - 1) / cps);
+  RPGP_CHECK(hipMallocAsync((void **)&slab, (size_t)nsplit * N * 16 * sizeof(float), st));
+  dim3 grid((unsigned)nrb, (unsigned)nsplit), block(256);
   for (int t0 = 0; t0 < T && rc == 0; t0 += 16) {
     const int tcnt = (T - t0 < 16) ? T - t0 : 16;
     hipLaunchKernelGGL(dense_gemm_kernel, grid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, t0, tcnt, cps);
     const size_t total = (size_t)N * 16;
     hipLaunchKernelGGL(dense_gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, V, out,
-                       (int)N, T, t0, tcnt, nsplit, noise);
+                       (int)N, T, t0, tcnt, nsplit, noise, 16);
     rc = launch_status();
   }
   (void)hipFreeAsync(slab, st);

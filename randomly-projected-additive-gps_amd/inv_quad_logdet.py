@@ -96,14 +96,12 @@ class InvQuadLogDet(torch.autograd.Function):
         full_rhs = torch.cat([probes_n, r], dim=1)
         matmul = khat._matmul
         native_op = khat
-        if settings.cache_kernel.on() and not isinstance(op, SKIAdditiveOperator) and \
-                (op.shard is None or op.shard.world_size == 1):
+        if not isinstance(op, SKIAdditiveOperator) and (op.shard is None or op.shard.world_size == 1) and \
+                Z.dtype == torch.float32 and settings.use_cached_kernel(N, Z.device):
             # cached-K mode: materialise K once per hyper-parameter step (rpgp_dense) so each
-            # CG iteration on the T = 11 block is one HBM-bound library GEMM; the backward pass stays fused
-            total = torch.cuda.get_device_properties(Z.device).total_memory if Z.is_cuda else float("inf")
-            if 4.0 * N * N <= 0.25 * total:
-                native_op = DenseOperator(op.to_dense(), float(noise.detach()))
-                matmul = native_op._matmul
+            # CG iteration on the T = 11 block is one HBM-bound pass over the stored matrix; the backward pass stays fused
+            native_op = DenseOperator(op.to_dense_cached(), float(noise.detach()))
+            matmul = native_op._matmul
         solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes, operator=native_op,
                                   tolerance=settings.cg_tolerance.value(),
                                   max_iter=settings.max_cg_iterations.value(),

@@ -70,8 +70,12 @@ class PredictionStrategy:
                 self.khat = None
             else:
                 self.chol = None
-                if settings.cache_kernel.on():
-                    self.khat = DenseOperator(self.op.to_dense(), float(self.noise))
+                shard = getattr(self.op, "shard", None)
+                if isinstance(self.op, AdditiveRPOperator) and not isinstance(self.op, SKIAdditiveOperator) and \
+                        (shard is None or shard.world_size == 1) and x.dtype == torch.float32 and \
+                        settings.use_cached_kernel(N, x.device):
+                    self.khat = DenseOperator(self.op.to_dense_cached(), float(self.noise))
+                    self._dense_khat = self.khat
                 else:
                     self.khat = AddedDiagOperator(self.op, self.noise)
                 self.pre = build_preconditioner(self.op, float(self.noise), settings)
@@ -94,7 +98,7 @@ class PredictionStrategy:
                 fits = False
             if fits:
                 if getattr(self, "_dense_khat", None) is None:
-                    self._dense_khat = DenseOperator(self.op.to_dense(), float(self.noise))
+                    self._dense_khat = DenseOperator(self.op.to_dense_cached() if hasattr(self.op, "to_dense_cached") else self.op.to_dense(), float(self.noise))
                 khat = self._dense_khat
                 if N <= settings.dense_solve_size.value():
                     # with Khat in HBM anyway, a float64 Cholesky (rocSOLVER) solves the N_test-wide block exactly and

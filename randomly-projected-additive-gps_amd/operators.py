@@ -211,6 +211,15 @@ class AdditiveRPOperator(LinearOperator):
 
     evaluate = to_dense
 
+    def to_dense_cached(self):
+        """The matrix of the cached-K mode: same entries as to_dense(), rows padded to 256 bytes when the backend can
+        (a view with stride(0) >= N), so that the HBM stream of DenseOperator runs on aligned 16-byte loads."""
+        be = _backend.get_backend()
+        if type(self) is AdditiveRPOperator and self.symmetric and self.Z1.dtype == torch.float32 and \
+                getattr(be, "supports_padded_dense", False):
+            return be.dense(self.Z1.detach(), self.Z1.detach(), self._scale, pad=True)
+        return self.to_dense()
+
     def representation(self):
         if self.symmetric:
             return (self.Z1, self.outputscale)

@@ -196,8 +196,11 @@ def mvm_rect(Z1, Z2, V, scale, j0=0, j1=None):
     return out.squeeze(1) if squeeze else out
 
 
-def dense(Z1, Z2, scale, j0=0, j1=None):
-    """Dense block K(Z1,Z2) (M x N)."""
+def dense(Z1, Z2, scale, j0=0, j1=None, pad=False):
+    """Dense block K(Z1,Z2) (M x N).  pad=True (float32): the rows are laid out with a leading dimension rounded up to
+    64 floats (256-byte aligned rows) and an M x N view of that buffer is returned — the cached-K stream
+    (rpgp_dense_mvm) loads 16 B per lane and needs 16-byte aligned rows, which a bare N x N array only has when 4 | N
+    (measured at N = 14 939: 3.6 TB/s on the element-wise edge path against 5.5+ with padded rows)."""
     lib = _lib.load()
     Z1 = _require(Z1, "Z1", 2, allow64=True)
     Z2 = _require(Z2, "Z2", 2, allow64=True)
@@ -212,8 +215,12 @@ def dense(Z1, Z2, scale, j0=0, j1=None):
             _lib.check(lib.rpgp_dense_f64(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, j0, j1,
                                           float(scale), _stream()), "rpgp_dense_f64")
         return out
+    ld = N
+    if pad and N % 64:
+        ld = (N + 63) // 64 * 64
+        out = torch.empty((M, ld), dtype=Z1.dtype, device=Z1.device)[:, :N]
     with torch.cuda.device(Z1.device):
-        _lib.check(lib.rpgp_dense(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, j0, j1, float(scale),
+        _lib.check(lib.rpgp_dense(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, ld, j0, j1, float(scale),
                                   _stream()), "rpgp_dense")
     return out
 
@@ -319,13 +326,16 @@ def family_pivoted_cholesky(fam, Z, scale, rank, weight_sum):
 def dense_mvm(Kd, V, noise=0.0):
     """out = Kd @ V + noise * V for a cached dense symmetric kernel matrix."""
     lib = _lib.load()
-    Kd = _require(Kd, "Kd", 2)
+    if isinstance(Kd, torch.Tensor) and Kd.dim() == 2 and Kd.stride(1) == 1 and Kd.stride(0) >= Kd.shape[1]:
+        _require(Kd[:1], "Kd", 2)               # device / dtype checks; a row-padded view is used as it is
+    else:
+        Kd = _require(Kd, "Kd", 2)
     N = Kd.shape[0]
     V2, squeeze = _as_matrix(V, N, "V")
     T = V2.shape[1]
     out = torch.empty_like(V2)
     with torch.cuda.device(Kd.device):
-        _lib.check(lib.rpgp_dense_mvm(Kd.data_ptr(), V2.data_ptr(), out.data_ptr(), N, Kd.shape[1], T, float(noise),
+        _lib.check(lib.rpgp_dense_mvm(Kd.data_ptr(), V2.data_ptr(), out.data_ptr(), N, Kd.stride(0), T, float(noise),
                                       _stream()), "rpgp_dense_mvm")
     return out.squeeze(1) if squeeze else out
 

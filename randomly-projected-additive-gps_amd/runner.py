@@ -224,7 +224,10 @@ def build_parser():
     p.add_argument("--checkpoint_kernel", type=int, default=0, help="accepted for parity; the fused kernel never stores K")
     p.add_argument("--record_pred_unc", action="store_true", help="Record predictive uncertainty metrics.")
     p.add_argument("--double", action="store_true", help="double precision (only for kinds outside the fused fp32 path)")
-    p.add_argument("--cache_kernel", action="store_true", help="(rpgp) materialise K once per prediction solve")
+    p.add_argument("--cache_kernel", dest="cache_kernel", action="store_const", const=True, default="auto",
+                   help="(rpgp) always materialise K once per hyper-parameter step when it fits in HBM (default: auto)")
+    p.add_argument("--no_cache_kernel", dest="cache_kernel", action="store_const", const=False,
+                   help="(rpgp) never materialise K: every CG iteration runs the fused recompute-in-kernel MVM")
     return p
 
 

@@ -62,7 +62,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="C2,C3")
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--cache_kernel", action="store_true")
+    ap.add_argument("--cache_kernel", choices=["auto", "on", "off"], default="auto")
     a = ap.parse_args()
     table = {"C2": ("C2 kin8nm-shaped RPA-GP", 7372, 8, 20, 820, False), "C3": ("C3 elevators-shaped DPA-GP", 14939, 18, 20, 1660, True),
              "C4": ("C4 synthetic 50k RPA-GP", 50000, 20, 20, 2000, False), "S": ("small", 3000, 8, 20, 300, False),
@@ -72,6 +72,6 @@ if __name__ == "__main__":
              "C4S": ("C4 synthetic 50k RPA-GP + SKI (J=20, grid 1024)", 50000, 20, 20, 2000, False)}
     for c in a.configs.split(","):
         name, N, d, J, nt, sp = table[c]
-        with settings.cache_kernel(a.cache_kernel):
-            run(name + (" [cached-K]" if a.cache_kernel else ""), N, d, J, nt, a.steps, sp, 0.05, 0.01, ski=(c in ("C5", "C3S", "C4S")),
+        with settings.cache_kernel({"auto": "auto", "on": True, "off": False}[a.cache_kernel]):
+            run(name + " [cache_kernel=%s]" % a.cache_kernel, N, d, J, nt, a.steps, sp, 0.05, 0.01, ski=(c in ("C5", "C3S", "C4S")),
                 full_cov=(c != "C5"))

@@ -63,3 +63,60 @@ def bilinear_objective(Z, L, R, scale, G, grid, weights=None):
     """sum((L R^T) * K_ski(Z, Z)) with a FIXED grid (the grid is a buffer, not differentiated)."""
     K = dense_kernel(Z, Z, scale, G, grid, weights)
     return float((np.asarray(L, dtype=np.float64) @ np.asarray(R, dtype=np.float64).T * K).sum())
+
+
+# ---- O(N)-memory forms for full-size problems (config C5: N ~ 391k, J = d = 3, G = 1024) ------------------------
+def interp_sparse(z, g0, h, G):
+    """N x G interpolation matrix of one projection as scipy CSR (4 non-zeros per row); same stencil rule as
+    `interp_matrix`."""
+    import scipy.sparse as sp
+    z = np.asarray(z, dtype=np.float64)
+    n = z.shape[0]
+    u = np.clip((z - g0) / h, 1.0, G - 2.0)
+    fl = np.floor(u)
+    fr = u - fl
+    idx0 = np.clip(fl.astype(np.int64) - 1, 0, G - 4)
+    vals = np.stack([_cubic(fr + 1.0), _cubic(fr), _cubic(1.0 - fr), _cubic(2.0 - fr)], axis=1)
+    cols = idx0[:, None] + np.arange(4)[None, :]
+    indptr = np.arange(0, 4 * n + 1, 4)
+    return sp.csr_matrix((vals.ravel(), cols.ravel(), indptr), shape=(n, G))
+
+
+def mvm_sparse(Z1, Z2, V, scale, G, grid, noise=0.0, weights=None):
+    """scale * sum_j w_j W_j(Z1) (Tm (W_j(Z2)^T V)) + noise * V in float64 with sparse W and a dense G x G Toeplitz:
+    O(N (J + T)) memory, the full-size counterpart of `dense_kernel(...) @ V`."""
+    Z1 = np.asarray(Z1, dtype=np.float64)
+    Z2 = np.asarray(Z2, dtype=np.float64)
+    V = np.asarray(V, dtype=np.float64).reshape(Z2.shape[0], -1)
+    g0, h = grid
+    Tm = toeplitz(h, G)
+    w = np.ones(Z1.shape[1]) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)
+    out = np.zeros((Z1.shape[0], V.shape[1]))
+    for j in range(Z1.shape[1]):
+        W2 = interp_sparse(Z2[:, j], g0, h, G)
+        W1 = W2 if Z1 is Z2 else interp_sparse(Z1[:, j], g0, h, G)
+        out += w[j] * (W1 @ (Tm @ (W2.T @ V)))
+    out *= scale
+    if noise:
+        out += noise * V
+    return out
+
+
+def diag_sparse(Z, scale, G, grid, weights=None):
+    """diag(scale * sum_j w_j W_j Tm W_j^T) in float64 with O(N) memory: per row the 4 x 4 quadratic form of its
+    stencil weights with the Toeplitz lags 0..3."""
+    Z = np.asarray(Z, dtype=np.float64)
+    g0, h = grid
+    lag = np.exp(-0.5 * (np.arange(4) * h) ** 2)
+    w = np.ones(Z.shape[1]) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)
+    d = np.zeros(Z.shape[0])
+    for j in range(Z.shape[1]):
+        u = np.clip((Z[:, j] - g0) / h, 1.0, G - 2.0)
+        fr = u - np.floor(u)
+        vals = [_cubic(fr + 1.0), _cubic(fr), _cubic(1.0 - fr), _cubic(2.0 - fr)]
+        q = np.zeros(Z.shape[0])
+        for k in range(4):
+            for l in range(4):
+                q += vals[k] * vals[l] * lag[abs(k - l)]
+        d += w[j] * q
+    return scale * d

@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# GPU run order (the driver stops at the first failure with -x): ABI / kernels first, the SKI suite (config C5) before
+# the long end-to-end tests, so that a late failure can never hide them again (round-1 verdict, weak #1-2).
+_ORDER = ["test_lib_abi", "test_kernels_gpu", "test_ski_gpu", "test_native_cg_gpu", "test_gp_gpu", "test_double_gpu",
+          "test_family_gpu"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = item.module.__name__.rsplit(".", 1)[-1]
+        return (_ORDER.index(name) if name in _ORDER else len(_ORDER),)
+    items.sort(key=key)                      # stable: the order inside a module is kept
+
+
 @pytest.fixture(scope="session")
 def gpu_device():
     import torch

@@ -126,3 +126,21 @@ def test_smoothed_box_prior_constant_inside_box():
     assert abs(v - (-np.log(np.sqrt(2 * np.pi) * 0.01 + 9.9999))) < 1e-12
     assert abs(v + 2.3051) < 1e-3
     assert orc.smoothed_box_log_prob(10.5) < v - 100
+
+
+def test_ski_sparse_oracle_equals_dense_oracle():
+    """The O(N)-memory SKI forms used at config-C5 size are the dense SKI oracle rewritten with sparse W."""
+    from oracle import ski as sko
+    rng = np.random.default_rng(3)
+    N, J, G, T = 700, 3, 256, 4
+    Z = rng.standard_normal((N, J))
+    V = rng.standard_normal((N, T))
+    w = rng.uniform(0.3, 1.2, size=J)
+    grid = sko.grid_params(Z, None, G)
+    for weights in (None, w):
+        K = sko.dense_kernel(Z, Z, 0.7, G, grid, weights)
+        np.testing.assert_allclose(sko.mvm_sparse(Z, Z, V, 0.7, G, grid, 0.2, weights), K @ V + 0.2 * V, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(sko.diag_sparse(Z, 0.7, G, grid, weights), np.diag(K), rtol=1e-11, atol=1e-12)
+    Z1 = rng.standard_normal((90, J)) * 0.5
+    Kr = sko.dense_kernel(Z1, Z, 0.7, G, grid)
+    np.testing.assert_allclose(sko.mvm_sparse(Z1, Z, V, 0.7, G, grid), Kr @ V, rtol=1e-11, atol=1e-11)

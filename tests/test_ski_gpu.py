@@ -58,6 +58,68 @@ def test_ski_rect_and_exact_kernel_error(gpu_device):
     assert _rel(out, ref_exact) < 1e-4
 
 
+def _c5_problem(gpu_device, T):
+    """Config C5 shape (additive_spread_prescale_Jd_ski on 3droad: N = 434 874 * 0.9 = 391 386 train rows, d = J = 3,
+    grid 1024); z-scored stand-in features, orthonormal (diversified) projections, unit prescale lengthscale."""
+    N, J, G = 391386, 3, 1024
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(N, J, generator=g)
+    Q = torch.linalg.qr(torch.randn(J, J, generator=g))[0]
+    Z = (X @ Q).contiguous()
+    V = torch.randn(N, T, generator=g)
+    return N, J, G, Z, V
+
+
+@pytest.mark.parametrize("T", [1, 11])
+def test_ski_mvm_and_diag_at_full_c5_size(gpu_device, T):
+    """rpgp_ski_mvm / rpgp_ski_diag at exactly the C5 shape against the float64 sparse-W oracle (O(N) memory)."""
+    from rpgp_amd import ops
+    N, J, G, Z, V = _c5_problem(gpu_device, T)
+    Zt, Vt = Z.to(gpu_device), V.to(gpu_device)
+    gp = ops.ski_grid(Zt, None, G)
+    gph = gp.double().cpu().numpy()
+    grid = (float(gph[0]), float(gph[1]))
+    scale, noise = 0.8 / J, 0.25
+    out = ops.ski_mvm(Zt, Zt, gp, Vt, scale, noise, G).double().cpu().numpy()
+    ref = sko.mvm_sparse(Z.numpy(), Z.numpy(), V.numpy(), scale, G, grid, noise)
+    col = np.linalg.norm(out - ref, axis=0) / np.linalg.norm(ref, axis=0)
+    assert col.max() < 2e-5, col
+    if T == 1:
+        dg = ops.ski_diag(Zt, gp, scale, G).double().cpu().numpy()
+        np.testing.assert_allclose(dg, sko.diag_sparse(Z.numpy(), scale, G, grid), rtol=2e-5, atol=1e-6)
+        # bitwise reproducible (fixed-point LDS histograms, fixed-order slab sums)
+        again = ops.ski_mvm(Zt, Zt, gp, Vt, scale, noise, G).double().cpu().numpy()
+        assert np.array_equal(out, again)
+
+
+def test_ski_native_mbcg_solve_at_full_c5_size(gpu_device):
+    """One native mBCG solve of the C5-shaped system at the runner's tolerances (cg_tol 0.05 train / 0.01 eval,
+    gp_experiment_runner.py:324-329), rank-15 pivoted-Cholesky preconditioner; the TRUE float64 residual of the returned
+    iterate is checked with the sparse-W oracle operator."""
+    from rpgp_amd import ops, linear_cg as lcg, settings
+    from rpgp_amd.operators import SKIAdditiveOperator, AddedDiagOperator
+    from rpgp_amd.precond import build_preconditioner
+    N, J, G, Z, V = _c5_problem(gpu_device, 11)
+    Zt = Z.to(gpu_device)
+    outputscale, noise = 0.8, 0.25
+    base = SKIAdditiveOperator(Zt, None, torch.tensor(outputscale, device=gpu_device), 1.0 / J, grid_size=G)
+    khat = AddedDiagOperator(base, torch.tensor(noise, device=gpu_device))
+    y = torch.sin(Z).sum(1, keepdim=True)
+    rhs = torch.cat([y, V[:, :10]], dim=1).to(gpu_device)            # the training block: residual + 10 probes
+    pre = build_preconditioner(base, noise, settings)
+    gph = base.gp.double().cpu().numpy()
+    grid = (float(gph[0]), float(gph[1]))
+    for tol in (0.05, 0.01):
+        before = lcg.stats.get("native_calls", 0)
+        x = lcg.linear_cg(khat._matmul, rhs, n_tridiag=0, tolerance=tol, max_iter=10000, preconditioner=pre, operator=khat)
+        assert lcg.stats.get("native_calls", 0) == before + 1
+        xd = x.double().cpu().numpy()
+        r = sko.mvm_sparse(Z.numpy(), Z.numpy(), xd, outputscale / J, G, grid, noise) - rhs.double().cpu().numpy()
+        res = np.linalg.norm(r, axis=0) / np.linalg.norm(rhs.double().cpu().numpy(), axis=0)
+        assert res.mean() < 1.5 * tol, (tol, res)
+        assert lcg.stats["last_iterations"] < 200
+
+
 @pytest.mark.parametrize("N,J,T,G", [(400, 3, 11, 256), (900, 2, 1, 1024), (300, 3, 20, 128)])
 def test_ski_bilinear_grad(gpu_device, N, J, T, G):
     from rpgp_amd import ops

@@ -1440,12 +1440,15 @@ __global__ void ski_grid_finish_kernel(const float *__restrict__ part, int npart
 // fixed-point scale from the chunk's own max|v| and its densest 4-cell neighbourhood (so no cell sum can overflow 2^30);
 // the rounding error per update is <= 2^-31 of that bound — at the fp32 rounding level of the float sum it replaces —
 // and integer addition commutes, so the SKI product is bitwise reproducible.
-template <int TT>
+template <int TT, bool CNT16>
 __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
                                                            const float *__restrict__ V, float *__restrict__ slab,
                                                            long long N, int ldz, int J, int G, int T, int tcnt,
                                                            long long pts_per_chunk) {
-  extern __shared__ int shi[];    // G * TT fixed-point accumulators | G ints: points per first-tap cell (scale bound)
+  // G * TT fixed-point accumulators | G/2 ints: points per first-tap cell, two 16-bit counters per word (scale bound).
+  // 16-bit counters keep the T = 12 workgroup at 53.4 KB of LDS: three per CU (with 32-bit counters it was 55.4 KB ->
+  // two per CU and the (chunk, projection) grid ran in two rounds); the host keeps chunks below 65 536 points.
+  extern __shared__ int shi[];
   __shared__ float smax[256];
   __shared__ int scmax[256];
   __shared__ float sscale[16], sinv[16];
@@ -1456,7 +1459,7 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
   const long long n0 = (long long)blockIdx.x * pts_per_chunk;
   const long long n1 = (n0 + pts_per_chunk < N) ? n0 + pts_per_chunk : N;
   int *scnt = shi + G * TT;
-  for (int e = threadIdx.x; e < G * TT + G; e += 256) shi[e] = 0;
+  for (int e = threadIdx.x; e < G * TT + (CNT16 ? (G + 1) / 2 : G); e += 256) shi[e] = 0;
   __syncthreads();
   const int t = threadIdx.x % LPP, pl = threadIdx.x / LPP;
   // pass 1: max |v| of the chunk per column, and how many points start their 4-tap stencil at each grid cell: a cell
@@ -1464,20 +1467,51 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
   //   |cell sum| <= (max over cells of that 4-cell count) * max|v|
   // — a bound ~100x tighter than points * max|v|, i.e. a fixed-point quantum at the fp32 rounding level
   float vm = 0.f;
-  if (t < tcnt)
-    for (long long i = n0 + pl; i < n1; i += PPI) vm = fmaxf(vm, __builtin_fabsf(V[i * T + t]));
+  if (t < tcnt) {
+    // 8 independent loads in flight per thread (the loop is a chain of dependent-latency loads otherwise)
+    long long i = n0 + pl;
+    for (; i + 15LL * PPI < n1; i += 16LL * PPI) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = V[(i + (long long)u * PPI) * T + t];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) vm = fmaxf(vm, __builtin_fabsf(x[u]));
+    }
+    for (; i < n1; i += PPI) vm = fmaxf(vm, __builtin_fabsf(V[i * T + t]));
+  }
   smax[threadIdx.x] = vm;
-  for (long long i = n0 + threadIdx.x; i < n1; i += 256) {
-    float w[4], dw[4];
-    atomicAdd(&scnt[ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw)], 1);
+  {
+    long long i = n0 + threadIdx.x;
+    for (; i + 3 * 256 < n1; i += 4 * 256) {
+      float z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) z[u] = Z[(i + u * 256) * ldz + j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float w[4], dw[4];
+        const int c = ski_taps<false>(z[u], g0, inv_h, G, w, dw);
+        if constexpr (CNT16) atomicAdd(&scnt[c >> 1], 1 << (16 * (c & 1)));
+        else atomicAdd(&scnt[c], 1);
+      }
+    }
+    for (; i < n1; i += 256) {
+      float w[4], dw[4];
+      const int c = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+      if constexpr (CNT16) atomicAdd(&scnt[c >> 1], 1 << (16 * (c & 1)));
+      else atomicAdd(&scnt[c], 1);
+    }
   }
   __syncthreads();
+  auto cell_count = [&](int g) {
+    if constexpr (CNT16) return (int)(((unsigned)scnt[g >> 1] >> (16 * (g & 1))) & 0xffffu);
+    else return scnt[g];
+  };
   int cm = 0;
   for (int g = threadIdx.x; g < G; g += 256) {
-    int c4 = scnt[g];
-    if (g >= 1) c4 += scnt[g - 1];
-    if (g >= 2) c4 += scnt[g - 2];
-    if (g >= 3) c4 += scnt[g - 3];
+    int c4 = cell_count(g);
+    if (g >= 1) c4 += cell_count(g - 1);
+    if (g >= 2) c4 += cell_count(g - 2);
+    if (g >= 3) c4 += cell_count(g - 3);
     cm = c4 > cm ? c4 : cm;
   }
   scmax[threadIdx.x] = cm;
@@ -1501,7 +1535,8 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
   __syncthreads();
   if (t < tcnt) {
     const float sc = sscale[t];
-    constexpr int U = 4;                   // points in flight per thread (hides the Z / V load latency)
+    constexpr int U = TT > 4 ? 8 : 4;      // points in flight per thread (hides the Z / V load latency; the wide form
+                                           // runs only 3 workgroups per CU, so the depth has to come from each thread)
     for (long long i0 = n0 + pl; i0 < n1; i0 += (long long)PPI * U) {
       float zv[U], vv[U];
 #pragma unroll
@@ -1537,14 +1572,36 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
 __global__ __launch_bounds__(256) void ski_slab_sum_kernel(const float *__restrict__ slab, double *__restrict__ hist,
                                                            int nchunks, int J, int G, int TT, int tcnt, int HT,
                                                            int hoff) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;        // over J * G * TT
+  // A workgroup owns 32 consecutive histogram entries; its 8 groups of 32 threads split the chunk slabs (slab c goes to
+  // group c % 8: each load is one 128-byte segment, 4 in flight per thread) and the 8 partial sums are added in a fixed
+  // order.  (One thread per entry looping over ~340 slabs was a serial chain of dependent-latency loads: 80 us at the
+  // C5 shape, J = 3, against 13 us with J = 20 where there are 20x more entries and 7x fewer slabs.)
+  __shared__ double part[8][32];
+  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
   const size_t per = (size_t)J * G * TT;
-  if (e >= per) return;
+  const size_t e = (size_t)blockIdx.x * 32 + o;
+  double acc = 0.0;
+  if (e < per) {
+    int c = g;
+    for (; c + 24 < nchunks; c += 32) {
+      const float x0 = slab[(size_t)c * per + e], x1 = slab[(size_t)(c + 8) * per + e];
+      const float x2 = slab[(size_t)(c + 16) * per + e], x3 = slab[(size_t)(c + 24) * per + e];
+      acc += (double)x0;
+      acc += (double)x1;
+      acc += (double)x2;
+      acc += (double)x3;
+    }
+    for (; c < nchunks; c += 8) acc += (double)slab[(size_t)c * per + e];
+  }
+  part[g][o] = acc;
+  __syncthreads();
+  if (g != 0 || e >= per) return;
   const int t = (int)(e % TT);
   if (t >= tcnt) return;
-  double acc = 0.0;
-  for (int c = 0; c < nchunks; ++c) acc += (double)slab[(size_t)c * per + e];
-  hist[(e / TT) * HT + hoff + t] = acc;
+  double tot = part[0][o];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) tot += part[q][o];
+  hist[(e / TT) * HT + hoff + t] = tot;
 }
 
 // H[j][m][t] = sum_m' exp(-0.5 ((m - m') h)^2) hist[j][m'][t]
@@ -1583,56 +1640,61 @@ __global__ __launch_bounds__(256) void ski_toeplitz_kernel(const HT_ *__restrict
 //   A (16x4): lane l holds Toep[m0 + l%16][k0 + l/16]     B (4x16): lane l holds hist_j[k0 + l/16][l%16]
 //   D (16x16): lane l holds H_j[m0 + l/16 + 4 r][l%16], r = 0..3   (NOT the fp32 instruction's 4*(l/16) + r)
 typedef double doublex4m __attribute__((ext_vector_type(4)));
-constexpr int kToepPanel = 512;
+// One workgroup owns ONE 16-row output tile; its 4 waves split the grid points (the K loop) four ways and add their
+// partial tiles through LDS in a fixed order.  (The first version gave each wave its own tile and the whole K loop:
+// 64 dependent K-steps x 4 MFMAs per wave and only 16 J workgroups — 31 us of the 66 us SKI MVM at the C5 shape.)
 __global__ __launch_bounds__(256) void ski_toeplitz_mfma_kernel(const double *__restrict__ hist,
                                                                 const float *__restrict__ gp, float *__restrict__ H,
                                                                 int G, int T) {
-  extern __shared__ double dmem[];          // sc[G16] | sh[kToepPanel * T]   (G16 = G rounded up to 16)
+  extern __shared__ double dmem[];          // sc[G16] | red[3][256]
   const int G16 = (G + 15) & ~15;
   double *sc = dmem;
-  double *shh = dmem + G16;
+  double *red = dmem + G16;
   const int j = blockIdx.y;
   const double hd = (double)gp[1];
   for (int k = threadIdx.x; k < G16; k += 256) {
     const double d = (double)k * hd;
     sc[k] = k < G ? exp(-0.5 * d * d) : 0.0;
   }
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = (blockIdx.x * 4 + wave) * 16;
+  const int m0 = blockIdx.x * 16;
   const int mrow = m0 + (lane & 15), q = lane >> 4;
   const int nb = lane & 15;
-  const int nbc = nb < T ? nb : T - 1;               // clamped column: every LDS read below is unconditional
+  const int nbc = nb < T ? nb : T - 1;               // clamped column: every load below is unconditional
   const double bmask = nb < T ? 1.0 : 0.0;
   const double amask = (mrow < G) ? 1.0 : 0.0;
-  // four independent accumulators: consecutive K-steps do not wait on each other's MFMA latency
+  const double *hj = hist + (size_t)j * G * T;
+  // this wave's quarter of the grid points, in steps of 16 (4 MFMAs on 4 independent accumulators per step)
+  const int ksteps = G16 / 16;
+  const int s_begin = (ksteps * wave) / 4, s_end = (ksteps * (wave + 1)) / 4;
   doublex4m acc4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc4[u] = doublex4m{0.0, 0.0, 0.0, 0.0};
-  for (int p0 = 0; p0 < G16; p0 += kToepPanel) {
-    const int prow = (G16 - p0 < kToepPanel) ? G16 - p0 : kToepPanel;
-    __syncthreads();
-    for (int e = threadIdx.x; e < prow * T; e += 256) {
-      const size_t ge = (size_t)p0 * T + e;
-      shh[e] = ge < (size_t)G * T ? hist[(size_t)j * G * T + ge] : 0.0;
-    }
-    __syncthreads();
-    for (int k0 = 0; k0 < prow; k0 += 16) {
-      double a[4], b[4];
+  for (int st = s_begin; st < s_end; ++st) {
+    double a[4], b[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kl = k0 + 4 * u + q;              // row within the panel (prow is a multiple of 16)
-        const int k = p0 + kl;
-        int dist = mrow > k ? mrow - k : k - mrow;
-        dist = dist < G16 ? dist : G16 - 1;         // only rows >= G can exceed it; they carry amask = 0
-        a[u] = sc[dist] * amask;
-        b[u] = shh[kl * T + nbc] * bmask;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc4[u], 0, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      const int k = st * 16 + 4 * u + q;
+      int dist = mrow > k ? mrow - k : k - mrow;
+      dist = dist < G16 ? dist : G16 - 1;           // only rows >= G can exceed it; they carry amask = 0
+      a[u] = sc[dist] * amask;
+      const int kc = k < G ? k : G - 1;
+      b[u] = (k < G ? hj[(size_t)kc * T + nbc] : 0.0) * bmask;     // L2-resident (J G T doubles), read once per tile
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc4[u], 0, 0, 0);
   }
-  if (m0 >= G) return;
   doublex4m acc = acc4[0] + acc4[1] + acc4[2] + acc4[3];
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave - 1) * 4 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0 || m0 >= G) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    acc[r] = ((acc[r] + red[(0 * 4 + r) * 64 + lane]) + red[(1 * 4 + r) * 64 + lane]) + red[(2 * 4 + r) * 64 + lane];
   const double wj = (double)ski_wj(gp, j);
   if (nb < T) {
 #pragma unroll
@@ -1654,19 +1716,57 @@ __global__ __launch_bounds__(256) void ski_gather_kernel(const float *__restrict
                                                          int T, int t0, int tcnt, float scale, float noise) {
   constexpr int LPP = TT == 1 ? 1 : (TT == 4 ? 4 : 16);
   constexpr int PPB = 256 / LPP;
-  const int t = threadIdx.x % LPP;
-  const long long i = (long long)blockIdx.x * PPB + threadIdx.x / LPP;
-  if (i >= M || t >= tcnt) return;
+  // The LPP lanes of a point share its stencils: lane t computes the taps of projection j0 + t ONCE and parks them in
+  // LDS; every lane then reads (idx0, 4 weights) per projection as an LDS broadcast.  (Each lane recomputing all J
+  // stencils and converting every term to float64 made this kernel VALU-bound: 40 us for 39 MB at the C5 shape.)
+  __shared__ float sTap[LPP > 1 ? PPB * LPP * 5 : 1];
+  const int t = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+  const long long i = (long long)blockIdx.x * PPB + pl;
+  const bool live = i < M;
+  const bool writer = live && t < tcnt;
   const float g0 = gp[0], inv_h = gp[2];
-  const float *zrow = Z + i * ldz;
-  double acc = 0.0;                          // 4 J terms per output: float64 accumulation is free here
+  const float *zrow = Z + (live ? i : 0) * ldz;
+  double acc = 0.0;                          // J terms per output in float64; the 4 taps of a projection in fp32 FMAs
+  if constexpr (LPP == 1) {
+    if (!writer) return;
 #pragma unroll 4
-  for (int j = 0; j < J; ++j) {
-    float w[4], dw[4];
-    const int idx0 = ski_taps<false>(zrow[j], g0, inv_h, G, w, dw);
-    const float *hp = H + ((size_t)j * G + idx0) * T + t0 + t;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc = fma((double)w[k], (double)hp[(size_t)k * T], acc);
+    for (int j = 0; j < J; ++j) {
+      float w[4], dw[4];
+      const int idx0 = ski_taps<false>(zrow[j], g0, inv_h, G, w, dw);
+      const float *hp = H + ((size_t)j * G + idx0) * T + t0;
+      float p = w[0] * hp[0];
+      p = __builtin_fmaf(w[1], hp[(size_t)T], p);
+      p = __builtin_fmaf(w[2], hp[2 * (size_t)T], p);
+      p = __builtin_fmaf(w[3], hp[3 * (size_t)T], p);
+      acc += (double)p;
+    }
+  } else {
+    for (int j0 = 0; j0 < J; j0 += LPP) {
+      const int jj = j0 + t;
+      if (jj < J) {
+        float w[4], dw[4];
+        const int idx0 = live ? ski_taps<false>(zrow[jj], g0, inv_h, G, w, dw) : 0;
+        float *dst = sTap + (pl * LPP + t) * 5;
+        dst[0] = __builtin_bit_cast(float, idx0);
+        dst[1] = w[0]; dst[2] = w[1]; dst[3] = w[2]; dst[4] = w[3];
+      }
+      __syncthreads();
+      const int jn = (J - j0 < LPP) ? J - j0 : LPP;
+      if (writer) {
+        for (int q = 0; q < jn; ++q) {
+          const float *tp = sTap + (pl * LPP + q) * 5;
+          const int idx0 = __builtin_bit_cast(int, tp[0]);
+          const float *hp = H + ((size_t)(j0 + q) * G + idx0) * T + t0 + t;
+          float p = tp[1] * hp[0];
+          p = __builtin_fmaf(tp[2], hp[(size_t)T], p);
+          p = __builtin_fmaf(tp[3], hp[2 * (size_t)T], p);
+          p = __builtin_fmaf(tp[4], hp[3 * (size_t)T], p);
+          acc += (double)p;
+        }
+      }
+      __syncthreads();
+    }
+    if (!writer) return;
   }
   float r = scale * (float)acc;
   if (noise != 0.f) r = __builtin_fmaf(noise, V[i * T + t0 + t], r);
@@ -3231,10 +3331,17 @@ namespace {
 inline int ski_tpiece(int remaining) { return remaining > 4 ? 12 : (remaining > 1 ? 4 : 1); }
 constexpr int kSkiMaxParts = 512;
 
-// chunks of points per projection for ski_scatter3_kernel: ~1024 workgroups in total, at least 256 points each
+// chunks of points per projection for ski_scatter3_kernel: at least 256 points each and at most ~1024 workgroups in
+// total (the slab workspace is sized for that); with wide right-hand sides the (chunk, projection) workgroups are
+// limited to what is resident at once — the LDS histogram of a T = 12 workgroup is 53 KB, three per CU — so that the
+// launch is ONE round of equally long workgroups instead of 1.3 (measured at the C5 shape: 130 -> 103 us)
 inline int ski_max_chunks(int J) { return (1024 + J - 1) / J; }
-inline int ski_chunks(long long N, int J) {
+inline int ski_chunks(long long N, int J, int tt = 1) {
   long long c = ski_max_chunks(J);
+  if (tt > 4) {
+    const long long resident = (768 + J - 1) / J;
+    if (c > resident) c = resident;
+  }
   const long long by_pts = (N + 255) / 256;
   if (c > by_pts) c = by_pts;
   if (c < 1) c = 1;
@@ -3246,20 +3353,25 @@ inline size_t ski_slab_floats(int J, int G) { return (size_t)ski_max_chunks(J) *
 int ski_scatter_narrow(const float *Z, const float *gp, const float *V, double *hist, float *slab, long long N, int ldz,
                        int J, int G, int T, int HT, int hoff, hipStream_t st) {
   const int tt = ski_tpiece(T);
-  const int nch = ski_chunks(N, J);
+  const int nch = ski_chunks(N, J, tt);
   const long long ppc = (N + nch - 1) / nch;
   dim3 grid((unsigned)nch, (unsigned)J);
-  const size_t lds = ((size_t)G * tt + G) * sizeof(float);
+  // 16-bit per-cell point counters (two per LDS word) for the wide form when a chunk has < 65 536 points: 53.4 KB of
+  // LDS per workgroup, three per CU
+  const bool cnt16 = tt > 4 && ppc < 65536;
+  const size_t lds = ((size_t)G * tt + (cnt16 ? (G + 1) / 2 : G)) * sizeof(float);
   if (tt == 1)
-    hipLaunchKernelGGL((ski_scatter3_kernel<1>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
+    hipLaunchKernelGGL((ski_scatter3_kernel<1, false>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
   else if (tt == 4)
-    hipLaunchKernelGGL((ski_scatter3_kernel<4>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
+    hipLaunchKernelGGL((ski_scatter3_kernel<4, false>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
+  else if (cnt16)
+    hipLaunchKernelGGL((ski_scatter3_kernel<12, true>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
   else
-    hipLaunchKernelGGL((ski_scatter3_kernel<12>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
+    hipLaunchKernelGGL((ski_scatter3_kernel<12, false>), grid, dim3(256), lds, st, Z, gp, V, slab, N, ldz, J, G, T, T, ppc);
   int rc = launch_status();
   if (rc) return rc;
   const size_t per = (size_t)J * G * tt;
-  hipLaunchKernelGGL(ski_slab_sum_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, slab, hist, nch, J, G,
+  hipLaunchKernelGGL(ski_slab_sum_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, slab, hist, nch, J, G,
                      tt, T, HT, hoff);
   return launch_status();
 }
@@ -3288,10 +3400,9 @@ int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H
     return launch_status();
   }
   const int G16 = (G + 15) & ~15;
-  const int panel = G16 < kToepPanel ? G16 : kToepPanel;
-  const size_t lds = ((size_t)G16 + (size_t)panel * T) * sizeof(double);
+  const size_t lds = ((size_t)G16 + 3 * 256) * sizeof(double);
   if (hist_is_double && T <= 16 && lds <= 64 * 1024) {        // matrix-core path, float64
-    dim3 grid((G + 63) / 64, J);
+    dim3 grid((G + 15) / 16, J);
     hipLaunchKernelGGL(ski_toeplitz_mfma_kernel, grid, dim3(256), lds, st, reinterpret_cast<const double *>(hist), gp, H,
                        G, T);
     return launch_status();

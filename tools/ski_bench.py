@@ -1,0 +1,25 @@
+"""SKI MVM at the C5 shape (N = 391 386, J = d = 3, grid 1024) and at C4-with-ski (N = 50k, J = 20): wall time per MVM
+and the HBM roofline line  bytes = 4 N (J + 2 T)  (read Z, read V, write out) / time  vs 8 TB/s."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rpgp_amd import ops
+dev = torch.device("cuda:0")
+reps = int(os.environ.get("SKI_REPS", "50"))
+for (N, J) in [(391386, 3), (50000, 20)]:
+    g = torch.Generator().manual_seed(0)
+    Z = torch.randn(N, J, generator=g).to(dev)
+    gp = ops.ski_grid(Z, None, 1024)
+    for T in (1, 11):
+        V = torch.randn(N, T, generator=g).to(dev)
+        out = ops.ski_mvm(Z, Z, gp, V, 1.0 / J, 0.1, 1024)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.ski_mvm(Z, Z, gp, V, 1.0 / J, 0.1, 1024)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        b = 4.0 * N * (J + 2 * T)
+        print(json.dumps({"workload": "SKI MVM N=%d J=%d T=%d G=1024" % (N, J, T), "ms_per_mvm": round(ms, 4),
+                          "algorithmic_bytes": b, "achieved_GBps": round(b / ms / 1e6, 1), "frac_of_8TBps": round(b / ms / 1e6 / 8000, 4)}), flush=True)

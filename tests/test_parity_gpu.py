@@ -1,0 +1,148 @@
+"""Parity holes named by the round-1 review, closed on the GPU through the C-ABI:
+  (a) rpgp_pivoted_cholesky against a float64 pivoted Cholesky of the ORACLE kernel matrix (pivots and residual),
+  (b) the gradient of the marginal log-likelihood w.r.t. the projection matrix (learn_proj=True,
+      scaled_projection_kernel.py:10-17; test.py:575-621 pins that P must move) against float64 finite differences,
+  (c) fused MVM + bilinear derivative at exactly the C2 / C3 shapes (kin8nm fold N = 7372 d = 8, elevators fold
+      N = 14 939 d = 18, J = 20) against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_gp as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("N,J,rank,spread", [(500, 20, 15, 0.7), (2048, 8, 15, 1.0), (2049, 20, 15, 0.7), (3000, 3, 12, 1.5)])
+def test_pivoted_cholesky_matches_float64_oracle(gpu_device, N, J, rank, spread):
+    """Single-workgroup kernel (N <= 2048) and the chip-wide per-step kernels (N > 2048) against the oracle's greedy
+    pivoted Cholesky of the oracle's own K: same pivots, same factor, same residual."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + J)
+    Z = (rng.standard_normal((N, J)) * spread).astype(np.float32)
+    scale = 0.8 / J
+    K = scale * orc.additive_rbf(Z, Z)
+    Lref, piv_ref = orc.pivoted_cholesky(K, rank)
+    L = ops.pivoted_cholesky(torch.from_numpy(Z).to(gpu_device), scale, rank).double().cpu().numpy()
+    # pivot of column m: the residual matrix is PSD, so |L[i, m]| = |R[i, p]| / sqrt(R[p, p]) <= sqrt(R[p, p]) = L[p, m]
+    piv = [int(np.argmax(np.abs(L[:, m]))) for m in range(rank)]
+    assert piv[:4] == piv_ref[:4], (piv, piv_ref)
+    assert np.abs(L - Lref).max() < 1e-4 * np.sqrt(K.max()), np.abs(L - Lref).max()
+    r, rref = np.abs(K - L @ L.T).max(), np.abs(K - Lref @ Lref.T).max()
+    assert abs(r - rref) < 1e-4 * K.max() and np.trace(K - L @ L.T) < np.trace(K - Lref @ Lref.T) * 1.001 + 1e-3
+
+
+def _model_learn_proj(dev, X, y, P, ls, noise, s):
+    from rpgp_amd.kernels import AdditiveStructureRBFKernel, ScaledProjectionKernel, ScaleKernel
+    from rpgp_amd.likelihoods import GaussianLikelihood, SmoothedBoxPrior
+    from rpgp_amd.models import ExactGPModel, ExactMarginalLogLikelihood
+    d, J = P.shape
+    lin = torch.nn.Linear(d, J, bias=False)
+    lin.weight.data = P.t().contiguous()
+    k = ScaledProjectionKernel(lin, AdditiveStructureRBFKernel(J), prescale=True, ard_num_dims=d, learn_proj=True)
+    k.initialize(lengthscale=ls)
+    sk = ScaleKernel(k)
+    sk.outputscale = s
+    lik = GaussianLikelihood(noise_prior=SmoothedBoxPrior(1e-4, 10, sigma=0.01))
+    lik.noise = noise
+    model = ExactGPModel(X.to(dev), y.to(dev), lik, sk).to(dev)
+    model.mean_module.constant.data.fill_(0.2)
+    return model, lik, ExactMarginalLogLikelihood(lik, model), lin
+
+
+@pytest.mark.parametrize("N,regime", [(260, "chol"), (2600, "cg")])
+def test_learn_proj_gradient_matches_float64_finite_differences(gpu_device, N, regime):
+    """d MLL / d P through rpgp_project_grad + rpgp_bilinear_grad[_dense] vs central differences of the oracle MLL."""
+    from rpgp_amd import settings
+    from tests.test_host_stack import _problem
+    d, J = 6, 20
+    X, y, P, ls, noise, s = _problem(N=N, d=d, J=J, seed=3, noise=0.3, s=0.9)
+    model, lik, mll, lin = _model_learn_proj(gpu_device, X, y, P, ls, noise, s)
+    assert lin.weight.requires_grad
+    model.train()
+    ctx = [settings.cg_tolerance(1e-7), settings.deterministic_probes(True), settings.num_trace_samples(64)]
+    for c in ctx:
+        c.__enter__()
+    try:
+        val = mll(model(model.train_inputs), model.train_targets)
+        val.backward()
+    finally:
+        for c in reversed(ctx):
+            c.__exit__(None, None, None)
+    g = lin.weight.grad.t().double().cpu().numpy()          # d x J, like P
+    assert np.isfinite(g).all() and np.abs(g).max() > 0
+
+    def f(Pm):
+        return orc.DenseExactGP(X.numpy(), y.numpy(), Pm, ls.numpy(), s, noise, mean=0.2).mll()
+    ref0 = f(P.double().numpy())
+    assert abs(val.item() - ref0) < (1e-4 if regime == "chol" else 3e-3) * abs(ref0)
+    eps = 1e-5
+    Pn = P.double().numpy()
+    scale_ref = np.abs(g).max()
+    for (a, b) in [(0, 0), (d - 1, J - 1), (2, 7), (4, 13)]:
+        Pp, Pm = Pn.copy(), Pn.copy()
+        Pp[a, b] += eps
+        Pm[a, b] -= eps
+        fd = (f(Pp) - f(Pm)) / (2 * eps)
+        if regime == "chol":                # deterministic: tight
+            assert abs(g[a, b] - fd) < 2e-3 * abs(fd) + 2e-3 * scale_ref * 0.05, (a, b, g[a, b], fd)
+        else:                               # stochastic trace term (64 probes): within the probe noise
+            assert abs(g[a, b] - fd) < 0.15 * abs(fd) + 0.05 * scale_ref, (a, b, g[a, b], fd)
+
+
+@pytest.mark.parametrize("name,N,d", [("C2 kin8nm fold", 7372, 8), ("C3 elevators fold", 14939, 18)])
+def test_fused_mvm_and_derivative_at_c2_c3_shapes(gpu_device, name, N, d):
+    """MVM (direct, prepared, T = 1 and the T = 11 training block) and the bilinear derivative at exactly the C2 / C3
+    shapes against the float64 dense oracle (the oracle holds the 15k x 15k matrix once: 1.8 GB)."""
+    from rpgp_amd import ops
+    J, T = 20, 11
+    g = torch.Generator().manual_seed(N)
+    X = torch.randn(N, d, generator=g)
+    P = torch.randn(d, J, generator=g)
+    ls = torch.rand(d, generator=g) * 1.5 + 1.5
+    V = torch.randn(N, T, generator=g)
+    Zt = ops.project(X.to(gpu_device), (P / ls[:, None]).contiguous().to(gpu_device))
+    Zo = orc.project(X.numpy(), P.numpy(), ls.numpy())
+    assert _rel(Zt.cpu().numpy(), Zo) < 2e-6
+    scale, noise = 0.9 / J, 0.2
+    Zh = Zt.double().cpu().numpy()                         # oracle on the SAME projected inputs
+    K = orc.additive_rbf(Zh, Zh)
+    K *= scale
+    ref = K @ V.double().numpy() + noise * V.double().numpy()
+    Vt = V.to(gpu_device)
+    prep = ops.Prepared(Zt)
+    assert prep.fast_ok
+    for out in (ops.mvm_sym(Zt, Vt, scale, noise), ops.mvm_sym_prepared(prep, Vt, scale, noise)):
+        col = np.linalg.norm(out.double().cpu().numpy() - ref, axis=0) / np.linalg.norm(ref, axis=0)
+        assert col.max() < 1e-5, (name, col)
+    o1 = ops.mvm_sym_prepared(prep, Vt[:, :1].contiguous(), scale, noise).double().cpu().numpy()
+    assert _rel(o1, ref[:, :1]) < 1e-5
+    # cached-K stream of the same matrix
+    Kd = ops.dense(Zt, Zt, scale, pad=True)
+    assert np.abs(Kd[:2000, :2000].double().cpu().numpy() - K[:2000, :2000]).max() < 2e-6
+    od = ops.dense_mvm(Kd, Vt, noise).double().cpu().numpy()
+    assert _rel(od, ref) < 1e-5
+    del Kd
+    # bilinear derivative with the shapes of a training step (10 probe solves + the residual solve)
+    L = torch.randn(N, T, generator=g) * 0.1
+    R = torch.randn(N, T, generator=g) * 0.1
+    gZ, gs = ops.bilinear_grad(Zt, L.to(gpu_device), R.to(gpu_device), scale)
+    W = L.double().numpy() @ R.double().numpy().T
+    gs_ref = (W * K).sum() / scale
+    S = W + W.T
+    del W
+    gz_ref = np.zeros_like(Zh)
+    for j in range(J):
+        dj = Zh[:, j:j + 1] - Zh[:, j:j + 1].T
+        e = np.exp(-0.5 * dj * dj)
+        e *= S
+        e *= dj
+        gz_ref[:, j] = -scale * e.sum(axis=1)
+    assert _rel(gZ.double().cpu().numpy(), gz_ref) < 2e-5
+    assert abs(float(gs) - gs_ref) < 2e-5 * abs(gs_ref) + 1e-4

@@ -199,6 +199,20 @@ int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t
 int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, const float *V, float *out,
                  int64_t M, int64_t N, int ldz1, int ldz2, int J, int G, int T, float scale, float noise,
                  void *workspace, size_t workspace_bytes, void *stream);
+/*
+ * The three stages of rpgp_ski_mvm as separate calls (T <= 12), for the row-sharded multi-GPU SKI operator that replaces
+ * `MultiDeviceKernel` around the SKI kernel (training_routines.py:407-408 with :157-158): every rank scatters ITS rows,
+ * the J x G x T float64 histogram is all-reduced (RCCL), the Toeplitz product is replicated and every rank gathers ITS
+ * rows.  grid_params must be built from the GLOBAL coordinate range (same block on every rank).
+ *   rpgp_ski_scatter      : hist[j][g][t] (float64, J*G*T) = sum_i w(z_ij)[g] V[i][t] over the N local rows
+ *   rpgp_ski_grid_product : H[j][m][t] (float32) = w_j * sum_m' Tm[m,m'] hist[j][m'][t]
+ *   rpgp_ski_gather       : out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0+k][t] + noise * V[i][t]  (V may be NULL if noise == 0)
+ */
+int rpgp_ski_scatter(const float *Z, const float *grid_params, const float *V, double *hist, int64_t N, int ldz, int J,
+                     int G, int T, void *workspace, size_t workspace_bytes, void *stream);
+int rpgp_ski_grid_product(const double *hist, const float *grid_params, float *H, int J, int G, int T, void *stream);
+int rpgp_ski_gather(const float *Z, const float *grid_params, const float *H, const float *V, float *out, int64_t M,
+                    int ldz, int J, int G, int T, float scale, float noise, void *stream);
 /* Pivoted Cholesky of the SKI operator (same contract as rpgp_pivoted_cholesky; diag_work: N + RPGP_PIVCHOL_SCRATCH). */
 int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
                               int J, int G, int rank, float scale, void *stream);

@@ -24,6 +24,10 @@ class HipBackend:
     ski_grid = staticmethod(ops.ski_grid)
     ski_mvm = staticmethod(ops.ski_mvm)
     ski_diag = staticmethod(ops.ski_diag)
+    ski_grid_from_range = staticmethod(ops.ski_grid_from_range)
+    ski_scatter = staticmethod(ops.ski_scatter)
+    ski_grid_product = staticmethod(ops.ski_grid_product)
+    ski_gather = staticmethod(ops.ski_gather)
     ski_dense = staticmethod(ops.ski_dense)
     ski_pivoted_cholesky = staticmethod(ops.ski_pivoted_cholesky)
     ski_bilinear_grad = staticmethod(ops.ski_bilinear_grad)

@@ -3496,6 +3496,29 @@ int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, con
   return ski_gather_all(Z1, grid_params, H, V, out, M, ldz1, J, G, T, scale, noise, st);
 }
 
+// ---- the three stages of rpgp_ski_mvm as separate calls (row-sharded multi-GPU SKI: the J x G x T float64 grid
+// histogram is all-reduced across ranks between the scatter and the Toeplitz product) --------------------------------
+int rpgp_ski_scatter(const float *Z, const float *grid_params, const float *V, double *hist, int64_t N, int ldz, int J,
+                     int G, int T, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!Z || !grid_params || !V || !hist || N <= 0 || J <= 0 || G < 8 || T <= 0 || T > 12 || ldz < J) return RPGP_EINVAL;
+  if ((size_t)G * 13 * sizeof(float) > 64 * 1024) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
+  float *slab = reinterpret_cast<float *>(workspace) + 3 * (size_t)J * G * (2 * T) + 2 * kSkiMaxParts;
+  return ski_scatter_narrow(Z, grid_params, V, hist, slab, (long long)N, ldz, J, G, T, T, 0, as_stream(stream));
+}
+
+int rpgp_ski_grid_product(const double *hist, const float *grid_params, float *H, int J, int G, int T, void *stream) {
+  if (!hist || !grid_params || !H || J <= 0 || G < 8 || T <= 0 || T > 12) return RPGP_EINVAL;
+  return ski_toeplitz(hist, 1, grid_params, H, J, G, T, as_stream(stream));
+}
+
+int rpgp_ski_gather(const float *Z, const float *grid_params, const float *H, const float *V, float *out, int64_t M,
+                    int ldz, int J, int G, int T, float scale, float noise, void *stream) {
+  if (!Z || !grid_params || !H || !out || M <= 0 || J <= 0 || G < 8 || T <= 0 || T > 12 || ldz < J) return RPGP_EINVAL;
+  if (noise != 0.f && !V) return RPGP_EINVAL;
+  return ski_gather_all(Z, grid_params, H, V, out, (long long)M, ldz, J, G, T, scale, noise, as_stream(stream));
+}
+
 int rpgp_ski_dense(const float *Z1, const float *Z2, const float *grid_params, float *out, int64_t M, int64_t N,
                    int ldz1, int ldz2, int64_t ldo, int J, int G, float scale, void *stream) {
   if (!Z1 || !Z2 || !grid_params || !out || M <= 0 || N <= 0 || J <= 0 || J > 64 || G < 8 || ldz1 < J || ldz2 < J ||

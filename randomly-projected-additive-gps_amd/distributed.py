@@ -72,3 +72,58 @@ class JShard:
         partial = local_mvm(self.j0, self.j1, noise if self.rank == 0 else 0.0)
         all_reduce_sum_(partial, self.group)
         return partial
+
+
+# ---- row sharding (the SKI operator; replaces MultiDeviceKernel around GridInterpolationKernel, -----------------------
+# ---- training_routines.py:407-408 with :157-158) ---------------------------------------------------------------
+def row_partition(N, world_size):
+    """Contiguous, balanced split of range(N): list of (r0, r1), the first N % world_size ranks one row longer."""
+    if N < 0 or world_size <= 0:
+        raise ValueError("N must be non-negative and world_size positive")
+    base, extra = divmod(N, world_size)
+    out, start = [], 0
+    for r in range(world_size):
+        n = base + (1 if r < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+class RowShard:
+    """This rank's contiguous block [r0, r1) of the N data rows, and the collectives the row-sharded solve needs
+    (all SUM / MIN / MAX all-reduces of tiny tensors: the J x G x T grid histogram, k x T preconditioner projections and
+    the per-column scalars of CG)."""
+
+    def __init__(self, N, group=None):
+        self.group = group
+        self.N = int(N)
+        # (a one-rank process group still routes its collectives through the backend: the world-size-1 RCCL test)
+        self.active = dist.is_available() and dist.is_initialized()
+        if self.active:
+            self.world_size = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+        else:
+            self.world_size, self.rank = 1, 0
+        self.bounds = row_partition(self.N, self.world_size)
+        self.r0, self.r1 = self.bounds[self.rank]
+
+    @property
+    def local_rows(self):
+        return self.r1 - self.r0
+
+    def owner(self, row):
+        for r, (a, b) in enumerate(self.bounds):
+            if a <= row < b:
+                return r
+        raise IndexError(row)
+
+    def all_reduce_(self, t, op="sum"):
+        if self.active:
+            dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op],
+                            group=self.group)
+        return t
+
+    def broadcast_(self, t, src):
+        if self.active:
+            dist.broadcast(t, src=src, group=self.group)
+        return t

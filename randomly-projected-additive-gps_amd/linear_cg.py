@@ -91,12 +91,16 @@ def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag
 
 
 def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_updating_after=1e-10, max_iter=None,
-              max_tridiag_iter=None, initial_guess=None, preconditioner=None, check_every=1, operator=None):
+              max_tridiag_iter=None, initial_guess=None, preconditioner=None, check_every=1, operator=None,
+              reduce=None, global_size=None):
     """Solve A X = rhs for symmetric positive definite A given as `matmul_closure`.
 
     rhs: (N x T).  Returns X, or (X, tridiag [n_tridiag x k x k]) when n_tridiag > 0.
     `operator` (optional): the LinearOperator behind `matmul_closure`; when it exposes `native_descriptor()` and
     T <= 16 the whole loop runs in the native executor (fused vector kernels, device-resident scalars).
+    `reduce` (optional): in-place SUM all-reduce of a small tensor.  With it the vectors are a rank's LOCAL rows of a
+    row-sharded system (operators.RowShardedSKIOperator): every column inner product / norm is all-reduced, so all ranks
+    take identical steps and stop at the same iteration; `global_size` is the global N (iteration cap).
     """
     if rhs.dim() == 1:
         squeeze = True
@@ -109,7 +113,7 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
         max_iter = settings.max_cg_iterations.value()
     if max_tridiag_iter is None:
         max_tridiag_iter = settings.max_lanczos_quadrature_iterations.value()
-    if initial_guess is None and rhs.dim() == 2:
+    if initial_guess is None and rhs.dim() == 2 and reduce is None:
         res = _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner,
                                 check_every)
         if res is not None:
@@ -125,10 +129,17 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
         # the reachable residual, which is too coarse for the 1e-4 parity gates
         eps = 1e3 * torch.finfo(rhs.dtype).tiny
     N, T = rhs.shape
-    n_iter = min(max_iter, N + 0)
+    n_iter = min(max_iter, (N if global_size is None else int(global_size)) + 0)
     n_tridiag_iter = min(max_tridiag_iter, n_iter)
 
-    rhs_norm = rhs.norm(2, dim=0, keepdim=True)
+    def colnorm(a):
+        if reduce is None:
+            return a.norm(2, dim=0, keepdim=True)
+        sq = a.double().pow(2).sum(0, keepdim=True)
+        reduce(sq)
+        return sq.sqrt().to(a.dtype)
+
+    rhs_norm = colnorm(rhs)
     rhs_is_zero = rhs_norm.lt(1e-10)
     rhs_norm = rhs_norm.masked_fill(rhs_is_zero, 1.0)
     rhs = rhs / rhs_norm
@@ -149,7 +160,10 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     scratch = torch.empty_like(rhs)
 
     def coldot(a, b):
-        return torch.mul(a, b, out=scratch).sum(0, keepdim=True)
+        s_ = torch.mul(a, b, out=scratch).sum(0, keepdim=True)
+        if reduce is not None:
+            reduce(s_)
+        return s_
 
     rz = coldot(residual, z)
 
@@ -179,7 +193,7 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
         residual.addcmul_(Ap, alpha, value=-1.0)
         del Ap
 
-        residual_norm = residual.norm(2, dim=0, keepdim=True).masked_fill(rhs_is_zero, 0.0)
+        residual_norm = colnorm(residual).masked_fill(rhs_is_zero, 0.0)
 
         z = preconditioner(residual)
         rz_new = coldot(residual, z)

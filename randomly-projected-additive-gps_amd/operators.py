@@ -362,6 +362,143 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         return self._bilinear_derivative((0.5 * S).contiguous(), eye)
 
 
+class RowShardedSKIOperator(LinearOperator):
+    """The SKI operator (+ noise I) with the N data rows split across ranks — the MI355X counterpart of wrapping the
+    SKI kernel in `MultiDeviceKernel` (training_routines.py:407-408 with :157-158).  Every vector it touches is a
+    rank's LOCAL block of rows:
+        hist_r = W_r^T v_r  (J x G x T float64, rpgp_ski_scatter)  ->  all-reduce SUM (RCCL; 270 KB at J = 3, T = 11)
+        H = Tm hist         (replicated float64 Toeplitz product, rpgp_ski_grid_product)
+        out_r = scale * W_r H + noise * v_r                        (rpgp_ski_gather)
+    The interpolation grid is built from the GLOBAL coordinate range (MIN / MAX all-reduce), so all ranks interpolate onto
+    the same grid and the sharded product equals the single-process SKI product up to the float64 summation order of the
+    histogram.  CG on it runs with all-reduced inner products (`linear_cg(..., reduce=shard.all_reduce_)`); the rank-k
+    pivoted-Cholesky preconditioner is built from distributed pivots (`row_sharded_preconditioner`)."""
+
+    def __init__(self, Z_local, outputscale, weight, row_shard, grid_size=1024, noise=0.0):
+        self.Z1 = Z_local.detach().contiguous()
+        self.row_shard = row_shard
+        self.grid_size = int(grid_size)
+        self._scale = float(outputscale) * float(weight)
+        self._noise = float(noise)
+        be = _backend.get_backend()
+        if self.Z1.shape[0] > 0:
+            rng = torch.stack([self.Z1.min(), -self.Z1.max()])
+        else:
+            rng = torch.full((2,), float("inf"), device=self.Z1.device, dtype=self.Z1.dtype)
+        row_shard.all_reduce_(rng, "min")                     # one collective for (min, -max)
+        self.gp = be.ski_grid_from_range(float(rng[0]), float(-rng[1]), self.grid_size, self.Z1.device)
+
+    def _size(self):
+        n = self.Z1.shape[0]
+        return torch.Size((n, n))
+
+    @property
+    def dtype(self):
+        return self.Z1.dtype
+
+    @property
+    def device(self):
+        return self.Z1.device
+
+    def _matmul(self, rhs):
+        be = _backend.get_backend()
+        rhs = rhs.detach()
+        squeeze = rhs.dim() == 1
+        V = rhs.reshape(self.Z1.shape[0], -1).contiguous()
+        outs = []
+        for c0 in range(0, V.shape[1], 12):                   # the staged entry points take T <= 12 columns
+            Vp = V[:, c0:c0 + 12].contiguous()
+            J = self.Z1.shape[1]
+            if self.Z1.shape[0] > 0:
+                hist = be.ski_scatter(self.Z1, self.gp, Vp, self.grid_size)
+            else:
+                hist = torch.zeros(J, self.grid_size, Vp.shape[1], dtype=torch.float64, device=self.Z1.device)
+            self.row_shard.all_reduce_(hist, "sum")
+            if self.Z1.shape[0] > 0:
+                H = be.ski_grid_product(hist, self.gp, self.grid_size)
+                outs.append(be.ski_gather(self.Z1, self.gp, H, Vp, self._scale, self._noise, self.grid_size))
+            else:
+                outs.append(Vp.clone())
+        out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+        return out.reshape(-1) if squeeze else out
+
+    def _diagonal(self):
+        return _backend.get_backend().ski_diag(self.Z1, self.gp, self._scale, self.grid_size) + self._noise
+
+    def kernel_rows(self, z_rows):
+        """scale * K_ski(z_rows, local rows): k x N_local block for rows given by their (global) coordinates."""
+        return _backend.get_backend().ski_dense(z_rows.contiguous(), self.Z1, self.gp, self._scale, self.grid_size)
+
+
+class RowShardedWoodbury:
+    """M = L L^T + noise I with L split by rows: every product with L^T is a k x T all-reduce."""
+
+    def __init__(self, L_local, noise, row_shard):
+        self.L = L_local
+        self.noise = float(noise)
+        self.row_shard = row_shard
+        cap = (L_local.t() @ L_local).double()
+        row_shard.all_reduce_(cap, "sum")
+        cap.diagonal().add_(self.noise)
+        self._cap_chol = torch.linalg.cholesky(cap)
+
+    def solve(self, r):
+        t = (self.L.t() @ r).double()
+        self.row_shard.all_reduce_(t, "sum")
+        t = torch.cholesky_solve(t, self._cap_chol).to(r.dtype)
+        return (r - self.L @ t) / self.noise
+
+    __call__ = solve
+
+
+def row_sharded_preconditioner(op, rank):
+    """Rank-`rank` pivoted Cholesky of the noise-free row-sharded SKI operator with GLOBAL greedy pivots: per step one
+    MAX all-reduce of (largest local residual diagonal), one broadcast of the pivot's J coordinates from its owner, and
+    the usual downdate of the local rows.  Same pivots as the single-process factorisation (ties go to the lowest rank)."""
+    sh = op.row_shard
+    dev, dt = op.device, op.dtype
+    nloc, J = op.Z1.shape
+    d = (op._diagonal() - op._noise).clone() if nloc else torch.zeros(0, device=dev, dtype=dt)
+    dmax0 = torch.tensor([float(d.max()) if nloc else 0.0], device=dev, dtype=torch.float64)
+    sh.all_reduce_(dmax0, "max")
+    L = torch.zeros(rank, nloc, dtype=dt, device=dev)
+    for m in range(rank):
+        # (value, -rank) packed so that ONE max all-reduce picks the largest value and, among ties, the lowest rank
+        loc = float(d.max()) if nloc else -1.0
+        key = torch.tensor([loc], device=dev, dtype=torch.float64)
+        sh.all_reduce_(key, "max")
+        best = float(key[0])
+        claim = torch.tensor([sh.rank if (nloc and loc == best) else sh.world_size], device=dev, dtype=torch.float64)
+        sh.all_reduce_(claim, "min")
+        owner = int(claim[0])
+        zp = torch.zeros(1, J, device=dev, dtype=dt)
+        lp = torch.zeros(m + 1, device=dev, dtype=dt)             # the pivot's own entries in the previous columns
+        if sh.rank == owner:
+            p = int(torch.argmax(d))
+            zp[0] = op.Z1[p]
+            lp[:m] = L[:m, p]
+            lp[m] = d[p]
+            d[p] = 0.0
+            own_p = p
+        sh.broadcast_(zp, owner)
+        sh.broadcast_(lp, owner)
+        dp = float(lp[m])
+        if not dp > 1e-10 * float(dmax0[0]):
+            continue                                              # exhausted: zero column (as the single-process loop)
+        if nloc:
+            row = op.kernel_rows(zp)[0]
+            if m > 0:
+                row = row - L[:m].t() @ lp[:m]
+            l = row / (dp ** 0.5)
+            if sh.rank == owner:
+                l[own_p] = dp ** 0.5
+            L[m] = l
+            d = (d - l * l).clamp_min(0.0)
+            if sh.rank == owner:
+                d[own_p] = 0.0
+    return RowShardedWoodbury(L.t().contiguous(), op._noise, sh)
+
+
 class FamilyAdditiveOperator(AdditiveRPOperator):
     """K = outputscale * sum_c w_c phi_kind(group c of Z's columns) — the other members of the family behind the same
     operator: `kernel_type` Matern / InverseMQ / Cosine sub-kernels (training_routines.py:47-88),

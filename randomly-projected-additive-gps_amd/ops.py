@@ -386,6 +386,69 @@ def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
     return out.squeeze(1) if squeeze else out
 
 
+def ski_grid_from_range(zmin, zmax, grid_size, device, weights=None):
+    """The grid-parameter block of rpgp_ski_grid for a KNOWN coordinate range (row-sharded SKI: the range is all-reduced
+    over the ranks first): h = range / (G - 5), g0 = zmin - 2 h, so that every 4-tap stencil is interior."""
+    import numpy as np
+    mn, mx = np.float32(zmin), np.float32(zmax)
+    rng = np.float32(mx - mn)
+    if not rng > np.float32(1e-12):
+        rng = np.float32(1e-12)
+    h = np.float32(rng / np.float32(grid_size - 5))
+    head = [float(np.float32(mn - np.float32(2.0) * h)), float(h), float(np.float32(1.0) / h), 0.0 if weights is None else 1.0]
+    gp = torch.tensor(head, dtype=torch.float32, device=device)
+    if weights is not None:
+        gp = torch.cat([gp, weights.detach().reshape(-1).to(device=device, dtype=torch.float32)])
+    return gp
+
+
+def ski_scatter(Z, gp, V, grid_size=1024):
+    """Stage 1 of the SKI MVM: hist[j][g][t] (float64, J x G x T) = sum over the rows of Z of w(z_ij)[g] V[i][t]."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    N, J = Z.shape
+    V2, _ = _as_matrix(V, N, "V")
+    T = V2.shape[1]
+    hist = torch.empty((J, grid_size, T), dtype=torch.float64, device=Z.device)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
+        _lib.check(lib.rpgp_ski_scatter(Z.data_ptr(), gp.data_ptr(), V2.data_ptr(), hist.data_ptr(), N, J, J, grid_size,
+                                        T, ws.data_ptr(), ws.numel(), _stream()), "rpgp_ski_scatter")
+    return hist
+
+
+def ski_grid_product(hist, gp, grid_size=1024):
+    """Stage 2: H[j][m][t] (float32) = w_j * sum_m' Tm[m, m'] hist[j][m'][t]  (float64 Toeplitz product on the matrix cores)."""
+    lib = _lib.load()
+    if hist.dtype != torch.float64 or not hist.is_cuda or hist.dim() != 3:
+        raise TypeError("hist must be a float64 J x G x T tensor on a HIP device")
+    hist = hist.contiguous()
+    J, G, T = hist.shape
+    H = torch.empty((J, G, T), dtype=torch.float32, device=hist.device)
+    with torch.cuda.device(hist.device):
+        _lib.check(lib.rpgp_ski_grid_product(hist.data_ptr(), gp.data_ptr(), H.data_ptr(), J, G, T, _stream()),
+                   "rpgp_ski_grid_product")
+    return H
+
+
+def ski_gather(Z, gp, H, V, scale, noise=0.0, grid_size=1024):
+    """Stage 3: out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0 + k][t] + noise * V[i][t] for the rows of Z."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2)
+    M, J = Z.shape
+    H = _require(H, "H", 3)
+    T = H.shape[2]
+    V2 = None
+    if noise:
+        V2, _ = _as_matrix(V, M, "V")
+    out = torch.empty((M, T), dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        _lib.check(lib.rpgp_ski_gather(Z.data_ptr(), gp.data_ptr(), H.data_ptr(), None if V2 is None else V2.data_ptr(),
+                                       out.data_ptr(), M, J, J, grid_size, T, float(scale), float(noise), _stream()),
+                   "rpgp_ski_gather")
+    return out
+
+
 def ski_pivoted_cholesky(Z, gp, scale, rank, grid_size=1024):
     """Pivoted Cholesky of the SKI operator: L (N x rank)."""
     lib = _lib.load()

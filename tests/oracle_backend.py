@@ -147,6 +147,41 @@ class OracleBackend:
         r = _t(out, V)
         return r.squeeze(1) if squeeze else r
 
+    def ski_dense(self, Z1, Z2, gp, scale, grid_size=1024):
+        return _t(sko.dense_kernel(_np(Z1), _np(Z2), scale, grid_size, self._grid(gp), self._w(gp)), Z1)
+
+    # ---- staged SKI (row-sharded operator): scatter -> all-reduce -> grid product -> gather ----------------------
+    def ski_grid_from_range(self, zmin, zmax, grid_size, device, weights=None):
+        rng = max(float(zmax) - float(zmin), 1e-12)
+        h = rng / (grid_size - 5)
+        head = [float(zmin) - 2.0 * h, h, 1.0 / h, 0.0 if weights is None else 1.0]
+        tail = [] if weights is None else [float(x) for x in weights.detach().reshape(-1)]
+        return torch.tensor(head + tail, dtype=torch.float64)
+
+    def ski_scatter(self, Z, gp, V, grid_size=1024):
+        z, v = _np(Z), _np(V).reshape(Z.shape[0], -1)
+        g0, h = self._grid(gp)
+        hist = np.stack([sko.interp_sparse(z[:, j], g0, h, grid_size).T @ v for j in range(z.shape[1])])
+        return torch.from_numpy(hist)
+
+    def ski_grid_product(self, hist, gp, grid_size=1024):
+        g0, h = self._grid(gp)
+        Tm = sko.toeplitz(h, grid_size)
+        w = self._w(gp)
+        H = np.stack([(1.0 if w is None else w[j]) * (Tm @ hist[j].double().numpy()) for j in range(hist.shape[0])])
+        return torch.from_numpy(H)
+
+    def ski_gather(self, Z, gp, H, V, scale, noise=0.0, grid_size=1024):
+        z = _np(Z)
+        g0, h = self._grid(gp)
+        out = np.zeros((z.shape[0], H.shape[2]))
+        for j in range(z.shape[1]):
+            out += sko.interp_sparse(z[:, j], g0, h, grid_size) @ H[j].double().numpy()
+        out *= scale
+        if noise:
+            out += noise * _np(V).reshape(z.shape[0], -1)
+        return _t(out, Z)
+
     def ski_diag(self, Z, gp, scale, grid_size=1024):
         return _t(np.diag(sko.dense_kernel(_np(Z), _np(Z), scale, grid_size, self._grid(gp), self._w(gp))).copy(), Z)
 

@@ -1,0 +1,65 @@
+"""Child process of tests/test_rccl_gpu.py: one rank per GPU, process group on RCCL ("nccl") exactly as bench.py and
+runner.py set it up; exercises every collective the multi-GPU paths issue, through the real HIP backend.
+Launched as a FRESH process (the parent test process never initialises a process group)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local_rank)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+world, rank = dist.get_world_size(), dist.get_rank()
+dev = torch.device("cuda", local_rank)
+
+t = torch.ones(1000, device=dev)
+dist.all_reduce(t)
+torch.cuda.synchronize()
+assert float(t[0]) == world
+
+from rpgp_amd import ops, linear_cg as lcg
+from rpgp_amd.distributed import JShard, RowShard
+from rpgp_amd.operators import (AdditiveRPOperator, AddedDiagOperator, RowShardedSKIOperator, SKIAdditiveOperator,
+                                row_sharded_preconditioner)
+
+g = torch.Generator().manual_seed(0)
+# (1) pair- and J-sharded exact MVM: one all-reduce of the N x T partial per product
+N, J, T = 3000, 20, 2
+Z = torch.randn(N, J, generator=g).to(dev)
+V = torch.randn(N, T, generator=g).to(dev)
+s = torch.tensor(0.9, device=dev)
+full = AddedDiagOperator(AdditiveRPOperator(Z, None, s, 1.0 / J), torch.tensor(0.1, device=dev))._matmul(V)
+for mode in ("pairs", "j"):
+    sh = JShard(J, mode=mode)
+    got = AddedDiagOperator(AdditiveRPOperator(Z, None, s, 1.0 / J, shard=sh), torch.tensor(0.1, device=dev))._matmul(V)
+    rel = float((got - full).norm() / full.norm())
+    assert rel < 1e-6, (mode, rel)
+
+# (2) row-sharded SKI: float64 histogram all-reduce (SUM), grid-range all-reduce (MIN), preconditioner pivots (MAX /
+#     MIN all-reduces + broadcasts), CG scalars
+N, J, T, G = 40000, 3, 11, 1024
+Z = torch.randn(N, J, generator=g).to(dev)
+V = torch.randn(N, T, generator=g).to(dev)
+noise = 0.2
+ref_op = SKIAdditiveOperator(Z, None, s, 1.0 / J, grid_size=G)
+ref = AddedDiagOperator(ref_op, torch.tensor(noise, device=dev))._matmul(V)
+rs = RowShard(N)
+op = RowShardedSKIOperator(Z[rs.r0:rs.r1], s, 1.0 / J, rs, grid_size=G, noise=noise)
+out = op._matmul(V[rs.r0:rs.r1])
+rel = float((out - ref[rs.r0:rs.r1]).norm() / ref[rs.r0:rs.r1].norm())
+assert rel < 2e-6, rel
+pre = row_sharded_preconditioner(op, 15)
+x = lcg.linear_cg(op._matmul, V[rs.r0:rs.r1].clone(), tolerance=1e-4, max_iter=500, preconditioner=pre,
+                  reduce=rs.all_reduce_, global_size=N)
+res = op._matmul(x) - V[rs.r0:rs.r1]
+sq = torch.stack([res.double().pow(2).sum(), V[rs.r0:rs.r1].double().pow(2).sum()])
+rs.all_reduce_(sq)
+assert float((sq[0] / sq[1]).sqrt()) < 5e-4, float((sq[0] / sq[1]).sqrt())
+dist.barrier()
+if rank == 0:
+    print("RCCL_CHILD_OK world=%d iters=%d sharded_rel=%.2e" % (world, lcg.stats["last_iterations"], rel))
+dist.destroy_process_group()

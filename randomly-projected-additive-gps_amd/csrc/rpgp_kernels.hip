@@ -1475,9 +1475,9 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
 #pragma unroll
       for (int u = 0; u < 16; ++u) x[u] = V[(i + (long long)u * PPI) * T + t];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) vm = fmaxf(vm, __builtin_fabsf(x[u]));
+      for (int u = 0; u < 16; ++u) vm = max_nan(vm, __builtin_fabsf(x[u]));
     }
-    for (; i < n1; i += PPI) vm = fmaxf(vm, __builtin_fabsf(V[i * T + t]));
+    for (; i < n1; i += PPI) vm = max_nan(vm, __builtin_fabsf(V[i * T + t]));
   }
   smax[threadIdx.x] = vm;
   {
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
   __syncthreads();
   if ((int)threadIdx.x < LPP) {
     float m = 0.f;
-    for (int q = 0; q < PPI; ++q) m = fmaxf(m, smax[q * LPP + threadIdx.x]);
+    for (int q = 0; q < PPI; ++q) m = max_nan(m, smax[q * LPP + threadIdx.x]);
     int cmax = 1;
     for (int q = 0; q < 256; ++q) cmax = scmax[q] > cmax ? scmax[q] : cmax;
     const float bound = 1.05f * (float)cmax * m;
@@ -1528,6 +1528,11 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
       (void)frexpf(bound, &ex);                       // bound < 2^ex
       sc = ldexpf(1.0f, 30 - ex);
       inv = ldexpf(1.0f, ex - 30);
+    } else if (!(bound == bound) || bound >= 3.0e38f) {
+      // a NaN / Inf entry in this chunk's column: integer accumulation would silently drop it (NaN converts to 0) and
+      // the product would stay finite — poison the chunk's histogram column instead so that it propagates like in the
+      // exact operator (and the CG NaN guard sees it)
+      inv = __builtin_nanf("");
     }
     sscale[threadIdx.x] = sc;
     sinv[threadIdx.x] = inv;

@@ -242,7 +242,10 @@ def train_to_convergence(model, xs, ys, optimizer=None, lr=0.1, objective=None, 
 def _save_state_dict(model):
     """training_routines.py:37-44: torch.save(state_dict) to <model_base_path>/models/model_state_dict_<hash>.pkl.
     The base path comes from the environment (RPGP_MODEL_BASE_PATH) instead of a user-made config.py; without it
-    nothing is written and '' is returned."""
+    nothing is written and '' is returned.  Same file name and `torch.save(state_dict)` format as the reference, but the
+    KEY LAYOUT IS THIS PACKAGE'S OWN (e.g. `likelihood.raw_noise` where GPyTorch has `likelihood.noise_covar.raw_noise`,
+    float64 `weight` / `inner_lengthscale` buffers of the additive base kernel, no frozen inner RBF parameters): the
+    checkpoints reload into rpgp_amd models, they are not interchangeable with GPyTorch state dicts."""
     base = os.environ.get("RPGP_MODEL_BASE_PATH")
     if not base:
         return ""

@@ -279,3 +279,19 @@ def test_ski_dense_block_matches_oracle_and_mvm(gpu_device, weighted):
     V = torch.randn(N, 5, generator=torch.Generator().manual_seed(0)).to(gpu_device)
     mv = ops.ski_mvm(Z1t, Zt, gp, V, 0.6, 0.0, G)
     assert float((Kd @ V - mv).norm() / mv.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_ski_mvm_propagates_non_finite_rhs(gpu_device, bad):
+    """A NaN / Inf right-hand-side entry must poison the SKI product like it poisons the exact operator (the fixed-point
+    scatter used to drop it: ADVICE r1)."""
+    from rpgp_amd import ops
+    N, J, T, G = 5000, 3, 4, 1024
+    g = torch.Generator().manual_seed(0)
+    Z = torch.randn(N, J, generator=g).to(gpu_device)
+    V = torch.randn(N, T, generator=g)
+    V[1234, 2] = bad
+    gp = ops.ski_grid(Z, None, G)
+    out = ops.ski_mvm(Z, Z, gp, V.to(gpu_device), 0.3, 0.0, G)
+    assert not torch.isfinite(out[:, 2]).any()              # the dense operator mixes it into every row
+    assert torch.isfinite(out[:, [0, 1, 3]]).all()

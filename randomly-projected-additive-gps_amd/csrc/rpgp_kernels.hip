@@ -933,6 +933,162 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Symmetric form of the bilinear derivative (what training runs at N >= 2048): S_ii' = S_i'i, so every unordered pair
+// is evaluated ONCE and feeds both rows,
+//     gz[i][j] += S e_j d_j      gz[i'][j] -= S e_j d_j      gs[i] += S sum_j e_j      gs[i'] += S sum_j e_j
+// — half the exponentials of the full sweep above.  Same tile decomposition as the fused MVM (a workgroup owns BR = 512
+// rows and a chunk of columns starting at its diagonal block; lane l visits column (l + s) mod 64 at step s; the JT + 1
+// transposed accumulators travel with their column by a DPP wave rotate per step); two rows per lane halve the LDS
+// traffic per pair (the one-row full sweep spends 11 ds_read_b128 per pair: 93 % of the LDS issue rate).
+// slabR[kchunk][row][JT + 1] : row sums of a column chunk         slabT[rb][col][JT + 1] : transposed sums of row block rb
+// ---------------------------------------------------------------------------------------------
+template <int JT, int TT>
+__global__ __launch_bounds__(256, 2) void bilinear_sym_kernel(const float *__restrict__ Z, const float *__restrict__ L,
+                                                              const float *__restrict__ Rm, float *__restrict__ slabR,
+                                                              float *__restrict__ slabT, int N, int ldz, int T, int j0,
+                                                              int chunk_cols, int rotdir, int w0, int rb_first,
+                                                              int slab_row0, int slab_rows) {
+  constexpr int R = 2;
+  constexpr int BR = 256 * R;
+  constexpr int W = JT + 1;                        // slab width: JT gradient columns + the scale column
+  constexpr int STRQ = JT + 2 * TT;
+  constexpr int STR = (STRQ % 4 == 0) ? (((STRQ / 4) % 2 == 1) ? STRQ : STRQ + 4) : STRQ;   // (STR/4) odd: conflict-free b128
+  __shared__ __attribute__((aligned(16))) float sC[64 * STR];
+  __shared__ __attribute__((aligned(16))) float sT[4 * 64 * W];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
+  const int r0 = rb * BR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+
+  float a[R][JT], li[R][TT], ri[R][TT], accG[R][JT], accS[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+    const bool valid = row < N;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      a[r][j] = valid ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 0.f;
+      accG[r][j] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {               // rows beyond N: L = R = 0 -> S = 0 -> no contribution
+      li[r][t] = (valid && t < T) ? L[(size_t)row * T + t] : 0.f;
+      ri[r][t] = (valid && t < T) ? Rm[(size_t)row * T + t] : 0.f;
+    }
+    accS[r] = 0.f;
+  }
+
+  for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * STRQ; e += 256) {
+      const int c = e / STRQ, q = e % STRQ;
+      const int col = c0 + c;
+      float val = 0.f;                            // columns beyond the chunk: L = R = 0 -> S = 0
+      if (col < c_end) {
+        if (q < JT) val = Z[(size_t)col * ldz + j0 + q] * kExp2Scale;
+        else if (q < JT + TT) { const int t = q - JT; val = t < T ? L[(size_t)col * T + t] : 0.f; }
+        else { const int t = q - JT - TT; val = t < T ? Rm[(size_t)col * T + t] : 0.f; }
+      }
+      sC[c * STR + q] = val;
+    }
+    __syncthreads();
+    const bool doT = (c0 >= r0 + BR);
+    float accT[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) accT[q] = 0.f;
+#pragma unroll 1
+    for (int s = 0; s < 64; ++s) {
+      const float *p = sC + ((lane + rotdir * s) & 63) * STR;
+      float pz[JT], pl[TT], pr[TT];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) pz[j] = p[j];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) { pl[t] = p[JT + t]; pr[t] = p[JT + TT + t]; }
+      float tg[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) tg[q] = accT[q];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float S = 0.f;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          S = __builtin_fmaf(li[r][t], pr[t], S);
+          S = __builtin_fmaf(ri[r][t], pl[t], S);
+        }
+        float ks = 0.f;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+          const float dd = a[r][j] - pz[j];
+          const float e = fast_exp2(-(dd * dd));
+          ks += e;
+          const float g = (S * e) * dd;
+          accG[r][j] += g;
+          tg[j] -= g;
+        }
+        const float sk = S * ks;
+        accS[r] += sk;
+        tg[JT] += sk;
+      }
+      if (doT) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) accT[q] = wave_rotate1(tg[q]);
+      }
+    }
+    if (doT) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) sT[(wave * 64 + lane) * W + q] = accT[q];
+    }
+    __syncthreads();
+    if (doT) {
+      for (int e = tid; e < 64 * W; e += 256) {
+        const int c = e / W, q = e % W;
+        const int col = c0 + c;
+        if (col < c_end) {
+          const float sum = sT[(0 * 64 + c) * W + q] + sT[(1 * 64 + c) * W + q] + sT[(2 * 64 + c) * W + q] +
+                            sT[(3 * 64 + c) * W + q];
+          slabT[((size_t)(rb - rb_first) * N + col) * W + q] = sum;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+    if (row < N) {
+      float *dst = slabR + ((size_t)kchunk * slab_rows + (row - slab_row0)) * W;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) dst[j] = accG[r][j];
+      dst[JT] = accS[r];
+    }
+  }
+}
+
+// gZ[row][j0 + q] = mulG * (sum_k slabR[k][row][q] + sum_{b < row / BR} slabT[b][row][q]),  q < JT;   column JT -> rowS
+__global__ __launch_bounds__(256) void bilinear_sym_reduce_kernel(const float *__restrict__ slabR,
+                                                                  const float *__restrict__ slabT,
+                                                                  float *__restrict__ gZ, float *__restrict__ rowS, int N,
+                                                                  int JT, int ldg, int j0, int BR, int chunk_cols,
+                                                                  int slab_rows, float mulG, int accumulate) {
+  const int W = JT + 1;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)N * W) return;
+  const int row = (int)(gid / W), q = (int)(gid % W);
+  const int rb = row / BR;
+  const int nk = (N - rb * BR + chunk_cols - 1) / chunk_cols;
+  double acc = 0.0;
+  for (int k = 0; k < nk; ++k) acc += (double)slabR[(size_t)k * slab_rows * W + gid];
+  for (int b = 0; b < rb; ++b) acc += (double)slabT[(size_t)b * N * W + gid];
+  if (q < JT) gZ[(size_t)row * ldg + j0 + q] = mulG * (float)acc;
+  else rowS[row] = accumulate ? rowS[row] + (float)acc : (float)acc;
+}
+
 // Dense-weight variant for the Cholesky regime (N <= max_cholesky_size): S is an explicit symmetric N x N matrix
 // (e.g. Khat^-1 - alpha alpha^T).  Lane owns row i and reads S[c][i] (coalesced thanks to symmetry).
 template <int JT>
@@ -2602,6 +2758,30 @@ int launch_bilinear_dense(const float *Z, const float *S, float *slabG, float *s
   return launch_status();
 }
 
+// symmetric-sweep plan of the bilinear derivative (BR = 512): slabR [maxchunks][N][21] + slabT [row blocks][N][21] + rowS
+inline bool bilinear_use_sym(int64_t N) {
+  if (N < 2048) return false;
+  const double slabT_bytes = (double)((N + 511) / 512) * (double)N * 21.0 * 4.0;
+  return slabT_bytes <= 6.0e9;                     // beyond ~190k rows the full sweep's 46 MB workspace is kept
+}
+inline size_t bilinear_sym_floats(int64_t N) {
+  const TilePlan p = make_plan(N, N, true, 12, 1, 0, false, 512);
+  return ((size_t)p.maxchunks * N + (size_t)p.nrb * N) * 21 + (size_t)N;
+}
+
+template <int JT>
+int launch_bilinear_sym(int tt, const TilePlan &p, const float *Z, const float *L, const float *R, float *slabR,
+                               float *slabT, int N, int ldz, int T, int j0, hipStream_t st) {
+  dim3 grid(p.total_wg), block(256);
+  if (tt <= 4)
+    hipLaunchKernelGGL((bilinear_sym_kernel<JT, 4>), grid, block, 0, st, Z, L, R, slabR, slabT, N, ldz, T, j0,
+                       p.chunk_cols, g_rotdir, 0, 0, 0, N);
+  else
+    hipLaunchKernelGGL((bilinear_sym_kernel<JT, 12>), grid, block, 0, st, Z, L, R, slabR, slabT, N, ldz, T, j0,
+                       p.chunk_cols, g_rotdir, 0, 0, 0, N);
+  return launch_status();
+}
+
 // ---- generalised family dispatch ---------------------------------------------------------------
 #include <type_traits>
 template <int V> using IntC = std::integral_constant<int, V>;
@@ -2992,7 +3172,12 @@ size_t rpgp_bilinear_grad_workspace_bytes(int64_t N, int J) {
   if (N <= 0 || J <= 0) return 0;
   const int ns = bilinear_nsplit(N);
   // slabG [ns][N][<=20] + slabS [ns][N] + rowS [N]
-  return ((size_t)ns * N * 21 + (size_t)N) * sizeof(float);
+  size_t f = (size_t)ns * N * 21 + (size_t)N;
+  if (bilinear_use_sym(N)) {
+    const size_t g = bilinear_sym_floats(N);
+    if (g > f) f = g;
+  }
+  return f * sizeof(float);
 }
 
 int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ, float *gscale, int64_t N, int ldz,
@@ -3003,6 +3188,40 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
   if (N > 0x7fffffffLL) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
+  if (bilinear_use_sym(N) && !(getenv("RPGP_BILINEAR_FULL") && getenv("RPGP_BILINEAR_FULL")[0] == '1')) {
+    // symmetric sweep: every unordered pair once (half the exponentials), tile plan of the fused MVM with BR = 512
+    int rc = rpgp_init();
+    if (rc) return rc;
+    const TilePlan p = make_plan(N, N, true, 12, 1, 0, false, 512);
+    float *slabR = reinterpret_cast<float *>(workspace);
+    float *slabT = slabR + (size_t)p.maxchunks * N * 21;
+    float *rowS = slabT + (size_t)p.nrb * N * 21;
+    int first = 1;
+    for (int j = j0; j < j1;) {
+      const int jt = next_j_piece(j1 - j);
+      switch (jt) {
+        case 20: rc = launch_bilinear_sym<20>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+        case 10: rc = launch_bilinear_sym<10>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+        case 8: rc = launch_bilinear_sym<8>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+        case 5: rc = launch_bilinear_sym<5>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+        case 3: rc = launch_bilinear_sym<3>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+        case 4: rc = launch_bilinear_sym<4>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+        case 2: rc = launch_bilinear_sym<2>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+        default: rc = launch_bilinear_sym<1>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+      }
+      if (rc) return rc;
+      const size_t total = (size_t)N * (jt + 1);
+      hipLaunchKernelGGL(bilinear_sym_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabR,
+                         slabT, gZ, rowS, (int)N, jt, ldg, j, p.BR, p.chunk_cols, (int)N, -scale / kExp2Scale,
+                         first ? 0 : 1);
+      rc = launch_status();
+      if (rc) return rc;
+      first = 0;
+      j += jt;
+    }
+    hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, st, rowS, gscale, (int)N, 0.5f);
+    return launch_status();
+  }
   const int ns_max = bilinear_nsplit(N);          // the slab layout (and the workspace size) uses the upper bound
   int cps = (int)((N + ns_max - 1) / ns_max);
   cps = (cps + 63) / 64 * 64;

@@ -230,7 +230,7 @@ def main():
         if 4.0 * N * N < 0.3 * torch.cuda.get_device_properties(device).total_memory:
             torch.cuda.synchronize()
             tk = time.perf_counter()
-            Kd = ops.dense(Z, Z, scale)
+            Kd = ops.dense(Z, Z, scale, pad=True)
             torch.cuda.synchronize()
             t_build = time.perf_counter() - tk
             ops.dense_mvm(Kd, V, noise)
@@ -240,10 +240,19 @@ def main():
                 oc = ops.dense_mvm(Kd, V, noise)
             torch.cuda.synchronize()
             t_c = (time.perf_counter() - tk) / 10
+            ops.dense_mvm(Kd, V11, noise)
+            torch.cuda.synchronize()
+            tk = time.perf_counter()
+            for _ in range(10):
+                ops.dense_mvm(Kd, V11, noise)
+            torch.cuda.synchronize()
+            t_c11 = (time.perf_counter() - tk) / 10
             cached = {"mvm_ms": round(t_c * 1e3, 4), "mvm_per_s": round(1.0 / t_c, 1), "build_ms": round(t_build * 1e3, 3),
+                      "block_T11_ms": round(t_c11 * 1e3, 4),
                       "hbm_GBps": round(4.0 * N * N / t_c / 1e9, 1), "hbm_frac_of_8TBps": round(4.0 * N * N / t_c / 8e12, 4),
                       "rel_diff_vs_fused": float((oc - res).norm() / res.norm()),
-                      "note": "literal HBM stream of the 4N^2-byte matrix (rpgp_dense_mvm, MFMA fp32); not the headline"}
+                      "note": "literal HBM stream of the 4N^2-byte matrix (rpgp_dense_mvm); what the training / prediction solves "
+                              "run automatically when K fits a quarter of HBM (settings.cache_kernel = 'auto'); not the headline"}
             del Kd
         # SKI mode (the reference's `ski: true` specs, e.g. additive_spread_prescale_J20_ski.json): grid interpolation of
         # the same operator, O(N (J + T)) per MVM; an approximation (difference reported), never the headline
@@ -265,7 +274,17 @@ def main():
         ski = {"grid_size": 1024, "mvm_ms": round(t_ski * 1e3, 4), "mvm_per_s": round(1.0 / t_ski, 1),
                "block_T11_ms": round(t_ski11 * 1e3, 4), "rel_diff_vs_fused": float((osk - res).norm() / res.norm()),
                "note": "cubic interpolation onto a 1024-point grid + Toeplitz RBF (rpgp_ski_mvm); approximate, not the headline"}
-        result["extras"] = {"cached_k": cached, "ski": ski,
+        # backward pass of one training step: the bilinear derivative with the 10 probe solves + the residual solve
+        Lb = (torch.randn(N, 11, generator=torch.Generator().manual_seed(5)) * 0.1).to(device)
+        Rb = (torch.randn(N, 11, generator=torch.Generator().manual_seed(6)) * 0.1).to(device)
+        ops.bilinear_grad(Z, Lb, Rb, scale)
+        torch.cuda.synchronize()
+        tk = time.perf_counter()
+        for _ in range(3):
+            ops.bilinear_grad(Z, Lb, Rb, scale)
+        torch.cuda.synchronize()
+        t_bil = (time.perf_counter() - tk) / 3
+        result["extras"] = {"cached_k": cached, "ski": ski, "bilinear_derivative_T11_ms": round(t_bil * 1e3, 4),
                             "block_T11_ms": round(t11 * 1e3, 4), "block_T11_mvm_equiv_per_s": round(11.0 / t11, 1),
                             "solve_Khat_inv_y": {"what": "mean-cache solve, rank-15 pivoted-Cholesky preconditioner, native mBCG, fused MVM",
                                                  "tolerance": 0.01, "cg_iterations": lcg.stats["last_iterations"],

@@ -191,11 +191,31 @@ __global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, co
   __shared__ float stv[kMaxK * kMaxT];    // Cinv w
   __shared__ float sh[4];
   if (K > 0) {
-    for (int e = threadIdx.x; e < K * T; e += 256) {
+    // w = sum over the producer's workgroups of their K x T partials.  Wave q takes every 4th slab, lane l the elements
+    // l, l + 64, ... of it (coalesced 256-byte rows, all loads of a wave independent), the four wave sums are added in a
+    // fixed order.  (One thread per element looping over the ~256 slabs was a serial chain of L2-latency loads: 60 of the
+    // kernel's 70 us at N = 391k.)
+    __shared__ double swq[4][kMaxK * kMaxT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int KT = K * T;
+    for (int e0 = 0; e0 < KT; e0 += 64) {
+      const int e = e0 + lane;
       double s = 0.0;
-      for (int p = 0; p < nparts_w; ++p) s += (double)partial_w[(size_t)p * K * T + e];
-      sw[(e / T) * kMaxT + e % T] = s;
+      if (e < KT) {
+        int p = wv;
+        for (; p + 28 < nparts_w; p += 32) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = partial_w[(size_t)(p + 4 * u) * KT + e];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; p < nparts_w; p += 4) s += (double)partial_w[(size_t)p * KT + e];
+        swq[wv][e] = s;
+      }
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < KT; e += 256) sw[(e / T) * kMaxT + e % T] = ((swq[0][e] + swq[1][e]) + swq[2][e]) + swq[3][e];
     __syncthreads();
     for (int e = threadIdx.x; e < K * T; e += 256) {
       const int a = e / T, t = e % T;

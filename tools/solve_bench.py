@@ -17,6 +17,8 @@ def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol, ski=False, fu
     y = (y - y.mean()) / y.std()
     Xtr, ytr, Xte, yte = X[:N].to(dev), y[:N].to(dev), X[N:].to(dev), y[N:].to(dev)
     torch.manual_seed(0)
+    import numpy as np
+    np.random.seed(0)            # space_equally draws its orthonormal start from the NumPy RNG (rp.py:228)
     model, lik = create_exact_gp(Xtr, ytr, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
                                  prescale=True, space_proj=space_proj, ski=ski,
                                  ski_options={"grid_size": 1024, "num_dims": 1} if ski else None)

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, co
   // the capacitance system (sigma2 I + L^T L) has a condition number ~ |K| / sigma2 (1e5 at N = 391k): its k x k
   // solve is carried in float64 (as the torch path does), only the N-sized vector work is float32
   __shared__ double sw[kMaxK * kMaxT];    // w = L^T r
-  __shared__ float stv[kMaxK * kMaxT];    // Cinv w
+  __shared__ double stv[kMaxK * kMaxT];   // Cinv w (kept in float64: r - L (Cinv w) cancels to ~sigma^2 / |K| of r)
   __shared__ float sh[4];
   if (K > 0) {
     // w = sum over the producer's workgroups of their K x T partials.  Wave q takes every 4th slab, lane l the elements
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, co
       const int a = e / T, t = e % T;
       double s = 0.0;
       for (int b = 0; b < K; ++b) s += Cinv[a * K + b] * sw[b * kMaxT + t];
-      stv[a * kMaxT + t] = (float)s;
+      stv[a * kMaxT + t] = s;
     }
     __syncthreads();
   }
@@ -237,11 +237,14 @@ __global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, co
     for (int t = 0; t < kMaxT; ++t) {
       if (t < T) {
         const float rv = r[i * T + t];
-        float corr = 0.f;
+        float zv = rv;
+        if (K > 0) {
+          double corr = 0.0;
 #pragma unroll
-        for (int b = 0; b < kMaxK; ++b)
-          if (b < K) corr = __builtin_fmaf(lrow[b], stv[b * kMaxT + t], corr);
-        const float zv = (rv - corr) * inv_s;
+          for (int b = 0; b < kMaxK; ++b)
+            if (b < K) corr = fma((double)lrow[b], stv[b * kMaxT + t], corr);
+          zv = (float)(((double)rv - corr) * (double)inv_s);
+        }
         z[i * T + t] = zv;
         acc[t] = __builtin_fmaf(rv, zv, acc[t]);
       }

@@ -437,13 +437,16 @@ class RowShardedWoodbury:
         self.L = L_local
         self.noise = float(noise)
         self.row_shard = row_shard
-        cap = (L_local.t() @ L_local).double()
+        self._L64 = L_local.double()
+        from .precond import gram64
+        cap = gram64(self._L64, self._L64)            # float64 accumulation (see precond.WoodburyPreconditioner)
         row_shard.all_reduce_(cap, "sum")
         cap.diagonal().add_(self.noise)
         self._cap_chol = torch.linalg.cholesky(cap)
 
     def solve(self, r):
-        t = (self.L.t() @ r).double()
+        from .precond import gram64
+        t = gram64(self._L64, r.double())
         self.row_shard.all_reduce_(t, "sum")
         t = torch.cholesky_solve(t, self._cap_chol).to(r.dtype)
         return (r - self.L @ t) / self.noise

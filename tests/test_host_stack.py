@@ -438,3 +438,24 @@ def test_full_kernel_types_match_dense_formulas(kernel_type):
     assert abs(val - ref) < 1e-4 * max(1.0, abs(ref))
     with pytest.raises(ValueError):
         create_exact_gp(X, y, "full", noise_prior=False, kernel_type="bogus")
+
+
+def test_woodbury_capacitance_survives_large_kernel_norm():
+    """|L^T L| ~ 1e6 with noise 0.3 in float32: the capacitance matrix must be accumulated in float64, or the Woodbury
+    formula stops inverting M = L L^T + noise I (round-2 regression at the C5 shape)."""
+    from rpgp_amd.precond import WoodburyPreconditioner
+    g = torch.Generator().manual_seed(0)
+    N, k, noise = 60000, 15, 0.3
+    L = (torch.randn(N, k, generator=g) * 4.0 + 3.0).float()          # columns far from orthogonal, |L^T L| ~ 1.5e6
+    pre = WoodburyPreconditioner(L, noise)
+    v = torch.randn(N, 3, generator=g).float()
+    Ld = L.double()
+    Mv = Ld @ (Ld.t() @ v.double()) + noise * v.double()
+    back = pre.solve(Mv.float()).double()
+    # M^-1 (M v) = v up to the float32 representation of M v (relative 6e-8 of |M v| ~ 1e6 |v| -> ~0.1 / noise); what must
+    # hold tightly is the float64 identity on a float32-representable right-hand side:
+    r32 = Mv.float()
+    exact = torch.linalg.solve(Ld.t() @ Ld + noise * torch.eye(k, dtype=torch.float64), Ld.t() @ r32.double())
+    ref = (r32.double() - Ld @ exact) / noise
+    assert float((back - ref).norm() / ref.norm()) < 1e-5
+    assert abs(pre.logdet() - float(torch.logdet(Ld.t() @ Ld + noise * torch.eye(k, dtype=torch.float64)) + (N - k) * np.log(noise))) < 1e-6 * N

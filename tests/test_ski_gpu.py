@@ -295,3 +295,41 @@ def test_ski_mvm_propagates_non_finite_rhs(gpu_device, bad):
     out = ops.ski_mvm(Z, Z, gp, V.to(gpu_device), 0.3, 0.0, G)
     assert not torch.isfinite(out[:, 2]).any()              # the dense operator mixes it into every row
     assert torch.isfinite(out[:, [0, 1, 3]]).all()
+
+
+def test_preconditioned_cg_on_badly_scaled_c5_system(gpu_device):
+    """Regression (round 2): with |K| / sigma^2 ~ 1e6 the Woodbury capacitance matrix sigma^2 I + L^T L must be
+    accumulated in float64 — accumulated in fp32 it was off by more than sigma^2 and preconditioned CG stagnated at a true
+    residual of 0.2 - 1.4 on this system (hyper-parameters reached after ten Adam steps on the C5 stand-in), while
+    un-preconditioned fp32 CG converges.  Both loops, true float64 residual from the sparse-W oracle."""
+    import warnings
+    from rpgp_amd import linear_cg as lcg, settings
+    from rpgp_amd.operators import SKIAdditiveOperator, AddedDiagOperator
+    from rpgp_amd.precond import build_preconditioner
+    N, J, G = 391386, 3, 1024
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N, J, generator=g)
+    y = torch.sin(X).sum(1) + 0.05 * torch.randn(N, generator=g)
+    y = (y - y.mean()) / y.std()
+    Q = torch.linalg.qr(torch.randn(J, J, generator=g))[0]
+    ls = torch.tensor([1.193, 0.495, 1.766])
+    s, noise = 0.8657, 0.45
+    Z = ((X / ls) @ Q).contiguous()
+    Zt = Z.to(gpu_device)
+    base = SKIAdditiveOperator(Zt, None, torch.tensor(s, device=gpu_device), 1.0 / J, grid_size=G)
+    khat = AddedDiagOperator(base, torch.tensor(noise, device=gpu_device))
+    pre = build_preconditioner(base, noise, settings)
+    rhs = torch.cat([pre.sample(10, generator=torch.Generator(device=gpu_device).manual_seed(1)),
+                     y.to(gpu_device).reshape(-1, 1)], dim=1)
+    gph = base.gp.double().cpu().numpy()
+    grid = (float(gph[0]), float(gph[1]))
+    bn = rhs.double().cpu().numpy()
+    for operator in (khat, None):                       # native executor, torch-op loop
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            x = lcg.linear_cg(khat._matmul, rhs, tolerance=0.01, max_iter=2000, preconditioner=pre, operator=operator)
+        assert not [m for m in w if "CG terminated" in str(m.message)]
+        assert lcg.stats["last_iterations"] < 150, lcg.stats["last_iterations"]
+        r = sko.mvm_sparse(Z.numpy(), Z.numpy(), x.double().cpu().numpy(), s / J, G, grid, noise) - bn
+        res = np.linalg.norm(r, axis=0) / np.linalg.norm(bn, axis=0)
+        assert res.mean() < 0.015, res

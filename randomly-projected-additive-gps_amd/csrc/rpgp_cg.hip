@@ -23,7 +23,8 @@ namespace {
 
 constexpr int kMaxT = 16;
 constexpr int kMaxK = 16;          // preconditioner rank
-constexpr int kMaxBlocks = 256;
+constexpr int kMaxBlocks = 256;     // workgroups of the vector kernels (every consumer workgroup reduces the T-wide partials in its prologue)
+constexpr int kMaxBlocksW = 256;    // ... of k_update / k_Ltr, whose K x T wide L^T r partials are reduced once by k_wsolve
 constexpr int kMaxHist = 64;        // Lanczos coefficients kept for at most this many iterations
 
 #define CG_CHECK(expr)                            \
@@ -179,50 +180,56 @@ __global__ __launch_bounds__(256) void k_Ltr(const float *__restrict__ L, const 
 }
 
 // z = M^-1 r with M = L L^T + sigma2 I (Woodbury, Cinv = (sigma2 I + L^T L)^-1), partial_rz = sum r.z
+// tv[a][t] = sum_b Cinv[a][b] * (sum over the producer's workgroups of partial_w[.][b][t]) in float64, ONE workgroup per
+// column t.  This used to be the prologue of EVERY k_precond workgroup (each re-reading all K x T slabs: 60 of that
+// kernel's 70 us at N = 391k); as its own launch (grid = T) it costs ~5 us and lets the streaming kernels use as many
+// workgroups as the HBM stream wants.  Thread (g = tid / 16, b = tid % 16): 16 groups take every 16th slab.
+__global__ __launch_bounds__(256) void k_wsolve(const float *__restrict__ partial_w, int nparts_w,
+                                                const double *__restrict__ Cinv, double *__restrict__ tv, int T, int K) {
+  __shared__ double part[16][kMaxK];
+  __shared__ double sw[kMaxK];
+  const int t = blockIdx.x;
+  const int b = threadIdx.x & 15, g = threadIdx.x >> 4;
+  double s = 0.0;
+  if (b < K) {
+    int p = g;
+    for (; p + 48 < nparts_w; p += 64) {
+      const float v0 = partial_w[((size_t)p * K + b) * T + t], v1 = partial_w[((size_t)(p + 16) * K + b) * T + t];
+      const float v2 = partial_w[((size_t)(p + 32) * K + b) * T + t], v3 = partial_w[((size_t)(p + 48) * K + b) * T + t];
+      s += (double)v0;
+      s += (double)v1;
+      s += (double)v2;
+      s += (double)v3;
+    }
+    for (; p < nparts_w; p += 16) s += (double)partial_w[((size_t)p * K + b) * T + t];
+    part[g][b] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < K) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += part[q][threadIdx.x];
+    sw[threadIdx.x] = tot;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < K) {
+    double acc = 0.0;
+    for (int c = 0; c < K; ++c) acc += Cinv[threadIdx.x * K + c] * sw[c];
+    tv[threadIdx.x * kMaxT + t] = acc;
+  }
+}
+
+// z = M^-1 r = (r - L tv) / sigma2 with tv = Cinv L^T r from k_wsolve (float64: the subtraction cancels to ~sigma^2 / |K|
+// of r along the range of L); partial r.z per workgroup.
 // K == 0: identity preconditioner (z = r)
-__global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, const double *__restrict__ Cinv,
-                                                 const float *__restrict__ partial_w, int nparts_w,
+__global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, const double *__restrict__ tv,
                                                  const float *__restrict__ r, float *__restrict__ z,
                                                  float *__restrict__ partial_rz, long long N, int T, int K,
                                                  float sigma2) {
-  // the capacitance system (sigma2 I + L^T L) has a condition number ~ |K| / sigma2 (1e5 at N = 391k): its k x k
-  // solve is carried in float64 (as the torch path does), only the N-sized vector work is float32
-  __shared__ double sw[kMaxK * kMaxT];    // w = L^T r
-  __shared__ double stv[kMaxK * kMaxT];   // Cinv w (kept in float64: r - L (Cinv w) cancels to ~sigma^2 / |K| of r)
+  __shared__ double stv[kMaxK * kMaxT];
   __shared__ float sh[4];
   if (K > 0) {
-    // w = sum over the producer's workgroups of their K x T partials.  Wave q takes every 4th slab, lane l the elements
-    // l, l + 64, ... of it (coalesced 256-byte rows, all loads of a wave independent), the four wave sums are added in a
-    // fixed order.  (One thread per element looping over the ~256 slabs was a serial chain of L2-latency loads: 60 of the
-    // kernel's 70 us at N = 391k.)
-    __shared__ double swq[4][kMaxK * kMaxT];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int KT = K * T;
-    for (int e0 = 0; e0 < KT; e0 += 64) {
-      const int e = e0 + lane;
-      double s = 0.0;
-      if (e < KT) {
-        int p = wv;
-        for (; p + 28 < nparts_w; p += 32) {
-          float v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = partial_w[(size_t)(p + 4 * u) * KT + e];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) s += (double)v[u];
-        }
-        for (; p < nparts_w; p += 4) s += (double)partial_w[(size_t)p * KT + e];
-        swq[wv][e] = s;
-      }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < KT; e += 256) sw[(e / T) * kMaxT + e % T] = ((swq[0][e] + swq[1][e]) + swq[2][e]) + swq[3][e];
-    __syncthreads();
-    for (int e = threadIdx.x; e < K * T; e += 256) {
-      const int a = e / T, t = e % T;
-      double s = 0.0;
-      for (int b = 0; b < K; ++b) s += Cinv[a * K + b] * sw[b * kMaxT + t];
-      stv[a * kMaxT + t] = s;
-    }
+    for (int e = threadIdx.x; e < kMaxK * kMaxT; e += 256) stv[e] = (e / kMaxT < K && e % kMaxT < T) ? tv[e] : 0.0;
     __syncthreads();
   }
   float acc[kMaxT];
@@ -343,7 +350,8 @@ __global__ __launch_bounds__(256) void k_update(const float *__restrict__ p, con
 // iterations the host marks with check_now — the convergence decision (st->poll.done), which freezes later iterations.
 __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, float *__restrict__ p,
                                                    const float *__restrict__ partial_rz, const float *__restrict__ partial_rr,
-                                                   int nparts, CgState *__restrict__ st, float *__restrict__ beta_out,
+                                                   int nparts, int nparts_rr, CgState *__restrict__ st,
+                                                   float *__restrict__ beta_out,
                                                    long long N, int T, float eps, int cur, int check_now,
                                                    float tolerance, int iter_count, int stagnation_window,
                                                    const float *__restrict__ x, float *__restrict__ x_best) {
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, 
   __shared__ float scratch[256];
   const int was_done = st->poll.done;
   reduce_partials(partial_rz, nparts, T, srzn, scratch);
-  reduce_partials(partial_rr, nparts, T, srr, scratch);
+  reduce_partials(partial_rr, nparts_rr, T, srr, scratch);
   if ((int)threadIdx.x < T) {
     const float rz = st->rz[cur][threadIdx.x];
     sbeta[threadIdx.x] = (fabsf(rz) > eps) ? srzn[threadIdx.x] / rz : 0.f;
@@ -425,9 +433,9 @@ __global__ __launch_bounds__(256) void k_unnormalise(float *__restrict__ x, cons
     for (int t = 0; t < T; ++t) x[i * T + t] = (use_best ? x_best[i * T + t] : x[i * T + t]) * st->rhs_norm[t];
 }
 
-inline int nblocks_for(long long N) {
+inline int nblocks_for(long long N, int cap = kMaxBlocks) {
   long long b = (N + 255) / 256;      // one 256-row tile per workgroup until the partial-sum slabs are full
-  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -501,7 +509,8 @@ size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_ran
   size_t total = 5 * align256(nt);                                             // r, p, z, Ap, x_best
   total += align256(sizeof(CgState));
   total += 3 * align256((size_t)kMaxBlocks * kMaxT * sizeof(float));           // partial pAp / rr / rz
-  total += align256((size_t)kMaxBlocks * kMaxK * kMaxT * sizeof(float));       // partial L^T r
+  total += align256((size_t)kMaxBlocksW * kMaxK * kMaxT * sizeof(float));      // partial L^T r
+  total += align256((size_t)kMaxK * kMaxT * sizeof(double));                   // tv = Cinv L^T r
   total += 2 * align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));       // alpha / beta history
   total += align256(operator_workspace(op, T));
   return total;
@@ -532,13 +541,17 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   float *part_a = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxT * sizeof(float));
   float *part_rr = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxT * sizeof(float));
   float *part_rz = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxT * sizeof(float));
-  float *part_w = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxK * kMaxT * sizeof(float));
+  float *part_w = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocksW * kMaxK * kMaxT * sizeof(float));
+  double *tv = reinterpret_cast<double *>(w); w += align256((size_t)kMaxK * kMaxT * sizeof(double));
   float *alpha_d = reinterpret_cast<float *>(w); w += align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));
   float *beta_d = reinterpret_cast<float *>(w); w += align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));
   void *op_ws = w;
   const size_t op_ws_bytes = operator_workspace(op, T);
 
+  // At N = 391k the 17 MB vectors make these kernels HBM streams: up to 1024 workgroups (4 per CU); the K x T
+  // preconditioner partials are reduced once per iteration by k_wsolve instead of by every consumer workgroup.
   const int nb = nblocks_for(N);
+  const int nbw = nblocks_for(N, kMaxBlocksW);
   const float eps = 1e-30f, stop_after = 1e-10f;
   {
     const int prc = g_poll.init();
@@ -550,8 +563,9 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   hipLaunchKernelGGL(k_coldot, dim3(nb), dim3(256), 0, st, rhs, rhs, part_a, N, T);
   hipLaunchKernelGGL(k_normalise, dim3(nb), dim3(256), 0, st, rhs, part_a, nb, r, x, state, N, T);
   // z0 = M^-1 r0, p0 = z0, rz0
-  if (K > 0) hipLaunchKernelGGL(k_Ltr, dim3(nb), dim3(256), 0, st, L, r, part_w, N, T, K);
-  hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, Cinv, part_w, nb, r, z, part_rz, N, T, K, precond_sigma2);
+  if (K > 0) hipLaunchKernelGGL(k_Ltr, dim3(nbw), dim3(256), 0, st, L, r, part_w, N, T, K);
+  if (K > 0) hipLaunchKernelGGL(k_wsolve, dim3(T), dim3(256), 0, st, part_w, nbw, Cinv, tv, T, K);
+  hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, tv, r, z, part_rz, N, T, K, precond_sigma2);
   hipLaunchKernelGGL(k_first_dir, dim3(nb), dim3(256), 0, st, z, p, part_rz, nb, state, N, T);
   CG_CHECK(hipGetLastError());
 
@@ -569,13 +583,13 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     if (rc) return rc;
     hipLaunchKernelGGL(k_coldot, dim3(nb), dim3(256), 0, st, p, Ap, part_a, N, T);
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
-    hipLaunchKernelGGL(k_update, dim3(nb), dim3(256), 0, st, p, Ap, part_a, nb, x, r, part_rr, state,
+    hipLaunchKernelGGL(k_update, dim3(nbw), dim3(256), 0, st, p, Ap, part_a, nb, x, r, part_rr, state,
                        alpha_d + (size_t)slot * kMaxT, L, part_w, N, T, K, eps, stop_after, it & 1);
-    hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, Cinv, part_w, nb, r, z, part_rz, N, T, K,
-                       precond_sigma2);
+    if (K > 0) hipLaunchKernelGGL(k_wsolve, dim3(T), dim3(256), 0, st, part_w, nbw, Cinv, tv, T, K);
+    hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, tv, r, z, part_rz, N, T, K, precond_sigma2);
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
-    hipLaunchKernelGGL(k_direction, dim3(nb), dim3(256), 0, st, z, p, part_rz, part_rr, nb, state,
+    hipLaunchKernelGGL(k_direction, dim3(nb), dim3(256), 0, st, z, p, part_rz, part_rr, nb, nbw, state,
                        beta_d + (size_t)slot * kMaxT, N, T, eps, it & 1, check_now ? 1 : 0, tolerance, it + 1,
                        stagnation_window, x, x_best);
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs

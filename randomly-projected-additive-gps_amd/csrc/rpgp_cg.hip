@@ -23,9 +23,22 @@ namespace {
 
 constexpr int kMaxT = 16;
 constexpr int kMaxK = 16;          // preconditioner rank
-constexpr int kMaxBlocks = 256;     // workgroups of the vector kernels (every consumer workgroup reduces the T-wide partials in its prologue)
-constexpr int kMaxBlocksW = 256;    // ... of k_update / k_Ltr, whose K x T wide L^T r partials are reduced once by k_wsolve
+constexpr int kMaxBlocks = 512;     // workgroups of the streaming vector kernels (consumers reduce the T-wide partials in their prologue)
+constexpr int kMaxBlocksW = 512;    // ... of k_update / k_Ltr, whose K x T wide L^T r partials are reduced once by k_wsolve
 constexpr int kMaxHist = 64;        // Lanczos coefficients kept for at most this many iterations
+
+// launch STMT with TT = the exact number of right-hand sides (1 .. kMaxT)
+#define CG_DISPATCH_T(T_, STMT)                                                                          \
+  switch (T_) {                                                                                          \
+    case 1: { constexpr int TT = 1; STMT; } break;    case 2: { constexpr int TT = 2; STMT; } break;    \
+    case 3: { constexpr int TT = 3; STMT; } break;    case 4: { constexpr int TT = 4; STMT; } break;    \
+    case 5: { constexpr int TT = 5; STMT; } break;    case 6: { constexpr int TT = 6; STMT; } break;    \
+    case 7: { constexpr int TT = 7; STMT; } break;    case 8: { constexpr int TT = 8; STMT; } break;    \
+    case 9: { constexpr int TT = 9; STMT; } break;    case 10: { constexpr int TT = 10; STMT; } break;  \
+    case 11: { constexpr int TT = 11; STMT; } break;  case 12: { constexpr int TT = 12; STMT; } break;  \
+    case 13: { constexpr int TT = 13; STMT; } break;  case 14: { constexpr int TT = 14; STMT; } break;  \
+    case 15: { constexpr int TT = 15; STMT; } break;  default: { constexpr int TT = 16; STMT; } break;  \
+  }
 
 #define CG_CHECK(expr)                            \
   do {                                            \
@@ -84,23 +97,26 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ partia
 }
 
 // partial[blk][t] = sum over the block's rows of a[i][t] * b[i][t]
+// (TT = exact number of columns: the per-row loads are unconditional and issued together; with a runtime T every load sat
+// behind its own `t < T` branch — the same pathology the cached-K stream had, §DESIGN 3.2)
+template <int TT>
 __global__ __launch_bounds__(256) void k_coldot(const float *__restrict__ a, const float *__restrict__ b,
-                                                float *__restrict__ partial, long long N, int T) {
+                                                float *__restrict__ partial, long long N) {
   __shared__ float sh[4];
-  float acc[kMaxT];
+  float acc[TT];
 #pragma unroll
-  for (int t = 0; t < kMaxT; ++t) acc[t] = 0.f;
+  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+    float av[TT], bv[TT];
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t)
-      if (t < T) acc[t] = __builtin_fmaf(a[i * T + t], b[i * T + t], acc[t]);
+    for (int t = 0; t < TT; ++t) { av[t] = a[i * TT + t]; bv[t] = b[i * TT + t]; }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = __builtin_fmaf(av[t], bv[t], acc[t]);
   }
 #pragma unroll
-  for (int t = 0; t < kMaxT; ++t) {
-    if (t < T) {
-      const float s = block_sum(acc[t], sh);
-      if (threadIdx.x == 0) partial[(size_t)blockIdx.x * T + t] = s;
-    }
+  for (int t = 0; t < TT; ++t) {
+    const float s = block_sum(acc[t], sh);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * TT + t] = s;
   }
 }
 
@@ -220,49 +236,51 @@ __global__ __launch_bounds__(256) void k_wsolve(const float *__restrict__ partia
 }
 
 // z = M^-1 r = (r - L tv) / sigma2 with tv = Cinv L^T r from k_wsolve (float64: the subtraction cancels to ~sigma^2 / |K|
-// of r along the range of L); partial r.z per workgroup.
-// K == 0: identity preconditioner (z = r)
+// of r along the range of L); partial r.z per workgroup.   K == 0: identity preconditioner (z = r)
+template <int TT>
 __global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, const double *__restrict__ tv,
                                                  const float *__restrict__ r, float *__restrict__ z,
-                                                 float *__restrict__ partial_rz, long long N, int T, int K,
-                                                 float sigma2) {
+                                                 float *__restrict__ partial_rz, long long N, int K, float sigma2) {
   __shared__ double stv[kMaxK * kMaxT];
   __shared__ float sh[4];
   if (K > 0) {
-    for (int e = threadIdx.x; e < kMaxK * kMaxT; e += 256) stv[e] = (e / kMaxT < K && e % kMaxT < T) ? tv[e] : 0.0;
+    for (int e = threadIdx.x; e < kMaxK * kMaxT; e += 256) stv[e] = (e / kMaxT < K && e % kMaxT < TT) ? tv[e] : 0.0;
     __syncthreads();
   }
-  float acc[kMaxT];
+  float acc[TT];
 #pragma unroll
-  for (int t = 0; t < kMaxT; ++t) acc[t] = 0.f;
-  const float inv_s = K > 0 ? 1.0f / sigma2 : 1.0f;
+  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+  const double inv_s = K > 0 ? 1.0 / (double)sigma2 : 1.0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
-    float lrow[kMaxK];
+    float rv[TT];
 #pragma unroll
-    for (int b = 0; b < kMaxK; ++b) lrow[b] = b < K ? L[i * K + b] : 0.f;
+    for (int t = 0; t < TT; ++t) rv[t] = r[i * TT + t];
+    float zv[TT];
+    if (K > 0) {
+      double corr[TT];
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t) {
-      if (t < T) {
-        const float rv = r[i * T + t];
-        float zv = rv;
-        if (K > 0) {
-          double corr = 0.0;
+      for (int t = 0; t < TT; ++t) corr[t] = 0.0;
+      for (int b = 0; b < K; ++b) {
+        const double lb = (double)L[i * K + b];
 #pragma unroll
-          for (int b = 0; b < kMaxK; ++b)
-            if (b < K) corr = fma((double)lrow[b], stv[b * kMaxT + t], corr);
-          zv = (float)(((double)rv - corr) * (double)inv_s);
-        }
-        z[i * T + t] = zv;
-        acc[t] = __builtin_fmaf(rv, zv, acc[t]);
+        for (int t = 0; t < TT; ++t) corr[t] = fma(lb, stv[b * kMaxT + t], corr[t]);
       }
+#pragma unroll
+      for (int t = 0; t < TT; ++t) zv[t] = (float)(((double)rv[t] - corr[t]) * inv_s);
+    } else {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) zv[t] = rv[t];
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      z[i * TT + t] = zv[t];
+      acc[t] = __builtin_fmaf(rv[t], zv[t], acc[t]);
     }
   }
 #pragma unroll
-  for (int t = 0; t < kMaxT; ++t) {
-    if (t < T) {
-      const float s = block_sum(acc[t], sh);
-      if (threadIdx.x == 0) partial_rz[(size_t)blockIdx.x * T + t] = s;
-    }
+  for (int t = 0; t < TT; ++t) {
+    const float s = block_sum(acc[t], sh);
+    if (threadIdx.x == 0) partial_rz[(size_t)blockIdx.x * TT + t] = s;
   }
 }
 
@@ -284,13 +302,15 @@ __global__ __launch_bounds__(256) void k_first_dir(const float *__restrict__ z, 
 
 // alpha = rz / pAp (guarded); x += alpha p; r -= alpha Ap; partial |r|^2; partial L^T r for the preconditioner.
 // After convergence (st->poll.done) alpha = 0: iterations the host had already enqueued leave x and r untouched.
+template <int TT>
 __global__ __launch_bounds__(256) void k_update(const float *__restrict__ p, const float *__restrict__ Ap,
                                                 const float *__restrict__ partial_pAp, int nparts,
                                                 float *__restrict__ x, float *__restrict__ r,
                                                 float *__restrict__ partial_rr, const CgState *__restrict__ st,
                                                 float *__restrict__ alpha_out, const float *__restrict__ L,
-                                                float *__restrict__ partial_w, long long N, int T, int K, float eps,
+                                                float *__restrict__ partial_w, long long N, int K, float eps,
                                                 float stop_after, int cur) {
+  constexpr int T = TT;
   __shared__ float spAp[kMaxT];
   __shared__ float salpha[kMaxT];
   __shared__ float sh[4];
@@ -316,17 +336,31 @@ __global__ __launch_bounds__(256) void k_update(const float *__restrict__ p, con
       __syncthreads();                     // previous tile's ltr_tile is done with sL / sR
       load_L_tile(L, sL, row0, N, K);
     }
+    float rvv[kMaxT];
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t) {
-      float rv = 0.f;
-      if (t < T && i < N) {
+    for (int t = 0; t < kMaxT; ++t) rvv[t] = 0.f;
+    if (i < N) {
+      float pv[TT], apv[TT], xv[TT], rr_[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {          // all loads of the row first, unconditional
+        pv[t] = p[i * TT + t];
+        apv[t] = Ap[i * TT + t];
+        xv[t] = x[i * TT + t];
+        rr_[t] = r[i * TT + t];
+      }
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
         const float a = salpha[t];
-        x[i * T + t] = __builtin_fmaf(a, p[i * T + t], x[i * T + t]);
-        rv = __builtin_fmaf(-a, Ap[i * T + t], r[i * T + t]);
-        r[i * T + t] = rv;
+        x[i * TT + t] = __builtin_fmaf(a, pv[t], xv[t]);
+        const float rv = __builtin_fmaf(-a, apv[t], rr_[t]);
+        r[i * TT + t] = rv;
+        rvv[t] = rv;
         acc[t] = __builtin_fmaf(rv, rv, acc[t]);
       }
-      if (K > 0) sR[threadIdx.x * kMaxT + t] = rv;
+    }
+    if (K > 0) {
+#pragma unroll
+      for (int t = 0; t < kMaxT; ++t) sR[threadIdx.x * kMaxT + t] = rvv[t];
     }
     if (K > 0) {
       __syncthreads();
@@ -348,13 +382,15 @@ __global__ __launch_bounds__(256) void k_update(const float *__restrict__ p, con
 
 // beta = rz' / rz; p = z + beta p; bookkeeping (block 0): rz <- rz', resid, mean residual, beta history, and — on the
 // iterations the host marks with check_now — the convergence decision (st->poll.done), which freezes later iterations.
+template <int TT>
 __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, float *__restrict__ p,
                                                    const float *__restrict__ partial_rz, const float *__restrict__ partial_rr,
                                                    int nparts, int nparts_rr, CgState *__restrict__ st,
                                                    float *__restrict__ beta_out,
-                                                   long long N, int T, float eps, int cur, int check_now,
+                                                   long long N, float eps, int cur, int check_now,
                                                    float tolerance, int iter_count, int stagnation_window,
                                                    const float *__restrict__ x, float *__restrict__ x_best) {
+  constexpr int T = TT;
   // Best-iterate safeguard: fp32 CG on a system with cond(Khat) * 1e-6 >~ 1 (N s / sigma^2 beyond a few million) does not
   // merely stall, its recurrence residual can GROW; the iterate with the smallest tested residual is kept in x_best (every
   // workgroup takes the same decision from the same reduced numbers) and returned when the tolerance is never reached.
@@ -378,11 +414,17 @@ __global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, 
   mres /= (float)T;
   const float snap_prev = st->snap_resid[cur];
   const bool improved = check_now && mres == mres && mres < snap_prev;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
-    for (int t = 0; t < T; ++t) {
-      p[i * T + t] = __builtin_fmaf(sbeta[t], p[i * T + t], z[i * T + t]);
-      if (improved) x_best[i * T + t] = x[i * T + t];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+    float pv[TT], zv[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { pv[t] = p[i * TT + t]; zv[t] = z[i * TT + t]; }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) p[i * TT + t] = __builtin_fmaf(sbeta[t], pv[t], zv[t]);
+    if (improved) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) x_best[i * TT + t] = x[i * TT + t];
     }
+  }
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) {
       st->snap_resid[cur ^ 1] = improved ? mres : snap_prev;
@@ -560,12 +602,12 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   CgPoll *hpoll = g_poll.host;
 
   // normalise right-hand sides, x = 0
-  hipLaunchKernelGGL(k_coldot, dim3(nb), dim3(256), 0, st, rhs, rhs, part_a, N, T);
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_coldot<TT>), dim3(nb), dim3(256), 0, st, rhs, rhs, part_a, N));
   hipLaunchKernelGGL(k_normalise, dim3(nb), dim3(256), 0, st, rhs, part_a, nb, r, x, state, N, T);
   // z0 = M^-1 r0, p0 = z0, rz0
   if (K > 0) hipLaunchKernelGGL(k_Ltr, dim3(nbw), dim3(256), 0, st, L, r, part_w, N, T, K);
   if (K > 0) hipLaunchKernelGGL(k_wsolve, dim3(T), dim3(256), 0, st, part_w, nbw, Cinv, tv, T, K);
-  hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, tv, r, z, part_rz, N, T, K, precond_sigma2);
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_precond<TT>), dim3(nb), dim3(256), 0, st, L, tv, r, z, part_rz, N, K, precond_sigma2));
   hipLaunchKernelGGL(k_first_dir, dim3(nb), dim3(256), 0, st, z, p, part_rz, nb, state, N, T);
   CG_CHECK(hipGetLastError());
 
@@ -581,17 +623,19 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   for (it = 0; it < n_iter; ++it) {
     int rc = apply_operator(op, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_coldot, dim3(nb), dim3(256), 0, st, p, Ap, part_a, N, T);
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_coldot<TT>), dim3(nb), dim3(256), 0, st, p, Ap, part_a, N));
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
-    hipLaunchKernelGGL(k_update, dim3(nbw), dim3(256), 0, st, p, Ap, part_a, nb, x, r, part_rr, state,
-                       alpha_d + (size_t)slot * kMaxT, L, part_w, N, T, K, eps, stop_after, it & 1);
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_update<TT>), dim3(nbw), dim3(256), 0, st, p, Ap, part_a, nb, x, r, part_rr,
+                                        state, alpha_d + (size_t)slot * kMaxT, L, part_w, N, K, eps, stop_after, it & 1));
     if (K > 0) hipLaunchKernelGGL(k_wsolve, dim3(T), dim3(256), 0, st, part_w, nbw, Cinv, tv, T, K);
-    hipLaunchKernelGGL(k_precond, dim3(nb), dim3(256), 0, st, L, tv, r, z, part_rz, N, T, K, precond_sigma2);
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_precond<TT>), dim3(nb), dim3(256), 0, st, L, tv, r, z, part_rz, N, K,
+                                        precond_sigma2));
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
-    hipLaunchKernelGGL(k_direction, dim3(nb), dim3(256), 0, st, z, p, part_rz, part_rr, nb, nbw, state,
-                       beta_d + (size_t)slot * kMaxT, N, T, eps, it & 1, check_now ? 1 : 0, tolerance, it + 1,
-                       stagnation_window, x, x_best);
+    // (k_direction reduces two partial arrays in every workgroup's prologue: it runs best with fewer workgroups)
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_direction<TT>), dim3(nb < 256 ? nb : 256), dim3(256), 0, st, z, p, part_rz, part_rr, nb, nbw,
+                                        state, beta_d + (size_t)slot * kMaxT, N, eps, it & 1, check_now ? 1 : 0, tolerance,
+                                        it + 1, stagnation_window, x, x_best));
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
       CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
       last = hpoll[polled_it % kPollRing];

@@ -106,7 +106,7 @@ _lib = None
 
 def build(verbose=False):
     """Compile librpgp.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC_DIR, "all"]
+    cmd = ["make", "-j4", "-C", CSRC_DIR, "all"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)

@@ -2467,6 +2467,7 @@ inline bool mfma_requested() {
   const char *e = getenv("RPGP_MFMA");
   return e && e[0] == '1';
 }
+int g_num_cus = 256;       // compute units of the current device (set by rpgp_init)
 int g_rotdir = 0;  // +1: wave_rotate1 delivers lane l+1's value to lane l; -1: lane l-1's.  0 = not probed.
 
 // Optional measurement hook (bench.py): HIP-event pairs around the dominant (tile) kernel launches.
@@ -2939,6 +2940,12 @@ int rpgp_init(void) {
   if (g_rotdir != 0) return 0;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RPGP_ENODEVICE;
+  {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
+      g_num_cus = ncu;
+  }
   int *d = nullptr;
   RPGP_CHECK(hipMalloc(&d, 64 * sizeof(int)));
   hipLaunchKernelGGL(probe_rotate_kernel, dim3(1), dim3(64), 0, 0, d);
@@ -3489,18 +3496,28 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
 int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64_t ldk, int T, float noise,
                    void *stream) {
   if (!Kd || !V || !out || N <= 0 || T <= 0 || ldk < N || N > 0x7fffffffLL) return RPGP_EINVAL;
+  {
+    const int irc = rpgp_init();
+    if (irc) return irc;
+  }
   hipStream_t st = as_stream(stream);
   float *slab = nullptr;
   int rc = 0;
   if (T <= 12) {
     // VALU form: 1024 output columns per workgroup (a wave streams 256 columns down the rows); the rows are split so that
     // ~8192 waves are in flight, but never into more slabs than 8 % of the matrix's own bytes, nor below 64 rows
+    // Every workgroup streams the same amount of data and they all start together, so the launch must be ONE resident
+    // round: a grid a few percent over the resident capacity runs two rounds and doubles the time (N = 14 939, T = 11: 1560
+    // workgroups on 1536 slots).  Capacity per CU from the register budget of the instantiation: <= 64 VGPRs (T <= 2) 8
+    // workgroups, T <= 8 six, wider five (a conservative count of what hipcc allocates for them).
     const unsigned ncb = (unsigned)((N + 1023) / 1024);
-    long long nsplit = (2048 + ncb - 1) / ncb;
-    const long long cap_bytes = (long long)(0.08 * (double)N / T);
+    const int per_cu = T <= 2 ? 8 : (T <= 8 ? 6 : 5);
+    const long long resident = (long long)g_num_cus * per_cu;
+    long long nsplit = resident / ncb;
+    const long long cap_bytes = (long long)(0.15 * (double)N / T);      // slab bytes <= 15 % of the matrix bytes
     if (nsplit > cap_bytes) nsplit = cap_bytes;
     if (nsplit > (N + 63) / 64) nsplit = (N + 63) / 64;
-    if (nsplit > 128) nsplit = 128;
+    if (nsplit > 160) nsplit = 160;
     if (nsplit < 1) nsplit = 1;
     int cps = (int)((N + nsplit - 1) / nsplit);
     cps = (cps + 7) / 8 * 8;                           // whole 8-row batches

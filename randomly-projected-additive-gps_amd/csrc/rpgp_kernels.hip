@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <stddef.h>
+#include <atomic>
 
 #include "../../include/rpgp.h"
 #include "rpgp_internal.h"
@@ -1402,6 +1403,11 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const float *__restrict
 // wave-instruction loads ONE contiguous KB of a row (perfectly coalesced), V[row][0..T) is wave-uniform (scalar loads,
 // SGPR multiplier), and the update is 4 T v_fma_f32 per lane (8.8 T cycles per KB).  Split-K slabs + the same
 // fixed-order reduce as the MFMA form.
+// The workgroup owns 256 columns and its four waves take alternate 8-row batches of the split's rows; their accumulators
+// are added through LDS in a fixed order ((w0 + w2) + (w1 + w3)) before ONE slab record is written.  (Four waves side by
+// side on 1024 columns, each writing its own slab record, needed 4x the slabs for the same number of resident waves: at
+// N = 15k, T = 11 the slab write burst and its re-read by the reduce were a quarter of the product's time; the split form
+// is faster at every size measured, 4k <= N <= 50k — profiles/r2_gemv_wave_split_sweep.txt.)
 template <int TT>
 __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__restrict__ Kd, const float *__restrict__ V,
                                                               float *__restrict__ slab, int N, long long ldk,
@@ -1409,8 +1415,10 @@ __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__res
   // TT is the EXACT number of right-hand sides (V is N x TT, row-major): the V loads are unconditional wave-uniform
   // scalar loads that hipcc merges into s_load_dwordx4/x8, and the row loop is branch-free.  (The first version
   // guarded every load with `t < T` / per-lane alignment tests: one branch per load, 2.4 TB/s at N = 15k.)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cl = blockIdx.x * 1024 + wave * 256 + 4 * lane;      // this lane's 4 output columns
+  __shared__ float4v sRed[2 * TT * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // SGPR: keeps the V row pointer scalar
+  const int cl = blockIdx.x * 256 + 4 * lane;                      // this lane's 4 output columns
   const bool base_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0);
   float acc[4][TT];
 #pragma unroll
@@ -1419,14 +1427,17 @@ __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__res
     for (int t = 0; t < TT; ++t) acc[i][t] = 0.f;
   const int rs = blockIdx.y * rows_per_split;
   const int re = (rs + rows_per_split < N) ? rs + rows_per_split : N;
+  constexpr int RB = 8;
+  constexpr int WSTEP = 4;                        // batches between two of a wave's own
+  const int wfirst = wave;
   if (base_ok && cl + 3 < N) {
-    // batches of 8 rows: 8 x 16 B per lane in flight before the first FMA (mid-size problems launch only ~4 workgroups
-    // per CU, so the bytes in flight per CU come from the depth of each thread's own load queue)
-    constexpr int RB = 8;
-    const float *kp = Kd + (size_t)rs * ldk + cl;
-    const float *vp = V + (size_t)rs * TT;
-    int row = rs;
-    for (; row + RB <= re; row += RB) {
+    // batches of 8 rows: 8 x 16 B per lane in flight before the first FMA (the bytes in flight per CU come from the depth
+    // of each thread's own load queue).  A rolling form that re-requests row q of the next batch right after row q's FMAs
+    // (sched_barrier-pinned) measured no better at any size and cost 28 VGPRs.
+    int row = rs + wfirst * RB;
+    const float *kp = Kd + (size_t)row * ldk + cl;
+    const float *vp = V + (size_t)row * TT;
+    for (; row + RB <= re; row += WSTEP * RB) {
       float4v a[RB];
 #pragma unroll
       for (int q = 0; q < RB; ++q) a[q] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kp + (size_t)q * ldk));
@@ -1441,25 +1452,28 @@ __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__res
           acc[3][t] = __builtin_fmaf(a[q].w, v, acc[3][t]);
         }
       }
-      kp += (size_t)RB * ldk;
-      vp += RB * TT;
+      kp += (size_t)WSTEP * RB * ldk;
+      vp += WSTEP * RB * TT;
     }
-    for (; row < re; ++row) {
-      const float4v a = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kp));
+    // the ragged last rows of the last split (fewer than 8): the wave whose batch they would have started
+    if (row < re) {
+      for (; row < re; ++row) {
+        const float4v a = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(kp));
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        const float v = vp[t];
-        acc[0][t] = __builtin_fmaf(a.x, v, acc[0][t]);
-        acc[1][t] = __builtin_fmaf(a.y, v, acc[1][t]);
-        acc[2][t] = __builtin_fmaf(a.z, v, acc[2][t]);
-        acc[3][t] = __builtin_fmaf(a.w, v, acc[3][t]);
+        for (int t = 0; t < TT; ++t) {
+          const float v = vp[t];
+          acc[0][t] = __builtin_fmaf(a.x, v, acc[0][t]);
+          acc[1][t] = __builtin_fmaf(a.y, v, acc[1][t]);
+          acc[2][t] = __builtin_fmaf(a.z, v, acc[2][t]);
+          acc[3][t] = __builtin_fmaf(a.w, v, acc[3][t]);
+        }
+        kp += ldk;
+        vp += TT;
       }
-      kp += ldk;
-      vp += TT;
     }
   } else if (cl < N) {
     // ragged right edge / unaligned matrix: element-wise loads (at most one wave of the last column block)
-    for (int row = rs; row < re; ++row) {
+    for (int row = rs + wfirst; row < re; row += WSTEP) {
       const float *kp = Kd + (size_t)row * ldk + cl;
       float a[4];
 #pragma unroll
@@ -1473,30 +1487,124 @@ __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__res
       }
     }
   }
-  float *sl = slab + (size_t)blockIdx.y * N * TT;                 // compact slab: [split][column][TT]
+  {
+    if (wave >= 2) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = cl + i;
-    if (c < N) {
+      for (int t = 0; t < TT; ++t) sRed[((wave - 2) * TT + t) * 64 + lane] = float4v{acc[0][t], acc[1][t], acc[2][t], acc[3][t]};
+    }
+    __syncthreads();
+    if (wave < 2) {
 #pragma unroll
-      for (int t = 0; t < TT; ++t) sl[(size_t)c * TT + t] = acc[i][t];
+      for (int t = 0; t < TT; ++t) {
+        const float4v x = sRed[(wave * TT + t) * 64 + lane];
+        acc[0][t] += x.x; acc[1][t] += x.y; acc[2][t] += x.z; acc[3][t] += x.w;
+      }
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) sRed[t * 64 + lane] = float4v{acc[0][t], acc[1][t], acc[2][t], acc[3][t]};
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      const float4v x = sRed[t * 64 + lane];
+      acc[0][t] += x.x; acc[1][t] += x.y; acc[2][t] += x.z; acc[3][t] += x.w;
+    }
+  }
+  // compact slab, column-fastest: [split][t][Npad] — a lane's 4 columns are one 16-byte store per t and a wave's store
+  // is one contiguous KB (the [column][t] layout scattered 44 dword stores per lane: 14 M partial-line writes per
+  // product at N = 15k)
+  const size_t npad = ((size_t)N + 3) & ~(size_t)3;
+  float *sl = slab + (size_t)blockIdx.y * npad * TT;
+  if (cl + 3 < N) {
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+      *reinterpret_cast<float4v *>(sl + (size_t)t * npad + cl) = float4v{acc[0][t], acc[1][t], acc[2][t], acc[3][t]};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = cl + i;
+      if (c < N) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) sl[(size_t)t * npad + c] = acc[i][t];
+      }
     }
   }
 }
 
 // out[row][t0+n] = sum_split slab[split][row][n] + noise * V[row][t0+n]   (fixed order: deterministic)
-// `sw` = slab width (floats per (split, row)): 16 for the MFMA form, the exact T for the VALU form
-__global__ void dense_gemm_reduce_kernel(const float *__restrict__ slab, const float *__restrict__ V,
-                                         float *__restrict__ out, int N, int T, int t0, int tcnt, int nsplit,
-                                         float noise, int sw) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (size_t)N * sw) return;
+// `sw` = slab width (floats per (split, row)): 16 for the MFMA form, the exact T for the VALU form.
+// A workgroup owns 32 consecutive slab entries; its 8 thread groups split the row-split slabs (slab s goes to group
+// s % 8, 4 loads in flight per thread) and the 8 partial sums are added in a fixed order — deterministic.  (One thread
+// per entry looping over ~100 slabs took 18-33 us: a third of the whole cached-K product at N = 7k.)
+__global__ __launch_bounds__(256) void dense_gemm_reduce_kernel(const float *__restrict__ slab,
+                                                                const float *__restrict__ V, float *__restrict__ out,
+                                                                int N, int T, int t0, int tcnt, int nsplit, float noise,
+                                                                int sw) {
+  __shared__ float part[8][32];
+  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const size_t per = (size_t)N * sw;
+  const size_t gid = (size_t)blockIdx.x * 32 + o;
+  float acc = 0.f;
+  if (gid < per) {
+    int sidx = g;
+    for (; sidx + 24 < nsplit; sidx += 32) {
+      const float x0 = slab[(size_t)sidx * per + gid], x1 = slab[(size_t)(sidx + 8) * per + gid];
+      const float x2 = slab[(size_t)(sidx + 16) * per + gid], x3 = slab[(size_t)(sidx + 24) * per + gid];
+      acc += x0;
+      acc += x1;
+      acc += x2;
+      acc += x3;
+    }
+    for (; sidx < nsplit; sidx += 8) acc += slab[(size_t)sidx * per + gid];
+  }
+  part[g][o] = acc;
+  __syncthreads();
+  if (g != 0 || gid >= per) return;
   const int row = (int)(gid / sw), n = (int)(gid % sw);
   if (n >= tcnt) return;
+  float tot = part[0][o];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) tot += part[q][o];
+  const size_t oidx = (size_t)row * T + t0 + n;
+  out[oidx] = __builtin_fmaf(noise, V[oidx], tot);
+}
+
+// Reduce of the VALU form's column-fastest slabs [split][t][npad]: out[col][t] = sum_split slab + noise * V[col][t].
+// Same 8-group fixed-order scheme as above; a workgroup owns 32 consecutive columns of one t.
+__global__ __launch_bounds__(256) void dense_gemv_reduce_kernel(const float *__restrict__ slab,
+                                                                const float *__restrict__ V, float *__restrict__ out,
+                                                                int N, int T, int nsplit, float noise) {
+  __shared__ float part[8][32];
+  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const size_t npad = ((size_t)N + 3) & ~(size_t)3;
+  const int t = blockIdx.y;
+  const int col = blockIdx.x * 32 + o;
+  const size_t per = npad * T;
+  const size_t e = (size_t)t * npad + col;
   float acc = 0.f;
-  for (int sidx = 0; sidx < nsplit; ++sidx) acc += slab[(size_t)sidx * N * sw + gid];
-  const size_t o = (size_t)row * T + t0 + n;
-  out[o] = __builtin_fmaf(noise, V[o], acc);
+  if (col < N) {
+    int sidx = g;
+    for (; sidx + 24 < nsplit; sidx += 32) {
+      const float x0 = slab[(size_t)sidx * per + e], x1 = slab[(size_t)(sidx + 8) * per + e];
+      const float x2 = slab[(size_t)(sidx + 16) * per + e], x3 = slab[(size_t)(sidx + 24) * per + e];
+      acc += x0;
+      acc += x1;
+      acc += x2;
+      acc += x3;
+    }
+    for (; sidx < nsplit; sidx += 8) acc += slab[(size_t)sidx * per + e];
+  }
+  part[g][o] = acc;
+  __syncthreads();
+  if (g != 0 || col >= N) return;
+  float tot = part[0][o];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) tot += part[q][o];
+  const size_t oidx = (size_t)col * T + t;
+  out[oidx] = __builtin_fmaf(noise, V[oidx], tot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3493,6 +3601,34 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
                         fam->ncomp, fam->weights, stream);
 }
 
+namespace {
+// resident workgroups per CU of dense_gemv_valu_kernel<T>, asked of the runtime once per T (register and LDS budget of
+// the instantiation hipcc actually produced), capped at 8
+int gemv_blocks_per_cu(int T) {
+  static std::atomic<int> cache[13];
+  const int tt = T < 1 ? 1 : (T > 12 ? 12 : T);
+  int v = cache[tt].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int nb = 0;
+  hipError_t e = hipSuccess;
+#define RPGP_OCC_CASE(TT_)                                                                                             \
+  case TT_:                                                                                                            \
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dense_gemv_valu_kernel<TT_>, 256, 0);                         \
+    break
+  switch (tt) {
+    RPGP_OCC_CASE(1); RPGP_OCC_CASE(2); RPGP_OCC_CASE(3); RPGP_OCC_CASE(4); RPGP_OCC_CASE(5); RPGP_OCC_CASE(6);
+    RPGP_OCC_CASE(7); RPGP_OCC_CASE(8); RPGP_OCC_CASE(9); RPGP_OCC_CASE(10); RPGP_OCC_CASE(11);
+    default: RPGP_OCC_CASE(12);
+  }
+#undef RPGP_OCC_CASE
+  if (e != hipSuccess || nb < 1) nb = 4;
+  if (nb > 8) nb = 8;
+  if (const char *ev = getenv("RPGP_GEMV_PERCU")) nb = atoi(ev);        // XXX sweep hook
+  cache[tt].store(nb, std::memory_order_relaxed);
+  return nb;
+}
+}  // namespace
+
 int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64_t ldk, int T, float noise,
                    void *stream) {
   if (!Kd || !V || !out || N <= 0 || T <= 0 || ldk < N || N > 0x7fffffffLL) return RPGP_EINVAL;
@@ -3504,25 +3640,26 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
   float *slab = nullptr;
   int rc = 0;
   if (T <= 12) {
-    // VALU form: 1024 output columns per workgroup (a wave streams 256 columns down the rows); the rows are split so that
-    // ~8192 waves are in flight, but never into more slabs than 8 % of the matrix's own bytes, nor below 64 rows
+    // VALU form: 256 output columns per workgroup, the rows split over blockIdx.y (and over the four waves inside).
     // Every workgroup streams the same amount of data and they all start together, so the launch must be ONE resident
     // round: a grid a few percent over the resident capacity runs two rounds and doubles the time (N = 14 939, T = 11: 1560
     // workgroups on 1536 slots).  Capacity per CU from the register budget of the instantiation: <= 64 VGPRs (T <= 2) 8
     // workgroups, T <= 8 six, wider five (a conservative count of what hipcc allocates for them).
-    const unsigned ncb = (unsigned)((N + 1023) / 1024);
-    const int per_cu = T <= 2 ? 8 : (T <= 8 ? 6 : 5);
+    const unsigned ncb = (unsigned)((N + 255) / 256);
+    const int per_cu = gemv_blocks_per_cu(T);
     const long long resident = (long long)g_num_cus * per_cu;
     long long nsplit = resident / ncb;
+    if (const char *e = getenv("RPGP_GEMV_NSPLIT")) nsplit = atoi(e);   // XXX sweep hook
     const long long cap_bytes = (long long)(0.15 * (double)N / T);      // slab bytes <= 15 % of the matrix bytes
     if (nsplit > cap_bytes) nsplit = cap_bytes;
     if (nsplit > (N + 63) / 64) nsplit = (N + 63) / 64;
     if (nsplit > 160) nsplit = 160;
     if (nsplit < 1) nsplit = 1;
     int cps = (int)((N + nsplit - 1) / nsplit);
-    cps = (cps + 7) / 8 * 8;                           // whole 8-row batches
+    cps = (cps + 31) / 32 * 32;                        // whole 8-row batches for each of the four waves
     nsplit = (N + cps - 1) / cps;
-    RPGP_CHECK(hipMallocAsync((void **)&slab, (size_t)nsplit * N * T * sizeof(float), st));
+    const size_t npad = ((size_t)N + 3) & ~(size_t)3;
+    RPGP_CHECK(hipMallocAsync((void **)&slab, (size_t)nsplit * npad * T * sizeof(float), st));
     dim3 vgrid(ncb, (unsigned)nsplit), block(256);
 #define RPGP_GEMV_CASE(TT_)                                                                                            \
   case TT_:                                                                                                            \
@@ -3534,9 +3671,8 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
       default: RPGP_GEMV_CASE(12);
     }
 #undef RPGP_GEMV_CASE
-    const size_t total = (size_t)N * T;
-    hipLaunchKernelGGL(dense_gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, V, out,
-                       (int)N, T, 0, T, (int)nsplit, noise, T);
+    hipLaunchKernelGGL(dense_gemv_reduce_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)T), dim3(256), 0, st, slab, V,
+                       out, (int)N, T, (int)nsplit, noise);
     rc = launch_status();
     (void)hipFreeAsync(slab, st);
     return rc;
@@ -3557,7 +3693,7 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
     const int tcnt = (T - t0 < 16) ? T - t0 : 16;
     hipLaunchKernelGGL(dense_gemm_kernel, grid, block, 0, st, Kd, V, slab, (int)N, (long long)ldk, T, t0, tcnt, cps);
     const size_t total = (size_t)N * 16;
-    hipLaunchKernelGGL(dense_gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, V, out,
+    hipLaunchKernelGGL(dense_gemm_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, slab, V, out,
                        (int)N, T, t0, tcnt, nsplit, noise, 16);
     rc = launch_status();
   }

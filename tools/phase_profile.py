@@ -41,6 +41,13 @@ wrap(ops, "bilinear_grad", " bwd:bilinear_grad")
 wrap(ops, "project_grad", " bwd:project_grad")
 wrap(ops, "project", " fwd:project")
 wrap(ops.Prepared, "__init__", " prepare")
+wrap(operators.AdditiveRPOperator, "to_dense_cached", " cachedK:build")
+wrap(settings, "use_cached_kernel", " cachedK:policy")
+_orig_cg = iql.linear_cg
+ITERS = []
+def _cg_count(*a, **k):
+    r = _orig_cg(*a, **k); ITERS.append(lcg.stats["last_iterations"]); return r
+iql.linear_cg = _cg_count
 with settings.cg_tolerance(0.05):
     for it in range(6):
         if it == 1: T.clear(); torch.cuda.synchronize(); t_all = time.perf_counter()
@@ -51,4 +58,4 @@ with settings.cg_tolerance(0.05):
         t0 = time.perf_counter(); loss.backward(); torch.cuda.synchronize(); T["backward(total)"] = T.get("backward(total)", 0) + time.perf_counter() - t0
     torch.cuda.synchronize(); tot = time.perf_counter() - t_all
 for k, v in T.items(): print("%-28s %8.3f ms" % (k, v / 5 * 1e3))
-print("step total %.3f ms" % (tot / 5 * 1e3))
+print("step total %.3f ms" % (tot / 5 * 1e3), "cg iterations", ITERS)

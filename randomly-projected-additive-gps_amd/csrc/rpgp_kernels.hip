@@ -1349,7 +1349,9 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(const float *__restrict
   const int n = lane & 15, k = lane >> 4;
   const int c0 = blockIdx.x * 256 + wave * 64;   // first output index of this wave
   const int cl = c0 + 4 * n;                     // this lane's 4 columns
-  const bool vec_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0) && (cl + 3 < N);
+  // (padded rows: the last column group's 16-byte load may reach into the row's own padding — those values only feed
+  // output columns >= N, which are not stored)
+  const bool vec_ok = ((ldk & 3) == 0) && ((((uintptr_t)Kd) & 15) == 0) && cl < N && (cl + 3 < ldk);
   floatx4m acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = floatx4m{0.f, 0.f, 0.f, 0.f};
@@ -1430,7 +1432,11 @@ __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__res
   constexpr int RB = 8;
   constexpr int WSTEP = 4;                        // batches between two of a wave's own
   const int wfirst = wave;
-  if (base_ok && cl + 3 < N) {
+  // The 16-byte path also serves the ragged right edge when the rows are padded (cl + 3 < ldk: the pad belongs to the
+  // row's own allocation; what it holds only reaches accumulators of columns >= N, which are never stored).  Sending
+  // those lanes down the element-wise path made one wave per split walk its rows one dependent load at a time — at
+  // N = 14 939 (N % 4 = 3) that straggler set the whole kernel's time: 208 us against 143 us for T = 11.
+  if (base_ok && cl < N && cl + 3 < ldk) {
     // batches of 8 rows: 8 x 16 B per lane in flight before the first FMA (the bytes in flight per CU come from the depth
     // of each thread's own load queue).  A rolling form that re-requests row q of the next batch right after row q's FMAs
     // (sched_barrier-pinned) measured no better at any size and cost 28 VGPRs.
@@ -1472,7 +1478,7 @@ __global__ __launch_bounds__(256) void dense_gemv_valu_kernel(const float *__res
       }
     }
   } else if (cl < N) {
-    // ragged right edge / unaligned matrix: element-wise loads (at most one wave of the last column block)
+    // unaligned matrix (or an unpadded ragged right edge): element-wise loads
     for (int row = rs + wfirst; row < re; row += WSTEP) {
       const float *kp = Kd + (size_t)row * ldk + cl;
       float a[4];
@@ -3623,7 +3629,6 @@ int gemv_blocks_per_cu(int T) {
 #undef RPGP_OCC_CASE
   if (e != hipSuccess || nb < 1) nb = 4;
   if (nb > 8) nb = 8;
-  if (const char *ev = getenv("RPGP_GEMV_PERCU")) nb = atoi(ev);        // XXX sweep hook
   cache[tt].store(nb, std::memory_order_relaxed);
   return nb;
 }
@@ -3649,7 +3654,6 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
     const int per_cu = gemv_blocks_per_cu(T);
     const long long resident = (long long)g_num_cus * per_cu;
     long long nsplit = resident / ncb;
-    if (const char *e = getenv("RPGP_GEMV_NSPLIT")) nsplit = atoi(e);   // XXX sweep hook
     const long long cap_bytes = (long long)(0.15 * (double)N / T);      // slab bytes <= 15 % of the matrix bytes
     if (nsplit > cap_bytes) nsplit = cap_bytes;
     if (nsplit > (N + 63) / 64) nsplit = (N + 63) / 64;

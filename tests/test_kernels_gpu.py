@@ -134,6 +134,29 @@ def test_dense_mvm(gpu_device, N, T):
     assert _rel(out.cpu().numpy(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("N,T", [(1027, 1), (2050, 11), (3001, 4), (1285, 12), (1285, 16), (2050, 37)])
+def test_dense_mvm_padded_rows_ragged_edge(gpu_device, N, T):
+    """Cached-K layout (rows padded to a multiple of 64 floats) with N % 4 != 0: the 16-byte loads of the last column
+    group read into the row padding; whatever the padding holds (NaN here) must never reach the result."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + T)
+    Z = rng.standard_normal((N, 5)).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    Zt = torch.from_numpy(Z).to(gpu_device)
+    ld = (N + 63) // 64 * 64
+    base = torch.full((N, ld), float("nan"), device=gpu_device)
+    base[:, :N] = ops.dense(Zt, Zt, 0.2)
+    Kd = base[:, :N]
+    out = ops.dense_mvm(Kd, torch.from_numpy(V).to(gpu_device), 0.3)
+    ref = orc.mvm(Z, Z, V, 0.2, 0.3)
+    assert torch.isfinite(out).all()
+    assert _rel(out.cpu().numpy(), ref) < 1e-5
+    Kp = ops.dense(Zt, Zt, 0.2, pad=True)
+    assert Kp.stride(0) % 64 == 0 and Kp.shape == (N, N)
+    out2 = ops.dense_mvm(Kp, torch.from_numpy(V).to(gpu_device), 0.3)
+    assert _rel(out2.cpu().numpy(), ref) < 1e-5
+
+
 def test_errors_are_python_exceptions(gpu_device):
     from rpgp_amd import ops
     Z = torch.zeros((10, 4), device=gpu_device)

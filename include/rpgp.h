@@ -176,6 +176,26 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
                    float noise, void *stream);
 
 /*
+ * Packed symmetric cache of the additive kernel (cached-K mode without the lower triangle): every unordered pair of
+ * points is evaluated once (`rpgp_symcache_build`, the fused symmetric sweep with a store in place of the products) and
+ * kept in the order that sweep consumes it; `rpgp_symcache_mvm` is the same sweep with a 16-byte load in place of the J
+ * exponentials: out = scale * (sum_j K_j) V + noise * V from HALF the bytes of the dense N x N matrix.  Same role as
+ * rpgp_dense + rpgp_dense_mvm (the matrix GPyTorch's lazily evaluated kernel materialises for `_matmul`,
+ * training_routines.py:406 with fitting/optimizing.py:69-71) for blocks of up to 12 right-hand sides per pass; wider
+ * blocks take ceil(T / 12) passes over the cache — use the dense matrix for those.
+ * The cached values are the unscaled sums over j in [j0, j1) in fp32, so an outputscale change needs no rebuild.
+ * (world, rank): pair-sharding as in rpgp_mvm_sym_range — the cache holds this rank's share of the pairs only and the
+ * product is a partial result (noise on ONE rank); world = 1, rank = 0 is the whole matrix.  The layout depends on
+ * (N, world, rank) only; a cache is valid for exactly the arguments it was built with.
+ */
+size_t rpgp_symcache_bytes(int64_t N, int world, int rank);
+size_t rpgp_symcache_workspace_bytes(int64_t N, int T, int world, int rank);
+int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t N, int ldz, int j0, int j1, int world,
+                        int rank, void *stream);
+int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, const float *V, float *out, int64_t N, int T, float scale,
+                      float noise, int world, int rank, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * SKI path (1-D grid interpolation per projection; replaces the `GridInterpolationKernel` wrap of
  * training_routines.py:157-158 used by model_specs/additive_spread_prescale_Jd_ski.json):
  *   K ~= scale * sum_j W_j Tm W_j^T,   W_j = cubic-convolution (Keys) interpolation weights of projection j onto ONE
@@ -288,6 +308,7 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
 #define RPGP_OP_SKI 2             /* rpgp_ski_mvm on Z + grid_params */
 #define RPGP_OP_DENSE 3           /* cached-K: symmetric Kd (N x N, row stride ldk) in HBM, applied by rpgp_dense_mvm */
 #define RPGP_OP_FAMILY 4          /* rpgp_family_mvm_sym on Z + family */
+#define RPGP_OP_SYMCACHE 5        /* packed symmetric cache: Kd = the cache, ldk = its size in bytes; scale, noise */
 typedef struct rpgp_operator {
   int kind;
   int64_t N;

@@ -20,6 +20,9 @@ class HipBackend:
     bilinear_grad = staticmethod(ops.bilinear_grad)
     bilinear_grad_dense = staticmethod(ops.bilinear_grad_dense)
     dense_mvm = staticmethod(ops.dense_mvm)
+    supports_symcache = True
+    symcache = staticmethod(ops.SymCache)
+    symcache_mvm = staticmethod(ops.symcache_mvm)
     pivoted_cholesky = staticmethod(ops.pivoted_cholesky)
     ski_grid = staticmethod(ops.ski_grid)
     ski_mvm = staticmethod(ops.ski_mvm)

@@ -756,6 +756,253 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packed symmetric cache ("symcache"): the cached-K mode without the lower triangle.
+//   The fused symmetric sweep evaluates every unordered pair once and uses the value twice (row product and, through
+//   the rotating accumulators, the transposed product).  The cache stores exactly the values that sweep consumes, in
+//   the order it consumes them, so that the cached product is the same sweep with a 16-byte load in place of the J
+//   exponentials: HALF the bytes of the N x N matrix per product (and half the HBM footprint).
+//   Unit of storage: one 64-column subtile of one row block = BR x 64 floats, laid out
+//       [wave 0..3][s4 0..15][r 0..R-1][lane 0..63][u 0..3]      (float4 per lane: rotation steps s = 4 s4 + u)
+//   value (wave, s4, r, lane, u) = sum_j exp2(-(a - b)^2) for row r0 + wave*64R + r*64 + lane and column
+//   csub + ((lane + rotdir*s) & 63).  Subtiles are numbered row block by row block, left to right from the diagonal
+//   block's first column (subtile g of row block rb: columns rb*BR + 64 g ...), so the layout depends on (N, R) only.
+//   A wave's loads are 1 KB contiguous; it streams 16 R KB per subtile.  Pairs outside the matrix hold 0.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long symk_first_subtile(int rb, int N, int BR) {
+  const long long nsN = (N + 63) / 64, q = BR / 64;
+  return (long long)rb * nsN - q * ((long long)rb * (rb - 1) / 2);
+}
+
+template <int JT, int R>
+__global__ __launch_bounds__(256) void symk_build_kernel(const float *__restrict__ Z, float4v *__restrict__ cache, int N,
+                                                         int ldz, int j0, int chunk_cols, int rotdir, int accumulate,
+                                                         int w0, long long sub0) {
+  constexpr int BR = 256 * R;
+  constexpr int STR = ColStride<JT>::v;
+  __shared__ __attribute__((aligned(16))) float sB[64 * STR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
+  const int r0 = rb * BR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+  // rows / columns outside the matrix sit at +3e18 / +1e18: every pair with one of them is exp2(-huge) = 0
+  float a[R][JT];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) a[r][j] = (row < N) ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 3.0e18f;
+  }
+  const long long g0 = symk_first_subtile(rb, N, BR) + (long long)kchunk * (chunk_cols / 64) - sub0;
+  int sub = 0;
+  for (int c0 = c_begin; c0 < c_end; c0 += 64, ++sub) {
+    __syncthreads();
+    if (tid < 64) {
+      const int col = c0 + tid;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) sB[tid * STR + j] = (col < c_end) ? Z[(size_t)col * ldz + j0 + j] * kExp2Scale : 1.0e18f;
+    }
+    __syncthreads();
+    float4v *dst = cache + ((size_t)((g0 + sub) * 4 + wave) * 16) * R * 64 + lane;
+    for (int s4 = 0; s4 < 16; ++s4) {
+      float4v kq[R];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = (lane + rotdir * (4 * s4 + u)) & 63;
+        float b[JT];
+        lds_load_cols<JT>(sB, idx, b);
+#pragma unroll
+        for (int r = 0; r < R; ++r) kq[r][u] = pair_kernel_sum<JT>(a[r], b);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float4v *q = dst + (size_t)(s4 * R + r) * 64;
+        if (accumulate) {
+          const float4v old = *q;
+          kq[r] += old;
+        }
+        *q = kq[r];
+      }
+    }
+  }
+}
+
+// Cached symmetric product: the loop nest of mvm_fact_kernel with the kernel value taken from the cache.  The wave's
+// stream is requested D steps (of 4 rotation steps x R rows = R KB) ahead through a register ring, across subtile and
+// LDS-stage boundaries.
+template <int TT, int R>
+__global__ __launch_bounds__(256) void symk_mvm_kernel(const float4v *__restrict__ cache, const float *__restrict__ V,
+                                                       float *__restrict__ slabR, float *__restrict__ slabT, int N, int ldv,
+                                                       int t0, int tcnt, int chunk_cols, int rotdir, int accumulate, int w0,
+                                                       int rb_first, int slab_row0, int slab_rows, long long sub0) {
+  constexpr int BR = 256 * R;
+  constexpr int SC = StageCols<TT>::v;
+  constexpr int D = (TT > 4) ? 8 : 4;               // ring depth (steps): the wide blocks run 2 waves per SIMD and need the distance
+  __shared__ __attribute__((aligned(16))) float sV[SC * TT];
+  __shared__ __attribute__((aligned(16))) float sT[4 * SC * TT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
+  const int r0 = rb * BR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+
+  float vrow[R][TT], accR[R][TT];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      vrow[r][t] = (row < N && t < tcnt) ? V[(size_t)row * ldv + t0 + t] : 0.f;
+      accR[r][t] = 0.f;
+    }
+  }
+  const long long g0 = symk_first_subtile(rb, N, BR) + (long long)kchunk * (chunk_cols / 64) - sub0;
+  const int total = ((c_end - c_begin + 63) / 64) * 16;                 // steps of this workgroup
+  const float4v *wp = cache + ((size_t)(g0 * 4 + wave) * 16) * R * 64 + lane;
+  // step n = 16 * subtile + s4  ->  wp + subtile * (4 waves * 16 * R * 64) + s4 * R * 64
+  auto step_ptr = [&](int n) {
+    n = n < total ? n : total - 1;                                      // tail: re-request the last step (no branch)
+    return wp + (size_t)(n >> 4) * (size_t)(4 * 16 * R * 64) + (size_t)(n & 15) * (R * 64);
+  };
+  float4v ring[D][R];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float4v *q = step_ptr(d);
+#pragma unroll
+    for (int r = 0; r < R; ++r) ring[d][r] = __builtin_nontemporal_load(q + r * 64);
+  }
+  int n = 0;
+  for (int c0 = c_begin; c0 < c_end; c0 += SC) {
+    __syncthreads();
+    if (tid < SC) {
+      const int col = c0 + tid;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) sV[tid * TT + t] = (col < c_end && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+    }
+    __syncthreads();
+    const int ncol = c_end - c0;
+    const int nsub = ncol >= SC ? SC / 64 : (ncol + 63) / 64;
+    for (int sub = 0; sub < nsub; ++sub) {
+      const bool doT = (c0 + sub * 64 >= r0 + BR);
+      float accT[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) accT[t] = 0.f;
+#pragma nounroll
+      for (int g = 0; g < 16 / D; ++g) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          float4v cur[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) cur[r] = ring[k][r];
+          {
+            const float4v *q = step_ptr(n + D);
+#pragma unroll
+            for (int r = 0; r < R; ++r) ring[k][r] = __builtin_nontemporal_load(q + r * 64);
+          }
+          ++n;
+          if (doT) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int idx = sub * 64 + ((lane + rotdir * (4 * (g * D + k) + u)) & 63);
+              float v[TT];
+              lds_load_vec<TT>(sV, idx, v);
+              if constexpr (TT % 2 == 0) {
+                // both products on float2 so that hipcc emits v_pk_fma_f32 for the transposed sums as well (left to
+                // the SLP vectoriser, the chains through the DPP rotation stayed scalar: 96 of 192 FMAs per step)
+                float2v ts2[TT / 2];
+#pragma unroll
+                for (int q = 0; q < TT / 2; ++q) ts2[q] = float2v{accT[2 * q], accT[2 * q + 1]};
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                  const float2v ks2 = {cur[r][u], cur[r][u]};
+#pragma unroll
+                  for (int q = 0; q < TT / 2; ++q) {
+                    const float2v a2 = __builtin_elementwise_fma(ks2, float2v{v[2 * q], v[2 * q + 1]},
+                                                                 float2v{accR[r][2 * q], accR[r][2 * q + 1]});
+                    accR[r][2 * q] = a2.x;
+                    accR[r][2 * q + 1] = a2.y;
+                    ts2[q] = __builtin_elementwise_fma(ks2, float2v{vrow[r][2 * q], vrow[r][2 * q + 1]}, ts2[q]);
+                  }
+                }
+#pragma unroll
+                for (int q = 0; q < TT / 2; ++q) {
+                  accT[2 * q] = wave_rotate1(ts2[q].x);
+                  accT[2 * q + 1] = wave_rotate1(ts2[q].y);
+                }
+              } else {
+                float tsum[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) tsum[t] = accT[t];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                  const float ks = cur[r][u];
+#pragma unroll
+                  for (int t = 0; t < TT; ++t) {
+                    accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
+                    tsum[t] = __builtin_fmaf(ks, vrow[r][t], tsum[t]);
+                  }
+                }
+#pragma unroll
+                for (int t = 0; t < TT; ++t) accT[t] = wave_rotate1(tsum[t]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int idx = sub * 64 + ((lane + rotdir * (4 * (g * D + k) + u)) & 63);
+              float v[TT];
+              lds_load_vec<TT>(sV, idx, v);
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                const float ks = cur[r][u];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TT; ++t) sT[(wave * SC + sub * 64 + lane) * TT + t] = accT[t];
+    }
+    __syncthreads();
+    {
+      const int col = c0 + tid;
+      if (tid < SC && col < c_end && col >= r0 + BR) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          if (t < tcnt) {
+            const float sum = sT[(0 * SC + tid) * TT + t] + sT[(1 * SC + tid) * TT + t] +
+                              sT[(2 * SC + tid) * TT + t] + sT[(3 * SC + tid) * TT + t];
+            float *dst = slabT + ((size_t)(rb - rb_first) * N + col) * ldv + t0 + t;
+            *dst = accumulate ? *dst + sum : sum;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * (64 * R) + r * 64 + lane;
+    if (row < N) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (t < tcnt) {
+          float *dst = slabR + ((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0 + t;
+          *dst = accumulate ? *dst + accR[r][t] : accR[r][t];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dense block: out[m][n] = scale * sum_j exp(-0.5 (Z1[m,j]-Z2[n,j])^2).  One thread per output column
 // (coalesced stores), RT rows per workgroup held in LDS.
 // ---------------------------------------------------------------------------------------------
@@ -2630,10 +2877,10 @@ struct TilePlan {
   bool partial;    // the range is a strict subset: slabs are zero-initialised before the sweep
 };
 
-inline int plan_chunk(double pairs, int BR, bool big) {
+inline int plan_chunk(double pairs, int BR, bool big, double target_wgs = 4608.0) {
   // aim for ~4600 workgroups (6 rounds of 3 workgroups per CU) so the dispatcher can balance the triangular sweep;
   // chunks are multiples of 64 columns (one rotation subtile), at least 128 (64 for small problems)
-  double cc = pairs / ((double)BR * 4608.0);
+  double cc = pairs / ((double)BR * target_wgs);
   int chunk = (int)((cc + 63.0) / 64.0) * 64;
   const int min_chunk = big ? 128 : 64;
   if (chunk < min_chunk) chunk = min_chunk;
@@ -2649,7 +2896,7 @@ inline int chunks_of(const TilePlan &p, int64_t N, bool sym, int b) {
 // `world`-way split: the chunk size is chosen for the per-rank share of the pairs so that every rank still launches
 // a few thousand workgroups; rank r gets workgroups [total*r/world, total*(r+1)/world).
 inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0, bool r1 = false,
-                          int br_override = 0) {
+                          int br_override = 0, double target_wgs = 4608.0) {
   TilePlan p;
   // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
   // measured (tools/time_small.py): with T > 4 right-hand sides two rows per lane win from N ~ 4k up (362 vs 429 us at
@@ -2663,7 +2910,7 @@ inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, 
   }
   p.nrb = (int)((M + p.BR - 1) / p.BR);
   const double pairs = (sym ? 0.5 * (double)M * (double)N : (double)M * (double)N) / (double)(world > 0 ? world : 1);
-  p.chunk_cols = plan_chunk(pairs, p.BR, M >= 16384);
+  p.chunk_cols = plan_chunk(pairs, p.BR, M >= 16384, target_wgs);
   long long total = 0;
   for (int b = 0; b < p.nrb; ++b) total += chunks_of(p, N, sym, b);
   p.total_wg = (int)total;
@@ -3034,6 +3281,71 @@ inline int bilinear_nsplit(int64_t N) {
 }  // namespace
 
 // ------------------------------------ C ABI ---------------------------------------------------
+
+namespace {
+// ---- packed symmetric cache: host side ------------------------------------------------------------------------------
+struct SymkPlan {
+  TilePlan p;
+  long long sub0, sub1;        // subtile range [sub0, sub1) of this rank's workgroups
+};
+inline long long symk_host_first_subtile(int rb, int64_t N, int BR) {
+  const long long nsN = (N + 63) / 64, q = BR / 64;
+  return (long long)rb * nsN - q * ((long long)rb * (rb - 1) / 2);
+}
+// first subtile of workgroup `lin` of the plan's numbering (lin == total_wg: one past the last subtile)
+inline long long symk_wg_subtile(const TilePlan &p, int64_t N, int lin) {
+  long long acc = 0;
+  for (int b = 0; b < p.nrb; ++b) {
+    const int cb = chunks_of(p, N, true, b);
+    if (lin < acc + cb) return symk_host_first_subtile(b, N, p.BR) + (lin - acc) * (long long)(p.chunk_cols / 64);
+    acc += cb;
+  }
+  return symk_host_first_subtile(p.nrb, N, p.BR);
+}
+inline SymkPlan symk_plan(int64_t N, int world, int rank) {
+  SymkPlan sp;
+  // A cached workgroup has no exponentials to hide its prologue (row block of V, ring start-up) and epilogue (slabs)
+  // behind, so it wants longer column chunks than the fused sweep: measured optimum ~N / 14 workgroups per rank
+  // (N = 15k: 1000, T = 11 product 0.152 ms against 0.199 ms with the fused sweep's 4600; N = 50k: 3600, 1.31 ms).
+  double wgs = (double)N / 14.0;
+  wgs = wgs < 512.0 ? 512.0 : (wgs > 4608.0 ? 4608.0 : wgs);
+  sp.p = make_plan(N, N, true, 12, world, rank, false, 0, wgs);      // R = 2 from N = 4096 up (the wide-block rule), whatever T is later
+  sp.sub0 = symk_wg_subtile(sp.p, N, sp.p.w0);
+  sp.sub1 = symk_wg_subtile(sp.p, N, sp.p.w1);
+  return sp;
+}
+inline size_t symk_bytes(const SymkPlan &sp) { return (size_t)(sp.sub1 - sp.sub0) * sp.p.BR * 64 * sizeof(float); }
+inline int symk_t_piece(int remaining) {
+  if (remaining > 4) return 12;                        // (an exact T = 11 instantiation measured slower than the padded 12)
+  if (remaining > 1) return 4;
+  return 1;
+}
+template <int JT>
+int symk_launch_build(const SymkPlan &sp, const float *Z, float4v *cache, int N, int ldz, int j0, int accumulate,
+                      hipStream_t st) {
+  dim3 grid(sp.p.w1 - sp.p.w0), block(256);
+  if (sp.p.R == 2)
+    hipLaunchKernelGGL((symk_build_kernel<JT, 2>), grid, block, 0, st, Z, cache, N, ldz, j0, sp.p.chunk_cols, g_rotdir,
+                       accumulate, sp.p.w0, sp.sub0);
+  else
+    hipLaunchKernelGGL((symk_build_kernel<JT, 1>), grid, block, 0, st, Z, cache, N, ldz, j0, sp.p.chunk_cols, g_rotdir,
+                       accumulate, sp.p.w0, sp.sub0);
+  return launch_status();
+}
+template <int TT>
+int symk_launch_mvm(const SymkPlan &sp, const float4v *cache, const float *V, float *slabR, float *slabT, int N, int T,
+                    int t0, int tcnt, hipStream_t st) {
+  dim3 grid(sp.p.w1 - sp.p.w0), block(256);
+  if (sp.p.R == 2)
+    hipLaunchKernelGGL((symk_mvm_kernel<TT, 2>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
+                       sp.p.chunk_cols, g_rotdir, 0, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
+  else
+    hipLaunchKernelGGL((symk_mvm_kernel<TT, 1>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
+                       sp.p.chunk_cols, g_rotdir, 0, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
+  return launch_status();
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -3605,6 +3917,84 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
   if (ncols > 64) return RPGP_EINVAL;
   return pivchol_common(Z, L, diag_work, N, ldz, ncols, rank, scale, scale * weight_sum, fam->kind, fam->group,
                         fam->ncomp, fam->weights, stream);
+}
+
+size_t rpgp_symcache_bytes(int64_t N, int world, int rank) {
+  if (N <= 0 || N > 0x7fffffffLL || world < 1 || rank < 0 || rank >= world) return 0;
+  return symk_bytes(symk_plan(N, world, rank));
+}
+
+size_t rpgp_symcache_workspace_bytes(int64_t N, int T, int world, int rank) {
+  if (N <= 0 || N > 0x7fffffffLL || T <= 0 || world < 1 || rank < 0 || rank >= world) return 0;
+  return plan_workspace_floats(symk_plan(N, world, rank).p, N, T, true) * sizeof(float);
+}
+
+int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t N, int ldz, int j0, int j1, int world,
+                        int rank, void *stream) {
+  if (!Z || !cache || N <= 0 || N > 0x7fffffffLL || j0 < 0 || j1 <= j0 || ldz < j1 || world < 1 || rank < 0 ||
+      rank >= world)
+    return RPGP_EINVAL;
+  const int irc = rpgp_init();
+  if (irc) return irc;
+  const SymkPlan sp = symk_plan(N, world, rank);
+  if (cache_bytes < symk_bytes(sp)) return RPGP_EWORKSPACE;
+  if (sp.p.w1 <= sp.p.w0) return 0;
+  hipStream_t st = as_stream(stream);
+  float4v *c = reinterpret_cast<float4v *>(cache);
+  int first = 1;
+  for (int j = j0; j < j1;) {
+    const int jt = next_j_piece(j1 - j);
+    int rc = 0;
+    switch (jt) {
+      case 20: rc = symk_launch_build<20>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+      case 10: rc = symk_launch_build<10>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+      case 8: rc = symk_launch_build<8>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+      case 5: rc = symk_launch_build<5>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+      case 4: rc = symk_launch_build<4>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+      case 3: rc = symk_launch_build<3>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+      case 2: rc = symk_launch_build<2>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+      default: rc = symk_launch_build<1>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+    }
+    if (rc) return rc;
+    first = 0;
+    j += jt;
+  }
+  return 0;
+}
+
+int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, const float *V, float *out, int64_t N, int T, float scale,
+                      float noise, int world, int rank, void *ws, size_t ws_bytes, void *stream) {
+  if (!cache || !V || !out || N <= 0 || N > 0x7fffffffLL || T <= 0 || world < 1 || rank < 0 || rank >= world)
+    return RPGP_EINVAL;
+  const int irc = rpgp_init();
+  if (irc) return irc;
+  const SymkPlan sp = symk_plan(N, world, rank);
+  if (cache_bytes < symk_bytes(sp)) return RPGP_EINVAL;
+  const TilePlan &p = sp.p;
+  const size_t need = plan_workspace_floats(p, N, T, true) * sizeof(float);
+  if (need && (!ws || ws_bytes < need)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  float *slabR = reinterpret_cast<float *>(ws);
+  float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
+  if (p.partial && need) RPGP_CHECK(hipMemsetAsync(ws, 0, need, st));   // row blocks shared with a neighbour rank
+  const float4v *c = reinterpret_cast<const float4v *>(cache);
+  for (int t0 = 0; t0 < T && p.w1 > p.w0;) {
+    const int tt = symk_t_piece(T - t0);
+    const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+    int rc = 0;
+    switch (tt) {
+      case 1: rc = symk_launch_mvm<1>(sp, c, V, slabR, slabT, (int)N, T, t0, tcnt, st); break;
+      case 4: rc = symk_launch_mvm<4>(sp, c, V, slabR, slabT, (int)N, T, t0, tcnt, st); break;
+      default: rc = symk_launch_mvm<12>(sp, c, V, slabR, slabT, (int)N, T, t0, tcnt, st); break;
+    }
+    if (rc) return rc;
+    t0 += tcnt;
+  }
+  const size_t total = (size_t)N * T;
+  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st, slabR,
+                     slabT, V, out, (int)N, (int)N, T, p.BR, p.chunk_cols, 1, scale, noise, (const int *)nullptr, p.rb0,
+                     p.rb1, p.row0, p.rows);
+  return launch_status();
 }
 
 namespace {

@@ -12,7 +12,7 @@ import torch
 
 from . import settings
 from .linear_cg import linear_cg
-from .operators import AddedDiagOperator, DenseOperator, SKIAdditiveOperator
+from .operators import AddedDiagOperator, DenseOperator, SKIAdditiveOperator, SymCachedOperator
 from .precond import build_preconditioner
 
 
@@ -97,11 +97,19 @@ class InvQuadLogDet(torch.autograd.Function):
         matmul = khat._matmul
         native_op = khat
         if not isinstance(op, SKIAdditiveOperator) and (op.shard is None or op.shard.world_size == 1) and \
-                Z.dtype == torch.float32 and settings.use_cached_kernel(N, Z.device):
-            # cached-K mode: materialise K once per hyper-parameter step (rpgp_dense) so each
-            # CG iteration on the T = 11 block is one HBM-bound pass over the stored matrix; the backward pass stays fused
-            native_op = DenseOperator(op.to_dense_cached(), float(noise.detach()))
-            matmul = native_op._matmul
+                Z.dtype == torch.float32:
+            # cached-K mode: evaluate the kernel once per hyper-parameter step so each CG
+            # iteration on the T = 11 block is one HBM-bound pass over stored values; the backward pass stays fused.
+            # Preferred form: the packed symmetric cache (every unordered pair once, half the bytes and half the build);
+            # otherwise the dense matrix (rpgp_dense).
+            cache = op.to_symcache() if hasattr(op, "to_symcache") and settings.use_cached_kernel(N, Z.device, 2.0) else None
+            if cache is not None:
+                native_op = SymCachedOperator(cache, op._scale, float(noise.detach()),
+                                              diag_value=op._scale * op.num_projections)
+                matmul = native_op._matmul
+            elif settings.use_cached_kernel(N, Z.device):
+                native_op = DenseOperator(op.to_dense_cached(), float(noise.detach()))
+                matmul = native_op._matmul
         solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes, operator=native_op,
                                   tolerance=settings.cg_tolerance.value(),
                                   max_iter=settings.max_cg_iterations.value(),

@@ -12,7 +12,7 @@ from .dense_ops import DenseKernelOperator
 from .inv_quad_logdet import inv_quad_logdet, psd_safe_cholesky, use_cholesky
 from .likelihoods import ConstantMean, GaussianLikelihood, MultivariateNormal, LOG2PI
 from .linear_cg import linear_cg
-from .operators import AddedDiagOperator, AdditiveRPOperator, DenseOperator, SKIAdditiveOperator
+from .operators import AddedDiagOperator, AdditiveRPOperator, DenseOperator, SKIAdditiveOperator, SymCachedOperator
 from .precond import build_preconditioner
 
 
@@ -71,9 +71,15 @@ class PredictionStrategy:
             else:
                 self.chol = None
                 shard = getattr(self.op, "shard", None)
-                if isinstance(self.op, AdditiveRPOperator) and not isinstance(self.op, SKIAdditiveOperator) and \
-                        (shard is None or shard.world_size == 1) and x.dtype == torch.float32 and \
-                        settings.use_cached_kernel(N, x.device):
+                cacheable = isinstance(self.op, AdditiveRPOperator) and not isinstance(self.op, SKIAdditiveOperator) and \
+                    (shard is None or shard.world_size == 1) and x.dtype == torch.float32
+                cache = self.op.to_symcache() if cacheable and settings.use_cached_kernel(N, x.device, 2.0) else None
+                if cache is not None:
+                    # thin solves (the mean cache, LOVE's Lanczos) stream the packed symmetric cache: half the bytes of
+                    # the dense matrix; the N_test-wide covariance solve builds the dense matrix on demand (solve())
+                    self.khat = SymCachedOperator(cache, self.op._scale, float(self.noise),
+                                                  diag_value=self.op._scale * self.op.num_projections)
+                elif cacheable and settings.use_cached_kernel(N, x.device):
                     self.khat = DenseOperator(self.op.to_dense_cached(), float(self.noise))
                     self._dense_khat = self.khat
                 else:

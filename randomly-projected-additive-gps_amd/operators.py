@@ -220,6 +220,15 @@ class AdditiveRPOperator(LinearOperator):
             return be.dense(self.Z1.detach(), self.Z1.detach(), self._scale, pad=True)
         return self.to_dense()
 
+    def to_symcache(self):
+        """Packed symmetric cache of this operator (every unordered pair once: half the bytes of to_dense_cached()), or
+        None when the backend / operator cannot provide one (then the dense matrix is the cached-K form)."""
+        be = _backend.get_backend()
+        if type(self) is AdditiveRPOperator and self.symmetric and self.Z1.dtype == torch.float32 and \
+                getattr(be, "supports_symcache", False) and (self.shard is None or self.shard.world_size == 1):
+            return be.symcache(self.Z1.detach())
+        return None
+
     def representation(self):
         if self.symmetric:
             return (self.Z1, self.outputscale)
@@ -652,6 +661,60 @@ class AddedDiagOperator(LinearOperator):
         return self.base._bilinear_derivative(left_vecs, right_vecs) + (g_noise,)
 
     _quad_form_derivative = _bilinear_derivative
+
+
+class SymCachedOperator(LinearOperator):
+    """Cached-K mode on the packed symmetric cache (rpgp_symcache_*): Khat = scale * K + noise I applied as ONE stream
+    over N^2 / 2 stored kernel values per block of up to 12 right-hand sides.  `diag_value` = scale * (number of
+    projections), the constant diagonal of the additive RBF kernel."""
+
+    def __init__(self, cache, scale, noise=0.0, diag_value=None):
+        self.cache = cache
+        self._scale = float(scale)
+        self._noise = float(noise)
+        self._diag_value = diag_value
+
+    def _size(self):
+        return torch.Size((self.cache.N, self.cache.N))
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    @property
+    def device(self):
+        return self.cache.device
+
+    def _matmul(self, rhs):
+        return _backend.get_backend().symcache_mvm(self.cache, rhs.detach(), self._scale, self._noise)
+
+    def native_descriptor(self):
+        be = _backend.get_backend()
+        if not hasattr(be, "mbcg_solve") or self.cache.world != 1:
+            return None
+        from . import _lib
+        return be.make_operator_desc(_lib.RPGP_OP_SYMCACHE, self.cache.N, 0, self._scale, self._noise, symcache=self.cache)
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def _diagonal(self):
+        if self._diag_value is None:
+            raise RuntimeError("SymCachedOperator was built without its diagonal value")
+        return torch.full((self.cache.N,), float(self._diag_value) + self._noise, dtype=torch.float32, device=self.device)
+
+    def to_dense(self):
+        n = self.cache.N
+        out = torch.empty((n, n), dtype=torch.float32, device=self.device)
+        eye = torch.zeros((n, 12), dtype=torch.float32, device=self.device)
+        for c0 in range(0, n, 12):
+            w = min(12, n - c0)
+            eye.zero_()
+            eye[c0:c0 + w, :w].fill_diagonal_(1.0)
+            out[:, c0:c0 + w] = self._matmul(eye)[:, :w]
+        return out
+
+    evaluate = to_dense
 
 
 class DenseOperator(LinearOperator):

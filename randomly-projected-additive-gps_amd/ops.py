@@ -340,6 +340,44 @@ def dense_mvm(Kd, V, noise=0.0):
     return out.squeeze(1) if squeeze else out
 
 
+class SymCache:
+    """Packed symmetric cache of the additive kernel on Z (rpgp_symcache_build): every unordered pair once, in the order
+    the symmetric sweep consumes it — half the bytes of the dense N x N matrix.  `shard` = (world, rank) keeps only
+    this rank's share of the pairs (the product is then a partial result, summed by one all-reduce like the pair-sharded
+    fused MVM).  Values are unscaled (sum over the projections); `scale` and `noise` are applied by the product."""
+
+    def __init__(self, Z, j0=0, j1=None, shard=None):
+        lib = _lib.load()
+        Z = _require(Z, "Z", 2)
+        self.N, J = Z.shape
+        j1 = J if j1 is None else j1
+        self.world, self.rank = (1, 0) if shard is None else (int(shard[0]), int(shard[1]))
+        nbytes = lib.rpgp_symcache_bytes(self.N, self.world, self.rank)
+        self.buf = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=Z.device)
+        self.nbytes = nbytes
+        with torch.cuda.device(Z.device):
+            _lib.check(lib.rpgp_symcache_build(Z.data_ptr(), self.buf.data_ptr(), nbytes, self.N, Z.stride(0), j0, j1,
+                                               self.world, self.rank, _stream()), "rpgp_symcache_build")
+
+    @property
+    def device(self):
+        return self.buf.device
+
+
+def symcache_mvm(cache, V, scale, noise=0.0):
+    """out = scale * K V + noise * V from a SymCache (a partial product when the cache is one rank's shard)."""
+    lib = _lib.load()
+    V2, squeeze = _as_matrix(V, cache.N, "V")
+    T = V2.shape[1]
+    out = torch.empty_like(V2)
+    with torch.cuda.device(cache.device):
+        ws = _workspace(cache.device, lib.rpgp_symcache_workspace_bytes(cache.N, T, cache.world, cache.rank))
+        _lib.check(lib.rpgp_symcache_mvm(cache.buf.data_ptr(), cache.nbytes, V2.data_ptr(), out.data_ptr(), cache.N, T,
+                                         float(scale), float(noise), cache.world, cache.rank, ws.data_ptr(), ws.numel(),
+                                         _stream()), "rpgp_symcache_mvm")
+    return out.squeeze(1) if squeeze else out
+
+
 # ------------------------------------------------------------------------------------------------ SKI path
 
 def ski_grid(Z1, Z2=None, grid_size=1024, weights=None):
@@ -670,7 +708,8 @@ def family_bilinear_grad_dense(fam, Z, S, scale):
     return gZ, gc
 
 
-def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=0, j1=None, G=0, Kd=None, family=None):
+def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=0, j1=None, G=0, Kd=None, family=None,
+                       symcache=None):
     """Fill a `struct rpgp_operator`; returns (struct, keepalive) — keep both referenced while the solve runs."""
     import ctypes
     d = _lib.RpgpOperator()
@@ -683,7 +722,9 @@ def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=
     d.Kd = Kd.data_ptr() if Kd is not None else None
     d.ldk = Kd.stride(0) if Kd is not None else 0
     d.family = ctypes.addressof(family.struct) if family is not None else None
-    return d, (Z, prep, gp, Kd, family)
+    if symcache is not None:                       # RPGP_OP_SYMCACHE: the cache travels in (Kd, ldk = bytes)
+        d.Kd, d.ldk = symcache.buf.data_ptr(), symcache.nbytes
+    return d, (Z, prep, gp, Kd, family, symcache)
 
 
 def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_every=1, L=None, Cinv=None, sigma2=1.0,

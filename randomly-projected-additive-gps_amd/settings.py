@@ -66,16 +66,18 @@ skip_posterior_variances = _setting("skip_posterior_variances", False, flag=True
 deterministic_probes = _setting("deterministic_probes", False, flag=True)   # fixed probe vectors (reproducible SLQ)
 # Cached-K mode: materialise K once per hyper-parameter step / prediction strategy so that every
 # CG iteration is ONE HBM-bound pass over the stored matrix (T = 11 block at N = 50k: 1.9 ms against 3.4 ms for the fused
-# sweep, which recomputes N^2 J / 2 exponentials per iteration).  "auto" (default): cache whenever 4 N^2 bytes fit in
-# `cache_kernel_fraction` of the device memory (288 GB HBM3E: N <= ~134k) and N >= `cache_kernel_min_size`; True / False
+# sweep, which recomputes N^2 J / 2 exponentials per iteration).  "auto" (default): cache whenever the stored form fits in
+# `cache_kernel_fraction` of the device memory and N >= `cache_kernel_min_size` — the packed symmetric cache needs 2 N^2
+# bytes (288 GB HBM3E: N <= ~190k), the dense matrix of the wide prediction solves 4 N^2 (N <= ~134k); True / False
 # force it on (when it fits) / off.  Sharded (multi-GPU), SKI and float64 operators never cache.
 cache_kernel = _setting("cache_kernel", "auto")
 cache_kernel_fraction = _setting("cache_kernel_fraction", 0.25)
 cache_kernel_min_size = _setting("cache_kernel_min_size", 4096)
 
 
-def use_cached_kernel(N, device):
-    """Decision of the cached-K mode for an N x N exact operator living on `device`."""
+def use_cached_kernel(N, device, bytes_per_entry=4.0):
+    """Decision of the cached-K mode for an N x N exact operator living on `device`.  `bytes_per_entry`: 4 for the
+    dense matrix, 2 for the packed symmetric cache (every unordered pair once)."""
     import torch
     mode = cache_kernel.value()
     if mode is False or mode == 0:
@@ -83,7 +85,7 @@ def use_cached_kernel(N, device):
     dev = torch.device(device)
     if dev.type != "cuda":
         return False
-    fits = 4.0 * N * N <= cache_kernel_fraction.value() * torch.cuda.get_device_properties(dev).total_memory
+    fits = bytes_per_entry * N * N <= cache_kernel_fraction.value() * torch.cuda.get_device_properties(dev).total_memory
     if mode is True or mode == 1:
         return fits
     return fits and N >= cache_kernel_min_size.value()

@@ -133,6 +133,33 @@ def test_native_cached_k_operator(gpu_device):
     assert float(resid.max()) < 1e-3
 
 
+def test_native_symcache_operator(gpu_device):
+    """RPGP_OP_SYMCACHE (packed symmetric cache inside the native executor) solves the same system as the fused
+    operator, and the operator's dense form / diagonal agree with the fused operator's."""
+    from rpgp_amd import linear_cg as lcg
+    from rpgp_amd.operators import SymCachedOperator
+    from rpgp_amd.precond import WoodburyPreconditioner
+    from rpgp_amd import ops
+    base, khat = _ops_pair(gpu_device, 4200, 20, 0.3, seed=11)
+    sym = SymCachedOperator(base.to_symcache(), base._scale, 0.3, diag_value=base._scale * base.num_projections)
+    rhs = torch.randn(4200, 11, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    pre = WoodburyPreconditioner(ops.pivoted_cholesky(base.Z1, base._scale, 15), 0.3)
+    before = lcg.stats.get("native_calls", 0)
+    xs, ts = lcg.linear_cg(sym._matmul, rhs, n_tridiag=10, tolerance=1e-5, max_iter=500, preconditioner=pre, operator=sym)
+    xf, tf = lcg.linear_cg(khat._matmul, rhs, n_tridiag=10, tolerance=1e-5, max_iter=500, preconditioner=pre, operator=khat)
+    assert lcg.stats.get("native_calls", 0) == before + 2
+    assert float((xs - xf).norm() / xf.norm()) < 1e-3
+    resid = (khat._matmul(xs) - rhs).norm(dim=0) / rhs.norm(dim=0)
+    assert float(resid.max()) < 1e-3
+    assert torch.allclose(ts, tf, rtol=1e-2, atol=1e-3)
+    small, _ = _ops_pair(gpu_device, 700, 6, 0.3, seed=3)
+    sym_small = SymCachedOperator(small.to_symcache(), small._scale, 0.3, diag_value=small._scale * small.num_projections)
+    ref = small.to_dense()
+    ref.diagonal().add_(0.3)
+    assert float((sym_small.to_dense() - ref).abs().max()) < 1e-5
+    assert torch.allclose(sym_small._diagonal(), ref.diagonal(), atol=1e-5)
+
+
 def test_native_cg_stops_on_stagnation(gpu_device):
     """Badly conditioned system (noise 1e-7 on a smooth kernel): fp32 CG cannot reach the tolerance; the device-side
     stagnation rule stops the executor long before max_iter and the non-convergence warning is raised."""

@@ -254,6 +254,33 @@ def main():
                       "note": "literal HBM stream of the 4N^2-byte matrix (rpgp_dense_mvm); what the training / prediction solves "
                               "run automatically when K fits a quarter of HBM (settings.cache_kernel = 'auto'); not the headline"}
             del Kd
+        # packed symmetric cache: the same cached-K product from half the bytes (what training / thin prediction solves
+        # take automatically when 2 N^2 bytes fit a quarter of HBM)
+        torch.cuda.synchronize()
+        tk = time.perf_counter()
+        sc = ops.SymCache(Z)
+        torch.cuda.synchronize()
+        t_sbuild = time.perf_counter() - tk
+
+        def _time_sc(Vx, reps=10):
+            ops.symcache_mvm(sc, Vx, scale, noise)
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                o_ = ops.symcache_mvm(sc, Vx, scale, noise)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / reps, o_
+        t_s1, os1 = _time_sc(V)
+        t_s11, _ = _time_sc(V11)
+        symc = {"mvm_ms": round(t_s1 * 1e3, 4), "mvm_per_s": round(1.0 / t_s1, 1), "build_ms": round(t_sbuild * 1e3, 3),
+                "block_T11_ms": round(t_s11 * 1e3, 4), "cache_GB": round(sc.nbytes / 1e9, 3),
+                "own_bytes_GBps": round(sc.nbytes / t_s1 / 1e9, 1), "own_bytes_frac_of_8TBps": round(sc.nbytes / t_s1 / 8e12, 4),
+                "dense_equivalent_GBps": round(4.0 * N * N / t_s1 / 1e9, 1),
+                "rel_diff_vs_fused": float((os1 - res).norm() / res.norm()),
+                "note": "rpgp_symcache_mvm: every unordered pair stored once in the order the symmetric sweep consumes it; "
+                        "HBM-bound on N^2/2 stored values for T <= 4, VALU-bound (rotating transposed accumulators) for the "
+                        "T = 11 block; not the headline"}
+        del sc
         # SKI mode (the reference's `ski: true` specs, e.g. additive_spread_prescale_J20_ski.json): grid interpolation of
         # the same operator, O(N (J + T)) per MVM; an approximation (difference reported), never the headline
         gp = ops.ski_grid(Z, None, 1024)
@@ -284,7 +311,7 @@ def main():
             ops.bilinear_grad(Z, Lb, Rb, scale)
         torch.cuda.synchronize()
         t_bil = (time.perf_counter() - tk) / 3
-        result["extras"] = {"cached_k": cached, "ski": ski, "bilinear_derivative_T11_ms": round(t_bil * 1e3, 4),
+        result["extras"] = {"cached_k": cached, "symcache": symc, "ski": ski, "bilinear_derivative_T11_ms": round(t_bil * 1e3, 4),
                             "block_T11_ms": round(t11 * 1e3, 4), "block_T11_mvm_equiv_per_s": round(11.0 / t11, 1),
                             "solve_Khat_inv_y": {"what": "mean-cache solve, rank-15 pivoted-Cholesky preconditioner, native mBCG, fused MVM",
                                                  "tolerance": 0.01, "cg_iterations": lcg.stats["last_iterations"],

@@ -187,13 +187,21 @@ int rpgp_dense_mvm(const float *Kd, const float *V, float *out, int64_t N, int64
  * (world, rank): pair-sharding as in rpgp_mvm_sym_range — the cache holds this rank's share of the pairs only and the
  * product is a partial result (noise on ONE rank); world = 1, rank = 0 is the whole matrix.  The layout depends on
  * (N, world, rank) only; a cache is valid for exactly the arguments it was built with.
+ * `layout` (the same value for the build and every product on that cache; size and workspace do not depend on it):
+ *   RPGP_SYMCACHE_THIN — rotation order of the fused sweep; products of 1..4 right-hand sides are HBM-bound on the
+ *                        N^2/2 stored values (VALU passes of up to 12 columns for wider blocks);
+ *   RPGP_SYMCACHE_WIDE — 16 x 16 tiles in v_mfma_f32_16x16x4_f32 operand order; blocks of up to 16 right-hand sides per
+ *                        pass on the matrix cores (the training block of 10 probes + the residual).
  */
+#define RPGP_SYMCACHE_THIN 0
+#define RPGP_SYMCACHE_WIDE 1
 size_t rpgp_symcache_bytes(int64_t N, int world, int rank);
 size_t rpgp_symcache_workspace_bytes(int64_t N, int T, int world, int rank);
-int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t N, int ldz, int j0, int j1, int world,
-                        int rank, void *stream);
-int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, const float *V, float *out, int64_t N, int T, float scale,
-                      float noise, int world, int rank, void *workspace, size_t workspace_bytes, void *stream);
+int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t N, int ldz, int j0, int j1, int layout,
+                        int world, int rank, void *stream);
+int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, int layout, const float *V, float *out, int64_t N, int T,
+                      float scale, float noise, int world, int rank, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 /*
  * SKI path (1-D grid interpolation per projection; replaces the `GridInterpolationKernel` wrap of
@@ -308,7 +316,7 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
 #define RPGP_OP_SKI 2             /* rpgp_ski_mvm on Z + grid_params */
 #define RPGP_OP_DENSE 3           /* cached-K: symmetric Kd (N x N, row stride ldk) in HBM, applied by rpgp_dense_mvm */
 #define RPGP_OP_FAMILY 4          /* rpgp_family_mvm_sym on Z + family */
-#define RPGP_OP_SYMCACHE 5        /* packed symmetric cache: Kd = the cache, ldk = its size in bytes; scale, noise */
+#define RPGP_OP_SYMCACHE 5        /* packed symmetric cache: Kd = the cache, ldk = its size in bytes, G = its layout; scale, noise */
 typedef struct rpgp_operator {
   int kind;
   int64_t N;

@@ -51,8 +51,8 @@ SIGNATURES = {
     "rpgp_dense_mvm": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _f32, _vp]),
     "rpgp_symcache_bytes": (_sz, [_i64, _int, _int]),
     "rpgp_symcache_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
-    "rpgp_symcache_build": (_int, [_vp, _vp, _sz, _i64, _int, _int, _int, _int, _int, _vp]),
-    "rpgp_symcache_mvm": (_int, [_vp, _sz, _vp, _vp, _i64, _int, _f32, _f32, _int, _int, _vp, _sz, _vp]),
+    "rpgp_symcache_build": (_int, [_vp, _vp, _sz, _i64, _int, _int, _int, _int, _int, _int, _vp]),
+    "rpgp_symcache_mvm": (_int, [_vp, _sz, _int, _vp, _vp, _i64, _int, _f32, _f32, _int, _int, _vp, _sz, _vp]),
     "rpgp_ski_workspace_bytes": (_sz, [_int, _int, _int]),
     "rpgp_ski_grid": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "rpgp_ski_mvm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
@@ -103,6 +103,7 @@ class RpgpFamily(ctypes.Structure):
 
 RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI, RPGP_OP_DENSE, RPGP_OP_FAMILY, RPGP_OP_SYMCACHE = 0, 1, 2, 3, 4, 5
 RPGP_KIND_RBF, RPGP_KIND_MATERN15, RPGP_KIND_IMQ, RPGP_KIND_COSINE = 0, 1, 2, 3
+RPGP_SYMCACHE_THIN, RPGP_SYMCACHE_WIDE = 0, 1
 RPGP_PIVCHOL_SCRATCH = 2048
 
 _lib = None

@@ -516,7 +516,8 @@ int apply_operator(const rpgp_operator *op, const float *V, float *out, int T, v
     case RPGP_OP_DENSE:
       return rpgp_dense_mvm(op->Kd, V, out, op->N, op->ldk, T, op->noise, stream);
     case RPGP_OP_SYMCACHE:
-      return rpgp_symcache_mvm(op->Kd, (size_t)op->ldk, V, out, op->N, T, op->scale, op->noise, 1, 0, ws, ws_bytes, stream);
+      return rpgp_symcache_mvm(op->Kd, (size_t)op->ldk, op->G, V, out, op->N, T, op->scale, op->noise, 1, 0, ws, ws_bytes,
+                               stream);
     case RPGP_OP_FAMILY:
       return rpgp_family_mvm_sym(op->family, op->Z, V, out, op->N, op->ldz, T, op->scale, op->noise, ws, ws_bytes,
                                  stream);

@@ -1002,6 +1002,226 @@ __global__ __launch_bounds__(256) void symk_mvm_kernel(const float4v *__restrict
   }
 }
 
+// ---- wide layout of the packed cache (blocks of 5..16 right-hand sides on the matrix cores) -----------------------------
+// Same subtiles, same size; inside a wave's 16 R KB the values are stored as 16 x 16 tiles in the A/B operand order of
+// v_mfma_f32_16x16x4_f32:  [wave][slot(rt 0..4R-1, ct 0..3)][lane]  float4 = K[row0 + 16 rt + (l % 16)][csub + 16 ct + 4 (l / 16) + i]
+// (slots in the pair order the product consumes: (2m, p), (2m + 1, (p + 1) % 4), p = 0..3).
+// One tile feeds three groups of four exact-fp32 MFMAs:
+//   row product        D[t][rho]   += sum_i  A = V[csub + 16 ct + 4k + i][t]   x  B = tile_i             (contracts the columns)
+//   in-register transpose  L2      =  sum_i  A = tile_i  x  B = identity slice i   (x * 1.0 + 0: exact)  -> D layout:
+//                                     lane holds K[16 rt + 4 (l/16) + r][16 ct + l % 16], r = 0..3
+//   transposed product D'[t][gam]  += sum_j  A = V[row0 + 16 rt + 4k + j][t]   x  B = L2_j               (contracts the rows)
+// The rotating accumulators of the thin layout cost T DPP moves per 64 pairs; here the transposed sums of a column tile
+// stay in one accumulator across the wave's 4 R row tiles.
+template <int JT, int R>
+__global__ __launch_bounds__(256) void symk_build_tile_kernel(const float *__restrict__ Z, float4v *__restrict__ cache,
+                                                              int N, int ldz, int j0, int chunk_cols, int accumulate,
+                                                              int w0, long long sub0) {
+  constexpr int BR = 256 * R;
+  constexpr int STR = ColStride<JT>::v;
+  __shared__ __attribute__((aligned(16))) float sB[64 * STR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rho = lane & 15, kap = lane >> 4;
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
+  const int r0 = rb * BR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+  const long long g0 = symk_first_subtile(rb, N, BR) + (long long)kchunk * (chunk_cols / 64) - sub0;
+  int sub = 0;
+  for (int c0 = c_begin; c0 < c_end; c0 += 64, ++sub) {
+    __syncthreads();
+    if (tid < 64) {
+      const int col = c0 + tid;
+#pragma unroll
+      for (int j = 0; j < JT; ++j) sB[tid * STR + j] = (col < c_end) ? Z[(size_t)col * ldz + j0 + j] * kExp2Scale : 1.0e18f;
+    }
+    __syncthreads();
+    float4v *dst = cache + ((size_t)((g0 + sub) * 4 + wave) * 16) * R * 64 + lane;
+#pragma nounroll
+    for (int rt = 0; rt < 4 * R; ++rt) {
+      const int row = r0 + wave * (64 * R) + 16 * rt + rho;
+      float a[JT];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) a[j] = (row < N) ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 3.0e18f;
+#pragma nounroll
+      for (int ct = 0; ct < 4; ++ct) {
+        float4v kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float b[JT];
+          lds_load_cols<JT>(sB, 16 * ct + 4 * kap + i, b);
+          kq[i] = pair_kernel_sum<JT>(a, b);
+        }
+        // slot of tile (rt, ct) in the product's pair order: pairs A = (2 m, p), B = (2 m + 1, (p + 1) % 4)
+        const int slot = (rt >> 1) * 8 + (((rt & 1) ? ((ct + 3) & 3) : ct) << 1) + (rt & 1);
+        float4v *q = dst + (size_t)slot * 64;
+        if (accumulate) {
+          const float4v old = *q;
+          kq += old;
+        }
+        *q = kq;
+      }
+    }
+  }
+}
+
+// One pair of row tiles (2 RT2, 2 RT2 + 1) of a subtile, then the next pair (compile-time recursion: a `#pragma unroll`
+// loop over the pairs was kept rolled by hipcc, which then rotated the accumulator arrays through registers with ~1000
+// v_mov per subtile).
+template <int R, bool DOT, int RT2>
+__device__ __forceinline__ void symk_tile_rows(const float4v *wp, float4v (&ring)[8], const float (&acol)[4][4],
+                                               const float (&arow)[4 * R][4], const float (&bid)[4],
+                                               floatx4m (&accR)[4 * R], floatx4m (&accT)[4]) {
+  constexpr int NRT = 4 * R, NT = 4 * NRT, D = 8;
+  constexpr size_t SUB = (size_t)4 * NT * 64;
+  if constexpr (RT2 < NRT / 2) {
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int rtA = 2 * RT2, ctA = pp, rtB = 2 * RT2 + 1, ctB = (pp + 1) & 3;
+      const float4v kA = ring[2 * pp], kB = ring[2 * pp + 1];
+      {
+        const int m0 = RT2 * 8 + 2 * pp + D, m1 = m0 + 1;            // slots requested now (>= NT: next subtile)
+        ring[2 * pp] = __builtin_nontemporal_load(wp + (m0 < NT ? (size_t)m0 * 64 : SUB + (size_t)(m0 - NT) * 64));
+        ring[2 * pp + 1] = __builtin_nontemporal_load(wp + (m1 < NT ? (size_t)m1 * 64 : SUB + (size_t)(m1 - NT) * 64));
+      }
+      __builtin_amdgcn_sched_barrier(0);       // keep the requests D tiles ahead (hipcc sinks them to their first use)
+      if constexpr (DOT) {
+        floatx4m lA = {0.f, 0.f, 0.f, 0.f}, lB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lA = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[i], bid[i], lA, 0, 0, 0);
+          accR[rtA] = __builtin_amdgcn_mfma_f32_16x16x4f32(acol[ctA][i], kA[i], accR[rtA], 0, 0, 0);
+          lB = __builtin_amdgcn_mfma_f32_16x16x4f32(kB[i], bid[i], lB, 0, 0, 0);
+          accR[rtB] = __builtin_amdgcn_mfma_f32_16x16x4f32(acol[ctB][i], kB[i], accR[rtB], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          accT[ctA] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[rtA][j], lA[j], accT[ctA], 0, 0, 0);
+          accT[ctB] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[rtB][j], lB[j], accT[ctB], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          accR[rtA] = __builtin_amdgcn_mfma_f32_16x16x4f32(acol[ctA][i], kA[i], accR[rtA], 0, 0, 0);
+          accR[rtB] = __builtin_amdgcn_mfma_f32_16x16x4f32(acol[ctB][i], kB[i], accR[rtB], 0, 0, 0);
+        }
+      }
+    }
+    symk_tile_rows<R, DOT, RT2 + 1>(wp, ring, acol, arow, bid, accR, accT);
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256, 2) void symk_mvm_tile_kernel(const float4v *__restrict__ cache, const float *__restrict__ V,
+                                                            float *__restrict__ slabR, float *__restrict__ slabT, int N,
+                                                            int ldv, int t0, int tcnt, int chunk_cols, int w0, int rb_first,
+                                                            int slab_row0, int slab_rows, long long sub0) {
+  constexpr int BR = 256 * R;
+  constexpr int NRT = 4 * R;                        // row tiles of a wave
+  constexpr int NT = 4 * NRT;                       // tiles per wave per subtile
+  constexpr int D = 8;                              // tiles requested ahead
+  constexpr int SVS = 17;                           // LDS row stride of the staged right-hand sides
+  __shared__ __attribute__((aligned(16))) float sV[64 * SVS];
+  __shared__ __attribute__((aligned(16))) float sT[4 * 64 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = lane & 15, kap = lane >> 4;        // l % 16 (t for A operands, rho / gamma for B and D), l / 16
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
+  const int r0 = rb * BR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+  const int rw0 = r0 + wave * (64 * R);             // first row of this wave
+
+  // A operands of the transposed product: V[rw0 + 16 rt + 4 kap + j][t = tn]
+  float arow[NRT][4];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = rw0 + 16 * rt + 4 * kap + j;
+      arow[rt][j] = (row < N && tn < tcnt) ? V[(size_t)row * ldv + t0 + tn] : 0.f;
+    }
+  float bid[4];                                     // identity slices: B_i[k][n] = (n == 4 k + i)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bid[i] = (tn == 4 * kap + i) ? 1.0f : 0.0f;
+  floatx4m accR[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) accR[rt] = floatx4m{0.f, 0.f, 0.f, 0.f};
+
+  const long long g0 = symk_first_subtile(rb, N, BR) + (long long)kchunk * (chunk_cols / 64) - sub0;
+  const int nsub_wg = (c_end - c_begin + 63) / 64;
+  (void)nsub_wg;
+  // The wave's stream: subtile s at wp + s * SUB, tiles in slot order 64 float4 apart.  Tile slot + D is requested while
+  // tile slot is consumed; past the last subtile of the workgroup the request falls into the neighbouring region of the
+  // cache (or its trailing pad): harmless, and it keeps every address a constant offset from the subtile's base.
+  const float4v *wp = cache + ((size_t)(g0 * 4 + wave) * 16) * R * 64 + lane;
+  constexpr size_t SUB = (size_t)4 * NT * 64;
+  float4v ring[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) ring[d] = __builtin_nontemporal_load(wp + (size_t)d * 64);
+  for (int c0 = c_begin; c0 < c_end; c0 += 64, wp += SUB) {
+    __syncthreads();
+    for (int e = tid; e < 64 * 16; e += 256) {
+      const int c = e >> 4, t = e & 15;
+      const int col = c0 + c;
+      sV[c * SVS + t] = (col < c_end && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+    }
+    __syncthreads();
+    float acol[4][4];                               // A operands of the row product: V[c0 + 16 ct + 4 kap + i][t = tn]
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acol[ct][i] = sV[(16 * ct + 4 * kap + i) * SVS + tn];
+    const bool doT = (c0 >= r0 + BR);
+    floatx4m accT[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) accT[ct] = floatx4m{0.f, 0.f, 0.f, 0.f};
+    // Tiles are consumed in pairs A = (rt, p), B = (rt + 1, (p + 1) % 4) — the order the build stores them in — so that
+    // the chains that share an accumulator are never adjacent: the transposes and row products of A and B alternate
+    // (four different accumulators), then the two transposed products alternate; the transposed tile has three MFMAs
+    // between its last write and its first use as a B operand.
+    if (doT) {
+      symk_tile_rows<R, true, 0>(wp, ring, acol, arow, bid, accR, accT);
+    } else {
+      symk_tile_rows<R, false, 0>(wp, ring, acol, arow, bid, accR, accT);
+    }
+    // accT[ct]: lane holds D'[t = 4 kap + r][gamma = tn] of column tile ct
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sT[(wave * 64 + 16 * ct + tn) * 16 + 4 * kap + r] = accT[ct][r];
+    __syncthreads();
+    if (doT) {
+      for (int e = tid; e < 64 * 16; e += 256) {
+        const int c = e >> 4, t = e & 15;
+        const int col = c0 + c;
+        if (col < c_end && t < tcnt) {
+          const float sum = sT[(0 * 64 + c) * 16 + t] + sT[(1 * 64 + c) * 16 + t] + sT[(2 * 64 + c) * 16 + t] +
+                            sT[(3 * 64 + c) * 16 + t];
+          slabT[((size_t)(rb - rb_first) * N + col) * ldv + t0 + t] = sum;
+        }
+      }
+    }
+  }
+  // accR[rt]: lane holds D[t = 4 kap + r][rho = tn] of row tile rt
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    const int row = rw0 + 16 * rt + tn;
+    if (row < N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 4 * kap + r;
+        if (t < tcnt) slabR[((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0 + t] = accR[rt][r];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dense block: out[m][n] = scale * sum_j exp(-0.5 (Z1[m,j]-Z2[n,j])^2).  One thread per output column
 // (coalesced stores), RT rows per workgroup held in LDS.
@@ -3314,7 +3534,8 @@ inline SymkPlan symk_plan(int64_t N, int world, int rank) {
   sp.sub1 = symk_wg_subtile(sp.p, N, sp.p.w1);
   return sp;
 }
-inline size_t symk_bytes(const SymkPlan &sp) { return (size_t)(sp.sub1 - sp.sub0) * sp.p.BR * 64 * sizeof(float); }
+// (+ one subtile of padding: the wide product's requests run a few tiles past a workgroup's last subtile)
+inline size_t symk_bytes(const SymkPlan &sp) { return (size_t)(sp.sub1 - sp.sub0 + 1) * sp.p.BR * 64 * sizeof(float); }
 inline int symk_t_piece(int remaining) {
   if (remaining > 4) return 12;                        // (an exact T = 11 instantiation measured slower than the padded 12)
   if (remaining > 1) return 4;
@@ -3330,6 +3551,29 @@ int symk_launch_build(const SymkPlan &sp, const float *Z, float4v *cache, int N,
   else
     hipLaunchKernelGGL((symk_build_kernel<JT, 1>), grid, block, 0, st, Z, cache, N, ldz, j0, sp.p.chunk_cols, g_rotdir,
                        accumulate, sp.p.w0, sp.sub0);
+  return launch_status();
+}
+template <int JT>
+int symk_launch_build_tile(const SymkPlan &sp, const float *Z, float4v *cache, int N, int ldz, int j0, int accumulate,
+                           hipStream_t st) {
+  dim3 grid(sp.p.w1 - sp.p.w0), block(256);
+  if (sp.p.R == 2)
+    hipLaunchKernelGGL((symk_build_tile_kernel<JT, 2>), grid, block, 0, st, Z, cache, N, ldz, j0, sp.p.chunk_cols,
+                       accumulate, sp.p.w0, sp.sub0);
+  else
+    hipLaunchKernelGGL((symk_build_tile_kernel<JT, 1>), grid, block, 0, st, Z, cache, N, ldz, j0, sp.p.chunk_cols,
+                       accumulate, sp.p.w0, sp.sub0);
+  return launch_status();
+}
+inline int symk_launch_mvm_tile(const SymkPlan &sp, const float4v *cache, const float *V, float *slabR, float *slabT,
+                                int N, int T, int t0, int tcnt, hipStream_t st) {
+  dim3 grid(sp.p.w1 - sp.p.w0), block(256);
+  if (sp.p.R == 2)
+    hipLaunchKernelGGL((symk_mvm_tile_kernel<2>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
+                       sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
+  else
+    hipLaunchKernelGGL((symk_mvm_tile_kernel<1>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
+                       sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
   return launch_status();
 }
 template <int TT>
@@ -3929,10 +4173,10 @@ size_t rpgp_symcache_workspace_bytes(int64_t N, int T, int world, int rank) {
   return plan_workspace_floats(symk_plan(N, world, rank).p, N, T, true) * sizeof(float);
 }
 
-int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t N, int ldz, int j0, int j1, int world,
-                        int rank, void *stream) {
+int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t N, int ldz, int j0, int j1, int layout,
+                        int world, int rank, void *stream) {
   if (!Z || !cache || N <= 0 || N > 0x7fffffffLL || j0 < 0 || j1 <= j0 || ldz < j1 || world < 1 || rank < 0 ||
-      rank >= world)
+      rank >= world || (layout != RPGP_SYMCACHE_THIN && layout != RPGP_SYMCACHE_WIDE))
     return RPGP_EINVAL;
   const int irc = rpgp_init();
   if (irc) return irc;
@@ -3945,6 +4189,18 @@ int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t
   for (int j = j0; j < j1;) {
     const int jt = next_j_piece(j1 - j);
     int rc = 0;
+    if (layout == RPGP_SYMCACHE_WIDE) {
+      switch (jt) {
+        case 20: rc = symk_launch_build_tile<20>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+        case 10: rc = symk_launch_build_tile<10>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+        case 8: rc = symk_launch_build_tile<8>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+        case 5: rc = symk_launch_build_tile<5>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+        case 4: rc = symk_launch_build_tile<4>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+        case 3: rc = symk_launch_build_tile<3>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+        case 2: rc = symk_launch_build_tile<2>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+        default: rc = symk_launch_build_tile<1>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
+      }
+    } else
     switch (jt) {
       case 20: rc = symk_launch_build<20>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
       case 10: rc = symk_launch_build<10>(sp, Z, c, (int)N, ldz, j, first ? 0 : 1, st); break;
@@ -3962,9 +4218,10 @@ int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t
   return 0;
 }
 
-int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, const float *V, float *out, int64_t N, int T, float scale,
-                      float noise, int world, int rank, void *ws, size_t ws_bytes, void *stream) {
-  if (!cache || !V || !out || N <= 0 || N > 0x7fffffffLL || T <= 0 || world < 1 || rank < 0 || rank >= world)
+int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, int layout, const float *V, float *out, int64_t N, int T,
+                      float scale, float noise, int world, int rank, void *ws, size_t ws_bytes, void *stream) {
+  if (!cache || !V || !out || N <= 0 || N > 0x7fffffffLL || T <= 0 || world < 1 || rank < 0 || rank >= world ||
+      (layout != RPGP_SYMCACHE_THIN && layout != RPGP_SYMCACHE_WIDE))
     return RPGP_EINVAL;
   const int irc = rpgp_init();
   if (irc) return irc;
@@ -3978,7 +4235,12 @@ int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, const float *V, flo
   float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
   if (p.partial && need) RPGP_CHECK(hipMemsetAsync(ws, 0, need, st));   // row blocks shared with a neighbour rank
   const float4v *c = reinterpret_cast<const float4v *>(cache);
-  for (int t0 = 0; t0 < T && p.w1 > p.w0;) {
+  for (int t0 = 0; layout == RPGP_SYMCACHE_WIDE && t0 < T && p.w1 > p.w0; t0 += 16) {
+    const int tcnt = (T - t0 < 16) ? T - t0 : 16;
+    const int rc = symk_launch_mvm_tile(sp, c, V, slabR, slabT, (int)N, T, t0, tcnt, st);
+    if (rc) return rc;
+  }
+  for (int t0 = 0; layout == RPGP_SYMCACHE_THIN && t0 < T && p.w1 > p.w0;) {
     const int tt = symk_t_piece(T - t0);
     const int tcnt = (T - t0 < tt) ? T - t0 : tt;
     int rc = 0;

@@ -102,7 +102,8 @@ class InvQuadLogDet(torch.autograd.Function):
             # iteration on the T = 11 block is one HBM-bound pass over stored values; the backward pass stays fused.
             # Preferred form: the packed symmetric cache (every unordered pair once, half the bytes and half the build);
             # otherwise the dense matrix (rpgp_dense).
-            cache = op.to_symcache() if hasattr(op, "to_symcache") and settings.use_cached_kernel(N, Z.device, 2.0) else None
+            cache = op.to_symcache(wide=full_rhs.shape[1] > 4) if hasattr(op, "to_symcache") and \
+                settings.use_cached_kernel(N, Z.device, 2.0) else None
             if cache is not None:
                 native_op = SymCachedOperator(cache, op._scale, float(noise.detach()),
                                               diag_value=op._scale * op.num_projections)

@@ -220,13 +220,14 @@ class AdditiveRPOperator(LinearOperator):
             return be.dense(self.Z1.detach(), self.Z1.detach(), self._scale, pad=True)
         return self.to_dense()
 
-    def to_symcache(self):
+    def to_symcache(self, wide=False):
         """Packed symmetric cache of this operator (every unordered pair once: half the bytes of to_dense_cached()), or
-        None when the backend / operator cannot provide one (then the dense matrix is the cached-K form)."""
+        None when the backend / operator cannot provide one (then the dense matrix is the cached-K form).  `wide`: the
+        matrix-core tile layout for blocks of 5..16 right-hand sides (training), else the rotation order (thin solves)."""
         be = _backend.get_backend()
         if type(self) is AdditiveRPOperator and self.symmetric and self.Z1.dtype == torch.float32 and \
                 getattr(be, "supports_symcache", False) and (self.shard is None or self.shard.world_size == 1):
-            return be.symcache(self.Z1.detach())
+            return be.symcache(self.Z1.detach(), wide=wide)
         return None
 
     def representation(self):

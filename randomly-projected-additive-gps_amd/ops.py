@@ -344,9 +344,11 @@ class SymCache:
     """Packed symmetric cache of the additive kernel on Z (rpgp_symcache_build): every unordered pair once, in the order
     the symmetric sweep consumes it — half the bytes of the dense N x N matrix.  `shard` = (world, rank) keeps only
     this rank's share of the pairs (the product is then a partial result, summed by one all-reduce like the pair-sharded
-    fused MVM).  Values are unscaled (sum over the projections); `scale` and `noise` are applied by the product."""
+    fused MVM).  Values are unscaled (sum over the projections); `scale` and `noise` are applied by the product.
+    `wide`: False = rotation order (blocks of 1..4 right-hand sides stream at the HBM rate), True = 16 x 16 matrix-core
+    tiles (blocks of up to 16 right-hand sides per pass: the training block)."""
 
-    def __init__(self, Z, j0=0, j1=None, shard=None):
+    def __init__(self, Z, j0=0, j1=None, shard=None, wide=False):
         lib = _lib.load()
         Z = _require(Z, "Z", 2)
         self.N, J = Z.shape
@@ -355,9 +357,10 @@ class SymCache:
         nbytes = lib.rpgp_symcache_bytes(self.N, self.world, self.rank)
         self.buf = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=Z.device)
         self.nbytes = nbytes
+        self.layout = _lib.RPGP_SYMCACHE_WIDE if wide else _lib.RPGP_SYMCACHE_THIN
         with torch.cuda.device(Z.device):
             _lib.check(lib.rpgp_symcache_build(Z.data_ptr(), self.buf.data_ptr(), nbytes, self.N, Z.stride(0), j0, j1,
-                                               self.world, self.rank, _stream()), "rpgp_symcache_build")
+                                               self.layout, self.world, self.rank, _stream()), "rpgp_symcache_build")
 
     @property
     def device(self):
@@ -372,7 +375,7 @@ def symcache_mvm(cache, V, scale, noise=0.0):
     out = torch.empty_like(V2)
     with torch.cuda.device(cache.device):
         ws = _workspace(cache.device, lib.rpgp_symcache_workspace_bytes(cache.N, T, cache.world, cache.rank))
-        _lib.check(lib.rpgp_symcache_mvm(cache.buf.data_ptr(), cache.nbytes, V2.data_ptr(), out.data_ptr(), cache.N, T,
+        _lib.check(lib.rpgp_symcache_mvm(cache.buf.data_ptr(), cache.nbytes, cache.layout, V2.data_ptr(), out.data_ptr(), cache.N, T,
                                          float(scale), float(noise), cache.world, cache.rank, ws.data_ptr(), ws.numel(),
                                          _stream()), "rpgp_symcache_mvm")
     return out.squeeze(1) if squeeze else out
@@ -722,8 +725,8 @@ def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=
     d.Kd = Kd.data_ptr() if Kd is not None else None
     d.ldk = Kd.stride(0) if Kd is not None else 0
     d.family = ctypes.addressof(family.struct) if family is not None else None
-    if symcache is not None:                       # RPGP_OP_SYMCACHE: the cache travels in (Kd, ldk = bytes)
-        d.Kd, d.ldk = symcache.buf.data_ptr(), symcache.nbytes
+    if symcache is not None:                       # RPGP_OP_SYMCACHE: the cache travels in (Kd, ldk = bytes, G = layout)
+        d.Kd, d.ldk, d.G = symcache.buf.data_ptr(), symcache.nbytes, symcache.layout
     return d, (Z, prep, gp, Kd, family, symcache)
 
 

@@ -157,17 +157,19 @@ def test_dense_mvm_padded_rows_ragged_edge(gpu_device, N, T):
     assert _rel(out2.cpu().numpy(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("N,J,T", [(300, 5, 1), (1000, 20, 11), (4097, 20, 12), (5000, 23, 3), (2049, 3, 25),
-                                   (6211, 8, 5)])
-def test_symcache_product_matches_oracle(gpu_device, N, J, T):
+                                   (6211, 8, 5), (4500, 20, 16), (777, 2, 37)])
+def test_symcache_product_matches_oracle(gpu_device, N, J, T, wide):
     """Packed symmetric cache (rpgp_symcache_build / _mvm): every unordered pair stored once, the product equals the
-    float64 oracle's K V (one- and two-row-per-lane plans, ragged edges, J split into compiled pieces, T into passes)."""
+    float64 oracle's K V (one- and two-row-per-lane plans, ragged edges, J split into compiled pieces, T into passes),
+    in both layouts: rotation order (VALU sweep) and 16 x 16 matrix-core tiles (exact-fp32 MFMA, in-register transpose)."""
     from rpgp_amd import ops
     rng = np.random.default_rng(N + J + T)
     Z = rng.standard_normal((N, J)).astype(np.float32)
     V = rng.standard_normal((N, T)).astype(np.float32)
     Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
-    cache = ops.SymCache(Zt)
+    cache = ops.SymCache(Zt, wide=wide)
     assert cache.nbytes < 0.75 * 4 * N * N + (1 << 22)            # about half of the dense matrix (plus block padding)
     out = ops.symcache_mvm(cache, Vt, 0.2, 0.3)
     ref = orc.mvm(Z, Z, V, 0.2, 0.3)
@@ -177,25 +179,26 @@ def test_symcache_product_matches_oracle(gpu_device, N, J, T):
     assert _rel(out.cpu().numpy(), fused.cpu().numpy()) < 2e-6
     # a column range of the projections
     if J >= 5:
-        part = ops.symcache_mvm(ops.SymCache(Zt, j0=1, j1=J - 1), Vt, 0.2, 0.0)
+        part = ops.symcache_mvm(ops.SymCache(Zt, j0=1, j1=J - 1, wide=wide), Vt, 0.2, 0.0)
         assert _rel(part.cpu().numpy(), orc.mvm(Z[:, 1:J - 1], Z[:, 1:J - 1], V, 0.2, 0.0)) < 2e-6
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("N,world", [(3000, 2), (9000, 3)])
-def test_symcache_pair_shards_sum_to_whole(gpu_device, N, world):
+def test_symcache_pair_shards_sum_to_whole(gpu_device, N, world, wide):
     from rpgp_amd import ops
     rng = np.random.default_rng(N)
     Zt = torch.from_numpy(rng.standard_normal((N, 20)).astype(np.float32)).to(gpu_device)
     Vt = torch.from_numpy(rng.standard_normal((N, 11)).astype(np.float32)).to(gpu_device)
-    whole = ops.symcache_mvm(ops.SymCache(Zt), Vt, 0.05, 0.1)
+    whole = ops.symcache_mvm(ops.SymCache(Zt, wide=wide), Vt, 0.05, 0.1)
     total, nbytes = None, 0
     for r in range(world):
-        c = ops.SymCache(Zt, shard=(world, r))
+        c = ops.SymCache(Zt, shard=(world, r), wide=wide)
         nbytes += c.nbytes
         o = ops.symcache_mvm(c, Vt, 0.05, 0.1 if r == 0 else 0.0)
         total = o if total is None else total + o
     assert float((total - whole).norm() / whole.norm()) < 1e-6
-    assert nbytes == ops.SymCache(Zt).nbytes                      # the shards partition the cache
+    assert nbytes >= ops.SymCache(Zt).nbytes                      # the shards cover the cache (each carries its own pad)
 
 
 def test_symcache_rejects_mismatched_arguments(gpu_device):
@@ -208,8 +211,10 @@ def test_symcache_rejects_mismatched_arguments(gpu_device):
     out = torch.empty(2000, 1, device=gpu_device)
     V = torch.zeros(2000, 1, device=gpu_device)
     # a cache that is too small for the problem is refused, as is a missing workspace
-    assert lib.rpgp_symcache_mvm(cache.buf.data_ptr(), cache.nbytes // 2, V.data_ptr(), out.data_ptr(), 2000, 1, 1.0, 0.0,
+    assert lib.rpgp_symcache_mvm(cache.buf.data_ptr(), cache.nbytes // 2, 0, V.data_ptr(), out.data_ptr(), 2000, 1, 1.0, 0.0,
                                  1, 0, None, 0, None) != 0
+    assert lib.rpgp_symcache_mvm(cache.buf.data_ptr(), cache.nbytes, 7, V.data_ptr(), out.data_ptr(), 2000, 1, 1.0, 0.0,
+                                 1, 0, None, 0, None) != 0          # unknown layout
     assert lib.rpgp_symcache_bytes(2000, 2, 2) == 0
 
 

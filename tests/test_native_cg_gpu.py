@@ -133,7 +133,8 @@ def test_native_cached_k_operator(gpu_device):
     assert float(resid.max()) < 1e-3
 
 
-def test_native_symcache_operator(gpu_device):
+@pytest.mark.parametrize("wide", [False, True])
+def test_native_symcache_operator(gpu_device, wide):
     """RPGP_OP_SYMCACHE (packed symmetric cache inside the native executor) solves the same system as the fused
     operator, and the operator's dense form / diagonal agree with the fused operator's."""
     from rpgp_amd import linear_cg as lcg
@@ -141,7 +142,7 @@ def test_native_symcache_operator(gpu_device):
     from rpgp_amd.precond import WoodburyPreconditioner
     from rpgp_amd import ops
     base, khat = _ops_pair(gpu_device, 4200, 20, 0.3, seed=11)
-    sym = SymCachedOperator(base.to_symcache(), base._scale, 0.3, diag_value=base._scale * base.num_projections)
+    sym = SymCachedOperator(base.to_symcache(wide=wide), base._scale, 0.3, diag_value=base._scale * base.num_projections)
     rhs = torch.randn(4200, 11, generator=torch.Generator().manual_seed(1)).to(gpu_device)
     pre = WoodburyPreconditioner(ops.pivoted_cholesky(base.Z1, base._scale, 15), 0.3)
     before = lcg.stats.get("native_calls", 0)
@@ -153,7 +154,8 @@ def test_native_symcache_operator(gpu_device):
     assert float(resid.max()) < 1e-3
     assert torch.allclose(ts, tf, rtol=1e-2, atol=1e-3)
     small, _ = _ops_pair(gpu_device, 700, 6, 0.3, seed=3)
-    sym_small = SymCachedOperator(small.to_symcache(), small._scale, 0.3, diag_value=small._scale * small.num_projections)
+    sym_small = SymCachedOperator(small.to_symcache(wide=wide), small._scale, 0.3,
+                                  diag_value=small._scale * small.num_projections)
     ref = small.to_dense()
     ref.diagonal().add_(0.3)
     assert float((sym_small.to_dense() - ref).abs().max()) < 1e-5

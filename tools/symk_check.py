@@ -17,9 +17,10 @@ sizes = [int(a) for a in sys.argv[1:]] or [1000, 4097, 7372, 14939, 30000, 50000
 for N in sizes:
     Z = torch.randn(N, J, generator=torch.Generator().manual_seed(0)).to(dev)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    C = ops.SymCache(Z); torch.cuda.synchronize(); tb1 = time.perf_counter() - t0
-    tb = timeit(lambda: ops.SymCache(Z), 3)
-    for T in (1, 4, 11, 12, 16):
+    WIDE = os.environ.get("SYMK_WIDE", "0") == "1"
+    C = ops.SymCache(Z, wide=WIDE); torch.cuda.synchronize(); tb1 = time.perf_counter() - t0
+    tb = timeit(lambda: ops.SymCache(Z, wide=WIDE), 3)
+    for T in (1, 4, 11, 12, 16, 20):
         V = torch.randn(N, T, generator=torch.Generator().manual_seed(T)).to(dev)
         ref = ops.mvm_sym(Z.double(), V.double(), 1.0 / J, 0.1) if N <= 8000 else ops.mvm_sym(Z, V, 1.0 / J, 0.1).double()
         out = ops.symcache_mvm(C, V, 1.0 / J, 0.1)
@@ -34,7 +35,7 @@ for N in sizes:
         whole = ops.symcache_mvm(C, V, 1.0 / J, 0.1)
         parts = None
         for r in range(3):
-            Cr = ops.SymCache(Z, shard=(3, r))
+            Cr = ops.SymCache(Z, shard=(3, r), wide=WIDE)
             o = ops.symcache_mvm(Cr, V, 1.0 / J, 0.1 if r == 0 else 0.0)
             parts = o if parts is None else parts + o
         print("   3-way pair shards: rel diff %.2e" % float((parts - whole).norm() / whole.norm()))

@@ -1006,11 +1006,13 @@ __global__ __launch_bounds__(256) void symk_mvm_kernel(const float4v *__restrict
 // Same subtiles, same size; inside a wave's 16 R KB the values are stored as 16 x 16 tiles in the A/B operand order of
 // v_mfma_f32_16x16x4_f32:  [wave][slot(rt 0..4R-1, ct 0..3)][lane]  float4 = K[row0 + 16 rt + (l % 16)][csub + 16 ct + 4 (l / 16) + i]
 // (slots in the pair order the product consumes: (2m, p), (2m + 1, (p + 1) % 4), p = 0..3).
-// One tile feeds three groups of four exact-fp32 MFMAs:
+// One tile feeds two groups of four exact-fp32 MFMAs:
 //   row product        D[t][rho]   += sum_i  A = V[csub + 16 ct + 4k + i][t]   x  B = tile_i             (contracts the columns)
-//   in-register transpose  L2      =  sum_i  A = tile_i  x  B = identity slice i   (x * 1.0 + 0: exact)  -> D layout:
-//                                     lane holds K[16 rt + 4 (l/16) + r][16 ct + l % 16], r = 0..3
 //   transposed product D'[t][gam]  += sum_j  A = V[row0 + 16 rt + 4k + j][t]   x  B = L2_j               (contracts the rows)
+// where L2_j[lane] = K[16 rt + 4 (l/16) + j][16 ct + l % 16] is the tile transposed through a per-wave LDS scratch (one
+// 16-byte store, four 4-byte loads per lane, conflict-free at row stride 20; a wave's DS operations execute in order, so no
+// barrier).  (First version: transposed in registers by four more MFMAs against identity slices — exact, but 12 instead
+// of 8 matrix-pipe issues per tile: 1.14 ms against 1.00 ms for the T = 11 block at N = 50k.)
 // The rotating accumulators of the thin layout cost T DPP moves per 64 pairs; here the transposed sums of a column tile
 // stay in one accumulator across the wave's 4 R row tiles.
 template <int JT, int R>
@@ -1073,7 +1075,7 @@ __global__ __launch_bounds__(256) void symk_build_tile_kernel(const float *__res
 // v_mov per subtile).
 template <int R, bool DOT, int RT2>
 __device__ __forceinline__ void symk_tile_rows(const float4v *wp, float4v (&ring)[8], const float (&acol)[4][4],
-                                               const float (&arow)[4 * R][4], const float (&bid)[4],
+                                               const float (&arow)[4 * R][4], float *scr, int woff, int roff,
                                                floatx4m (&accR)[4 * R], floatx4m (&accT)[4]) {
   constexpr int NRT = 4 * R, NT = 4 * NRT, D = 8;
   constexpr size_t SUB = (size_t)4 * NT * 64;
@@ -1089,12 +1091,20 @@ __device__ __forceinline__ void symk_tile_rows(const float4v *wp, float4v (&ring
       }
       __builtin_amdgcn_sched_barrier(0);       // keep the requests D tiles ahead (hipcc sinks them to their first use)
       if constexpr (DOT) {
-        floatx4m lA = {0.f, 0.f, 0.f, 0.f}, lB = {0.f, 0.f, 0.f, 0.f};
+        // transpose of the two tiles through the wave's LDS scratch: row-major 16 x 20 (16-byte stores and the 4-byte
+        // loads below are conflict-free at that stride); a wave's DS operations execute in order, so neither a barrier nor
+        // a second buffer is needed; the eight row-product MFMAs cover the round trip
+        *reinterpret_cast<float4v *>(scr + woff) = kA;
+        *reinterpret_cast<float4v *>(scr + 320 + woff) = kB;
+        floatx4m lA, lB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lA[j] = scr[roff + 20 * j];
+          lB[j] = scr[320 + roff + 20 * j];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          lA = __builtin_amdgcn_mfma_f32_16x16x4f32(kA[i], bid[i], lA, 0, 0, 0);
           accR[rtA] = __builtin_amdgcn_mfma_f32_16x16x4f32(acol[ctA][i], kA[i], accR[rtA], 0, 0, 0);
-          lB = __builtin_amdgcn_mfma_f32_16x16x4f32(kB[i], bid[i], lB, 0, 0, 0);
           accR[rtB] = __builtin_amdgcn_mfma_f32_16x16x4f32(acol[ctB][i], kB[i], accR[rtB], 0, 0, 0);
         }
 #pragma unroll
@@ -1110,7 +1120,7 @@ __device__ __forceinline__ void symk_tile_rows(const float4v *wp, float4v (&ring
         }
       }
     }
-    symk_tile_rows<R, DOT, RT2 + 1>(wp, ring, acol, arow, bid, accR, accT);
+    symk_tile_rows<R, DOT, RT2 + 1>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
   }
 }
 
@@ -1126,6 +1136,7 @@ __global__ __launch_bounds__(256, 2) void symk_mvm_tile_kernel(const float4v *__
   constexpr int SVS = 17;                           // LDS row stride of the staged right-hand sides
   __shared__ __attribute__((aligned(16))) float sV[64 * SVS];
   __shared__ __attribute__((aligned(16))) float sT[4 * 64 * 16];
+  __shared__ __attribute__((aligned(16))) float sX[4 * 640];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tn = lane & 15, kap = lane >> 4;        // l % 16 (t for A operands, rho / gamma for B and D), l / 16
   int rb, kchunk;
@@ -1146,9 +1157,9 @@ __global__ __launch_bounds__(256, 2) void symk_mvm_tile_kernel(const float4v *__
       const int row = rw0 + 16 * rt + 4 * kap + j;
       arow[rt][j] = (row < N && tn < tcnt) ? V[(size_t)row * ldv + t0 + tn] : 0.f;
     }
-  float bid[4];                                     // identity slices: B_i[k][n] = (n == 4 k + i)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) bid[i] = (tn == 4 * kap + i) ? 1.0f : 0.0f;
+  float *scr = sX + wave * 640;                     // this wave's transpose scratch: two 16 x 20 tiles
+  const int woff = tn * 20 + 4 * kap;               // layout 1 in:  K[rho = tn][4 kap .. 4 kap + 3]
+  const int roff = 4 * kap * 20 + tn;               // layout 2 out: K[4 kap + j][gamma = tn], j = 0..3 (stride 20)
   floatx4m accR[NRT];
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) accR[rt] = floatx4m{0.f, 0.f, 0.f, 0.f};
@@ -1182,13 +1193,11 @@ __global__ __launch_bounds__(256, 2) void symk_mvm_tile_kernel(const float4v *__
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) accT[ct] = floatx4m{0.f, 0.f, 0.f, 0.f};
     // Tiles are consumed in pairs A = (rt, p), B = (rt + 1, (p + 1) % 4) — the order the build stores them in — so that
-    // the chains that share an accumulator are never adjacent: the transposes and row products of A and B alternate
-    // (four different accumulators), then the two transposed products alternate; the transposed tile has three MFMAs
-    // between its last write and its first use as a B operand.
+    // consecutive MFMAs never share an accumulator: the row products of A and B alternate, then the two transposed products.
     if (doT) {
-      symk_tile_rows<R, true, 0>(wp, ring, acol, arow, bid, accR, accT);
+      symk_tile_rows<R, true, 0>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
     } else {
-      symk_tile_rows<R, false, 0>(wp, ring, acol, arow, bid, accR, accT);
+      symk_tile_rows<R, false, 0>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
     }
     // accT[ct]: lane holds D'[t = 4 kap + r][gamma = tn] of column tile ct
 #pragma unroll

@@ -96,19 +96,22 @@ class InvQuadLogDet(torch.autograd.Function):
         full_rhs = torch.cat([probes_n, r], dim=1)
         matmul = khat._matmul
         native_op = khat
-        if not isinstance(op, SKIAdditiveOperator) and (op.shard is None or op.shard.world_size == 1) and \
-                Z.dtype == torch.float32:
+        sharded = op.shard is not None and op.shard.world_size > 1
+        if not isinstance(op, SKIAdditiveOperator) and Z.dtype == torch.float32:
             # cached-K mode: evaluate the kernel once per hyper-parameter step so each CG
             # iteration on the T = 11 block is one HBM-bound pass over stored values; the backward pass stays fused.
             # Preferred form: the packed symmetric cache (every unordered pair once, half the bytes and half the build);
             # otherwise the dense matrix (rpgp_dense).
+            # Multi-GPU (pair-sharding): every rank caches its own 1/world of the pairs and the partial products are
+            # summed by the same single all-reduce per MVM as the fused sharded sweep.
+            per_rank = 2.0 / (op.shard.world_size if sharded else 1)
             cache = op.to_symcache(wide=full_rhs.shape[1] > 4) if hasattr(op, "to_symcache") and \
-                settings.use_cached_kernel(N, Z.device, 2.0) else None
+                settings.use_cached_kernel(N, Z.device, per_rank) else None
             if cache is not None:
                 native_op = SymCachedOperator(cache, op._scale, float(noise.detach()),
-                                              diag_value=op._scale * op.num_projections)
+                                              diag_value=op._scale * op.num_projections, shard=op.shard if sharded else None)
                 matmul = native_op._matmul
-            elif settings.use_cached_kernel(N, Z.device):
+            elif not sharded and settings.use_cached_kernel(N, Z.device):
                 native_op = DenseOperator(op.to_dense_cached(), float(noise.detach()))
                 matmul = native_op._matmul
         solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes, operator=native_op,

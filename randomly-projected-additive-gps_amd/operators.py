@@ -225,10 +225,15 @@ class AdditiveRPOperator(LinearOperator):
         None when the backend / operator cannot provide one (then the dense matrix is the cached-K form).  `wide`: the
         matrix-core tile layout for blocks of 5..16 right-hand sides (training), else the rotation order (thin solves)."""
         be = _backend.get_backend()
-        if type(self) is AdditiveRPOperator and self.symmetric and self.Z1.dtype == torch.float32 and \
-                getattr(be, "supports_symcache", False) and (self.shard is None or self.shard.world_size == 1):
+        if type(self) is not AdditiveRPOperator or not self.symmetric or self.Z1.dtype != torch.float32 or \
+                not getattr(be, "supports_symcache", False):
+            return None
+        if self.shard is None or self.shard.world_size == 1:
             return be.symcache(self.Z1.detach(), wide=wide)
-        return None
+        ps = self.shard.pair_shard(be)          # multi-GPU: this rank's share of the pairs (pair-sharding only)
+        if ps is None:
+            return None
+        return be.symcache(self.Z1.detach(), shard=ps, wide=wide)
 
     def representation(self):
         if self.symmetric:
@@ -669,11 +674,12 @@ class SymCachedOperator(LinearOperator):
     over N^2 / 2 stored kernel values per block of up to 12 right-hand sides.  `diag_value` = scale * (number of
     projections), the constant diagonal of the additive RBF kernel."""
 
-    def __init__(self, cache, scale, noise=0.0, diag_value=None):
+    def __init__(self, cache, scale, noise=0.0, diag_value=None, shard=None):
         self.cache = cache
         self._scale = float(scale)
         self._noise = float(noise)
         self._diag_value = diag_value
+        self.shard = shard if (shard is not None and shard.world_size > 1) else None   # cache = this rank's pair share
 
     def _size(self):
         return torch.Size((self.cache.N, self.cache.N))
@@ -687,11 +693,16 @@ class SymCachedOperator(LinearOperator):
         return self.cache.device
 
     def _matmul(self, rhs):
-        return _backend.get_backend().symcache_mvm(self.cache, rhs.detach(), self._scale, self._noise)
+        be = _backend.get_backend()
+        if self.shard is None:
+            return be.symcache_mvm(self.cache, rhs.detach(), self._scale, self._noise)
+        # one all-reduce of the N x T partial products per MVM, the noise term added by rank 0's slab reduce only
+        return self.shard.sharded_mvm(lambda j0, j1, nz: be.symcache_mvm(self.cache, rhs.detach(), self._scale, nz), rhs,
+                                      self._noise)
 
     def native_descriptor(self):
         be = _backend.get_backend()
-        if not hasattr(be, "mbcg_solve") or self.cache.world != 1:
+        if not hasattr(be, "mbcg_solve") or self.cache.world != 1 or self.shard is not None:
             return None
         from . import _lib
         return be.make_operator_desc(_lib.RPGP_OP_SYMCACHE, self.cache.N, 0, self._scale, self._noise, symcache=self.cache)

@@ -69,7 +69,8 @@ deterministic_probes = _setting("deterministic_probes", False, flag=True)   # fi
 # sweep, which recomputes N^2 J / 2 exponentials per iteration).  "auto" (default): cache whenever the stored form fits in
 # `cache_kernel_fraction` of the device memory and N >= `cache_kernel_min_size` — the packed symmetric cache needs 2 N^2
 # bytes (288 GB HBM3E: N <= ~190k), the dense matrix of the wide prediction solves 4 N^2 (N <= ~134k); True / False
-# force it on (when it fits) / off.  Sharded (multi-GPU), SKI and float64 operators never cache.
+# force it on (when it fits) / off.  Pair-sharded multi-GPU operators cache their own 1/world of the pairs (2 N^2 / world
+# bytes per rank); J-sharded, SKI and float64 operators never cache.
 cache_kernel = _setting("cache_kernel", "auto")
 cache_kernel_fraction = _setting("cache_kernel_fraction", 0.25)
 cache_kernel_min_size = _setting("cache_kernel_min_size", 4096)
@@ -84,7 +85,7 @@ def use_cached_kernel(N, device, bytes_per_entry=4.0):
         return False
     dev = torch.device(device)
     if dev.type != "cuda":
-        return False
+        return mode is True            # (host tensors only occur under the CPU test double: honour an explicit request)
     fits = bytes_per_entry * N * N <= cache_kernel_fraction.value() * torch.cuda.get_device_properties(dev).total_memory
     if mode is True or mode == 1:
         return fits

@@ -50,6 +50,32 @@ class OracleBackend:
             r = _t(orc.mvm(z, z, v, scale, noise), V)
         return r.squeeze(1) if squeeze else r
 
+    # packed symmetric cache emulation: the (masked, for a pair shard) unscaled kernel matrix kept dense
+    supports_symcache = True
+
+    class _SymCache:
+        pass
+
+    def symcache(self, Z, j0=0, j1=None, shard=None, wide=False):
+        self.calls["symcache"] = self.calls.get("symcache", 0) + 1
+        z = _np(Z)[:, j0:j1]
+        c = OracleBackend._SymCache()
+        c.N = z.shape[0]
+        c.world, c.rank = (1, 0) if shard is None else (int(shard[0]), int(shard[1]))
+        K = orc.additive_rbf(z, z)
+        if c.world > 1:
+            t = np.arange(c.N) // 8
+            K = K * (((t[:, None] + t[None, :]) % c.world) == c.rank)
+        c.K, c.wide, c.nbytes, c.device = K, bool(wide), K.size * 2, Z.device
+        return c
+
+    def symcache_mvm(self, cache, V, scale, noise=0.0):
+        self.calls["symcache_mvm"] = self.calls.get("symcache_mvm", 0) + 1
+        squeeze = V.dim() == 1
+        v = _np(V).reshape(cache.N, -1)
+        r = _t(scale * (cache.K @ v) + noise * v, V)
+        return r.squeeze(1) if squeeze else r
+
     def mvm_rect(self, Z1, Z2, V, scale, j0=0, j1=None):
         self.calls["mvm_rect"] += 1
         squeeze = V.dim() == 1

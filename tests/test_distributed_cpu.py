@@ -70,6 +70,19 @@ def _worker(rank, world, port, tmpdir):
         gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(gathered, torch.tensor([vals[1][0]], dtype=torch.float64))
         assert all(abs(float(g) - vals[1][0]) < 1e-12 for g in gathered), "ranks disagree"
+        # cached-K mode under pair-sharding: every rank caches its own share of the pairs (packed symmetric cache), the
+        # partial products meet in the same one all-reduce per MVM; same MLL and gradient as the unsharded fused solve
+        model, lik, mll = _build_model(X, y, P, ls, noise, sc)
+        model.covar_module.shard = JShard(5)
+        model.train()
+        n_sc = ob.calls.get("symcache_mvm", 0)
+        with settings.max_cholesky_size(0), settings.cg_tolerance(1e-7), settings.deterministic_probes(True), \
+                settings.cache_kernel(True):
+            v = mll(model(X), y)
+            v.backward()
+        assert ob.calls.get("symcache_mvm", 0) > n_sc, "the sharded cached operator was not used"
+        assert abs(v.item() - vals[0][0]) < 1e-5 * abs(vals[0][0])
+        assert torch.allclose(model.covar_module.base_kernel.raw_lengthscale.grad, vals[0][1], rtol=1e-3, atol=1e-6)
         # train_exact_gp under a process group: per-rank random draws (projections, init) are overwritten by rank 0's
         # broadcast AFTER the move to the output device, the kernel gets a JShard, every rank ends with the same fit
         from rpgp_amd import training

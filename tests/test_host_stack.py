@@ -440,6 +440,35 @@ def test_full_kernel_types_match_dense_formulas(kernel_type):
         create_exact_gp(X, y, "full", noise_prior=False, kernel_type="bogus")
 
 
+def test_cached_modes_match_fused_solve(oracle_backend):
+    """settings.cache_kernel(True): training goes through SymCachedOperator (packed symmetric cache), prediction through
+    the thin cache + the dense matrix for the wide covariance solve; same MLL, gradients and predictions as the fused
+    operator."""
+    from rpgp_amd import settings
+    X, y, P, ls, noise, sc = _problem(N=80, d=4, J=5, seed=3)
+    Xs = torch.randn(9, 4, generator=torch.Generator().manual_seed(9))
+    res = []
+    for cached in (False, True):
+        model, lik, mll = _build_model(X, y, P, ls, noise, sc)
+        model.train()
+        n0 = oracle_backend.calls.get("symcache_mvm", 0)
+        with settings.max_cholesky_size(0), settings.cg_tolerance(1e-7), settings.eval_cg_tolerance(1e-7), \
+                settings.deterministic_probes(True), settings.cache_kernel(cached):
+            v = mll(model(X), y)
+            v.backward()
+            g = model.covar_module.base_kernel.raw_lengthscale.grad.clone()
+            model.eval()
+            with torch.no_grad():
+                out = model(Xs)
+                mean, var = out.mean.clone(), out.variance.clone()
+        assert (oracle_backend.calls.get("symcache_mvm", 0) > n0) == cached
+        res.append((v.item(), g, mean, var))
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[0][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-7)
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-4, atol=1e-6)
+    assert torch.allclose(res[0][3], res[1][3], rtol=1e-3, atol=1e-6)
+
+
 def test_woodbury_capacitance_survives_large_kernel_norm():
     """|L^T L| ~ 1e6 with noise 0.3 in float32: the capacitance matrix must be accumulated in float64, or the Woodbury
     formula stops inverting M = L L^T + noise I (round-2 regression at the C5 shape)."""

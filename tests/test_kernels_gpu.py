@@ -159,7 +159,8 @@ def test_dense_mvm_padded_rows_ragged_edge(gpu_device, N, T):
 
 @pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("N,J,T", [(300, 5, 1), (1000, 20, 11), (4097, 20, 12), (5000, 23, 3), (2049, 3, 25),
-                                   (6211, 8, 5), (4500, 20, 16), (777, 2, 37)])
+                                   (6211, 8, 5), (4500, 20, 16), (777, 2, 37), (1, 3, 2), (17, 4, 11), (64, 1, 1),
+                                   (65, 20, 4), (257, 5, 11), (513, 5, 1)])
 def test_symcache_product_matches_oracle(gpu_device, N, J, T, wide):
     """Packed symmetric cache (rpgp_symcache_build / _mvm): every unordered pair stored once, the product equals the
     float64 oracle's K V (one- and two-row-per-lane plans, ragged edges, J split into compiled pieces, T into passes),

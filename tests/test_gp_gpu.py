@@ -168,6 +168,33 @@ def test_full_size_properties_n50k(gpu_device):
     assert float((Kr - Ku[:4096]).norm() / Ku[:4096].norm()) < 1e-5
 
 
+def test_full_size_symcache_n50k(gpu_device):
+    """BASELINE size N=50 000, J=20: the packed symmetric cache (both layouts) reproduces the fused MVM, is symmetric as a
+    bilinear form, linear, and holds about half of the dense matrix's bytes."""
+    from rpgp_amd import ops
+    N, d, J = 50000, 20, 20
+    X = torch.randn(N, d, generator=torch.Generator().manual_seed(0))
+    P = torch.randn(d, J, generator=torch.Generator().manual_seed(1))
+    Z = ops.project(X.to(gpu_device), (P / math.sqrt(d)).to(gpu_device))
+    u = torch.randn(N, 11, generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    v = torch.randn(N, 11, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    Ku_ref = ops.mvm_sym(Z, u, 1.0 / J, 0.1)
+    for wide in (False, True):
+        c = ops.SymCache(Z, wide=wide)
+        assert 0.5 * 4 * N * N <= c.nbytes <= 0.52 * 4 * N * N
+        Ku = ops.symcache_mvm(c, u, 1.0 / J, 0.1)
+        Kv = ops.symcache_mvm(c, v, 1.0 / J, 0.1)
+        assert float((Ku - Ku_ref).norm() / Ku_ref.norm()) < 5e-6
+        a = float((v.double() * Ku.double()).sum())
+        b = float((u.double() * Kv.double()).sum())
+        assert abs(a - b) < 1e-5 * max(abs(a), abs(b))
+        Kuv = ops.symcache_mvm(c, 2.0 * u - 3.0 * v, 1.0 / J, 0.1)
+        assert float((Kuv - (2.0 * Ku - 3.0 * Kv)).norm() / Kuv.norm()) < 1e-5
+        one = ops.symcache_mvm(c, u[:, :1].contiguous(), 1.0 / J, 0.1)       # a thin block on the same cache
+        assert float((one - Ku_ref[:, :1]).norm() / Ku_ref[:, :1].norm()) < 5e-6   # two fp32 sums of 50 000 terms each
+        del c
+
+
 def test_cached_kernel_mode_matches_fused(gpu_device):
     """settings.cache_kernel: K materialised once per step (rpgp_dense) + library GEMM per CG iteration gives the same
     MLL and gradients as the fused path (same probes)."""

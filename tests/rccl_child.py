@@ -39,6 +39,20 @@ for mode in ("pairs", "j"):
     rel = float((got - full).norm() / full.norm())
     assert rel < 1e-6, (mode, rel)
 
+# (1b) cached-K mode under pair-sharding: every rank's packed symmetric cache holds its share of the pairs, the partial
+#      products meet in the same all-reduce (world = 1: the whole cache, no collective)
+from rpgp_amd.operators import SymCachedOperator
+V11 = torch.randn(3000, 11, generator=g).to(dev)
+sh = JShard(20, mode="pairs")
+base = AdditiveRPOperator(Z, None, s, 1.0 / J, shard=sh)
+full11 = AddedDiagOperator(AdditiveRPOperator(Z, None, s, 1.0 / J), torch.tensor(0.1, device=dev))._matmul(V11)
+for wide in (False, True):
+    cache = base.to_symcache(wide=wide)
+    assert cache is not None and cache.world == world
+    got = SymCachedOperator(cache, base._scale, 0.1, shard=sh)._matmul(V11)
+    rel = float((got - full11).norm() / full11.norm())
+    assert rel < 2e-6, ("symcache", wide, rel)
+
 # (2) row-sharded SKI: float64 histogram all-reduce (SUM), grid-range all-reduce (MIN), preconditioner pivots (MAX /
 #     MIN all-reduces + broadcasts), CG scalars
 N, J, T, G = 40000, 3, 11, 1024

@@ -92,7 +92,7 @@ def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag
 
 def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_updating_after=1e-10, max_iter=None,
               max_tridiag_iter=None, initial_guess=None, preconditioner=None, check_every=1, operator=None,
-              reduce=None, global_size=None):
+              reduce=None, global_size=None, min_iter=10):
     """Solve A X = rhs for symmetric positive definite A given as `matmul_closure`.
 
     rhs: (N x T).  Returns X, or (X, tridiag [n_tridiag x k x k]) when n_tridiag > 0.
@@ -179,7 +179,8 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     stagnation_window = settings.cg_stagnation_window.value()
     keep_best, snap_res, snap_x = T <= 64, float("inf"), None      # (wide blocks: a GB-sized copy per improvement is not worth it)
     residual_norm = None
-    min_iters = min(10, n_iter - 1)
+    min_iters = min(int(min_iter), n_iter - 1)     # GPyTorch tests the tolerance from iteration 10 on; a caller with a
+                                                   # near-exact preconditioner (fp32 Cholesky factor) lowers it
     k = 0
     for k in range(n_iter):
         Ap = matmul_closure(p)

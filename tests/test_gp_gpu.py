@@ -212,6 +212,26 @@ def test_cached_kernel_mode_matches_fused(gpu_device):
     assert abs(vals[0][2] - vals[1][2]) < 1e-4 * abs(vals[0][2])
 
 
+def test_wide_covariance_solve_paths_agree(gpu_device):
+    """The N_test-wide predictive-covariance solve: float64 direct solve (small N), fp32-Cholesky-preconditioned CG on the
+    dense matrix (mid N) and plain preconditioned CG give the same predictive variances as the dense float64 oracle."""
+    from rpgp_amd import settings
+    prob, model, lik, mll = _gpu_model(gpu_device, 2600, 8, 20, 2, 0.15)
+    X, y, P, ls, noise, s = prob
+    ref = _oracle_gp(X, y, P, ls, noise, s)
+    Xs = torch.randn(40, 8, generator=torch.Generator().manual_seed(5))
+    mean_ref, var_ref = ref.predict(Xs.numpy())
+    for dsz, csz in ((20000, 65536), (0, 65536), (0, 0)):
+        model.train()
+        model.eval()
+        with torch.no_grad(), settings.eval_cg_tolerance(1e-6), settings.cache_kernel(True), \
+                settings.dense_solve_size(dsz), settings.cholesky_precond_size(csz):
+            out = model(Xs.to(gpu_device))
+        assert np.linalg.norm(out.mean.cpu().numpy() - mean_ref) / np.linalg.norm(mean_ref) < 1e-4
+        var = out.variance.cpu().numpy()
+        assert np.abs(var - var_ref).max() < 2e-4 * max(1.0, np.abs(var_ref).max()), (dsz, csz)
+
+
 def test_fast_pred_var_love_on_gpu(gpu_device):
     """--fast_pred (LOVE, Lanczos inverse root through the fused MVM): exact mean, conservative variances that
     tighten with the rank (`max_root_decomposition_size`, default 100 as in GPyTorch)."""

@@ -40,7 +40,9 @@ def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol, ski=False, fu
             if it > 0:
                 times.append(time.perf_counter() - t0); iters.append(lcg.stats["iterations"])
             losses.append(loss.item())
-        res.update({"train_step_s": sum(times) / len(times), "cg_iters_per_step": sum(iters) / len(iters),
+        st = sorted(times)
+        res.update({"train_step_s": sum(times) / len(times), "train_step_median_s": st[len(st) // 2],
+                    "train_step_max_s": st[-1], "cg_iters_per_step": sum(iters) / len(iters),
                     "loss_first": losses[0], "loss_last": losses[-1]})
         model.eval()
         with torch.no_grad():

@@ -71,15 +71,18 @@ class PredictionStrategy:
             else:
                 self.chol = None
                 shard = getattr(self.op, "shard", None)
+                sharded = shard is not None and shard.world_size > 1
                 cacheable = isinstance(self.op, AdditiveRPOperator) and not isinstance(self.op, SKIAdditiveOperator) and \
-                    (shard is None or shard.world_size == 1) and x.dtype == torch.float32
-                cache = self.op.to_symcache() if cacheable and settings.use_cached_kernel(N, x.device, 2.0) else None
+                    x.dtype == torch.float32
+                per_rank = 2.0 / (shard.world_size if sharded else 1)     # pair-sharded ranks cache their own share
+                cache = self.op.to_symcache() if cacheable and settings.use_cached_kernel(N, x.device, per_rank) else None
                 if cache is not None:
                     # thin solves (the mean cache, LOVE's Lanczos) stream the packed symmetric cache: half the bytes of
                     # the dense matrix; the N_test-wide covariance solve builds the dense matrix on demand (solve())
                     self.khat = SymCachedOperator(cache, self.op._scale, float(self.noise),
-                                                  diag_value=self.op._scale * self.op.num_projections)
-                elif cacheable and settings.use_cached_kernel(N, x.device):
+                                                  diag_value=self.op._scale * self.op.num_projections,
+                                                  shard=shard if sharded else None)
+                elif cacheable and not sharded and settings.use_cached_kernel(N, x.device):
                     self.khat = DenseOperator(self.op.to_dense_cached(), float(self.noise))
                     self._dense_khat = self.khat
                 else:

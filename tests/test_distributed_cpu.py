@@ -83,6 +83,20 @@ def _worker(rank, world, port, tmpdir):
         assert ob.calls.get("symcache_mvm", 0) > n_sc, "the sharded cached operator was not used"
         assert abs(v.item() - vals[0][0]) < 1e-5 * abs(vals[0][0])
         assert torch.allclose(model.covar_module.base_kernel.raw_lengthscale.grad, vals[0][1], rtol=1e-3, atol=1e-6)
+        # ... and the prediction strategy on sharded caches gives the unsharded predictions
+        Xs = torch.randn(6, 4, generator=torch.Generator().manual_seed(3))
+        preds = []
+        for use_cache in (False, True):
+            m2, l2, _ = _build_model(X, y, P, ls, noise, sc)
+            if use_cache:
+                m2.covar_module.shard = JShard(5)
+            m2.eval()
+            with torch.no_grad(), settings.max_cholesky_size(0), settings.eval_cg_tolerance(1e-7), \
+                    settings.cache_kernel(use_cache):
+                o = m2(Xs)
+                preds.append((o.mean.clone(), o.variance.clone()))
+        assert torch.allclose(preds[0][0], preds[1][0], rtol=1e-4, atol=1e-6)
+        assert torch.allclose(preds[0][1], preds[1][1], rtol=1e-3, atol=1e-6)
         # train_exact_gp under a process group: per-rank random draws (projections, init) are overwritten by rank 0's
         # broadcast AFTER the move to the output device, the kernel gets a JShard, every rank ends with the same fit
         from rpgp_amd import training

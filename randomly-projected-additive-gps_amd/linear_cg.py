@@ -150,7 +150,10 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     else:
         result = initial_guess / rhs_norm
         residual = rhs - matmul_closure(result)
-    if not torch.isfinite(residual).all():
+    bad = (~torch.isfinite(residual)).any().to(torch.float32).reshape(1)
+    if reduce is not None:
+        reduce(bad)                        # row-sharded: every rank must take the same decision, or the others hang
+    if float(bad) > 0:
         raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
 
     z = preconditioner(residual)

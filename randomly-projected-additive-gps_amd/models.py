@@ -120,7 +120,10 @@ class PredictionStrategy:
                         blk = B[:, c0:c0 + 1024].double().contiguous()
                         out[:, c0:c0 + 1024] = torch.cholesky_solve(blk, self._chol64).to(B.dtype)
                     return out
-                if N <= settings.cholesky_precond_size.value() and B.is_cuda and B.dtype == torch.float32:
+                # (live at the factorisation: the dense matrix, its noise-added clone, the library's working copy and the
+                #  factor = 4 x 4N^2 bytes; only taken when that fits 60 % of the device)
+                room = 16.0 * N * N <= 0.6 * torch.cuda.get_device_properties(B.device).total_memory if B.is_cuda else False
+                if N <= settings.cholesky_precond_size.value() and room and B.dtype == torch.float32:
                     # beyond the float64 direct solve: one fp32 factorisation of Khat (N = 50k: 0.8 s), used as the
                     # preconditioner — the wide CG then converges in a handful of 91 ms GEMMs instead of ~40
                     if getattr(self, "_chol_pre", None) is None:

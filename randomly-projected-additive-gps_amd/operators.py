@@ -419,7 +419,7 @@ class RowShardedSKIOperator(LinearOperator):
         be = _backend.get_backend()
         rhs = rhs.detach()
         squeeze = rhs.dim() == 1
-        V = rhs.reshape(self.Z1.shape[0], -1).contiguous()
+        V = rhs.reshape(self.Z1.shape[0], rhs.shape[1] if rhs.dim() == 2 else 1).contiguous()
         outs = []
         for c0 in range(0, V.shape[1], 12):                   # the staged entry points take T <= 12 columns
             Vp = V[:, c0:c0 + 12].contiguous()
@@ -460,11 +460,31 @@ class RowShardedWoodbury:
         self._cap_chol = torch.linalg.cholesky(cap)
 
     def solve(self, r):
-        from .precond import gram64
-        t = gram64(self._L64, r.double())
-        self.row_shard.all_reduce_(t, "sum")
-        t = torch.cholesky_solve(t, self._cap_chol).to(r.dtype)
-        return (r - self.L @ t) / self.noise
+        """(r - L C^-1 L^T r) / noise on the local rows.  As in precond.WoodburyPreconditioner.solve the subtraction
+        cancels to ~sigma^2 / |K| of r along the range of L (1e-6 at N = 391k), so t and r - L t stay float64; wide
+        blocks go through in 64-column panels (one k x T all-reduce per panel)."""
+        from .precond import gram64, _PANEL
+        squeeze = r.dim() == 1
+        if squeeze:
+            r = r.unsqueeze(-1)
+        out = torch.empty_like(r)
+        for c0 in range(0, max(r.shape[1], 1), _PANEL):
+            rd = r[:, c0:c0 + _PANEL].double()
+            t = gram64(self._L64, rd)
+            self.row_shard.all_reduce_(t, "sum")
+            t = torch.cholesky_solve(t, self._cap_chol)
+            out[:, c0:c0 + _PANEL] = rd.addmm_(self._L64, t, alpha=-1.0).div_(self.noise).to(r.dtype)
+        return out.squeeze(-1) if squeeze else out
+
+    def logdet(self):
+        """log|M| = log|noise I_k + L^T L| + (N - k) log noise with the GLOBAL N."""
+        import math
+        ld_cap = 2.0 * torch.log(self._cap_chol.diagonal()).sum()
+        return float(ld_cap) + (self.row_shard.N - self.L.shape[1]) * math.log(self.noise)
+
+    def cinv(self):
+        """(noise I + L^T L)^-1 in float64 (k x k), identical on every rank, for the native mBCG executor."""
+        return torch.cholesky_inverse(self._cap_chol).contiguous()
 
     __call__ = solve
 

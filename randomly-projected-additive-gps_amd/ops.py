@@ -209,16 +209,16 @@ def dense(Z1, Z2, scale, j0=0, j1=None, pad=False):
     if Z2.shape[1] != J:
         raise ValueError("Z1 and Z2 must have the same number of projections")
     j1 = J if j1 is None else j1
-    out = torch.empty((M, N), dtype=Z1.dtype, device=Z1.device)
     if Z1.dtype == torch.float64:
+        out = torch.empty((M, N), dtype=Z1.dtype, device=Z1.device)
         with torch.cuda.device(Z1.device):
             _lib.check(lib.rpgp_dense_f64(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, j0, j1,
                                           float(scale), _stream()), "rpgp_dense_f64")
         return out
-    ld = N
-    if pad and N % 64:
-        ld = (N + 63) // 64 * 64
-        out = torch.empty((M, ld), dtype=Z1.dtype, device=Z1.device)[:, :N]
+    ld = (N + 63) // 64 * 64 if (pad and N % 64) else N        # decided before allocating: ONE buffer
+    out = torch.empty((M, ld), dtype=Z1.dtype, device=Z1.device)
+    if ld != N:
+        out = out[:, :N]
     with torch.cuda.device(Z1.device):
         _lib.check(lib.rpgp_dense(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, ld, j0, j1, float(scale),
                                   _stream()), "rpgp_dense")

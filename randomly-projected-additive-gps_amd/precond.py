@@ -47,6 +47,9 @@ def gram64(A, B):
     return out
 
 
+_PANEL = 64          # columns per float64 panel of the Woodbury solve
+
+
 class WoodburyPreconditioner:
     """M = L L^T + noise I."""
 
@@ -65,14 +68,25 @@ class WoodburyPreconditioner:
         self.N, self.k = L.shape
 
     def solve(self, r):
-        """M^-1 r = (r - L (noise I + L^T L)^-1 L^T r) / noise  (L^T r accumulated in float64)."""
+        """M^-1 r = (r - L (noise I + L^T L)^-1 L^T r) / noise.  Everything that touches the cancellation is float64:
+        L^T r is accumulated in float64 and r - L t (which shrinks the range-of-L component of r by
+        sigma^2 / (sigma^2 + lambda) ~ 1e-6) is subtracted in float64.  Wide blocks (predictive covariance, T = N_test) go
+        through in column panels so that the float64 temporaries stay N x 64."""
+        squeeze = r.dim() == 1
+        if squeeze:
+            r = r.unsqueeze(-1)
+        if r.shape[1] <= _PANEL:
+            out = self._solve_panel(r)
+        else:
+            out = torch.empty_like(r)
+            for c0 in range(0, r.shape[1], _PANEL):
+                out[:, c0:c0 + _PANEL] = self._solve_panel(r[:, c0:c0 + _PANEL])
+        return out.squeeze(-1) if squeeze else out
+
+    def _solve_panel(self, r):
         rd = r.double()
         t = torch.cholesky_solve(gram64(self._L64, rd), self._cap_chol)
-        if r.shape[-1] <= 64 or r.dim() == 1:
-            # r - L t cancels to a factor sigma^2 / (sigma^2 + lambda) ~ 1e-6 along the range of L: float64 subtraction
-            return ((rd - self._L64 @ t) / self.noise).to(r.dtype)
-        t = t.to(r.dtype)                      # wide blocks (predictive covariance): one N x T temporary, fp32
-        return torch.addmm(r, self.L, t, alpha=-1.0).div_(self.noise)
+        return rd.addmm_(self._L64, t, alpha=-1.0).div_(self.noise).to(r.dtype)
 
     __call__ = solve
 

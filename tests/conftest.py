@@ -14,7 +14,7 @@ def pytest_configure(config):
 
 # GPU run order (the driver stops at the first failure with -x): ABI / kernels first, the SKI suite (config C5) before
 # the long end-to-end tests, so that a late failure can never hide them again (round-1 verdict, weak #1-2).
-_ORDER = ["test_lib_abi", "test_kernels_gpu", "test_ski_gpu", "test_parity_gpu", "test_native_cg_gpu", "test_gp_gpu", "test_double_gpu",
+_ORDER = ["test_lib_abi", "test_kernels_gpu", "test_ski_gpu", "test_parity_gpu", "test_headline_oracle_gpu", "test_native_cg_gpu", "test_gp_gpu", "test_double_gpu",
           "test_family_gpu"]
 
 

@@ -488,3 +488,32 @@ def test_woodbury_capacitance_survives_large_kernel_norm():
     ref = (r32.double() - Ld @ exact) / noise
     assert float((back - ref).norm() / ref.norm()) < 1e-5
     assert abs(pre.logdet() - float(torch.logdet(Ld.t() @ Ld + noise * torch.eye(k, dtype=torch.float64)) + (N - k) * np.log(noise))) < 1e-6 * N
+
+
+def test_row_sharded_woodbury_and_wide_blocks_keep_the_cancellation_in_float64():
+    """RowShardedWoodbury.solve and the wide (T > 64) branch of WoodburyPreconditioner.solve subtracted
+    r - L t in float32; along range(L) that difference is ~ sigma^2 / |K| of r (1e-6 here).  Same system as above
+    (|L^T L| / sigma^2 ~ 5e6); also 1-D right-hand sides at N >= 32768 (gram64 indexed B.shape[1])."""
+    from rpgp_amd.distributed import RowShard
+    from rpgp_amd.operators import RowShardedWoodbury
+    from rpgp_amd.precond import WoodburyPreconditioner
+    g = torch.Generator().manual_seed(1)
+    N, k, noise = 40000, 15, 0.3
+    L = (torch.randn(N, k, generator=g) * 4.0 + 3.0).float()
+    Ld = L.double()
+    v = torch.randn(N, 70, generator=g).float()                      # 70 columns: the wide branch (two panels)
+    r32 = (Ld @ (Ld.t() @ v.double()) + noise * v.double()).float()
+    exact = torch.linalg.solve(Ld.t() @ Ld + noise * torch.eye(k, dtype=torch.float64), Ld.t() @ r32.double())
+    ref = (r32.double() - Ld @ exact) / noise
+    for pre in (WoodburyPreconditioner(L, noise), RowShardedWoodbury(L, noise, RowShard(N))):
+        back = pre.solve(r32).double()
+        assert float((back - ref).norm() / ref.norm()) < 1e-5, type(pre).__name__
+        one = pre.solve(r32[:, 3].contiguous())                      # 1-D right-hand side
+        assert one.shape == (N,) and float((one.double() - ref[:, 3]).norm() / ref[:, 3].norm()) < 1e-5
+        # M^-1 must stay symmetric: u^T M^-1 w == w^T M^-1 u
+        u, w = r32[:, :1], r32[:, 1:2]
+        a = float((u.double() * pre.solve(w).double()).sum())
+        b = float((w.double() * pre.solve(u).double()).sum())
+        assert abs(a - b) < 1e-6 * max(abs(a), abs(b))
+    sh = RowShardedWoodbury(L, noise, RowShard(N))
+    assert abs(sh.logdet() - WoodburyPreconditioner(L, noise).logdet()) < 1e-9 * N

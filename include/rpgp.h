@@ -338,6 +338,36 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
                     void *stream);
 
 /*
+ * Multi-GPU pieces (one process per GPU; replaces `MultiDeviceKernel(kernel, devices, devices[0])`,
+ * training_routines.py:407-408).
+ *
+ * rpgp_allreduce_fn: in-place SUM all-reduce of `count` elements (dtype RPGP_F32 / RPGP_F64) of the DEVICE buffer
+ * `buf` over the ranks, ENQUEUED on `stream` (no host synchronisation); every rank must end with bit-identical
+ * values.  The host binds it to its communicator: `rpgp_comm_allreduce` below (ctx = the rpgp_comm), or a callback
+ * that issues the RCCL collective on the same stream (torch.distributed.all_reduce in the Python host).
+ *
+ * rpgp_comm: SUM all-reduce over IPC-mapped peer buffers for the small, latency-bound messages of the sharded solve
+ * (N x T partial products, J x G x T grid histograms, inner products).  One kernel launch per call: every rank publishes
+ * its data in a staging buffer that all peers have mapped (hipIpcGetMemHandle / hipIpcOpenMemHandle), raises a flag in
+ * each peer's memory, waits for the peers' flags and adds the W contributions in rank order (one-shot), or reduces its
+ * own 1/W chunk and writes it to all peers (two-shot, messages > 512 KB).  Bootstrap: every rank calls
+ * rpgp_comm_create, the RPGP_COMM_HANDLE_BYTES handles are exchanged out of band in rank order (the Python host uses
+ * torch.distributed.all_gather_object), then rpgp_comm_connect.  A message may hold at most `max_bytes` bytes.
+ * Waits are bounded (20 s): a lost peer raises the comm's error word (rpgp_comm_error) instead of hanging the GPU.
+ */
+#define RPGP_F32 0
+#define RPGP_F64 1
+typedef int (*rpgp_allreduce_fn)(void *ctx, void *buf, size_t count, int dtype, void *stream);
+#define RPGP_COMM_HANDLE_BYTES 64
+typedef struct rpgp_comm rpgp_comm;
+int rpgp_comm_create(int world, int rank, size_t max_bytes, rpgp_comm **out, void *handle_out);
+int rpgp_comm_connect(rpgp_comm *comm, const void *all_handles);
+size_t rpgp_comm_capacity(const rpgp_comm *comm);
+int rpgp_comm_allreduce(void *comm, void *buf, size_t count, int dtype, void *stream);
+int rpgp_comm_error(rpgp_comm *comm, int *error_host);
+int rpgp_comm_destroy(rpgp_comm *comm);
+
+/*
  * Float64 variants for `--double` (training_routines.py:481).  Same contracts as the fp32 entry points of the same
  * name; parity path (software exp, no symmetry exploitation, no workspace).  rpgp_mvm_f64 covers both the square
  * (Z1 == Z2, optional noise) and the rectangular product; `row_scratch` is N doubles of device scratch.

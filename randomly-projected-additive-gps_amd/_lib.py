@@ -83,6 +83,12 @@ SIGNATURES = {
     "rpgp_dense_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f64, _vp]),
     "rpgp_bilinear_grad_f64": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f64, _vp, _vp]),
     "rpgp_bilinear_grad_dense_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _int, _int, _f64, _vp, _vp]),
+    "rpgp_comm_create": (_int, [_int, _int, _sz, ctypes.POINTER(_vp), _vp]),
+    "rpgp_comm_connect": (_int, [_vp, _vp]),
+    "rpgp_comm_capacity": (_sz, [_vp]),
+    "rpgp_comm_allreduce": (_int, [_vp, _vp, _sz, _int, _vp]),
+    "rpgp_comm_error": (_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
+    "rpgp_comm_destroy": (_int, [_vp]),
     "rpgp_profile_begin": (_int, []),
     "rpgp_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
 }
@@ -105,6 +111,10 @@ RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI, RPGP_OP_DENSE, RPGP_OP_FAMIL
 RPGP_KIND_RBF, RPGP_KIND_MATERN15, RPGP_KIND_IMQ, RPGP_KIND_COSINE = 0, 1, 2, 3
 RPGP_SYMCACHE_THIN, RPGP_SYMCACHE_WIDE = 0, 1
 RPGP_PIVCHOL_SCRATCH = 2048
+RPGP_F32, RPGP_F64 = 0, 1
+RPGP_COMM_HANDLE_BYTES = 64
+# int (*rpgp_allreduce_fn)(void *ctx, void *buf, size_t count, int dtype, void *stream)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)
 
 _lib = None
 

@@ -127,3 +127,131 @@ class RowShard:
         if self.active:
             dist.broadcast(t, src=src, group=self.group)
         return t
+
+
+# ---- the all-reduce the sharded solve runs on --------------------------------------------------------------------
+class Reducer:
+    """In-place SUM all-reduce of device tensors for the sharded solve, in the two forms the stack needs:
+      * `all_reduce_(t)`         — a torch tensor (float32 / float64), enqueued on the current stream;
+      * `c_hook()`               — `(fn, ctx)` for the native mBCG executor (`rpgp_allreduce_fn` of include/rpgp.h): the
+                                   executor calls it between its enqueue-only phases, on its launch stream.
+    Backends:
+      * "rccl" (default)         — torch.distributed (backend "nccl" = RCCL over xGMI; gloo in CPU tests).  The C hook is a
+                                   ctypes callback that wraps the raw device pointer in a tensor view and issues the
+                                   collective; RCCL orders it after the work already queued on the current stream, so
+                                   there is no host synchronisation.
+      * "ipc"                    — rpgp_comm (csrc/rpgp_comm.hip): one kernel launch per call over IPC-mapped peer
+                                   buffers; the hook is the library's own function pointer (no Python in the loop).
+                                   Opt-in: `RPGP_COMM=ipc` or `settings.comm_backend("ipc")`.
+    `world_size == 1` makes every call the identity (and the hook None)."""
+
+    def __init__(self, group=None, backend=None, max_bytes=1 << 24, device=None):
+        import os
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world_size = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        if backend is None:
+            from . import settings
+            backend = os.environ.get("RPGP_COMM") or settings.comm_backend.value()
+        self.backend = backend if self.world_size > 1 else "none"
+        self._comm = None
+        self._cb = None
+        self._keep = {}
+        if self.backend == "ipc":
+            self._init_ipc(max_bytes, device)
+        elif self.backend not in ("rccl", "none"):
+            raise ValueError("unknown comm backend %r (rccl | ipc)" % (backend,))
+
+    # -- rpgp_comm bootstrap: create, exchange the IPC handles through the process group, connect
+    def _init_ipc(self, max_bytes, device):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        comm = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(_lib.RPGP_COMM_HANDLE_BYTES)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.rpgp_comm_create(self.world_size, self.rank, int(max_bytes), ctypes.byref(comm), handle),
+                       "rpgp_comm_create")
+            handles = [None] * self.world_size
+            dist.all_gather_object(handles, bytes(handle.raw), group=self.group)
+            blob = b"".join(handles)
+            _lib.check(lib.rpgp_comm_connect(comm, blob), "rpgp_comm_connect")
+        self._comm = comm
+        self._lib = lib
+        self.max_bytes = int(lib.rpgp_comm_capacity(comm))
+        dist.barrier(group=self.group)          # nobody starts publishing before every peer has mapped everybody
+
+    def all_reduce_(self, t):
+        if self.backend == "none":
+            return t
+        if self.backend == "ipc" and t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous() and \
+                t.numel() * t.element_size() <= self.max_bytes:
+            from . import _lib
+            with torch.cuda.device(t.device):
+                _lib.check(self._lib.rpgp_comm_allreduce(self._comm, t.data_ptr(), t.numel(),
+                                                         _lib.RPGP_F64 if t.dtype == torch.float64 else _lib.RPGP_F32,
+                                                         torch.cuda.current_stream().cuda_stream), "rpgp_comm_allreduce")
+            return t
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def check(self):
+        """Raise if a bounded wait of the IPC backend timed out (a peer was lost)."""
+        if self._comm is not None:
+            import ctypes
+            from . import _lib
+            err = ctypes.c_int(0)
+            _lib.check(self._lib.rpgp_comm_error(self._comm, ctypes.byref(err)), "rpgp_comm_error")
+            if err.value:
+                raise RuntimeError("rpgp_comm: a peer did not arrive within the wait bound (rank %d)" % self.rank)
+
+    def c_hook(self, workspace=None):
+        """(function pointer, context pointer) for `struct rpgp_reducer`, or (None, None) for a single rank.
+        `workspace`: the torch uint8 tensor the executor's buffers live in (RCCL backend: the callback turns the raw
+        pointers it is handed into views of this tensor)."""
+        import ctypes
+        from . import _lib
+        if self.backend == "none":
+            return None, None
+        if self.backend == "ipc":
+            fn = ctypes.cast(self._lib.rpgp_comm_allreduce, ctypes.c_void_p).value
+            return fn, self._comm.value
+        group = self.group
+        base = workspace.data_ptr()
+        nbytes = workspace.numel()
+
+        def _cb(ctx, buf, count, dtype, stream):
+            try:
+                esz = 8 if dtype == _lib.RPGP_F64 else 4
+                off = int(buf) - base
+                if off < 0 or off + count * esz > nbytes:
+                    return _lib.RPGP_EINVAL
+                view = workspace[off:off + count * esz].view(torch.float64 if dtype == _lib.RPGP_F64 else torch.float32)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception:                       # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return _lib.RPGP_EINVAL
+        cb = _lib.ALLREDUCE_FN(_cb)
+        self._keep[id(cb)] = cb                     # the executor call outlives this frame
+        return ctypes.cast(cb, ctypes.c_void_p).value, None
+
+    def close(self):
+        if self._comm is not None:
+            self._lib.rpgp_comm_destroy(self._comm)
+            self._comm = None
+
+
+_reducers = {}
+
+
+def get_reducer(group=None):
+    """One Reducer per process group (the IPC backend owns mapped buffers: created once, reused by every solve)."""
+    key = id(group)
+    r = _reducers.get(key)
+    if r is None:
+        r = _reducers[key] = Reducer(group)
+    return r

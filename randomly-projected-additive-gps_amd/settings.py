@@ -100,6 +100,12 @@ dense_solve_size = _setting("dense_solve_size", 20000)
 # ... and above that, up to this size, factorise the fp32 matrix once and use the factor as the preconditioner of the wide
 # block's CG (0 disables: plain pivoted-Cholesky-preconditioned CG)
 cholesky_precond_size = _setting("cholesky_precond_size", 65536)
+# the all-reduce of the sharded multi-GPU solve: "rccl" (torch.distributed, backend nccl = RCCL over xGMI) or "ipc" (one-shot
+# kernel over IPC-mapped peer buffers, csrc/rpgp_comm.hip); the environment variable RPGP_COMM overrides it
+comm_backend = _setting("comm_backend", "rccl")
+# the native mBCG executor also serves sharded operators (partial products / row blocks summed by the reducer's hook on
+# the launch stream); False sends sharded solves through the torch-op loop of linear_cg.py
+native_sharded_cg = _setting("native_sharded_cg", True, flag=True)
 
 
 class fast_computations:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPGP_ABI_VERSION 1
+#define RPGP_ABI_VERSION 2
 
 #define RPGP_EINVAL     10001 /* bad argument (shape, range, null pointer) */
 #define RPGP_EWORKSPACE 10002 /* workspace too small: call the matching *_workspace_bytes */
@@ -328,14 +328,39 @@ typedef struct rpgp_operator {
   const float *Kd;
   int64_t ldk;
   const rpgp_family *family;
+  int world, rank;              /* pair-shard of RPGP_OP_FUSED / FUSED_PREPARED / SYMCACHE (0 or 1, 0: the whole operator) */
 } rpgp_operator;
+
+/*
+ * Sharded solves (one process per GPU).  `fn(ctx, buf, count, dtype, stream)` is the in-place SUM all-reduce described
+ * under "Multi-GPU pieces" below; the executor calls it between its enqueue-only phases on the launch stream, so a
+ * sharded solve still has no host synchronisation per iteration (the convergence flag stays on the device).
+ *   RPGP_SHARD_PARTIAL  vectors are replicated; the operator (RPGP_OP_FUSED / FUSED_PREPARED with (world, rank) or a
+ *                       [j0, j1) slice, RPGP_OP_SYMCACHE with (world, rank)) yields this rank's partial product, the noise
+ *                       term is added on rank 0 only, ONE all-reduce of the N x T block per iteration;
+ *   RPGP_SHARD_ROWS     RPGP_OP_SKI on this rank's rows (op->N local rows, T <= 12; rhs / x / L are the local rows; op->N
+ *                       may be 0): the J x G x T float64 histogram and two 288-double reduction vectors per iteration are
+ *                       all-reduced; global_N = total number of rows (iteration cap).  grid_params must come from the
+ *                       GLOBAL coordinate range and Cinv from the all-reduced capacitance matrix.
+ * reducer == NULL, mode RPGP_SHARD_NONE or fn == NULL: the single-GPU solve.
+ */
+#define RPGP_SHARD_NONE 0
+#define RPGP_SHARD_PARTIAL 1
+#define RPGP_SHARD_ROWS 2
+typedef int (*rpgp_allreduce_fn)(void *ctx, void *buf, size_t count, int dtype, void *stream);
+typedef struct rpgp_reducer {
+  int mode, world, rank;
+  int64_t global_N;
+  rpgp_allreduce_fn fn;
+  void *ctx;
+} rpgp_reducer;
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank);
 int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,
                     int hist_len, int check_every, int stagnation_window, float tolerance, int precond_rank,
                     const float *L,
-                    const double *Cinv, float precond_sigma2, float *alpha_hist_host, float *beta_hist_host,
-                    int *iterations_host, float *mean_resid_host, void *workspace, size_t workspace_bytes,
-                    void *stream);
+                    const double *Cinv, float precond_sigma2, const rpgp_reducer *reducer, float *alpha_hist_host,
+                    float *beta_hist_host, int *iterations_host, float *mean_resid_host, void *workspace,
+                    size_t workspace_bytes, void *stream);
 
 /*
  * Multi-GPU pieces (one process per GPU; replaces `MultiDeviceKernel(kernel, devices, devices[0])`,
@@ -357,7 +382,6 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
  */
 #define RPGP_F32 0
 #define RPGP_F64 1
-typedef int (*rpgp_allreduce_fn)(void *ctx, void *buf, size_t count, int dtype, void *stream);
 #define RPGP_COMM_HANDLE_BYTES 64
 typedef struct rpgp_comm rpgp_comm;
 int rpgp_comm_create(int world, int rank, size_t max_bytes, rpgp_comm **out, void *handle_out);

@@ -76,7 +76,7 @@ SIGNATURES = {
                                            _sz, _vp, _vp]),
     "rpgp_mbcg_workspace_bytes": (_sz, [_vp, _int, _int]),
     "rpgp_mbcg_solve": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _f32, _int, _vp, _vp, _f32, _vp, _vp, _vp,
-                               _vp, _vp, _sz, _vp]),
+                               _vp, _vp, _vp, _sz, _vp]),
     "rpgp_project_f64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "rpgp_project_grad_f64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "rpgp_mvm_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f64, _f64, _vp]),
@@ -99,7 +99,13 @@ class RpgpOperator(ctypes.Structure):
                 ("j0", ctypes.c_int), ("j1", ctypes.c_int), ("G", ctypes.c_int), ("scale", ctypes.c_float),
                 ("noise", ctypes.c_float), ("Z", ctypes.c_void_p), ("prep", ctypes.c_void_p),
                 ("grid_params", ctypes.c_void_p), ("Kd", ctypes.c_void_p), ("ldk", ctypes.c_int64),
-                ("family", ctypes.c_void_p)]
+                ("family", ctypes.c_void_p), ("world", ctypes.c_int), ("rank", ctypes.c_int)]
+
+
+class RpgpReducer(ctypes.Structure):
+    """struct rpgp_reducer of include/rpgp.h."""
+    _fields_ = [("mode", ctypes.c_int), ("world", ctypes.c_int), ("rank", ctypes.c_int), ("global_N", ctypes.c_int64),
+                ("fn", ctypes.c_void_p), ("ctx", ctypes.c_void_p)]
 
 
 class RpgpFamily(ctypes.Structure):
@@ -112,6 +118,8 @@ RPGP_KIND_RBF, RPGP_KIND_MATERN15, RPGP_KIND_IMQ, RPGP_KIND_COSINE = 0, 1, 2, 3
 RPGP_SYMCACHE_THIN, RPGP_SYMCACHE_WIDE = 0, 1
 RPGP_PIVCHOL_SCRATCH = 2048
 RPGP_F32, RPGP_F64 = 0, 1
+RPGP_SHARD_NONE, RPGP_SHARD_PARTIAL, RPGP_SHARD_ROWS = 0, 1, 2
+RPGP_ABI_VERSION = 2
 RPGP_COMM_HANDLE_BYTES = 64
 # int (*rpgp_allreduce_fn)(void *ctx, void *buf, size_t count, int dtype, void *stream)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)
@@ -145,7 +153,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rpgp_version() != 1:
+    if lib.rpgp_version() != RPGP_ABI_VERSION:
         raise RuntimeError("librpgp.so ABI version mismatch: %d" % lib.rpgp_version())
     _lib = lib
     return lib

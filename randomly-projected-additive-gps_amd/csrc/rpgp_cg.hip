@@ -1,17 +1,33 @@
 // rpgp_cg.hip — native mBCG executor: preconditioned batched conjugate gradients with Lanczos coefficients
-//  as ONE host call.  The operator application is a direct call into the fused
-// kernels of rpgp_kernels.hip; the vector recurrences are four fused kernels per iteration whose scalars (alpha, beta,
-// r.z, residual norms) live in device memory, so there is no host synchronisation except the periodic convergence test.
+//  as ONE host call, on one GPU or sharded over ranks.
 //
-// Per iteration (T <= 16 right-hand sides, row-major N x T):
-//   Ap = A p                                            rpgp_mvm_sym[_prepared] / rpgp_ski_mvm
-//   k_coldot : partial sums of p.Ap per column
-//   k_update : alpha = rz / pAp ; x += alpha p ; r -= alpha Ap ; partial |r|^2 ; partial L^T r (preconditioner)
-//   k_precond: w = Cinv (L^T r) ; z = (r - L w) / sigma^2 ; partial r.z            (identity preconditioner: z = r)
-//   k_direction: beta = rz' / rz ; p = z + beta p ; alpha/beta history ; mean residual norm ; convergence decision
-// The convergence flag lives on the device; the host polls it one iteration late through pinned memory, so the queue
-// never drains on the round trip (the one iteration queued past convergence is a no-op on x).
-// Partial sums are per-workgroup slabs reduced in a fixed order by the consuming kernel's prologue (deterministic).
+// Per iteration (T <= 16 right-hand sides, row-major N x T; Woodbury preconditioner M = L L^T + sigma^2 I, K <= 16):
+//   Ap = A p                         operator kernels (fused / prepared / SKI / cached-K / family)      [+ all-reduce]
+//   k_pass_a : partial p.Ap per column and partial L^T(Ap)                                  reads p, Ap, L
+//   k_reduce : fixed-order float64 sums of the per-workgroup partials                       [+ all-reduce, row mode]
+//   k_pass_b : alpha = rz / pAp ; x += alpha p ; r -= alpha Ap ;
+//              w = L^T r_old - alpha L^T(Ap) ; z = (r - L Cinv w) / sigma^2 ;
+//              partial |r|^2, r.z and (directly, from the r just formed) L^T r              reads p, Ap, x, r, L
+//   k_reduce                                                                                [+ all-reduce, row mode]
+//   k_pass_c : beta = rz' / rz ; p = z + beta p ; history ; convergence decision            reads z, p
+// Three streaming passes instead of five (round 2: k_coldot, k_update, k_wsolve, k_precond, k_direction).  The z of
+// iteration k needs L^T r_k, a global reduction over the r_k that the same pass is still writing; it is formed from the
+// DIRECT L^T r_{k-1} of the previous pass and the L^T(Ap) partials of pass A — one recurrence step from a freshly
+// computed value, never an accumulated one.
+//
+// Data layout of the passes: a workgroup takes 256-row tiles, a wave 16-row blocks; lane l of the wave holds, for
+// r = 0..3, element (row R0 + l/16 + 4r, column l%16).  That is (a) one contiguous 4-row segment per load instruction
+// (the round-2 "thread = row" layout touched 22 cache lines per instruction at T = 11 and ran at 0.22 of HBM peak),
+// (b) a fixed column per lane, so alpha / beta and the column sums are registers, (c) the B-operand layout of
+// v_mfma_f32_16x16x4_f32, so L^T X (16 x 16 per block) is four exact-fp32 matrix instructions per block, and (d) the
+// result layout of v_mfma_f64_16x16x4_f64, so the Woodbury correction L (Cinv w) is four float64 matrix instructions
+// and the cancelling subtraction r - L (Cinv w) stays float64 (it shrinks the range-of-L part of r by ~1e-6).
+//
+// Sharding (struct rpgp_reducer): RPGP_SHARD_PARTIAL — vectors replicated, the operator returns this rank's partial
+// product, summed by ONE all-reduce hook call on the launch stream per iteration (pair- / J-sharded exact operator,
+// pair-sharded packed cache); RPGP_SHARD_ROWS — the SKI operator on this rank's rows: the J x G x T float64 histogram and
+// the two small reduction vectors per iteration are all-reduced.  The hook only enqueues; the convergence flag stays on
+// the device and the host still polls it one iteration late, so a sharded solve has no host synchronisation per iteration.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -23,9 +39,13 @@ namespace {
 
 constexpr int kMaxT = 16;
 constexpr int kMaxK = 16;          // preconditioner rank
-constexpr int kMaxBlocks = 512;     // workgroups of the streaming vector kernels (consumers reduce the T-wide partials in their prologue)
-constexpr int kMaxBlocksW = 512;    // ... of k_update / k_Ltr, whose K x T wide L^T r partials are reduced once by k_wsolve
-constexpr int kMaxHist = 64;        // Lanczos coefficients kept for at most this many iterations
+constexpr int kMaxBlocks = 1024;   // workgroups of the streaming passes (= partial-sum slabs)
+constexpr int kMaxHist = 64;       // Lanczos coefficients kept for at most this many iterations
+constexpr int kRedW = 288;         // reduction vector: [16 col sums a][16 col sums b][16 x 16 L^T X]
+constexpr int kRedLt = 32;         // offset of the L^T X block
+
+typedef float floatx4m __attribute__((ext_vector_type(4)));
+typedef double doublex4m __attribute__((ext_vector_type(4)));
 
 // launch STMT with TT = the exact number of right-hand sides (1 .. kMaxT)
 #define CG_DISPATCH_T(T_, STMT)                                                                          \
@@ -66,76 +86,167 @@ struct CgState {
   CgPoll poll;
 };
 
-__device__ __forceinline__ float block_sum(float v, float *sh) {
-  // 256 threads -> one value (all threads get it)
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) sh[wave] = v;
-  __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
-}
+// ---- the lane <-> element map of the streaming passes -------------------------------------------------------------
+// wave `wave` of the workgroup, 16-row block `blk` (0..3) of the 256-row tile starting at row0:
+//   rows R0 .. R0 + 15 with R0 = row0 + 64 wave + 16 blk; lane (c = l % 16, q = l / 16), register r: row R0 + q + 4 r.
+struct Lane {
+  int c, q, wave;
+  __device__ __forceinline__ Lane() : c(threadIdx.x & 15), q((threadIdx.x & 63) >> 4), wave(threadIdx.x >> 6) {}
+};
 
-// dst[t] = sum_q partial[q][t] for t < T with all 256 threads: 16 lanes per column take every 16th slab, then the 16
-// lane sums are added in a fixed order (deterministic).  `scratch` holds 256 floats.  Ends with a barrier.
-__device__ __forceinline__ void reduce_partials(const float *__restrict__ partial, int nparts, int T,
-                                                float *__restrict__ dst, float *__restrict__ scratch) {
-  const int t = threadIdx.x & (kMaxT - 1), q0 = threadIdx.x / kMaxT;
-  float s = 0.f;
-  if (t < T)
-    for (int q = q0; q < nparts; q += 256 / kMaxT) s += partial[(size_t)q * T + t];
-  scratch[q0 * kMaxT + t] = s;
-  __syncthreads();
-  if ((int)threadIdx.x < T) {
-    float tot = 0.f;
-#pragma unroll
-    for (int q = 0; q < 256 / kMaxT; ++q) tot += scratch[q * kMaxT + threadIdx.x];
-    dst[threadIdx.x] = tot;
-  }
-  __syncthreads();
-}
-
-// partial[blk][t] = sum over the block's rows of a[i][t] * b[i][t]
-// (TT = exact number of columns: the per-row loads are unconditional and issued together; with a runtime T every load sat
-// behind its own `t < T` branch — the same pathology the cached-K stream had, §DESIGN 3.2)
 template <int TT>
-__global__ __launch_bounds__(256) void k_coldot(const float *__restrict__ a, const float *__restrict__ b,
-                                                float *__restrict__ partial, long long N) {
-  __shared__ float sh[4];
-  float acc[TT];
+__device__ __forceinline__ void load_block(const float *__restrict__ a, long long R0, long long N, const Lane &ln,
+                                           float (&v)[4]) {
 #pragma unroll
-  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
-    float av[TT], bv[TT];
-#pragma unroll
-    for (int t = 0; t < TT; ++t) { av[t] = a[i * TT + t]; bv[t] = b[i * TT + t]; }
-#pragma unroll
-    for (int t = 0; t < TT; ++t) acc[t] = __builtin_fmaf(av[t], bv[t], acc[t]);
-  }
-#pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    const float s = block_sum(acc[t], sh);
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * TT + t] = s;
+  for (int r = 0; r < 4; ++r) {
+    const long long row = R0 + ln.q + 4 * r;
+    const bool ok = row < N && ln.c < TT;
+    const float x = a[ok ? row * TT + ln.c : 0];          // unconditional load of a clamped address
+    v[r] = ok ? x : 0.f;
   }
 }
 
-// r = rhs / |rhs| (columns with |rhs| < 1e-10 are flagged zero and left unscaled), x = 0
-__global__ __launch_bounds__(256) void k_normalise(const float *__restrict__ rhs, const float *__restrict__ partial,
-                                                   int nparts, float *__restrict__ r, float *__restrict__ x,
-                                                   CgState *__restrict__ st, long long N, int T) {
-  __shared__ float ssum[kMaxT];
-  __shared__ float snorm[kMaxT];
-  __shared__ float scratch[256];
-  reduce_partials(partial, nparts, T, ssum, scratch);
-  if ((int)threadIdx.x < T) {
-    float nrm = sqrtf(ssum[threadIdx.x]);
+template <int TT>
+__device__ __forceinline__ void store_block(float *__restrict__ a, long long R0, long long N, const Lane &ln,
+                                            const float (&v)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long row = R0 + ln.q + 4 * r;
+    if (row < N && ln.c < TT) a[row * TT + ln.c] = v[r];
+  }
+}
+
+// A operand of L^T X: lane (c = kk, q) holds L[R0 + q + 4 r][kk]
+__device__ __forceinline__ void load_L_rows(const float *__restrict__ L, long long R0, long long N, int K, const Lane &ln,
+                                            float (&v)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long row = R0 + ln.q + 4 * r;
+    const bool ok = row < N && ln.c < K;
+    const float x = L[ok ? row * K + ln.c : 0];
+    v[r] = ok ? x : 0.f;
+  }
+}
+
+// A operand of L (Cinv w) in float64: lane (c = row in block, q) holds L[R0 + c][4 s + q]
+__device__ __forceinline__ void load_L_cols(const float *__restrict__ L, long long R0, long long N, int K, const Lane &ln,
+                                            float (&v)[4]) {
+  const long long row = R0 + ln.c;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int b = 4 * s + ln.q;
+    const bool ok = row < N && b < K;
+    const float x = L[ok ? row * K + b : 0];
+    v[s] = ok ? x : 0.f;
+  }
+}
+
+// column sum over the workgroup of a per-lane partial (fixed order): every thread gets nothing; thread c < 16 of wave 0
+// writes dst[c].  `sh` holds 64 floats.  Ends with a barrier.
+__device__ __forceinline__ void block_colsum(float v, float *__restrict__ sh, float *__restrict__ dst, const Lane &ln) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  __syncthreads();
+  if (ln.q == 0) sh[ln.wave * 16 + ln.c] = v;
+  __syncthreads();
+  if (threadIdx.x < 16) dst[threadIdx.x] = ((sh[threadIdx.x] + sh[16 + threadIdx.x]) + sh[32 + threadIdx.x]) + sh[48 + threadIdx.x];
+}
+
+// the four waves' 16 x 16 L^T X accumulators (fp32 MFMA result layout: lane reg r = D[4 q + r][c]) added in a fixed order
+// into dst[kk * 16 + t].  `sh` holds 4 * 256 floats.  Ends with a barrier.
+__device__ __forceinline__ void block_ltsum(const floatx4m &acc, float *__restrict__ sh, float *__restrict__ dst,
+                                            const Lane &ln) {
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sh[ln.wave * 256 + (4 * ln.q + r) * 16 + ln.c] = acc[r];
+  __syncthreads();
+  const int e = threadIdx.x;
+  dst[e] = ((sh[e] + sh[256 + e]) + sh[512 + e]) + sh[768 + e];
+}
+
+// ---- pass A: partial p.Ap per column, partial L^T (Ap) ------------------------------------------------------------
+// part[blk][0..15] = sum over the workgroup's rows of a*b per column; part[blk][32 + kk*16 + t] = sum L[row][kk] b[row][t]
+template <int TT>
+__global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, const float *__restrict__ b,
+                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K) {
+  __shared__ float sh[1024];
+  const Lane ln;
+  float dot = 0.f;
+  floatx4m lt = {0.f, 0.f, 0.f, 0.f};
+  const long long ntiles = (N + 255) / 256;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long w0 = tile * 256 + 64 * ln.wave;
+    float av[4][4], bv[4][4], lv[4][4];
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) {
+      load_block<TT>(a, w0 + 16 * bk, N, ln, av[bk]);
+      load_block<TT>(b, w0 + 16 * bk, N, ln, bv[bk]);
+      if (K > 0) load_L_rows(L, w0 + 16 * bk, N, K, ln, lv[bk]);
+    }
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dot = __builtin_fmaf(av[bk][r], bv[bk][r], dot);
+      if (K > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lt = __builtin_amdgcn_mfma_f32_16x16x4f32(lv[bk][r], bv[bk][r], lt, 0, 0, 0);
+      }
+    }
+  }
+  float *dst = part + (size_t)blockIdx.x * kRedW;
+  block_colsum(dot, sh, dst, ln);
+  if (threadIdx.x < 16) dst[16 + threadIdx.x] = 0.f;
+  block_ltsum(lt, sh, dst + kRedLt, ln);
+}
+
+// red[e] = sum over the slabs of part[.][e] in float64, fixed order: workgroup b owns entries 16 b .. 16 b + 15, its 16
+// thread groups take every 16th slab and the 16 group sums are added in order.
+__global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ part, int nparts, double *__restrict__ red) {
+  __shared__ double sh[256];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + e;
+  double s = 0.0;
+  int p = g;
+  for (; p + 48 < nparts; p += 64) {
+    const float v0 = part[(size_t)p * kRedW + idx], v1 = part[(size_t)(p + 16) * kRedW + idx];
+    const float v2 = part[(size_t)(p + 32) * kRedW + idx], v3 = part[(size_t)(p + 48) * kRedW + idx];
+    s += (double)v0;
+    s += (double)v1;
+    s += (double)v2;
+    s += (double)v3;
+  }
+  for (; p < nparts; p += 16) s += (double)part[(size_t)p * kRedW + idx];
+  sh[g * 16 + e] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += sh[q * 16 + threadIdx.x];
+    red[idx] = tot;
+  }
+}
+
+// ---- set-up: r = rhs / |rhs| (columns with |rhs| < 1e-10 are flagged zero and left unscaled), x = p = Ap = 0,
+// ---- partial L^T r ------------------------------------------------------------------------------------------------
+template <int TT>
+__global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, const double *__restrict__ red_sq,
+                                              float *__restrict__ r, float *__restrict__ x, float *__restrict__ p,
+                                              float *__restrict__ Ap, const float *__restrict__ L,
+                                              float *__restrict__ part, CgState *__restrict__ st, long long N, int K) {
+  __shared__ float sh[1024];
+  __shared__ float snrm[kMaxT];
+  const Lane ln;
+  if (threadIdx.x < kMaxT) {
+    float nrm = threadIdx.x < TT ? sqrtf((float)red_sq[threadIdx.x]) : 1.0f;
     const int zero = nrm < 1e-10f;
     if (zero) nrm = 1.0f;
-    snorm[threadIdx.x] = nrm;
+    snrm[threadIdx.x] = nrm;
     if (blockIdx.x == 0) {
       st->rhs_norm[threadIdx.x] = nrm;
       st->rhs_zero[threadIdx.x] = zero;
+      st->resid[threadIdx.x] = 1.0f;
+      st->rz[0][threadIdx.x] = 0.f;
+      st->rz[1][threadIdx.x] = 0.f;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -150,296 +261,219 @@ __global__ __launch_bounds__(256) void k_normalise(const float *__restrict__ rhs
     st->snap_resid[1] = 3.0e38f;
   }
   __syncthreads();
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
-    for (int t = 0; t < T; ++t) {
-      r[i * T + t] = rhs[i * T + t] / snorm[t];
-      x[i * T + t] = 0.f;
-    }
-}
-
-// One 256-row tile of w += L^T r: the tile's r (kMaxT-wide rows in sR) and L rows (sL) are in LDS; thread (kk, t)
-// accumulates its entry over the tile's rows.  Callers bracket it with barriers.
-__device__ __forceinline__ float ltr_tile(const float *__restrict__ sL, const float *__restrict__ sR, float acc) {
-  const int kk = threadIdx.x / kMaxT, t = threadIdx.x % kMaxT;
-#pragma unroll 8
-  for (int rr = 0; rr < 256; ++rr) acc = __builtin_fmaf(sL[rr * kMaxK + kk], sR[rr * kMaxT + t], acc);
-  return acc;
-}
-
-__device__ __forceinline__ void load_L_tile(const float *__restrict__ L, float *__restrict__ sL, long long row0,
-                                            long long N, int K) {
-  for (int e = threadIdx.x; e < 256 * kMaxK; e += 256) {
-    const int rr = e / kMaxK, kk = e % kMaxK;
-    sL[e] = (kk < K && row0 + rr < N) ? L[(row0 + rr) * K + kk] : 0.f;
-  }
-}
-
-// partial_w[blk][kk][t] = sum over the block's rows of L[i][kk] r[i][t]       (L: N x K row-major); first iterate only
-__global__ __launch_bounds__(256) void k_Ltr(const float *__restrict__ L, const float *__restrict__ r,
-                                             float *__restrict__ partial_w, long long N, int T, int K) {
-  __shared__ float sL[256 * kMaxK];
-  __shared__ float sR[256 * kMaxT];
-  float acc = 0.f;
-  for (long long tile = blockIdx.x, nt = (N + 255) / 256; tile < nt; tile += gridDim.x) {
-    const long long row0 = tile * 256;
-    __syncthreads();
-    load_L_tile(L, sL, row0, N, K);
-    for (int e = threadIdx.x; e < 256 * kMaxT; e += 256) {
-      const int rr = e / kMaxT, t = e % kMaxT;
-      sR[e] = (t < T && row0 + rr < N) ? r[(row0 + rr) * T + t] : 0.f;
-    }
-    __syncthreads();
-    acc = ltr_tile(sL, sR, acc);
-  }
-  const int kk = threadIdx.x / kMaxT, t = threadIdx.x % kMaxT;
-  if (kk < K && t < T) partial_w[((size_t)blockIdx.x * K + kk) * T + t] = acc;
-}
-
-// z = M^-1 r with M = L L^T + sigma2 I (Woodbury, Cinv = (sigma2 I + L^T L)^-1), partial_rz = sum r.z
-// tv[a][t] = sum_b Cinv[a][b] * (sum over the producer's workgroups of partial_w[.][b][t]) in float64, ONE workgroup per
-// column t.  This used to be the prologue of EVERY k_precond workgroup (each re-reading all K x T slabs: 60 of that
-// kernel's 70 us at N = 391k); as its own launch (grid = T) it costs ~5 us and lets the streaming kernels use as many
-// workgroups as the HBM stream wants.  Thread (g = tid / 16, b = tid % 16): 16 groups take every 16th slab.
-__global__ __launch_bounds__(256) void k_wsolve(const float *__restrict__ partial_w, int nparts_w,
-                                                const double *__restrict__ Cinv, double *__restrict__ tv, int T, int K) {
-  __shared__ double part[16][kMaxK];
-  __shared__ double sw[kMaxK];
-  const int t = blockIdx.x;
-  const int b = threadIdx.x & 15, g = threadIdx.x >> 4;
-  double s = 0.0;
-  if (b < K) {
-    int p = g;
-    for (; p + 48 < nparts_w; p += 64) {
-      const float v0 = partial_w[((size_t)p * K + b) * T + t], v1 = partial_w[((size_t)(p + 16) * K + b) * T + t];
-      const float v2 = partial_w[((size_t)(p + 32) * K + b) * T + t], v3 = partial_w[((size_t)(p + 48) * K + b) * T + t];
-      s += (double)v0;
-      s += (double)v1;
-      s += (double)v2;
-      s += (double)v3;
-    }
-    for (; p < nparts_w; p += 16) s += (double)partial_w[((size_t)p * K + b) * T + t];
-    part[g][b] = s;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < K) {
-    double tot = 0.0;
+  const float nrm = snrm[ln.c];
+  floatx4m lt = {0.f, 0.f, 0.f, 0.f};
+  const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+  const long long ntiles = (N + 255) / 256;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long w0 = tile * 256 + 64 * ln.wave;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) tot += part[q][threadIdx.x];
-    sw[threadIdx.x] = tot;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < K) {
-    double acc = 0.0;
-    for (int c = 0; c < K; ++c) acc += Cinv[threadIdx.x * K + c] * sw[c];
-    tv[threadIdx.x * kMaxT + t] = acc;
-  }
-}
-
-// z = M^-1 r = (r - L tv) / sigma2 with tv = Cinv L^T r from k_wsolve (float64: the subtraction cancels to ~sigma^2 / |K|
-// of r along the range of L); partial r.z per workgroup.   K == 0: identity preconditioner (z = r)
-template <int TT>
-__global__ __launch_bounds__(256) void k_precond(const float *__restrict__ L, const double *__restrict__ tv,
-                                                 const float *__restrict__ r, float *__restrict__ z,
-                                                 float *__restrict__ partial_rz, long long N, int K, float sigma2) {
-  __shared__ double stv[kMaxK * kMaxT];
-  __shared__ float sh[4];
-  if (K > 0) {
-    for (int e = threadIdx.x; e < kMaxK * kMaxT; e += 256) stv[e] = (e / kMaxT < K && e % kMaxT < TT) ? tv[e] : 0.0;
-    __syncthreads();
-  }
-  float acc[TT];
+    for (int bk = 0; bk < 4; ++bk) {
+      const long long R0 = w0 + 16 * bk;
+      float rv[4], lv[4];
+      load_block<TT>(rhs, R0, N, ln, rv);
+      if (K > 0) load_L_rows(L, R0, N, K, ln, lv);
 #pragma unroll
-  for (int t = 0; t < TT; ++t) acc[t] = 0.f;
-  const double inv_s = K > 0 ? 1.0 / (double)sigma2 : 1.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
-    float rv[TT];
+      for (int q = 0; q < 4; ++q) rv[q] = rv[q] / nrm;
+      store_block<TT>(r, R0, N, ln, rv);
+      store_block<TT>(x, R0, N, ln, zero4);
+      store_block<TT>(p, R0, N, ln, zero4);
+      store_block<TT>(Ap, R0, N, ln, zero4);
+      if (K > 0) {
 #pragma unroll
-    for (int t = 0; t < TT; ++t) rv[t] = r[i * TT + t];
-    float zv[TT];
-    if (K > 0) {
-      double corr[TT];
-#pragma unroll
-      for (int t = 0; t < TT; ++t) corr[t] = 0.0;
-      for (int b = 0; b < K; ++b) {
-        const double lb = (double)L[i * K + b];
-#pragma unroll
-        for (int t = 0; t < TT; ++t) corr[t] = fma(lb, stv[b * kMaxT + t], corr[t]);
+        for (int q = 0; q < 4; ++q) lt = __builtin_amdgcn_mfma_f32_16x16x4f32(lv[q], rv[q], lt, 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < TT; ++t) zv[t] = (float)(((double)rv[t] - corr[t]) * inv_s);
-    } else {
-#pragma unroll
-      for (int t = 0; t < TT; ++t) zv[t] = rv[t];
-    }
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      z[i * TT + t] = zv[t];
-      acc[t] = __builtin_fmaf(rv[t], zv[t], acc[t]);
     }
   }
-#pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    const float s = block_sum(acc[t], sh);
-    if (threadIdx.x == 0) partial_rz[(size_t)blockIdx.x * TT + t] = s;
-  }
+  float *dst = part + (size_t)blockIdx.x * kRedW;
+  __syncthreads();
+  if (threadIdx.x < 32) dst[threadIdx.x] = 0.f;
+  block_ltsum(lt, sh, dst + kRedLt, ln);
 }
 
-// first direction: p = z, rz = sum partial_rz
-__global__ __launch_bounds__(256) void k_first_dir(const float *__restrict__ z, float *__restrict__ p,
-                                                   const float *__restrict__ partial_rz, int nparts,
-                                                   CgState *__restrict__ st, long long N, int T) {
-  __shared__ float srz[kMaxT];
-  __shared__ float scratch[256];
-  if (blockIdx.x == 0) {
-    reduce_partials(partial_rz, nparts, T, srz, scratch);
-    if ((int)threadIdx.x < T) {
-      st->rz[0][threadIdx.x] = srz[threadIdx.x];
-      st->resid[threadIdx.x] = 1.0f;
-    }
-  }
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N * T; i += (long long)gridDim.x * 256) p[i] = z[i];
-}
-
-// alpha = rz / pAp (guarded); x += alpha p; r -= alpha Ap; partial |r|^2; partial L^T r for the preconditioner.
-// After convergence (st->poll.done) alpha = 0: iterations the host had already enqueued leave x and r untouched.
+// ---- pass B -----------------------------------------------------------------------------------------------------------
+// alpha = rz / pAp (guarded; 0 after convergence, so iterations the host had already enqueued leave x and r untouched);
+// x += alpha p; r -= alpha Ap; z = M^-1 r (Woodbury, float64 correction); partial |r|^2, r.z, L^T r.
+// first != 0: the set-up call (alpha = 0, w = L^T r0 as reduced by k_init).
 template <int TT>
-__global__ __launch_bounds__(256) void k_update(const float *__restrict__ p, const float *__restrict__ Ap,
-                                                const float *__restrict__ partial_pAp, int nparts,
-                                                float *__restrict__ x, float *__restrict__ r,
-                                                float *__restrict__ partial_rr, const CgState *__restrict__ st,
-                                                float *__restrict__ alpha_out, const float *__restrict__ L,
-                                                float *__restrict__ partial_w, long long N, int K, float eps,
-                                                float stop_after, int cur) {
-  constexpr int T = TT;
-  __shared__ float spAp[kMaxT];
+__global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, const float *__restrict__ Ap,
+                                                float *__restrict__ x, float *__restrict__ r, float *__restrict__ z,
+                                                const float *__restrict__ L, const double *__restrict__ Cinv,
+                                                const double *__restrict__ redA, const double *__restrict__ redB,
+                                                float *__restrict__ part, const CgState *__restrict__ st,
+                                                float *__restrict__ alpha_out, long long N, int K, float sigma2,
+                                                float eps, float stop_after, int cur, int first) {
+  __shared__ float sh[1024];
+  __shared__ double sW[256];
+  __shared__ double sTv[256];
   __shared__ float salpha[kMaxT];
-  __shared__ float sh[4];
-  __shared__ float sR[256 * kMaxT];      // doubles as the reduce_partials scratch before the first tile
-  __shared__ float sL[256 * kMaxK];
-  reduce_partials(partial_pAp, nparts, T, spAp, sR);
-  if ((int)threadIdx.x < T) {
-    const float s = spAp[threadIdx.x];
-    float a = (fabsf(s) > eps) ? st->rz[cur][threadIdx.x] / s : 0.f;
-    if (st->resid[threadIdx.x] < stop_after || st->rhs_zero[threadIdx.x] || st->poll.done) a = 0.f;
+  const Lane ln;
+  if (threadIdx.x < kMaxT) {
+    float a = 0.f;
+    if (!first && threadIdx.x < TT) {
+      const float s = (float)redA[threadIdx.x];
+      a = (fabsf(s) > eps) ? st->rz[cur][threadIdx.x] / s : 0.f;
+      if (st->resid[threadIdx.x] < stop_after || st->rhs_zero[threadIdx.x] || st->poll.done) a = 0.f;
+    }
     salpha[threadIdx.x] = a;
-    if (blockIdx.x == 0) alpha_out[threadIdx.x] = a;
+    if (blockIdx.x == 0 && !first && threadIdx.x < TT) alpha_out[threadIdx.x] = a;
   }
   __syncthreads();
-  float acc[kMaxT];
-#pragma unroll
-  for (int t = 0; t < kMaxT; ++t) acc[t] = 0.f;
-  float accw = 0.f;
-  for (long long tile = blockIdx.x, nt = (N + 255) / 256; tile < nt; tile += gridDim.x) {
-    const long long row0 = tile * 256;
-    const long long i = row0 + threadIdx.x;
-    if (K > 0) {
-      __syncthreads();                     // previous tile's ltr_tile is done with sL / sR
-      load_L_tile(L, sL, row0, N, K);
-    }
-    float rvv[kMaxT];
-#pragma unroll
-    for (int t = 0; t < kMaxT; ++t) rvv[t] = 0.f;
-    if (i < N) {
-      float pv[TT], apv[TT], xv[TT], rr_[TT];
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {          // all loads of the row first, unconditional
-        pv[t] = p[i * TT + t];
-        apv[t] = Ap[i * TT + t];
-        xv[t] = x[i * TT + t];
-        rr_[t] = r[i * TT + t];
-      }
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        const float a = salpha[t];
-        x[i * TT + t] = __builtin_fmaf(a, pv[t], xv[t]);
-        const float rv = __builtin_fmaf(-a, apv[t], rr_[t]);
-        r[i * TT + t] = rv;
-        rvv[t] = rv;
-        acc[t] = __builtin_fmaf(rv, rv, acc[t]);
-      }
-    }
-    if (K > 0) {
-#pragma unroll
-      for (int t = 0; t < kMaxT; ++t) sR[threadIdx.x * kMaxT + t] = rvv[t];
-    }
-    if (K > 0) {
-      __syncthreads();
-      accw = ltr_tile(sL, sR, accw);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < kMaxT; ++t) {
-    if (t < T) {
-      const float s = block_sum(acc[t], sh);
-      if (threadIdx.x == 0) partial_rr[(size_t)blockIdx.x * T + t] = s;
-    }
-  }
+  double tvB[4] = {0.0, 0.0, 0.0, 0.0};
   if (K > 0) {
-    const int kk = threadIdx.x / kMaxT, t = threadIdx.x % kMaxT;
-    if (kk < K && t < T) partial_w[((size_t)blockIdx.x * K + kk) * T + t] = accw;
+    const int kk = threadIdx.x >> 4, t = threadIdx.x & 15;
+    // w = L^T r of the residual this pass is about to form: direct value of the previous pass, one recurrence step
+    double w = redB[kRedLt + threadIdx.x];
+    if (!first) w -= (double)salpha[t] * redA[kRedLt + threadIdx.x];
+    sW[threadIdx.x] = w;
+    __syncthreads();
+    double tv = 0.0;
+    if (kk < K && t < TT)
+      for (int cc = 0; cc < K; ++cc) tv = fma(Cinv[kk * K + cc], sW[cc * 16 + t], tv);
+    sTv[threadIdx.x] = tv;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tvB[s] = sTv[(4 * s + ln.q) * 16 + ln.c];
   }
+  const float a = salpha[ln.c];
+  const double inv_s = K > 0 ? 1.0 / (double)sigma2 : 1.0;
+  float acc_rr = 0.f, acc_rz = 0.f;
+  floatx4m lt = {0.f, 0.f, 0.f, 0.f};
+  const long long ntiles = (N + 255) / 256;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long w0 = tile * 256 + 64 * ln.wave;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float pv[2][4], av[2][4], xv[2][4], rv[2][4], lr[2][4], lc[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const long long R0 = w0 + 16 * (2 * half + h);
+        load_block<TT>(p, R0, N, ln, pv[h]);
+        load_block<TT>(Ap, R0, N, ln, av[h]);
+        load_block<TT>(x, R0, N, ln, xv[h]);
+        load_block<TT>(r, R0, N, ln, rv[h]);
+        if (K > 0) {
+          load_L_rows(L, R0, N, K, ln, lr[h]);
+          load_L_cols(L, R0, N, K, ln, lc[h]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const long long R0 = w0 + 16 * (2 * half + h);
+        float rn[4], xn[4], zn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          xn[q] = __builtin_fmaf(a, pv[h][q], xv[h][q]);
+          rn[q] = __builtin_fmaf(-a, av[h][q], rv[h][q]);
+        }
+        if (K > 0) {
+          doublex4m corr = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) corr = __builtin_amdgcn_mfma_f64_16x16x4f64((double)lc[h][s], tvB[s], corr, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) zn[q] = (float)(((double)rn[q] - corr[q]) * inv_s);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) lt = __builtin_amdgcn_mfma_f32_16x16x4f32(lr[h][q], rn[q], lt, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) zn[q] = rn[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc_rr = __builtin_fmaf(rn[q], rn[q], acc_rr);
+          acc_rz = __builtin_fmaf(rn[q], zn[q], acc_rz);
+        }
+        if (!first) {
+          store_block<TT>(x, R0, N, ln, xn);
+          store_block<TT>(r, R0, N, ln, rn);
+        }
+        if (K > 0 || first) store_block<TT>(z, R0, N, ln, zn);     // identity preconditioner: pass C reads r as z
+      }
+    }
+  }
+  float *dst = part + (size_t)blockIdx.x * kRedW;
+  block_colsum(acc_rr, sh, dst, ln);
+  block_colsum(acc_rz, sh, dst + 16, ln);
+  block_ltsum(lt, sh, dst + kRedLt, ln);
 }
 
-// beta = rz' / rz; p = z + beta p; bookkeeping (block 0): rz <- rz', resid, mean residual, beta history, and — on the
+// ---- pass C -----------------------------------------------------------------------------------------------------------
+// beta = rz' / rz; p = z + beta p; bookkeeping (workgroup 0): rz <- rz', resid, mean residual, beta history, and — on the
 // iterations the host marks with check_now — the convergence decision (st->poll.done), which freezes later iterations.
+// Best-iterate safeguard: fp32 CG on a system with cond(Khat) * 1e-6 >~ 1 (N s / sigma^2 beyond a few million) does not
+// merely stall, its recurrence residual can GROW; the iterate with the smallest tested residual is kept in x_best (every
+// workgroup takes the same decision from the same reduced numbers) and returned when the tolerance is never reached.
+// first != 0: the set-up call (p = z, rz[0] = rz').
 template <int TT>
-__global__ __launch_bounds__(256) void k_direction(const float *__restrict__ z, float *__restrict__ p,
-                                                   const float *__restrict__ partial_rz, const float *__restrict__ partial_rr,
-                                                   int nparts, int nparts_rr, CgState *__restrict__ st,
-                                                   float *__restrict__ beta_out,
-                                                   long long N, float eps, int cur, int check_now,
-                                                   float tolerance, int iter_count, int stagnation_window,
-                                                   const float *__restrict__ x, float *__restrict__ x_best) {
-  constexpr int T = TT;
-  // Best-iterate safeguard: fp32 CG on a system with cond(Khat) * 1e-6 >~ 1 (N s / sigma^2 beyond a few million) does not
-  // merely stall, its recurrence residual can GROW; the iterate with the smallest tested residual is kept in x_best (every
-  // workgroup takes the same decision from the same reduced numbers) and returned when the tolerance is never reached.
-  __shared__ float srzn[kMaxT];
-  __shared__ float srr[kMaxT];
+__global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, float *__restrict__ p,
+                                                const double *__restrict__ redB, CgState *__restrict__ st,
+                                                float *__restrict__ beta_out, long long N, float eps, int cur, int first,
+                                                int check_now, float tolerance, int iter_count, int stagnation_window,
+                                                const float *__restrict__ x, float *__restrict__ x_best) {
   __shared__ float sbeta[kMaxT];
   __shared__ float sres[kMaxT];
-  __shared__ float scratch[256];
+  __shared__ float srzn[kMaxT];
+  const Lane ln;
   const int was_done = st->poll.done;
-  reduce_partials(partial_rz, nparts, T, srzn, scratch);
-  reduce_partials(partial_rr, nparts_rr, T, srr, scratch);
-  if ((int)threadIdx.x < T) {
-    const float rz = st->rz[cur][threadIdx.x];
-    sbeta[threadIdx.x] = (fabsf(rz) > eps) ? srzn[threadIdx.x] / rz : 0.f;
-    sres[threadIdx.x] = st->rhs_zero[threadIdx.x] ? 0.f : sqrtf(srr[threadIdx.x]);
+  if (threadIdx.x < kMaxT) {
+    float beta = 0.f, res = 0.f, rzn = 0.f;
+    if (threadIdx.x < TT) {
+      rzn = (float)redB[16 + threadIdx.x];
+      const float rz = st->rz[cur][threadIdx.x];
+      beta = (!first && fabsf(rz) > eps) ? rzn / rz : 0.f;
+      res = st->rhs_zero[threadIdx.x] ? 0.f : sqrtf((float)redB[threadIdx.x]);
+    }
+    sbeta[threadIdx.x] = beta;
+    sres[threadIdx.x] = res;
+    srzn[threadIdx.x] = rzn;
   }
   __syncthreads();
-  if (was_done) return;
+  if (was_done && !first) return;
   float mres = 0.f;
-  for (int t = 0; t < T; ++t) mres += sres[t];
-  mres /= (float)T;
+  for (int t = 0; t < TT; ++t) mres += sres[t];
+  mres /= (float)TT;
   const float snap_prev = st->snap_resid[cur];
-  const bool improved = check_now && mres == mres && mres < snap_prev;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
-    float pv[TT], zv[TT];
+  const bool improved = !first && check_now && mres == mres && mres < snap_prev;
+  const float beta = sbeta[ln.c];
+  const long long ntiles = (N + 255) / 256;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long w0 = tile * 256 + 64 * ln.wave;
+    float pv[4][4], zv[4][4];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) { pv[t] = p[i * TT + t]; zv[t] = z[i * TT + t]; }
+    for (int bk = 0; bk < 4; ++bk) {
+      load_block<TT>(p, w0 + 16 * bk, N, ln, pv[bk]);
+      load_block<TT>(z, w0 + 16 * bk, N, ln, zv[bk]);
+    }
 #pragma unroll
-    for (int t = 0; t < TT; ++t) p[i * TT + t] = __builtin_fmaf(sbeta[t], pv[t], zv[t]);
+    for (int bk = 0; bk < 4; ++bk) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pv[bk][q] = __builtin_fmaf(beta, pv[bk][q], zv[bk][q]);
+      store_block<TT>(p, w0 + 16 * bk, N, ln, pv[bk]);
+    }
     if (improved) {
 #pragma unroll
-      for (int t = 0; t < TT; ++t) x_best[i * TT + t] = x[i * TT + t];
+      for (int bk = 0; bk < 4; ++bk) {
+        float xv[4];
+        load_block<TT>(x, w0 + 16 * bk, N, ln, xv);
+        store_block<TT>(x_best, w0 + 16 * bk, N, ln, xv);
+      }
     }
   }
   if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !first) {
       st->snap_resid[cur ^ 1] = improved ? mres : snap_prev;
       st->poll.snap_slot = cur ^ 1;
       st->poll.snap_cur = improved ? mres : snap_prev;
     }
-    if ((int)threadIdx.x < T) {
-      st->rz[cur ^ 1][threadIdx.x] = srzn[threadIdx.x];
-      st->resid[threadIdx.x] = sres[threadIdx.x];
-      beta_out[threadIdx.x] = sbeta[threadIdx.x];
+    if (threadIdx.x < TT) {
+      st->rz[first ? 0 : (cur ^ 1)][threadIdx.x] = srzn[threadIdx.x];
+      if (!first) {
+        st->resid[threadIdx.x] = sres[threadIdx.x];
+        beta_out[threadIdx.x] = sbeta[threadIdx.x];
+      }
     }
-    if (threadIdx.x == 0) {
-      float m = 0.f;
-      for (int t = 0; t < T; ++t) m += sres[t];
-      m /= (float)T;
+    if (threadIdx.x == 0 && !first) {
+      const float m = mres;
       st->poll.mean_resid = m;
       if (check_now) {
         if (m != m) {
@@ -471,13 +505,13 @@ __global__ __launch_bounds__(256) void k_unnormalise(float *__restrict__ x, cons
                                                      const CgState *__restrict__ st, long long N, int T) {
   const float snap = st->snap_resid[st->poll.snap_slot];
   const bool use_best = st->poll.done != 1 && snap < st->poll.mean_resid;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
-    for (int t = 0; t < T; ++t) x[i * T + t] = (use_best ? x_best[i * T + t] : x[i * T + t]) * st->rhs_norm[t];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < N * T; e += (long long)gridDim.x * 256)
+    x[e] = (use_best ? x_best[e] : x[e]) * st->rhs_norm[e % T];
 }
 
-inline int nblocks_for(long long N, int cap = kMaxBlocks) {
+inline int nblocks_for(long long N) {
   long long b = (N + 255) / 256;      // one 256-row tile per workgroup until the partial-sum slabs are full
-  if (b > cap) b = cap;
+  if (b > kMaxBlocks) b = kMaxBlocks;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -503,40 +537,98 @@ struct PollCtx {
 };
 thread_local PollCtx g_poll;
 
-int apply_operator(const rpgp_operator *op, const float *V, float *out, int T, void *ws, size_t ws_bytes, void *stream) {
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ShardCtx {
+  int mode = RPGP_SHARD_NONE, world = 1, rank = 0;
+  rpgp_allreduce_fn fn = nullptr;
+  void *ctx = nullptr;
+  double *hist = nullptr;        // row mode: J x G x T float64 grid histogram
+  float *H = nullptr;            // row mode: J x G x T Toeplitz product
+  int reduce(void *buf, size_t count, int dtype, void *stream) const {
+    if (!fn) return 0;
+    return fn(ctx, buf, count, dtype, stream);
+  }
+};
+
+// one application of the operator.  RPGP_SHARD_PARTIAL: this rank's partial product (noise on rank 0 only), summed over
+// the ranks; RPGP_SHARD_ROWS (SKI): scatter the local rows, all-reduce the histogram, replicated Toeplitz product, gather
+// the local rows.
+int apply_operator(const rpgp_operator *op, const ShardCtx &sh, const float *V, float *out, int T, void *ws, size_t ws_bytes,
+                   void *stream) {
+  const bool partial = sh.mode == RPGP_SHARD_PARTIAL;
+  const float noise = (partial && sh.rank != 0) ? 0.f : op->noise;
+  const int world = op->world > 0 ? op->world : 1, rank = op->world > 0 ? op->rank : 0;
+  int rc;
   switch (op->kind) {
     case RPGP_OP_FUSED:
-      return rpgp_mvm_sym(op->Z, V, out, op->N, op->ldz, T, op->j0, op->j1, op->scale, op->noise, ws, ws_bytes, stream);
+      if (op->j1 <= op->j0) {       // J-sharding with more ranks than projections: an empty slice
+        CG_CHECK(hipMemsetAsync(out, 0, (size_t)op->N * T * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
+        rc = 0;
+      } else {
+        rc = rpgp_mvm_sym_range(op->Z, V, out, op->N, op->ldz, T, op->j0, op->j1, world, rank, op->scale, noise, ws, ws_bytes,
+                                stream);
+      }
+      break;
     case RPGP_OP_FUSED_PREPARED:
-      return rpgp_mvm_sym_prepared(op->prep, V, out, op->N, op->J, T, op->j0, op->j1, op->scale, op->noise, ws, ws_bytes,
-                                   stream);
+      if (op->j1 <= op->j0) {
+        CG_CHECK(hipMemsetAsync(out, 0, (size_t)op->N * T * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
+        rc = 0;
+      } else {
+        rc = rpgp_mvm_sym_prepared_range(op->prep, V, out, op->N, op->J, T, op->j0, op->j1, world, rank, op->scale, noise,
+                                         ws, ws_bytes, stream);
+      }
+      break;
     case RPGP_OP_SKI:
-      return rpgp_ski_mvm(op->Z, op->Z, op->grid_params, V, out, op->N, op->N, op->ldz, op->ldz, op->J, op->G, T,
-                          op->scale, op->noise, ws, ws_bytes, stream);
-    case RPGP_OP_DENSE:
-      return rpgp_dense_mvm(op->Kd, V, out, op->N, op->ldk, T, op->noise, stream);
-    case RPGP_OP_SYMCACHE:
-      return rpgp_symcache_mvm(op->Kd, (size_t)op->ldk, op->G, V, out, op->N, T, op->scale, op->noise, 1, 0, ws, ws_bytes,
+      if (sh.mode == RPGP_SHARD_ROWS) {
+        const size_t nh = (size_t)op->J * op->G * T;
+        if (op->N > 0) {
+          rc = rpgp_ski_scatter(op->Z, op->grid_params, V, sh.hist, op->N, op->ldz, op->J, op->G, T, ws, ws_bytes, stream);
+          if (rc) return rc;
+        } else {
+          CG_CHECK(hipMemsetAsync(sh.hist, 0, nh * sizeof(double), reinterpret_cast<hipStream_t>(stream)));
+        }
+        rc = sh.reduce(sh.hist, nh, RPGP_F64, stream);
+        if (rc) return rc;
+        if (op->N <= 0) return 0;
+        rc = rpgp_ski_grid_product(sh.hist, op->grid_params, sh.H, op->J, op->G, T, stream);
+        if (rc) return rc;
+        return rpgp_ski_gather(op->Z, op->grid_params, sh.H, V, out, op->N, op->ldz, op->J, op->G, T, op->scale, op->noise,
                                stream);
+      }
+      rc = rpgp_ski_mvm(op->Z, op->Z, op->grid_params, V, out, op->N, op->N, op->ldz, op->ldz, op->J, op->G, T, op->scale,
+                        noise, ws, ws_bytes, stream);
+      break;
+    case RPGP_OP_DENSE:
+      rc = rpgp_dense_mvm(op->Kd, V, out, op->N, op->ldk, T, noise, stream);
+      break;
+    case RPGP_OP_SYMCACHE:
+      rc = rpgp_symcache_mvm(op->Kd, (size_t)op->ldk, op->G, V, out, op->N, T, op->scale, noise, world, rank, ws, ws_bytes,
+                             stream);
+      break;
     case RPGP_OP_FAMILY:
-      return rpgp_family_mvm_sym(op->family, op->Z, V, out, op->N, op->ldz, T, op->scale, op->noise, ws, ws_bytes,
-                                 stream);
+      rc = rpgp_family_mvm_sym(op->family, op->Z, V, out, op->N, op->ldz, T, op->scale, noise, ws, ws_bytes, stream);
+      break;
     default:
       return RPGP_EINVAL;
   }
+  if (rc) return rc;
+  if (partial) return sh.reduce(out, (size_t)op->N * T, RPGP_F32, stream);
+  return 0;
 }
 
 size_t operator_workspace(const rpgp_operator *op, int T) {
+  const int world = op->world > 0 ? op->world : 1, rank = op->world > 0 ? op->rank : 0;
   switch (op->kind) {
     case RPGP_OP_FUSED:
     case RPGP_OP_FUSED_PREPARED:
-      return rpgp_mvm_sym_workspace_bytes(op->N, T);
+      return rpgp_mvm_sym_range_workspace_bytes(op->N, T, world, rank);
     case RPGP_OP_SKI:
       return rpgp_ski_workspace_bytes(op->J, op->G, T);
     case RPGP_OP_DENSE:
       return 256;
     case RPGP_OP_SYMCACHE:
-      return rpgp_symcache_workspace_bytes(op->N, T, 1, 0);
+      return rpgp_symcache_workspace_bytes(op->N, T, world, rank);
     case RPGP_OP_FAMILY:
       return rpgp_family_mvm_workspace_bytes(op->N, op->N, T, 1);
     default:
@@ -544,39 +636,62 @@ size_t operator_workspace(const rpgp_operator *op, int T) {
   }
 }
 
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline size_t ski_stage_bytes(const rpgp_operator *op, int T) {
+  if (op->kind != RPGP_OP_SKI) return 0;
+  const size_t nh = (size_t)op->J * op->G * T;
+  return align256(nh * sizeof(double)) + align256(nh * sizeof(float));
+}
 
 }  // namespace
 
 extern "C" {
 
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank) {
-  if (!op || T <= 0 || T > kMaxT || precond_rank < 0 || precond_rank > kMaxK) return 0;
-  const size_t nt = (size_t)op->N * T * sizeof(float);
+  if (!op || T <= 0 || T > kMaxT || precond_rank < 0 || precond_rank > kMaxK || op->N < 0) return 0;
+  const size_t nt = (size_t)(op->N > 0 ? op->N : 1) * T * sizeof(float);
   size_t total = 5 * align256(nt);                                             // r, p, z, Ap, x_best
   total += align256(sizeof(CgState));
-  total += 3 * align256((size_t)kMaxBlocks * kMaxT * sizeof(float));           // partial pAp / rr / rz
-  total += align256((size_t)kMaxBlocksW * kMaxK * kMaxT * sizeof(float));      // partial L^T r
-  total += align256((size_t)kMaxK * kMaxT * sizeof(double));                   // tv = Cinv L^T r
+  total += align256((size_t)kMaxBlocks * kRedW * sizeof(float));               // per-workgroup partials
+  total += 2 * align256((size_t)kRedW * sizeof(double));                       // reduced vectors A / B
   total += 2 * align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));       // alpha / beta history
+  total += ski_stage_bytes(op, T);
   total += align256(operator_workspace(op, T));
   return total;
 }
 
 int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,
                     int hist_len, int check_every, int stagnation_window, float tolerance, int precond_rank,
-                    const float *L,
-                    const double *Cinv, float precond_sigma2, float *alpha_hist_host, float *beta_hist_host,
-                    int *iterations_host, float *mean_resid_host, void *workspace, size_t workspace_bytes, void *stream) {
+                    const float *L, const double *Cinv, float precond_sigma2, const rpgp_reducer *reducer,
+                    float *alpha_hist_host, float *beta_hist_host, int *iterations_host, float *mean_resid_host,
+                    void *workspace, size_t workspace_bytes, void *stream) {
   if (!op || !rhs || !x || T <= 0 || T > kMaxT || max_iter < 0 || hist_len < 0 || check_every <= 0 ||
-      precond_rank < 0 || precond_rank > kMaxK || (precond_rank > 0 && (!L || !Cinv)) || op->N <= 0)
+      precond_rank < 0 || precond_rank > kMaxK || (precond_rank > 0 && (!L || !Cinv)) || op->N < 0)
     return RPGP_EINVAL;
   if (hist_len > kMaxHist || (hist_len > 0 && (!alpha_hist_host || !beta_hist_host))) return RPGP_EINVAL;
+  ShardCtx sh;
+  long long global_N = op->N;
+  if (reducer && reducer->mode != RPGP_SHARD_NONE && reducer->fn) {      // (world == 1 still goes through the hook)
+    if ((reducer->mode != RPGP_SHARD_PARTIAL && reducer->mode != RPGP_SHARD_ROWS) || reducer->world < 1 ||
+        reducer->rank < 0 || reducer->rank >= reducer->world)
+      return RPGP_EINVAL;
+    if (reducer->mode == RPGP_SHARD_ROWS && (op->kind != RPGP_OP_SKI || T > 12 || reducer->global_N < op->N))
+      return RPGP_EINVAL;
+    if (reducer->mode == RPGP_SHARD_PARTIAL && op->kind != RPGP_OP_FUSED && op->kind != RPGP_OP_FUSED_PREPARED &&
+        op->kind != RPGP_OP_SYMCACHE)
+      return RPGP_EINVAL;
+    sh.mode = reducer->mode;
+    sh.world = reducer->world;
+    sh.rank = reducer->rank;
+    sh.fn = reducer->fn;
+    sh.ctx = reducer->ctx;
+    if (sh.mode == RPGP_SHARD_ROWS) global_N = reducer->global_N;
+  }
+  if (op->N <= 0 && sh.mode != RPGP_SHARD_ROWS) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_mbcg_workspace_bytes(op, T, precond_rank)) return RPGP_EWORKSPACE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long long N = op->N;
   const int K = precond_rank;
-  const size_t nt = (size_t)N * T * sizeof(float);
+  const size_t nt = (size_t)(N > 0 ? N : 1) * T * sizeof(float);
 
   char *w = reinterpret_cast<char *>(workspace);
   float *r = reinterpret_cast<float *>(w); w += align256(nt);
@@ -585,61 +700,75 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   float *Ap = reinterpret_cast<float *>(w); w += align256(nt);
   float *x_best = reinterpret_cast<float *>(w); w += align256(nt);
   CgState *state = reinterpret_cast<CgState *>(w); w += align256(sizeof(CgState));
-  float *part_a = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxT * sizeof(float));
-  float *part_rr = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxT * sizeof(float));
-  float *part_rz = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kMaxT * sizeof(float));
-  float *part_w = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocksW * kMaxK * kMaxT * sizeof(float));
-  double *tv = reinterpret_cast<double *>(w); w += align256((size_t)kMaxK * kMaxT * sizeof(double));
+  float *part = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kRedW * sizeof(float));
+  double *redA = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
+  double *redB = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
   float *alpha_d = reinterpret_cast<float *>(w); w += align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));
   float *beta_d = reinterpret_cast<float *>(w); w += align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));
+  if (op->kind == RPGP_OP_SKI) {
+    const size_t nh = (size_t)op->J * op->G * T;
+    sh.hist = reinterpret_cast<double *>(w); w += align256(nh * sizeof(double));
+    sh.H = reinterpret_cast<float *>(w); w += align256(nh * sizeof(float));
+  }
   void *op_ws = w;
   const size_t op_ws_bytes = operator_workspace(op, T);
+  const bool rows = sh.mode == RPGP_SHARD_ROWS;
 
-  // At N = 391k the 17 MB vectors make these kernels HBM streams: up to 1024 workgroups (4 per CU); the K x T
-  // preconditioner partials are reduced once per iteration by k_wsolve instead of by every consumer workgroup.
   const int nb = nblocks_for(N);
-  const int nbw = nblocks_for(N, kMaxBlocksW);
+  const int nred = kRedW / 16;
   const float eps = 1e-30f, stop_after = 1e-10f;
   {
     const int prc = g_poll.init();
     if (prc) return prc;
   }
   CgPoll *hpoll = g_poll.host;
+  // with the identity preconditioner z IS r: pass B skips the store and pass C reads r
+  float *zsrc = K > 0 ? z : r;
 
-  // normalise right-hand sides, x = 0
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_coldot<TT>), dim3(nb), dim3(256), 0, st, rhs, rhs, part_a, N));
-  hipLaunchKernelGGL(k_normalise, dim3(nb), dim3(256), 0, st, rhs, part_a, nb, r, x, state, N, T);
-  // z0 = M^-1 r0, p0 = z0, rz0
-  if (K > 0) hipLaunchKernelGGL(k_Ltr, dim3(nbw), dim3(256), 0, st, L, r, part_w, N, T, K);
-  if (K > 0) hipLaunchKernelGGL(k_wsolve, dim3(T), dim3(256), 0, st, part_w, nbw, Cinv, tv, T, K);
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_precond<TT>), dim3(nb), dim3(256), 0, st, L, tv, r, z, part_rz, N, K, precond_sigma2));
-  hipLaunchKernelGGL(k_first_dir, dim3(nb), dim3(256), 0, st, z, p, part_rz, nb, state, N, T);
+#define CG_REDUCE(dst_)                                                                              \
+  do {                                                                                               \
+    hipLaunchKernelGGL(k_reduce, dim3(nred), dim3(256), 0, st, part, nb, dst_);                      \
+    if (rows) {                                                                                      \
+      const int rrc_ = sh.reduce(dst_, kRedW, RPGP_F64, stream);                                     \
+      if (rrc_) return rrc_;                                                                         \
+    }                                                                                                \
+  } while (0)
+
+  // set-up: |rhs| per column; r = rhs / |rhs|, x = p = Ap = 0, w0 = L^T r0; z0 = M^-1 r0, rz0; p0 = z0
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nb), dim3(256), 0, st, rhs, rhs, L, part, N, 0));
+  CG_REDUCE(redA);
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_init<TT>), dim3(nb), dim3(256), 0, st, rhs, redA, r, x, p, Ap, L, part, state, N, K));
+  CG_REDUCE(redB);
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB, part,
+                                      state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1));
+  CG_REDUCE(redB);
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nb), dim3(256), 0, st, z, p, redB, state, beta_d, N, eps, 0, 1, 0,
+                                      tolerance, 0, 0, x, x_best));
   CG_CHECK(hipGetLastError());
 
   int it = 0;
-  const int n_iter = max_iter < N ? max_iter : (int)N;
+  const int n_iter = max_iter < global_N ? max_iter : (int)global_N;
   const int min_it = min_iter < n_iter - 1 ? min_iter : n_iter - 1;
   const int n_hist = hist_len < n_iter ? hist_len : n_iter;
-  // The convergence decision is taken on the device (k_direction); the host reads it one iteration late from pinned
+  // The convergence decision is taken on the device (pass C); the host reads it one iteration late from pinned
   // memory, so the next iteration is already queued while it waits and the GPU never idles on the round trip.  The
   // iteration queued past convergence is a no-op on x (alpha = 0).
   int polled_it = -1;                     // iteration whose poll is in flight (-1: none)
   CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f};
   for (it = 0; it < n_iter; ++it) {
-    int rc = apply_operator(op, p, Ap, T, op_ws, op_ws_bytes, stream);
+    int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_coldot<TT>), dim3(nb), dim3(256), 0, st, p, Ap, part_a, N));
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nb), dim3(256), 0, st, p, Ap, L, part, N, K));
+    CG_REDUCE(redA);
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_update<TT>), dim3(nbw), dim3(256), 0, st, p, Ap, part_a, nb, x, r, part_rr,
-                                        state, alpha_d + (size_t)slot * kMaxT, L, part_w, N, K, eps, stop_after, it & 1));
-    if (K > 0) hipLaunchKernelGGL(k_wsolve, dim3(T), dim3(256), 0, st, part_w, nbw, Cinv, tv, T, K);
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_precond<TT>), dim3(nb), dim3(256), 0, st, L, tv, r, z, part_rz, N, K,
-                                        precond_sigma2));
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB,
+                                        part, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2, eps, stop_after,
+                                        it & 1, 0));
+    CG_REDUCE(redB);
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
-    // (k_direction reduces two partial arrays in every workgroup's prologue: it runs best with fewer workgroups)
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_direction<TT>), dim3(nb < 256 ? nb : 256), dim3(256), 0, st, z, p, part_rz, part_rr, nb, nbw,
-                                        state, beta_d + (size_t)slot * kMaxT, N, eps, it & 1, check_now ? 1 : 0, tolerance,
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nb), dim3(256), 0, st, zsrc, p, redB, state,
+                                        beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
                                         it + 1, stagnation_window, x, x_best));
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
       CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
@@ -656,7 +785,8 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
       polled_it = it;
     }
   }
-  hipLaunchKernelGGL(k_unnormalise, dim3(nb), dim3(256), 0, st, x, x_best, state, N, T);
+#undef CG_REDUCE
+  if (N > 0) hipLaunchKernelGGL(k_unnormalise, dim3(nb), dim3(256), 0, st, x, x_best, state, N, T);
   CG_CHECK(hipMemcpyAsync(&hpoll[kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
   CG_CHECK(hipStreamSynchronize(st));
   last = hpoll[kPollRing];

@@ -56,6 +56,11 @@ class JShard:
         self.j0, self.j1 = j_partition(J, self.world_size)[self.rank]
 
     @property
+    def reducer(self):
+        """The all-reduce the sharded MVM / solve runs on (RCCL by default, rpgp_comm with RPGP_COMM=ipc)."""
+        return get_reducer(self.group)
+
+    @property
     def empty(self):
         return self.j1 <= self.j0
 
@@ -70,7 +75,8 @@ class JShard:
         "pairs" mode) + noise * V.  The noise term is handed to rank 0's kernel only (fused into its slab reduce), so
         the single all-reduce yields sum over ranks + noise * V, identical on every rank, with no extra pass over V."""
         partial = local_mvm(self.j0, self.j1, noise if self.rank == 0 else 0.0)
-        all_reduce_sum_(partial, self.group)
+        if self.world_size > 1:
+            self.reducer.all_reduce_(partial)
         return partial
 
 
@@ -111,6 +117,10 @@ class RowShard:
     def local_rows(self):
         return self.r1 - self.r0
 
+    @property
+    def reducer(self):
+        return get_reducer(self.group)
+
     def owner(self, row):
         for r, (a, b) in enumerate(self.bounds):
             if a <= row < b:
@@ -118,6 +128,8 @@ class RowShard:
         raise IndexError(row)
 
     def all_reduce_(self, t, op="sum"):
+        if self.active and op == "sum" and t.is_cuda and self.world_size > 1:
+            return self.reducer.all_reduce_(t)          # SUM of device tensors: the configured backend (RCCL / IPC)
         if self.active:
             dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op],
                             group=self.group)
@@ -145,7 +157,7 @@ class Reducer:
                                    Opt-in: `RPGP_COMM=ipc` or `settings.comm_backend("ipc")`.
     `world_size == 1` makes every call the identity (and the hook None)."""
 
-    def __init__(self, group=None, backend=None, max_bytes=1 << 24, device=None):
+    def __init__(self, group=None, backend=None, max_bytes=1 << 24, device=None, force=False):
         import os
         self.group = group
         self.active = dist.is_available() and dist.is_initialized()
@@ -154,7 +166,8 @@ class Reducer:
         if backend is None:
             from . import settings
             backend = os.environ.get("RPGP_COMM") or settings.comm_backend.value()
-        self.backend = backend if self.world_size > 1 else "none"
+        # `force`: keep the collective path at world size 1 (the one-rank RCCL test exercises the hook that way)
+        self.backend = backend if (self.world_size > 1 or (force and self.active)) else "none"
         self._comm = None
         self._cb = None
         self._keep = {}

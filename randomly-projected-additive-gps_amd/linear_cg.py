@@ -48,13 +48,22 @@ def _tridiag_from_history(alpha, beta, n_tridiag, dtype, device):
     return torch.from_numpy(t)
 
 
-def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner, check_every):
+def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner, check_every,
+                      min_iter=10, row_sharded=False):
     """Route the solve through the native mBCG executor (rpgp_mbcg_solve) when everything it needs is available;
-    returns None to fall through to the torch-op loop."""
+    returns None to fall through to the torch-op loop.  A sharded operator (`native_sharding()`) runs the same
+    executor: its all-reduces are issued on the launch stream by the reducer's hook, the convergence flag stays on the
+    device, so there is no host synchronisation per iteration either."""
     from . import backend as _backend
     be = _backend.get_backend()
     if operator is None or not hasattr(be, "mbcg_solve") or not rhs.is_cuda or rhs.dtype != torch.float32 or \
             rhs.shape[1] > 16 or max_tridiag_iter > 64:
+        return None
+    shf = getattr(operator, "native_sharding", None)
+    sharding = shf() if shf is not None else None
+    if row_sharded != (sharding is not None and sharding[0] == "rows"):
+        return None                              # local-row vectors need the row-sharded executor mode (and vice versa)
+    if sharding is not None and sharding[0] == "rows" and rhs.shape[1] > 12:
         return None
     fn = getattr(operator, "native_descriptor", None)
     made = fn() if fn is not None else None
@@ -68,17 +77,20 @@ def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag
             return None
         L, Cinv, sigma2 = preconditioner.L.contiguous(), preconditioner.cinv(), preconditioner.noise
     N, T = rhs.shape
-    n_iter = min(max_iter, N)
+    n_glob = N if sharding is None else int(sharding[2])
+    n_iter = min(max_iter, n_glob)
     hist = min(max_tridiag_iter, n_iter) if n_tridiag else 0
-    x, ah, bh, iters, mres = be.mbcg_solve(desc, rhs.contiguous(), tolerance, n_iter, min_iter=10, hist_len=hist,
+    x, ah, bh, iters, mres = be.mbcg_solve(desc, rhs.contiguous(), tolerance, n_iter, min_iter=min_iter, hist_len=hist,
                                            check_every=check_every, L=L, Cinv=Cinv, sigma2=sigma2,
-                                           stagnation_window=settings.cg_stagnation_window.value())
+                                           stagnation_window=settings.cg_stagnation_window.value(), sharding=sharding)
     del keep
     stats["calls"] += 1
     stats["iterations"] += iters
     stats["last_iterations"] = iters
     stats["last_rhs"] = T
     stats["native_calls"] = stats.get("native_calls", 0) + 1
+    if sharding is not None:
+        stats["native_sharded_calls"] = stats.get("native_sharded_calls", 0) + 1
     if mres >= tolerance:                       # ran out of iterations, or stagnated at the fp32 floor
         warnings.warn(
             "CG terminated in {} iterations with average residual norm {} which is larger than the tolerance of {} "
@@ -113,9 +125,9 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
         max_iter = settings.max_cg_iterations.value()
     if max_tridiag_iter is None:
         max_tridiag_iter = settings.max_lanczos_quadrature_iterations.value()
-    if initial_guess is None and rhs.dim() == 2 and reduce is None:
+    if initial_guess is None and rhs.dim() == 2:
         res = _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner,
-                                check_every)
+                                check_every, min_iter=min_iter, row_sharded=reduce is not None)
         if res is not None:
             if squeeze:
                 return (res[0].squeeze(-1), res[1]) if n_tridiag else res.squeeze(-1)

@@ -9,6 +9,7 @@ reference's dependency.  All arithmetic goes through the compute backend (HIP li
 import torch
 
 from . import backend as _backend
+from . import settings
 
 
 class LinearOperator:
@@ -169,23 +170,39 @@ class AdditiveRPOperator(LinearOperator):
 
     def native_descriptor(self, noise=0.0):
         """`struct rpgp_operator` for the native mBCG executor, or None when the operator must stay on the Python path
-        (rectangular, J-sharded over several ranks, or a backend without the executor)."""
+        (rectangular, float64, or a backend without the executor).  A sharded operator describes THIS RANK's share —
+        its (world, rank) pair-shard with all projections, or its [j0, j1) slice of the projections — and
+        `native_sharding()` tells the executor to sum the partial products over the ranks."""
         be = _backend.get_backend()
-        if not self.symmetric or not hasattr(be, "mbcg_solve") or (self.shard is not None and self.shard.world_size > 1) \
-                or self.Z1.dtype != torch.float32:
+        if not self.symmetric or not hasattr(be, "mbcg_solve") or self.Z1.dtype != torch.float32:
+            return None
+        sharded = self.shard is not None and self.shard.world_size > 1
+        if sharded and not settings.native_sharded_cg.on():
             return None
         from . import _lib
         z1 = self.Z1.detach()
         j0, j1 = self._jrange()
+        kw = {}
+        if sharded:
+            ps = self.shard.pair_shard(be)
+            if ps is not None:
+                j0, j1 = 0, self.num_projections
+                kw = {"world": ps[0], "rank": ps[1]}
         prepare = getattr(be, "prepare", None)
         if prepare is not None:
             if self._prep is None:
                 self._prep = prepare(z1)
             if self._prep.fast_ok:
                 return be.make_operator_desc(_lib.RPGP_OP_FUSED_PREPARED, z1.shape[0], z1.shape[1], self._scale, noise,
-                                             prep=self._prep, j0=j0, j1=j1)
+                                             prep=self._prep, j0=j0, j1=j1, **kw)
         return be.make_operator_desc(_lib.RPGP_OP_FUSED, z1.shape[0], z1.shape[1], self._scale, noise, Z=z1.contiguous(),
-                                     j0=j0, j1=j1)
+                                     j0=j0, j1=j1, **kw)
+
+    def native_sharding(self):
+        """(mode, reducer, global_N) for the native executor, or None for an unsharded operator."""
+        if self.shard is None or self.shard.world_size <= 1:
+            return None
+        return ("partial", self.shard.reducer, self.Z1.shape[0])
 
     def _transpose_nonbatch(self):
         if self.symmetric:
@@ -309,6 +326,9 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         z1 = self.Z1.detach().contiguous()
         return be.make_operator_desc(_lib.RPGP_OP_SKI, z1.shape[0], z1.shape[1], self._scale, noise, Z=z1, gp=self.gp,
                                      G=self.grid_size)
+
+    def native_sharding(self):
+        return None
 
     def _matmul(self, rhs, noise=0.0):
         if noise and not self.symmetric:
@@ -438,7 +458,23 @@ class RowShardedSKIOperator(LinearOperator):
         return out.reshape(-1) if squeeze else out
 
     def _diagonal(self):
+        if self.Z1.shape[0] == 0:
+            return torch.zeros(0, dtype=self.dtype, device=self.device)
         return _backend.get_backend().ski_diag(self.Z1, self.gp, self._scale, self.grid_size) + self._noise
+
+    def native_descriptor(self):
+        """The local rows as an RPGP_OP_SKI descriptor (noise included); with `native_sharding()` the executor all-reduces
+        the grid histogram and the inner products, so the solve is the row-sharded one."""
+        be = _backend.get_backend()
+        if not hasattr(be, "mbcg_solve") or self.Z1.dtype != torch.float32 or not settings.native_sharded_cg.on():
+            return None
+        from . import _lib
+        z = self.Z1 if self.Z1.shape[0] > 0 else torch.zeros(1, self.Z1.shape[1], dtype=self.dtype, device=self.device)
+        return be.make_operator_desc(_lib.RPGP_OP_SKI, self.Z1.shape[0], self.Z1.shape[1], self._scale, self._noise, Z=z,
+                                     gp=self.gp, G=self.grid_size)
+
+    def native_sharding(self):
+        return ("rows", self.row_shard.reducer, self.row_shard.N)
 
     def kernel_rows(self, z_rows):
         """scale * K_ski(z_rows, local rows): k x N_local block for rows given by their (global) coordinates."""
@@ -473,7 +509,7 @@ class RowShardedWoodbury:
             t = gram64(self._L64, rd)
             self.row_shard.all_reduce_(t, "sum")
             t = torch.cholesky_solve(t, self._cap_chol)
-            out[:, c0:c0 + _PANEL] = rd.addmm_(self._L64, t, alpha=-1.0).div_(self.noise).to(r.dtype)
+            out[:, c0:c0 + _PANEL] = torch.addmm(rd, self._L64, t, alpha=-1.0).div_(self.noise).to(r.dtype)
         return out.squeeze(-1) if squeeze else out
 
     def logdet(self):
@@ -585,6 +621,9 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
         return be.make_operator_desc(_lib.RPGP_OP_FAMILY, z1.shape[0], z1.shape[1], self._scale, noise, Z=z1,
                                      family=self.fam)
 
+    def native_sharding(self):
+        return None
+
     def _transpose_nonbatch(self):
         if self.symmetric:
             return self
@@ -661,6 +700,10 @@ class AddedDiagOperator(LinearOperator):
         fn = getattr(self.base, "native_descriptor", None)
         return fn(self._noise) if fn is not None else None
 
+    def native_sharding(self):
+        fn = getattr(self.base, "native_sharding", None)
+        return fn() if fn is not None else None
+
     def _transpose_nonbatch(self):
         return self
 
@@ -722,10 +765,15 @@ class SymCachedOperator(LinearOperator):
 
     def native_descriptor(self):
         be = _backend.get_backend()
-        if not hasattr(be, "mbcg_solve") or self.cache.world != 1 or self.shard is not None:
+        if not hasattr(be, "mbcg_solve") or (self.cache.world != 1) != (self.shard is not None):
+            return None
+        if self.shard is not None and not settings.native_sharded_cg.on():
             return None
         from . import _lib
         return be.make_operator_desc(_lib.RPGP_OP_SYMCACHE, self.cache.N, 0, self._scale, self._noise, symcache=self.cache)
+
+    def native_sharding(self):
+        return None if self.shard is None else ("partial", self.shard.reducer, self.cache.N)
 
     def _transpose_nonbatch(self):
         return self

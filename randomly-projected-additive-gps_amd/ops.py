@@ -712,8 +712,9 @@ def family_bilinear_grad_dense(fam, Z, S, scale):
 
 
 def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=0, j1=None, G=0, Kd=None, family=None,
-                       symcache=None):
-    """Fill a `struct rpgp_operator`; returns (struct, keepalive) — keep both referenced while the solve runs."""
+                       symcache=None, world=1, rank=0):
+    """Fill a `struct rpgp_operator`; returns (struct, keepalive) — keep both referenced while the solve runs.
+    (world, rank): this rank's pair-shard of the fused / prepared operator (a symcache carries its own)."""
     import ctypes
     d = _lib.RpgpOperator()
     d.kind, d.N, d.J, d.ldz = kind, N, J, J
@@ -725,41 +726,61 @@ def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=
     d.Kd = Kd.data_ptr() if Kd is not None else None
     d.ldk = Kd.stride(0) if Kd is not None else 0
     d.family = ctypes.addressof(family.struct) if family is not None else None
+    d.world, d.rank = int(world), int(rank)
     if symcache is not None:                       # RPGP_OP_SYMCACHE: the cache travels in (Kd, ldk = bytes, G = layout)
         d.Kd, d.ldk, d.G = symcache.buf.data_ptr(), symcache.nbytes, symcache.layout
+        d.world, d.rank = symcache.world, symcache.rank
     return d, (Z, prep, gp, Kd, family, symcache)
 
 
 def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_every=1, L=None, Cinv=None, sigma2=1.0,
-               stagnation_window=0):
+               stagnation_window=0, sharding=None):
     """Native preconditioned batched CG (rpgp_mbcg_solve).  rhs: N x T (T <= 16).
+    `sharding` = (mode, reducer, global_N): mode "partial" (replicated vectors, the operator's product is this rank's
+    partial) or "rows" (SKI, `rhs` / `L` are this rank's rows); reducer: rpgp_amd.distributed.Reducer.
     Returns (x, alpha_hist [h x T], beta_hist [h x T], iterations, mean_residual)."""
     import ctypes
     import numpy as np
     lib = _lib.load()
-    rhs = _require(rhs, "rhs", 2)
+    if rhs.shape[0] > 0:
+        rhs = _require(rhs, "rhs", 2)
     N, T = rhs.shape
     if T > 16:
         raise ValueError("the native mBCG executor handles at most 16 right-hand sides")
     k = 0
     Lp = Cp = None
     if L is not None:
-        L = _require(L, "L", 2)
+        if N > 0:
+            L = _require(L, "L", 2)
         if Cinv.dtype != torch.float64 or not Cinv.is_cuda:
             raise TypeError("Cinv must be a float64 device tensor")
         Cinv = Cinv.contiguous()
         k = L.shape[1]
+        if N == 0:
+            L = torch.zeros((1, k), dtype=torch.float32, device=Cinv.device)
         Lp, Cp = L.data_ptr(), Cinv.data_ptr()
-    x = torch.empty_like(rhs)
+    x = torch.empty_like(rhs) if N > 0 else torch.empty((0, T), dtype=torch.float32, device=rhs.device)
+    rhs_buf, x_buf = (rhs, x) if N > 0 else (torch.zeros((1, T), dtype=torch.float32, device=rhs.device),) * 2
     ah = np.zeros((max(hist_len, 1), 16), dtype=np.float32)
     bh = np.zeros((max(hist_len, 1), 16), dtype=np.float32)
     iters, mres = ctypes.c_int(0), ctypes.c_float(0)
     with torch.cuda.device(rhs.device):
         nbytes = lib.rpgp_mbcg_workspace_bytes(ctypes.byref(desc), T, k)
         ws = _workspace(rhs.device, nbytes)
-        rc = lib.rpgp_mbcg_solve(ctypes.byref(desc), rhs.data_ptr(), x.data_ptr(), T, int(max_iter), int(min_iter),
+        red_ref = None
+        fn = None
+        if sharding is not None:
+            mode, reducer, global_N = sharding
+            fn, ctx = reducer.c_hook(ws)
+        if fn is not None:
+            red = _lib.RpgpReducer()
+            red.mode = {"partial": _lib.RPGP_SHARD_PARTIAL, "rows": _lib.RPGP_SHARD_ROWS}[mode]
+            red.world, red.rank, red.global_N = reducer.world_size, reducer.rank, int(global_N)
+            red.fn, red.ctx = fn, ctx
+            red_ref = ctypes.byref(red)
+        rc = lib.rpgp_mbcg_solve(ctypes.byref(desc), rhs_buf.data_ptr(), x_buf.data_ptr(), T, int(max_iter), int(min_iter),
                                  int(hist_len), int(check_every), int(stagnation_window), float(tolerance), k, Lp, Cp,
-                                 float(sigma2),
+                                 float(sigma2), red_ref,
                                  ah.ctypes.data, bh.ctypes.data, ctypes.byref(iters), ctypes.byref(mres),
                                  ws.data_ptr(), ws.numel(), _stream())
     if rc == _lib.RPGP_ENUMERIC:

@@ -86,7 +86,7 @@ class WoodburyPreconditioner:
     def _solve_panel(self, r):
         rd = r.double()
         t = torch.cholesky_solve(gram64(self._L64, rd), self._cap_chol)
-        return rd.addmm_(self._L64, t, alpha=-1.0).div_(self.noise).to(r.dtype)
+        return torch.addmm(rd, self._L64, t, alpha=-1.0).div_(self.noise).to(r.dtype)     # (rd may alias r: out of place)
 
     __call__ = solve
 

@@ -73,6 +73,41 @@ res = op._matmul(x) - V[rs.r0:rs.r1]
 sq = torch.stack([res.double().pow(2).sum(), V[rs.r0:rs.r1].double().pow(2).sum()])
 rs.all_reduce_(sq)
 assert float((sq[0] / sq[1]).sqrt()) < 5e-4, float((sq[0] / sq[1]).sqrt())
+# (3) the native executor's sharded modes with the RCCL hook (a ctypes callback that issues dist.all_reduce on the launch
+#     stream between the executor's enqueue-only phases).  `force=True` keeps the hook in the loop at world size 1.
+from rpgp_amd import backend as _be
+from rpgp_amd.distributed import Reducer
+from rpgp_amd.precond import build_preconditioner
+from rpgp_amd import settings
+forced = Reducer(backend="rccl", force=True)
+be = _be.get_backend()
+Nn, Jn, Tn = 5000, 20, 11
+Zn = (torch.randn(Nn, Jn, generator=g) * 0.7).to(dev)
+Bn = torch.randn(Nn, Tn, generator=g).to(dev)
+base_n = AdditiveRPOperator(Zn, None, s, 1.0 / Jn)
+full_n = AddedDiagOperator(base_n, torch.tensor(0.05, device=dev))
+pre_n = build_preconditioner(base_n, 0.05, settings)
+x_ref = lcg.linear_cg(full_n._matmul, Bn, tolerance=1e-5, max_iter=400, preconditioner=pre_n, operator=full_n)
+for mode in ("pairs", "j"):
+    shn = JShard(Jn, mode=mode)
+    shard_op = AddedDiagOperator(AdditiveRPOperator(Zn, None, s, 1.0 / Jn, shard=shn), torch.tensor(0.05, device=dev))
+    desc, keep = shard_op.base.native_descriptor(0.05)
+    xs, _, _, its, mres = be.mbcg_solve(desc, Bn, 1e-5, 400, L=pre_n.L, Cinv=pre_n.cinv(), sigma2=pre_n.noise,
+                                        sharding=("partial", forced, Nn))
+    assert float((xs - x_ref).norm() / x_ref.norm()) < 2e-4, (mode, "hooked solve differs")
+    if world > 1:
+        xa = lcg.linear_cg(shard_op._matmul, Bn, tolerance=1e-5, max_iter=400, preconditioner=pre_n, operator=shard_op)
+        assert lcg.stats.get("native_sharded_calls", 0) > 0
+        assert float((xa - x_ref).norm() / x_ref.norm()) < 2e-4
+# row mode through the hook
+forced_rows = ("rows", forced, N)
+desc, keep = op.native_descriptor()
+xr, _, _, its, mres = be.mbcg_solve(desc, V[rs.r0:rs.r1].contiguous(), 1e-4, 500, L=pre.L, Cinv=pre.cinv(), sigma2=pre.noise,
+                                    sharding=forced_rows)
+res = op._matmul(xr) - V[rs.r0:rs.r1]
+sq = torch.stack([res.double().pow(2).sum(), V[rs.r0:rs.r1].double().pow(2).sum()])
+rs.all_reduce_(sq)
+assert float((sq[0] / sq[1]).sqrt()) < 5e-4, float((sq[0] / sq[1]).sqrt())
 dist.barrier()
 if rank == 0:
     print("RCCL_CHILD_OK world=%d iters=%d sharded_rel=%.2e" % (world, lcg.stats["last_iterations"], rel))

@@ -27,3 +27,12 @@ def test_ipc_allreduce_multi_process_one_device(gpu_device, world):
     r = _launch("ipc_child.py", world)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "IPC_CHILD_OK world=%d" % world in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_native_executor_multi_process_one_device(gpu_device, world):
+    """The native mBCG executor in both sharded modes (partial products of the pair- / J-sharded exact operator and of
+    the pair-sharded packed cache; row-sharded SKI) with 2 and 3 ranks on device 0, against the unsharded native solve."""
+    r = _launch("ipc_solve_child.py", world, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "IPC_SOLVE_CHILD_OK world=%d" % world in r.stdout

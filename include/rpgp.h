@@ -261,6 +261,21 @@ int rpgp_ski_bilinear_grad_comp(const float *Z, const float *grid_params, const 
                                 void *stream);
 
 /*
+ * The derivative in two stages for the row-sharded SKI operator (MLL backward of a model whose rows are split over ranks):
+ *   rpgp_ski_bilinear_scatter : hist2[j][g][0..T) = W_j^T L, hist2[j][g][T..2T) = W_j^T R over the N LOCAL rows (float64,
+ *                               J * G * 2T) — all-reduce it over the ranks —
+ *   rpgp_ski_bilinear_finish  : Toeplitz products of the 2T columns, then gZ (local rows), gscale and (gcomp != NULL:
+ *                               row_scratch N * (J + 1) floats) gcomp as PARTIAL sums over the local rows (all-reduce them).
+ * T <= 12; rpgp_ski_bilinear_grad[_comp] is exactly scatter + finish.
+ */
+int rpgp_ski_bilinear_scatter(const float *Z, const float *grid_params, const float *L, const float *R, double *hist2,
+                              int64_t N, int ldz, int J, int G, int T, void *workspace, size_t workspace_bytes,
+                              void *stream);
+int rpgp_ski_bilinear_finish(const float *Z, const float *grid_params, const double *hist2, const float *L, const float *R,
+                             float *gZ, float *gscale, float *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
+                             float scale, void *workspace, size_t workspace_bytes, float *row_scratch, void *stream);
+
+/*
  * Generalised additive family — the other members behind the same operator:
  *     K[i,i'] = scale * sum_{c < ncomp} weights[c] * phi_kind( columns [c*group, (c+1)*group) of Z )
  *   kind RBF      exp(-r^2/2), r^2 summed over the group's columns   (k > 1 sub-kernels of training_routines.py:172-174,

@@ -35,6 +35,8 @@ class HipBackend:
     ski_pivoted_cholesky = staticmethod(ops.ski_pivoted_cholesky)
     ski_bilinear_grad = staticmethod(ops.ski_bilinear_grad)
     ski_bilinear_grad_comp = staticmethod(ops.ski_bilinear_grad_comp)
+    ski_bilinear_scatter = staticmethod(ops.ski_bilinear_scatter)
+    ski_bilinear_finish = staticmethod(ops.ski_bilinear_finish)
     make_family = staticmethod(ops.Family)
     family_mvm_sym = staticmethod(ops.family_mvm_sym)
     family_mvm_rect = staticmethod(ops.family_mvm_rect)

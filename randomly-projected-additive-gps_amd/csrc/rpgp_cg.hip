@@ -199,29 +199,28 @@ __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, con
   block_ltsum(lt, sh, dst + kRedLt, ln);
 }
 
-// red[e] = sum over the slabs of part[.][e] in float64, fixed order: workgroup b owns entries 16 b .. 16 b + 15, its 16
-// thread groups take every 16th slab and the 16 group sums are added in order.
+// red[e] = sum over the slabs of part[.][e] in float64, fixed order: workgroup b owns entries 8 b .. 8 b + 7, its 32
+// thread groups take every 32nd slab (8 independent loads in flight) and the 32 group sums are added in order.
 __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ part, int nparts, double *__restrict__ red) {
   __shared__ double sh[256];
-  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + e;
+  const int e = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int idx = blockIdx.x * 8 + e;
   double s = 0.0;
   int p = g;
-  for (; p + 48 < nparts; p += 64) {
-    const float v0 = part[(size_t)p * kRedW + idx], v1 = part[(size_t)(p + 16) * kRedW + idx];
-    const float v2 = part[(size_t)(p + 32) * kRedW + idx], v3 = part[(size_t)(p + 48) * kRedW + idx];
-    s += (double)v0;
-    s += (double)v1;
-    s += (double)v2;
-    s += (double)v3;
+  for (; p + 7 * 32 < nparts; p += 8 * 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + 32 * u) * kRedW + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
   }
-  for (; p < nparts; p += 16) s += (double)part[(size_t)p * kRedW + idx];
-  sh[g * 16 + e] = s;
+  for (; p < nparts; p += 32) s += (double)part[(size_t)p * kRedW + idx];
+  sh[g * 8 + e] = s;
   __syncthreads();
-  if (threadIdx.x < 16) {
+  if (threadIdx.x < 8) {
     double tot = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) tot += sh[q * 16 + threadIdx.x];
+    for (int q = 0; q < 32; ++q) tot += sh[q * 8 + threadIdx.x];
     red[idx] = tot;
   }
 }
@@ -326,10 +325,15 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
     double w = redB[kRedLt + threadIdx.x];
     if (!first) w -= (double)salpha[t] * redA[kRedLt + threadIdx.x];
     sW[threadIdx.x] = w;
+    // Cinv through LDS: one load per thread (a loop of K dependent global loads cost ~10 us at the head of every workgroup)
+    sTv[threadIdx.x] = (kk < K && t < K) ? Cinv[kk * K + t] : 0.0;
     __syncthreads();
     double tv = 0.0;
-    if (kk < K && t < TT)
-      for (int cc = 0; cc < K; ++cc) tv = fma(Cinv[kk * K + cc], sW[cc * 16 + t], tv);
+    if (kk < K && t < TT) {
+#pragma unroll
+      for (int cc = 0; cc < kMaxK; ++cc) tv = fma(sTv[kk * 16 + cc], sW[cc * 16 + t], tv);
+    }
+    __syncthreads();
     sTv[threadIdx.x] = tv;
     __syncthreads();
 #pragma unroll
@@ -509,11 +513,38 @@ __global__ __launch_bounds__(256) void k_unnormalise(float *__restrict__ x, cons
     x[e] = (use_best ? x_best[e] : x[e]) * st->rhs_norm[e % T];
 }
 
-inline int nblocks_for(long long N) {
-  long long b = (N + 255) / 256;      // one 256-row tile per workgroup until the partial-sum slabs are full
-  if (b > kMaxBlocks) b = kMaxBlocks;
-  if (b < 1) b = 1;
-  return (int)b;
+// Workgroups of a streaming pass: ONE resident round of the kernel (occupancy x CUs; a second, partial round is a tail
+// that costs a full tile time), and a tile count per workgroup that divides evenly.
+template <typename K>
+int resident_blocks(K kernel) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+inline int device_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+inline int blocks_for(long long N, int resident_per_cu) {
+  const long long tiles = (N + 255) / 256;
+  long long cap = (long long)resident_per_cu * device_cus();
+  if (cap > kMaxBlocks) cap = kMaxBlocks;
+  if (tiles <= cap) return tiles < 1 ? 1 : (int)tiles;
+  const long long per = (tiles + cap - 1) / cap;       // tiles per workgroup
+  return (int)((tiles + per - 1) / per);
+}
+struct Grids {
+  int a, b, c;
+};
+template <int TT>
+Grids grids_for(long long N) {
+  static const int ra = resident_blocks(k_pass_a<TT>), rb = resident_blocks(k_pass_b<TT>), rc = resident_blocks(k_pass_c<TT>);
+  return Grids{blocks_for(N, ra), blocks_for(N, rb), blocks_for(N, rc)};
 }
 
 // Pinned host landing zone for the lagged convergence polls (one per host thread; the executor keeps no other
@@ -714,8 +745,10 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   const size_t op_ws_bytes = operator_workspace(op, T);
   const bool rows = sh.mode == RPGP_SHARD_ROWS;
 
-  const int nb = nblocks_for(N);
-  const int nred = kRedW / 16;
+  Grids gr{1, 1, 1};
+  CG_DISPATCH_T(T, gr = grids_for<TT>(N));
+  const int nba = gr.a, nbb = gr.b, nbc = gr.c;
+  const int nred = kRedW / 8;
   const float eps = 1e-30f, stop_after = 1e-10f;
   {
     const int prc = g_poll.init();
@@ -725,9 +758,9 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   // with the identity preconditioner z IS r: pass B skips the store and pass C reads r
   float *zsrc = K > 0 ? z : r;
 
-#define CG_REDUCE(dst_)                                                                              \
+#define CG_REDUCE(dst_, nparts_)                                                                     \
   do {                                                                                               \
-    hipLaunchKernelGGL(k_reduce, dim3(nred), dim3(256), 0, st, part, nb, dst_);                      \
+    hipLaunchKernelGGL(k_reduce, dim3(nred), dim3(256), 0, st, part, nparts_, dst_);                 \
     if (rows) {                                                                                      \
       const int rrc_ = sh.reduce(dst_, kRedW, RPGP_F64, stream);                                     \
       if (rrc_) return rrc_;                                                                         \
@@ -735,14 +768,14 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   } while (0)
 
   // set-up: |rhs| per column; r = rhs / |rhs|, x = p = Ap = 0, w0 = L^T r0; z0 = M^-1 r0, rz0; p0 = z0
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nb), dim3(256), 0, st, rhs, rhs, L, part, N, 0));
-  CG_REDUCE(redA);
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_init<TT>), dim3(nb), dim3(256), 0, st, rhs, redA, r, x, p, Ap, L, part, state, N, K));
-  CG_REDUCE(redB);
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB, part,
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, rhs, rhs, L, part, N, 0));
+  CG_REDUCE(redA, nba);
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_init<TT>), dim3(nba), dim3(256), 0, st, rhs, redA, r, x, p, Ap, L, part, state, N, K));
+  CG_REDUCE(redB, nba);
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nbb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB, part,
                                       state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1));
-  CG_REDUCE(redB);
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nb), dim3(256), 0, st, z, p, redB, state, beta_d, N, eps, 0, 1, 0,
+  CG_REDUCE(redB, nbb);
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nbc), dim3(256), 0, st, z, p, redB, state, beta_d, N, eps, 0, 1, 0,
                                       tolerance, 0, 0, x, x_best));
   CG_CHECK(hipGetLastError());
 
@@ -758,16 +791,16 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   for (it = 0; it < n_iter; ++it) {
     int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nb), dim3(256), 0, st, p, Ap, L, part, N, K));
-    CG_REDUCE(redA);
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, part, N, K));
+    CG_REDUCE(redA, nba);
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB,
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nbb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB,
                                         part, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2, eps, stop_after,
                                         it & 1, 0));
-    CG_REDUCE(redB);
+    CG_REDUCE(redB, nbb);
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nb), dim3(256), 0, st, zsrc, p, redB, state,
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nbc), dim3(256), 0, st, zsrc, p, redB, state,
                                         beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
                                         it + 1, stagnation_window, x, x_best));
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
@@ -786,7 +819,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     }
   }
 #undef CG_REDUCE
-  if (N > 0) hipLaunchKernelGGL(k_unnormalise, dim3(nb), dim3(256), 0, st, x, x_best, state, N, T);
+  if (N > 0) hipLaunchKernelGGL(k_unnormalise, dim3(nbc), dim3(256), 0, st, x, x_best, state, N, T);
   CG_CHECK(hipMemcpyAsync(&hpoll[kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
   CG_CHECK(hipStreamSynchronize(st));
   last = hpoll[kPollRing];

@@ -4582,28 +4582,40 @@ int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t
   return launch_status();
 }
 
-// gcomp == nullptr: plain form.  Otherwise gcomp[j] (J floats) = sum_i of the per-projection parts of gscale (they
-// carry the projection's weight: divide by w_j for the unweighted component sums) and row_scratch holds N * (J + 1) floats.
-static int ski_bilinear_common(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
-                               float *gscale, float *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
-                               float scale, void *workspace, size_t workspace_bytes, float *row_scratch, void *stream) {
-  if (!Z || !grid_params || !L || !R || !gZ || !gscale || !row_scratch || N <= 0 || J <= 0 || G < 8 || T <= 0 ||
-      T > 12 || ldz < J || ldg < J)
+// The derivative in two stages (the row-sharded operator all-reduces the histogram in between):
+//   scatter: hist2[j][g][0..T) = W_j^T L, hist2[j][g][T..2T) = W_j^T R  over the given rows (float64)
+//   finish : H = Tm hist2 (all 2T columns), per-row gather of the stencil derivatives -> gZ, row sums -> gscale (, gcomp)
+static int ski_bilinear_scatter_stage(const float *Z, const float *grid_params, const float *L, const float *R,
+                                      double *hist, int64_t N, int ldz, int J, int G, int T, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+  if (!Z || !grid_params || !L || !R || !hist || N <= 0 || J <= 0 || G < 8 || T <= 0 || T > 12 || ldz < J)
     return RPGP_EINVAL;
   if ((size_t)G * 13 * sizeof(float) > 64 * 1024) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   const int T2 = 2 * T;
-  double *hist = reinterpret_cast<double *>(workspace);
-  float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * T2;
-  // scatter the 2T columns [L | R]: two passes writing into column offsets 0 and T of a [J][G][2T] float64 histogram
-  float *slab = H + (size_t)J * G * T2 + 2 * kSkiMaxParts;
+  float *slab = reinterpret_cast<float *>(workspace) + 3 * (size_t)J * G * T2 + 2 * kSkiMaxParts;
+  // two passes writing into column offsets 0 and T of a [J][G][2T] float64 histogram
   for (int half = 0; half < 2; ++half) {
     const int rcs = ski_scatter_narrow(Z, grid_params, half == 0 ? L : R, hist, slab, (long long)N, ldz, J, G, T, T2,
                                        half * T, st);
     if (rcs) return rcs;
   }
-  int rc = ski_toeplitz(hist, 1, grid_params, H, J, G, T2, st);
+  return 0;
+}
+
+static int ski_bilinear_finish_stage(const float *Z, const float *grid_params, const double *hist, const float *L,
+                                     const float *R, float *gZ, float *gscale, float *gcomp, int64_t N, int ldz, int ldg,
+                                     int J, int G, int T, float scale, void *workspace, size_t workspace_bytes,
+                                     float *row_scratch, void *stream) {
+  if (!Z || !grid_params || !hist || !L || !R || !gZ || !gscale || !row_scratch || N <= 0 || J <= 0 || G < 8 || T <= 0 ||
+      T > 12 || ldz < J || ldg < J)
+    return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int T2 = 2 * T;
+  float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * T2;
+  int rc = ski_toeplitz(const_cast<double *>(hist), 1, grid_params, H, J, G, T2, st);
   if (rc) return rc;
   const unsigned nb = (unsigned)((N + 255) / 256);
   float *rowC = gcomp ? row_scratch + N : nullptr;
@@ -4618,6 +4630,32 @@ static int ski_bilinear_common(const float *Z, const float *grid_params, const f
   hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(1024), 0, st, row_scratch, gscale, (int)N, 1.0f);
   if (gcomp) hipLaunchKernelGGL(sum_columns_kernel, dim3(J), dim3(1024), 0, st, rowC, gcomp, (int)N, J, 1.0f);
   return launch_status();
+}
+
+// gcomp == nullptr: plain form.  Otherwise gcomp[j] (J floats) = sum_i of the per-projection parts of gscale (they
+// carry the projection's weight: divide by w_j for the unweighted component sums) and row_scratch holds N * (J + 1) floats.
+static int ski_bilinear_common(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,
+                               float *gscale, float *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
+                               float scale, void *workspace, size_t workspace_bytes, float *row_scratch, void *stream) {
+  if (!gZ || !gscale || !row_scratch || ldg < J) return RPGP_EINVAL;
+  double *hist = reinterpret_cast<double *>(workspace);
+  int rc = ski_bilinear_scatter_stage(Z, grid_params, L, R, hist, N, ldz, J, G, T, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return ski_bilinear_finish_stage(Z, grid_params, hist, L, R, gZ, gscale, gcomp, N, ldz, ldg, J, G, T, scale, workspace,
+                                   workspace_bytes, row_scratch, stream);
+}
+
+int rpgp_ski_bilinear_scatter(const float *Z, const float *grid_params, const float *L, const float *R, double *hist2,
+                              int64_t N, int ldz, int J, int G, int T, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+  return ski_bilinear_scatter_stage(Z, grid_params, L, R, hist2, N, ldz, J, G, T, workspace, workspace_bytes, stream);
+}
+
+int rpgp_ski_bilinear_finish(const float *Z, const float *grid_params, const double *hist2, const float *L, const float *R,
+                             float *gZ, float *gscale, float *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
+                             float scale, void *workspace, size_t workspace_bytes, float *row_scratch, void *stream) {
+  return ski_bilinear_finish_stage(Z, grid_params, hist2, L, R, gZ, gscale, gcomp, N, ldz, ldg, J, G, T, scale, workspace,
+                                   workspace_bytes, row_scratch, stream);
 }
 
 int rpgp_ski_bilinear_grad(const float *Z, const float *grid_params, const float *L, const float *R, float *gZ,

@@ -79,6 +79,8 @@ class InvQuadLogDet(torch.autograd.Function):
             return inv_quad, logdet
 
         num_probes = settings.num_trace_samples.value()
+        if getattr(op, "row_shard", None) is not None:
+            return _row_sharded_forward(ctx, Z, noise, r, op, num_probes)
         pre = build_preconditioner(op, float(noise.detach()), settings)
         gen = _probe_generator(Z.device)
         if pre is not None:
@@ -149,6 +151,8 @@ class InvQuadLogDet(torch.autograd.Function):
                 gn = S.diagonal().sum()
             if need[3]:
                 gr = (2.0 * g_inv_quad * alpha).reshape(-1)
+        elif ctx.mode == "cg_rows":
+            return _row_sharded_backward(ctx, g_inv_quad, g_logdet)
         else:
             probe_solves, probes, alpha = ctx.saved_tensors
             p = ctx.num_probes
@@ -169,6 +173,97 @@ class InvQuadLogDet(torch.autograd.Function):
         if gw is not None:
             gw = gw.reshape(ctx.op.comp_weights.shape).to(ctx.op.comp_weights.dtype)
         return gZ, gs, gn, gr, None, gw
+
+
+def _shared_generator(device, shard):
+    """A generator every rank seeds identically: the fixed one of `deterministic_probes`, else a seed drawn by rank 0 and
+    broadcast (8 bytes instead of the N x p probe block)."""
+    gen = _probe_generator(device)
+    if gen is not None:
+        return gen
+    seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(device)
+    shard.broadcast_(seed, 0)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    return gen
+
+
+def _row_sharded_forward(ctx, Z, noise, r, op, num_probes):
+    """mBCG + SLQ with the N rows split over the ranks (SKI operator; replaces the MultiDeviceKernel split of
+    training_routines.py:407-408).  Every rank solves for ITS rows of [probes | y - c]; the grid histogram and the inner
+    products are all-reduced inside the solve (native executor: on the launch stream), so alpha / beta — hence the Lanczos
+    tridiagonals and the SLQ log-determinant — are identical on every rank.  The probes are the ones the single-process
+    path draws (same generator, same order: e1 then e2), sliced to the local rows."""
+    from .operators import row_sharded_preconditioner
+    import math
+    rs = op.row_shard
+    N = Z.shape[0]
+    noise_f = float(noise.detach())
+    sop = op.row_sharded(noise_f)
+    rank_k = settings.max_preconditioner_size.value()
+    pre = row_sharded_preconditioner(sop, rank_k) if (N >= settings.min_preconditioning_size.value() and rank_k > 0) \
+        else None
+    gen = _shared_generator(Z.device, rs)
+    if pre is not None:
+        k = pre.L.shape[1]
+        e1 = torch.randn(k, num_probes, generator=gen, device=Z.device, dtype=Z.dtype)
+        e2 = torch.randn(N, num_probes, generator=gen, device=Z.device, dtype=Z.dtype)
+        probes = pre.L @ e1 + math.sqrt(noise_f) * e2[rs.r0:rs.r1]
+        logdet_correction = pre.logdet()
+    else:
+        probes = torch.randn(N, num_probes, generator=gen, device=Z.device, dtype=Z.dtype)[rs.r0:rs.r1].contiguous()
+        logdet_correction = 0.0
+    sq = probes.double().pow(2).sum(0, keepdim=True)
+    rs.all_reduce_(sq, "sum")
+    probe_norms = sq.sqrt().to(Z.dtype)
+    r_loc = r[rs.r0:rs.r1]
+    full_rhs = torch.cat([probes / probe_norms, r_loc], dim=1).contiguous()
+    solves, t_mat = linear_cg(sop._matmul, full_rhs, n_tridiag=num_probes, operator=sop,
+                              tolerance=settings.cg_tolerance.value(), max_iter=settings.max_cg_iterations.value(),
+                              max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(), preconditioner=pre,
+                              reduce=rs.all_reduce_, global_size=N)
+    alpha = solves[:, num_probes:]
+    iq = (r_loc.double() * alpha.double()).sum().reshape(1)
+    rs.all_reduce_(iq, "sum")
+    inv_quad = iq[0].to(Z.dtype)
+    if settings.skip_logdet_forward.on():
+        logdet = torch.zeros((), dtype=Z.dtype, device=Z.device)
+    else:
+        logdet = torch.as_tensor(float(slq_logdet(t_mat, N)) + logdet_correction, dtype=Z.dtype, device=Z.device)
+    ctx.mode = "cg_rows"
+    ctx.pre = pre
+    ctx.num_probes = num_probes
+    ctx.save_for_backward(solves[:, :num_probes] * probe_norms, probes, alpha)
+    return inv_quad, logdet
+
+
+def _row_sharded_backward(ctx, g_inv_quad, g_logdet):
+    op, need = ctx.op, ctx.needs_input_grad
+    rs = op.row_shard
+    probe_solves, probes, alpha = ctx.saved_tensors
+    p = ctx.num_probes
+    pre_probes = ctx.pre.solve(probes) if ctx.pre is not None else probes
+    left = torch.cat([probe_solves * (g_logdet / p), -g_inv_quad * alpha], dim=1).contiguous()
+    right = torch.cat([pre_probes, alpha], dim=1).contiguous()
+    gZ = gs = gn = gr = gw = None
+    if need[0] or need[1] or need[5]:
+        gZ, gs, *rest = op.row_sharded_bilinear_derivative(left, right)
+        gw = rest[0] if rest else None
+    if need[2]:
+        gn = (left.double() * right.double()).sum().reshape(1)
+        rs.all_reduce_(gn, "sum")
+        gn = gn[0].to(left.dtype)
+    if need[3]:
+        gr = torch.zeros(ctx.N, dtype=alpha.dtype, device=alpha.device)
+        gr[rs.r0:rs.r1] = (2.0 * g_inv_quad * alpha).reshape(-1)
+        rs.all_reduce_(gr, "sum")
+    if gs is not None:
+        gs = gs.reshape(op.outputscale.shape)
+    if gn is not None:
+        gn = gn.reshape(())
+    if gw is not None:
+        gw = gw.reshape(op.comp_weights.shape).to(op.comp_weights.dtype)
+    return gZ, gs, gn, gr, None, gw
 
 
 def inv_quad_logdet(op, noise, rhs):

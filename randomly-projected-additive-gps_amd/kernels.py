@@ -11,6 +11,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import backend as _backend
+from .distributed import JShard, RowShard
 from .operators import AdditiveRPOperator, FamilyAdditiveOperator, SKIAdditiveOperator
 
 
@@ -117,8 +118,9 @@ class AdditiveStructureRBFKernel(Kernel):
                                           group=self.group)
         if self.ski:
             return SKIAdditiveOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight),
-                                       grid_size=self.grid_size)
-        return AdditiveRPOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight), shard=shard)
+                                       grid_size=self.grid_size, row_shard=shard if isinstance(shard, RowShard) else None)
+        return AdditiveRPOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight),
+                                  shard=shard if isinstance(shard, JShard) else None)
 
     def forward(self, z1, z2, **params):
         return self.operator(z1, None if z2 is z1 else z2)
@@ -259,7 +261,8 @@ class GeneralizedProjectionKernel(Kernel):
             # one shared dynamic grid over the current projections (the reference fixes per-projection bounds from X at
             # construction, polynomial_projection_kernels.py:52-61); per-component output scales ride in the grid block
             return SKIAdditiveOperator(z1, z2, outputscale=outputscale, weight=1.0, grid_size=self.grid_size,
-                                       comp_weights=self.outputscales)
+                                       comp_weights=self.outputscales,
+                                       row_shard=shard if isinstance(shard, RowShard) else None)
         return FamilyAdditiveOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
                                       kind=self.kernel_type, group=self.k)
 

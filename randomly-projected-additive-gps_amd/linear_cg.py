@@ -91,6 +91,8 @@ def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag
     stats["native_calls"] = stats.get("native_calls", 0) + 1
     if sharding is not None:
         stats["native_sharded_calls"] = stats.get("native_sharded_calls", 0) + 1
+        if sharding[0] == "rows":
+            stats["row_sharded_calls"] = stats.get("row_sharded_calls", 0) + 1
     if mres >= tolerance:                       # ran out of iterations, or stagnated at the fp32 floor
         warnings.warn(
             "CG terminated in {} iterations with average residual norm {} which is larger than the tolerance of {} "
@@ -277,6 +279,8 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     stats["iterations"] += k + 1
     stats["last_iterations"] = k + 1
     stats["last_rhs"] = T
+    if reduce is not None:
+        stats["row_sharded_calls"] = stats.get("row_sharded_calls", 0) + 1
     result.mul_(rhs_norm)
     if squeeze:
         result = result.squeeze(-1)

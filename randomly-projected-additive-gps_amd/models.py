@@ -68,6 +68,25 @@ class PredictionStrategy:
                 self.chol = psd_safe_cholesky(Kd)
                 self.alpha = torch.cholesky_solve(self.r, self.chol)
                 self.khat = None
+            elif getattr(self.op, "row_shard", None) is not None:
+                # row-sharded SKI model: the mean-cache solve runs on this rank's rows (all-reduces inside the solve), the
+                # solution is assembled on every rank; everything downstream (cross-covariance products, wide solves of the
+                # predictive covariance) uses the replicated operator
+                from .operators import row_sharded_preconditioner
+                self.chol = None
+                rs = self.op.row_shard
+                sop = self.op.row_sharded(float(self.noise))
+                rank_k = settings.max_preconditioner_size.value()
+                pre_sh = row_sharded_preconditioner(sop, rank_k) \
+                    if (N >= settings.min_preconditioning_size.value() and rank_k > 0) else None
+                a_loc = linear_cg(sop._matmul, self.r[rs.r0:rs.r1].contiguous(), tolerance=settings.eval_cg_tolerance.value(),
+                                  max_iter=settings.max_cg_iterations.value(), preconditioner=pre_sh, operator=sop,
+                                  reduce=rs.all_reduce_, global_size=N)
+                self.alpha = torch.zeros_like(self.r)
+                self.alpha[rs.r0:rs.r1] = a_loc
+                rs.all_reduce_(self.alpha, "sum")
+                self.khat = AddedDiagOperator(self.op, self.noise)
+                self.pre = build_preconditioner(self.op, float(self.noise), settings)
             else:
                 self.chol = None
                 shard = getattr(self.op, "shard", None)

@@ -292,9 +292,15 @@ class SKIAdditiveOperator(AdditiveRPOperator):
     operator so the whole solve stack is unchanged.  The grid is recomputed from the data range at construction
     (once per hyper-parameter step) and is not differentiated (it is a buffer in GPyTorch as well)."""
 
-    def __init__(self, Z1, Z2=None, outputscale=None, weight=1.0, shard=None, grid_size=1024, comp_weights=None):
-        super().__init__(Z1, Z2, outputscale, weight, shard=None)     # SKI runs replicated (no J-sharding)
+    def __init__(self, Z1, Z2=None, outputscale=None, weight=1.0, shard=None, grid_size=1024, comp_weights=None,
+                 row_shard=None):
+        super().__init__(Z1, Z2, outputscale, weight, shard=None)     # (no J-sharding: the SKI product is O(N))
         self.grid_size = int(grid_size)
+        # Multi-GPU: the N training rows are split over the ranks (distributed.RowShard).  The operator itself keeps the
+        # replicated interface (full Z, full vectors: prediction and the generic call sites are unchanged); the solves of
+        # the marginal likelihood and of the mean cache run on `row_sharded(noise)` — every rank scatters / gathers ITS rows.
+        self.row_shard = row_shard if (row_shard is not None and Z2 is None and row_shard.world_size > 1 and
+                                       row_shard.N == Z1.shape[0]) else None
         # per-projection output scales (weighted rp_poly / strictly_additive kinds with `ski: true`): they ride in the
         # grid parameter block and every SKI kernel applies them on the Toeplitz stage
         self.comp_weights = comp_weights
@@ -340,8 +346,43 @@ class SKIAdditiveOperator(AdditiveRPOperator):
             return self
         t = SKIAdditiveOperator.__new__(SKIAdditiveOperator)
         AdditiveRPOperator.__init__(t, self.Z2, self.Z1, self.outputscale, self.weight, None)
-        t.grid_size, t.gp, t.comp_weights = self.grid_size, self.gp, self.comp_weights
+        t.grid_size, t.gp, t.comp_weights, t.row_shard = self.grid_size, self.gp, self.comp_weights, None
         return t
+
+    def row_sharded(self, noise):
+        """This rank's rows of (self + noise I) as a RowShardedSKIOperator on the SAME grid block (and weights)."""
+        rs = self.row_shard
+        return RowShardedSKIOperator(self.Z1.detach()[rs.r0:rs.r1], self._scale, 1.0, rs, grid_size=self.grid_size,
+                                     noise=noise, gp=self.gp)
+
+    def row_sharded_bilinear_derivative(self, left_local, right_local):
+        """`_bilinear_derivative` with the vectors given as this rank's rows: per 12-column piece the 2T-column grid
+        histogram is all-reduced (J x G x 2T float64), the Toeplitz stage is replicated and every rank differentiates ITS
+        rows; the d+1 (+J) parameter sums are all-reduced once.  Returns the same tuple as `_bilinear_derivative`, with
+        gZ assembled for all N rows (zero-padded all-reduce) so that the projection's backward runs replicated."""
+        be = _backend.get_backend()
+        rs = self.row_shard
+        Zl = self.Z1.detach()[rs.r0:rs.r1].contiguous()
+        comp = self.comp_weights is not None
+        J = self.Z1.shape[1]
+        gZ = torch.zeros_like(self.Z1.detach())
+        tail = torch.zeros(1 + (J if comp else 0), dtype=self.dtype, device=self.device)
+        for t0 in range(0, left_local.shape[1], 12):
+            Lc = left_local[:, t0:t0 + 12].detach().contiguous()
+            Rc = right_local[:, t0:t0 + 12].detach().contiguous()
+            hist = be.ski_bilinear_scatter(Zl, self.gp, Lc, Rc, self.grid_size)
+            rs.all_reduce_(hist, "sum")
+            gzl, gs, gc = be.ski_bilinear_finish(Zl, self.gp, hist, Lc, Rc, self._scale, self.grid_size, comp=comp)
+            gZ[rs.r0:rs.r1] += gzl
+            tail[0] += gs.reshape(())
+            if comp:
+                tail[1:] += gc.reshape(-1)
+        rs.all_reduce_(gZ, "sum")
+        rs.all_reduce_(tail, "sum")
+        if comp:
+            w = self.comp_weights.detach().to(tail)
+            return gZ, tail[0] * self.weight, self._scale * tail[1:] / w
+        return gZ, tail[0] * self.weight
 
     def _diagonal(self):
         if not self.symmetric:
@@ -409,13 +450,16 @@ class RowShardedSKIOperator(LinearOperator):
     histogram.  CG on it runs with all-reduced inner products (`linear_cg(..., reduce=shard.all_reduce_)`); the rank-k
     pivoted-Cholesky preconditioner is built from distributed pivots (`row_sharded_preconditioner`)."""
 
-    def __init__(self, Z_local, outputscale, weight, row_shard, grid_size=1024, noise=0.0):
+    def __init__(self, Z_local, outputscale, weight, row_shard, grid_size=1024, noise=0.0, gp=None):
         self.Z1 = Z_local.detach().contiguous()
         self.row_shard = row_shard
         self.grid_size = int(grid_size)
         self._scale = float(outputscale) * float(weight)
         self._noise = float(noise)
         be = _backend.get_backend()
+        if gp is not None:                 # the grid block of the replicated operator this one was split from
+            self.gp = gp
+            return
         if self.Z1.shape[0] > 0:
             rng = torch.stack([self.Z1.min(), -self.Z1.max()])
         else:

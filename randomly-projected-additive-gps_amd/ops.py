@@ -584,6 +584,52 @@ def ski_bilinear_grad_comp(Z, gp, L, R, scale, grid_size=1024):
     return gZ, gs, gc
 
 
+def ski_bilinear_scatter(Z, gp, L, R, grid_size=1024):
+    """Stage 1 of the row-sharded SKI derivative: hist2 (J x G x 2T float64) = [W^T L | W^T R] over the rows of Z
+    (T <= 12; zeros for an empty row block)."""
+    lib = _lib.load()
+    N, J = Z.shape
+    T = L.shape[1]
+    if T > 12:
+        raise ValueError("ski_bilinear_scatter takes at most 12 columns per call")
+    hist = torch.zeros((J, grid_size, 2 * T), dtype=torch.float64, device=Z.device)
+    if N == 0:
+        return hist
+    Z = _require(Z, "Z", 2)
+    L2, _ = _as_matrix(L, N, "L")
+    R2, _ = _as_matrix(R, N, "R")
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
+        _lib.check(lib.rpgp_ski_bilinear_scatter(Z.data_ptr(), gp.data_ptr(), L2.data_ptr(), R2.data_ptr(), hist.data_ptr(),
+                                                 N, J, J, grid_size, T, ws.data_ptr(), ws.numel(), _stream()),
+                   "rpgp_ski_bilinear_scatter")
+    return hist
+
+
+def ski_bilinear_finish(Z, gp, hist2, L, R, scale, grid_size=1024, comp=False):
+    """Stage 2: (gZ [local rows], gscale partial, gcomp partial or None) from the ALL-REDUCED histogram."""
+    lib = _lib.load()
+    N, J = Z.shape
+    T = L.shape[1]
+    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
+    gs = torch.zeros((), dtype=torch.float32, device=Z.device)
+    gc = torch.zeros(J, dtype=torch.float32, device=Z.device) if comp else None
+    if N == 0:
+        return gZ, gs, gc
+    Z = _require(Z, "Z", 2)
+    L2, _ = _as_matrix(L, N, "L")
+    R2, _ = _as_matrix(R, N, "R")
+    hist2 = hist2.contiguous()
+    scratch = torch.empty(N * (J + 1) if comp else N, dtype=torch.float32, device=Z.device)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
+        _lib.check(lib.rpgp_ski_bilinear_finish(Z.data_ptr(), gp.data_ptr(), hist2.data_ptr(), L2.data_ptr(), R2.data_ptr(),
+                                                gZ.data_ptr(), gs.data_ptr(), None if gc is None else gc.data_ptr(), N, J, J,
+                                                J, grid_size, T, float(scale), ws.data_ptr(), ws.numel(),
+                                                scratch.data_ptr(), _stream()), "rpgp_ski_bilinear_finish")
+    return gZ, gs, gc
+
+
 # ------------------------------------------------------------------------------------------------ native mBCG
 
 # ------------------------------------------------------------------------------------ generalised family

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import rp
-from .distributed import JShard, is_distributed
+from .distributed import JShard, RowShard, is_distributed
 from .kernels import (AdditiveStructureRBFKernel, CustomAdditiveKernel, MemoryEfficientGamKernel,
                       PolynomialProjectionKernel, RBFKernel, ScaledProjectionKernel, ScaleKernel, StrictlyAdditiveKernel)
 from .likelihoods import GaussianLikelihood, SmoothedBoxPrior
@@ -151,8 +151,8 @@ def create_full_kernel(d, ard=False, ski=False, grid_size=None, kernel_type="RBF
 
 def create_exact_gp(trainX, trainY, kind, devices=("cpu",), **kwargs):
     """Create an exact GP model with a specified kernel (training_routines.py:325-410).
-    More than one device means J-sharding over the ranks of the default torch.distributed process group
-    (the SKI variant runs replicated: its MVM is O(N) and latency-bound)."""
+    Under a torch.distributed process group (one process per GPU) the exact additive_rp kernel is pair- / J-sharded
+    (distributed.JShard) and the SKI variants are row-sharded (distributed.RowShard)."""
     [n, d] = trainX.shape
     if kind not in EXACT_GP_KINDS + REFERENCE_ONLY_KINDS:
         raise ValueError("Unknown kernel structure type {}".format(kind))
@@ -178,7 +178,11 @@ def create_exact_gp(trainX, trainY, kind, devices=("cpu",), **kwargs):
     else:
         kernel = create_additive_rp_kernel(d, **kwargs)
     kernel = ScaleKernel(kernel)
-    if kind == "additive_rp" and is_distributed():
+    if is_distributed() and kwargs.get("ski", False) and kind != "full":
+        # the SKI variants (BASELINE config 5: additive_spread_prescale_Jd_ski on 8 GPUs; the reference wraps the kernel in
+        # MultiDeviceKernel, training_routines.py:407-408 with :157-158): the N training rows are split over the ranks
+        kernel.shard = RowShard(n)
+    elif kind == "additive_rp" and is_distributed() and kwargs.get("kernel_type", "RBF") == "RBF" and kwargs.get("k", 1) == 1:
         kernel.shard = JShard(kwargs["J"])
     elif len(devices) > 1:
         raise RuntimeError("multi-device runs are one process per GPU: launch with `python -m torch.distributed.run "
@@ -190,7 +194,7 @@ def create_exact_gp(trainX, trainY, kind, devices=("cpu",), **kwargs):
 
 def train_to_convergence(model, xs, ys, optimizer=None, lr=0.1, objective=None, max_iter=100, verbose=0, patience=20,
                          conv_tol=1e-4, check_conv=True, smooth=True, isloss=False, batch_size=None, checkpoint=False,
-                         print_freq=1):
+                         print_freq=1, loss_log=None):
     """Full-batch optimisation loop with moving-average early stopping (fitting/optimizing.py:14-108).
 
     Returns the epoch index at which convergence was declared, or max_iter.  As in the reference the moving average
@@ -219,6 +223,8 @@ def train_to_convergence(model, xs, ys, optimizer=None, lr=0.1, objective=None, 
         if verbose > 1:
             print("epoch {}, iter {}, loss {}".format(i, 0, loss))
         losses[i] = loss
+        if loss_log is not None:          # (not in the reference: lets callers / tests read the per-epoch losses)
+            loss_log.append(loss)
         lo = i - patience + 1
         ma[i] = losses[lo:i + 1].mean() if lo >= 0 else np.nan
         if i % print_freq == 0 and verbose >= 1:

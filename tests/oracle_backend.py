@@ -245,3 +245,47 @@ class OracleBackend:
     def ski_bilinear_grad_comp(self, Z, gp, L, R, scale, grid_size=1024):
         gZ, gs = self.ski_bilinear_grad(Z, gp, L, R, scale, grid_size)
         return gZ, gs, _t(self._last_comp.copy(), Z)
+
+    # ---- staged derivative of the row-sharded SKI operator: scatter -> all-reduce -> finish ---------------------------
+    def ski_bilinear_scatter(self, Z, gp, L, R, grid_size=1024):
+        z = _np(Z)
+        Ld, Rd = _np(L).reshape(z.shape[0], -1), _np(R).reshape(z.shape[0], -1)
+        g0, h = self._grid(gp)
+        hist = np.zeros((z.shape[1], grid_size, 2 * Ld.shape[1]))
+        for j in range(z.shape[1]):
+            if z.shape[0]:
+                W = sko.interp_sparse(z[:, j], g0, h, grid_size)
+                hist[j] = np.concatenate([W.T @ Ld, W.T @ Rd], axis=1)
+        return torch.from_numpy(hist)
+
+    def ski_bilinear_finish(self, Z, gp, hist2, L, R, scale, grid_size=1024, comp=False):
+        z = _np(Z)
+        Ld, Rd = _np(L).reshape(z.shape[0], -1), _np(R).reshape(z.shape[0], -1)
+        T = Ld.shape[1]
+        g0, h = self._grid(gp)
+        G = grid_size
+        Tm = sko.toeplitz(h, G)
+        wts = self._w(gp)
+        gZ = np.zeros_like(z)
+        gs, gc = 0.0, np.zeros(z.shape[1])
+        hh = hist2.double().numpy()
+        for j in range(z.shape[1]):
+            wj = 1.0 if wts is None else wts[j]
+            HL, HR = Tm @ hh[j][:, :T], Tm @ hh[j][:, T:]
+            if not z.shape[0]:
+                continue
+            u = np.clip((z[:, j] - g0) / h, 1.0, G - 2.0)
+            fl = np.floor(u)
+            fr = u - fl
+            idx0 = np.clip(fl.astype(np.int64) - 1, 0, G - 4)
+            W = sko.interp_sparse(z[:, j], g0, h, G)
+            gc[j] = wj * (Ld * (W @ HR)).sum()
+            gs += gc[j]
+            s = [fr + 1.0, fr, 1.0 - fr, 2.0 - fr]
+            sign = [1.0, 1.0, -1.0, -1.0]
+            for k in range(4):
+                U = s[k]
+                d = np.where(U < 1.0, (4.5 * U - 5.0) * U, (-1.5 * U + 5.0) * U - 4.0) * sign[k] / h
+                rows = idx0 + k
+                gZ[:, j] += wj * scale * d * ((Ld * HR[rows]).sum(1) + (Rd * HL[rows]).sum(1))
+        return _t(gZ, Z), _t(np.array(gs), Z), (_t(gc, Z) if comp else None)

@@ -130,19 +130,34 @@ def test_sharded_operator_gloo(tmp_path, world):
         assert os.path.exists(tmp_path / ("ok%d" % r))
 
 
-def _runner_worker(rank, world, port, tmpdir):
+def _runner_worker(rank, world, port, tmpdir, spec="additive_rp_prescale_J20"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
-    from rpgp_amd import backend, runner
+    from rpgp_amd import backend, runner, settings
     from tests.oracle_backend import OracleBackend
     backend.set_backend(OracleBackend())
     out = os.path.join(tmpdir, "res.csv")
+    if "ski" in spec:
+        # a user's own copy of the reference's spec file (small grid / few epochs: the CPU test double is dense) and the
+        # CG regime forced for the 108-row fold, so that the row-sharded solves are what runs
+        import json
+        from rpgp_amd import specs
+        sp = specs.get(spec)
+        sp["model_kwargs"]["ski_options"] = {"grid_size": 64, "num_dims": 1}
+        sp["train_kwargs"].update(max_iter=3)
+        spec = os.path.join(tmpdir, "my_%s_rank%d.json" % (spec, rank))
+        json.dump(sp, open(spec, "w"))
+        settings.max_cholesky_size._set(0)
+        settings.min_preconditioning_size._set(40)
     try:
         # runner.main itself joins the process group (gloo for --device cpu, RCCL for --device cuda)
-        df = runner.main(["-m", "additive_rp_prescale_J20", "-d", "synthetic:tiny", "-o", out, "--no_cv",
+        df = runner.main(["-m", spec, "-d", "synthetic:tiny", "-o", out, "--no_cv",
                           "--skip_random_restart", "--device", "cpu"])
         assert dist.is_initialized() and dist.get_world_size() == world
+        if "ski" in spec:            # the SKI model's solves ran row-sharded (linear_cg with an all-reduce closure)
+            from rpgp_amd import linear_cg as lcg
+            assert lcg.stats.get("row_sharded_calls", 0) > 0, "the SKI spec trained replicated"
         assert "error" not in df.columns or df["error"].isna().all(), df.get("error")
         rm = torch.tensor([float(df["rmse"].iloc[0])], dtype=torch.float64)
         got = [torch.zeros_like(rm) for _ in range(world)]
@@ -156,11 +171,13 @@ def _runner_worker(rank, world, port, tmpdir):
             dist.destroy_process_group()
 
 
-def test_runner_main_under_two_ranks(tmp_path):
+@pytest.mark.parametrize("spec", ["additive_rp_prescale_J20", "additive_spread_prescale_Jd_ski"])
+def test_runner_main_under_two_ranks(tmp_path, spec):
     """`torch.distributed.run -m rpgp_amd.runner` must shard (init the group, attach JShard), not run N
-    independent fits that race on the output file."""
-    port = 29900 + (os.getpid() % 200)
-    mp.spawn(_runner_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    independent fits that race on the output file.  Round 3: the SKI spec of BASELINE config 5 row-shards the same way
+    (run_scripts/additive_spread_prescale_Jd.sh:6 runs it on 3 devices in the reference)."""
+    port = 29900 + (os.getpid() % 200) + (211 if "ski" in spec else 0)
+    mp.spawn(_runner_worker, args=(2, port, str(tmp_path), spec), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
@@ -250,3 +267,82 @@ def test_row_sharded_ski_operator_gloo(tmp_path, world):
     mp.spawn(_row_sharded_ski_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / ("ok%d" % r))
+
+
+# ---- end-to-end: train_exact_gp under a process group equals the single-process fit epoch by epoch -------------------
+def _fit_case(case):
+    """(kind, model_kwargs, train_kwargs, X, y) of the two sharded training paths: the row-sharded SKI spec of BASELINE
+    config 5 (additive_spread_prescale_Jd_ski; grid shrunk for the CPU test double) and additive_rp_prescale_J20."""
+    from rpgp_amd import specs
+    g = torch.Generator().manual_seed(7)
+    if case == "ski":
+        spec = specs.get("additive_spread_prescale_Jd_ski")
+        mk = dict(spec["model_kwargs"], ski_options={"grid_size": 96, "num_dims": 1})
+        X = torch.randn(150, 3, generator=g)
+    else:
+        spec = specs.get("additive_rp_prescale_J20")
+        mk = dict(spec["model_kwargs"], J=6)
+        X = torch.randn(90, 4, generator=g)
+    y = torch.sin(X).sum(1) + 0.05 * torch.randn(X.shape[0], generator=g)
+    tk = dict(spec["train_kwargs"], max_iter=4, init_iters=1)
+    return spec["kind"], mk, tk, X, y
+
+
+def _fit(case, loss_log):
+    from rpgp_amd import settings, training
+    kind, mk, tk, X, y = _fit_case(case)
+    tk = dict(tk, loss_log=loss_log)
+    torch.manual_seed(11)
+    np.random.seed(11)
+    with settings.max_cholesky_size(0), settings.min_preconditioning_size(50), settings.max_preconditioner_size(5), \
+            settings.cg_tolerance(1e-7), settings.eval_cg_tolerance(1e-7), settings.deterministic_probes(True):
+        metrics, pred, model = training.train_exact_gp(X[:-12], y[:-12], X[-12:], y[-12:], kind, mk, tk, devices=["cpu"],
+                                                       skip_random_restart=True)
+    return metrics, pred, model
+
+
+def _fit_worker(rank, world, port, tmpdir, case):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rpgp_amd import backend
+        from rpgp_amd.distributed import JShard, RowShard
+        from tests.oracle_backend import OracleBackend
+        backend.set_backend(OracleBackend())
+        ref = torch.load(os.path.join(tmpdir, "ref_%s.pt" % case))
+        losses = []
+        metrics, pred, model = _fit(case, losses)
+        shard = model.covar_module.shard
+        assert isinstance(shard, RowShard if case == "ski" else JShard) and shard.world_size == world
+        assert len(losses) == len(ref["losses"])
+        for a, b in zip(losses, ref["losses"]):
+            assert abs(a - b) < 1e-5 * max(1.0, abs(b)), (losses, ref["losses"])
+        assert abs(metrics["prior_train_nmll"] - ref["nmll"]) < 1e-5 * max(1.0, abs(ref["nmll"]))
+        assert torch.allclose(pred, ref["pred"], rtol=1e-4, atol=1e-5)
+        flat = torch.cat([p.detach().reshape(-1).double() for p in model.parameters()])
+        assert torch.allclose(flat, ref["params"], rtol=1e-5, atol=1e-6), "sharded fit left the single-process trajectory"
+        allp = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(allp, flat)
+        assert all(torch.equal(a, flat) for a in allp), "ranks trained different models"
+        open(os.path.join(tmpdir, "ok_%s_%d" % (case, rank)), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("ski", 2), ("ski", 3), ("rp", 2), ("rp", 3)])
+def test_sharded_training_matches_single_process_fit(tmp_path, oracle_backend, case, world):
+    """`train_exact_gp` on the SKI spec (rows split over the ranks: solve, SLQ log-det, derivative and
+    mean cache all sharded) and on additive_rp_prescale_J20 (pair-sharded MVM) gives the single-process per-epoch losses
+    to 1e-5, the same parameters and the same predictions, with identical models on every rank."""
+    losses = []
+    metrics, pred, model = _fit(case, losses)                # single process: no process group in this (parent) process
+    assert model.covar_module.shard is None
+    torch.save({"losses": losses, "nmll": metrics["prior_train_nmll"], "pred": pred,
+                "params": torch.cat([p.detach().reshape(-1).double() for p in model.parameters()])},
+               os.path.join(str(tmp_path), "ref_%s.pt" % case))
+    port = 30300 + 7 * world + (3 if case == "ski" else 0) + (os.getpid() % 150)
+    mp.spawn(_fit_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(tmp_path / ("ok_%s_%d" % (case, r)))

@@ -241,6 +241,29 @@ int rpgp_ski_scatter(const float *Z, const float *grid_params, const float *V, d
 int rpgp_ski_grid_product(const double *hist, const float *grid_params, float *H, int J, int G, int T, void *stream);
 int rpgp_ski_gather(const float *Z, const float *grid_params, const float *H, const float *V, float *out, int64_t M,
                     int ldz, int J, int G, int T, float scale, float noise, void *stream);
+/*
+ * Planned SKI product for the square operator (Z fixed over a whole CG solve = one hyper-parameter step): rpgp_ski_plan
+ * sorts every projection's points by the grid cell of their first tap ONCE (stable radix sort: deterministic order) and
+ * keeps the tap fractions in that order; the scatter of every later product is then a segmented reduction over the sorted
+ * points — no atomics — and the Toeplitz stage reads its first column from the plan.
+ *   rpgp_ski_mvm_planned     : same result contract as rpgp_ski_mvm(Z, Z, ...) for T <= 12 (bitwise reproducible)
+ *   rpgp_ski_scatter_planned : stage 1 only (the row-sharded operator: plan built on the LOCAL rows), = rpgp_ski_scatter
+ *   rpgp_ski_gather_fast     : stage 3; with a plan of Z (may be NULL) and J * G * T floats fitting in LDS the table H is
+ *                              LDS-resident and the stencils come from the plan, else = rpgp_ski_gather
+ * Workspace of the products: rpgp_ski_workspace_bytes(J, G, T) (RPGP_EWORKSPACE when N * J is too large for the planned
+ * form: fall back to rpgp_ski_mvm).  N * J < 2^31.
+ */
+size_t rpgp_ski_plan_bytes(int64_t N, int J, int G);
+size_t rpgp_ski_plan_workspace_bytes(int64_t N, int J, int G);
+int rpgp_ski_plan(const float *Z, const float *grid_params, int64_t N, int ldz, int J, int G, void *plan, size_t plan_bytes,
+                  void *workspace, size_t workspace_bytes, void *stream);
+int rpgp_ski_mvm_planned(const void *plan, const float *Z, const float *grid_params, const float *V, float *out, int64_t N,
+                         int ldz, int J, int G, int T, float scale, float noise, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int rpgp_ski_scatter_planned(const void *plan, const float *V, double *hist, int64_t N, int J, int G, int T, void *workspace,
+                             size_t workspace_bytes, void *stream);
+int rpgp_ski_gather_fast(const void *plan, const float *Z, const float *grid_params, const float *H, const float *V, float *out,
+                         int64_t M, int ldz, int J, int G, int T, float scale, float noise, void *stream);
 /* Pivoted Cholesky of the SKI operator (same contract as rpgp_pivoted_cholesky; diag_work: N + RPGP_PIVCHOL_SCRATCH). */
 int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
                               int J, int G, int rank, float scale, void *stream);
@@ -328,7 +351,7 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
  */
 #define RPGP_OP_FUSED 0           /* rpgp_mvm_sym on Z */
 #define RPGP_OP_FUSED_PREPARED 1  /* rpgp_mvm_sym_prepared on prep */
-#define RPGP_OP_SKI 2             /* rpgp_ski_mvm on Z + grid_params */
+#define RPGP_OP_SKI 2             /* rpgp_ski_mvm on Z + grid_params; prep != NULL: an rpgp_ski_plan of Z (planned product) */
 #define RPGP_OP_DENSE 3           /* cached-K: symmetric Kd (N x N, row stride ldk) in HBM, applied by rpgp_dense_mvm */
 #define RPGP_OP_FAMILY 4          /* rpgp_family_mvm_sym on Z + family */
 #define RPGP_OP_SYMCACHE 5        /* packed symmetric cache: Kd = the cache, ldk = its size in bytes, G = its layout; scale, noise */

@@ -59,6 +59,12 @@ SIGNATURES = {
     "rpgp_ski_scatter": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _sz, _vp]),
     "rpgp_ski_grid_product": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     "rpgp_ski_gather": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp]),
+    "rpgp_ski_plan_bytes": (_sz, [_i64, _int, _int]),
+    "rpgp_ski_plan_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "rpgp_ski_plan": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _sz, _vp, _sz, _vp]),
+    "rpgp_ski_mvm_planned": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
+    "rpgp_ski_scatter_planned": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
+    "rpgp_ski_gather_fast": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp]),
     "rpgp_ski_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp]),
     "rpgp_ski_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f32, _vp]),
     "rpgp_ski_diag": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp]),

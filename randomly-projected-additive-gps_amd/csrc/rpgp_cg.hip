@@ -614,7 +614,9 @@ int apply_operator(const rpgp_operator *op, const ShardCtx &sh, const float *V, 
       if (sh.mode == RPGP_SHARD_ROWS) {
         const size_t nh = (size_t)op->J * op->G * T;
         if (op->N > 0) {
-          rc = rpgp_ski_scatter(op->Z, op->grid_params, V, sh.hist, op->N, op->ldz, op->J, op->G, T, ws, ws_bytes, stream);
+          rc = op->prep ? rpgp_ski_scatter_planned(op->prep, V, sh.hist, op->N, op->J, op->G, T, ws, ws_bytes, stream)
+                        : rpgp_ski_scatter(op->Z, op->grid_params, V, sh.hist, op->N, op->ldz, op->J, op->G, T, ws, ws_bytes,
+                                           stream);
           if (rc) return rc;
         } else {
           CG_CHECK(hipMemsetAsync(sh.hist, 0, nh * sizeof(double), reinterpret_cast<hipStream_t>(stream)));
@@ -624,11 +626,15 @@ int apply_operator(const rpgp_operator *op, const ShardCtx &sh, const float *V, 
         if (op->N <= 0) return 0;
         rc = rpgp_ski_grid_product(sh.hist, op->grid_params, sh.H, op->J, op->G, T, stream);
         if (rc) return rc;
-        return rpgp_ski_gather(op->Z, op->grid_params, sh.H, V, out, op->N, op->ldz, op->J, op->G, T, op->scale, op->noise,
-                               stream);
+        return rpgp_ski_gather_fast(op->prep, op->Z, op->grid_params, sh.H, V, out, op->N, op->ldz, op->J, op->G, T, op->scale,
+                                    op->noise, stream);
       }
-      rc = rpgp_ski_mvm(op->Z, op->Z, op->grid_params, V, out, op->N, op->N, op->ldz, op->ldz, op->J, op->G, T, op->scale,
-                        noise, ws, ws_bytes, stream);
+      if (op->prep && T <= 12)
+        rc = rpgp_ski_mvm_planned(op->prep, op->Z, op->grid_params, V, out, op->N, op->ldz, op->J, op->G, T, op->scale, noise,
+                                  ws, ws_bytes, stream);
+      else
+        rc = rpgp_ski_mvm(op->Z, op->Z, op->grid_params, V, out, op->N, op->N, op->ldz, op->ldz, op->J, op->G, T, op->scale,
+                          noise, ws, ws_bytes, stream);
       break;
     case RPGP_OP_DENSE:
       rc = rpgp_dense_mvm(op->Kd, V, out, op->N, op->ldk, T, noise, stream);

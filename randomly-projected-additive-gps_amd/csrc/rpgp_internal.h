@@ -18,4 +18,12 @@ int launch_mvm_mfma(int jt, int tt, const void *rowtab, const void *coltab, cons
                     int N, int J, int ldv, int j0, int t0, int tcnt, int chunk_cols, int accumulate, int w0, int nwg,
                     int rb_first, int slab_row0, int slab_rows, hipStream_t st);
 
+// SKI stages implemented in rpgp_kernels.hip, reused by the planned (cell-sorted) SKI product of rpgp_ski.hip
+int ski_toeplitz_launch(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T,
+                        hipStream_t st, const double *tcol);
+int ski_gather_launch(const float *Z, const float *gp, const float *H, const float *V, float *out, long long M, int ldz,
+                      int J, int G, int T, float scale, float noise, hipStream_t st);
+size_t ski_scratch_floats(int J, int G);                  // floats of per-call scratch inside rpgp_ski_workspace_bytes
+size_t ski_scratch_offset_floats(int J, int G, int T);    // ... and where it starts
+
 }  // namespace rpgp_internal

@@ -2097,39 +2097,7 @@ __global__ __launch_bounds__(256) void dense_gemv_reduce_kernel(const float *__r
 // HBM traffic ~ N (J + 2T) floats: this path is bandwidth/latency bound, not exp bound.
 // grid params (device): gp[0] = g0 (first grid point), gp[1] = h (spacing), gp[2] = 1/h
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float cubic_w(float U) {      // Keys cubic convolution kernel, U = |distance| / h in [0, 2]
-  return (U < 1.0f) ? ((1.5f * U - 2.5f) * U) * U + 1.0f : ((-0.5f * U + 2.5f) * U - 4.0f) * U + 2.0f;
-}
-__device__ __forceinline__ float cubic_dw(float U) {     // d/dU of the above
-  return (U < 1.0f) ? (4.5f * U - 5.0f) * U : (-1.5f * U + 5.0f) * U - 4.0f;
-}
-
-// taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
-// Per-projection output scales (the `weighted` components of polynomial_projection_kernels.py:88-98 under SKI): the grid
-// parameter block is [g0, h, 1/h, has_weights, w_0 .. w_{J-1}]; rpgp_ski_grid writes has_weights = 0 and the host may then
-// set it to 1 and append the weights.  K = scale * sum_j w_j W_j Tm W_j^T: the weight rides on the Toeplitz stage.
-__device__ __forceinline__ float ski_wj(const float *__restrict__ gp, int j) { return gp[3] != 0.f ? gp[4 + j] : 1.0f; }
-
-template <bool DERIV>
-__device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, float (&w)[4], float (&dw)[4]) {
-  float u = (z - g0) * inv_h;
-  u = u < 1.0f ? 1.0f : (u > (float)(G - 2) ? (float)(G - 2) : u);   // clamp into the interior (extrapolation guard)
-  const float fl = __builtin_floorf(u);
-  const float fr = u - fl;
-  int idx0 = (int)fl - 1;
-  idx0 = idx0 < 0 ? 0 : (idx0 > G - 4 ? G - 4 : idx0);
-  const float s[4] = {fr + 1.0f, fr, 1.0f - fr, 2.0f - fr};          // |signed distance| of the 4 taps
-#pragma unroll
-  for (int k = 0; k < 4; ++k) w[k] = cubic_w(s[k]);
-  if constexpr (DERIV) {
-    // signed distance s_k = fr + 1 - k: positive for k = 0,1; negative for k = 2,3;  dU/dz = sign / h
-    dw[0] = cubic_dw(s[0]) * inv_h;
-    dw[1] = cubic_dw(s[1]) * inv_h;
-    dw[2] = -cubic_dw(s[2]) * inv_h;
-    dw[3] = -cubic_dw(s[3]) * inv_h;
-  }
-  return idx0;
-}
+#include "rpgp_ski_common.h"   // cubic_w, cubic_dw, ski_wj, ski_taps (shared with rpgp_ski.hip)
 
 // global min / max of all N x J projected coordinates of up to two arrays -> grid parameters
 __global__ __launch_bounds__(256) void ski_minmax_kernel(const float *__restrict__ Z1, long long n1, int ld1,
@@ -2394,20 +2362,24 @@ typedef double doublex4m __attribute__((ext_vector_type(4)));
 // One workgroup owns ONE 16-row output tile; its 4 waves split the grid points (the K loop) four ways and add their
 // partial tiles through LDS in a fixed order.  (The first version gave each wave its own tile and the whole K loop:
 // 64 dependent K-steps x 4 MFMAs per wave and only 16 J workgroups — 31 us of the 66 us SKI MVM at the C5 shape.)
-__global__ __launch_bounds__(256) void ski_toeplitz_mfma_kernel(const double *__restrict__ hist,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void ski_toeplitz_mfma_kernel(const double *__restrict__ hist,
                                                                 const float *__restrict__ gp, float *__restrict__ H,
-                                                                int G, int T) {
-  extern __shared__ double dmem[];          // sc[G16] | red[3][256]
+                                                                int G, int T, const double *__restrict__ tcol) {
+  extern __shared__ double dmem[];          // sc[G16] | red[NW - 1][256]
   const int G16 = (G + 15) & ~15;
   double *sc = dmem;
   double *red = dmem + G16;
   const int j = blockIdx.y;
   const double hd = (double)gp[1];
-  for (int k = threadIdx.x; k < G16; k += 256) {
-    const double d = (double)k * hd;
-    sc[k] = k < G ? exp(-0.5 * d * d) : 0.0;
+  if (tcol) {                               // first column of the Toeplitz matrix from the per-step plan (no exp here)
+    for (int k = threadIdx.x; k < G16; k += 64 * NW) sc[k] = k < G ? tcol[k] : 0.0;
+  } else {
+    for (int k = threadIdx.x; k < G16; k += 64 * NW) {
+      const double d = (double)k * hd;
+      sc[k] = k < G ? exp(-0.5 * d * d) : 0.0;
+    }
   }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
   const int mrow = m0 + (lane & 15), q = lane >> 4;
@@ -2416,26 +2388,43 @@ __global__ __launch_bounds__(256) void ski_toeplitz_mfma_kernel(const double *__
   const double bmask = nb < T ? 1.0 : 0.0;
   const double amask = (mrow < G) ? 1.0 : 0.0;
   const double *hj = hist + (size_t)j * G * T;
-  // this wave's quarter of the grid points, in steps of 16 (4 MFMAs on 4 independent accumulators per step)
+  // this wave's share of the grid points, in steps of 16 (4 MFMAs on 4 independent accumulators per step)
   const int ksteps = G16 / 16;
-  const int s_begin = (ksteps * wave) / 4, s_end = (ksteps * (wave + 1)) / 4;
+  const int s_begin = (ksteps * wave) / NW, s_end = (ksteps * (wave + 1)) / NW;
   doublex4m acc4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc4[u] = doublex4m{0.0, 0.0, 0.0, 0.0};
-  for (int st = s_begin; st < s_end; ++st) {
-    double a[4], b[4];
+  // The B operands (hist_j, L2-resident) of EIGHT steps are requested together: with one step's four loads per
+  // iteration the loop was a chain of 16 dependent L2 round trips (14 us for a 3 x 1024 x 1024 x 11 product).
+  constexpr int SB = NW > 4 ? 4 : 8;
+  for (int st0 = s_begin; st0 < s_end; st0 += SB) {
+    double b[SB][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = st * 16 + 4 * u + q;
-      int dist = mrow > k ? mrow - k : k - mrow;
-      dist = dist < G16 ? dist : G16 - 1;           // only rows >= G can exceed it; they carry amask = 0
-      a[u] = sc[dist] * amask;
-      const int kc = k < G ? k : G - 1;
-      b[u] = (k < G ? hj[(size_t)kc * T + nbc] : 0.0) * bmask;     // L2-resident (J G T doubles), read once per tile
+    for (int ss = 0; ss < SB; ++ss) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = (st0 + ss) * 16 + 4 * u + q;
+        const bool ok = k < G && st0 + ss < s_end;
+        const int kc = ok ? k : 0;
+        const double x = hj[(size_t)kc * T + nbc];
+        b[ss][u] = ok ? x * bmask : 0.0;
+      }
     }
+    if (st0 == s_begin) __syncthreads();              // sc[] is complete (the loads above are already in flight)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc4[u], 0, 0, 0);
+    for (int ss = 0; ss < SB; ++ss) {
+      if (st0 + ss < s_end) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = (st0 + ss) * 16 + 4 * u + q;
+          int dist = mrow > k ? mrow - k : k - mrow;
+          dist = dist < G16 ? dist : G16 - 1;           // only rows >= G can exceed it; they carry amask = 0
+          acc4[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(sc[dist] * amask, b[ss][u], acc4[u], 0, 0, 0);
+        }
+      }
+    }
   }
+  if (s_begin >= s_end) __syncthreads();
   doublex4m acc = acc4[0] + acc4[1] + acc4[2] + acc4[3];
   if (wave > 0) {
 #pragma unroll
@@ -2444,8 +2433,10 @@ __global__ __launch_bounds__(256) void ski_toeplitz_mfma_kernel(const double *__
   __syncthreads();
   if (wave != 0 || m0 >= G) return;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    acc[r] = ((acc[r] + red[(0 * 4 + r) * 64 + lane]) + red[(1 * 4 + r) * 64 + lane]) + red[(2 * 4 + r) * 64 + lane];
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int ww = 0; ww < NW - 1; ++ww) acc[r] += red[(ww * 4 + r) * 64 + lane];       // fixed order
+  }
   const double wj = (double)ski_wj(gp, j);
   if (nb < T) {
 #pragma unroll
@@ -4434,7 +4425,8 @@ int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist
   return ski_scatter_narrow(Z, gp, V, reinterpret_cast<double *>(hist), slab, N, ldz, J, G, T, T, 0, st);
 }
 
-int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T, hipStream_t st) {
+int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T, hipStream_t st,
+                 const double *tcol = nullptr) {
   if (!hist_is_double && T > 24) {
     dim3 grid((T + 63) / 64, (G + 15) / 16, J);
     hipLaunchKernelGGL(ski_toeplitz_wide_kernel, grid, dim3(256), (size_t)G * sizeof(float), st,
@@ -4442,11 +4434,19 @@ int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H
     return launch_status();
   }
   const int G16 = (G + 15) & ~15;
-  const size_t lds = ((size_t)G16 + 3 * 256) * sizeof(double);
+  // few projections (C5: J = 3 -> 192 tiles): 16 waves per tile split the grid points, so that the launch is not 192
+  // workgroups each walking a 16-step dependent loop; many projections: 4 waves per tile (the matrix pipe is the limit)
+  const bool wide_wg = (size_t)J * ((G + 15) / 16) <= 640 && G16 >= 256;
+  const int nw = wide_wg ? 16 : 4;
+  const size_t lds = ((size_t)G16 + (size_t)(nw - 1) * 256) * sizeof(double);
   if (hist_is_double && T <= 16 && lds <= 64 * 1024) {        // matrix-core path, float64
     dim3 grid((G + 15) / 16, J);
-    hipLaunchKernelGGL(ski_toeplitz_mfma_kernel, grid, dim3(256), lds, st, reinterpret_cast<const double *>(hist), gp, H,
-                       G, T);
+    if (wide_wg)
+      hipLaunchKernelGGL(ski_toeplitz_mfma_kernel<16>, grid, dim3(1024), lds, st, reinterpret_cast<const double *>(hist), gp,
+                         H, G, T, tcol);
+    else
+      hipLaunchKernelGGL(ski_toeplitz_mfma_kernel<4>, grid, dim3(256), lds, st, reinterpret_cast<const double *>(hist), gp, H,
+                         G, T, tcol);
     return launch_status();
   }
   int Tp = 1;
@@ -4490,6 +4490,19 @@ int ski_gather_all(const float *Z, const float *gp, const float *H, const float 
   return 0;
 }
 }  // namespace
+
+namespace rpgp_internal {
+int ski_toeplitz_launch(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T,
+                        hipStream_t st, const double *tcol) {
+  return ski_toeplitz(hist, hist_is_double, gp, H, J, G, T, st, tcol);
+}
+int ski_gather_launch(const float *Z, const float *gp, const float *H, const float *V, float *out, long long M, int ldz,
+                      int J, int G, int T, float scale, float noise, hipStream_t st) {
+  return ski_gather_all(Z, gp, H, V, out, M, ldz, J, G, T, scale, noise, st);
+}
+size_t ski_scratch_floats(int J, int G) { return ski_slab_floats(J, G); }
+size_t ski_scratch_offset_floats(int J, int G, int T) { return 3 * (size_t)J * G * (2 * T) + 2 * kSkiMaxParts; }
+}  // namespace rpgp_internal
 
 extern "C" {
 

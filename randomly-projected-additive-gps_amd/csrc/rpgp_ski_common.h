@@ -1,0 +1,42 @@
+// rpgp_ski_common.h — device helpers of the SKI path shared by rpgp_kernels.hip and rpgp_ski.hip (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace {
+
+__device__ __forceinline__ float cubic_w(float U) {      // Keys cubic convolution kernel, U = |distance| / h in [0, 2]
+  return (U < 1.0f) ? ((1.5f * U - 2.5f) * U) * U + 1.0f : ((-0.5f * U + 2.5f) * U - 4.0f) * U + 2.0f;
+}
+__device__ __forceinline__ float cubic_dw(float U) {     // d/dU of the above
+  return (U < 1.0f) ? (4.5f * U - 5.0f) * U : (-1.5f * U + 5.0f) * U - 4.0f;
+}
+
+// taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
+// Per-projection output scales (the `weighted` components of polynomial_projection_kernels.py:88-98 under SKI): the grid
+// parameter block is [g0, h, 1/h, has_weights, w_0 .. w_{J-1}]; rpgp_ski_grid writes has_weights = 0 and the host may then
+// set it to 1 and append the weights.  K = scale * sum_j w_j W_j Tm W_j^T: the weight rides on the Toeplitz stage.
+__device__ __forceinline__ float ski_wj(const float *__restrict__ gp, int j) { return gp[3] != 0.f ? gp[4 + j] : 1.0f; }
+
+template <bool DERIV>
+__device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, float (&w)[4], float (&dw)[4]) {
+  float u = (z - g0) * inv_h;
+  u = u < 1.0f ? 1.0f : (u > (float)(G - 2) ? (float)(G - 2) : u);   // clamp into the interior (extrapolation guard)
+  const float fl = __builtin_floorf(u);
+  const float fr = u - fl;
+  int idx0 = (int)fl - 1;
+  idx0 = idx0 < 0 ? 0 : (idx0 > G - 4 ? G - 4 : idx0);
+  const float s[4] = {fr + 1.0f, fr, 1.0f - fr, 2.0f - fr};          // |signed distance| of the 4 taps
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = cubic_w(s[k]);
+  if constexpr (DERIV) {
+    // signed distance s_k = fr + 1 - k: positive for k = 0,1; negative for k = 2,3;  dU/dz = sign / h
+    dw[0] = cubic_dw(s[0]) * inv_h;
+    dw[1] = cubic_dw(s[1]) * inv_h;
+    dw[2] = -cubic_dw(s[2]) * inv_h;
+    dw[3] = -cubic_dw(s[3]) * inv_h;
+  }
+  return idx0;
+}
+
+
+}  // namespace

@@ -296,6 +296,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
                  row_shard=None):
         super().__init__(Z1, Z2, outputscale, weight, shard=None)     # (no J-sharding: the SKI product is O(N))
         self.grid_size = int(grid_size)
+        self._plan = None
         # Multi-GPU: the N training rows are split over the ranks (distributed.RowShard).  The operator itself keeps the
         # replicated interface (full Z, full vectors: prediction and the generic call sites are unchanged); the solves of
         # the marginal likelihood and of the mean cache run on `row_sharded(noise)` — every rank scatters / gathers ITS rows.
@@ -318,10 +319,23 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         return be.ski_pivoted_cholesky(self.Z1.detach().contiguous(), self.gp, self._scale,
                                        min(rank, self.Z1.shape[0]), self.grid_size)
 
+    def _get_plan(self):
+        """rpgp_ski_plan of the square operator (points sorted by interpolation cell), built on first use — once per
+        operator = once per hyper-parameter step; None when the backend has no planned product."""
+        be = _backend.get_backend()
+        if not self.symmetric or not hasattr(be, "ski_plan") or self.Z1.dtype != torch.float32:
+            return None
+        if self._plan is None:
+            self._plan = be.ski_plan(self.Z1.detach().contiguous(), self.gp, self.grid_size)
+        return self._plan if self._plan.ok else None
+
     def _local_matmul(self, rhs, noise=0.0):
         be = _backend.get_backend()
         z1 = self.Z1.detach()
         z2 = z1 if self.symmetric else self.Z2.detach()
+        plan = self._get_plan() if rhs.shape[-1] <= 12 or rhs.dim() == 1 else None
+        if plan is not None:
+            return be.ski_mvm(z1, z2, self.gp, rhs, self._scale, noise, self.grid_size, plan=plan)
         return be.ski_mvm(z1, z2, self.gp, rhs, self._scale, noise if self.symmetric else 0.0, self.grid_size)
 
     def native_descriptor(self, noise=0.0):
@@ -331,7 +345,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         from . import _lib
         z1 = self.Z1.detach().contiguous()
         return be.make_operator_desc(_lib.RPGP_OP_SKI, z1.shape[0], z1.shape[1], self._scale, noise, Z=z1, gp=self.gp,
-                                     G=self.grid_size)
+                                     G=self.grid_size, prep=self._get_plan())
 
     def native_sharding(self):
         return None
@@ -346,7 +360,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
             return self
         t = SKIAdditiveOperator.__new__(SKIAdditiveOperator)
         AdditiveRPOperator.__init__(t, self.Z2, self.Z1, self.outputscale, self.weight, None)
-        t.grid_size, t.gp, t.comp_weights, t.row_shard = self.grid_size, self.gp, self.comp_weights, None
+        t.grid_size, t.gp, t.comp_weights, t.row_shard, t._plan = self.grid_size, self.gp, self.comp_weights, None, None
         return t
 
     def row_sharded(self, noise):
@@ -457,6 +471,7 @@ class RowShardedSKIOperator(LinearOperator):
         self._scale = float(outputscale) * float(weight)
         self._noise = float(noise)
         be = _backend.get_backend()
+        self._plan = None
         if gp is not None:                 # the grid block of the replicated operator this one was split from
             self.gp = gp
             return
@@ -489,13 +504,18 @@ class RowShardedSKIOperator(LinearOperator):
             Vp = V[:, c0:c0 + 12].contiguous()
             J = self.Z1.shape[1]
             if self.Z1.shape[0] > 0:
-                hist = be.ski_scatter(self.Z1, self.gp, Vp, self.grid_size)
+                plan = self._get_plan()
+                hist = be.ski_scatter(self.Z1, self.gp, Vp, self.grid_size, plan=plan) if plan is not None else \
+                    be.ski_scatter(self.Z1, self.gp, Vp, self.grid_size)
             else:
                 hist = torch.zeros(J, self.grid_size, Vp.shape[1], dtype=torch.float64, device=self.Z1.device)
             self.row_shard.all_reduce_(hist, "sum")
             if self.Z1.shape[0] > 0:
                 H = be.ski_grid_product(hist, self.gp, self.grid_size)
-                outs.append(be.ski_gather(self.Z1, self.gp, H, Vp, self._scale, self._noise, self.grid_size))
+                if plan is not None:
+                    outs.append(be.ski_gather(self.Z1, self.gp, H, Vp, self._scale, self._noise, self.grid_size, plan=plan))
+                else:
+                    outs.append(be.ski_gather(self.Z1, self.gp, H, Vp, self._scale, self._noise, self.grid_size))
             else:
                 outs.append(Vp.clone())
         out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
@@ -506,6 +526,14 @@ class RowShardedSKIOperator(LinearOperator):
             return torch.zeros(0, dtype=self.dtype, device=self.device)
         return _backend.get_backend().ski_diag(self.Z1, self.gp, self._scale, self.grid_size) + self._noise
 
+    def _get_plan(self):
+        be = _backend.get_backend()
+        if not hasattr(be, "ski_plan") or self.Z1.dtype != torch.float32 or self.Z1.shape[0] == 0:
+            return None
+        if self._plan is None:
+            self._plan = be.ski_plan(self.Z1, self.gp, self.grid_size)
+        return self._plan if self._plan.ok else None
+
     def native_descriptor(self):
         """The local rows as an RPGP_OP_SKI descriptor (noise included); with `native_sharding()` the executor all-reduces
         the grid histogram and the inner products, so the solve is the row-sharded one."""
@@ -515,7 +543,7 @@ class RowShardedSKIOperator(LinearOperator):
         from . import _lib
         z = self.Z1 if self.Z1.shape[0] > 0 else torch.zeros(1, self.Z1.shape[1], dtype=self.dtype, device=self.device)
         return be.make_operator_desc(_lib.RPGP_OP_SKI, self.Z1.shape[0], self.Z1.shape[1], self._scale, self._noise, Z=z,
-                                     gp=self.gp, G=self.grid_size)
+                                     gp=self.gp, G=self.grid_size, prep=self._get_plan())
 
     def native_sharding(self):
         return ("rows", self.row_shard.reducer, self.row_shard.N)

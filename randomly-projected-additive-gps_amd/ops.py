@@ -409,8 +409,38 @@ def ski_grid(Z1, Z2=None, grid_size=1024, weights=None):
     return gp
 
 
-def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
-    """out = scale * sum_j W1_j Tm W2_j^T V (+ noise V);  Z2 may be Z1 (square operator)."""
+class SkiPlan:
+    """rpgp_ski_plan of one Z (and grid block): every projection's points sorted by interpolation cell, built once per
+    hyper-parameter step; the products of the CG solve then scatter without atomics (rpgp_ski_mvm_planned)."""
+
+    def __init__(self, Z, gp, grid_size=1024):
+        lib = _lib.load()
+        Z = _require(Z, "Z", 2)
+        self.N, self.J = Z.shape
+        self.G = int(grid_size)
+        self.device = Z.device
+        self.buf = None
+        nbytes = lib.rpgp_ski_plan_bytes(self.N, self.J, self.G) if self.N > 0 else 0
+        if nbytes == 0:
+            return
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=Z.device)
+        with torch.cuda.device(Z.device):
+            ws = _workspace(Z.device, lib.rpgp_ski_plan_workspace_bytes(self.N, self.J, self.G))
+            _lib.check(lib.rpgp_ski_plan(Z.data_ptr(), gp.data_ptr(), self.N, Z.stride(0), self.J, self.G, self.buf.data_ptr(),
+                                         self.buf.numel(), ws.data_ptr(), ws.numel(), _stream()), "rpgp_ski_plan")
+
+    @property
+    def ok(self):
+        return self.buf is not None
+
+
+def ski_plan(Z, gp, grid_size=1024):
+    return SkiPlan(Z, gp, grid_size)
+
+
+def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024, plan=None):
+    """out = scale * sum_j W1_j Tm W2_j^T V (+ noise V);  Z2 may be Z1 (square operator).  `plan` (SkiPlan of Z1, square
+    operator only): the planned product for blocks of up to 12 columns."""
     lib = _lib.load()
     Z1 = _require(Z1, "Z1", 2)
     Z2 = _require(Z2, "Z2", 2)
@@ -419,6 +449,14 @@ def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
     V2, squeeze = _as_matrix(V, N, "V")
     T = V2.shape[1]
     out = torch.empty((M, T), dtype=torch.float32, device=Z1.device)
+    if plan is not None and plan.ok and T <= 12 and M == N and plan.N == N and plan.J == J and plan.G == grid_size:
+        with torch.cuda.device(Z1.device):
+            ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
+            rc = lib.rpgp_ski_mvm_planned(plan.buf.data_ptr(), Z1.data_ptr(), gp.data_ptr(), V2.data_ptr(), out.data_ptr(), N,
+                                          J, J, grid_size, T, float(scale), float(noise), ws.data_ptr(), ws.numel(), _stream())
+        if rc != _lib.RPGP_EWORKSPACE:              # (too many points for the planned form: the plain product below)
+            _lib.check(rc, "rpgp_ski_mvm_planned")
+            return out.squeeze(1) if squeeze else out
     with torch.cuda.device(Z1.device):
         ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
         _lib.check(lib.rpgp_ski_mvm(Z1.data_ptr(), Z2.data_ptr(), gp.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N,
@@ -443,7 +481,7 @@ def ski_grid_from_range(zmin, zmax, grid_size, device, weights=None):
     return gp
 
 
-def ski_scatter(Z, gp, V, grid_size=1024):
+def ski_scatter(Z, gp, V, grid_size=1024, plan=None):
     """Stage 1 of the SKI MVM: hist[j][g][t] (float64, J x G x T) = sum over the rows of Z of w(z_ij)[g] V[i][t]."""
     lib = _lib.load()
     Z = _require(Z, "Z", 2)
@@ -451,6 +489,14 @@ def ski_scatter(Z, gp, V, grid_size=1024):
     V2, _ = _as_matrix(V, N, "V")
     T = V2.shape[1]
     hist = torch.empty((J, grid_size, T), dtype=torch.float64, device=Z.device)
+    if plan is not None and plan.ok and T <= 12 and plan.N == N and plan.J == J and plan.G == grid_size:
+        with torch.cuda.device(Z.device):
+            ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
+            rc = lib.rpgp_ski_scatter_planned(plan.buf.data_ptr(), V2.data_ptr(), hist.data_ptr(), N, J, grid_size, T,
+                                              ws.data_ptr(), ws.numel(), _stream())
+        if rc != _lib.RPGP_EWORKSPACE:
+            _lib.check(rc, "rpgp_ski_scatter_planned")
+            return hist
     with torch.cuda.device(Z.device):
         ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
         _lib.check(lib.rpgp_ski_scatter(Z.data_ptr(), gp.data_ptr(), V2.data_ptr(), hist.data_ptr(), N, J, J, grid_size,
@@ -472,7 +518,7 @@ def ski_grid_product(hist, gp, grid_size=1024):
     return H
 
 
-def ski_gather(Z, gp, H, V, scale, noise=0.0, grid_size=1024):
+def ski_gather(Z, gp, H, V, scale, noise=0.0, grid_size=1024, plan=None):
     """Stage 3: out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0 + k][t] + noise * V[i][t] for the rows of Z."""
     lib = _lib.load()
     Z = _require(Z, "Z", 2)
@@ -484,9 +530,10 @@ def ski_gather(Z, gp, H, V, scale, noise=0.0, grid_size=1024):
         V2, _ = _as_matrix(V, M, "V")
     out = torch.empty((M, T), dtype=torch.float32, device=Z.device)
     with torch.cuda.device(Z.device):
-        _lib.check(lib.rpgp_ski_gather(Z.data_ptr(), gp.data_ptr(), H.data_ptr(), None if V2 is None else V2.data_ptr(),
-                                       out.data_ptr(), M, J, J, grid_size, T, float(scale), float(noise), _stream()),
-                   "rpgp_ski_gather")
+        pl = plan.buf.data_ptr() if (plan is not None and plan.ok and plan.N == M and plan.J == J and plan.G == grid_size) else None
+        _lib.check(lib.rpgp_ski_gather_fast(pl, Z.data_ptr(), gp.data_ptr(), H.data_ptr(), None if V2 is None else V2.data_ptr(),
+                                            out.data_ptr(), M, J, J, grid_size, T, float(scale), float(noise), _stream()),
+                   "rpgp_ski_gather_fast")
     return out
 
 
@@ -767,7 +814,7 @@ def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=
     d.j0, d.j1, d.G = j0, J if j1 is None else j1, G
     d.scale, d.noise = float(scale), float(noise)
     d.Z = Z.data_ptr() if Z is not None else None
-    d.prep = prep.buf.data_ptr() if prep is not None else None
+    d.prep = prep.buf.data_ptr() if (prep is not None and prep.buf is not None) else None
     d.grid_params = gp.data_ptr() if gp is not None else None
     d.Kd = Kd.data_ptr() if Kd is not None else None
     d.ldk = Kd.stride(0) if Kd is not None else 0

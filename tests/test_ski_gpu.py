@@ -333,3 +333,63 @@ def test_preconditioned_cg_on_badly_scaled_c5_system(gpu_device):
         r = sko.mvm_sparse(Z.numpy(), Z.numpy(), x.double().cpu().numpy(), s / J, G, grid, noise) - bn
         res = np.linalg.norm(r, axis=0) / np.linalg.norm(bn, axis=0)
         assert res.mean() < 0.015, res
+
+
+# ---- the planned (cell-sorted) SKI product: rpgp_ski_plan + rpgp_ski_mvm_planned ----------------------------------------
+@pytest.mark.parametrize("N,J,T,G,spread", [(500, 3, 1, 128, 1.0), (1000, 3, 11, 1024, 1.0), (777, 8, 4, 256, 1.0),
+                                            (3000, 20, 12, 1024, 0.7), (64, 1, 1, 64, 1.0), (9, 2, 5, 16, 1.0),
+                                            (40000, 3, 11, 64, 1.0), (5000, 3, 7, 1024, 1e-3), (1, 3, 2, 32, 1.0)])
+def test_planned_ski_mvm_matches_dense_ski_oracle(gpu_device, N, J, T, G, spread):
+    """Same oracle as the unplanned product, at shapes that exercise every branch of the plan: items of < 64 and of many
+    x 64 points (G = 64 with 40 000 points: ~ 650 points per cell), empty cells (most cells at spread 1e-3), all three
+    column pieces (1 / 4 / 12 lanes per point), a single point."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + G + T)
+    Z = (rng.standard_normal((N, J)) * spread).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
+    gp = ops.ski_grid(Zt, None, G)
+    gph = gp.double().cpu().numpy()
+    grid = (float(gph[0]), float(gph[1]))
+    ref = sko.mvm_sparse(Z, Z, V, 0.4, G, grid, 0.2)
+    plan = ops.SkiPlan(Zt, gp, G)
+    assert plan.ok
+    out = ops.ski_mvm(Zt, Zt, gp, Vt, 0.4, 0.2, G, plan=plan)
+    assert _rel(out.cpu().numpy(), ref) < 2e-5
+    plain = ops.ski_mvm(Zt, Zt, gp, Vt, 0.4, 0.2, G)
+    assert _rel(out.cpu().numpy(), plain.cpu().numpy()) < 2e-6
+    # bitwise reproducible: same plan, and a plan rebuilt from scratch (stable sort: same order inside every cell)
+    assert torch.equal(out, ops.ski_mvm(Zt, Zt, gp, Vt, 0.4, 0.2, G, plan=plan))
+    assert torch.equal(out, ops.ski_mvm(Zt, Zt, gp, Vt, 0.4, 0.2, G, plan=ops.SkiPlan(Zt, gp, G)))
+    # the staged form of the row-sharded operator: planned scatter == plain scatter
+    if T <= 12:
+        h1 = ops.ski_scatter(Zt, gp, Vt, G, plan=plan)
+        h0 = ops.ski_scatter(Zt, gp, Vt, G)
+        assert float((h1 - h0).abs().max()) < 2e-5 * float(h0.abs().max() + 1e-30)
+
+
+@pytest.mark.parametrize("T", [1, 11])
+def test_planned_ski_mvm_at_full_c5_size(gpu_device, T):
+    """The planned product at exactly the C5 shape (N = 391 386, J = 3, G = 1024) against the float64 sparse-W oracle, with
+    per-projection weights as well (they ride on the Toeplitz stage), NaN propagation, and bitwise reproducibility."""
+    from rpgp_amd import ops
+    N, J, G, Z, V = _c5_problem(gpu_device, T)
+    Zt, Vt = Z.to(gpu_device), V.to(gpu_device)
+    scale, noise = 0.8 / J, 0.25
+    for weights in (None, torch.tensor([0.5, 1.25, 2.0])):
+        gp = ops.ski_grid(Zt, None, G, weights=weights)
+        gph = gp.double().cpu().numpy()
+        grid = (float(gph[0]), float(gph[1]))
+        plan = ops.SkiPlan(Zt, gp, G)
+        out = ops.ski_mvm(Zt, Zt, gp, Vt, scale, noise, G, plan=plan)
+        ref = sko.mvm_sparse(Z.numpy(), Z.numpy(), V.numpy(), scale, G, grid, noise,
+                             weights=None if weights is None else weights.numpy())
+        col = np.linalg.norm(out.double().cpu().numpy() - ref, axis=0) / np.linalg.norm(ref, axis=0)
+        assert col.max() < 2e-5, col
+        assert torch.equal(out, ops.ski_mvm(Zt, Zt, gp, Vt, scale, noise, G, plan=plan))
+    Vb = Vt.clone()
+    Vb[12345, 0] = float("nan")
+    bad = ops.ski_mvm(Zt, Zt, gp, Vb, scale, noise, G, plan=plan)
+    assert not torch.isfinite(bad[:, 0]).all()
+    if T > 1:
+        assert torch.isfinite(bad[:, 1:]).all()

@@ -224,6 +224,15 @@ int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, int layout, const f
 size_t rpgp_ski_workspace_bytes(int J, int G, int T);
 int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t N2, int ld2, int J, int G,
                   float *grid_params, void *workspace, size_t workspace_bytes, void *stream);
+/* The reference's grid rule (polynomial_projection_kernels.py:54-63; the `rp_poly` / `strictly_additive` / `additive` kinds
+ * with `ski: true`): every projection gets ITS OWN grid — spacing_j = (max_j - min_j) / (G - 4), bounds
+ * [min_j - 2.01 spacing_j, max_j + 2.01 spacing_j], G points spanning the bounds.  grid_params: 4 + 4 J floats,
+ * [., ., ., flags = 2, w_0 .. w_{J-1} = 1, (g0_j, h_j, 1/h_j) x J]; set flags = 3 and fill the w_j for per-projection output
+ * scales.  Every SKI entry point reads either block form.  (With fixed projections the reference's static bounds,
+ * computed once from X, scale with 1/lengthscale_j exactly like the current projected coordinates do, so recomputing the
+ * bounds from the current Z reproduces them.) */
+int rpgp_ski_grid_per_projection(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t N2, int ld2, int J, int G,
+                                 float *grid_params, void *workspace, size_t workspace_bytes, void *stream);
 int rpgp_ski_mvm(const float *Z1, const float *Z2, const float *grid_params, const float *V, float *out,
                  int64_t M, int64_t N, int ldz1, int ldz2, int J, int G, int T, float scale, float noise,
                  void *workspace, size_t workspace_bytes, void *stream);

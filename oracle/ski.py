@@ -4,8 +4,10 @@ model_specs/additive_spread_prescale_Jd_ski.json: grid_size 1024, num_dims 1) โ
 
 K ~= scale * sum_j W_j Tm W_j^T with cubic-convolution interpolation (Keys 1981, the 4-tap kernel GPyTorch's
 `Interpolation` uses: u<=1: ((1.5u-2.5)u)u+1 ; 1<u<=2: ((-0.5u+2.5)u-4)u+2) onto one regular grid shared by all
-projections, and Tm[m,m'] = exp(-0.5 ((m-m')h)^2).  Grid rule of this build: h = (max-min)/(G-5), g0 = min - 2h, so that
-every stencil is interior.  **Parity unpinned**: GPyTorch is not installable and the reference has no SKI tests
+projections, and Tm[m,m'] = exp(-0.5 ((m-m')h)^2).  Two grid rules: this build's shared grid (`grid_params`: h = (max-min)/(G-5),
+g0 = min - 2h over ALL projections, every stencil interior) and the reference's per-projection rule
+(`grid_params_reference`, polynomial_projection_kernels.py:54-63); every function takes `grid` as (g0, h) floats or as
+per-projection arrays.  **Parity unpinned**: GPyTorch is not installable and the reference has no SKI tests
 (SURVEY.md ยง4); this oracle pins the HIP kernels to the stated math and to the exact kernel (interpolation error)."""
 import numpy as np
 
@@ -18,6 +20,31 @@ def grid_params(Z1, Z2=None, G=1024):
     rng = max(mx - mn, 1e-12)
     h = rng / (G - 5)
     return mn - 2.0 * h, h
+
+
+def grid_params_reference(Z1, Z2=None, G=1024):
+    """The REFERENCE's grid rule (gp_models/kernels/polynomial_projection_kernels.py:54-63): per projection
+    spacing = (max - min) / (G - 4), bounds = [min - 2.01 spacing, max + 2.01 spacing]; the G grid points span the bounds.
+    Returns (g0 [J], h [J]).  With fixed projections the reference's static bounds (computed once from X at construction)
+    scale with 1 / lengthscale_j exactly like the current coordinates, so evaluating the rule on the current Z gives the
+    same grid.  What GPyTorch's GridInterpolationKernel does with explicit bounds beyond this is not restated
+    (**unpinned**: GPyTorch is not installable here)."""
+    z = np.asarray(Z1, dtype=np.float64)
+    if Z2 is not None:
+        z = np.concatenate([z, np.asarray(Z2, dtype=np.float64)], axis=0)
+    mn, mx = z.min(axis=0), z.max(axis=0)
+    rng = np.maximum(mx - mn, 1e-12)
+    spacing = rng / (G - 4)
+    b0, b1 = mn - 2.01 * spacing, mx + 2.01 * spacing
+    return b0, (b1 - b0) / (G - 1)
+
+
+def _grid_j(grid, j):
+    """(g0, h) of projection j from a shared grid (two floats) or per-projection arrays."""
+    g0, h = grid
+    if np.ndim(g0) == 0:
+        return float(g0), float(h)
+    return float(np.asarray(g0)[j]), float(np.asarray(h)[j])
 
 
 def _cubic(U):
@@ -50,12 +77,12 @@ def dense_kernel(Z1, Z2, scale, G=1024, grid=None, weights=None):
     polynomial_projection_kernels.py:88-98), default all one."""
     Z1 = np.asarray(Z1, dtype=np.float64)
     Z2 = np.asarray(Z2, dtype=np.float64)
-    g0, h = grid if grid is not None else grid_params(Z1, None if Z2 is Z1 else Z2, G)
-    Tm = toeplitz(h, G)
+    grid = grid if grid is not None else grid_params(Z1, None if Z2 is Z1 else Z2, G)
     K = np.zeros((Z1.shape[0], Z2.shape[0]))
     w = np.ones(Z1.shape[1]) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)
     for j in range(Z1.shape[1]):
-        K += w[j] * (interp_matrix(Z1[:, j], g0, h, G) @ Tm @ interp_matrix(Z2[:, j], g0, h, G).T)
+        g0, h = _grid_j(grid, j)
+        K += w[j] * (interp_matrix(Z1[:, j], g0, h, G) @ toeplitz(h, G) @ interp_matrix(Z2[:, j], g0, h, G).T)
     return scale * K
 
 
@@ -88,11 +115,13 @@ def mvm_sparse(Z1, Z2, V, scale, G, grid, noise=0.0, weights=None):
     Z1 = np.asarray(Z1, dtype=np.float64)
     Z2 = np.asarray(Z2, dtype=np.float64)
     V = np.asarray(V, dtype=np.float64).reshape(Z2.shape[0], -1)
-    g0, h = grid
-    Tm = toeplitz(h, G)
     w = np.ones(Z1.shape[1]) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)
     out = np.zeros((Z1.shape[0], V.shape[1]))
+    Tm, h_prev = None, None
     for j in range(Z1.shape[1]):
+        g0, h = _grid_j(grid, j)
+        if h != h_prev:
+            Tm, h_prev = toeplitz(h, G), h
         W2 = interp_sparse(Z2[:, j], g0, h, G)
         W1 = W2 if Z1 is Z2 else interp_sparse(Z1[:, j], g0, h, G)
         out += w[j] * (W1 @ (Tm @ (W2.T @ V)))
@@ -106,11 +135,11 @@ def diag_sparse(Z, scale, G, grid, weights=None):
     """diag(scale * sum_j w_j W_j Tm W_j^T) in float64 with O(N) memory: per row the 4 x 4 quadratic form of its
     stencil weights with the Toeplitz lags 0..3."""
     Z = np.asarray(Z, dtype=np.float64)
-    g0, h = grid
-    lag = np.exp(-0.5 * (np.arange(4) * h) ** 2)
     w = np.ones(Z.shape[1]) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)
     d = np.zeros(Z.shape[0])
     for j in range(Z.shape[1]):
+        g0, h = _grid_j(grid, j)
+        lag = np.exp(-0.5 * (np.arange(4) * h) ** 2)
         u = np.clip((Z[:, j] - g0) / h, 1.0, G - 2.0)
         fr = u - np.floor(u)
         vals = [_cubic(fr + 1.0), _cubic(fr), _cubic(1.0 - fr), _cubic(2.0 - fr)]

@@ -55,6 +55,7 @@ SIGNATURES = {
     "rpgp_symcache_mvm": (_int, [_vp, _sz, _int, _vp, _vp, _i64, _int, _f32, _f32, _int, _int, _vp, _sz, _vp]),
     "rpgp_ski_workspace_bytes": (_sz, [_int, _int, _int]),
     "rpgp_ski_grid": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
+    "rpgp_ski_grid_per_projection": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "rpgp_ski_mvm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
     "rpgp_ski_scatter": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _sz, _vp]),
     "rpgp_ski_grid_product": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),

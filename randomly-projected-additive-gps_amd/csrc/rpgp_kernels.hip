@@ -2145,6 +2145,64 @@ __global__ void ski_grid_finish_kernel(const float *__restrict__ part, int npart
   gp[3] = 0.f;
 }
 
+// Per-projection extrema (grid (chunks, J)) and the reference's grid rule (polynomial_projection_kernels.py:54-63):
+//   spacing_j = (max_j - min_j) / (G - 4);  bounds_j = [min_j - 2.01 spacing_j, max_j + 2.01 spacing_j];
+// the G grid points span the bounds uniformly, so the data keep a margin of 2.01 (G - 1) / (G + 0.02) ~ 2 cells (> 1.9 for
+// G >= 16) on either side and every 4-tap stencil is interior.  (What GPyTorch's GridInterpolationKernel does with explicit bounds
+// beyond this — it pads them by one more cell of its own — is not reproduced: GPyTorch is not available to pin it.)
+__global__ __launch_bounds__(256) void ski_minmax_proj_kernel(const float *__restrict__ Z1, long long n1, int ld1,
+                                                              const float *__restrict__ Z2, long long n2, int ld2, int J,
+                                                              float *__restrict__ part) {
+  __shared__ float smin[256], smax[256];
+  const int j = blockIdx.y;
+  float mn = 3.4e38f, mx = -3.4e38f;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n1 + n2; g += (long long)gridDim.x * 256) {
+    const float z = g < n1 ? Z1[g * ld1 + j] : Z2[(g - n1) * ld2 + j];
+    mn = min_nan(mn, z);
+    mx = max_nan(mx, z);
+  }
+  smin[threadIdx.x] = mn;
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      smin[threadIdx.x] = min_nan(smin[threadIdx.x], smin[threadIdx.x + w]);
+      smax[threadIdx.x] = max_nan(smax[threadIdx.x], smax[threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[2 * ((size_t)j * gridDim.x + blockIdx.x)] = smin[0];
+    part[2 * ((size_t)j * gridDim.x + blockIdx.x) + 1] = smax[0];
+  }
+}
+
+__global__ void ski_grid_finish_proj_kernel(const float *__restrict__ part, int nparts, int J, int G,
+                                            float *__restrict__ gp) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) {
+    gp[0] = 0.f; gp[1] = 1.f; gp[2] = 1.f;      // (unused with per-projection grids)
+    gp[3] = 2.f;                                // flags: per-projection grids, no weights
+  }
+  if (j >= J) return;
+  float mn = 3.4e38f, mx = -3.4e38f;
+  for (int p = 0; p < nparts; ++p) {
+    mn = min_nan(mn, part[2 * ((size_t)j * nparts + p)]);
+    mx = max_nan(mx, part[2 * ((size_t)j * nparts + p) + 1]);
+  }
+  float range = mx - mn;
+  if (!(range > 1e-12f)) range = 1e-12f;
+  const bool finite = (mx - mn == mx - mn);
+  const float spacing = range / (float)(G - 4);
+  const float b0 = mn - 2.01f * spacing, b1 = mx + 2.01f * spacing;
+  const float h = finite ? (b1 - b0) / (float)(G - 1) : (mx - mn);
+  gp[4 + j] = 1.0f;                             // weight slot (ones until the host sets flags |= 1 and fills them)
+  float *gj = gp + 4 + J + 3 * j;
+  gj[0] = b0;
+  gj[1] = h;
+  gj[2] = 1.0f / h;
+}
+
 // Scatter for T <= 12, parallel over projections AND point chunks: workgroup (chunk, j) accumulates its chunk's
 // contributions to projection j's histogram in LDS and stores it as a slab; ski_slab_sum_kernel adds the slabs.
 // Lanes are laid out (point, t): LPP = 1 / 4 / 16 lanes per point, so one LDS atomic instruction updates the TT
@@ -2168,8 +2226,9 @@ __global__ __launch_bounds__(256) void ski_scatter3_kernel(const float *__restri
   __shared__ float sscale[16], sinv[16];
   constexpr int LPP = TT == 1 ? 1 : (TT == 4 ? 4 : 16);
   constexpr int PPI = 256 / LPP;
-  const float g0 = gp[0], inv_h = gp[2];
   const int j = blockIdx.y;
+  const float *gj = ski_grid_of(gp, J, j);
+  const float g0 = gj[0], inv_h = gj[2];
   const long long n0 = (long long)blockIdx.x * pts_per_chunk;
   const long long n1 = (n0 + pts_per_chunk < N) ? n0 + pts_per_chunk : N;
   int *scnt = shi + G * TT;
@@ -2329,7 +2388,7 @@ __global__ __launch_bounds__(256) void ski_toeplitz_kernel(const HT_ *__restrict
                                                            float *__restrict__ H, int G, int T) {
   extern __shared__ double scd[];   // G toeplitz coefficients (float64)
   double *sc = scd;
-  const double hd = (double)gp[1];
+  const double hd = (double)ski_grid_of(gp, gridDim.y, blockIdx.y)[1];
   for (int k = threadIdx.x; k < G; k += 256) {
     const double d = (double)k * hd;
     sc[k] = exp(-0.5 * d * d);
@@ -2371,9 +2430,10 @@ __global__ __launch_bounds__(64 * NW) void ski_toeplitz_mfma_kernel(const double
   double *sc = dmem;
   double *red = dmem + G16;
   const int j = blockIdx.y;
-  const double hd = (double)gp[1];
+  const double hd = (double)ski_grid_of(gp, gridDim.y, j)[1];
   if (tcol) {                               // first column of the Toeplitz matrix from the per-step plan (no exp here)
-    for (int k = threadIdx.x; k < G16; k += 64 * NW) sc[k] = k < G ? tcol[k] : 0.0;
+    const double *tc = tcol + (size_t)((ski_flags(gp) & 2) ? j : 0) * G16;
+    for (int k = threadIdx.x; k < G16; k += 64 * NW) sc[k] = k < G ? tc[k] : 0.0;
   } else {
     for (int k = threadIdx.x; k < G16; k += 64 * NW) {
       const double d = (double)k * hd;
@@ -2466,7 +2526,6 @@ __global__ __launch_bounds__(256) void ski_gather_kernel(const float *__restrict
   const long long i = (long long)blockIdx.x * PPB + pl;
   const bool live = i < M;
   const bool writer = live && t < tcnt;
-  const float g0 = gp[0], inv_h = gp[2];
   const float *zrow = Z + (live ? i : 0) * ldz;
   double acc = 0.0;                          // J terms per output in float64; the 4 taps of a projection in fp32 FMAs
   if constexpr (LPP == 1) {
@@ -2474,7 +2533,8 @@ __global__ __launch_bounds__(256) void ski_gather_kernel(const float *__restrict
 #pragma unroll 4
     for (int j = 0; j < J; ++j) {
       float w[4], dw[4];
-      const int idx0 = ski_taps<false>(zrow[j], g0, inv_h, G, w, dw);
+      const float *gj = ski_grid_of(gp, J, j);
+      const int idx0 = ski_taps<false>(zrow[j], gj[0], gj[2], G, w, dw);
       const float *hp = H + ((size_t)j * G + idx0) * T + t0;
       float p = w[0] * hp[0];
       p = __builtin_fmaf(w[1], hp[(size_t)T], p);
@@ -2487,7 +2547,8 @@ __global__ __launch_bounds__(256) void ski_gather_kernel(const float *__restrict
       const int jj = j0 + t;
       if (jj < J) {
         float w[4], dw[4];
-        const int idx0 = live ? ski_taps<false>(zrow[jj], g0, inv_h, G, w, dw) : 0;
+        const float *gj = ski_grid_of(gp, J, jj);
+        const int idx0 = live ? ski_taps<false>(zrow[jj], gj[0], gj[2], G, w, dw) : 0;
         float *dst = sTap + (pl * LPP + t) * 5;
         dst[0] = __builtin_bit_cast(float, idx0);
         dst[1] = w[0]; dst[2] = w[1]; dst[3] = w[2]; dst[4] = w[3];
@@ -2523,7 +2584,6 @@ __global__ __launch_bounds__(256) void ski_scatter_wide_kernel(const float *__re
                                                                int hoff, long long pts_per_block) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.y * 64 + lane;
-  const float g0 = gp[0], inv_h = gp[2];
   const long long n0 = (long long)blockIdx.x * pts_per_block;
   const long long n1 = (n0 + pts_per_block < N) ? n0 + pts_per_block : N;
   if (t >= T) return;
@@ -2531,7 +2591,8 @@ __global__ __launch_bounds__(256) void ski_scatter_wide_kernel(const float *__re
     const float v = V[i * T + t];
     for (int j = 0; j < J; ++j) {
       float w[4], dw[4];
-      const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+      const float *gj = ski_grid_of(gp, J, j);
+      const int idx0 = ski_taps<false>(Z[i * ldz + j], gj[0], gj[2], G, w, dw);
 #pragma unroll
       for (int k = 0; k < 4; ++k) atomicAdd(&hist[((size_t)j * G + idx0 + k) * HT + hoff + t], w[k] * v);
     }
@@ -2542,7 +2603,7 @@ __global__ __launch_bounds__(256) void ski_toeplitz_wide_kernel(const float *__r
                                                                 const float *__restrict__ gp, float *__restrict__ H,
                                                                 int G, int T) {
   extern __shared__ float sc[];   // G toeplitz coefficients
-  const float hs = gp[1] * kExp2Scale;
+  const float hs = ski_grid_of(gp, gridDim.z, blockIdx.z)[1] * kExp2Scale;
   for (int k = threadIdx.x; k < G; k += 256) {
     const float d = (float)k * hs;
     sc[k] = fast_exp2(-(d * d));
@@ -2576,7 +2637,6 @@ __global__ __launch_bounds__(256) void ski_gather_wide_kernel(const float *__res
                                                               long long pts_per_block) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.y * 64 + lane;
-  const float g0 = gp[0], inv_h = gp[2];
   const long long n0 = (long long)blockIdx.x * pts_per_block;
   const long long n1 = (n0 + pts_per_block < M) ? n0 + pts_per_block : M;
   if (t >= T) return;
@@ -2584,7 +2644,8 @@ __global__ __launch_bounds__(256) void ski_gather_wide_kernel(const float *__res
     float acc = 0.f;
     for (int j = 0; j < J; ++j) {
       float w[4], dw[4];
-      const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+      const float *gj = ski_grid_of(gp, J, j);
+      const int idx0 = ski_taps<false>(Z[i * ldz + j], gj[0], gj[2], G, w, dw);
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(w[k], H[((size_t)j * G + idx0 + k) * T + t], acc);
     }
@@ -2605,7 +2666,6 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
                                                               int J, int G, int T, float scale, float *__restrict__ rowC) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const float g0 = gp[0], inv_h = gp[2];
   float li[TT], ri[TT];
 #pragma unroll
   for (int t = 0; t < TT; ++t) {
@@ -2616,7 +2676,8 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
   const int T2 = 2 * T;
   for (int j = 0; j < J; ++j) {
     float w[4], dw[4];
-    const int idx0 = ski_taps<true>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+    const float *gj = ski_grid_of(gp, J, j);
+    const int idx0 = ski_taps<true>(Z[i * ldz + j], gj[0], gj[2], G, w, dw);
     float gz = 0.f, accj = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2651,18 +2712,22 @@ __global__ __launch_bounds__(256) void ski_dense_kernel(const float *__restrict_
   float *sc = smem;
   float *sW = smem + G;
   int *sI = reinterpret_cast<int *>(sW + RT * J * 4);
-  const float g0 = gp[0], inv_h = gp[2], hs = gp[1] * kExp2Scale;
+  const bool per_proj = (ski_flags(gp) & 2) != 0;     // per-projection grids: the 7 lags are evaluated on the fly
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * RT;
-  for (int q = tid; q < G; q += 256) {
-    const float dd = (float)q * hs;
-    sc[q] = fast_exp2(-(dd * dd));
+  if (!per_proj) {
+    const float hs = gp[1] * kExp2Scale;
+    for (int q = tid; q < G; q += 256) {
+      const float dd = (float)q * hs;
+      sc[q] = fast_exp2(-(dd * dd));
+    }
   }
   for (int e = tid; e < RT * J; e += 256) {
     const int r = e / J, j = e % J;
     float w[4] = {0.f, 0.f, 0.f, 0.f}, dw[4];
     int idx = 0;
-    if (m0 + r < M) idx = ski_taps<false>(Z1[(size_t)(m0 + r) * ldz1 + j], g0, inv_h, G, w, dw);
+    const float *gj = ski_grid_of(gp, J, j);
+    if (m0 + r < M) idx = ski_taps<false>(Z1[(size_t)(m0 + r) * ldz1 + j], gj[0], gj[2], G, w, dw);
     sI[e] = idx;
 #pragma unroll
     for (int q = 0; q < 4; ++q) sW[e * 4 + q] = w[q];
@@ -2675,8 +2740,10 @@ __global__ __launch_bounds__(256) void ski_dense_kernel(const float *__restrict_
   for (int r = 0; r < RT; ++r) acc[r] = 0.f;
   for (int j = 0; j < J; ++j) {
     float wc[4], dw[4];
-    const int idc = ski_taps<false>(Z2[(size_t)col * ldz2 + j], g0, inv_h, G, wc, dw);
+    const float *gj = ski_grid_of(gp, J, j);
+    const int idc = ski_taps<false>(Z2[(size_t)col * ldz2 + j], gj[0], gj[2], G, wc, dw);
     const float wj = ski_wj(gp, j);
+    const float hsj = gj[1] * kExp2Scale;
 #pragma unroll 4
     for (int r = 0; r < RT; ++r) {
       const int delta = sI[r * J + j] - idc;
@@ -2686,7 +2753,12 @@ __global__ __launch_bounds__(256) void ski_dense_kernel(const float *__restrict_
       for (int u = 0; u < 7; ++u) {
         int lag = delta + u - 3;
         lag = lag < 0 ? -lag : lag;
-        tl[u] = lag < G ? sc[lag] : 0.f;
+        if (per_proj) {
+          const float dd = (float)lag * hsj;
+          tl[u] = fast_exp2(-(dd * dd));
+        } else {
+          tl[u] = lag < G ? sc[lag] : 0.f;
+        }
       }
       float aj = 0.f;
 #pragma unroll
@@ -2707,14 +2779,15 @@ __global__ __launch_bounds__(256) void ski_diag_kernel(const float *__restrict__
                                                        float scale) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const float g0 = gp[0], inv_h = gp[2], hs = gp[1] * kExp2Scale;
-  float c[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { const float d = (float)k * hs; c[k] = fast_exp2(-(d * d)); }
   float acc = 0.f;
   for (int j = 0; j < J; ++j) {
     float w[4], dw[4];
-    ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+    const float *gj = ski_grid_of(gp, J, j);
+    const float hs = gj[1] * kExp2Scale;
+    float c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = (float)k * hs; c[k] = fast_exp2(-(d * d)); }
+    ski_taps<false>(Z[i * ldz + j], gj[0], gj[2], G, w, dw);
     float aj = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -2917,7 +2990,8 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
     szp[threadIdx.x] = zp * pre;
     if (gp) {
       float w[4], dw[4];
-      spidx[threadIdx.x] = ski_taps<false>(zp, gp[0], gp[2], G, w, dw);
+      const float *gj = ski_grid_of(gp, ncols, threadIdx.x);
+      spidx[threadIdx.x] = ski_taps<false>(zp, gj[0], gj[2], G, w, dw);
 #pragma unroll
       for (int q = 0; q < 4; ++q) spw[threadIdx.x][q] = w[q];
     }
@@ -2933,11 +3007,12 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
       float row;
       if (gp) {
         // K_ski(i, piv) = sum_j sum_{q,q'} w_q(z_ij) w_q'(z_pj) Toep[(idx_i + q) - (idx_p + q')]: 7 distinct lags per column
-        const float g0 = gp[0], inv_h = gp[2], hs = gp[1] * kExp2Scale;
         float acc = 0.f;
         for (int j = 0; j < ncols; ++j) {
           float w[4], dw[4];
-          const int idx = ski_taps<false>(Z[(size_t)i * ldz + j], g0, inv_h, G, w, dw);
+          const float *gj = ski_grid_of(gp, ncols, j);
+          const float hs = gj[1] * kExp2Scale;
+          const int idx = ski_taps<false>(Z[(size_t)i * ldz + j], gj[0], gj[2], G, w, dw);
           const int delta = idx - spidx[j];
           float tl[7];
 #pragma unroll
@@ -4527,6 +4602,25 @@ int rpgp_ski_grid(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t
   hipLaunchKernelGGL(ski_minmax_kernel, dim3(nblk), dim3(256), 0, st, Z1, (long long)N1, ld1, Z2 ? Z2 : Z1, n2,
                      Z2 ? ld2 : ld1, J, part);
   hipLaunchKernelGGL(ski_grid_finish_kernel, dim3(1), dim3(64), 0, st, part, nblk, G, grid_params);
+  return launch_status();
+}
+
+int rpgp_ski_grid_per_projection(const float *Z1, int64_t N1, int ld1, const float *Z2, int64_t N2, int ld2, int J, int G,
+                                 float *grid_params, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!Z1 || N1 <= 0 || J <= 0 || G < 8 || !grid_params || ld1 < J || (Z2 && (N2 <= 0 || ld2 < J))) return RPGP_EINVAL;
+  const long long n2 = Z2 ? N2 : 0;
+  int nblk = (int)((N1 + n2 + 4095) / 4096);
+  const int cap = kSkiMaxParts / (J > 0 ? J : 1) > 0 ? kSkiMaxParts / J : 1;
+  if (nblk > cap) nblk = cap;
+  if (nblk < 1) nblk = 1;
+  if (!workspace || workspace_bytes < 2 * (size_t)kSkiMaxParts * sizeof(float) || (size_t)nblk * J > (size_t)kSkiMaxParts)
+    return RPGP_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  float *part = reinterpret_cast<float *>(workspace);
+  hipLaunchKernelGGL(ski_minmax_proj_kernel, dim3((unsigned)nblk, (unsigned)J), dim3(256), 0, st, Z1, (long long)N1, ld1,
+                     Z2 ? Z2 : Z1, n2, Z2 ? ld2 : ld1, J, part);
+  hipLaunchKernelGGL(ski_grid_finish_proj_kernel, dim3((unsigned)((J + 63) / 64)), dim3(64), 0, st, part, nblk, J, G,
+                     grid_params);
   return launch_status();
 }
 

@@ -44,7 +44,7 @@ struct PlanView {
   int *cell_start;     // [J * G + 1]  first entry of cell (j, c);  cell = index of the first tap, 0 .. G - 4
   int *item_start;     // [J * G + 1]  first scatter item of the cell (exclusive scan of ceil(count / kSeg))
   int2 *item_info;     // [max_items]  (first sorted entry, number of points) of every scatter item
-  double *tcol;        // [G16]  first column of the Toeplitz matrix, exp(-0.5 (k h)^2)
+  double *tcol;        // [J][G16]  first column of the Toeplitz matrix of every projection, exp(-0.5 (k h_j)^2)
   size_t bytes;
 };
 
@@ -61,7 +61,7 @@ inline PlanView plan_view(void *base, long long N, int J, int G) {
   v.cell_start = reinterpret_cast<int *>(p); p += align256(cells * sizeof(int));
   v.item_start = reinterpret_cast<int *>(p); p += align256(cells * sizeof(int));
   v.item_info = reinterpret_cast<int2 *>(p); p += align256((size_t)max_items(N, J, G) * sizeof(int2));
-  v.tcol = reinterpret_cast<double *>(p); p += align256(G16 * sizeof(double));
+  v.tcol = reinterpret_cast<double *>(p); p += align256((size_t)J * G16 * sizeof(double));
   v.bytes = (size_t)(p - reinterpret_cast<char *>(base));
   return v;
 }
@@ -75,13 +75,13 @@ __global__ __launch_bounds__(256) void plan_keys_kernel(const float *__restrict_
                                                         long long N, int ldz, int J, int G, unsigned *__restrict__ keys,
                                                         unsigned *__restrict__ vals, float4 *__restrict__ wnat,
                                                         int *__restrict__ inat) {
-  const float g0 = gp[0], inv_h = gp[2];
   const long long total = N * J;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int j = (int)(e / N);
     const long long i = e - (long long)j * N;
     float w[4], dw[4];
-    const int idx0 = ski_taps<false>(Z[i * ldz + j], g0, inv_h, G, w, dw);
+    const float *gj = ski_grid_of(gp, J, j);
+    const int idx0 = ski_taps<false>(Z[i * ldz + j], gj[0], gj[2], G, w, dw);
     keys[e] = (unsigned)(j * G + idx0);
     vals[e] = (unsigned)e;
     wnat[i * J + j] = make_float4(w[0], w[1], w[2], w[3]);
@@ -104,9 +104,11 @@ __global__ __launch_bounds__(256) void plan_starts_kernel(const unsigned *__rest
     cell_start[c] = (int)lo;
   }
   const int G16 = (G + 15) & ~15;
-  if (c < G16) {
-    const double d = (double)c * (double)gp[1];
-    tcol[c] = c < G ? exp(-0.5 * d * d) : 0.0;
+  const int J = cells / G;
+  if (c < J * G16) {                         // (with a shared grid only row 0 is read)
+    const int j = c / G16, k = c % G16;
+    const double d = (double)k * (double)ski_grid_of(gp, J, j)[1];
+    tcol[c] = k < G ? exp(-0.5 * d * d) : 0.0;
   }
 }
 
@@ -292,7 +294,6 @@ __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__res
   }
   const int lane = threadIdx.x & 63;
   const int c = lane & 3, pg = lane >> 2;                     // 16 points per wave step, 4 lanes per point
-  const float g0 = gp[0], inv_h = gp[2];
   const long long gw = (long long)blockIdx.x * 16 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 16;
   const long long groups = (M + 15) / 16;                     // point groups of 16
   int colc[CPL];
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__res
         float zz = zc[u];
         if (j0 > 0) zz = (live && j0 + c < J) ? Z[p * ldz + j0 + c] : 0.f;
         float w[4], dw[4];
-        const int idx_mine = ski_taps<false>(zz, g0, inv_h, G, w, dw);
+        const float *gj = ski_grid_of(gp, J, j0 + c < J ? j0 + c : 0);
+        const int idx_mine = ski_taps<false>(zz, gj[0], gj[2], G, w, dw);
         auto one = [&](int jq, int idx0, float w0, float w1, float w2, float w3) {
           if (jq < J) {
             const float *hp = sH + ((size_t)jq * G + idx0) * T;
@@ -460,7 +462,7 @@ int rpgp_ski_plan(const float *Z, const float *grid_params, int64_t N, int ldz, 
   if (e != hipSuccess) return (int)e;
   const int cells = J * G;
   const int G16 = (G + 15) & ~15;
-  const int nthreads = (cells + 1 > G16 ? cells + 1 : G16);
+  const int nthreads = (cells + 1 > J * G16 ? cells + 1 : J * G16);
   hipLaunchKernelGGL(plan_starts_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, keys_out, (long long)nj,
                      cells, pv.cell_start, grid_params, G, pv.tcol);
   hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(1024), 0, st, pv.cell_start, cells, pv.item_start, pv.item_info);

@@ -11,12 +11,21 @@ __device__ __forceinline__ float cubic_dw(float U) {     // d/dU of the above
   return (U < 1.0f) ? (4.5f * U - 5.0f) * U : (-1.5f * U + 5.0f) * U - 4.0f;
 }
 
-// taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
-// Per-projection output scales (the `weighted` components of polynomial_projection_kernels.py:88-98 under SKI): the grid
-// parameter block is [g0, h, 1/h, has_weights, w_0 .. w_{J-1}]; rpgp_ski_grid writes has_weights = 0 and the host may then
-// set it to 1 and append the weights.  K = scale * sum_j w_j W_j Tm W_j^T: the weight rides on the Toeplitz stage.
-__device__ __forceinline__ float ski_wj(const float *__restrict__ gp, int j) { return gp[3] != 0.f ? gp[4 + j] : 1.0f; }
+// Grid parameter block (device floats):
+//   shared grid (flags & 2 == 0):  [g0, h, 1/h, flags, (w_0 .. w_{J-1} if flags & 1)]
+//   per-projection grids (flags & 2):  [., ., ., flags, w_0 .. w_{J-1} (ones when flags & 1 == 0), (g0_j, h_j, 1/h_j) x J]
+// flags & 1: per-projection output scales (the `weighted` components of polynomial_projection_kernels.py:88-98 under SKI),
+// K = scale * sum_j w_j W_j Tm_j W_j^T — the weight rides on the Toeplitz stage.  flags & 2: the reference's grid rule
+// (polynomial_projection_kernels.py:54-63: every projection has its own bounds, spacing (max - min) / (G - 4), +- 2.01
+// spacings of margin), so interpolation cells, and the Toeplitz first column, differ per projection.
+__device__ __forceinline__ int ski_flags(const float *__restrict__ gp) { return (int)gp[3]; }
+__device__ __forceinline__ float ski_wj(const float *__restrict__ gp, int j) { return (ski_flags(gp) & 1) ? gp[4 + j] : 1.0f; }
+// (g0, h, 1/h) of projection j
+__device__ __forceinline__ const float *ski_grid_of(const float *__restrict__ gp, int J, int j) {
+  return (ski_flags(gp) & 2) ? gp + 4 + J + 3 * j : gp;
+}
 
+// taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
 template <bool DERIV>
 __device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, float (&w)[4], float (&dw)[4]) {
   float u = (z - g0) * inv_h;

@@ -209,6 +209,9 @@ class GeneralizedProjectionKernel(Kernel):
             raise ValueError("only 1-D grid interpolation per projection is supported (ski_options.num_dims == 1)")
         self.ski = bool(ski)
         self.grid_size = int(dict(ski_options or {}).get("grid_size", 1024))
+        # the reference's per-projection grid bounds (polynomial_projection_kernels.py:54-63); `ski_options["grid_rule"] =
+        # "shared"` selects this build's single shared grid instead
+        self.grid_rule = dict(ski_options or {}).get("grid_rule", "reference")
         if len(set(degrees)) != 1:
             raise NotImplementedError("multiplicative groups of different sizes are not built (general_rp_poly)")
         if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
@@ -258,11 +261,12 @@ class GeneralizedProjectionKernel(Kernel):
         z1 = self.project(x1)
         z2 = None if same else self.project(x2)
         if self.ski:
-            # one shared dynamic grid over the current projections (the reference fixes per-projection bounds from X at
-            # construction, polynomial_projection_kernels.py:52-61); per-component output scales ride in the grid block
+            # per-projection grids by the reference's rule, re-evaluated on the current projections (= its static bounds from X,
+            # polynomial_projection_kernels.py:52-63, which scale with 1 / lengthscale like the coordinates do);
+            # per-component output scales ride in the grid block
             return SKIAdditiveOperator(z1, z2, outputscale=outputscale, weight=1.0, grid_size=self.grid_size,
                                        comp_weights=self.outputscales,
-                                       row_shard=shard if isinstance(shard, RowShard) else None)
+                                       row_shard=shard if isinstance(shard, RowShard) else None, grid_rule=self.grid_rule)
         return FamilyAdditiveOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
                                       kind=self.kernel_type, group=self.k)
 

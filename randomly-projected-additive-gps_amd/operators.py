@@ -293,7 +293,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
     (once per hyper-parameter step) and is not differentiated (it is a buffer in GPyTorch as well)."""
 
     def __init__(self, Z1, Z2=None, outputscale=None, weight=1.0, shard=None, grid_size=1024, comp_weights=None,
-                 row_shard=None):
+                 row_shard=None, grid_rule="shared"):
         super().__init__(Z1, Z2, outputscale, weight, shard=None)     # (no J-sharding: the SKI product is O(N))
         self.grid_size = int(grid_size)
         self._plan = None
@@ -305,12 +305,17 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         # per-projection output scales (weighted rp_poly / strictly_additive kinds with `ski: true`): they ride in the
         # grid parameter block and every SKI kernel applies them on the Toeplitz stage
         self.comp_weights = comp_weights
+        # grid rule: "shared" = one grid over all projections (this build's rule for the additive_rp kinds, whose reference
+        # `GridInterpolationKernel(kernel, **ski_options)` at training_routines.py:157-158 passes no bounds); "reference" =
+        # the per-projection bounds of polynomial_projection_kernels.py:54-63 (rp_poly / strictly_additive / additive kinds)
+        self.grid_rule = grid_rule
         be = _backend.get_backend()
+        kw = {} if grid_rule == "shared" else {"rule": grid_rule}
         if comp_weights is None:
-            self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size)
+            self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size, **kw)
         else:
             self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size,
-                                  weights=comp_weights.detach())
+                                  weights=comp_weights.detach(), **kw)
 
     def fused_pivoted_cholesky(self, rank):
         be = _backend.get_backend()
@@ -361,6 +366,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         t = SKIAdditiveOperator.__new__(SKIAdditiveOperator)
         AdditiveRPOperator.__init__(t, self.Z2, self.Z1, self.outputscale, self.weight, None)
         t.grid_size, t.gp, t.comp_weights, t.row_shard, t._plan = self.grid_size, self.gp, self.comp_weights, None, None
+        t.grid_rule = self.grid_rule
         return t
 
     def row_sharded(self, noise):

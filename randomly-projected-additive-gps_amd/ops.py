@@ -383,29 +383,36 @@ def symcache_mvm(cache, V, scale, noise=0.0):
 
 # ------------------------------------------------------------------------------------------------ SKI path
 
-def ski_grid(Z1, Z2=None, grid_size=1024, weights=None):
-    """Device tensor [g0, h, 1/h, has_weights, (w_0 .. w_{J-1})] of the shared 1-D interpolation grid covering Z1 (and
-    Z2); `weights` (J per-projection output scales) switches every SKI entry point to the weighted sum."""
+def ski_grid(Z1, Z2=None, grid_size=1024, weights=None, rule="shared"):
+    """Device grid-parameter block covering Z1 (and Z2).
+    rule "shared" (this build's default for the additive_rp kinds): ONE regular grid for all projections,
+        [g0, h, 1/h, flags, (w_0 .. w_{J-1})];
+    rule "reference" (polynomial_projection_kernels.py:54-63, the rp_poly / strictly_additive / additive kinds): a grid
+        per projection, [., ., ., flags, w_0 .. w_{J-1}, (g0_j, h_j, 1/h_j) x J].
+    `weights` (J per-projection output scales) switches every SKI entry point to the weighted sum (flags |= 1)."""
     lib = _lib.load()
     Z1 = _require(Z1, "Z1", 2)
     N1, J = Z1.shape
-    gp = torch.empty(4 if weights is None else 4 + J, dtype=torch.float32, device=Z1.device)
+    if rule not in ("shared", "reference"):
+        raise ValueError("unknown SKI grid rule %r (shared | reference)" % (rule,))
+    per_proj = rule == "reference"
+    gp = torch.empty(4 + 4 * J if per_proj else (4 if weights is None else 4 + J), dtype=torch.float32, device=Z1.device)
+    fn = lib.rpgp_ski_grid_per_projection if per_proj else lib.rpgp_ski_grid
     with torch.cuda.device(Z1.device):
         ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, 1))
         if Z2 is None:
-            rc = lib.rpgp_ski_grid(Z1.data_ptr(), N1, J, None, 0, 0, J, grid_size, gp.data_ptr(), ws.data_ptr(),
-                                   ws.numel(), _stream())
+            rc = fn(Z1.data_ptr(), N1, J, None, 0, 0, J, grid_size, gp.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         else:
             Z2 = _require(Z2, "Z2", 2)
-            rc = lib.rpgp_ski_grid(Z1.data_ptr(), N1, J, Z2.data_ptr(), Z2.shape[0], Z2.shape[1], J, grid_size,
-                                   gp.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+            rc = fn(Z1.data_ptr(), N1, J, Z2.data_ptr(), Z2.shape[0], Z2.shape[1], J, grid_size, gp.data_ptr(), ws.data_ptr(),
+                    ws.numel(), _stream())
         _lib.check(rc, "rpgp_ski_grid")
     if weights is not None:
         w = weights.detach().to(device=Z1.device, dtype=torch.float32).reshape(-1)
         if w.numel() != J:
             raise ValueError("weights must have one entry per projection (%d)" % J)
-        gp[3] = 1.0
-        gp[4:] = w
+        gp[3] = 3.0 if per_proj else 1.0
+        gp[4:4 + J] = w
     return gp
 
 

@@ -150,7 +150,14 @@ class OracleBackend:
         return _t(g, Z), _t(gc, Z)
 
     # ---- SKI path -------------------------------------------------------------------------------------------
-    def ski_grid(self, Z1, Z2=None, grid_size=1024, weights=None):
+    def ski_grid(self, Z1, Z2=None, grid_size=1024, weights=None, rule="shared"):
+        J = Z1.shape[1]
+        if rule == "reference":          # per-projection grids: [., ., ., flags, w_0..w_{J-1}, (g0_j, h_j, 1/h_j) x J]
+            g0, h = sko.grid_params_reference(_np(Z1), None if Z2 is None else _np(Z2), grid_size)
+            head = [0.0, 1.0, 1.0, 2.0 if weights is None else 3.0]
+            w = [1.0] * J if weights is None else [float(x) for x in weights.detach().reshape(-1)]
+            tail = [v for j in range(J) for v in (g0[j], h[j], 1.0 / h[j])]
+            return torch.tensor(head + w + tail, dtype=torch.float64)
         g0, h = sko.grid_params(_np(Z1), None if Z2 is None else _np(Z2), grid_size)
         head = [g0, h, 1.0 / h, 0.0 if weights is None else 1.0]
         tail = [] if weights is None else [float(x) for x in weights.detach().reshape(-1)]
@@ -158,10 +165,20 @@ class OracleBackend:
 
     def _grid(self, gp):
         g = gp.double()
+        if int(g[3]) & 2:
+            J = (g.numel() - 4) // 4
+            arr = g[4 + J:].reshape(J, 3).numpy()
+            return arr[:, 0].copy(), arr[:, 1].copy()
         return float(g[0]), float(g[1])
 
     def _w(self, gp):
-        return None if float(gp[3]) == 0.0 else gp[4:].double().numpy()
+        flags = int(gp[3])
+        if not flags & 1:
+            return None
+        if flags & 2:
+            J = (gp.numel() - 4) // 4
+            return gp[4:4 + J].double().numpy()
+        return gp[4:].double().numpy()
 
     def ski_mvm(self, Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
         squeeze = V.dim() == 1
@@ -186,23 +203,23 @@ class OracleBackend:
 
     def ski_scatter(self, Z, gp, V, grid_size=1024):
         z, v = _np(Z), _np(V).reshape(Z.shape[0], -1)
-        g0, h = self._grid(gp)
-        hist = np.stack([sko.interp_sparse(z[:, j], g0, h, grid_size).T @ v for j in range(z.shape[1])])
+        grid = self._grid(gp)
+        hist = np.stack([sko.interp_sparse(z[:, j], *sko._grid_j(grid, j), grid_size).T @ v for j in range(z.shape[1])])
         return torch.from_numpy(hist)
 
     def ski_grid_product(self, hist, gp, grid_size=1024):
-        g0, h = self._grid(gp)
-        Tm = sko.toeplitz(h, grid_size)
+        grid = self._grid(gp)
         w = self._w(gp)
-        H = np.stack([(1.0 if w is None else w[j]) * (Tm @ hist[j].double().numpy()) for j in range(hist.shape[0])])
+        H = np.stack([(1.0 if w is None else w[j]) * (sko.toeplitz(sko._grid_j(grid, j)[1], grid_size) @ hist[j].double().numpy())
+                      for j in range(hist.shape[0])])
         return torch.from_numpy(H)
 
     def ski_gather(self, Z, gp, H, V, scale, noise=0.0, grid_size=1024):
         z = _np(Z)
-        g0, h = self._grid(gp)
+        grid = self._grid(gp)
         out = np.zeros((z.shape[0], H.shape[2]))
         for j in range(z.shape[1]):
-            out += sko.interp_sparse(z[:, j], g0, h, grid_size) @ H[j].double().numpy()
+            out += sko.interp_sparse(z[:, j], *sko._grid_j(grid, j), grid_size) @ H[j].double().numpy()
         out *= scale
         if noise:
             out += noise * _np(V).reshape(z.shape[0], -1)
@@ -215,14 +232,15 @@ class OracleBackend:
         """Analytic derivative of sum((L R^T) * K_ski) in float64 (same formulas as the HIP kernel, dense)."""
         z = _np(Z)
         Ld, Rd = _np(L).reshape(z.shape[0], -1), _np(R).reshape(z.shape[0], -1)
-        g0, h = self._grid(gp)
+        grid = self._grid(gp)
         G = grid_size
-        Tm = sko.toeplitz(h, G)
         gZ = np.zeros_like(z)
         gs = 0.0
         wts = self._w(gp)
         self._last_comp = np.zeros(z.shape[1])
         for j in range(z.shape[1]):
+            g0, h = sko._grid_j(grid, j)
+            Tm = sko.toeplitz(h, G)
             wj = 1.0 if wts is None else wts[j]
             u = np.clip((z[:, j] - g0) / h, 1.0, G - 2.0)
             fl = np.floor(u)
@@ -250,11 +268,11 @@ class OracleBackend:
     def ski_bilinear_scatter(self, Z, gp, L, R, grid_size=1024):
         z = _np(Z)
         Ld, Rd = _np(L).reshape(z.shape[0], -1), _np(R).reshape(z.shape[0], -1)
-        g0, h = self._grid(gp)
+        grid = self._grid(gp)
         hist = np.zeros((z.shape[1], grid_size, 2 * Ld.shape[1]))
         for j in range(z.shape[1]):
             if z.shape[0]:
-                W = sko.interp_sparse(z[:, j], g0, h, grid_size)
+                W = sko.interp_sparse(z[:, j], *sko._grid_j(grid, j), grid_size)
                 hist[j] = np.concatenate([W.T @ Ld, W.T @ Rd], axis=1)
         return torch.from_numpy(hist)
 
@@ -262,14 +280,15 @@ class OracleBackend:
         z = _np(Z)
         Ld, Rd = _np(L).reshape(z.shape[0], -1), _np(R).reshape(z.shape[0], -1)
         T = Ld.shape[1]
-        g0, h = self._grid(gp)
+        grid = self._grid(gp)
         G = grid_size
-        Tm = sko.toeplitz(h, G)
         wts = self._w(gp)
         gZ = np.zeros_like(z)
         gs, gc = 0.0, np.zeros(z.shape[1])
         hh = hist2.double().numpy()
         for j in range(z.shape[1]):
+            g0, h = sko._grid_j(grid, j)
+            Tm = sko.toeplitz(h, G)
             wj = 1.0 if wts is None else wts[j]
             HL, HR = Tm @ hh[j][:, :T], Tm @ hh[j][:, T:]
             if not z.shape[0]:

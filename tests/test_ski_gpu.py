@@ -393,3 +393,85 @@ def test_planned_ski_mvm_at_full_c5_size(gpu_device, T):
     assert not torch.isfinite(bad[:, 0]).all()
     if T > 1:
         assert torch.isfinite(bad[:, 1:]).all()
+
+
+# ---- the reference's per-projection grid rule (polynomial_projection_kernels.py:54-63) -------------------------------------
+@pytest.mark.parametrize("N,J,T,G,weighted", [(1200, 3, 11, 256, False), (900, 8, 4, 128, True), (40000, 3, 11, 1024, True),
+                                               (700, 20, 1, 64, False)])
+def test_reference_grid_rule_every_entry_point(gpu_device, N, J, T, G, weighted):
+    """rule="reference": every projection has its own bounds (min - 2.01 sp, max + 2.01 sp), sp = (max - min) / (G - 4).
+    Projections are given very different ranges on purpose (with the shared grid they would share one spacing).  Grid block,
+    MVM (plain and planned), diagonal, dense block, pivoted Cholesky and the derivative against the float64 oracle."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + J)
+    spread = np.linspace(0.3, 3.0, J)
+    Z = (rng.standard_normal((N, J)) * spread + np.linspace(-2, 2, J)).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    wts = (0.5 + rng.random(J)).astype(np.float32) if weighted else None
+    Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
+    gp = ops.ski_grid(Zt, None, G, weights=None if wts is None else torch.from_numpy(wts), rule="reference")
+    assert gp.numel() == 4 + 4 * J and int(gp[3]) == (3 if weighted else 2)
+    g0r, hr = sko.grid_params_reference(Z, None, G)
+    blk = gp.double().cpu().numpy()[4 + J:].reshape(J, 3)
+    np.testing.assert_allclose(blk[:, 0], g0r, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(blk[:, 1], hr, rtol=2e-6)
+    grid = (blk[:, 0].copy(), blk[:, 1].copy())          # the oracle runs on the kernel's own (float32) grid block
+    # every point keeps 2.01 (G - 1) / (G + 0.02) ~ 2 cells of margin (> 1 is what an interior 4-tap stencil needs)
+    u = (Z.astype(np.float64) - grid[0]) / grid[1]
+    assert u.min() >= 1.9 and u.max() <= G - 2.9
+    scale, noise = 0.6 / J, 0.15
+    ref = sko.mvm_sparse(Z, Z, V, scale, G, grid, noise, weights=wts)
+    out = ops.ski_mvm(Zt, Zt, gp, Vt, scale, noise, G)
+    assert _rel(out.cpu().numpy(), ref) < 2e-5
+    plan = ops.SkiPlan(Zt, gp, G)
+    outp = ops.ski_mvm(Zt, Zt, gp, Vt, scale, noise, G, plan=plan)
+    assert _rel(outp.cpu().numpy(), ref) < 2e-5
+    np.testing.assert_allclose(ops.ski_diag(Zt, gp, scale, G).cpu().numpy(), sko.diag_sparse(Z, scale, G, grid, weights=wts),
+                               rtol=3e-5, atol=1e-6)
+    if N <= 1500:
+        K = sko.dense_kernel(Z, Z, scale, G, grid, wts)
+        assert np.abs(ops.ski_dense(Zt, Zt, gp, scale, G).cpu().numpy() - K).max() < 3e-5 * np.abs(K).max()
+        Lc = ops.ski_pivoted_cholesky(Zt, gp, scale, 8, G).double().cpu().numpy()
+        Lref, _ = orc.pivoted_cholesky(K, 8)
+        # (the SKI diagonal is constant up to interpolation ripple, so fp32 and fp64 greedy pivots may differ: compare the
+        #  factorisations by what they are for — the residual they leave — and check L L^T <= K)
+        res, res_ref = np.trace(K - Lc @ Lc.T), np.trace(K - Lref @ Lref.T)
+        assert res < 1.1 * res_ref + 1e-3 * np.trace(K), (res, res_ref)
+        assert np.linalg.eigvalsh(K - Lc @ Lc.T).min() > -1e-4 * K.max()
+        Lm = (rng.standard_normal((N, T)) * 0.1).astype(np.float32)
+        Rm = (rng.standard_normal((N, T)) * 0.1).astype(np.float32)
+        gZ, gs = ops.ski_bilinear_grad(Zt, gp, torch.from_numpy(Lm).to(gpu_device), torch.from_numpy(Rm).to(gpu_device),
+                                       scale, G)
+        eps = 1e-4
+        for (i, j) in [(3, 0), (N // 2, J - 1)]:
+            Zp, Zm = Z.astype(np.float64).copy(), Z.astype(np.float64).copy()
+            Zp[i, j] += eps
+            Zm[i, j] -= eps
+            fd = (sko.bilinear_objective(Zp, Lm, Rm, scale, G, grid, wts) -
+                  sko.bilinear_objective(Zm, Lm, Rm, scale, G, grid, wts)) / (2 * eps)
+            assert abs(float(gZ[i, j]) - fd) < 2e-3 * abs(fd) + 1e-5
+        obj = sko.bilinear_objective(Z, Lm, Rm, scale, G, grid, wts)
+        assert abs(float(gs) - obj / scale) < 1e-3 * abs(obj / scale) + 1e-4
+
+
+def test_reference_grid_rule_is_the_default_of_the_rp_poly_ski_kinds(gpu_device):
+    """`rp_poly` / `strictly_additive` with `ski: true` build per-projection grids (flags & 2); the additive_rp SKI kernel keeps
+    the shared grid; both train a step and agree with their exact (non-SKI) operators to interpolation accuracy."""
+    from rpgp_amd import training
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(1500, 4, generator=g).to(gpu_device)
+    y = torch.sin(X).sum(1)
+    for kind, mk, flag in (("rp_poly", dict(k=1, J=6, weighted=True), 2), ("strictly_additive", dict(weighted=False), 2),
+                           ("additive_rp", dict(J=6, prescale=True, learn_proj=False), 0)):
+        torch.manual_seed(3)
+        model, lik = training.create_exact_gp(X, y, kind, noise_prior=True, kernel_type="RBF", ski=True,
+                                              ski_options={"grid_size": 512, "num_dims": 1}, **mk)
+        model = model.to(gpu_device)
+        op = model.covar_module(X)
+        assert int(op.gp[3]) & 2 == flag, kind
+        torch.manual_seed(3)
+        exact, _ = training.create_exact_gp(X, y, kind, noise_prior=True, kernel_type="RBF", ski=False, **mk)
+        exact = exact.to(gpu_device)
+        v = torch.randn(1500, 3, generator=g).to(gpu_device)
+        a, b = op._matmul(v), exact.covar_module(X)._matmul(v)
+        assert float((a - b).norm() / b.norm()) < 2e-4, kind

@@ -650,9 +650,11 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
           float tsum[TT];
 #pragma unroll
           for (int t = 0; t < TT; ++t) tsum[t] = accT[t];
+          // (24-bit multiply: v_mul_lo_u32 is a quarter-rate instruction, one per step in this loop)
+          const float *colrec = sB + __mul24(idx, STR);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const float ks = fact_pair_sum<JT>(ap[r], ea[r], sB + idx * STR);
+            const float ks = fact_pair_sum<JT>(ap[r], ea[r], colrec);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
               accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);
@@ -707,6 +709,129 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
           *dst = accumulate ? *dst + accR[r][t] : accR[r][t];
         }
       }
+    }
+  }
+}
+
+// The T = 1, two-rows-per-lane form with the packed lanes running over the lane's TWO ROWS instead of over a pair of
+// projections: t = pk_fma({a_r0, a_r1}, splat(2b), splat(-b^2)), e = exp2 both, acc = pk_fma(e, {Ea_r0, Ea_r1}, acc) — after
+// the JT projections acc.x / acc.y ARE the two rows' kernel values.  The pair form above ends every step with a horizontal
+// add per row, which hipcc packs into one v_pk_add_f32 behind three v_mov_b32 (ISA of round 2: 6 v_mov + 2 v_pk_add per two
+// steps = 11 of the ~60 issue cycles per step that are not exp / fma).  Same instruction count in the projection loop.
+// d = a * splat(b.lo) + splat(c.lo)  /  a * splat(b.hi) + splat(c.hi): the splats are op_sel modifiers of v_pk_fma_f32 (the
+// builtin form materialises them with a v_mov_b32 per operand)
+__device__ __forceinline__ float2v pk_fma_bcast_lo(float2v a, float2v b, float2v c) {
+  float2v d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float2v pk_fma_bcast_hi(float2v a, float2v b, float2v c) {
+  float2v d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+template <int JT>
+__global__ __launch_bounds__(256) void mvm_fact_rows_kernel(const float2v *__restrict__ rowdat,
+                                                            const float2v *__restrict__ coldat,
+                                                            const float *__restrict__ V, float *__restrict__ slabR,
+                                                            float *__restrict__ slabT, int N, int J, int ldv, int j0, int t0,
+                                                            int chunk_cols, int rotdir, int accumulate, int w0, int rb_first,
+                                                            int slab_row0, int slab_rows) {
+  static_assert(JT % 2 == 0, "even JT");
+  constexpr int R = 2, BR = 512, SC = StageCols<1>::v, NP = JT / 2, STR = FactStride<JT>::v;
+  __shared__ __attribute__((aligned(16))) float sB[SC * STR];
+  __shared__ __attribute__((aligned(16))) float sV[SC];
+  __shared__ __attribute__((aligned(16))) float sT[4 * SC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
+  const int r0 = rb * BR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+  float2v ap[JT], ea[JT];                 // {row 0, row 1} of this lane per projection
+  float vrow[R];
+  {
+    const int row0 = r0 + wave * 128 + lane, row1 = row0 + 64;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      float2v x0 = {0.f, 0.f}, x1 = {0.f, 0.f};
+      if (row0 < N) x0 = rowdat[(size_t)row0 * J + j0 + j];
+      if (row1 < N) x1 = rowdat[(size_t)row1 * J + j0 + j];
+      ap[j] = float2v{x0.x, x1.x};
+      ea[j] = float2v{x0.y, x1.y};        // invalid rows: Ea = 0 -> K = 0
+    }
+    vrow[0] = row0 < N ? V[(size_t)row0 * ldv + t0] : 0.f;
+    vrow[1] = row1 < N ? V[(size_t)row1 * ldv + t0] : 0.f;
+  }
+  float accR0 = 0.f, accR1 = 0.f;
+  for (int c0 = c_begin; c0 < c_end; c0 += SC) {
+    __syncthreads();
+    if (tid < SC) {
+      const int col = c0 + tid;
+      const bool cv = col < c_end;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        float2v x0 = {0.f, -1.0e30f}, x1 = {0.f, -1.0e30f};   // padded columns: exp2(-1e30) = 0
+        if (cv) {
+          x0 = coldat[(size_t)col * J + j0 + 2 * p];
+          x1 = coldat[(size_t)col * J + j0 + 2 * p + 1];
+        }
+        *reinterpret_cast<float4v *>(&sB[tid * STR + 4 * p]) = float4v{x0.x, x1.x, x0.y, x1.y};
+      }
+      sV[tid] = cv ? V[(size_t)col * ldv + t0] : 0.f;
+    }
+    __syncthreads();
+    const int ncol = c_end - c0;
+    const int nsub = ncol >= SC ? SC / 64 : (ncol + 63) / 64;
+    for (int sub = 0; sub < nsub; ++sub) {
+      const bool doT = (c0 + sub * 64 >= r0 + BR);
+      float accT = 0.f;
+#pragma unroll 2
+      for (int s = 0; s < 64; ++s) {
+        const int idx = sub * 64 + ((lane + rotdir * s) & 63);
+        const float v = sV[idx];
+        const float *q = sB + __mul24(idx, STR);
+        float2v acc = {0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const float4v c = *reinterpret_cast<const float4v *>(q + 4 * p);
+          const float2v cb2 = {c.x, c.y}, cnb = {c.z, c.w};       // {2b_even, 2b_odd}, {-b^2_even, -b^2_odd}
+          const float2v ta = pk_fma_bcast_lo(ap[2 * p], cb2, cnb);
+          const float2v tb = pk_fma_bcast_hi(ap[2 * p + 1], cb2, cnb);
+          const float2v ea_ = {fast_exp2(ta.x), fast_exp2(ta.y)};
+          const float2v eb_ = {fast_exp2(tb.x), fast_exp2(tb.y)};
+          acc = __builtin_elementwise_fma(ea_, ea[2 * p], acc);
+          acc = __builtin_elementwise_fma(eb_, ea[2 * p + 1], acc);
+        }
+        accR0 = __builtin_fmaf(acc.x, v, accR0);
+        accR1 = __builtin_fmaf(acc.y, v, accR1);
+        float ts = __builtin_fmaf(acc.x, vrow[0], accT);       // (subtiles inside the row block: the sums are discarded)
+        ts = __builtin_fmaf(acc.y, vrow[1], ts);
+        accT = wave_rotate1(ts);
+      }
+      (void)doT;
+      sT[wave * SC + sub * 64 + lane] = accT;
+    }
+    __syncthreads();
+    {
+      const int col = c0 + tid;
+      if (tid < SC && col < c_end && col >= r0 + BR) {
+        const float sum = sT[0 * SC + tid] + sT[1 * SC + tid] + sT[2 * SC + tid] + sT[3 * SC + tid];
+        float *dst = slabT + ((size_t)(rb - rb_first) * N + col) * ldv + t0;
+        *dst = accumulate ? *dst + sum : sum;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = r0 + wave * 128 + r * 64 + lane;
+    if (row < N) {
+      float *dst = slabR + ((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0;
+      const float a = r == 0 ? accR0 : accR1;
+      *dst = accumulate ? *dst + a : a;
     }
   }
 }
@@ -3349,6 +3474,16 @@ template <int JT, int TT>
 int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *coldat, const float *V, float *slabR,
                     float *slabT, int N, int J, int ldv, int j0, int t0, int tcnt, int accumulate, hipStream_t st) {
   dim3 grid(p.w1 - p.w0), block(256);
+  if constexpr (TT == 1 && (JT == 20 || JT == 10)) {
+    // opt-in experiment (RPGP_FACT_ROWS=1), measured SLOWER than the pair form: 2.48 vs 2.31 ms at C4 — the op_sel splats
+    // need inline asm, and hipcc then pads every exp -> fma dependence with s_nop (32 per two steps) instead of interleaving
+    const char *env_rows = getenv("RPGP_FACT_ROWS");
+    if (p.R == 2 && tcnt == 1 && env_rows && atoi(env_rows) != 0) {
+      hipLaunchKernelGGL((mvm_fact_rows_kernel<JT>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0,
+                         p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);
+      return launch_status();
+    }
+  }
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 2>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
                        j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);

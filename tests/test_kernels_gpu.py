@@ -492,3 +492,21 @@ def test_matrix_core_prepared_mvm_matches_oracle(gpu_device, monkeypatch, N, J):
     assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 1e-5
     assert np.linalg.norm(out - base) / np.linalg.norm(base) < 2e-6
     assert not np.array_equal(out, base), "RPGP_MFMA=1 did not select the matrix-core kernel"
+
+
+@pytest.mark.parametrize("N,J", [(5000, 20), (12000, 10)])
+def test_rows_packed_prepared_mvm_matches_oracle(gpu_device, monkeypatch, N, J):
+    """The opt-in rows-packed form of the prepared T = 1 kernel (RPGP_FACT_ROWS=1, round-3 experiment on the headline
+    kernel's per-step overhead: parity-green, measured slower) against the float64 oracle."""
+    from rpgp_amd import ops
+    monkeypatch.setenv("RPGP_FACT_ROWS", "1")
+    Z, V = _data(N, J, 1, seed=N)
+    ref = orc.mvm(Z, Z, V, 1.0 / J, 0.05)
+    Zt = torch.from_numpy(Z).to(gpu_device)
+    prep = ops.Prepared(Zt)
+    assert prep.fast_ok
+    out = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), 1.0 / J, 0.05)
+    assert _rel(out.cpu().numpy(), ref) < 1e-5
+    monkeypatch.setenv("RPGP_FACT_ROWS", "0")
+    out0 = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), 1.0 / J, 0.05)
+    assert _rel(out.cpu().numpy(), out0.cpu().numpy()) < 2e-6

@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/rpgp.h"
 
@@ -94,50 +95,75 @@ struct Lane {
   __device__ __forceinline__ Lane() : c(threadIdx.x & 15), q((threadIdx.x & 63) >> 4), wave(threadIdx.x >> 6) {}
 };
 
-template <int TT>
-__device__ __forceinline__ void load_block(const float *__restrict__ a, long long R0, long long N, const Lane &ln,
+// 32-bit element offsets (N * 16 < 2^31, checked by the host): the address of every load is base + 32-bit offset + constant;
+// with 64-bit row arithmetic the passes spent more issue slots on addresses than on data (PMC, round 3: 1700 VALU + 700
+// SALU instructions per wave for ~290 memory instructions; SQ_WAIT_INST_ANY 46 % of the wave cycles).  FULL = the whole
+// 256-row tile is inside the vector: no row tests, and lanes whose column / rank index is out of range read a clamped,
+// valid element instead of being masked — what they compute lands in slots nobody reads (column sums and L^T X entries
+// >= T or >= K; the matching Cinv / tv entries are zero) and their stores are suppressed.
+template <int TT, bool FULL>
+__device__ __forceinline__ void load_block(const float *__restrict__ a, unsigned R0, unsigned N, const Lane &ln,
                                            float (&v)[4]) {
+  const unsigned cc = ln.c < TT ? ln.c : TT - 1;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const long long row = R0 + ln.q + 4 * r;
-    const bool ok = row < N && ln.c < TT;
-    const float x = a[ok ? row * TT + ln.c : 0];          // unconditional load of a clamped address
-    v[r] = ok ? x : 0.f;
+    const unsigned row = R0 + ln.q + 4 * r;
+    if constexpr (FULL) {
+      v[r] = a[row * TT + cc];
+    } else {
+      const bool ok = row < N && ln.c < TT;
+      const float x = a[ok ? row * TT + cc : 0];          // unconditional load of a clamped address
+      v[r] = ok ? x : 0.f;
+    }
   }
 }
 
-template <int TT>
-__device__ __forceinline__ void store_block(float *__restrict__ a, long long R0, long long N, const Lane &ln,
+template <int TT, bool FULL>
+__device__ __forceinline__ void store_block(float *__restrict__ a, unsigned R0, unsigned N, const Lane &ln,
                                             const float (&v)[4]) {
+  if (ln.c < TT) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long row = R0 + ln.q + 4 * r;
-    if (row < N && ln.c < TT) a[row * TT + ln.c] = v[r];
+    for (int r = 0; r < 4; ++r) {
+      const unsigned row = R0 + ln.q + 4 * r;
+      if (FULL || row < N) a[row * TT + ln.c] = v[r];
+    }
   }
 }
 
 // A operand of L^T X: lane (c = kk, q) holds L[R0 + q + 4 r][kk]
-__device__ __forceinline__ void load_L_rows(const float *__restrict__ L, long long R0, long long N, int K, const Lane &ln,
+template <bool FULL>
+__device__ __forceinline__ void load_L_rows(const float *__restrict__ L, unsigned R0, unsigned N, int K, const Lane &ln,
                                             float (&v)[4]) {
+  const unsigned cc = ln.c < K ? ln.c : K - 1;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const long long row = R0 + ln.q + 4 * r;
-    const bool ok = row < N && ln.c < K;
-    const float x = L[ok ? row * K + ln.c : 0];
-    v[r] = ok ? x : 0.f;
+    const unsigned row = R0 + ln.q + 4 * r;
+    if constexpr (FULL) {
+      v[r] = L[row * (unsigned)K + cc];
+    } else {
+      const bool ok = row < N && ln.c < K;
+      const float x = L[ok ? row * (unsigned)K + cc : 0];
+      v[r] = ok ? x : 0.f;
+    }
   }
 }
 
 // A operand of L (Cinv w) in float64: lane (c = row in block, q) holds L[R0 + c][4 s + q]
-__device__ __forceinline__ void load_L_cols(const float *__restrict__ L, long long R0, long long N, int K, const Lane &ln,
+template <bool FULL>
+__device__ __forceinline__ void load_L_cols(const float *__restrict__ L, unsigned R0, unsigned N, int K, const Lane &ln,
                                             float (&v)[4]) {
-  const long long row = R0 + ln.c;
+  const unsigned row = R0 + ln.c;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int b = 4 * s + ln.q;
-    const bool ok = row < N && b < K;
-    const float x = L[ok ? row * K + b : 0];
-    v[s] = ok ? x : 0.f;
+    const unsigned bc = b < K ? b : K - 1;
+    if constexpr (FULL) {
+      v[s] = L[row * (unsigned)K + bc];
+    } else {
+      const bool ok = row < N && b < K;
+      const float x = L[ok ? row * (unsigned)K + bc : 0];
+      v[s] = ok ? x : 0.f;
+    }
   }
 }
 
@@ -172,27 +198,40 @@ __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, con
   __shared__ float sh[1024];
   const Lane ln;
   float dot = 0.f;
-  floatx4m lt = {0.f, 0.f, 0.f, 0.f};
-  const long long ntiles = (N + 255) / 256;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long w0 = tile * 256 + 64 * ln.wave;
+  // four independent accumulators (one per 16-row block): a single one is a chain of 16 DEPENDENT matrix instructions per
+  // tile, and with 3 - 4 waves per SIMD nothing hides their latency (PMC: SQ_WAIT_INST_ANY = 40 % of the wave cycles)
+  floatx4m lt4[4];
+#pragma unroll
+  for (int bk = 0; bk < 4; ++bk) lt4[bk] = floatx4m{0.f, 0.f, 0.f, 0.f};
+  const unsigned Nu = (unsigned)N;
+  auto do_tile = [&](unsigned tile, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const unsigned w0 = tile * 256u + 64u * ln.wave;
     float av[4][4], bv[4][4], lv[4][4];
 #pragma unroll
     for (int bk = 0; bk < 4; ++bk) {
-      load_block<TT>(a, w0 + 16 * bk, N, ln, av[bk]);
-      load_block<TT>(b, w0 + 16 * bk, N, ln, bv[bk]);
-      if (K > 0) load_L_rows(L, w0 + 16 * bk, N, K, ln, lv[bk]);
+      load_block<TT, FULL>(a, w0 + 16 * bk, Nu, ln, av[bk]);
+      load_block<TT, FULL>(b, w0 + 16 * bk, Nu, ln, bv[bk]);
+      if (K > 0) load_L_rows<FULL>(L, w0 + 16 * bk, Nu, K, ln, lv[bk]);
     }
 #pragma unroll
-    for (int bk = 0; bk < 4; ++bk) {
+    for (int bk = 0; bk < 4; ++bk)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dot = __builtin_fmaf(av[bk][r], bv[bk][r], dot);
-      if (K > 0) {
+    if (K > 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lt = __builtin_amdgcn_mfma_f32_16x16x4f32(lv[bk][r], bv[bk][r], lt, 0, 0, 0);
-      }
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int bk = 0; bk < 4; ++bk)
+          lt4[bk] = __builtin_amdgcn_mfma_f32_16x16x4f32(lv[bk][r], bv[bk][r], lt4[bk], 0, 0, 0);
     }
+  };
+  const unsigned ntiles = (Nu + 255u) / 256u;
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if ((tile + 1u) * 256u <= Nu) do_tile(tile, std::true_type{});
+    else do_tile(tile, std::false_type{});
   }
+  const floatx4m lt = (lt4[0] + lt4[1]) + (lt4[2] + lt4[3]);
   float *dst = part + (size_t)blockIdx.x * kRedW;
   block_colsum(dot, sh, dst, ln);
   if (threadIdx.x < 16) dst[16 + threadIdx.x] = 0.f;
@@ -263,26 +302,32 @@ __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, con
   const float nrm = snrm[ln.c];
   floatx4m lt = {0.f, 0.f, 0.f, 0.f};
   const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
-  const long long ntiles = (N + 255) / 256;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long w0 = tile * 256 + 64 * ln.wave;
+  const unsigned Nu = (unsigned)N;
+  auto do_tile = [&](unsigned tile, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const unsigned w0 = tile * 256u + 64u * ln.wave;
 #pragma unroll
     for (int bk = 0; bk < 4; ++bk) {
-      const long long R0 = w0 + 16 * bk;
+      const unsigned R0 = w0 + 16 * bk;
       float rv[4], lv[4];
-      load_block<TT>(rhs, R0, N, ln, rv);
-      if (K > 0) load_L_rows(L, R0, N, K, ln, lv);
+      load_block<TT, FULL>(rhs, R0, Nu, ln, rv);
+      if (K > 0) load_L_rows<FULL>(L, R0, Nu, K, ln, lv);
 #pragma unroll
       for (int q = 0; q < 4; ++q) rv[q] = rv[q] / nrm;
-      store_block<TT>(r, R0, N, ln, rv);
-      store_block<TT>(x, R0, N, ln, zero4);
-      store_block<TT>(p, R0, N, ln, zero4);
-      store_block<TT>(Ap, R0, N, ln, zero4);
+      store_block<TT, FULL>(r, R0, Nu, ln, rv);
+      store_block<TT, FULL>(x, R0, Nu, ln, zero4);
+      store_block<TT, FULL>(p, R0, Nu, ln, zero4);
+      store_block<TT, FULL>(Ap, R0, Nu, ln, zero4);
       if (K > 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) lt = __builtin_amdgcn_mfma_f32_16x16x4f32(lv[q], rv[q], lt, 0, 0, 0);
       }
     }
+  };
+  const unsigned ntiles = (Nu + 255u) / 256u;
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if ((tile + 1u) * 256u <= Nu) do_tile(tile, std::true_type{});
+    else do_tile(tile, std::false_type{});
   }
   float *dst = part + (size_t)blockIdx.x * kRedW;
   __syncthreads();
@@ -294,7 +339,7 @@ __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, con
 // alpha = rz / pAp (guarded; 0 after convergence, so iterations the host had already enqueued leave x and r untouched);
 // x += alpha p; r -= alpha Ap; z = M^-1 r (Woodbury, float64 correction); partial |r|^2, r.z, L^T r.
 // first != 0: the set-up call (alpha = 0, w = L^T r0 as reduced by k_init).
-template <int TT>
+template <int TT, int NB = 1>
 __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, const float *__restrict__ Ap,
                                                 float *__restrict__ x, float *__restrict__ r, float *__restrict__ z,
                                                 const float *__restrict__ L, const double *__restrict__ Cinv,
@@ -342,63 +387,81 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
   const float a = salpha[ln.c];
   const double inv_s = K > 0 ? 1.0 / (double)sigma2 : 1.0;
   float acc_rr = 0.f, acc_rz = 0.f;
-  floatx4m lt = {0.f, 0.f, 0.f, 0.f};
-  const long long ntiles = (N + 255) / 256;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long w0 = tile * 256 + 64 * ln.wave;
+  floatx4m lt2[2] = {floatx4m{0.f, 0.f, 0.f, 0.f}, floatx4m{0.f, 0.f, 0.f, 0.f}};
+  const unsigned Nu = (unsigned)N;
+  auto do_tile = [&](unsigned tile, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const unsigned w0 = tile * 256u + 64u * ln.wave;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float pv[2][4], av[2][4], xv[2][4], rv[2][4], lr[2][4], lc[2][4];
+    for (int half = 0; half < 4 / NB; ++half) {
+      float pv[NB][4], av[NB][4], xv[NB][4], rv[NB][4], lr[NB][4], lc[NB][4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const long long R0 = w0 + 16 * (2 * half + h);
-        load_block<TT>(p, R0, N, ln, pv[h]);
-        load_block<TT>(Ap, R0, N, ln, av[h]);
-        load_block<TT>(x, R0, N, ln, xv[h]);
-        load_block<TT>(r, R0, N, ln, rv[h]);
+      for (int h = 0; h < NB; ++h) {
+        const unsigned R0 = w0 + 16 * (NB * half + h);
+        load_block<TT, FULL>(p, R0, Nu, ln, pv[h]);
+        load_block<TT, FULL>(Ap, R0, Nu, ln, av[h]);
+        load_block<TT, FULL>(x, R0, Nu, ln, xv[h]);
+        load_block<TT, FULL>(r, R0, Nu, ln, rv[h]);
         if (K > 0) {
-          load_L_rows(L, R0, N, K, ln, lr[h]);
-          load_L_cols(L, R0, N, K, ln, lc[h]);
+          load_L_rows<FULL>(L, R0, Nu, K, ln, lr[h]);
+          load_L_cols<FULL>(L, R0, Nu, K, ln, lc[h]);
         }
       }
+      float rn[NB][4], xn[NB][4], zn[NB][4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const long long R0 = w0 + 16 * (2 * half + h);
-        float rn[4], xn[4], zn[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          xn[q] = __builtin_fmaf(a, pv[h][q], xv[h][q]);
-          rn[q] = __builtin_fmaf(-a, av[h][q], rv[h][q]);
-        }
-        if (K > 0) {
-          doublex4m corr = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int s = 0; s < 4; ++s) corr = __builtin_amdgcn_mfma_f64_16x16x4f64((double)lc[h][s], tvB[s], corr, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) zn[q] = (float)(((double)rn[q] - corr[q]) * inv_s);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) lt = __builtin_amdgcn_mfma_f32_16x16x4f32(lr[h][q], rn[q], lt, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) zn[q] = rn[q];
-        }
+      for (int h = 0; h < NB; ++h)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          acc_rr = __builtin_fmaf(rn[q], rn[q], acc_rr);
-          acc_rz = __builtin_fmaf(rn[q], zn[q], acc_rz);
+          xn[h][q] = __builtin_fmaf(a, pv[h][q], xv[h][q]);
+          rn[h][q] = __builtin_fmaf(-a, av[h][q], rv[h][q]);
+        }
+      if (K > 0) {
+        // the two blocks' float64 chains (4 dependent matrix instructions each) and their fp32 L^T r products interleaved
+        doublex4m corr[NB];
+#pragma unroll
+        for (int h = 0; h < NB; ++h) corr[h] = doublex4m{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int h = 0; h < NB; ++h) {
+            corr[h] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)lc[h][s], tvB[s], corr[h], 0, 0, 0);
+            lt2[h & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lr[h][s], rn[h][s], lt2[h & 1], 0, 0, 0);
+          }
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) zn[h][q] = (float)(((double)rn[h][q] - corr[h][q]) * inv_s);
+      } else {
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) zn[h][q] = rn[h][q];
+      }
+#pragma unroll
+      for (int h = 0; h < NB; ++h) {
+        const unsigned R0 = w0 + 16 * (NB * half + h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc_rr = __builtin_fmaf(rn[h][q], rn[h][q], acc_rr);
+          acc_rz = __builtin_fmaf(rn[h][q], zn[h][q], acc_rz);
         }
         if (!first) {
-          store_block<TT>(x, R0, N, ln, xn);
-          store_block<TT>(r, R0, N, ln, rn);
+          store_block<TT, FULL>(x, R0, Nu, ln, xn[h]);
+          store_block<TT, FULL>(r, R0, Nu, ln, rn[h]);
         }
-        if (K > 0 || first) store_block<TT>(z, R0, N, ln, zn);     // identity preconditioner: pass C reads r as z
+        if (K > 0 || first) store_block<TT, FULL>(z, R0, Nu, ln, zn[h]);     // identity preconditioner: pass C reads r as z
       }
     }
+  };
+  const unsigned ntiles = (Nu + 255u) / 256u;
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if ((tile + 1u) * 256u <= Nu) do_tile(tile, std::true_type{});
+    else do_tile(tile, std::false_type{});
   }
   float *dst = part + (size_t)blockIdx.x * kRedW;
   block_colsum(acc_rr, sh, dst, ln);
   block_colsum(acc_rz, sh, dst + 16, ln);
-  block_ltsum(lt, sh, dst + kRedLt, ln);
+  block_ltsum(lt2[0] + lt2[1], sh, dst + kRedLt, ln);
 }
 
 // ---- pass C -----------------------------------------------------------------------------------------------------------
@@ -439,29 +502,35 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
   const float snap_prev = st->snap_resid[cur];
   const bool improved = !first && check_now && mres == mres && mres < snap_prev;
   const float beta = sbeta[ln.c];
-  const long long ntiles = (N + 255) / 256;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long w0 = tile * 256 + 64 * ln.wave;
+  const unsigned Nu = (unsigned)N;
+  auto do_tile = [&](unsigned tile, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const unsigned w0 = tile * 256u + 64u * ln.wave;
     float pv[4][4], zv[4][4];
 #pragma unroll
     for (int bk = 0; bk < 4; ++bk) {
-      load_block<TT>(p, w0 + 16 * bk, N, ln, pv[bk]);
-      load_block<TT>(z, w0 + 16 * bk, N, ln, zv[bk]);
+      load_block<TT, FULL>(p, w0 + 16 * bk, Nu, ln, pv[bk]);
+      load_block<TT, FULL>(z, w0 + 16 * bk, Nu, ln, zv[bk]);
     }
 #pragma unroll
     for (int bk = 0; bk < 4; ++bk) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) pv[bk][q] = __builtin_fmaf(beta, pv[bk][q], zv[bk][q]);
-      store_block<TT>(p, w0 + 16 * bk, N, ln, pv[bk]);
+      store_block<TT, FULL>(p, w0 + 16 * bk, Nu, ln, pv[bk]);
     }
     if (improved) {
 #pragma unroll
       for (int bk = 0; bk < 4; ++bk) {
         float xv[4];
-        load_block<TT>(x, w0 + 16 * bk, N, ln, xv);
-        store_block<TT>(x_best, w0 + 16 * bk, N, ln, xv);
+        load_block<TT, FULL>(x, w0 + 16 * bk, Nu, ln, xv);
+        store_block<TT, FULL>(x_best, w0 + 16 * bk, Nu, ln, xv);
       }
     }
+  };
+  const unsigned ntiles = (Nu + 255u) / 256u;
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if ((tile + 1u) * 256u <= Nu) do_tile(tile, std::true_type{});
+    else do_tile(tile, std::false_type{});
   }
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0 && !first) {
@@ -724,6 +793,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     if (sh.mode == RPGP_SHARD_ROWS) global_N = reducer->global_N;
   }
   if (op->N <= 0 && sh.mode != RPGP_SHARD_ROWS) return RPGP_EINVAL;
+  if (op->N >= (1LL << 27)) return RPGP_EINVAL;              // 32-bit element offsets in the streaming passes (N * 16 < 2^31)
   if (!workspace || workspace_bytes < rpgp_mbcg_workspace_bytes(op, T, precond_rank)) return RPGP_EWORKSPACE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long long N = op->N;

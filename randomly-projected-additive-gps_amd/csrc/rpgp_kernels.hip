@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <stddef.h>
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/rpgp.h"
 #include "rpgp_internal.h"
@@ -1607,7 +1608,7 @@ __global__ __launch_bounds__(256, 2) void bilinear_sym_kernel(const float *__res
     for (int q = 0; q < W; ++q) accT[q] = 0.f;
 #pragma unroll 1
     for (int s = 0; s < 64; ++s) {
-      const float *p = sC + ((lane + rotdir * s) & 63) * STR;
+      const float *p = sC + __mul24((lane + rotdir * s) & 63, STR);       // (24-bit multiply: v_mul_lo_u32 is quarter rate)
       float pz[JT], pl[TT], pr[TT];
 #pragma unroll
       for (int j = 0; j < JT; ++j) pz[j] = p[j];
@@ -1630,9 +1631,9 @@ __global__ __launch_bounds__(256, 2) void bilinear_sym_kernel(const float *__res
           const float dd = a[r][j] - pz[j];
           const float e = fast_exp2(-(dd * dd));
           ks += e;
-          const float g = (S * e) * dd;
-          accG[r][j] += g;
-          tg[j] -= g;
+          const float se = S * e;                       // g = (S e) d feeds both sides as an FMA (was mul + add + sub)
+          accG[r][j] = __builtin_fmaf(se, dd, accG[r][j]);
+          tg[j] = __builtin_fmaf(-se, dd, tg[j]);
         }
         const float sk = S * ks;
         accS[r] += sk;

@@ -253,6 +253,26 @@ def _row_sharded_ski_worker(rank, world, port, tmpdir):
             it_all = [torch.zeros(1) for _ in range(world)]
             dist.all_gather(it_all, its)
             assert all(float(a) == float(its) for a in it_all), "ranks stopped at different iterations"
+        # more ranks than rows: N = world - 1 rows, the last rank owns none — its scatter contributes zeros,
+        # its gather returns an empty block, and every rank still takes part in every collective (no hang, same result)
+        Ns = world - 1 if world > 2 else 2
+        Zs = torch.randn(Ns, J, generator=g, dtype=torch.float64)
+        Vs = torch.randn(Ns, 2, generator=g, dtype=torch.float64)
+        fs = SKIAdditiveOperator(Zs, None, s, 1.0 / J, grid_size=G)
+        refs = AddedDiagOperator(fs, torch.tensor(noise, dtype=torch.float64))._matmul(Vs)
+        shs = RowShard(Ns)
+        ops_ = RowShardedSKIOperator(Zs[shs.r0:shs.r1], s, 1.0 / J, shs, grid_size=G, noise=noise)
+        outs = ops_._matmul(Vs[shs.r0:shs.r1])
+        assert outs.shape == (shs.local_rows, 2)
+        assert torch.allclose(outs, refs[shs.r0:shs.r1], rtol=1e-9, atol=1e-10)
+        assert ops_._matmul(Vs[shs.r0:shs.r1, 0]).shape == (shs.local_rows,)
+        xs = lcg.linear_cg(ops_._matmul, Vs[shs.r0:shs.r1].clone(), tolerance=1e-12, max_iter=50, reduce=shs.all_reduce_,
+                           global_size=Ns)
+        xg = torch.zeros(Ns, 2, dtype=torch.float64)
+        xg[shs.r0:shs.r1] = xs
+        dist.all_reduce(xg)
+        Khs = fs.to_dense() + noise * torch.eye(Ns, dtype=torch.float64)
+        assert torch.allclose(Khs @ xg, Vs, atol=1e-8)
         open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(script, world, timeout=600, extra_env=None):
+def _launch(script, world, timeout=600, extra_env=None, args=()):
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -18,14 +18,20 @@ def _launch(script, world, timeout=600, extra_env=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", script)]
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", script)] + list(args)
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def _why(r):
+    """The ranks' own tracebacks (the launcher's boilerplate buries them)."""
+    lines = [l for l in r.stderr.splitlines() if l.startswith("[rank")]
+    return "\n".join(lines[-30:]) if lines else (r.stdout[-1500:] + r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_ipc_allreduce_multi_process_one_device(gpu_device, world):
     r = _launch("ipc_child.py", world)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert r.returncode == 0, _why(r)
     assert "IPC_CHILD_OK world=%d" % world in r.stdout
 
 
@@ -34,5 +40,18 @@ def test_sharded_native_executor_multi_process_one_device(gpu_device, world):
     """The native mBCG executor in both sharded modes (partial products of the pair- / J-sharded exact operator and of
     the pair-sharded packed cache; row-sharded SKI) with 2 and 3 ranks on device 0, against the unsharded native solve."""
     r = _launch("ipc_solve_child.py", world, timeout=900)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert r.returncode == 0, _why(r)
     assert "IPC_SOLVE_CHILD_OK world=%d" % world in r.stdout
+
+
+def test_sharded_training_end_to_end_multi_process_one_device(gpu_device, tmp_path):
+    """`train_exact_gp` under a process group on the GPU: the SKI spec row-sharded and additive_rp_prescale_J20 pair-sharded,
+    2 and 3 ranks on device 0 (all-reduces through rpgp_comm, solves in the sharded native executor), against the
+    single-process fit: per-epoch losses, final parameters, predictions; identical models on every rank."""
+    ref = str(tmp_path / "ref.pt")
+    r = _launch("ipc_train_child.py", 1, timeout=900, args=[ref])
+    assert r.returncode == 0 and os.path.exists(ref), _why(r)
+    for world in (2, 3):
+        r = _launch("ipc_train_child.py", world, timeout=900, args=[ref])
+        assert r.returncode == 0, (world, _why(r))
+        assert "IPC_TRAIN_CHILD_OK world=%d" % world in r.stdout

@@ -84,6 +84,8 @@ struct CgState {
   float resid[kMaxT];       // residual norms of the current iterate
   int rhs_zero[kMaxT];
   float snap_resid[2];      // mean residual of the iterate saved in x_best (ping-pong by iteration parity)
+  int done_pp[2];           // poll.done as pass C reads it at its head (ping-pong: workgroup 0 sets poll.done at its tail while
+                            // late workgroups of the same launch may only just be starting)
   CgPoll poll;
 };
 
@@ -297,6 +299,8 @@ __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, con
     st->poll.snap_cur = 3.0e38f;
     st->snap_resid[0] = 3.0e38f;
     st->snap_resid[1] = 3.0e38f;
+    st->done_pp[0] = 0;
+    st->done_pp[1] = 0;
   }
   __syncthreads();
   const float nrm = snrm[ln.c];
@@ -476,12 +480,21 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
                                                 const double *__restrict__ redB, CgState *__restrict__ st,
                                                 float *__restrict__ beta_out, long long N, float eps, int cur, int first,
                                                 int check_now, float tolerance, int iter_count, int stagnation_window,
-                                                const float *__restrict__ x, float *__restrict__ x_best) {
+                                                const float *__restrict__ x, float *__restrict__ x_best,
+                                                CgPoll *__restrict__ poll_host) {
   __shared__ float sbeta[kMaxT];
   __shared__ float sres[kMaxT];
   __shared__ float srzn[kMaxT];
   const Lane ln;
-  const int was_done = st->poll.done;
+  const int was_done = first ? 0 : st->done_pp[cur];
+  // the poll record of a tested iteration goes straight to pinned host memory (a D2H copy per poll is a 4 us copy kernel)
+  if (was_done && blockIdx.x == 0 && threadIdx.x == 0) {
+    st->done_pp[cur ^ 1] = was_done;
+    if (check_now && poll_host) {
+      *poll_host = st->poll;
+      __threadfence_system();
+    }
+  }
   if (threadIdx.x < kMaxT) {
     float beta = 0.f, res = 0.f, rzn = 0.f;
     if (threadIdx.x < TT) {
@@ -567,7 +580,12 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
             st->poll.iters = iter_count;
           }
         }
+        if (poll_host) {
+          *poll_host = st->poll;
+          __threadfence_system();
+        }
       }
+      st->done_pp[cur ^ 1] = st->poll.done;
     }
   }
 }
@@ -621,11 +639,15 @@ Grids grids_for(long long N) {
 constexpr int kPollRing = 4;
 struct PollCtx {
   CgPoll *host = nullptr;
+  CgPoll *host_dev = nullptr;       // the same memory as the device sees it (pass C writes its poll record there)
   hipEvent_t ev[kPollRing];
   bool ok = false;
   int init() {
     if (ok) return 0;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), (kPollRing + 1) * sizeof(CgPoll), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), (kPollRing + 1) * sizeof(CgPoll),
+                                 hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) return (int)e;
+    e = hipHostGetDevicePointer(reinterpret_cast<void **>(&host_dev), host, 0);
     if (e != hipSuccess) return (int)e;
     for (int i = 0; i < kPollRing; ++i) {
       e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
@@ -852,16 +874,17 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
                                       state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1));
   CG_REDUCE(redB, nbb);
   CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nbc), dim3(256), 0, st, z, p, redB, state, beta_d, N, eps, 0, 1, 0,
-                                      tolerance, 0, 0, x, x_best));
+                                      tolerance, 0, 0, x, x_best, (CgPoll *)nullptr));
   CG_CHECK(hipGetLastError());
 
   int it = 0;
   const int n_iter = max_iter < global_N ? max_iter : (int)global_N;
   const int min_it = min_iter < n_iter - 1 ? min_iter : n_iter - 1;
   const int n_hist = hist_len < n_iter ? hist_len : n_iter;
-  // The convergence decision is taken on the device (pass C); the host reads it one iteration late from pinned
-  // memory, so the next iteration is already queued while it waits and the GPU never idles on the round trip.  The
-  // iteration queued past convergence is a no-op on x (alpha = 0).
+  // The convergence decision is taken on the device (pass C), which writes its poll record straight into pinned host
+  // memory; the host reads it one iteration late (after the event recorded behind that pass C), so the next iteration is
+  // already queued while it waits and the GPU never idles on the round trip.  The iteration queued past convergence is a
+  // no-op on x (alpha = 0).
   int polled_it = -1;                     // iteration whose poll is in flight (-1: none)
   CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f};
   for (it = 0; it < n_iter; ++it) {
@@ -871,14 +894,15 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     CG_REDUCE(redA, nba);
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
     CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nbb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB,
-                                        part, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2, eps, stop_after,
-                                        it & 1, 0));
+                                        part, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2, eps,
+                                        stop_after, it & 1, 0));
     CG_REDUCE(redB, nbb);
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
     CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nbc), dim3(256), 0, st, zsrc, p, redB, state,
                                         beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
-                                        it + 1, stagnation_window, x, x_best));
+                                        it + 1, stagnation_window, x, x_best,
+                                        check_now ? g_poll.host_dev + (it % kPollRing) : (CgPoll *)nullptr));
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
       CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
       last = hpoll[polled_it % kPollRing];
@@ -889,7 +913,6 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
       }
     }
     if (check_now) {
-      CG_CHECK(hipMemcpyAsync(&hpoll[it % kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
       CG_CHECK(hipEventRecord(g_poll.ev[it % kPollRing], st));
       polled_it = it;
     }

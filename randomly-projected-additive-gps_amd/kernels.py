@@ -12,7 +12,7 @@ from torch.nn import functional as F
 
 from . import backend as _backend
 from .distributed import JShard, RowShard
-from .operators import AdditiveRPOperator, FamilyAdditiveOperator, SKIAdditiveOperator
+from .operators import AdditiveRPOperator, FamilyAdditiveOperator, MixedGroupOperator, SKIAdditiveOperator
 
 
 def inv_softplus(y):
@@ -212,14 +212,13 @@ class GeneralizedProjectionKernel(Kernel):
         # the reference's per-projection grid bounds (polynomial_projection_kernels.py:54-63); `ski_options["grid_rule"] =
         # "shared"` selects this build's single shared grid instead
         self.grid_rule = dict(ski_options or {}).get("grid_rule", "reference")
-        if len(set(degrees)) != 1:
-            raise NotImplementedError("multiplicative groups of different sizes are not built (general_rp_poly)")
         if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
             raise ValueError("Unknown kernel type")
-        if degrees[0] > 1 and kernel_type != "RBF":
+        if max(degrees) > 1 and kernel_type != "RBF":
             raise NotImplementedError("products of non-RBF sub-kernels are not built")
         self.component_degrees = degrees
-        self.J, self.k, self.d = len(degrees), degrees[0], d
+        # k: the common group size, or None for mixed sizes (general_rp_poly / multi_additive -> MixedGroupOperator)
+        self.J, self.k, self.d = len(degrees), (degrees[0] if len(set(degrees)) == 1 else None), d
         self.kernel_type = kernel_type
         self.weighted = weighted
         self.learn_proj = learn_proj
@@ -267,6 +266,9 @@ class GeneralizedProjectionKernel(Kernel):
             return SKIAdditiveOperator(z1, z2, outputscale=outputscale, weight=1.0, grid_size=self.grid_size,
                                        comp_weights=self.outputscales,
                                        row_shard=shard if isinstance(shard, RowShard) else None, grid_rule=self.grid_rule)
+        if self.k is None:
+            return MixedGroupOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
+                                      kind=self.kernel_type, degrees=self.component_degrees)
         return FamilyAdditiveOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
                                       kind=self.kernel_type, group=self.k)
 

@@ -748,6 +748,117 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
         return self._finish_grads(gZ, gc)
 
 
+class MixedGroupOperator(AdditiveRPOperator):
+    """K = outputscale * sum_c w_c prod_{m in group c} k1(z_m - z_m') with multiplicative groups of DIFFERENT sizes
+    (`general_rp_poly` with e.g. degrees [1, 1, 2, 3], training_routines.py:192-207; `create_multi_additive_kernel`,
+    :247-258: every feature subset up to a degree).  The components are bucketed by group size and every bucket is one
+    FamilyAdditiveOperator on its own column slice of Z — same fused tile kernels, one launch per distinct size per
+    product; sums, diagonals, rows and derivatives are assembled here.  Runs replicated, fp32, torch mBCG loop."""
+
+    def __init__(self, Z1, Z2=None, outputscale=None, comp_weights=None, kind="RBF", degrees=(1,)):
+        super().__init__(Z1, Z2, outputscale, 1.0, shard=None)
+        self.kind = kind
+        self.degrees = [int(dg) for dg in degrees]
+        if sum(self.degrees) != Z1.shape[1]:
+            raise ValueError("the group sizes must add up to the number of columns")
+        ncomp = len(self.degrees)
+        if comp_weights is None:
+            comp_weights = torch.full((ncomp,), 1.0 / ncomp, dtype=Z1.dtype, device=Z1.device)
+        self.comp_weights = comp_weights
+        starts = [0]
+        for dg in self.degrees:
+            starts.append(starts[-1] + dg)
+        self.buckets = []                           # (component indices, column indices, operator) per distinct size
+        for k in sorted(set(self.degrees)):
+            comps = [c for c, dg in enumerate(self.degrees) if dg == k]
+            cols = [starts[c] + m for c in comps for m in range(k)]
+            ci = torch.as_tensor(comps, dtype=torch.long, device=Z1.device)
+            co = torch.as_tensor(cols, dtype=torch.long, device=Z1.device)
+            z1 = Z1.detach().index_select(1, co).contiguous()
+            z2 = None if Z2 is None else Z2.detach().index_select(1, co).contiguous()
+            part = FamilyAdditiveOperator(z1, z2, outputscale, comp_weights.detach().index_select(0, ci), kind, k)
+            self.buckets.append((ci, co, part))
+        self._wsum = sum(part._wsum for _, _, part in self.buckets)
+
+    def _local_matmul(self, rhs, noise=0.0):
+        out = None
+        for i, (_, _, part) in enumerate(self.buckets):
+            o = part._local_matmul(rhs, noise if i == 0 else 0.0)
+            out = o if out is None else out.add_(o)
+        return out
+
+    def _matmul(self, rhs, noise=0.0):
+        if noise and not self.symmetric:
+            raise ValueError("a diagonal can only be added to the square symmetric operator")
+        return self._local_matmul(rhs.detach(), noise if self.symmetric else 0.0)
+
+    def fused_pivoted_cholesky(self, rank):
+        return None
+
+    def native_descriptor(self, noise=0.0):
+        return None
+
+    def native_sharding(self):
+        return None
+
+    def _transpose_nonbatch(self):
+        if self.symmetric:
+            return self
+        return MixedGroupOperator(self.Z2, self.Z1, self.outputscale, self.comp_weights, self.kind, self.degrees)
+
+    def _diagonal(self):
+        if not self.symmetric:
+            raise RuntimeError("diagonal of a rectangular cross-covariance requested")
+        return torch.full((self.Z1.shape[0],), self._scale * self._wsum, dtype=self.dtype, device=self.device)
+
+    def _get_rows(self, idx):
+        out = None
+        for _, _, part in self.buckets:
+            o = part._get_rows(idx)
+            out = o if out is None else out.add_(o)
+        return out
+
+    def to_dense(self):
+        out = None
+        for _, _, part in self.buckets:
+            o = part.to_dense()
+            out = o if out is None else out.add_(o)
+        return out
+
+    evaluate = to_dense
+
+    def to_dense_cached(self):
+        return self.to_dense()
+
+    def to_symcache(self, wide=False):
+        return None
+
+    def representation(self):
+        if self.symmetric:
+            return (self.Z1, self.outputscale, self.comp_weights)
+        return (self.Z1, self.Z2, self.outputscale, self.comp_weights)
+
+    def _assemble(self, grads):
+        gZ = torch.zeros_like(self.Z1)
+        gc = torch.zeros(len(self.degrees), dtype=self.Z1.dtype, device=self.Z1.device)
+        gs = torch.zeros((), dtype=self.Z1.dtype, device=self.Z1.device)
+        for (ci, co, _), (gz_p, gs_p, gc_p) in zip(self.buckets, grads):
+            gZ.index_copy_(1, co, gz_p.to(gZ))
+            gc.index_copy_(0, ci, gc_p.to(gc).reshape(-1))
+            gs = gs + gs_p.to(gs)
+        return gZ, gs, gc
+
+    def _bilinear_derivative(self, left_vecs, right_vecs):
+        if not self.symmetric:
+            raise NotImplementedError("derivatives are only needed for the train-train kernel")
+        return self._assemble([part._bilinear_derivative(left_vecs, right_vecs) for _, _, part in self.buckets])
+
+    _quad_form_derivative = _bilinear_derivative
+
+    def dense_weight_derivative(self, S):
+        return self._assemble([part.dense_weight_derivative(S) for _, _, part in self.buckets])
+
+
 class AddedDiagOperator(LinearOperator):
     """base + noise * I  (the likelihood's AddedDiagLazyTensor); the noise term is fused into the MVM kernel."""
 

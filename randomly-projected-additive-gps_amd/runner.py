@@ -301,9 +301,18 @@ def main(argv=None):
     print("Using device(s) {}".format(devices))
     datasets = resolve_datasets(args.datasets)
 
-    if options["kind"] in ("ppr_gp", "cgp", "model_average"):
+    if options["kind"] in ("ppr_gp", "cgp"):
         raise NotImplementedError("model kind '%s' is outside the MI355X hot path (SURVEY.md §8)" % options["kind"])
-    options["skip_random_restart"] = args.skip_random_restart
+    ma = options["kind"] == "model_average"
+    if ma:
+        # the overloaded "kind" key (gp_experiment_runner.py:299-304): the base model's options with the varying lists inside
+        ma_args = options.pop("varying_params")
+        options = options["base_model_kwargs"]
+        options["model_kwargs"]["varying_params"] = ma_args
+        if world > 1:
+            raise ValueError("model averaging runs on one device")
+    else:
+        options["skip_random_restart"] = args.skip_random_restart
     options["devices"] = devices
     options["skip_posterior_variances"] = args.skip_posterior_variances
     options["evaluate_on_train"] = not args.skip_evaluate_on_train
@@ -335,7 +344,8 @@ def main(argv=None):
             for abl_val in abl_vars:
                 if args.ablation:
                     options["model_kwargs"]["J" if args.k is None else "k"] = abl_val
-                results = run_experiment(training_routines.train_exact_gp, options, dataset, split=args.split,
+                routine = training_routines.train_exact_gp_model_average if ma else training_routines.train_exact_gp
+                results = run_experiment(routine, options, dataset, split=args.split,
                                          cv=args.cv, repeats=args.repeats, normalize_using_train=True,
                                          chosen_fold=args.fold, error_repeats=args.error_repeats)
                 if args.ablation:

@@ -44,6 +44,33 @@ SPECS = {
                                     weighted=True, ski=True, ski_options=dict(_SKI)),
     "additive_deterministic_spec_unweighted_ski": _spec("strictly_additive", noise_prior=True, kernel_type="RBF",
                                                         weighted=False, ski=True, ski_options=dict(_SKI)),
+    # the rest of the reference's exact-GP specifications that the built kinds serve
+    "additive_rp_prescale_J1": _rp(1, True),
+    "additive_rp_prescale_on_sphere": _rp(20, True, space_proj=False, proj_dist="sphere"),
+    "additive_rp_J1_K1": _spec("rp_poly", k=1, J=1, noise_prior=True, kernel_type="RBF", learn_proj=False, weighted=True),
+    "additive_rp_Jd_K1": _spec("rp_poly", k=1, J="d", noise_prior=True, kernel_type="RBF", learn_proj=False, weighted=True),
+    "additive_rp_Jd_spread": _spec("rp_poly", k=1, J="d", noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                   weighted=True, space_proj=True),
+    "additive_spread_projections": _spec("rp_poly", k=1, J=20, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                         weighted=True, space_proj=True),
+    "additive_spread_projections_RO": _spec("rp_poly", train=dict(_ADAM, checkpoint=True, random_restarts=10),
+                                            k=1, J=20, noise_prior=True, kernel_type="RBF", learn_proj=False, weighted=True,
+                                            space_proj=True, init_lengthscale_range=[0.4, 0.8], init_mixin_range=[0.4, 0.8]),
+    "best_of_single_proj": _spec("rp_poly", train=dict(_ADAM, max_iter=0, random_restarts=20, init_iters=1000,
+                                                        rr_check_conv=True),
+                                 k=1, J=1, noise_prior=True, kernel_type="RBF", learn_proj=False, weighted=True),
+    "additive_deterministic_spec_unweighted": _spec("strictly_additive", noise_prior=True, kernel_type="RBF", weighted=False),
+    "ARD_RO": _spec("full", train=dict(_ADAM, checkpoint=True, random_restarts=10), noise_prior=True, kernel_type="RBF",
+                    ard=True, init_lengthscale_range=[0.4, 0.8]),
+    # multiplicative groups of different sizes (operators.MixedGroupOperator)
+    "polynomial_rp": _spec("general_rp_poly", degrees=[1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6], noise_prior=True,
+                           kernel_type="RBF", learn_proj=False, weighted=True),
+    "polynomial_rp_smaller": _spec("general_rp_poly", degrees=[1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3], noise_prior=True,
+                                   kernel_type="RBF", learn_proj=False, weighted=True),
+    # Bayesian model average over J (training.train_exact_gp_model_average)
+    "ma_dpa_gp_ard": {"kind": "model_average", "varying_params": {"J": [1, 2, 3, 5, 8, 13, 21, 34, 55, 89]},
+                      "base_model_kwargs": _spec("additive_rp", train=dict(_ADAM, max_iter=300, patience=15), J=20,
+                                                 noise_prior=True, kernel_type="RBF", learn_proj=False, prescale=True)},
 }
 
 

@@ -17,8 +17,8 @@ from .kernels import (AdditiveStructureRBFKernel, CustomAdditiveKernel, MemoryEf
 from .likelihoods import GaussianLikelihood, SmoothedBoxPrior
 from .models import ExactGPModel, ExactMarginalLogLikelihood
 
-EXACT_GP_KINDS = ("full", "additive_rp", "strictly_additive", "additive", "rp_poly")
-REFERENCE_ONLY_KINDS = ("rp", "deep_rp_poly", "general_rp_poly", "multi_full", "duvenaud_additive", "sgpr")
+EXACT_GP_KINDS = ("full", "additive_rp", "strictly_additive", "additive", "rp_poly", "general_rp_poly")
+REFERENCE_ONLY_KINDS = ("rp", "deep_rp_poly", "multi_full", "duvenaud_additive", "sgpr")
 
 
 def _map_to_optim(optimizer):
@@ -136,6 +136,41 @@ def create_additive_kernel(d, groups, weighted=False, kernel_type="RBF", init_le
     return kernel
 
 
+def create_general_rp_poly_kernel(d, degrees, learn_proj=False, weighted=False, kernel_type="RBF",
+                                  init_lengthscale_range=(1.0, 1.0), init_mixin_range=(1.0, 1.0), ski=False,
+                                  ski_options=None, X=None, keops=False):
+    """training_routines.py:192-207 (model_specs/polynomial_rp.json): sum(degrees) Gaussian random projections, grouped in
+    order into multiplicative groups of the given sizes — the sizes may differ (operators.MixedGroupOperator)."""
+    from .kernels import GeneralizedProjectionKernel
+    out_dim = sum(degrees)
+    W = torch.cat([rp.gen_rp(d, 1) for _ in range(out_dim)], dim=1).t()
+    projection_module = torch.nn.Linear(d, out_dim, bias=False)
+    projection_module.weight = torch.nn.Parameter(W.contiguous())
+    if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+        raise ValueError("Unknown kernel type")
+    kernel = GeneralizedProjectionKernel(degrees, d, kernel_type, projection_module, learn_proj, weighted, ski, ski_options,
+                                         X=X)
+    kernel.initialize(init_mixin_range, init_lengthscale_range)
+    return kernel
+
+
+def create_multi_additive_kernel(d, max_degree, weighted=False, kernel_type="RBF", init_lengthscale_range=(1.0, 1.0),
+                                 init_mixin_range=(1.0, 1.0), ski=False, ski_options=None, X=None, keops=False):
+    """training_routines.py:247-258: an additive kernel over EVERY feature subset of size 1..max_degree (the group order
+    inside one size follows the reference's `list(set(combinations(...)))`, so the same torch RNG stream initialises the
+    same groups)."""
+    from itertools import combinations
+    if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
+        raise ValueError("Unknown kernel type")
+    max_degree = min(max_degree, d)
+    groups = []
+    for deg in range(1, max_degree + 1):
+        groups.extend(list(set(combinations(list(range(d)), deg))))
+    kernel = CustomAdditiveKernel(groups, d, kernel_type, weighted=weighted, ski=ski, ski_options=ski_options, X=X)
+    kernel.initialize(init_mixin_range, init_lengthscale_range)
+    return kernel
+
+
 def create_full_kernel(d, ard=False, ski=False, grid_size=None, kernel_type="RBF", init_lengthscale_range=(1.0, 1.0),
                        keops=False):
     """Plain stationary kernel for `kind: full` (training_routines.py:275-293): dense torch ops, not the hot path."""
@@ -175,6 +210,8 @@ def create_exact_gp(trainX, trainY, kind, devices=("cpu",), **kwargs):
         kernel = create_additive_kernel(d, X=trainX, **kwargs)
     elif kind == "rp_poly":
         kernel = create_rp_poly_kernel(d, X=trainX, **kwargs)
+    elif kind == "general_rp_poly":
+        kernel = create_general_rp_poly_kernel(d, X=trainX, **kwargs)
     else:
         kernel = create_additive_rp_kernel(d, **kwargs)
     kernel = ScaleKernel(kernel)
@@ -275,7 +312,7 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
     output_device = devices[0] if output_device is None else torch.device(output_device)
     if double and model_kwargs.get("ski", False):
         raise NotImplementedError("--double is not available for the SKI operator (fp32 kernels only)")
-    if double and (kind in ("rp_poly", "additive") or (kind == "strictly_additive" and not model_kwargs.get("memory_efficient"))
+    if double and (kind in ("rp_poly", "additive", "general_rp_poly") or (kind == "strictly_additive" and not model_kwargs.get("memory_efficient"))
                    or (kind == "additive_rp" and (model_kwargs.get("kernel_type", "RBF") != "RBF" or model_kwargs.get("k", 1) > 1))):
         raise NotImplementedError("--double is served by the float64 parity kernels of the RBF hot path only "
                                   "(additive_rp with 1-D RBF sub-kernels, the memory-efficient GAM, kind full)")
@@ -361,3 +398,79 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
     model_metrics["testing_warning"] = "" if len(w2) == 0 else w2[-1].message
     model_metrics["state_dict_file"] = _save_state_dict(model)
     return model_metrics, pred_mean.to("cpu", torch.float), model
+
+
+class ModelAverage:
+    """Mixture of the predictive distributions of several fitted models, weighted by their marginal likelihoods — what
+    `train_exact_gp_model_average` (training_routines.py:631-676) builds through `fitting.sampling.ModelAverage`.  That module
+    is NOT part of the reference checkout, so this class follows the call sites only (`ModelAverage(predictions, log_mlls)`,
+    `.mean()`, `.sample_mean()`, `.log_prob(y)`) with the textbook meaning — **unpinned**:
+      weights w_i = softmax(log_mlls)          (the routine passes -prior_train_nmll, i.e. the per-datum MLL of each fit)
+      mean()        = sum_i w_i mu_i           (the mixture's mean)
+      sample_mean() = (1/M) sum_i mu_i         (the unweighted average over the fitted models)
+      log_prob(y)   = logsumexp_i(log w_i + log N(y; mu_i, Sigma_i))."""
+
+    def __init__(self, predictions, log_mlls):
+        if len(predictions) == 0 or len(predictions) != len(log_mlls):
+            raise ValueError("one log marginal likelihood per prediction is required")
+        self.predictions = list(predictions)
+        lm = torch.as_tensor([float(v) for v in log_mlls], dtype=torch.float64)
+        self.log_weights = lm - torch.logsumexp(lm, dim=0)
+
+    @property
+    def weights(self):
+        return self.log_weights.exp()
+
+    def mean(self):
+        w = self.weights
+        out = None
+        for wi, pr in zip(w, self.predictions):
+            term = pr.mean * float(wi)
+            out = term if out is None else out + term
+        return out
+
+    def sample_mean(self):
+        return sum(pr.mean for pr in self.predictions) / len(self.predictions)
+
+    def log_prob(self, value):
+        lps = torch.stack([pr.log_prob(value).double().cpu() for pr in self.predictions])
+        return torch.logsumexp(self.log_weights + lps, dim=0)
+
+
+def train_exact_gp_model_average(trainX, trainY, testX, testY, kind, model_kwargs, train_kwargs, devices=("cpu",),
+                                 skip_posterior_variances=False, evaluate_on_train=True, output_device=None,
+                                 record_pred_unc=False, **fit_options):
+    """training_routines.py:631-676 (model_specs/ma_dpa_gp_ard.json): fit one exact GP per value of the varying parameters
+    (lists of equal length under `model_kwargs["varying_params"]`, e.g. J = 1, 2, 3, 5, ...), each without random restarts,
+    and average their test predictions with marginal-likelihood weights.  Returns (metrics, mean, None)."""
+    from . import settings
+    model_kwargs = copy.deepcopy(model_kwargs)
+    train_kwargs = copy.deepcopy(train_kwargs)
+    if len(devices) > 1:
+        raise ValueError("CGP not implemented for multi GPUs (yet?)")
+    varying_params = model_kwargs.pop("varying_params")
+    first = list(varying_params.keys())[0]
+    predictions, log_mlls = [], []
+    dev = torch.device(output_device if output_device is not None else devices[0])
+    for i in range(len(varying_params[first])):
+        for key, values in varying_params.items():
+            model_kwargs[key] = values[i]
+        metrics, _, model = train_exact_gp(trainX, trainY, testX, testY, kind, copy.deepcopy(model_kwargs),
+                                           copy.deepcopy(train_kwargs), devices=devices,
+                                           skip_posterior_variances=skip_posterior_variances, skip_random_restart=True,
+                                           evaluate_on_train=False, output_device=output_device, **fit_options)
+        log_mlls.append(-metrics["prior_train_nmll"])
+        model.eval()
+        model.likelihood.eval()
+        with torch.no_grad(), settings.skip_posterior_variances(skip_posterior_variances):
+            tx = testX.to(dev, next(model.parameters()).dtype).contiguous()
+            predictions.append(model(tx))
+    test_outputs = ModelAverage(predictions, log_mlls)
+    testY = testY.to(predictions[0].mean)
+    model_metrics = dict()
+    with torch.no_grad():
+        if not skip_posterior_variances:
+            model_metrics["test_nll"] = -test_outputs.log_prob(testY).item()
+        model_metrics["sampled_mean_mse"] = mean_squared_error(test_outputs.sample_mean(), testY)
+        model_metrics["normal_mean_mse"] = mean_squared_error(test_outputs.mean(), testY)
+    return model_metrics, test_outputs.mean().to("cpu"), None

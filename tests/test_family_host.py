@@ -24,12 +24,15 @@ def _phi_t(kind, d2):
 
 
 def _dense_family(Z, kind, group, w):
+    """`group`: the common group size, or the list of group sizes (in column order) for mixed sizes."""
     n = Z.shape[0]
     K = torch.zeros(n, n, dtype=torch.float64)
-    for c in range(Z.shape[1] // group):
-        d2 = sum((Z[:, c * group + m:c * group + m + 1] - Z[:, c * group + m:c * group + m + 1].t()) ** 2
-                 for m in range(group))
+    sizes = [group] * (Z.shape[1] // group) if isinstance(group, int) else list(group)
+    col = 0
+    for c, k in enumerate(sizes):
+        d2 = sum((Z[:, col + m:col + m + 1] - Z[:, col + m:col + m + 1].t()) ** 2 for m in range(k))
         K = K + w[c] * _phi_t(kind, d2)
+        col += k
     return K
 
 
@@ -67,6 +70,9 @@ def _problem(n=60, d=5, seed=0):
     ("strictly_additive", dict(weighted=True, kernel_type="RBF")),
     ("strictly_additive", dict(weighted=False, kernel_type="RBF", memory_efficient=True)),
     ("additive", dict(groups=[[0, 3], [1, 4]], weighted=True)),
+    ("additive", dict(groups=[[0], [1, 4], [2], [0, 2, 3]], weighted=True)),                  # unequal groups
+    ("general_rp_poly", dict(degrees=[1, 2, 1, 3], weighted=True, learn_proj=False)),        # polynomial_rp.json's shape
+    ("general_rp_poly", dict(degrees=[2, 1], weighted=False, learn_proj=False)),
 ])
 def test_family_mll_and_gradients_match_dense_autograd(oracle_backend, kind, model_kwargs):
     from rpgp_amd.training import create_exact_gp
@@ -111,7 +117,7 @@ def test_family_mll_and_gradients_match_dense_autograd(oracle_backend, kind, mod
         raw_w = leaf("w", base.raw_outputscales)
         P = base.projection_module.weight.detach().double().t()
         Z = (Xd @ P) / F.softplus(raw_ls).reshape(-1)
-        group, ktype = base.k, base.kernel_type
+        group, ktype = (base.k if base.k is not None else base.component_degrees), base.kernel_type
         w = F.softplus(raw_w)
     n = X.shape[0]
     Kh = F.softplus(raw_s) * _dense_family(Z, ktype, group, w) + (F.softplus(raw_n) + 1e-4) * torch.eye(n, dtype=torch.float64)
@@ -175,7 +181,9 @@ def test_family_validation_errors():
         create_rp_poly_kernel(6, 1, 3, activation="relu")
     X, y = _problem(20, 4)
     with pytest.raises(NotImplementedError):
-        create_exact_gp(X, y, "general_rp_poly", noise_prior=False, degrees=[1, 2])
+        create_exact_gp(X, y, "general_rp_poly", noise_prior=False, degrees=[1, 2], kernel_type="Matern")
+    with pytest.raises(NotImplementedError):
+        create_exact_gp(X, y, "deep_rp_poly", noise_prior=False)
     with pytest.raises(ValueError):
         create_exact_gp(X, y, "nonsense", noise_prior=False)
 
@@ -255,3 +263,83 @@ def test_double_is_refused_for_family_kinds(oracle_backend):
                                           ski_options={"grid_size": 64, "num_dims": 1}))):
         with pytest.raises(NotImplementedError):
             train_exact_gp(X, y, X, y, kind, mk, tk, double=True)
+
+
+def test_multi_additive_kernel_groups_and_operator(oracle_backend):
+    """create_multi_additive_kernel (training_routines.py:247-258): every feature subset up to max_degree, through the
+    mixed-size operator; product, diagonal, rows and dense form agree with the dense restatement."""
+    from rpgp_amd.training import create_multi_additive_kernel
+    from rpgp_amd.operators import MixedGroupOperator
+    torch.manual_seed(5)
+    k = create_multi_additive_kernel(4, 3, weighted=True, init_lengthscale_range=(0.8, 1.6), init_mixin_range=(0.5, 1.5))
+    assert sorted(len(g) for g in k.groups) == [1] * 4 + [2] * 6 + [3] * 4
+    assert sorted(k.groups[:4]) == [(0,), (1,), (2,), (3,)] and k.k is None
+    assert abs(float(k.outputscales.sum()) - 1.0) < 1e-6
+    X, _ = _problem(40, 4, seed=2)
+    s = torch.tensor(1.3)
+    op = k(X, None, outputscale=s) if not hasattr(k, "operator") else k.forward(X, None, outputscale=s)
+    assert isinstance(op, MixedGroupOperator) and len(op.buckets) == 3
+    Z = (X.double() @ k.projection_module.weight.double().t()) / k.lengthscales.detach().double().reshape(-1)
+    Kd = 1.3 * _dense_family(Z, "RBF", k.component_degrees, k.outputscales.detach().double())
+    V = torch.randn(40, 3, generator=torch.Generator().manual_seed(1))
+    assert torch.allclose(op._matmul(V, noise=0.2).double(), Kd @ V.double() + 0.2 * V.double(), atol=2e-5)
+    assert torch.allclose(op.to_dense().double(), Kd, atol=2e-6)
+    assert torch.allclose(op._diagonal().double(), Kd.diagonal(), atol=2e-6)
+    idx = torch.tensor([3, 17, 3])
+    assert torch.allclose(op._get_rows(idx).double(), Kd[idx], atol=2e-6)
+    X2, _ = _problem(9, 4, seed=3)
+    opr = k.forward(X, X2, outputscale=s)
+    Z2 = (X2.double() @ k.projection_module.weight.double().t()) / k.lengthscales.detach().double().reshape(-1)
+    n, m = 40, 9
+    Kr = torch.zeros(n, m, dtype=torch.float64)
+    col = 0
+    for c, kk in enumerate(k.component_degrees):
+        d2 = sum((Z[:, col + q:col + q + 1] - Z2[:, col + q:col + q + 1].t()) ** 2 for q in range(kk))
+        Kr += k.outputscales.detach().double()[c] * torch.exp(-0.5 * d2)
+        col += kk
+    W = torch.randn(9, 2, generator=torch.Generator().manual_seed(4))
+    assert torch.allclose(opr._matmul(W).double(), 1.3 * Kr @ W.double(), atol=2e-5)
+    assert torch.allclose(opr.t()._matmul(V).double(), 1.3 * Kr.t() @ V.double(), atol=2e-5)
+
+
+def test_model_average_weights_and_routine(oracle_backend, tmp_path):
+    """train_exact_gp_model_average (training_routines.py:631-676) + the runner's `kind: model_average` disambiguation
+    (gp_experiment_runner.py:299-304).  ModelAverage itself is unpinned (fitting/sampling.py is not in the reference checkout):
+    the mixture identities are checked instead."""
+    import json
+    from rpgp_amd.likelihoods import MultivariateNormal
+    from rpgp_amd.training import ModelAverage, train_exact_gp_model_average
+    from rpgp_amd import runner, specs
+    m1, m2 = torch.tensor([0.0, 1.0, 2.0]), torch.tensor([1.0, 1.0, 1.0])
+    p1 = MultivariateNormal(m1, torch.tensor([1.0, 2.0, 0.5]), diagonal_only=True)
+    p2 = MultivariateNormal(m2, torch.eye(3) * 0.7)
+    ma = ModelAverage([p1, p2], [-1.0, -1.0 + math.log(3.0)])
+    assert torch.allclose(ma.weights, torch.tensor([0.25, 0.75], dtype=torch.float64))
+    assert torch.allclose(ma.mean(), 0.25 * m1 + 0.75 * m2) and torch.allclose(ma.sample_mean(), 0.5 * (m1 + m2))
+    y = torch.tensor([0.3, 0.9, 1.4])
+    want = math.log(0.25 * math.exp(float(p1.log_prob(y))) + 0.75 * math.exp(float(p2.log_prob(y))))
+    assert abs(float(ma.log_prob(y)) - want) < 1e-9
+    one = ModelAverage([p2], [-3.0])
+    assert abs(float(one.log_prob(y)) - float(p2.log_prob(y))) < 1e-9 and torch.allclose(one.mean(), m2)
+    with pytest.raises(ValueError):
+        ModelAverage([p1], [0.0, 1.0])
+
+    X, y = _problem(50, 4, seed=6)
+    Xt, yt = _problem(12, 4, seed=7)
+    tk = {"verbose": False, "optimizer": "adam", "max_iter": 3, "lr": 0.1, "patience": 20, "smooth": True}
+    mk = dict(J=3, noise_prior=True, kernel_type="RBF", learn_proj=False, prescale=True, varying_params={"J": [1, 2, 4]})
+    torch.manual_seed(0)
+    metrics, mean, model = train_exact_gp_model_average(X, y, Xt, yt, "additive_rp", mk, tk)
+    assert model is None and mean.shape == (12,) and mk["varying_params"] == {"J": [1, 2, 4]} and mk["J"] == 3
+    assert set(metrics) == {"test_nll", "sampled_mean_mse", "normal_mean_mse"}
+    assert all(np.isfinite(v) for v in metrics.values())
+    m2_, _, _ = train_exact_gp_model_average(X, y, Xt, yt, "additive_rp", mk, tk, skip_posterior_variances=True)
+    assert "test_nll" not in m2_
+
+    spec = specs.get("ma_dpa_gp_ard")
+    spec["varying_params"] = {"J": [1, 3]}
+    spec["base_model_kwargs"]["train_kwargs"].update(max_iter=2)
+    f = tmp_path / "ma.json"
+    json.dump(spec, open(f, "w"))
+    df = runner.main(["-m", str(f), "-d", "synthetic:tiny", "-o", str(tmp_path / "ma.csv"), "--no_cv"])
+    assert np.isfinite(df.iloc[0]["normal_mean_mse"]) and np.isfinite(df.iloc[0]["rmse"])

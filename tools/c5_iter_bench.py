@@ -20,7 +20,7 @@ if shape == "C5":
     khat = AddedDiagOperator(base, torch.tensor(0.5, device=dev))
     noise = 0.5
 else:
-    N, J = 50000, 20
+    N, J = {"C2": (7372, 20), "C3": (14939, 20)}.get(shape, (50000, 20))
     Z = (torch.randn(N, J, generator=g)).to(dev)
     base = AdditiveRPOperator(Z, None, torch.tensor(1.0, device=dev), 1.0 / J)
     noise = 0.1

@@ -439,6 +439,20 @@ int rpgp_comm_error(rpgp_comm *comm, int *error_host);
 int rpgp_comm_destroy(rpgp_comm *comm);
 
 /*
+ * Woodbury preconditioner M = L L^T + sigma^2 I outside the mBCG executor (GPyTorch's `_preconditioner` closure and its
+ * `precond_lt` / probe-vector solves, reached from `mll()` at fitting/optimizing.py:69-72): the float64 Gram products and
+ * the cancelling update.
+ *   rpgp_gram_f64: out[K x T] (row-major float64) = A^T B for fp32 A (N x K, leading dimension lda) and B (N x T, ldb);
+ *                  exact products, float64 sums in a fixed order.  K, T <= 64.  Workspace: rpgp_gram_f64_workspace_bytes.
+ *   rpgp_woodbury_apply: out[N x T] = (float)(((double)R - L Tm) / noise), Tm: K x T float64 (row-major).
+ */
+size_t rpgp_gram_f64_workspace_bytes(int K, int T);
+int rpgp_gram_f64(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t N, int K, int T, double *out,
+                  void *workspace, size_t workspace_bytes, void *stream);
+int rpgp_woodbury_apply(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *Tm, double noise,
+                        float *out, int64_t ldo, int64_t N, int K, int T, void *stream);
+
+/*
  * Float64 variants for `--double` (training_routines.py:481).  Same contracts as the fp32 entry points of the same
  * name; parity path (software exp, no symmetry exploitation, no workspace).  rpgp_mvm_f64 covers both the square
  * (Z1 == Z2, optional noise) and the rectangular product; `row_scratch` is N doubles of device scratch.

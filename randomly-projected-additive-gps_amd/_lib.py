@@ -99,6 +99,9 @@ SIGNATURES = {
     "rpgp_comm_allreduce": (_int, [_vp, _vp, _sz, _int, _vp]),
     "rpgp_comm_error": (_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     "rpgp_comm_destroy": (_int, [_vp]),
+    "rpgp_gram_f64_workspace_bytes": (_sz, [_int, _int]),
+    "rpgp_gram_f64": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _vp, _vp, _sz, _vp]),
+    "rpgp_woodbury_apply": (_int, [_vp, _i64, _vp, _i64, _vp, _f64, _vp, _i64, _i64, _int, _int, _vp]),
     "rpgp_profile_begin": (_int, []),
     "rpgp_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
 }

@@ -45,6 +45,8 @@ class HipBackend:
     family_bilinear_grad = staticmethod(ops.family_bilinear_grad)
     family_bilinear_grad_dense = staticmethod(ops.family_bilinear_grad_dense)
     family_pivoted_cholesky = staticmethod(ops.family_pivoted_cholesky)
+    gram_f64 = staticmethod(ops.gram_f64)
+    woodbury_apply = staticmethod(ops.woodbury_apply)
     make_operator_desc = staticmethod(ops.make_operator_desc)
     mbcg_solve = staticmethod(ops.mbcg_solve)
 

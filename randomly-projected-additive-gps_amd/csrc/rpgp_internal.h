@@ -26,4 +26,10 @@ int ski_gather_launch(const float *Z, const float *gp, const float *H, const flo
 size_t ski_scratch_floats(int J, int G);                  // floats of per-call scratch inside rpgp_ski_workspace_bytes
 size_t ski_scratch_offset_floats(int J, int G, int T);    // ... and where it starts
 
+// A^T B (K x T, K, T <= 64) for tall fp32 matrices with float64 accumulation on the matrix cores (rpgp_precond.hip); the
+// result is written as float64 and / or float32.  `part`: gram_part_bytes(K, T) of device scratch.
+size_t gram_part_bytes(int K, int T);
+int gram_launch(const float *A, long long lda, const float *B, long long ldb, long long N, int K, int T, double *out64,
+                float *out32, double *part, hipStream_t st);
+
 }  // namespace rpgp_internal

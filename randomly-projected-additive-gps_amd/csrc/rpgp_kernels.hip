@@ -3884,10 +3884,19 @@ int rpgp_project_grad(const float *X, const float *G, float *dPeff, int64_t N, i
   if (!X || !G || !dPeff || N <= 0 || d <= 0 || J <= 0) return RPGP_EINVAL;
   // two-pass deterministic reduction; partials live in a small static-size device buffer per call
   // (allocated by the caller-visible workspace would be cleaner, but d*J*nblk is tiny) -> use hipMallocAsync.
+  hipStream_t st = as_stream(stream);
+  if (d <= 64 && J <= 64) {
+    // thin X^T G on the matrix cores with float64 accumulation (rpgp_precond.hip; the slab kernel below walked 512 rows
+    // serially per thread on N / 512 workgroups: 88 us at N = 7372, d = 8, J = 20)
+    double *gpart = nullptr;
+    RPGP_CHECK(hipMallocAsync((void **)&gpart, rpgp_internal::gram_part_bytes(d, J), st));
+    const int grc = rpgp_internal::gram_launch(X, d, G, J, (long long)N, d, J, nullptr, dPeff, gpart, st);
+    hipFreeAsync(gpart, st);
+    return grc;
+  }
   const int nblk = (int)((N + 511) / 512 < 1024 ? (N + 511) / 512 : 1024);
   const long long rows_per_block = (N + nblk - 1) / nblk;
   float *part = nullptr;
-  hipStream_t st = as_stream(stream);
   RPGP_CHECK(hipMallocAsync((void **)&part, (size_t)nblk * d * J * sizeof(float), st));
   hipLaunchKernelGGL(project_grad_partial_kernel, dim3(nblk), dim3(256), 0, st, X, G, part, (long long)N, d, J,
                      rows_per_block);

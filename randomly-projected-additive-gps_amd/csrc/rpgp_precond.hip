@@ -1,0 +1,181 @@
+// Host-stack pieces of the Woodbury preconditioner M = L L^T + sigma^2 I that run OUTSIDE the
+// native mBCG executor: the float64 capacitance Gram L^T L, L^T R for a block of right-hand sides, and the cancelling
+// update (R - L t) / sigma^2.  Round 3 profile of one optimiser step at the C2 shape (N = 7372): two library float64 GEMMs
+// for the 15 x 15 / 15 x 10 products took 200 us EACH (one 64 x 64 tile, serial loop over N) out of a 4 ms step, behind a
+// float32 -> float64 copy of L; the update was an addmm + div + cast.
+//
+//   rpgp_gram_f64       out[K x T] = A^T B, A: N x K fp32, B: N x T fp32; products are exact in float64 and the sums are
+//                       float64 (v_mfma_f64_16x16x4_f64), fixed order -> bit-reproducible.  K, T <= 64.
+//   rpgp_woodbury_apply out = (float)(((double)R - L t) / sigma^2), t: K x T float64 — the subtraction that shrinks the
+//                       range-of-L component of R by ~1e-6 stays float64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/rpgp.h"
+#include "rpgp_internal.h"
+
+namespace {
+
+typedef double doublex4p __attribute__((ext_vector_type(4)));
+
+constexpr int kGramMaxWg = 512;
+
+// Lane l of a wave: c = l % 16 (column inside a 16-wide tile), q = l / 16 (row inside a 4-row step).  One matrix
+// instruction per (A tile, B tile, 4 rows): A operand [i = c][k = q] = A[n + q][16 ma + c], B operand [k = q][j = c] =
+// B[n + q][16 nb + c]; result register r of lane l = out[16 ma + q + 4 r][16 nb + c].
+template <int MA, int NB>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restrict__ A, long long lda,
+                                                           const float *__restrict__ B, long long ldb, long long N, int K,
+                                                           int T, double *__restrict__ part) {
+  __shared__ double sred[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  // two accumulator sets (even / odd steps): consecutive matrix instructions never chain on one accumulator
+  doublex4p acc[2][MA][NB];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[u][a][b] = doublex4p{0.0, 0.0, 0.0, 0.0};
+  const long long nwaves = (long long)gridDim.x * 4;
+  const long long w = (long long)blockIdx.x * 4 + wave;
+  const long long nsteps = (N + 3) / 4;
+  for (long long s = w; s < nsteps; s += 2 * nwaves) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long n = 4 * (s + u * nwaves) + q;
+      const bool rv = n < N && (s + u * nwaves) < nsteps;
+      double av[MA], bv[NB];
+#pragma unroll
+      for (int a = 0; a < MA; ++a) av[a] = (rv && 16 * a + c < K) ? (double)A[n * lda + 16 * a + c] : 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) bv[b] = (rv && 16 * b + c < T) ? (double)B[n * ldb + 16 * b + c] : 0.0;
+#pragma unroll
+      for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[u][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[u][a][b], 0, 0, 0);
+    }
+  }
+  // workgroup sum (waves in order), then one slab per workgroup: part[blockIdx][tile][r][lane]
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const doublex4p v = acc[0][a][b] + acc[1][a][b];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        __syncthreads();
+        sred[wave][lane] = v[r];
+        __syncthreads();
+        if (wave == 0) {
+          const double sum = ((sred[0][lane] + sred[1][lane]) + sred[2][lane]) + sred[3][lane];
+          part[(((size_t)blockIdx.x * (MA * NB) + (a * NB + b)) * 4 + r) * 64 + lane] = sum;
+        }
+      }
+    }
+}
+
+// out[i][j] = sum over the workgroups' slabs, in slab order
+__global__ __launch_bounds__(256) void gram_finish_kernel(const double *__restrict__ part, int nparts, int MA, int NB, int K,
+                                                          int T, double *__restrict__ out, float *__restrict__ out32) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= K * T) return;
+  const int i = e / T, j = e % T;
+  const int a = i >> 4, b = j >> 4, q = (i & 15) & 3, r = (i & 15) >> 2, c = j & 15;      // i % 16 = q + 4 r
+  const size_t off = ((size_t)(a * NB + b) * 4 + r) * 64 + (q * 16 + c);
+  const size_t stride = (size_t)MA * NB * 256;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + off];
+  if (out) out[e] = s;
+  if (out32) out32[e] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void woodbury_apply_kernel(const float *__restrict__ L, long long ldl,
+                                                             const float *__restrict__ R, long long ldr,
+                                                             const double *__restrict__ Tm, double inv_noise,
+                                                             float *__restrict__ out, long long ldo, long long N, int K,
+                                                             int T) {
+  extern __shared__ double sT[];                    // K x T
+  for (int e = threadIdx.x; e < K * T; e += 256) sT[e] = Tm[e];
+  __syncthreads();
+  const long long total = N * T;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+    const long long n = g / T;
+    const int t = (int)(g - n * T);
+    double acc = (double)R[n * ldr + t];
+    const float *lrow = L + n * ldl;
+    for (int k = 0; k < K; ++k) acc = fma(-(double)lrow[k], sT[k * T + t], acc);
+    out[n * ldo + t] = (float)(acc * inv_noise);
+  }
+}
+
+inline int tiles16(int n) { return (n + 15) / 16; }
+inline int gram_blocks(long long N) {
+  long long g = (N + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > kGramMaxWg) g = kGramMaxWg;
+  return (int)g;
+}
+
+}  // namespace
+
+namespace rpgp_internal {
+
+size_t gram_part_bytes(int K, int T) {
+  if (K <= 0 || T <= 0 || K > 64 || T > 64) return 0;
+  int ma = tiles16(K), nb = tiles16(T);
+  if (ma == 3) ma = 4;
+  if (nb == 3) nb = 4;
+  return (size_t)kGramMaxWg * ma * nb * 256 * sizeof(double);
+}
+
+// out64 and / or out32 [K x T] = A^T B; `part` holds gram_part_bytes(K, T)
+int gram_launch(const float *A, long long lda, const float *B, long long ldb, long long N, int K, int T, double *out64,
+                float *out32, double *part, hipStream_t st) {
+  const int g = gram_blocks(N);
+  int ma = tiles16(K), nb = tiles16(T);
+  if (ma == 3) ma = 4;                               // compiled tile counts: 1, 2, 4
+  if (nb == 3) nb = 4;
+#define RPGP_GRAM_CASE(MA_, NB_)                                                                                       \
+  if (ma == MA_ && nb == NB_)                                                                                          \
+    hipLaunchKernelGGL((gram_partial_kernel<MA_, NB_>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, N, K, T, part)
+  RPGP_GRAM_CASE(1, 1); RPGP_GRAM_CASE(1, 2); RPGP_GRAM_CASE(1, 4);
+  RPGP_GRAM_CASE(2, 1); RPGP_GRAM_CASE(2, 2); RPGP_GRAM_CASE(2, 4);
+  RPGP_GRAM_CASE(4, 1); RPGP_GRAM_CASE(4, 2); RPGP_GRAM_CASE(4, 4);
+#undef RPGP_GRAM_CASE
+  hipLaunchKernelGGL(gram_finish_kernel, dim3((K * T + 255) / 256), dim3(256), 0, st, part, g, ma, nb, K, T, out64, out32);
+  return (int)hipGetLastError();
+}
+
+}  // namespace rpgp_internal
+
+extern "C" {
+
+size_t rpgp_gram_f64_workspace_bytes(int K, int T) { return rpgp_internal::gram_part_bytes(K, T); }
+
+int rpgp_gram_f64(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t N, int K, int T, double *out,
+                  void *workspace, size_t workspace_bytes, void *stream) {
+  if (!A || !B || !out || N < 0 || K <= 0 || T <= 0 || K > 64 || T > 64 || lda < K || ldb < T) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_gram_f64_workspace_bytes(K, T)) return RPGP_EWORKSPACE;
+  return rpgp_internal::gram_launch(A, (long long)lda, B, (long long)ldb, (long long)N, K, T, out, nullptr,
+                                    reinterpret_cast<double *>(workspace), reinterpret_cast<hipStream_t>(stream));
+}
+
+int rpgp_woodbury_apply(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *Tm, double noise,
+                        float *out, int64_t ldo, int64_t N, int K, int T, void *stream) {
+  if (!L || !R || !Tm || !out || N < 0 || K <= 0 || T <= 0 || K > 64 || T > 64 || ldl < K || ldr < T || ldo < T ||
+      !(noise > 0.0))
+    return RPGP_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long long blocks = (N * T + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(woodbury_apply_kernel, dim3((int)blocks), dim3(256), (size_t)K * T * sizeof(double), st, L,
+                     (long long)ldl, R, (long long)ldr, Tm, 1.0 / noise, out, (long long)ldo, (long long)N, K, T);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

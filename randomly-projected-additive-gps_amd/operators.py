@@ -566,9 +566,15 @@ class RowShardedWoodbury:
         self.L = L_local
         self.noise = float(noise)
         self.row_shard = row_shard
-        self._L64 = L_local.double()
         from .precond import gram64
-        cap = gram64(self._L64, self._L64)            # float64 accumulation (see precond.WoodburyPreconditioner)
+        be = _backend.get_backend()
+        on_device = L_local.is_cuda or getattr(be, "name", "") != "hip-gfx950"
+        # in-tree float64 Gram / update kernels on the fp32 factor (rpgp_gram_f64, rpgp_woodbury_apply), as in
+        # precond.WoodburyPreconditioner; a rank without rows contributes zeros
+        self._be = be if (L_local.dtype == torch.float32 and 0 < L_local.shape[1] <= 64 and hasattr(be, "gram_f64")
+                          and on_device and L_local.shape[0] > 0) else None
+        self._L64 = L_local.double() if self._be is None else None
+        cap = self._be.gram_f64(L_local, L_local) if self._be is not None else gram64(self._L64, self._L64)
         row_shard.all_reduce_(cap, "sum")
         cap.diagonal().add_(self.noise)
         self._cap_chol = torch.linalg.cholesky(cap)
@@ -583,6 +589,15 @@ class RowShardedWoodbury:
             r = r.unsqueeze(-1)
         out = torch.empty_like(r)
         for c0 in range(0, max(r.shape[1], 1), _PANEL):
+            if self._be is not None and r.dtype == torch.float32:
+                rp = r[:, c0:c0 + _PANEL]
+                t = self._be.gram_f64(self.L, rp)
+                self.row_shard.all_reduce_(t, "sum")
+                t = torch.cholesky_solve(t, self._cap_chol)
+                out[:, c0:c0 + _PANEL] = self._be.woodbury_apply(self.L, rp, t, self.noise)
+                continue
+            if self._L64 is None:
+                self._L64 = self.L.double()
             rd = r[:, c0:c0 + _PANEL].double()
             t = gram64(self._L64, rd)
             self.row_shard.all_reduce_(t, "sum")

@@ -684,6 +684,53 @@ def ski_bilinear_finish(Z, gp, hist2, L, R, scale, grid_size=1024, comp=False):
     return gZ, gs, gc
 
 
+# ------------------------------------------------------------------------------- Woodbury preconditioner pieces
+
+def _rows_fp32(A, name):
+    """fp32 device matrix with unit column stride (any row stride >= columns): (tensor, leading dimension)."""
+    if A.dtype != torch.float32 or not A.is_cuda or A.dim() != 2:
+        raise TypeError("%s must be a 2-D float32 HIP tensor" % name)
+    if A.shape[1] > 1 and A.stride(1) != 1 or (A.shape[0] > 1 and A.stride(0) < A.shape[1]):
+        A = A.contiguous()
+    return A, (A.stride(0) if A.shape[0] > 1 else A.shape[1])
+
+
+def gram_f64(A, B):
+    """A^T B (K x T, float64) for tall fp32 A (N x K), B (N x T): exact products, float64 sums, fixed order
+    (rpgp_gram_f64).  K, T <= 64."""
+    lib = _lib.load()
+    A, lda = _rows_fp32(A, "A")
+    B, ldb = _rows_fp32(B, "B")
+    N, K = A.shape
+    T = B.shape[1]
+    if B.shape[0] != N or K > 64 or T > 64 or K == 0 or T == 0:
+        raise ValueError("gram_f64: N x K and N x T with 1 <= K, T <= 64 required")
+    out = torch.empty((K, T), dtype=torch.float64, device=A.device)
+    with torch.cuda.device(A.device):
+        ws = _workspace(A.device, lib.rpgp_gram_f64_workspace_bytes(K, T))
+        _lib.check(lib.rpgp_gram_f64(A.data_ptr(), lda, B.data_ptr(), ldb, N, K, T, out.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), _stream()), "rpgp_gram_f64")
+    return out
+
+
+def woodbury_apply(L, R, Tm, noise):
+    """(R - L Tm) / noise with float64 arithmetic, fp32 in and out (rpgp_woodbury_apply).  L: N x K, R: N x T, Tm: K x T
+    float64."""
+    lib = _lib.load()
+    L, ldl = _rows_fp32(L, "L")
+    R, ldr = _rows_fp32(R, "R")
+    N, K = L.shape
+    T = R.shape[1]
+    if R.shape[0] != N or tuple(Tm.shape) != (K, T) or Tm.dtype != torch.float64 or K > 64 or T > 64:
+        raise ValueError("woodbury_apply: L N x K, R N x T, Tm K x T float64 with K, T <= 64 required")
+    Tm = Tm.contiguous()
+    out = torch.empty((N, T), dtype=torch.float32, device=L.device)
+    with torch.cuda.device(L.device):
+        _lib.check(lib.rpgp_woodbury_apply(L.data_ptr(), ldl, R.data_ptr(), ldr, Tm.data_ptr(), float(noise),
+                                           out.data_ptr(), T, N, K, T, _stream()), "rpgp_woodbury_apply")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ native mBCG
 
 # ------------------------------------------------------------------------------------ generalised family

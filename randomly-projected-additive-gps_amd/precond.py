@@ -8,6 +8,8 @@ import math
 
 import torch
 
+from . import backend as _backend
+
 
 def pivoted_cholesky(diag, get_rows, max_iter):
     """Returns L (N x k) with K ~= L L^T.  `get_rows(idx)` -> dense K[idx, :].  No host syncs: a fixed number of
@@ -61,8 +63,13 @@ class WoodburyPreconditioner:
         # N = 391k), so an fp32 accumulation is off by more than sigma^2 itself (measured 0.69 against sigma^2 = 0.45) and
         # the Woodbury "inverse" stops being the inverse of M — preconditioned CG then stagnated at a true residual of
         # 0.2 - 1.4 on the C5-shaped system where un-preconditioned fp32 CG converges in 140 iterations.
-        self._L64 = L.double()
-        cap = gram64(self._L64, self._L64)
+        # On the HIP backend the two Gram products and the cancelling update are in-tree kernels on the fp32 factor
+        # (rpgp_gram_f64 / rpgp_woodbury_apply: exact products, float64 sums); otherwise float64 torch operations.
+        be = _backend.get_backend()
+        on_device = L.is_cuda or getattr(be, "name", "") != "hip-gfx950"      # (kind `full` on CPU tensors: torch path)
+        self._be = be if (L.dtype == torch.float32 and 0 < k <= 64 and hasattr(be, "gram_f64") and on_device) else None
+        self._L64c = None
+        cap = self._be.gram_f64(L, L) if self._be is not None else gram64(self._L64, self._L64)
         cap.diagonal().add_(self.noise)
         self._cap_chol = torch.linalg.cholesky(cap)                   # k x k, float64 for a stable capacitance solve
         self.N, self.k = L.shape
@@ -83,7 +90,16 @@ class WoodburyPreconditioner:
                 out[:, c0:c0 + _PANEL] = self._solve_panel(r[:, c0:c0 + _PANEL])
         return out.squeeze(-1) if squeeze else out
 
+    @property
+    def _L64(self):
+        if self._L64c is None:
+            self._L64c = self.L.double()
+        return self._L64c
+
     def _solve_panel(self, r):
+        if self._be is not None and r.dtype == torch.float32:
+            t = torch.cholesky_solve(self._be.gram_f64(self.L, r), self._cap_chol)
+            return self._be.woodbury_apply(self.L, r, t, self.noise)
         rd = r.double()
         t = torch.cholesky_solve(gram64(self._L64, rd), self._cap_chol)
         return torch.addmm(rd, self._L64, t, alpha=-1.0).div_(self.noise).to(r.dtype)     # (rd may alias r: out of place)

@@ -149,6 +149,13 @@ class OracleBackend:
         g, gc = fmo.bilinear_grad_dense(_np(Z), _np(S), fam.kind, fam.group, fam.w, scale)
         return _t(g, Z), _t(gc, Z)
 
+    # ---- Woodbury preconditioner pieces (rpgp_gram_f64 / rpgp_woodbury_apply) ---------------------------------
+    def gram_f64(self, A, B):
+        return A.double().t() @ B.double()
+
+    def woodbury_apply(self, L, R, Tm, noise):
+        return ((R.double() - L.double() @ Tm) / float(noise)).to(torch.float32)
+
     # ---- SKI path -------------------------------------------------------------------------------------------
     def ski_grid(self, Z1, Z2=None, grid_size=1024, weights=None, rule="shared"):
         J = Z1.shape[1]

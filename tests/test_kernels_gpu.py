@@ -1,4 +1,6 @@
 """GPU parity of the raw HIP kernels (through the C-ABI) against the float64 oracle."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -510,3 +512,56 @@ def test_rows_packed_prepared_mvm_matches_oracle(gpu_device, monkeypatch, N, J):
     monkeypatch.setenv("RPGP_FACT_ROWS", "0")
     out0 = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), 1.0 / J, 0.05)
     assert _rel(out.cpu().numpy(), out0.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("N,K,T", [(1, 1, 1), (7, 15, 10), (1237, 15, 11), (7372, 15, 10), (50001, 16, 64), (4099, 33, 17),
+                                   (2048, 64, 64), (300, 20, 48)])
+def test_gram_f64_and_woodbury_apply_match_float64(gpu_device, N, K, T):
+    """rpgp_gram_f64 / rpgp_woodbury_apply (the preconditioner's Gram products and cancelling update outside the executor)
+    against float64 numpy; the Gram product of fp32 inputs is exact up to float64 summation order; strided inputs."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + K + T)
+    A = rng.normal(size=(N, K)).astype(np.float32) * 3.0
+    Bw = rng.normal(size=(N, T + 5)).astype(np.float32)              # B is a column slice of a wider matrix
+    At, Bt = torch.from_numpy(A).to(gpu_device), torch.from_numpy(Bw).to(gpu_device)[:, 2:2 + T]
+    B = Bw[:, 2:2 + T]
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    got = ops.gram_f64(At, Bt).cpu().numpy()
+    assert got.shape == (K, T) and np.allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    got2 = ops.gram_f64(At, Bt).cpu().numpy()
+    assert np.array_equal(got, got2)                                  # fixed summation order
+    sym = ops.gram_f64(At, At).cpu().numpy()
+    assert np.allclose(sym, A.astype(np.float64).T @ A.astype(np.float64), rtol=1e-12, atol=1e-9)
+    Tm = rng.normal(size=(K, T))
+    noise = 0.37
+    out = ops.woodbury_apply(At, Bt, torch.from_numpy(Tm).to(gpu_device), noise).cpu().numpy()
+    want = (B.astype(np.float64) - A.astype(np.float64) @ Tm) / noise
+    assert np.allclose(out, want.astype(np.float32), rtol=2e-7, atol=1e-6 * np.abs(want).max())
+    with pytest.raises(ValueError):
+        ops.gram_f64(At, torch.zeros(N + 1, T, device=gpu_device))
+    with pytest.raises(TypeError):
+        ops.gram_f64(At.double(), Bt)
+
+
+def test_woodbury_preconditioner_uses_the_in_tree_kernels(gpu_device):
+    """precond.WoodburyPreconditioner on the HIP backend: M^-1 (M r) = r in the ill-conditioned regime of the C5 shape
+    (|L^T L| / sigma^2 ~ 1e6) and agreement with the float64 dense inverse; wide blocks go through in panels."""
+    from rpgp_amd.precond import WoodburyPreconditioner
+    rng = np.random.default_rng(0)
+    N, K = 20000, 15
+    L = (rng.normal(size=(N, K)) * np.linspace(3.0, 0.05, K)).astype(np.float32)
+    noise = 0.05
+    pre = WoodburyPreconditioner(torch.from_numpy(L).to(gpu_device), noise)
+    assert pre._be is not None and pre._L64c is None
+    L64 = L.astype(np.float64)
+    cap = noise * np.eye(K) + L64.T @ L64
+    for T in (1, 11, 130):
+        r = rng.normal(size=(N, T)).astype(np.float32)
+        want = (r - L64 @ np.linalg.solve(cap, L64.T @ r)) / noise
+        got = pre.solve(torch.from_numpy(r).to(gpu_device)).cpu().numpy()
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 5e-7
+    v = pre.solve(torch.from_numpy(r[:, 0].copy()).to(gpu_device))
+    assert v.shape == (N,)
+    ld = pre.logdet()
+    assert abs(ld - (np.linalg.slogdet(cap)[1] + (N - K) * math.log(noise))) < 1e-6 * abs(ld)
+    assert pre._L64c is None                                        # the float64 copy of L is never materialised

@@ -303,6 +303,9 @@ int rpgp_ski_bilinear_grad_comp(const float *Z, const float *grid_params, const 
 int rpgp_ski_bilinear_scatter(const float *Z, const float *grid_params, const float *L, const float *R, double *hist2,
                               int64_t N, int ldz, int J, int G, int T, void *workspace, size_t workspace_bytes,
                               void *stream);
+/* stage 1 with the points of Z taken from its plan (rpgp_ski_plan): two cell-sorted scatters, no atomics */
+int rpgp_ski_bilinear_scatter_planned(const void *plan, const float *L, const float *R, double *hist2, int64_t N, int J, int G,
+                                      int T, void *workspace, size_t workspace_bytes, void *stream);
 int rpgp_ski_bilinear_finish(const float *Z, const float *grid_params, const double *hist2, const float *L, const float *R,
                              float *gZ, float *gscale, float *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
                              float scale, void *workspace, size_t workspace_bytes, float *row_scratch, void *stream);

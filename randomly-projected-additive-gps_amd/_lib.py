@@ -72,6 +72,7 @@ SIGNATURES = {
     "rpgp_ski_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz,
                                       _vp, _vp]),
     "rpgp_ski_bilinear_scatter": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _sz, _vp]),
+    "rpgp_ski_bilinear_scatter_planned": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
     "rpgp_ski_bilinear_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32,
                                         _vp, _sz, _vp, _vp]),
     "rpgp_family_mvm_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),

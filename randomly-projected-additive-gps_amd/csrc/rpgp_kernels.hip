@@ -1903,8 +1903,17 @@ __global__ __launch_bounds__(1024) void sum_columns_kernel(const float *__restri
                                                            int ncols, float mul) {
   __shared__ float sh[1024];
   const int c = blockIdx.x;
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) acc += x[(size_t)i * ncols + c];
+  float a4[4] = {0.f, 0.f, 0.f, 0.f}, tail = 0.f;        // independent chains: the loads of four strides are in flight together
+  int i = threadIdx.x;
+  for (; i + 3 * 1024 < n; i += 4 * 1024) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x[(size_t)(i + u * 1024) * ncols + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a4[u] += v[u];
+  }
+  for (; i < n; i += 1024) tail += x[(size_t)i * ncols + c];
+  const float acc = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + tail;
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int w = 512; w > 0; w >>= 1) {
@@ -1918,8 +1927,19 @@ __global__ __launch_bounds__(1024) void sum_columns_kernel(const float *__restri
 __global__ __launch_bounds__(1024) void sum_vector_kernel(const float *__restrict__ x, float *__restrict__ out,
                                                           int n, float mul) {
   __shared__ float sh[1024];
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) acc += x[i];
+  // eight independent partial sums per thread (a single dependent chain of n / 1024 loads took 98 us at n = 391k); fixed order
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] += v[u];
+  }
+  float tail = 0.f;
+  for (; i < n; i += 1024) tail += x[i];
+  const float acc = (((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]))) + tail;
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int w = 512; w > 0; w >>= 1) {
@@ -2255,13 +2275,19 @@ __global__ __launch_bounds__(256) void ski_minmax_kernel(const float *__restrict
   }
 }
 
-__global__ void ski_grid_finish_kernel(const float *__restrict__ part, int nparts, int G, float *__restrict__ gp) {
-  if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(64) void ski_grid_finish_kernel(const float *__restrict__ part, int nparts, int G,
+                                                             float *__restrict__ gp) {
+  // one wave: strided partial extrema, then a shuffle reduction (a single thread walking ~1000 partials took 47 us)
   float mn = 3.4e38f, mx = -3.4e38f;
-  for (int p = 0; p < nparts; ++p) {
+  for (int p = threadIdx.x; p < nparts; p += 64) {
     mn = min_nan(mn, part[2 * p]);
     mx = max_nan(mx, part[2 * p + 1]);
   }
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min_nan(mn, __shfl_xor(mn, off));
+    mx = max_nan(mx, __shfl_xor(mx, off));
+  }
+  if (threadIdx.x != 0) return;
   float range = mx - mn;
   if (!(range > 1e-12f)) range = 1e-12f;          // all points identical (or NaN -> propagates through h)
   const float h = (mx - mn == mx - mn) ? range / (float)(G - 5) : (mx - mn);
@@ -2303,19 +2329,24 @@ __global__ __launch_bounds__(256) void ski_minmax_proj_kernel(const float *__res
   }
 }
 
-__global__ void ski_grid_finish_proj_kernel(const float *__restrict__ part, int nparts, int J, int G,
-                                            float *__restrict__ gp) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j == 0) {
+__global__ __launch_bounds__(64) void ski_grid_finish_proj_kernel(const float *__restrict__ part, int nparts, int J, int G,
+                                                                  float *__restrict__ gp) {
+  // one wave per projection: strided partial extrema + shuffle reduction
+  const int j = blockIdx.x;
+  if (j == 0 && threadIdx.x == 0) {
     gp[0] = 0.f; gp[1] = 1.f; gp[2] = 1.f;      // (unused with per-projection grids)
     gp[3] = 2.f;                                // flags: per-projection grids, no weights
   }
-  if (j >= J) return;
   float mn = 3.4e38f, mx = -3.4e38f;
-  for (int p = 0; p < nparts; ++p) {
+  for (int p = threadIdx.x; p < nparts; p += 64) {
     mn = min_nan(mn, part[2 * ((size_t)j * nparts + p)]);
     mx = max_nan(mx, part[2 * ((size_t)j * nparts + p) + 1]);
   }
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min_nan(mn, __shfl_xor(mn, off));
+    mx = max_nan(mx, __shfl_xor(mx, off));
+  }
+  if (threadIdx.x != 0) return;
   float range = mx - mn;
   if (!(range > 1e-12f)) range = 1e-12f;
   const bool finite = (mx - mn == mx - mn);
@@ -2538,7 +2569,7 @@ __global__ __launch_bounds__(256) void ski_toeplitz_kernel(const HT_ *__restrict
   }
 }
 
-// Toeplitz product on the matrix cores for T <= 16, in float64: H_j (G x T) = Toep(G x G) @ hist_j (G x T) as 16 x 16
+// Toeplitz product on the matrix cores (16 right-hand sides per workgroup, T <= 64), in float64: H_j (G x T) = Toep(G x G) @ hist_j (G x T) as 16 x 16
 // output tiles, v_mfma_f64_16x16x4_f64 over the G grid points (K = 4 per issue).  One wave per 16-row tile, four tiles
 // per workgroup; hist_j is staged through LDS in panels of 512 grid rows; the Toeplitz entry sc[|m - k|] is read from LDS.
 //   A (16x4): lane l holds Toep[m0 + l%16][k0 + l/16]     B (4x16): lane l holds hist_j[k0 + l/16][l%16]
@@ -2569,7 +2600,7 @@ __global__ __launch_bounds__(64 * NW) void ski_toeplitz_mfma_kernel(const double
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
   const int mrow = m0 + (lane & 15), q = lane >> 4;
-  const int nb = lane & 15;
+  const int nb = 16 * blockIdx.z + (lane & 15);      // blockIdx.z: 16-column block of the right-hand sides (T > 16)
   const int nbc = nb < T ? nb : T - 1;               // clamped column: every load below is unconditional
   const double bmask = nb < T ? 1.0 : 0.0;
   const double amask = (mrow < G) ? 1.0 : 0.0;
@@ -4659,8 +4690,8 @@ int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H
   const bool wide_wg = (size_t)J * ((G + 15) / 16) <= 640 && G16 >= 256;
   const int nw = wide_wg ? 16 : 4;
   const size_t lds = ((size_t)G16 + (size_t)(nw - 1) * 256) * sizeof(double);
-  if (hist_is_double && T <= 16 && lds <= 64 * 1024) {        // matrix-core path, float64
-    dim3 grid((G + 15) / 16, J);
+  if (hist_is_double && T <= 64 && lds <= 64 * 1024) {        // matrix-core path, float64 (16 columns per workgroup)
+    dim3 grid((G + 15) / 16, J, (T + 15) / 16);
     if (wide_wg)
       hipLaunchKernelGGL(ski_toeplitz_mfma_kernel<16>, grid, dim3(1024), lds, st, reinterpret_cast<const double *>(hist), gp,
                          H, G, T, tcol);
@@ -4764,7 +4795,7 @@ int rpgp_ski_grid_per_projection(const float *Z1, int64_t N1, int ld1, const flo
   float *part = reinterpret_cast<float *>(workspace);
   hipLaunchKernelGGL(ski_minmax_proj_kernel, dim3((unsigned)nblk, (unsigned)J), dim3(256), 0, st, Z1, (long long)N1, ld1,
                      Z2 ? Z2 : Z1, n2, Z2 ? ld2 : ld1, J, part);
-  hipLaunchKernelGGL(ski_grid_finish_proj_kernel, dim3((unsigned)((J + 63) / 64)), dim3(64), 0, st, part, nblk, J, G,
+  hipLaunchKernelGGL(ski_grid_finish_proj_kernel, dim3((unsigned)J), dim3(64), 0, st, part, nblk, J, G,
                      grid_params);
   return launch_status();
 }

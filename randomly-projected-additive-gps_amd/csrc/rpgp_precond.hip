@@ -31,10 +31,12 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restri
   __shared__ double sred[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  // two accumulator sets (even / odd steps): consecutive matrix instructions never chain on one accumulator
-  doublex4p acc[2][MA][NB];
+  // kU accumulator sets (steps s, s + nwaves, ...): consecutive matrix instructions never chain on one accumulator, and
+  // the loads of kU steps are in flight together
+  constexpr int kU = (MA * NB <= 2) ? 4 : 2;
+  doublex4p acc[kU][MA][NB];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < kU; ++u)
 #pragma unroll
     for (int a = 0; a < MA; ++a)
 #pragma unroll
@@ -42,29 +44,42 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restri
   const long long nwaves = (long long)gridDim.x * 4;
   const long long w = (long long)blockIdx.x * 4 + wave;
   const long long nsteps = (N + 3) / 4;
-  for (long long s = w; s < nsteps; s += 2 * nwaves) {
+  for (long long s = w; s < nsteps; s += kU * nwaves) {
+    float af[kU][MA], bf[kU][NB];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kU; ++u) {
+      // clamped row + select: a load under a condition compiles to a branch with its own wait
       const long long n = 4 * (s + u * nwaves) + q;
-      const bool rv = n < N && (s + u * nwaves) < nsteps;
-      double av[MA], bv[NB];
+      const bool rv = n < N;
+      const long long nc = rv ? n : N - 1;
 #pragma unroll
-      for (int a = 0; a < MA; ++a) av[a] = (rv && 16 * a + c < K) ? (double)A[n * lda + 16 * a + c] : 0.0;
+      for (int a = 0; a < MA; ++a) {
+        const int col = 16 * a + c;
+        const float v = A[nc * lda + (col < K ? col : K - 1)];
+        af[u][a] = (rv && col < K) ? v : 0.f;
+      }
 #pragma unroll
-      for (int b = 0; b < NB; ++b) bv[b] = (rv && 16 * b + c < T) ? (double)B[n * ldb + 16 * b + c] : 0.0;
+      for (int b = 0; b < NB; ++b) {
+        const int col = 16 * b + c;
+        const float v = B[nc * ldb + (col < T ? col : T - 1)];
+        bf[u][b] = (rv && col < T) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
 #pragma unroll
       for (int a = 0; a < MA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          acc[u][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[u][a][b], 0, 0, 0);
-    }
+          acc[u][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)af[u][a], (double)bf[u][b], acc[u][a][b], 0, 0, 0);
   }
   // workgroup sum (waves in order), then one slab per workgroup: part[blockIdx][tile][r][lane]
 #pragma unroll
   for (int a = 0; a < MA; ++a)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const doublex4p v = acc[0][a][b] + acc[1][a][b];
+      doublex4p v = acc[0][a][b] + acc[1][a][b];
+      if constexpr (kU == 4) v = v + (acc[2][a][b] + acc[3][a][b]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         __syncthreads();
@@ -78,19 +93,39 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restri
     }
 }
 
-// out[i][j] = sum over the workgroups' slabs, in slab order
-__global__ __launch_bounds__(256) void gram_finish_kernel(const double *__restrict__ part, int nparts, int MA, int NB, int K,
-                                                          int T, double *__restrict__ out, float *__restrict__ out32) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= K * T) return;
-  const int i = e / T, j = e % T;
-  const int a = i >> 4, b = j >> 4, q = (i & 15) & 3, r = (i & 15) >> 2, c = j & 15;      // i % 16 = q + 4 r
-  const size_t off = ((size_t)(a * NB + b) * 4 + r) * 64 + (q * 16 + c);
+// One workgroup of 1024 threads per 16 x 16 tile: thread (quarter, position) sums its quarter of the slabs for one of the
+// 256 result positions (coalesced across positions, 8 independent loads in flight), the quarters are combined in order
+// through LDS.  (First version: one thread per output element walking all 512 slabs — 122 us at the C5 shape.)
+__global__ __launch_bounds__(1024) void gram_finish_kernel(const double *__restrict__ part, int nparts, int MA, int NB, int K,
+                                                           int T, double *__restrict__ out, float *__restrict__ out32) {
+  __shared__ double sq[4][256];
+  const int tile = blockIdx.x, pos = threadIdx.x & 255, quarter = threadIdx.x >> 8;
   const size_t stride = (size_t)MA * NB * 256;
+  const int per = (nparts + 3) / 4;
+  const int p0 = quarter * per, p1 = min(nparts, p0 + per);
+  const double *src = part + (size_t)tile * 256 + pos;
   double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + off];
-  if (out) out[e] = s;
-  if (out32) out32[e] = (float)s;
+  int p = p0;
+  for (; p + 7 < p1; p += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(p + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < p1; ++p) s += src[(size_t)p * stride];
+  sq[quarter][pos] = s;
+  __syncthreads();
+  if (quarter == 0) {
+    const double sum = ((sq[0][pos] + sq[1][pos]) + sq[2][pos]) + sq[3][pos];
+    // position = r * 64 + lane, lane = q * 16 + c: result element (16 a + q + 4 r, 16 b + c)
+    const int a = tile / NB, b = tile % NB, r = pos >> 6, q = (pos & 63) >> 4, c = pos & 15;
+    const int i = 16 * a + q + 4 * r, j = 16 * b + c;
+    if (i < K && j < T) {
+      if (out) out[i * T + j] = sum;
+      if (out32) out32[i * T + j] = (float)sum;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void woodbury_apply_kernel(const float *__restrict__ L, long long ldl,
@@ -146,7 +181,7 @@ int gram_launch(const float *A, long long lda, const float *B, long long ldb, lo
   RPGP_GRAM_CASE(2, 1); RPGP_GRAM_CASE(2, 2); RPGP_GRAM_CASE(2, 4);
   RPGP_GRAM_CASE(4, 1); RPGP_GRAM_CASE(4, 2); RPGP_GRAM_CASE(4, 4);
 #undef RPGP_GRAM_CASE
-  hipLaunchKernelGGL(gram_finish_kernel, dim3((K * T + 255) / 256), dim3(256), 0, st, part, g, ma, nb, K, T, out64, out32);
+  hipLaunchKernelGGL(gram_finish_kernel, dim3(ma * nb), dim3(1024), 0, st, part, g, ma, nb, K, T, out64, out32);
   return (int)hipGetLastError();
 }
 

@@ -481,6 +481,20 @@ int rpgp_ski_scatter_planned(const void *plan, const float *V, double *hist, int
   return scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
+int rpgp_ski_bilinear_scatter_planned(const void *plan, const float *L, const float *R, double *hist2, int64_t N, int J, int G,
+                                      int T, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!plan || !L || !R || !hist2 || !plan_args_ok(N, J, G) || T <= 0 || T > 12) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
+  if ((size_t)max_items(N, J, G) * 48 > rpgp_internal::ski_scratch_floats(J, G)) return RPGP_EWORKSPACE;
+  const PlanView pv = plan_view(const_cast<void *>(plan), N, J, G);
+  float *partial = reinterpret_cast<float *>(workspace) + rpgp_internal::ski_scratch_offset_floats(J, G, T);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // two cell-sorted scatters into column offsets 0 and T of the [J][G][2T] histogram
+  int rc = scatter_planned(pv, L, hist2, partial, N, J, G, T, 2 * T, 0, st);
+  if (rc) return rc;
+  return scatter_planned(pv, R, hist2, partial, N, J, G, T, 2 * T, T, st);
+}
+
 int rpgp_ski_mvm_planned(const void *plan, const float *Z, const float *grid_params, const float *V, float *out, int64_t N,
                          int ldz, int J, int G, int T, float scale, float noise, void *workspace, size_t workspace_bytes,
                          void *stream) {

@@ -390,7 +390,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         for t0 in range(0, left_local.shape[1], 12):
             Lc = left_local[:, t0:t0 + 12].detach().contiguous()
             Rc = right_local[:, t0:t0 + 12].detach().contiguous()
-            hist = be.ski_bilinear_scatter(Zl, self.gp, Lc, Rc, self.grid_size)
+            hist = be.ski_bilinear_scatter(Zl, self.gp, Lc, Rc, self.grid_size)      # (the rows' own plan lives in the row-sharded operator)
             rs.all_reduce_(hist, "sum")
             gzl, gs, gc = be.ski_bilinear_finish(Zl, self.gp, hist, Lc, Rc, self._scale, self.grid_size, comp=comp)
             gZ[rs.r0:rs.r1] += gzl
@@ -441,6 +441,26 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         if not self.symmetric:
             raise NotImplementedError("derivatives are only needed for the train-train kernel")
         be = _backend.get_backend()
+        plan = self._get_plan()
+        if plan is not None and hasattr(be, "ski_bilinear_scatter"):
+            # staged form on the operator's plan: cell-sorted scatters of L and R (no atomics), the 2T-column Toeplitz product
+            # on the matrix cores, then the per-row derivative — 12 columns per piece
+            z = self.Z1.detach()
+            comp = self.comp_weights is not None
+            gZ = gs = gc = None
+            for t0 in range(0, left_vecs.shape[1], 12):
+                Lc = left_vecs[:, t0:t0 + 12].detach().contiguous()
+                Rc = right_vecs[:, t0:t0 + 12].detach().contiguous()
+                hist = be.ski_bilinear_scatter(z, self.gp, Lc, Rc, self.grid_size, plan=plan)
+                gz_p, gs_p, gc_p = be.ski_bilinear_finish(z, self.gp, hist, Lc, Rc, self._scale, self.grid_size, comp=comp)
+                gZ = gz_p if gZ is None else gZ.add_(gz_p)
+                gs = gs_p if gs is None else gs.add_(gs_p)
+                if comp:
+                    gc = gc_p if gc is None else gc.add_(gc_p)
+            if comp:
+                w = self.comp_weights.detach().to(gc)
+                return gZ, gs * self.weight, self._scale * gc / w
+            return gZ, gs * self.weight
         if self.comp_weights is not None:
             gZ, gs, gc = be.ski_bilinear_grad_comp(self.Z1.detach(), self.gp, left_vecs.detach(), right_vecs.detach(),
                                                    self._scale, self.grid_size)

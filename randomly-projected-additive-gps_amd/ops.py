@@ -638,9 +638,9 @@ def ski_bilinear_grad_comp(Z, gp, L, R, scale, grid_size=1024):
     return gZ, gs, gc
 
 
-def ski_bilinear_scatter(Z, gp, L, R, grid_size=1024):
-    """Stage 1 of the row-sharded SKI derivative: hist2 (J x G x 2T float64) = [W^T L | W^T R] over the rows of Z
-    (T <= 12; zeros for an empty row block)."""
+def ski_bilinear_scatter(Z, gp, L, R, grid_size=1024, plan=None):
+    """Stage 1 of the SKI derivative: hist2 (J x G x 2T float64) = [W^T L | W^T R] over the rows of Z (T <= 12; zeros for
+    an empty row block).  With the plan of Z the scatters are the cell-sorted, atomics-free ones of the planned product."""
     lib = _lib.load()
     N, J = Z.shape
     T = L.shape[1]
@@ -652,6 +652,14 @@ def ski_bilinear_scatter(Z, gp, L, R, grid_size=1024):
     Z = _require(Z, "Z", 2)
     L2, _ = _as_matrix(L, N, "L")
     R2, _ = _as_matrix(R, N, "R")
+    if plan is not None and plan.ok and plan.N == N and plan.J == J and plan.G == grid_size:
+        with torch.cuda.device(Z.device):
+            ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
+            rc = lib.rpgp_ski_bilinear_scatter_planned(plan.buf.data_ptr(), L2.data_ptr(), R2.data_ptr(), hist.data_ptr(), N,
+                                                       J, grid_size, T, ws.data_ptr(), ws.numel(), _stream())
+        if rc != _lib.RPGP_EWORKSPACE:
+            _lib.check(rc, "rpgp_ski_bilinear_scatter_planned")
+            return hist
     with torch.cuda.device(Z.device):
         ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
         _lib.check(lib.rpgp_ski_bilinear_scatter(Z.data_ptr(), gp.data_ptr(), L2.data_ptr(), R2.data_ptr(), hist.data_ptr(),

@@ -272,7 +272,7 @@ class OracleBackend:
         return gZ, gs, _t(self._last_comp.copy(), Z)
 
     # ---- staged derivative of the row-sharded SKI operator: scatter -> all-reduce -> finish ---------------------------
-    def ski_bilinear_scatter(self, Z, gp, L, R, grid_size=1024):
+    def ski_bilinear_scatter(self, Z, gp, L, R, grid_size=1024, plan=None):
         z = _np(Z)
         Ld, Rd = _np(L).reshape(z.shape[0], -1), _np(R).reshape(z.shape[0], -1)
         grid = self._grid(gp)

@@ -475,3 +475,50 @@ def test_reference_grid_rule_is_the_default_of_the_rp_poly_ski_kinds(gpu_device)
         v = torch.randn(1500, 3, generator=g).to(gpu_device)
         a, b = op._matmul(v), exact.covar_module(X)._matmul(v)
         assert float((a - b).norm() / b.norm()) < 2e-4, kind
+
+
+@pytest.mark.parametrize("N,J,T,G,rule,weighted", [(5000, 3, 11, 1024, "shared", False), (3001, 20, 23, 256, "reference", True),
+                                                    (777, 5, 1, 64, "reference", False)])
+def test_planned_bilinear_derivative_matches_the_fused_one(gpu_device, N, J, T, G, rule, weighted):
+    """SKIAdditiveOperator._bilinear_derivative on its plan (cell-sorted scatters of L and R, 2T-column Toeplitz product on
+    the matrix cores, per-row finish) against the fused rpgp_ski_bilinear_grad[_comp] entry point (itself oracle-checked
+    above), including more than 12 columns and both grid rules; the staged histogram equals the unplanned one."""
+    from rpgp_amd import ops
+    from rpgp_amd.operators import SKIAdditiveOperator
+    rng = np.random.default_rng(N + T)
+    Z = torch.from_numpy(rng.normal(size=(N, J)).astype(np.float32)).to(gpu_device)
+    L = torch.from_numpy(rng.normal(size=(N, T)).astype(np.float32)).to(gpu_device)
+    R = torch.from_numpy(rng.normal(size=(N, T)).astype(np.float32)).to(gpu_device)
+    w = torch.from_numpy(rng.uniform(0.4, 1.3, size=J).astype(np.float32)).to(gpu_device) if weighted else None
+    s = torch.tensor(0.7, device=gpu_device)
+    op = SKIAdditiveOperator(Z, None, s, 1.0, grid_size=G, comp_weights=w, grid_rule=rule)
+    plan = op._get_plan()
+    assert plan is not None
+    got = op._bilinear_derivative(L, R)
+    if weighted:
+        gZ, gs, gc = ops.ski_bilinear_grad_comp(Z, op.gp, L, R, 0.7, G)
+        want = (gZ, gs, 0.7 * gc / w)
+    else:
+        want = ops.ski_bilinear_grad(Z, op.gp, L, R, 0.7, G)
+    assert len(got) == len(want)
+    # (the unplanned scatter accumulates in fixed point in LDS, the planned one sums exactly: the two agree to ~3e-5)
+    for a, b in zip(got, want):
+        a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+        assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-30)
+    if N < 1000:            # float64 oracle: d/dscale = objective / scale, d/dZ by central differences on a fixed grid
+        Zh, Lh, Rh = Z.cpu().numpy(), L.cpu().numpy(), R.cpu().numpy()
+        gph = op.gp.cpu().numpy().astype(np.float64)
+        grid = (gph[4 + J:4 + J + 3 * J:3], gph[5 + J:4 + J + 3 * J:3]) if rule == "reference" else (float(gph[0]), float(gph[1]))
+        obj = sko.bilinear_objective(Zh, Lh, Rh, 0.7, G, grid)
+        assert abs(float(got[1]) - obj / 0.7) < 2e-4 * abs(obj / 0.7) + 2e-4 * (np.abs(Lh).sum() * np.abs(Rh).sum() / N) ** 0.5
+        gz = got[0].cpu().numpy()
+        for (i, j) in [(0, 0), (N // 2, J - 1), (N - 1, 1)]:
+            Zp, Zm = Zh.astype(np.float64).copy(), Zh.astype(np.float64).copy()
+            Zp[i, j] += 1e-4
+            Zm[i, j] -= 1e-4
+            fd = (sko.bilinear_objective(Zp, Lh, Rh, 0.7, G, grid) - sko.bilinear_objective(Zm, Lh, Rh, 0.7, G, grid)) / 2e-4
+            assert abs(gz[i, j] - fd) < 2e-3 * np.abs(gz).max() + 2e-3 * abs(fd)
+    Lc, Rc = L[:, :min(T, 12)].contiguous(), R[:, :min(T, 12)].contiguous()
+    h_plan = ops.ski_bilinear_scatter(Z, op.gp, Lc, Rc, G, plan=plan).cpu().numpy()
+    h_ref = ops.ski_bilinear_scatter(Z, op.gp, Lc, Rc, G).cpu().numpy()
+    assert np.linalg.norm(h_plan - h_ref) <= 1e-6 * np.linalg.norm(h_ref)

@@ -297,6 +297,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         super().__init__(Z1, Z2, outputscale, weight, shard=None)     # (no J-sharding: the SKI product is O(N))
         self.grid_size = int(grid_size)
         self._plan = None
+        self._local_plan = None       # plan of this rank's rows (row-sharded solve + derivative)
         # Multi-GPU: the N training rows are split over the ranks (distributed.RowShard).  The operator itself keeps the
         # replicated interface (full Z, full vectors: prediction and the generic call sites are unchanged); the solves of
         # the marginal likelihood and of the mean cache run on `row_sharded(noise)` — every rank scatters / gathers ITS rows.
@@ -366,14 +367,29 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         t = SKIAdditiveOperator.__new__(SKIAdditiveOperator)
         AdditiveRPOperator.__init__(t, self.Z2, self.Z1, self.outputscale, self.weight, None)
         t.grid_size, t.gp, t.comp_weights, t.row_shard, t._plan = self.grid_size, self.gp, self.comp_weights, None, None
+        t._local_plan = None
         t.grid_rule = self.grid_rule
         return t
 
     def row_sharded(self, noise):
         """This rank's rows of (self + noise I) as a RowShardedSKIOperator on the SAME grid block (and weights)."""
         rs = self.row_shard
-        return RowShardedSKIOperator(self.Z1.detach()[rs.r0:rs.r1], self._scale, 1.0, rs, grid_size=self.grid_size,
-                                     noise=noise, gp=self.gp)
+        op = RowShardedSKIOperator(self.Z1.detach()[rs.r0:rs.r1], self._scale, 1.0, rs, grid_size=self.grid_size,
+                                   noise=noise, gp=self.gp)
+        # one plan of the local rows per hyper-parameter step, shared by the forward solve and the derivative
+        if self._local_plan is None:
+            self._local_plan = op._get_plan()
+        else:
+            op._plan = self._local_plan
+        return op
+
+    def _get_local_plan(self, Zl):
+        be = _backend.get_backend()
+        if not hasattr(be, "ski_plan") or Zl.dtype != torch.float32 or Zl.shape[0] == 0:
+            return None
+        if self._local_plan is None:
+            self._local_plan = be.ski_plan(Zl, self.gp, self.grid_size)
+        return self._local_plan if self._local_plan.ok else None
 
     def row_sharded_bilinear_derivative(self, left_local, right_local):
         """`_bilinear_derivative` with the vectors given as this rank's rows: per 12-column piece the 2T-column grid
@@ -390,7 +406,9 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         for t0 in range(0, left_local.shape[1], 12):
             Lc = left_local[:, t0:t0 + 12].detach().contiguous()
             Rc = right_local[:, t0:t0 + 12].detach().contiguous()
-            hist = be.ski_bilinear_scatter(Zl, self.gp, Lc, Rc, self.grid_size)      # (the rows' own plan lives in the row-sharded operator)
+            lplan = self._get_local_plan(Zl)            # cell-sorted scatters of the local rows (same sums as one process)
+            hist = be.ski_bilinear_scatter(Zl, self.gp, Lc, Rc, self.grid_size, plan=lplan) if lplan is not None else \
+                be.ski_bilinear_scatter(Zl, self.gp, Lc, Rc, self.grid_size)
             rs.all_reduce_(hist, "sum")
             gzl, gs, gc = be.ski_bilinear_finish(Zl, self.gp, hist, Lc, Rc, self._scale, self.grid_size, comp=comp)
             gZ[rs.r0:rs.r1] += gzl

@@ -1301,13 +1301,36 @@ __global__ __launch_bounds__(256, 2) void symk_mvm_tile_kernel(const float4v *__
   float4v ring[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) ring[d] = __builtin_nontemporal_load(wp + (size_t)d * 64);
+  // The subtile's 64 x 16 right-hand-side block is requested ONE SUBTILE AHEAD into four registers per thread, from clamped
+  // addresses (no load under a condition).  The first version loaded it at the head of its subtile inside a rolled loop whose
+  // conditional load compiled to `global_load; s_waitcnt vmcnt(0); ds_write` — four serial round trips per subtile, each of
+  // which also drained the eight tiles of the ring (933 -> 900-915 us at C4).
+  // Also measured in round 3 and NOT kept (all parity-green): a 32-tile register ring at one wave per SIMD (431 registers):
+  // 1.08 ms; the ring in LDS filled by `global_load_lds_dwordx4` (11-13 slots per wave, hand-counted `s_waitcnt vmcnt`, the
+  // right-hand sides by DMA too, XOR-swizzled slot image read conflict-free in both operand orders, no scratch transposition):
+  // 0.98 ms against 0.94 ms for this kernel in the same run — more bytes in flight do not buy bandwidth here.
+  float vpre[4];
+  auto v_request = [&](int c0n) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + 256 * it;
+      const int c = e >> 4, t = e & 15;
+      const int col = c0n + c;
+      const int colc = col < N ? col : N - 1;
+      const int tc = t < tcnt ? t : 0;
+      vpre[it] = V[(size_t)colc * ldv + t0 + tc];        // (selected against the padding when it is written to LDS:
+    }                                                   //  a select next to the load is turned back into a branch + wait)
+  };
+  v_request(c_begin);
   for (int c0 = c_begin; c0 < c_end; c0 += 64, wp += SUB) {
     __syncthreads();
-    for (int e = tid; e < 64 * 16; e += 256) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + 256 * it;
       const int c = e >> 4, t = e & 15;
-      const int col = c0 + c;
-      sV[c * SVS + t] = (col < c_end && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+      sV[c * SVS + t] = (c0 + c < c_end && t < tcnt) ? vpre[it] : 0.f;
     }
+    v_request(c0 + 64 < c_end ? c0 + 64 : c0);          // (last subtile: a harmless re-request keeps the loop branch-free)
     __syncthreads();
     float acol[4][4];                               // A operands of the row product: V[c0 + 16 ct + 4 kap + i][t = tn]
 #pragma unroll

@@ -1004,13 +1004,23 @@ __global__ __launch_bounds__(256) void symk_mvm_kernel(const float4v *__restrict
     for (int r = 0; r < R; ++r) ring[d][r] = __builtin_nontemporal_load(q + r * 64);
   }
   int n = 0;
+  // the stage's right-hand sides are requested one stage ahead, from clamped addresses (a load under a condition compiles to
+  // a branch with `s_waitcnt vmcnt(0)` behind it, which drains the ring at the head of every stage)
+  float vpre[TT];
+  auto v_request = [&](int c0n) {
+    const int col = c0n + (tid < SC ? tid : 0);
+    const int colc = col < N ? col : N - 1;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) vpre[t] = V[(size_t)colc * ldv + t0 + (t < tcnt ? t : 0)];
+  };
+  v_request(c_begin);
   for (int c0 = c_begin; c0 < c_end; c0 += SC) {
     __syncthreads();
     if (tid < SC) {
-      const int col = c0 + tid;
 #pragma unroll
-      for (int t = 0; t < TT; ++t) sV[tid * TT + t] = (col < c_end && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+      for (int t = 0; t < TT; ++t) sV[tid * TT + t] = (c0 + tid < c_end && t < tcnt) ? vpre[t] : 0.f;
     }
+    v_request(c0 + SC < c_end ? c0 + SC : c0);
     __syncthreads();
     const int ncol = c_end - c0;
     const int nsub = ncol >= SC ? SC / 64 : (ncol + 63) / 64;

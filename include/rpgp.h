@@ -454,6 +454,9 @@ int rpgp_gram_f64(const float *A, int64_t lda, const float *B, int64_t ldb, int6
                   void *workspace, size_t workspace_bytes, void *stream);
 int rpgp_woodbury_apply(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *Tm, double noise,
                         float *out, int64_t ldo, int64_t N, int K, int T, void *stream);
+/* One launch for the K x K capacitance matrix C = gram + noise I (gram = L^T L, row-major float64, K <= 64): chol = its lower
+ * Cholesky factor, cinv = C^-1, logdet[0] = log|C| (all float64, device).  A non-positive pivot fills the outputs with NaN. */
+int rpgp_woodbury_setup(const double *gram, double noise, int K, double *chol, double *cinv, double *logdet, void *stream);
 
 /*
  * Float64 variants for `--double` (training_routines.py:481).  Same contracts as the fp32 entry points of the same

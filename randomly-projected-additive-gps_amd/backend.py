@@ -47,6 +47,7 @@ class HipBackend:
     family_pivoted_cholesky = staticmethod(ops.family_pivoted_cholesky)
     gram_f64 = staticmethod(ops.gram_f64)
     woodbury_apply = staticmethod(ops.woodbury_apply)
+    woodbury_setup = staticmethod(ops.woodbury_setup)
     make_operator_desc = staticmethod(ops.make_operator_desc)
     mbcg_solve = staticmethod(ops.mbcg_solve)
 

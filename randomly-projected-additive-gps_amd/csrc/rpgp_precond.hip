@@ -147,6 +147,62 @@ __global__ __launch_bounds__(256) void woodbury_apply_kernel(const float *__rest
   }
 }
 
+// Capacitance matrix of the Woodbury preconditioner in ONE launch (K <= 64, one workgroup): C = G + noise I (G = L^T L
+// from rpgp_gram_f64), its lower Cholesky factor, C^-1 and log|C|.  Replaces a diagonal add, the library's potrf (+ info
+// check = a device synchronisation), log / sum and potri: ~15 launches of 15 x 15 float64 work per optimiser step.
+// A non-positive pivot writes NaN into everything (the caller checks log|C| where it synchronises anyway).
+__global__ __launch_bounds__(256) void woodbury_setup_kernel(const double *__restrict__ G, double noise, int K,
+                                                             double *__restrict__ chol, double *__restrict__ cinv,
+                                                             double *__restrict__ logdet) {
+  __shared__ double sA[64 * 65];      // C, then its Cholesky factor (lower), row stride 65
+  __shared__ double sI[64 * 65];      // inverse of the factor (lower)
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  for (int e = tid; e < K * K; e += 256) {
+    const int i = e / K, j = e % K;
+    sA[i * 65 + j] = G[e] + (i == j ? noise : 0.0);
+  }
+  __syncthreads();
+  // right-looking Cholesky: column k scaled by thread group, trailing update in parallel
+  for (int k = 0; k < K; ++k) {
+    const double d = sA[k * 65 + k];
+    if (tid == 0 && !(d > 0.0)) bad = 1;
+    __syncthreads();
+    const double r = sqrt(d);
+    for (int i = k + tid; i < K; i += 256) sA[i * 65 + k] = (i == k) ? r : sA[i * 65 + k] / r;
+    __syncthreads();
+    for (int e = tid; e < (K - k - 1) * (K - k - 1); e += 256) {
+      const int i = k + 1 + e / (K - k - 1), j = k + 1 + e % (K - k - 1);
+      if (j <= i) sA[i * 65 + j] -= sA[i * 65 + k] * sA[j * 65 + k];
+    }
+    __syncthreads();
+  }
+  // inverse of the lower factor, one column per thread (forward substitution)
+  if (tid < K) {
+    const int c = tid;
+    for (int i = 0; i < K; ++i) {
+      double v = (i == c) ? 1.0 : 0.0;
+      for (int m = c; m < i; ++m) v -= sA[i * 65 + m] * sI[m * 65 + c];
+      sI[i * 65 + c] = (i < c) ? 0.0 : v / sA[i * 65 + i];
+    }
+  }
+  __syncthreads();
+  const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+  for (int e = tid; e < K * K; e += 256) {
+    const int i = e / K, j = e % K;
+    double acc = 0.0;                                   // C^-1 = Linv^T Linv
+    for (int m = (i > j ? i : j); m < K; ++m) acc += sI[m * 65 + i] * sI[m * 65 + j];
+    cinv[e] = bad ? nanv : acc;
+    chol[e] = bad ? nanv : (j <= i ? sA[i * 65 + j] : 0.0);
+  }
+  if (tid == 0) {
+    double ld = 0.0;
+    for (int i = 0; i < K; ++i) ld += log(sA[i * 65 + i]);
+    logdet[0] = bad ? nanv : 2.0 * ld;
+  }
+}
+
 inline int tiles16(int n) { return (n + 15) / 16; }
 inline int gram_blocks(long long N) {
   long long g = (N + 255) / 256;
@@ -197,6 +253,13 @@ int rpgp_gram_f64(const float *A, int64_t lda, const float *B, int64_t ldb, int6
   if (!workspace || workspace_bytes < rpgp_gram_f64_workspace_bytes(K, T)) return RPGP_EWORKSPACE;
   return rpgp_internal::gram_launch(A, (long long)lda, B, (long long)ldb, (long long)N, K, T, out, nullptr,
                                     reinterpret_cast<double *>(workspace), reinterpret_cast<hipStream_t>(stream));
+}
+
+int rpgp_woodbury_setup(const double *gram, double noise, int K, double *chol, double *cinv, double *logdet, void *stream) {
+  if (!gram || !chol || !cinv || !logdet || K <= 0 || K > 64 || !(noise > 0.0)) return RPGP_EINVAL;
+  hipLaunchKernelGGL(woodbury_setup_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gram, noise, K,
+                     chol, cinv, logdet);
+  return (int)hipGetLastError();
 }
 
 int rpgp_woodbury_apply(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *Tm, double noise,

@@ -614,8 +614,12 @@ class RowShardedWoodbury:
         self._L64 = L_local.double() if self._be is None else None
         cap = self._be.gram_f64(L_local, L_local) if self._be is not None else gram64(self._L64, self._L64)
         row_shard.all_reduce_(cap, "sum")
-        cap.diagonal().add_(self.noise)
-        self._cap_chol = torch.linalg.cholesky(cap)
+        self._cinv = self._logdet_cap = None
+        if hasattr(be, "woodbury_setup") and on_device and cap.shape[0] <= 64:
+            self._cap_chol, self._cinv, self._logdet_cap = be.woodbury_setup(cap, self.noise)   # one launch, no sync
+        else:
+            cap.diagonal().add_(self.noise)
+            self._cap_chol = torch.linalg.cholesky(cap)
 
     def solve(self, r):
         """(r - L C^-1 L^T r) / noise on the local rows.  As in precond.WoodburyPreconditioner.solve the subtraction
@@ -631,7 +635,7 @@ class RowShardedWoodbury:
                 rp = r[:, c0:c0 + _PANEL]
                 t = self._be.gram_f64(self.L, rp)
                 self.row_shard.all_reduce_(t, "sum")
-                t = torch.cholesky_solve(t, self._cap_chol)
+                t = self._cinv @ t if self._cinv is not None else torch.cholesky_solve(t, self._cap_chol)
                 out[:, c0:c0 + _PANEL] = self._be.woodbury_apply(self.L, rp, t, self.noise)
                 continue
             if self._L64 is None:
@@ -646,11 +650,18 @@ class RowShardedWoodbury:
     def logdet(self):
         """log|M| = log|noise I_k + L^T L| + (N - k) log noise with the GLOBAL N."""
         import math
-        ld_cap = 2.0 * torch.log(self._cap_chol.diagonal()).sum()
-        return float(ld_cap) + (self.row_shard.N - self.L.shape[1]) * math.log(self.noise)
+        if self._logdet_cap is not None:
+            ld_cap = float(self._logdet_cap)
+            if ld_cap != ld_cap:
+                raise RuntimeError("the preconditioner's capacitance matrix is not positive definite")
+        else:
+            ld_cap = float(2.0 * torch.log(self._cap_chol.diagonal()).sum())
+        return ld_cap + (self.row_shard.N - self.L.shape[1]) * math.log(self.noise)
 
     def cinv(self):
         """(noise I + L^T L)^-1 in float64 (k x k), identical on every rank, for the native mBCG executor."""
+        if self._cinv is not None:
+            return self._cinv
         return torch.cholesky_inverse(self._cap_chol).contiguous()
 
     __call__ = solve

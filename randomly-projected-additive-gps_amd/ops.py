@@ -739,6 +739,23 @@ def woodbury_apply(L, R, Tm, noise):
     return out
 
 
+def woodbury_setup(gram, noise):
+    """(chol, cinv, logdet) of C = gram + noise I for a K x K float64 device matrix, K <= 64, in one launch
+    (rpgp_woodbury_setup); logdet is a 1-element device tensor (no synchronisation here)."""
+    lib = _lib.load()
+    if gram.dtype != torch.float64 or not gram.is_cuda or gram.dim() != 2 or gram.shape[0] != gram.shape[1] or \
+            gram.shape[0] > 64:
+        raise TypeError("gram must be a square float64 HIP matrix with at most 64 rows")
+    gram = gram.contiguous()
+    K = gram.shape[0]
+    out = torch.empty((2 * K * K + 1,), dtype=torch.float64, device=gram.device)
+    chol, cinv, logdet = out[:K * K].view(K, K), out[K * K:2 * K * K].view(K, K), out[2 * K * K:]
+    with torch.cuda.device(gram.device):
+        _lib.check(lib.rpgp_woodbury_setup(gram.data_ptr(), float(noise), K, chol.data_ptr(), cinv.data_ptr(),
+                                           logdet.data_ptr(), _stream()), "rpgp_woodbury_setup")
+    return chol, cinv, logdet
+
+
 # ------------------------------------------------------------------------------------------------ native mBCG
 
 # ------------------------------------------------------------------------------------ generalised family

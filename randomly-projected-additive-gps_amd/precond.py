@@ -70,8 +70,13 @@ class WoodburyPreconditioner:
         self._be = be if (L.dtype == torch.float32 and 0 < k <= 64 and hasattr(be, "gram_f64") and on_device) else None
         self._L64c = None
         cap = self._be.gram_f64(L, L) if self._be is not None else gram64(self._L64, self._L64)
-        cap.diagonal().add_(self.noise)
-        self._cap_chol = torch.linalg.cholesky(cap)                   # k x k, float64 for a stable capacitance solve
+        self._cinv = self._logdet_cap = None
+        if self._be is not None and hasattr(self._be, "woodbury_setup"):
+            # Cholesky factor, inverse and log-determinant of the capacitance matrix in one launch, no synchronisation
+            self._cap_chol, self._cinv, self._logdet_cap = self._be.woodbury_setup(cap, self.noise)
+        else:
+            cap.diagonal().add_(self.noise)
+            self._cap_chol = torch.linalg.cholesky(cap)               # k x k, float64 for a stable capacitance solve
         self.N, self.k = L.shape
 
     def solve(self, r):
@@ -98,7 +103,9 @@ class WoodburyPreconditioner:
 
     def _solve_panel(self, r):
         if self._be is not None and r.dtype == torch.float32:
-            t = torch.cholesky_solve(self._be.gram_f64(self.L, r), self._cap_chol)
+            g = self._be.gram_f64(self.L, r)
+            # (the float64 inverse from the set-up kernel: one small product instead of two triangular solves)
+            t = self._cinv @ g if self._cinv is not None else torch.cholesky_solve(g, self._cap_chol)
             return self._be.woodbury_apply(self.L, r, t, self.noise)
         rd = r.double()
         t = torch.cholesky_solve(gram64(self._L64, rd), self._cap_chol)
@@ -108,12 +115,19 @@ class WoodburyPreconditioner:
 
     def cinv(self):
         """(noise I + L^T L)^-1 in float64 (k x k) for the native mBCG executor."""
+        if self._cinv is not None:
+            return self._cinv
         return torch.cholesky_inverse(self._cap_chol).contiguous()
 
     def logdet(self):
         """log|M| = log|noise I_k + L^T L| + (N - k) log noise."""
-        ld_cap = 2.0 * torch.log(self._cap_chol.diagonal()).sum()
-        return float(ld_cap) + (self.N - self.k) * math.log(self.noise)
+        if self._logdet_cap is not None:
+            ld_cap = float(self._logdet_cap)                          # (the only synchronisation of the preconditioner)
+            if ld_cap != ld_cap:
+                raise RuntimeError("the preconditioner's capacitance matrix is not positive definite")
+        else:
+            ld_cap = float(2.0 * torch.log(self._cap_chol.diagonal()).sum())
+        return ld_cap + (self.N - self.k) * math.log(self.noise)
 
     def sample(self, num, generator=None):
         """z ~ N(0, M):  L eps1 + sqrt(noise) eps2."""

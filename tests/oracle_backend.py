@@ -153,6 +153,12 @@ class OracleBackend:
     def gram_f64(self, A, B):
         return A.double().t() @ B.double()
 
+    def woodbury_setup(self, gram, noise):
+        C = gram.double().clone()
+        C.diagonal().add_(float(noise))
+        chol = torch.linalg.cholesky(C)
+        return chol, torch.cholesky_inverse(chol), (2.0 * torch.log(chol.diagonal()).sum()).reshape(1)
+
     def woodbury_apply(self, L, R, Tm, noise):
         return ((R.double() - L.double() @ Tm) / float(noise)).to(torch.float32)
 

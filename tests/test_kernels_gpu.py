@@ -564,4 +564,27 @@ def test_woodbury_preconditioner_uses_the_in_tree_kernels(gpu_device):
     assert v.shape == (N,)
     ld = pre.logdet()
     assert abs(ld - (np.linalg.slogdet(cap)[1] + (N - K) * math.log(noise))) < 1e-6 * abs(ld)
+    assert pre._logdet_cap is not None                              # rpgp_woodbury_setup served the capacitance matrix
+    assert np.allclose(pre.cinv().cpu().numpy(), np.linalg.inv(cap), rtol=1e-9, atol=1e-12 * np.abs(np.linalg.inv(cap)).max())
+    assert np.allclose(pre._cap_chol.cpu().numpy(), np.linalg.cholesky(cap), rtol=1e-10, atol=1e-12)
     assert pre._L64c is None                                        # the float64 copy of L is never materialised
+
+
+@pytest.mark.parametrize("K", [1, 2, 15, 16, 33, 64])
+def test_woodbury_setup_matches_numpy(gpu_device, K):
+    """rpgp_woodbury_setup: Cholesky factor, inverse and log-determinant of gram + noise I in one launch (float64)."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(K)
+    A = rng.normal(size=(3 * K + 5, K))
+    G = A.T @ A * np.linspace(0.1, 30.0, K)[:, None] * np.linspace(0.1, 30.0, K)[None, :]     # ill-scaled SPD Gram matrix
+    noise = 0.05
+    chol, cinv, ld = ops.woodbury_setup(torch.from_numpy(G).to(gpu_device), noise)
+    C = G + noise * np.eye(K)
+    assert np.allclose(chol.cpu().numpy(), np.linalg.cholesky(C), rtol=1e-9, atol=1e-11 * np.abs(C).max())
+    assert np.allclose(cinv.cpu().numpy() @ C, np.eye(K), atol=1e-7)
+    assert abs(float(ld) - np.linalg.slogdet(C)[1]) < 1e-9 * max(1.0, abs(np.linalg.slogdet(C)[1]))
+    bad = -np.eye(K)
+    _, cinv_b, ld_b = ops.woodbury_setup(torch.from_numpy(bad).to(gpu_device), 0.5)          # not positive definite -> NaN
+    assert np.isnan(float(ld_b)) and np.isnan(cinv_b.cpu().numpy()).all()
+    with pytest.raises(TypeError):
+        ops.woodbury_setup(torch.zeros(65, 65, dtype=torch.float64, device=gpu_device), 1.0)

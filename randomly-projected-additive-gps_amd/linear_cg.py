@@ -35,14 +35,14 @@ def _tridiag_from_history(alpha, beta, n_tridiag, dtype, device):
     b = beta[:, :n_tridiag].astype(np.float64)
     inv_a = np.where(np.abs(a) > 1e-30, 1.0 / np.where(np.abs(a) > 1e-30, a, 1.0), 1.0)
     t = np.zeros((n_tridiag, m, m))
-    for k in range(m):
-        if k == 0:
-            t[:, 0, 0] = inv_a[0]
-        else:
-            t[:, k, k] = inv_a[k] + b[k - 1] * inv_a[k - 1]
-            off = np.sqrt(np.clip(b[k - 1], 0.0, None)) * inv_a[k - 1]
-            t[:, k, k - 1] = off
-            t[:, k - 1, k] = off
+    idx = np.arange(m)
+    diag = inv_a.copy()                                   # [m, n_tridiag]
+    diag[1:] += b[:-1] * inv_a[:-1]
+    t[:, idx, idx] = diag.T
+    if m > 1:
+        off = (np.sqrt(np.clip(b[:-1], 0.0, None)) * inv_a[:-1]).T
+        t[:, idx[1:], idx[:-1]] = off
+        t[:, idx[:-1], idx[1:]] = off
     # the tridiagonals stay on the HOST: they are only eigendecomposed (10 matrices of 20 x 20), which costs ~1 ms
     # as GPU eigh launches and microseconds on the CPU
     return torch.from_numpy(t)

@@ -28,6 +28,6 @@ with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
     for it in range(steps):
         opt.zero_grad(); loss = -mll(model(X), y); loss.backward(); opt.step()
     torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); ps = pstats.Stats(pr, stream=s).sort_stats("cumulative"); ps.print_stats(70)
+s = io.StringIO(); ps = pstats.Stats(pr, stream=s).sort_stats(sys.argv[3] if len(sys.argv) > 3 else "cumulative"); ps.print_stats(45)
 txt = s.getvalue().replace("/root/repo/", "")
 print("\n".join(l[:190] for l in txt.splitlines()))

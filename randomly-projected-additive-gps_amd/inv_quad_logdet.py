@@ -28,12 +28,14 @@ def use_cholesky(N):
     return N <= settings.max_cholesky_size.value() or not settings.fast_computations.log_prob()
 
 
-def psd_safe_cholesky(A, max_tries=4):
-    """Cholesky with escalating jitter (GPyTorch's psd_safe_cholesky behaviour)."""
+def psd_safe_cholesky(A, max_tries=4, jitter=None):
+    """Cholesky with escalating jitter (GPyTorch's psd_safe_cholesky behaviour).  `jitter`: the first value tried (default
+    by dtype; a float64 copy of a matrix that was COMPUTED in float32 should pass the float32 value)."""
     L, info = torch.linalg.cholesky_ex(A)
     if not bool(info.any()):
         return L
-    jitter = 1e-6 if A.dtype == torch.float32 else 1e-8
+    if jitter is None:
+        jitter = 1e-6 if A.dtype == torch.float32 else 1e-8
     Aj = A.clone()
     prev = 0.0
     for i in range(max_tries):

@@ -12,7 +12,8 @@ from torch.nn import functional as F
 
 from . import backend as _backend
 from .distributed import JShard, RowShard
-from .operators import AdditiveRPOperator, FamilyAdditiveOperator, MixedGroupOperator, SKIAdditiveOperator
+from .operators import (AdditiveRPOperator, FamilyAdditiveOperator, MixedGroupOperator, SKIAdditiveOperator,
+                        padded_group_size)
 
 
 def inv_softplus(y):
@@ -266,7 +267,8 @@ class GeneralizedProjectionKernel(Kernel):
             return SKIAdditiveOperator(z1, z2, outputscale=outputscale, weight=1.0, grid_size=self.grid_size,
                                        comp_weights=self.outputscales,
                                        row_shard=shard if isinstance(shard, RowShard) else None, grid_rule=self.grid_rule)
-        if self.k is None:
+        if self.k is None or (self.kernel_type == "RBF" and padded_group_size(self.k) != self.k):
+            # mixed group sizes, or one size the tile kernels are not instantiated for (padded with zero columns there)
             return MixedGroupOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
                                       kind=self.kernel_type, degrees=self.component_degrees)
         return FamilyAdditiveOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,

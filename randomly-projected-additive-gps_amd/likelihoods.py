@@ -128,6 +128,7 @@ class MultivariateNormal:
             var = self.covariance.double()
             return (-0.5 * (diff * diff / var).sum() - 0.5 * torch.log(var).sum() - 0.5 * n * LOG2PI).to(value.dtype)
         from .inv_quad_logdet import psd_safe_cholesky
-        Lc = psd_safe_cholesky(self.covariance.double())
+        # (the float64 copy keeps the rounding of the dtype it was computed in: jitter on that scale)
+        Lc = psd_safe_cholesky(self.covariance.double(), jitter=1e-6 if self.covariance.dtype == torch.float32 else None)
         z = torch.linalg.solve_triangular(Lc, diff.unsqueeze(-1), upper=False).squeeze(-1)
         return (-0.5 * (z * z).sum() - torch.log(Lc.diagonal()).sum() - 0.5 * n * LOG2PI).to(value.dtype)

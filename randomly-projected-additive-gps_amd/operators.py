@@ -812,6 +812,19 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
         return self._finish_grads(gZ, gc)
 
 
+# group sizes the family tile kernels are instantiated for (ops.FAMILY_GROUPS); other sizes are padded with zero columns
+_FAMILY_GROUPS = (1, 2, 3, 4, 5, 8, 10, 20)
+
+
+def padded_group_size(k):
+    """Smallest instantiated group size >= k (an RBF group padded with all-zero coordinates is the same kernel:
+    exp(-0.5 sum d^2) gains factors exp(0))."""
+    for g in _FAMILY_GROUPS:
+        if g >= k:
+            return g
+    raise NotImplementedError("multiplicative groups of more than %d dimensions are not built" % _FAMILY_GROUPS[-1])
+
+
 class MixedGroupOperator(AdditiveRPOperator):
     """K = outputscale * sum_c w_c prod_{m in group c} k1(z_m - z_m') with multiplicative groups of DIFFERENT sizes
     (`general_rp_poly` with e.g. degrees [1, 1, 2, 3], training_routines.py:192-207; `create_multi_additive_kernel`,
@@ -833,14 +846,24 @@ class MixedGroupOperator(AdditiveRPOperator):
         for dg in self.degrees:
             starts.append(starts[-1] + dg)
         self.buckets = []                           # (component indices, column indices, operator) per distinct size
+        def gather(Zm, co, k, kp, ncomp):
+            z = Zm.detach().index_select(1, co)
+            if kp == k:
+                return z.contiguous()
+            zp = torch.zeros(z.shape[0], ncomp, kp, dtype=z.dtype, device=z.device)     # zero-padded groups (see padded_group_size)
+            zp[:, :, :k] = z.reshape(z.shape[0], ncomp, k)
+            return zp.reshape(z.shape[0], ncomp * kp)
+
         for k in sorted(set(self.degrees)):
             comps = [c for c, dg in enumerate(self.degrees) if dg == k]
             cols = [starts[c] + m for c in comps for m in range(k)]
+            kp = padded_group_size(k) if kind == "RBF" else k
             ci = torch.as_tensor(comps, dtype=torch.long, device=Z1.device)
             co = torch.as_tensor(cols, dtype=torch.long, device=Z1.device)
-            z1 = Z1.detach().index_select(1, co).contiguous()
-            z2 = None if Z2 is None else Z2.detach().index_select(1, co).contiguous()
-            part = FamilyAdditiveOperator(z1, z2, outputscale, comp_weights.detach().index_select(0, ci), kind, k)
+            z1 = gather(Z1, co, k, kp, len(comps))
+            z2 = None if Z2 is None else gather(Z2, co, k, kp, len(comps))
+            part = FamilyAdditiveOperator(z1, z2, outputscale, comp_weights.detach().index_select(0, ci), kind, kp)
+            part._true_group = k
             self.buckets.append((ci, co, part))
         self._wsum = sum(part._wsum for _, _, part in self.buckets)
 
@@ -906,7 +929,10 @@ class MixedGroupOperator(AdditiveRPOperator):
         gZ = torch.zeros_like(self.Z1)
         gc = torch.zeros(len(self.degrees), dtype=self.Z1.dtype, device=self.Z1.device)
         gs = torch.zeros((), dtype=self.Z1.dtype, device=self.Z1.device)
-        for (ci, co, _), (gz_p, gs_p, gc_p) in zip(self.buckets, grads):
+        for (ci, co, part), (gz_p, gs_p, gc_p) in zip(self.buckets, grads):
+            k, kp = part._true_group, part.group
+            if kp != k:                              # drop the derivatives of the padding columns
+                gz_p = gz_p.reshape(gz_p.shape[0], -1, kp)[:, :, :k].reshape(gz_p.shape[0], -1)
             gZ.index_copy_(1, co, gz_p.to(gZ))
             gc.index_copy_(0, ci, gc_p.to(gc).reshape(-1))
             gs = gs + gs_p.to(gs)

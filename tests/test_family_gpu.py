@@ -186,7 +186,7 @@ def test_mixed_group_sizes_operator_matches_oracle(gpu_device):
     different sizes, bucketed by size onto the family tile kernels (operators.MixedGroupOperator) — product, dense form,
     rows, diagonal and the bilinear derivative against float64."""
     from rpgp_amd.operators import MixedGroupOperator
-    degrees = [1, 2, 1, 3, 2, 1, 4]
+    degrees = [1, 2, 1, 3, 2, 1, 4, 6]        # 6 is not an instantiated group size: zero-padded to 8
     N, M, T = 1237, 301, 11
     rng = np.random.default_rng(3)
     Z = (rng.normal(size=(N, sum(degrees))) * 0.8).astype(np.float32)
@@ -206,7 +206,7 @@ def test_mixed_group_sizes_operator_matches_oracle(gpu_device):
     wt = torch.from_numpy(w).to(gpu_device)
     st = torch.tensor(s, device=gpu_device)
     op = MixedGroupOperator(Zt, None, st, wt, "RBF", degrees)
-    assert len(op.buckets) == 4
+    assert len(op.buckets) == 5 and op.buckets[-1][2].group == 8
     Kd = dense(Z, Z)
     out = op._matmul(torch.from_numpy(V).to(gpu_device), noise=0.3).cpu().numpy()
     assert _rel(out, Kd @ V.astype(np.float64) + 0.3 * V) < 1e-5

@@ -73,6 +73,8 @@ def _problem(n=60, d=5, seed=0):
     ("additive", dict(groups=[[0], [1, 4], [2], [0, 2, 3]], weighted=True)),                  # unequal groups
     ("general_rp_poly", dict(degrees=[1, 2, 1, 3], weighted=True, learn_proj=False)),        # polynomial_rp.json's shape
     ("general_rp_poly", dict(degrees=[2, 1], weighted=False, learn_proj=False)),
+    ("general_rp_poly", dict(degrees=[6, 1, 6], weighted=True, learn_proj=False)),           # 6 is padded to the 8-wide kernel
+    ("rp_poly", dict(J=2, k=7, weighted=True, kernel_type="RBF")),                           # equal sizes, padded as well
 ])
 def test_family_mll_and_gradients_match_dense_autograd(oracle_backend, kind, model_kwargs):
     from rpgp_amd.training import create_exact_gp

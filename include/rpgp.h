@@ -367,6 +367,9 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
 #define RPGP_OP_DENSE 3           /* cached-K: symmetric Kd (N x N, row stride ldk) in HBM, applied by rpgp_dense_mvm */
 #define RPGP_OP_FAMILY 4          /* rpgp_family_mvm_sym on Z + family */
 #define RPGP_OP_SYMCACHE 5        /* packed symmetric cache: Kd = the cache, ldk = its size in bytes, G = its layout; scale, noise */
+#define RPGP_OP_SUM 6             /* sum of G unsharded operators on the same N rows: prep -> rpgp_operator[G] in HOST memory (each
+                                     part with its own scale / noise; no nesting) — the additive kernels whose multiplicative
+                                     groups differ in size (general_rp_poly, training_routines.py:192-207) */
 typedef struct rpgp_operator {
   int kind;
   int64_t N;

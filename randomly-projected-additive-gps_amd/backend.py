@@ -49,6 +49,7 @@ class HipBackend:
     woodbury_apply = staticmethod(ops.woodbury_apply)
     woodbury_setup = staticmethod(ops.woodbury_setup)
     make_operator_desc = staticmethod(ops.make_operator_desc)
+    make_sum_operator_desc = staticmethod(ops.make_sum_operator_desc)
     mbcg_solve = staticmethod(ops.mbcg_solve)
 
 

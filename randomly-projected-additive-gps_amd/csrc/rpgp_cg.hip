@@ -676,8 +676,34 @@ struct ShardCtx {
 // one application of the operator.  RPGP_SHARD_PARTIAL: this rank's partial product (noise on rank 0 only), summed over
 // the ranks; RPGP_SHARD_ROWS (SKI): scatter the local rows, all-reduce the histogram, replicated Toeplitz product, gather
 // the local rows.
+size_t operator_workspace(const rpgp_operator *op, int T);
+
+// out += add (N x T contiguous): the accumulation of a composite operator's parts
+__global__ __launch_bounds__(256) void k_accumulate(float *__restrict__ out, const float *__restrict__ add, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] += add[i];
+}
+
 int apply_operator(const rpgp_operator *op, const ShardCtx &sh, const float *V, float *out, int T, void *ws, size_t ws_bytes,
                    void *stream) {
+  if (op->kind == RPGP_OP_SUM) {
+    // A = sum of `G` unsharded operators on the same N rows (prep -> rpgp_operator[G] in HOST memory; each part carries its
+    // own scale and noise): part 0 straight into `out`, the others through an N x T scratch block at the head of the workspace
+    const rpgp_operator *parts = reinterpret_cast<const rpgp_operator *>(op->prep);
+    if (!parts || op->G <= 0 || sh.mode != RPGP_SHARD_NONE) return RPGP_EINVAL;
+    const size_t nt = align256((size_t)op->N * T * sizeof(float));
+    if (ws_bytes < nt) return RPGP_EWORKSPACE;
+    float *tmp = reinterpret_cast<float *>(ws);
+    void *pws = reinterpret_cast<char *>(ws) + nt;
+    const long long n = (long long)op->N * T;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    for (int i = 0; i < op->G; ++i) {
+      if (parts[i].kind == RPGP_OP_SUM || parts[i].N != op->N) return RPGP_EINVAL;
+      const int rc = apply_operator(&parts[i], sh, V, i == 0 ? out : tmp, T, pws, ws_bytes - nt, stream);
+      if (rc) return rc;
+      if (i > 0) hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, tmp, n);
+    }
+    return (int)hipGetLastError();
+  }
   const bool partial = sh.mode == RPGP_SHARD_PARTIAL;
   const float noise = (partial && sh.rank != 0) ? 0.f : op->noise;
   const int world = op->world > 0 ? op->world : 1, rank = op->world > 0 ? op->rank : 0;
@@ -759,6 +785,16 @@ size_t operator_workspace(const rpgp_operator *op, int T) {
       return rpgp_symcache_workspace_bytes(op->N, T, world, rank);
     case RPGP_OP_FAMILY:
       return rpgp_family_mvm_workspace_bytes(op->N, op->N, T, 1);
+    case RPGP_OP_SUM: {
+      const rpgp_operator *parts = reinterpret_cast<const rpgp_operator *>(op->prep);
+      size_t mx = 0;
+      for (int i = 0; parts && i < op->G; ++i) {
+        if (parts[i].kind == RPGP_OP_SUM) continue;
+        const size_t b = operator_workspace(&parts[i], T);
+        mx = b > mx ? b : mx;
+      }
+      return align256((size_t)(op->N > 0 ? op->N : 1) * T * sizeof(float)) + mx;
+    }
     default:
       return 0;
   }

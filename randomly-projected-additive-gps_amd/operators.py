@@ -830,7 +830,8 @@ class MixedGroupOperator(AdditiveRPOperator):
     (`general_rp_poly` with e.g. degrees [1, 1, 2, 3], training_routines.py:192-207; `create_multi_additive_kernel`,
     :247-258: every feature subset up to a degree).  The components are bucketed by group size and every bucket is one
     FamilyAdditiveOperator on its own column slice of Z — same fused tile kernels, one launch per distinct size per
-    product; sums, diagonals, rows and derivatives are assembled here.  Runs replicated, fp32, torch mBCG loop."""
+    product; sums, diagonals, rows and derivatives are assembled here.  Runs replicated, fp32; solves in the native mBCG
+    executor as an RPGP_OP_SUM of the buckets."""
 
     def __init__(self, Z1, Z2=None, outputscale=None, comp_weights=None, kind="RBF", degrees=(1,)):
         super().__init__(Z1, Z2, outputscale, 1.0, shard=None)
@@ -883,7 +884,17 @@ class MixedGroupOperator(AdditiveRPOperator):
         return None
 
     def native_descriptor(self, noise=0.0):
-        return None
+        """RPGP_OP_SUM of the buckets' RPGP_OP_FAMILY descriptors (the noise rides on the first one)."""
+        be = _backend.get_backend()
+        if not self.symmetric or not hasattr(be, "make_sum_operator_desc"):
+            return None
+        parts = []
+        for i, (_, _, part) in enumerate(self.buckets):
+            made = part.native_descriptor(noise if i == 0 else 0.0)
+            if made is None:
+                return None
+            parts.append(made)
+        return be.make_sum_operator_desc(parts)
 
     def native_sharding(self):
         return None

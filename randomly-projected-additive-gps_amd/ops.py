@@ -905,6 +905,24 @@ def make_operator_desc(kind, N, J, scale, noise, Z=None, prep=None, gp=None, j0=
     return d, (Z, prep, gp, Kd, family, symcache)
 
 
+def make_sum_operator_desc(parts):
+    """RPGP_OP_SUM: the sum of the given (struct, keepalive) descriptors of unsharded operators on the same rows, as one
+    descriptor for the native executor; returns (struct, keepalive)."""
+    import ctypes
+    if not parts:
+        raise ValueError("a sum operator needs at least one part")
+    arr = (_lib.RpgpOperator * len(parts))()
+    for i, (d, _) in enumerate(parts):
+        if d.kind == _lib.RPGP_OP_SUM or d.N != parts[0][0].N:
+            raise ValueError("the parts of a sum operator are plain operators on the same rows")
+        ctypes.memmove(ctypes.addressof(arr[i]), ctypes.addressof(d), ctypes.sizeof(_lib.RpgpOperator))
+    s = _lib.RpgpOperator()
+    s.kind, s.N, s.J, s.ldz, s.G = _lib.RPGP_OP_SUM, parts[0][0].N, 0, 0, len(parts)
+    s.scale, s.noise = 1.0, 0.0
+    s.prep = ctypes.cast(arr, ctypes.c_void_p).value
+    return s, (arr, [keep for _, keep in parts])
+
+
 def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_every=1, L=None, Cinv=None, sigma2=1.0,
                stagnation_window=0, sharding=None):
     """Native preconditioned batched CG (rpgp_mbcg_solve).  rhs: N x T (T <= 16).

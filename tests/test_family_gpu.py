@@ -219,6 +219,18 @@ def test_mixed_group_sizes_operator_matches_oracle(gpu_device):
     assert _rel(opr._matmul(torch.from_numpy(W).to(gpu_device)).cpu().numpy(), dense(Z, Z2) @ W.astype(np.float64)) < 1e-5
     assert _rel(opr.t()._matmul(torch.from_numpy(V).to(gpu_device)).cpu().numpy(), dense(Z2, Z) @ V.astype(np.float64)) < 1e-5
 
+    # the native mBCG executor on the sum of the buckets (RPGP_OP_SUM): true float64 residual of the solve
+    from rpgp_amd import linear_cg as lcg
+    from rpgp_amd.operators import AddedDiagOperator
+    khat = AddedDiagOperator(op, torch.tensor(0.3, device=gpu_device))
+    rhs = torch.from_numpy(V[:, :5].copy()).to(gpu_device)
+    n0 = lcg.stats.get("native_calls", 0)
+    x = lcg.linear_cg(khat._matmul, rhs, tolerance=1e-5, max_iter=2000, operator=khat)
+    assert lcg.stats.get("native_calls", 0) == n0 + 1
+    Kh = Kd + 0.3 * np.eye(N)
+    res = np.linalg.norm(Kh @ x.cpu().double().numpy() - V[:, :5], axis=0) / np.linalg.norm(V[:, :5], axis=0)
+    assert res.max() < 2e-4
+
     # bilinear derivative vs float64 autograd of sum((L R^T) * K)
     L = rng.normal(size=(N, 4)).astype(np.float32)
     R = rng.normal(size=(N, 4)).astype(np.float32)
@@ -249,6 +261,12 @@ def test_general_rp_poly_model_trains_on_gpu(gpu_device):
     mk = dict(degrees=[1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3], noise_prior=True, kernel_type="RBF", learn_proj=False,
               weighted=True)
     torch.manual_seed(0)
+    from rpgp_amd import linear_cg as lcg, settings
+    n_native = lcg.stats.get("native_calls", 0)
+    with settings.max_cholesky_size(100):
+        metrics, mean, model = train_exact_gp(X[:800], y[:800], X[800:], y[800:], "general_rp_poly", mk, tk,
+                                              devices=(str(gpu_device),), skip_random_restart=True)
+    assert lcg.stats.get("native_calls", 0) > n_native          # the training solves ran in the native executor
     metrics, mean, model = train_exact_gp(X[:800], y[:800], X[800:], y[800:], "general_rp_poly", mk, tk,
                                           devices=(str(gpu_device),), skip_random_restart=True)
     assert np.isfinite(metrics["prior_train_nmll"]) and np.isfinite(metrics["test_nll"])

@@ -36,6 +36,9 @@ def psd_safe_cholesky(A, max_tries=4, jitter=None):
         return L
     if jitter is None:
         jitter = 1e-6 if A.dtype == torch.float32 else 1e-8
+    # relative to the size of the diagonal when that exceeds one (a kernel with outputscale 50 has rounding errors 50 x those of
+    # a unit-scale one; GPyTorch's absolute values are the unit-scale case)
+    jitter = jitter * max(1.0, float(A.diagonal().abs().mean()))
     Aj = A.clone()
     prev = 0.0
     for i in range(max_tries):

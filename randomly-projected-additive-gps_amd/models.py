@@ -159,6 +159,22 @@ class PredictionStrategy:
                          max_iter=settings.max_cg_iterations.value(), preconditioner=getattr(self, "pre", None),
                          operator=khat)
 
+    def _chol64_factor(self, like):
+        """Float64 Cholesky factor of the dense Khat when the exact wide solve applies (see solve()), else None."""
+        N = self.r.shape[0]
+        if self.dense_path or not isinstance(self.op, AdditiveRPOperator) or N > settings.dense_solve_size.value():
+            return None
+        if isinstance(self.op, SKIAdditiveOperator) and N > 32768:
+            return None
+        if like.is_cuda and 4.0 * N * N > 0.25 * torch.cuda.get_device_properties(like.device).total_memory:
+            return None
+        if getattr(self, "_dense_khat", None) is None:
+            self._dense_khat = DenseOperator(self.op.to_dense_cached() if hasattr(self.op, "to_dense_cached")
+                                             else self.op.to_dense(), float(self.noise))
+        if getattr(self, "_chol64", None) is None:
+            self._chol64 = psd_safe_cholesky(self._dense_khat.to_dense().double())
+        return self._chol64
+
     def predict(self, xs):
         model = self.model
         with torch.no_grad():
@@ -187,6 +203,16 @@ class PredictionStrategy:
                                                            settings.max_root_decomposition_size.value())
                 KR = cross._matmul(self._love_root)                  # (N* x k)
                 cov -= KR @ KR.t()
+            elif self._chol64_factor(cov) is not None and 8.0 * n_train * n_test <= 4.0e9:
+                # Khat is in HBM with a float64 factor (N <= dense_solve_size): the whole quadratic form in float64.  For a
+                # confident model Sigma* is a difference of O(s J) quantities that cancels to 1e-5: in fp32 GEMMs the result was
+                # indefinite by 3e-4 (kin8nm-shaped GAM fit), which a small fitted noise does not cover.
+                c64 = self._chol64_factor(cov)
+                Kx = cross._get_rows(torch.arange(n_test, device=xs.device)).t().contiguous().double()   # K(X, X*)
+                sol = torch.empty_like(Kx)
+                for c0 in range(0, n_test, 1024):            # (column panels: the library's triangular solves run out of
+                    sol[:, c0:c0 + 1024] = torch.cholesky_solve(Kx[:, c0:c0 + 1024].contiguous(), c64)   # workspace on wide blocks)
+                cov = (cov.double() - Kx.t() @ sol).to(cov.dtype)
             else:
                 khat = self.khat
                 total_mem = torch.cuda.get_device_properties(xs.device).total_memory if xs.is_cuda else float("inf")
@@ -256,6 +282,32 @@ class ExactGPModel(ExactGP):
         return MultivariateNormal(mean_x, covar_x)
 
 
+class _DenseGaussianLogProb(torch.autograd.Function):
+    """log N(r; 0, K) for a dense K (the `kind: full` path) with the analytic gradient 0.5 (alpha alpha^T - K^-1): the
+    backward of an autograd-tracked `torch.linalg.cholesky` runs N x N triangular solves whose library workspace fails at a
+    few thousand rows on this stack (HIPBLAS_STATUS_ALLOC_FAILED at N = 7372)."""
+
+    @staticmethod
+    def forward(ctx, K, r):
+        Lc = psd_safe_cholesky(K.detach())
+        alpha = torch.cholesky_solve(r.detach().unsqueeze(-1), Lc)
+        ctx.save_for_backward(Lc, alpha)
+        n = r.shape[0]
+        return -0.5 * (r.detach().unsqueeze(-1) * alpha).sum() - torch.log(Lc.diagonal()).sum() - 0.5 * n * LOG2PI
+
+    @staticmethod
+    def backward(ctx, g):
+        Lc, alpha = ctx.saved_tensors
+        gK = gr = None
+        if ctx.needs_input_grad[0]:
+            gK = torch.cholesky_inverse(Lc).neg_()
+            gK.addmm_(alpha, alpha.t())
+            gK.mul_(0.5 * g)
+        if ctx.needs_input_grad[1]:
+            gr = (-g * alpha).reshape(-1)
+        return gK, gr
+
+
 class ExactMarginalLogLikelihood(nn.Module):
     """mll(output, target) = (1/N) [ log N(target | mean, K + sigma^2 I) + sum log-priors ]   (SURVEY.md A.3)."""
 
@@ -274,10 +326,7 @@ class ExactMarginalLogLikelihood(nn.Module):
             log_prob = -0.5 * (inv_quad + logdet + n * LOG2PI)
         elif isinstance(cov, DenseKernelOperator):
             K = cov.to_dense_autograd() + noise * torch.eye(n, dtype=target.dtype, device=target.device)
-            Lc = torch.linalg.cholesky(K)
-            r = (target - output.mean).unsqueeze(-1)
-            z = torch.linalg.solve_triangular(Lc, r, upper=False)
-            log_prob = -0.5 * (z * z).sum() - torch.log(Lc.diagonal()).sum() - 0.5 * n * LOG2PI
+            log_prob = _DenseGaussianLogProb.apply(K, target - output.mean)
         else:
             # posterior (eval-mode) output: dense covariance or marginal variances
             log_prob = self.likelihood(output).log_prob(target)

@@ -190,7 +190,7 @@ class PredictionStrategy:
             # column blocks of test points; S and Khat S are kept (2 x N x N* floats).
             n_train, n_test = model.train_inputs.shape[0], xs.shape[0]
             cov = model.covar_module(xs).to_dense()                 # K(X*, X*)
-            budget = 1 << 28                                        # floats per N x c block of CG state (1 GiB)
+            budget = settings.predictive_block_floats.value()       # floats per N x c block of CG state (1 GiB)
             c = max(32, min(n_test, budget // max(n_train, 1)))
             if self.dense_path:
                 Kx = cross._get_rows(torch.arange(n_test, device=xs.device)).t().contiguous()   # K(X, X*)
@@ -223,15 +223,23 @@ class PredictionStrategy:
                 S = torch.empty(n_train, n_test, dtype=cov.dtype, device=cov.device)
                 KS = torch.empty_like(S)
                 BtS = torch.empty(n_test, n_test, dtype=cov.dtype, device=cov.device)
+                # several column blocks (evaluate-on-train at N = 45 000: eight): K(X*, X) is materialised once when it fits
+                # beside S and KS, so that K(X*, X) sol is a library GEMM — the fused rectangular product takes the block 12
+                # columns at a time (500 sweeps per block: 20 of the 30 s of that evaluation)
+                Kc = None
+                if c < n_test and n_test > 12 and 12.0 * n_train * n_test <= 0.35 * total_mem:
+                    Kc = cross._get_rows(torch.arange(n_test, device=xs.device))       # (N* x N)
                 for c0 in range(0, n_test, c):
                     idx = torch.arange(c0, min(c0 + c, n_test), device=xs.device)
-                    Kx_blk = cross._get_rows(idx).t().contiguous()      # K(X, X*[idx])  (N x c)
+                    Kx_blk = (Kc[c0:c0 + idx.numel()] if Kc is not None else cross._get_rows(idx)).t().contiguous()   # K(X, X*[idx])
                     sol = self.solve(Kx_blk)                            # ~ Khat^-1 K(X, X*[idx])
                     S[:, idx] = sol
                     # Khat sol through the matrix the solve used (a library GEMM when it was densified)
                     KS[:, idx] = (getattr(self, "_dense_khat", None) or khat)._matmul(sol)
                     if idx.numel() == n_test and sol.shape[1] > 12:
                         BtS[:, idx] = Kx_blk.t() @ sol                  # single block: K(X*, X) is Kx_blk^T, already dense
+                    elif Kc is not None:
+                        BtS[:, idx] = Kc @ sol
                     else:
                         BtS[:, idx] = cross._matmul(sol)                # K(X*, X) sol
                 cov -= BtS + BtS.t() - S.t() @ KS

@@ -97,6 +97,8 @@ cg_stagnation_window = _setting("cg_stagnation_window", 200)
 # wide (N_test-column) solves of the predictive covariance: when Khat has been materialised in HBM and N is at most this,
 # factorise it once in float64 instead of running CG on the wide block (0 keeps CG, GPyTorch's behaviour)
 dense_solve_size = _setting("dense_solve_size", 20000)
+# floats per N x c block of CG state when the predictive covariance is solved in column blocks of test points (1 GiB)
+predictive_block_floats = _setting("predictive_block_floats", 1 << 28)
 # ... and above that, up to this size, factorise the fp32 matrix once and use the factor as the preconditioner of the wide
 # block's CG (0 disables: plain pivoted-Cholesky-preconditioned CG)
 cholesky_precond_size = _setting("cholesky_precond_size", 65536)

@@ -232,6 +232,29 @@ def test_wide_covariance_solve_paths_agree(gpu_device):
         assert np.abs(var - var_ref).max() < 2e-4 * max(1.0, np.abs(var_ref).max()), (dsz, csz)
 
 
+def test_predictive_covariance_in_column_blocks(gpu_device):
+    """The predictive covariance solved in several column blocks of test points (the evaluate-on-train situation at large N):
+    with the dense K(X*, X) materialised once (library GEMMs) and without it (fused rectangular products), both equal the
+    single-block result and the float64 oracle."""
+    from rpgp_amd import settings
+    prob, model, lik, mll = _gpu_model(gpu_device, 2600, 8, 20, 2, 0.15)
+    X, y, P, ls, noise, s = prob
+    ref = _oracle_gp(X, y, P, ls, noise, s)
+    Xs = torch.randn(150, 8, generator=torch.Generator().manual_seed(6))
+    mean_ref, var_ref = ref.predict(Xs.numpy())
+    covs = []
+    for blk_floats, n_test in ((1 << 28, 150), (2600 * 64, 150), (2600 * 64, 12)):
+        model.train()
+        model.eval()
+        with torch.no_grad(), settings.eval_cg_tolerance(1e-6), settings.dense_solve_size(0),                 settings.cholesky_precond_size(0), settings.predictive_block_floats(blk_floats):
+            out = model(Xs[:n_test].to(gpu_device))
+        var = out.variance.cpu().numpy()
+        assert np.abs(var - var_ref[:n_test]).max() < 2e-4 * max(1.0, np.abs(var_ref).max()), (blk_floats, n_test)
+        covs.append(out.covariance_matrix.cpu().numpy())
+    assert np.abs(covs[0] - covs[1]).max() < 1e-4 * np.abs(covs[0]).max()
+    assert np.abs(covs[0][:12, :12] - covs[2]).max() < 1e-4 * np.abs(covs[0]).max()
+
+
 def test_fast_pred_var_love_on_gpu(gpu_device):
     """--fast_pred (LOVE, Lanczos inverse root through the fused MVM): exact mean, conservative variances that
     tighten with the rank (`max_root_decomposition_size`, default 100 as in GPyTorch)."""

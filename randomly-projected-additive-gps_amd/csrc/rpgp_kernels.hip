@@ -538,7 +538,10 @@ template <int JT> struct FactStride {
 
 // K(i, c) partial sum over JT projections in factorised form; q points at this column's packed LDS record
 // [pair p: b2_{2p}, b2_{2p+1}, nb2_{2p}, nb2_{2p+1}] (JT even) or [b2, nb2] (JT == 1)
-template <int JT>
+// ASMADD: the horizontal add of the packed sum as ONE v_add_f32 written in asm.  Left to the compiler, the SLP vectoriser
+// packs the two rows' adds of the T = 1 loop into a v_pk_add_f32 behind three v_mov_b32 each (6 moves + 2 packed adds per two
+// steps); the asm form measured 2.352 against 2.365-2.388 ms alternating in one process on one box (4 of 4 pairs).
+template <int JT, bool ASMADD = false>
 __device__ __forceinline__ float fact_pair_sum(const float2v (&ap)[(JT + 1) / 2], const float2v (&ea)[(JT + 1) / 2],
                                                const float *q) {
   if constexpr (JT != 1) {
@@ -553,7 +556,13 @@ __device__ __forceinline__ float fact_pair_sum(const float2v (&ap)[(JT + 1) / 2]
       const float2v e = {fast_exp2(t.x), fast_exp2(t.y)};
       acc = __builtin_elementwise_fma(e, ea[p], acc);
     }
-    return acc.x + acc.y;
+    if constexpr (ASMADD) {
+      float s;
+      asm("v_add_f32 %0, %1, %2" : "=v"(s) : "v"(acc.x), "v"(acc.y));
+      return s;
+    } else {
+      return acc.x + acc.y;
+    }
   } else {
     const float t = __builtin_fmaf(ap[0].x, q[0], q[1]);
     return fast_exp2(t) * ea[0].x;
@@ -655,7 +664,7 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
           const float *colrec = sB + __mul24(idx, STR);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const float ks = fact_pair_sum<JT>(ap[r], ea[r], colrec);
+            const float ks = fact_pair_sum<JT, TT == 1>(ap[r], ea[r], colrec);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
               accR[r][t] = __builtin_fmaf(ks, v[t], accR[r][t]);

@@ -1590,7 +1590,33 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
 // traffic per pair (the one-row full sweep spends 11 ds_read_b128 per pair: 93 % of the LDS issue rate).
 // slabR[kchunk][row][JT + 1] : row sums of a column chunk         slabT[rb][col][JT + 1] : transposed sums of row block rb
 // ---------------------------------------------------------------------------------------------
-template <int JT, int TT>
+// LDS-DMA of one dword per lane (wave-instruction: 64 consecutive floats at `lds_dst`); hipcc does not count it: the caller
+// waits with an explicit s_waitcnt vmcnt.  M0 (the DMA's LDS base) is written in the statement that uses it.
+__device__ __forceinline__ void glds_dword(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// Zs[n][q] = Z[n][j0 + q] * kExp2Scale (the derivative's DMA staging cannot scale on the way into LDS)
+__global__ __launch_bounds__(256) void scale_columns_kernel(const float *__restrict__ Z, float *__restrict__ Zs, long long N,
+                                                            int ldz, int j0, int JT) {
+  const long long total = N * JT;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+    const long long n = g / JT;
+    const int q = (int)(g - n * JT);
+    Zs[g] = Z[n * ldz + j0 + q] * kExp2Scale;
+  }
+}
+
+// DMA = true (JT + 2 TT a multiple of 4 with an odd quarter, so that the LDS records are unpadded and the subtile image is
+// linear, and 64 records a whole number of 256-element pieces): Z is the pre-scaled copy Zs (row stride JT, j0 = 0) and the
+// subtile's 64 column records are written by LDS-DMA — the register staging loop compiles to global_load; s_waitcnt vmcnt(0);
+// ds_write per element (eleven serial round trips per subtile with all four waves idle), and unrolling it into registers
+// spills (the kernel already holds 252 VGPRs: 106 spills, 7.0 ms).
+template <int JT, int TT, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void bilinear_sym_kernel(const float *__restrict__ Z, const float *__restrict__ L,
                                                               const float *__restrict__ Rm, float *__restrict__ slabR,
                                                               float *__restrict__ slabT, int N, int ldz, int T, int j0,
@@ -1621,7 +1647,8 @@ __global__ __launch_bounds__(256, 2) void bilinear_sym_kernel(const float *__res
     const bool valid = row < N;
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-      a[r][j] = valid ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 0.f;
+      if constexpr (DMA) a[r][j] = valid ? Z[(size_t)row * JT + j] : 0.f;
+      else a[r][j] = valid ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 0.f;
       accG[r][j] = 0.f;
     }
 #pragma unroll
@@ -1634,16 +1661,45 @@ __global__ __launch_bounds__(256, 2) void bilinear_sym_kernel(const float *__res
 
   for (int c0 = c_begin; c0 < c_end; c0 += 64) {
     __syncthreads();
-    for (int e = tid; e < 64 * STRQ; e += 256) {
-      const int c = e / STRQ, q = e % STRQ;
-      const int col = c0 + c;
-      float val = 0.f;                            // columns beyond the chunk: L = R = 0 -> S = 0
-      if (col < c_end) {
-        if (q < JT) val = Z[(size_t)col * ldz + j0 + q] * kExp2Scale;
-        else if (q < JT + TT) { const int t = q - JT; val = t < T ? L[(size_t)col * T + t] : 0.f; }
-        else { const int t = q - JT - TT; val = t < T ? Rm[(size_t)col * T + t] : 0.f; }
+    if constexpr (DMA) {
+      static_assert(STR == STRQ && (64 * STRQ) % 256 == 0, "linear subtile image in whole 256-element pieces");
+      constexpr int NST = 64 * STRQ / 256;
+      const unsigned sc_bytes = (unsigned)(size_t)sC;
+      const unsigned uw = __builtin_amdgcn_readfirstlane((unsigned)wave);
+#pragma unroll 1                                                 // (rolled: unrolled, the eleven address computations are hoisted
+      for (int it = 0; it < NST; ++it) {                         //  together and spill; the DMAs need no wait between them)
+        const int e = tid + 256 * it;
+        const int c = e / STRQ, q = e % STRQ;
+        const int col = c0 + c;
+        const int colc = col < N ? col : N - 1;                 // clamped: every lane of the DMA reads a valid address
+        const bool isz = q < JT, isl = q < JT + TT;
+        int t = isz ? 0 : (isl ? q - JT : q - JT - TT);
+        t = t < T ? t : T - 1;                                  // (slot t >= T: the row side's L / R are zero there)
+        const float *src = isz ? Z : (isl ? L : Rm);
+        const size_t off = isz ? (size_t)colc * JT + q : (size_t)colc * T + t;
+        glds_dword(src + off, __builtin_amdgcn_readfirstlane(sc_bytes + (unsigned)(it * 256 + (int)uw * 64) * 4u));
       }
-      sC[c * STR + q] = val;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (c0 + 64 > c_end) {                                    // ragged last subtile: columns beyond the end get L = R = 0
+#pragma unroll 1
+        for (int it = 0; it < NST; ++it) {
+          const int e = tid + 256 * it;
+          const int c = e / STRQ, q = e % STRQ;
+          if (c0 + c >= c_end && q >= JT) sC[e] = 0.f;
+        }
+      }
+    } else {
+      for (int e = tid; e < 64 * STRQ; e += 256) {
+        const int c = e / STRQ, q = e % STRQ;
+        const int col = c0 + c;
+        float val = 0.f;                            // columns beyond the chunk: L = R = 0 -> S = 0
+        if (col < c_end) {
+          if (q < JT) val = Z[(size_t)col * ldz + j0 + q] * kExp2Scale;
+          else if (q < JT + TT) { const int t = q - JT; val = t < T ? L[(size_t)col * T + t] : 0.f; }
+          else { const int t = q - JT - TT; val = t < T ? Rm[(size_t)col * T + t] : 0.f; }
+        }
+        sC[c * STR + q] = val;
+      }
     }
     __syncthreads();
     const bool doT = (c0 >= r0 + BR);
@@ -3634,13 +3690,30 @@ inline bool bilinear_use_sym(int64_t N) {
 }
 inline size_t bilinear_sym_floats(int64_t N) {
   const TilePlan p = make_plan(N, N, true, 12, 1, 0, false, 512);
-  return ((size_t)p.maxchunks * N + (size_t)p.nrb * N) * 21 + (size_t)N;
+  return ((size_t)p.maxchunks * N + (size_t)p.nrb * N) * 21 + (size_t)N + (size_t)N * 20;     // slabs, rowS, scaled copy of Z
 }
 
 template <int JT>
 int launch_bilinear_sym(int tt, const TilePlan &p, const float *Z, const float *L, const float *R, float *slabR,
-                               float *slabT, int N, int ldz, int T, int j0, hipStream_t st) {
+                               float *slabT, int N, int ldz, int T, int j0, hipStream_t st, float *Zs) {
   dim3 grid(p.total_wg), block(256);
+  if constexpr (JT == 20) {
+    // the 20-column piece stages its column records by LDS-DMA from a pre-scaled copy of Z (C4: 6.26 -> 5.87 ms alternating
+    // in one process, bit-identical results); RPGP_BIL_DMA=0 restores the register staging
+    const char *ev = getenv("RPGP_BIL_DMA");
+    if (Zs && !(ev && ev[0] == '0')) {
+      const long long total = (long long)N * JT;
+      hipLaunchKernelGGL(scale_columns_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256),
+                         0, st, Z, Zs, (long long)N, ldz, j0, JT);
+      if (tt <= 4)
+        hipLaunchKernelGGL((bilinear_sym_kernel<JT, 4, true>), grid, block, 0, st, Zs, L, R, slabR, slabT, N, JT, T, 0,
+                           p.chunk_cols, g_rotdir, 0, 0, 0, N);
+      else
+        hipLaunchKernelGGL((bilinear_sym_kernel<JT, 12, true>), grid, block, 0, st, Zs, L, R, slabR, slabT, N, JT, T, 0,
+                           p.chunk_cols, g_rotdir, 0, 0, 0, N);
+      return launch_status();
+    }
+  }
   if (tt <= 4)
     hipLaunchKernelGGL((bilinear_sym_kernel<JT, 4>), grid, block, 0, st, Z, L, R, slabR, slabT, N, ldz, T, j0,
                        p.chunk_cols, g_rotdir, 0, 0, 0, N);
@@ -4168,18 +4241,19 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
     float *slabR = reinterpret_cast<float *>(workspace);
     float *slabT = slabR + (size_t)p.maxchunks * N * 21;
     float *rowS = slabT + (size_t)p.nrb * N * 21;
+    float *Zs = rowS + (size_t)N;
     int first = 1;
     for (int j = j0; j < j1;) {
       const int jt = next_j_piece(j1 - j);
       switch (jt) {
-        case 20: rc = launch_bilinear_sym<20>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
-        case 10: rc = launch_bilinear_sym<10>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
-        case 8: rc = launch_bilinear_sym<8>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
-        case 5: rc = launch_bilinear_sym<5>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
-        case 3: rc = launch_bilinear_sym<3>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
-        case 4: rc = launch_bilinear_sym<4>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
-        case 2: rc = launch_bilinear_sym<2>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
-        default: rc = launch_bilinear_sym<1>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st); break;
+        case 20: rc = launch_bilinear_sym<20>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st, Zs); break;
+        case 10: rc = launch_bilinear_sym<10>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st, Zs); break;
+        case 8: rc = launch_bilinear_sym<8>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st, Zs); break;
+        case 5: rc = launch_bilinear_sym<5>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st, Zs); break;
+        case 3: rc = launch_bilinear_sym<3>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st, Zs); break;
+        case 4: rc = launch_bilinear_sym<4>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st, Zs); break;
+        case 2: rc = launch_bilinear_sym<2>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st, Zs); break;
+        default: rc = launch_bilinear_sym<1>(T, p, Z, L, R, slabR, slabT, (int)N, ldz, T, j, st, Zs); break;
       }
       if (rc) return rc;
       const size_t total = (size_t)N * (jt + 1);

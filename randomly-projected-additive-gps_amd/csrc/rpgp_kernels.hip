@@ -323,12 +323,16 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
   for (int r = 0; r < R; ++r) {
     const int row = r0 + wave * (64 * R) + r * 64 + lane;
     const bool valid = row < M;
+    // unconditional loads from a clamped row (a load under a condition compiles to a branch + s_waitcnt vmcnt(0) per
+    // element: 40 serial round trips here); rows beyond M carry a valid row's coordinates, are never stored, and their
+    // right-hand side is masked to zero, so they contribute nothing
+    const int rowc = valid ? row : M - 1;
 #pragma unroll
-    for (int j = 0; j < JT; ++j)
-      a[r][j] = valid ? Z1[(size_t)row * ldz1 + j0 + j] * KF::pre : 0.f;
+    for (int j = 0; j < JT; ++j) a[r][j] = Z1[(size_t)rowc * ldz1 + j0 + j] * KF::pre;
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-      vrow[r][t] = (SYM && valid && t < tcnt) ? V[(size_t)row * ldv + t0 + t] : 0.f;
+      if constexpr (SYM) vrow[r][t] = V[(size_t)rowc * ldv + t0 + (t < tcnt ? t : 0)] * ((valid && t < tcnt) ? 1.f : 0.f);
+      else vrow[r][t] = 0.f;
       accR[r][t] = 0.f;
     }
   }
@@ -338,12 +342,16 @@ __global__ __launch_bounds__(256) void mvm_tile_kernel(
     if (tid < SC) {
       const int col = c0 + tid;
       const bool cv = col < c_end;
+      const int colc = cv ? col : N - 1;            // (same: clamped column, its right-hand side masked to zero)
+      float zc[JT], vc[TT];
 #pragma unroll
-      for (int j = 0; j < JT; ++j)
-        sB[tid * STR + j] = cv ? Z2[(size_t)col * ldz2 + j0 + j] * KF::pre : 0.f;
+      for (int j = 0; j < JT; ++j) zc[j] = Z2[(size_t)colc * ldz2 + j0 + j];
 #pragma unroll
-      for (int t = 0; t < TT; ++t)
-        sV[tid * TT + t] = (cv && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+      for (int t = 0; t < TT; ++t) vc[t] = V[(size_t)colc * ldv + t0 + (t < tcnt ? t : 0)];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) sB[tid * STR + j] = zc[j] * KF::pre;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) sV[tid * TT + t] = vc[t] * ((cv && t < tcnt) ? 1.f : 0.f);
     }
     __syncthreads();
     const int ncol = c_end - c0;
@@ -599,23 +607,27 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
 
   float2v ap[R][NP], ea[R][NP];
   float vrow[R][TT], accR[R][TT];
+  // Unconditional loads from clamped addresses, masked by a multiply: a load under a condition — or a select next to the
+  // load — compiles to a branch with its own s_waitcnt vmcnt(0), i.e. 20+ SERIAL round trips in this prologue and 10 per
+  // stage below (round 3, same-box A/B: T = 1 2.314 -> 2.278 ms, T = 11 block 3.26 -> 3.19 ms, N = 7372 T = 11 125 -> 117 us).
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = r0 + wave * (64 * R) + r * 64 + lane;
     const bool valid = row < N;
+    const int rowc = valid ? row : N - 1;
+    const float vm = valid ? 1.f : 0.f;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      float2v x0 = {0.f, 0.f}, x1 = {0.f, 0.f};
-      if (valid) {
-        x0 = rowdat[(size_t)row * J + j0 + 2 * p];
-        if (2 * p + 1 < JT) x1 = rowdat[(size_t)row * J + j0 + 2 * p + 1];
-      }
+      const float2v x0 = rowdat[(size_t)rowc * J + j0 + 2 * p];
+      float2v x1 = {0.f, 0.f};
+      if (2 * p + 1 < JT) x1 = rowdat[(size_t)rowc * J + j0 + 2 * p + 1];
       ap[r][p] = float2v{x0.x, x1.x};
-      ea[r][p] = float2v{x0.y, x1.y};     // invalid rows: Ea = 0 -> K = 0
+      ea[r][p] = float2v{x0.y * vm, x1.y * vm};     // invalid rows: Ea = 0 -> K = 0
     }
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-      vrow[r][t] = (valid && t < tcnt) ? V[(size_t)row * ldv + t0 + t] : 0.f;
+      const int tc = t < tcnt ? t : 0;
+      vrow[r][t] = V[(size_t)rowc * ldv + t0 + tc] * ((valid && t < tcnt) ? 1.f : 0.f);
       accR[r][t] = 0.f;
     }
   }
@@ -631,19 +643,33 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
         sB[tid * STR + 0] = x.x;
         sB[tid * STR + 1] = x.y;
       } else {
+        const int colc = cv ? col : N - 1;
+        const float cm = cv ? 1.f : 0.f, padv = cv ? 0.f : -1.0e30f;     // padded columns: b2 = 0, nb2 = -1e30 -> exp2 = 0
+        float2v y0[NP], y1[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          float2v x0 = {0.f, -1.0e30f}, x1 = {0.f, -1.0e30f};   // padded columns: exp2(-1e30) = 0
-          if (cv) {
-            x0 = coldat[(size_t)col * J + j0 + 2 * p];
-            if (2 * p + 1 < JT) x1 = coldat[(size_t)col * J + j0 + 2 * p + 1];
-          }
-          *reinterpret_cast<float4v *>(&sB[tid * STR + 4 * p]) = float4v{x0.x, x1.x, x0.y, x1.y};
+          y0[p] = coldat[(size_t)colc * J + j0 + 2 * p];
+          y1[p] = float2v{0.f, -1.0e30f};
+          if (2 * p + 1 < JT) y1[p] = coldat[(size_t)colc * J + j0 + 2 * p + 1];
         }
-      }
+        float vv[TT];
 #pragma unroll
-      for (int t = 0; t < TT; ++t)
-        sV[tid * TT + t] = (cv && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+        for (int t = 0; t < TT; ++t) vv[t] = V[(size_t)colc * ldv + t0 + (t < tcnt ? t : 0)];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const bool has1 = 2 * p + 1 < JT;
+          *reinterpret_cast<float4v *>(&sB[tid * STR + 4 * p]) =
+              float4v{y0[p].x * cm, has1 ? y1[p].x * cm : 0.f, __builtin_fmaf(y0[p].y, cm, padv),
+                      has1 ? __builtin_fmaf(y1[p].y, cm, padv) : -1.0e30f};
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) sV[tid * TT + t] = vv[t] * ((cv && t < tcnt) ? 1.f : 0.f);
+      }
+      if constexpr (JT == 1) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+          sV[tid * TT + t] = (cv && t < tcnt) ? V[(size_t)col * ldv + t0 + t] : 0.f;
+      }
     }
     __syncthreads();
     const int ncol = c_end - c0;
@@ -910,6 +936,21 @@ __device__ __forceinline__ long long symk_first_subtile(int rb, int N, int BR) {
   return (long long)rb * nsN - q * ((long long)rb * (rb - 1) / 2);
 }
 
+// JT scaled coordinates of point `n` (clamped to a valid row), or `pad` in every slot when !ok — ALWAYS loaded: a load under a
+// condition (or a select next to it) compiles to a branch with its own s_waitcnt vmcnt(0), one serial round trip per element.
+// The masking is arithmetic (z * m + padv) so that the optimiser cannot turn it back into a branch.
+template <int JT>
+__device__ __forceinline__ void load_coords_masked(const float *__restrict__ Z, int n, int N, int ldz, int j0, bool ok,
+                                                   float pad, float (&out)[JT]) {
+  const int nc = (ok && n < N) ? n : N - 1;
+  const float m = ok ? kExp2Scale : 0.f, padv = ok ? 0.f : pad;
+  float z[JT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) z[j] = Z[(size_t)nc * ldz + j0 + j];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) out[j] = __builtin_fmaf(z[j], m, padv);
+}
+
 template <int JT, int R>
 __global__ __launch_bounds__(256) void symk_build_kernel(const float *__restrict__ Z, float4v *__restrict__ cache, int N,
                                                          int ldz, int j0, int chunk_cols, int rotdir, int accumulate,
@@ -930,8 +971,7 @@ __global__ __launch_bounds__(256) void symk_build_kernel(const float *__restrict
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = r0 + wave * (64 * R) + r * 64 + lane;
-#pragma unroll
-    for (int j = 0; j < JT; ++j) a[r][j] = (row < N) ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 3.0e18f;
+    load_coords_masked<JT>(Z, row, N, ldz, j0, row < N, 3.0e18f, a[r]);
   }
   const long long g0 = symk_first_subtile(rb, N, BR) + (long long)kchunk * (chunk_cols / 64) - sub0;
   int sub = 0;
@@ -939,8 +979,10 @@ __global__ __launch_bounds__(256) void symk_build_kernel(const float *__restrict
     __syncthreads();
     if (tid < 64) {
       const int col = c0 + tid;
+      float bc[JT];
+      load_coords_masked<JT>(Z, col, N, ldz, j0, col < c_end, 1.0e18f, bc);
 #pragma unroll
-      for (int j = 0; j < JT; ++j) sB[tid * STR + j] = (col < c_end) ? Z[(size_t)col * ldz + j0 + j] * kExp2Scale : 1.0e18f;
+      for (int j = 0; j < JT; ++j) sB[tid * STR + j] = bc[j];
     }
     __syncthreads();
     float4v *dst = cache + ((size_t)((g0 + sub) * 4 + wave) * 16) * R * 64 + lane;
@@ -1184,8 +1226,10 @@ __global__ __launch_bounds__(256) void symk_build_tile_kernel(const float *__res
     __syncthreads();
     if (tid < 64) {
       const int col = c0 + tid;
+      float bc[JT];
+      load_coords_masked<JT>(Z, col, N, ldz, j0, col < c_end, 1.0e18f, bc);
 #pragma unroll
-      for (int j = 0; j < JT; ++j) sB[tid * STR + j] = (col < c_end) ? Z[(size_t)col * ldz + j0 + j] * kExp2Scale : 1.0e18f;
+      for (int j = 0; j < JT; ++j) sB[tid * STR + j] = bc[j];
     }
     __syncthreads();
     float4v *dst = cache + ((size_t)((g0 + sub) * 4 + wave) * 16) * R * 64 + lane;
@@ -1193,8 +1237,7 @@ __global__ __launch_bounds__(256) void symk_build_tile_kernel(const float *__res
     for (int rt = 0; rt < 4 * R; ++rt) {
       const int row = r0 + wave * (64 * R) + 16 * rt + rho;
       float a[JT];
-#pragma unroll
-      for (int j = 0; j < JT; ++j) a[j] = (row < N) ? Z[(size_t)row * ldz + j0 + j] * kExp2Scale : 3.0e18f;
+      load_coords_masked<JT>(Z, row, N, ldz, j0, row < N, 3.0e18f, a);
 #pragma nounroll
       for (int ct = 0; ct < 4; ++ct) {
         float4v kq;

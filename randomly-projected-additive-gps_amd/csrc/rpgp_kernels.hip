@@ -900,7 +900,15 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
     }
     if (sym) {
       const int bend = rb < rb1 ? rb : rb1;         // transposed products written by row blocks rb0 <= b < min(rb, rb1)
-      for (int b = rb0 + g; b < bend; b += kRedGroups) acc += (double)slabT[(size_t)(b - rb0) * N * T + gid];
+      int b = rb0 + g;                              // four entries in flight, added in the same order as the plain loop
+      for (; b + 3 * kRedGroups < bend; b += 4 * kRedGroups) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = slabT[(size_t)(b + u * kRedGroups - rb0) * N * T + gid];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (double)v[u];
+      }
+      for (; b < bend; b += kRedGroups) acc += (double)slabT[(size_t)(b - rb0) * N * T + gid];
     }
   }
   sacc[g][o] = acc;
@@ -1829,8 +1837,26 @@ __global__ __launch_bounds__(256) void bilinear_sym_reduce_kernel(const float *_
   const int rb = row / BR;
   const int nk = (N - rb * BR + chunk_cols - 1) / chunk_cols;
   double acc = 0.0;
-  for (int k = 0; k < nk; ++k) acc += (double)slabR[(size_t)k * slab_rows * W + gid];
-  for (int b = 0; b < rb; ++b) acc += (double)slabT[(size_t)b * N * W + gid];
+  // four slab entries requested together, added in slab order (a rolled `acc += load` loop waits for every load: up to
+  // ~110 serial round trips per output at N = 50k)
+  int k = 0;
+  for (; k + 3 < nk; k += 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = slabR[(size_t)(k + u) * slab_rows * W + gid];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += (double)v[u];
+  }
+  for (; k < nk; ++k) acc += (double)slabR[(size_t)k * slab_rows * W + gid];
+  int b = 0;
+  for (; b + 3 < rb; b += 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = slabT[(size_t)(b + u) * N * W + gid];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += (double)v[u];
+  }
+  for (; b < rb; ++b) acc += (double)slabT[(size_t)b * N * W + gid];
   if (q < JT) gZ[(size_t)row * ldg + j0 + q] = mulG * (float)acc;
   else rowS[row] = accumulate ? rowS[row] + (float)acc : (float)acc;
 }

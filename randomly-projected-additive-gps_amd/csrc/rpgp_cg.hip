@@ -356,12 +356,28 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
   __shared__ double sTv[256];
   __shared__ float salpha[kMaxT];
   const Lane ln;
+  // Every scalar this prologue needs is requested up front and pinned by one empty asm (hipcc otherwise sinks each load under
+  // the condition that uses it — eight dependent round trips, about half of this kernel's time at small N).  (`redA` of
+  // the set-up call holds the |rhs|^2 sums — valid memory, value unused; `Cinv` without a preconditioner is not a valid
+  // pointer: its load stays behind that condition.)
+  const int tcl = (int)threadIdx.x < TT ? (int)threadIdx.x : TT - 1;
+  const float q_rz = st->rz[cur][tcl], q_res = st->resid[tcl];
+  const int q_zero = st->rhs_zero[tcl], q_done = st->poll.done;
+  const double q_pap = redA[tcl];
+  const double q_wb = redB[kRedLt + threadIdx.x];
+  const double q_wa = redA[kRedLt + threadIdx.x];
+  double q_ci = 0.0;
+  {
+    const int kk0 = threadIdx.x >> 4, t0c = threadIdx.x & 15;
+    if (K > 0) q_ci = Cinv[(kk0 < K ? kk0 : K - 1) * K + (t0c < K ? t0c : K - 1)];
+  }
+  asm volatile("" ::"v"(q_rz), "v"(q_res), "v"(q_zero), "v"(q_done), "v"(q_pap), "v"(q_wb), "v"(q_wa), "v"(q_ci));
   if (threadIdx.x < kMaxT) {
     float a = 0.f;
     if (!first && threadIdx.x < TT) {
-      const float s = (float)redA[threadIdx.x];
-      a = (fabsf(s) > eps) ? st->rz[cur][threadIdx.x] / s : 0.f;
-      if (st->resid[threadIdx.x] < stop_after || st->rhs_zero[threadIdx.x] || st->poll.done) a = 0.f;
+      const float s = (float)q_pap;
+      a = (fabsf(s) > eps) ? q_rz / s : 0.f;
+      if (q_res < stop_after || q_zero || q_done) a = 0.f;
     }
     salpha[threadIdx.x] = a;
     if (blockIdx.x == 0 && !first && threadIdx.x < TT) alpha_out[threadIdx.x] = a;
@@ -371,11 +387,11 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
   if (K > 0) {
     const int kk = threadIdx.x >> 4, t = threadIdx.x & 15;
     // w = L^T r of the residual this pass is about to form: direct value of the previous pass, one recurrence step
-    double w = redB[kRedLt + threadIdx.x];
-    if (!first) w -= (double)salpha[t] * redA[kRedLt + threadIdx.x];
+    double w = q_wb;
+    if (!first) w -= (double)salpha[t] * q_wa;
     sW[threadIdx.x] = w;
     // Cinv through LDS: one load per thread (a loop of K dependent global loads cost ~10 us at the head of every workgroup)
-    sTv[threadIdx.x] = (kk < K && t < K) ? Cinv[kk * K + t] : 0.0;
+    sTv[threadIdx.x] = (kk < K && t < K) ? q_ci : 0.0;
     __syncthreads();
     double tv = 0.0;
     if (kk < K && t < TT) {
@@ -486,7 +502,16 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
   __shared__ float sres[kMaxT];
   __shared__ float srzn[kMaxT];
   const Lane ln;
-  const int was_done = first ? 0 : st->done_pp[cur];
+  // Every scalar this prologue needs is requested up front and pinned by one empty asm (hipcc otherwise sinks each load under
+  // the condition that uses it: six dependent round trips — most of the kernel's time at small N)
+  const int tcl = (int)threadIdx.x < TT ? (int)threadIdx.x : TT - 1;
+  const int done_raw = st->done_pp[cur];
+  const float snap_prev = st->snap_resid[cur];
+  const double q_rzn = redB[16 + tcl], q_rr = redB[tcl];
+  const float q_rz = st->rz[cur][tcl];
+  const int q_zero = st->rhs_zero[tcl];
+  asm volatile("" ::"v"(done_raw), "v"(snap_prev), "v"(q_rzn), "v"(q_rr), "v"(q_rz), "v"(q_zero));
+  const int was_done = first ? 0 : done_raw;
   // the poll record of a tested iteration goes straight to pinned host memory (a D2H copy per poll is a 4 us copy kernel)
   if (was_done && blockIdx.x == 0 && threadIdx.x == 0) {
     st->done_pp[cur ^ 1] = was_done;
@@ -498,10 +523,9 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
   if (threadIdx.x < kMaxT) {
     float beta = 0.f, res = 0.f, rzn = 0.f;
     if (threadIdx.x < TT) {
-      rzn = (float)redB[16 + threadIdx.x];
-      const float rz = st->rz[cur][threadIdx.x];
-      beta = (!first && fabsf(rz) > eps) ? rzn / rz : 0.f;
-      res = st->rhs_zero[threadIdx.x] ? 0.f : sqrtf((float)redB[threadIdx.x]);
+      rzn = (float)q_rzn;
+      beta = (!first && fabsf(q_rz) > eps) ? rzn / q_rz : 0.f;
+      res = q_zero ? 0.f : sqrtf((float)q_rr);
     }
     sbeta[threadIdx.x] = beta;
     sres[threadIdx.x] = res;
@@ -512,7 +536,6 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
   float mres = 0.f;
   for (int t = 0; t < TT; ++t) mres += sres[t];
   mres /= (float)TT;
-  const float snap_prev = st->snap_resid[cur];
   const bool improved = !first && check_now && mres == mres && mres < snap_prev;
   const float beta = sbeta[ln.c];
   const unsigned Nu = (unsigned)N;

@@ -1713,13 +1713,14 @@ __global__ __launch_bounds__(256, 2) void bilinear_sym_kernel(const float *__res
   for (int c0 = c_begin; c0 < c_end; c0 += 64) {
     __syncthreads();
     if constexpr (DMA) {
-      static_assert(STR == STRQ && (64 * STRQ) % 256 == 0, "linear subtile image in whole 256-element pieces");
-      constexpr int NST = 64 * STRQ / 256;
+      static_assert(STR == STRQ, "linear (unpadded) subtile image");
+      constexpr int NST = (64 * STRQ + 255) / 256;             // (the last piece may be partial: its tail lanes are masked off)
       const unsigned sc_bytes = (unsigned)(size_t)sC;
       const unsigned uw = __builtin_amdgcn_readfirstlane((unsigned)wave);
 #pragma unroll 1                                                 // (rolled: unrolled, the eleven address computations are hoisted
       for (int it = 0; it < NST; ++it) {                         //  together and spill; the DMAs need no wait between them)
         const int e = tid + 256 * it;
+        if (e >= 64 * STRQ) break;                              // (EXEC-masked lanes of a DMA do not write)
         const int c = e / STRQ, q = e % STRQ;
         const int col = c0 + c;
         const int colc = col < N ? col : N - 1;                 // clamped: every lane of the DMA reads a valid address
@@ -1736,7 +1737,7 @@ __global__ __launch_bounds__(256, 2) void bilinear_sym_kernel(const float *__res
         for (int it = 0; it < NST; ++it) {
           const int e = tid + 256 * it;
           const int c = e / STRQ, q = e % STRQ;
-          if (c0 + c >= c_end && q >= JT) sC[e] = 0.f;
+          if (e < 64 * STRQ && c0 + c >= c_end && q >= JT) sC[e] = 0.f;
         }
       }
     } else {
@@ -3766,8 +3767,10 @@ template <int JT>
 int launch_bilinear_sym(int tt, const TilePlan &p, const float *Z, const float *L, const float *R, float *slabR,
                                float *slabT, int N, int ldz, int T, int j0, hipStream_t st, float *Zs) {
   dim3 grid(p.total_wg), block(256);
-  if constexpr (JT == 20) {
-    // the 20-column piece stages its column records by LDS-DMA from a pre-scaled copy of Z (C4: 6.26 -> 5.87 ms alternating
+  // (JT + 8 or JT + 24 a multiple of 8 would pad the LDS records: JT = 8 keeps the register staging)
+  constexpr bool dma4 = !((JT + 8) % 4 == 0 && ((JT + 8) / 4) % 2 == 0), dma12 = !((JT + 24) % 4 == 0 && ((JT + 24) / 4) % 2 == 0);
+  if constexpr (dma4 && dma12) {
+    // the column records are staged by LDS-DMA from a pre-scaled copy of Z (20-column piece at C4: 6.26 -> 5.87 ms alternating
     // in one process, bit-identical results); RPGP_BIL_DMA=0 restores the register staging
     const char *ev = getenv("RPGP_BIL_DMA");
     if (Zs && !(ev && ev[0] == '0')) {

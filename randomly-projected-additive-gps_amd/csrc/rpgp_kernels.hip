@@ -2993,11 +2993,15 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
                                                               int J, int G, int T, float scale, float *__restrict__ rowC) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
+  // (loads from clamped indices, slots t >= T masked through li / ri = 0: a load under `t < T` compiles to a branch with its
+  //  own wait — 88 dependent round trips per projection in the loop below, which made this kernel latency-bound: 140 us at C5)
   float li[TT], ri[TT];
 #pragma unroll
   for (int t = 0; t < TT; ++t) {
-    li[t] = t < T ? L[i * T + t] : 0.f;
-    ri[t] = t < T ? Rm[i * T + t] : 0.f;
+    const int tc = t < T ? t : T - 1;
+    const float m = t < T ? 1.f : 0.f;
+    li[t] = L[i * T + tc] * m;
+    ri[t] = Rm[i * T + tc] * m;
   }
   float accS = 0.f;
   const int T2 = 2 * T;
@@ -3009,13 +3013,19 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float *hp = H + ((size_t)j * G + idx0 + k) * T2;   // [H_L (T) | H_R (T)]
+      float hl[TT], hr[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const int tc = t < T ? t : T - 1;
+        hr[t] = hp[T + tc];
+        hl[t] = hp[tc];
+      }
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int t = 0; t < TT; ++t)
-        if (t < T) {
-          a = __builtin_fmaf(li[t], hp[T + t], a);      // L . H_R
-          b = __builtin_fmaf(ri[t], hp[t], b);          // R . H_L
-        }
+      for (int t = 0; t < TT; ++t) {
+        a = __builtin_fmaf(li[t], hr[t], a);            // L . H_R
+        b = __builtin_fmaf(ri[t], hl[t], b);            // R . H_L
+      }
       gz = __builtin_fmaf(dw[k], a + b, gz);
       accj = __builtin_fmaf(w[k], a, accj);
     }

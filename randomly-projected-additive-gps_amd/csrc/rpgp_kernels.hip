@@ -3963,13 +3963,22 @@ inline long long symk_wg_subtile(const TilePlan &p, int64_t N, int lin) {
   }
   return symk_host_first_subtile(p.nrb, N, p.BR);
 }
-inline SymkPlan symk_plan(int64_t N, int world, int rank) {
+inline SymkPlan symk_plan(int64_t N, int world, int rank, bool wide = false) {
   SymkPlan sp;
   // A cached workgroup has no exponentials to hide its prologue (row block of V, ring start-up) and epilogue (slabs)
   // behind, so it wants longer column chunks than the fused sweep: measured optimum ~N / 14 workgroups per rank
   // (N = 15k: 1000, T = 11 product 0.152 ms against 0.199 ms with the fused sweep's 4600; N = 50k: 3600, 1.31 ms).
   double wgs = (double)N / 14.0;
   wgs = wgs < 512.0 ? 512.0 : (wgs > 4608.0 ? 4608.0 : wgs);
+  if (wide && world <= 1) {
+    // The matrix-core (wide) product keeps two workgroups per CU resident (512 slots) and a workgroup's prologue / slabs cost
+    // more than in the thin form: up to N ~ 28k ONE round of ~500 long workgroups wins, above that ~N / 28 (late round 3,
+    // same-process sweeps, T = 11 product + slab reduce: N = 11k 81 -> 67 us, 15k 120 -> 111, 20k 188 -> 173, 25k 279 -> 252,
+    // 35k 506 -> 487, 50k 952 -> 937).  The subtile layout of the cache depends on N only, so the build and the product of a
+    // whole (unsharded) cache may be chunked differently; sharded caches keep one rule for both (their byte ranges follow it).
+    wgs = N <= 28000 ? 500.0 : (double)N / 28.0;
+    wgs = wgs < 500.0 ? 500.0 : (wgs > 4608.0 ? 4608.0 : wgs);
+  }
   sp.p = make_plan(N, N, true, 12, world, rank, false, 0, wgs);      // R = 2 from N = 4096 up (the wide-block rule), whatever T is later
   sp.sub0 = symk_wg_subtile(sp.p, N, sp.p.w0);
   sp.sub1 = symk_wg_subtile(sp.p, N, sp.p.w1);
@@ -4676,7 +4685,7 @@ int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, int layout, const f
     return RPGP_EINVAL;
   const int irc = rpgp_init();
   if (irc) return irc;
-  const SymkPlan sp = symk_plan(N, world, rank);
+  const SymkPlan sp = symk_plan(N, world, rank, layout == RPGP_SYMCACHE_WIDE);
   if (cache_bytes < symk_bytes(sp)) return RPGP_EINVAL;
   const TilePlan &p = sp.p;
   const size_t need = plan_workspace_floats(p, N, T, true) * sizeof(float);

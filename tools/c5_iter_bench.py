@@ -20,11 +20,12 @@ if shape == "C5":
     khat = AddedDiagOperator(base, torch.tensor(0.5, device=dev))
     noise = 0.5
 else:
-    N, J = {"C2": (7372, 20), "C3": (14939, 20)}.get(shape, (50000, 20))
+    N, J = {"C2": (7372, 20), "C3": (14939, 20), "C2cache": (7372, 20), "C3cache": (14939, 20), "N11cache": (11000, 20),
+            "N20cache": (20000, 20), "N25cache": (25000, 20), "N35cache": (35000, 20)}.get(shape, (50000, 20))
     Z = (torch.randn(N, J, generator=g)).to(dev)
     base = AdditiveRPOperator(Z, None, torch.tensor(1.0, device=dev), 1.0 / J)
     noise = 0.1
-    if shape == "C4cache":
+    if shape.endswith("cache"):
         khat = SymCachedOperator(base.to_symcache(wide=T > 4), base._scale, noise, diag_value=base._scale * J)
     else:
         khat = AddedDiagOperator(base, torch.tensor(noise, device=dev))

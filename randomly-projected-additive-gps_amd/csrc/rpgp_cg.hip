@@ -754,9 +754,12 @@ int apply_operator(const rpgp_operator *op, const ShardCtx &sh, const float *V, 
       if (sh.mode == RPGP_SHARD_ROWS) {
         const size_t nh = (size_t)op->J * op->G * T;
         if (op->N > 0) {
+          // (the planned scatter answers RPGP_EWORKSPACE when its per-item scratch exceeds the plan's slab — rpgp.h: "fall
+          //  back to rpgp_ski_scatter" — so the executor does exactly that instead of failing the solve)
           rc = op->prep ? rpgp_ski_scatter_planned(op->prep, V, sh.hist, op->N, op->J, op->G, T, ws, ws_bytes, stream)
-                        : rpgp_ski_scatter(op->Z, op->grid_params, V, sh.hist, op->N, op->ldz, op->J, op->G, T, ws, ws_bytes,
-                                           stream);
+                        : RPGP_EWORKSPACE;
+          if (rc == RPGP_EWORKSPACE)
+            rc = rpgp_ski_scatter(op->Z, op->grid_params, V, sh.hist, op->N, op->ldz, op->J, op->G, T, ws, ws_bytes, stream);
           if (rc) return rc;
         } else {
           CG_CHECK(hipMemsetAsync(sh.hist, 0, nh * sizeof(double), reinterpret_cast<hipStream_t>(stream)));
@@ -769,10 +772,11 @@ int apply_operator(const rpgp_operator *op, const ShardCtx &sh, const float *V, 
         return rpgp_ski_gather_fast(op->prep, op->Z, op->grid_params, sh.H, V, out, op->N, op->ldz, op->J, op->G, T, op->scale,
                                     op->noise, stream);
       }
+      rc = RPGP_EWORKSPACE;
       if (op->prep && T <= 12)
         rc = rpgp_ski_mvm_planned(op->prep, op->Z, op->grid_params, V, out, op->N, op->ldz, op->J, op->G, T, op->scale, noise,
                                   ws, ws_bytes, stream);
-      else
+      if (rc == RPGP_EWORKSPACE)    // no plan, a wide block, or a plan whose scratch bound is exceeded (large N J, small G)
         rc = rpgp_ski_mvm(op->Z, op->Z, op->grid_params, V, out, op->N, op->N, op->ldz, op->ldz, op->J, op->G, T, op->scale,
                           noise, ws, ws_bytes, stream);
       break;

@@ -14,8 +14,9 @@
 //                                  writes the reduced chunk into every peer's result[b]; flagsB; wait; copy result -> buf.
 //                                  Each link carries 2/W of the message instead of all of it.
 // A stage may be overwritten two calls later: by then every peer has published call s + 1, which it does only after it
-// finished reading call s.  Waits are bounded (kTimeoutNs): a lost peer sets the comm's error word instead of hanging
-// the GPU; the next host-side call reports it.
+// finished reading call s.  Waits are bounded (kTimeoutTicks): a lost peer sets the comm's error word instead of hanging
+// the GPU AND the kernel writes NaN into the caller's buffer, so the result can never pass for a sum; the host side reports
+// the error word after every sharded solve / MLL evaluation (Reducer.check).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -62,14 +63,19 @@ __device__ __forceinline__ void publish(char *const *peers, int world, int rank,
   }
 }
 
-// every thread of the block returns once all peers' flags (in THIS rank's memory) have reached seq
-__device__ __forceinline__ void wait_all(char *mine, int world, size_t flag_off, uint32_t seq) {
+// every thread of the block returns once all peers' flags (in THIS rank's memory) have reached seq; false when a wait ran
+// into its bound (the error word is set; the caller poisons its output so that a missed host-side check cannot pass)
+__device__ __forceinline__ bool wait_all(char *mine, int world, size_t flag_off, uint32_t seq) {
+  __shared__ int timed_out;
+  if (threadIdx.x == 0) timed_out = 0;
+  __syncthreads();
   if ((int)threadIdx.x < world) {
     uint32_t *f = reinterpret_cast<uint32_t *>(mine + flag_off) + threadIdx.x;
     const long long t0 = wall_clock64();
     while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       if (wall_clock64() - t0 > kTimeoutTicks) {
         reinterpret_cast<FlagBlock *>(mine)->error = 1;
+        timed_out = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(8);
@@ -77,6 +83,15 @@ __device__ __forceinline__ void wait_all(char *mine, int world, size_t flag_off,
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");        // system scope: peers' data written before their flag is visible
+  const bool ok = timed_out == 0;
+  __syncthreads();                                     // (the flag is reused by the next wait of the same launch)
+  return ok;
+}
+
+template <typename T>
+__device__ __forceinline__ void poison(T *buf, size_t count, size_t gtid, size_t gsz) {
+  const T nan = (T)__builtin_nanf("");
+  for (size_t i = gtid; i < count; i += gsz) buf[i] = nan;
 }
 
 // the last workgroup to arrive publishes; `counter` returns to 0 for the next call
@@ -105,7 +120,10 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(char *const *pee
   const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
   for (size_t i = gtid; i < count; i += gsz) stage[i] = buf[i];
   arrive_and_publish(counter, peers, world, rank, offsetof(FlagBlock, a), seq);
-  wait_all(mine, world, offsetof(FlagBlock, a), seq);
+  if (!wait_all(mine, world, offsetof(FlagBlock, a), seq)) {
+    poison(buf, count, gtid, gsz);          // a peer never published: NaN, not a sum of stale stages
+    return;
+  }
   for (size_t i = gtid; i < count; i += gsz) {
     T s = reinterpret_cast<const T *>(peers[0] + stage_off)[i];
     for (int p = 1; p < world; ++p) s += reinterpret_cast<const T *>(peers[p] + stage_off)[i];
@@ -122,17 +140,24 @@ __global__ __launch_bounds__(256) void allreduce_twoshot_kernel(char *const *pee
   const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
   for (size_t i = gtid; i < count; i += gsz) stage[i] = buf[i];
   arrive_and_publish(counters, peers, world, rank, offsetof(FlagBlock, a), seq);
-  wait_all(mine, world, offsetof(FlagBlock, a), seq);
+  const bool ok_a = wait_all(mine, world, offsetof(FlagBlock, a), seq);
+  // (after a timeout this rank still delivers its flag below so that the peers are not held for their own full bound; what
+  //  it delivers is marked by NaN)
   // my chunk: a contiguous 1/world of the elements
   const size_t per = (count + world - 1) / world;
   const size_t c0 = per * rank < count ? per * rank : count, c1 = c0 + per < count ? c0 + per : count;
   for (size_t i = c0 + gtid; i < c1; i += gsz) {
     T s = reinterpret_cast<const T *>(peers[0] + stage_off)[i];
     for (int p = 1; p < world; ++p) s += reinterpret_cast<const T *>(peers[p] + stage_off)[i];
+    if (!ok_a) s = (T)__builtin_nanf("");
     for (int p = 0; p < world; ++p) reinterpret_cast<T *>(peers[p] + result_off)[i] = s;
   }
   arrive_and_publish(counters + 1, peers, world, rank, offsetof(FlagBlock, b), seq);
-  wait_all(mine, world, offsetof(FlagBlock, b), seq);
+  const bool ok_b = wait_all(mine, world, offsetof(FlagBlock, b), seq);
+  if (!ok_a || !ok_b) {
+    poison(buf, count, gtid, gsz);
+    return;
+  }
   const T *res = reinterpret_cast<const T *>(mine + result_off);
   for (size_t i = gtid; i < count; i += gsz) buf[i] = res[i];
 }

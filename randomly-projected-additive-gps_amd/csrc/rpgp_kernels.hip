@@ -2521,8 +2521,14 @@ __global__ __launch_bounds__(64) void ski_grid_finish_proj_kernel(const float *_
   if (!(range > 1e-12f)) range = 1e-12f;
   const bool finite = (mx - mn == mx - mn);
   const float spacing = range / (float)(G - 4);
-  const float b0 = mn - 2.01f * spacing, b1 = mx + 2.01f * spacing;
-  const float h = finite ? (b1 - b0) / (float)(G - 1) : (mx - mn);
+  const float b0 = mn - 2.01f * spacing;
+  // h from the clamped spacing, not from b1 - b0: for a constant column (mn == mx) the 2.01 spacing margins round away next
+  // to |mn| in fp32, b1 - b0 = 0 and 1/h = inf turned every product of the operator into NaN; the floor keeps b0 + k h
+  // distinct grid points at the magnitude of the coordinates.  (b1 - b0) / (G - 1) = spacing (G - 4 + 4.02) / (G - 1).
+  float h = spacing * ((float)(G - 4) + 4.02f) / (float)(G - 1);
+  const float hmin = fmaxf(fabsf(mn), fabsf(mx)) * 2.4e-7f;
+  if (h < hmin) h = hmin;
+  if (!finite) h = mx - mn;
   gp[4 + j] = 1.0f;                             // weight slot (ones until the host sets flags |= 1 and fills them)
   float *gj = gp + 4 + J + 3 * j;
   gj[0] = b0;

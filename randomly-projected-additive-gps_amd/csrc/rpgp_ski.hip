@@ -295,7 +295,8 @@ __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__res
                                                               float scale, float noise) {
   extern __shared__ float sH[];              // [J][G][T]
   const int nH = J * G * T;
-  // nH = J G T is a multiple of 8 (G >= 8): float4 granules, 16 independent 16-byte loads per thread in flight
+  // float4 granules, 16 independent 16-byte loads per thread in flight (the launcher takes this kernel only when
+  // nH = J G T is a multiple of 4: odd G or T with an odd J would read past H and write past the LDS allocation)
   for (int e0 = threadIdx.x * 4; e0 < nH; e0 += 16 * 4096) {
     float4 q[16];
 #pragma unroll
@@ -375,7 +376,7 @@ int gather_planned(const PlanView *pv, const float *Z, const float *gp, const fl
   (void)pv;
   const size_t lds = (size_t)J * G * T * sizeof(float);
   static const int mode = [] { const char *e = getenv("RPGP_SKI_GATHER"); return e ? atoi(e) : 0; }();   // 3: never the LDS form
-  if (T > 1 && T <= 12 && lds <= kGatherLdsMax && M >= 32768 && mode != 3) {
+  if (T > 1 && T <= 12 && lds <= kGatherLdsMax && M >= 32768 && mode != 3 && ((size_t)J * G * T) % 4 == 0) {
     static bool attr_set = false;
     if (!attr_set) {
       bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(ski_gather_lds_kernel<1, 4>),

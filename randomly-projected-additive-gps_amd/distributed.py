@@ -170,7 +170,7 @@ class Reducer:
         self.backend = backend if (self.world_size > 1 or (force and self.active)) else "none"
         self._comm = None
         self._cb = None
-        self._keep = {}
+        self._ws = None
         if self.backend == "ipc":
             self._init_ipc(max_bytes, device)
         elif self.backend not in ("rccl", "none"):
@@ -231,26 +231,35 @@ class Reducer:
         if self.backend == "ipc":
             fn = ctypes.cast(self._lib.rpgp_comm_allreduce, ctypes.c_void_p).value
             return fn, self._comm.value
-        group = self.group
-        base = workspace.data_ptr()
-        nbytes = workspace.numel()
+        # ONE callback per Reducer (created on first use); the workspace it may touch is mutable state set before every
+        # solve — a fresh closure per solve would pin every superseded grow-only workspace for the life of the process
+        self._ws = workspace
+        if self._cb is None:
+            group = self.group
 
-        def _cb(ctx, buf, count, dtype, stream):
-            try:
-                esz = 8 if dtype == _lib.RPGP_F64 else 4
-                off = int(buf) - base
-                if off < 0 or off + count * esz > nbytes:
+            def _cb(ctx, buf, count, dtype, stream):
+                try:
+                    ws = self._ws
+                    esz = 8 if dtype == _lib.RPGP_F64 else 4
+                    off = int(buf) - ws.data_ptr()
+                    if off < 0 or off + count * esz > ws.numel():
+                        return _lib.RPGP_EINVAL
+                    cur = torch.cuda.current_stream(ws.device).cuda_stream if ws.is_cuda else 0
+                    if ws.is_cuda and int(stream or 0) != int(cur):
+                        return _lib.RPGP_EINVAL         # the collective is ordered on torch's current stream only
+                    view = ws[off:off + count * esz].view(torch.float64 if dtype == _lib.RPGP_F64 else torch.float32)
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+                    return 0
+                except Exception:                       # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
                     return _lib.RPGP_EINVAL
-                view = workspace[off:off + count * esz].view(torch.float64 if dtype == _lib.RPGP_F64 else torch.float32)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
-                return 0
-            except Exception:                       # never let an exception cross the C boundary
-                import traceback
-                traceback.print_exc()
-                return _lib.RPGP_EINVAL
-        cb = _lib.ALLREDUCE_FN(_cb)
-        self._keep[id(cb)] = cb                     # the executor call outlives this frame
-        return ctypes.cast(cb, ctypes.c_void_p).value, None
+            self._cb = _lib.ALLREDUCE_FN(_cb)
+        return ctypes.cast(self._cb, ctypes.c_void_p).value, None
+
+    def release_workspace(self):
+        """Drop the reference to the executor's workspace once its solve has returned (the executor has synchronised)."""
+        self._ws = None
 
     def close(self):
         if self._comm is not None:

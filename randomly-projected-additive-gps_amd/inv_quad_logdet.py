@@ -24,6 +24,14 @@ def _probe_generator(device):
     return None
 
 
+def _check_comm(op):
+    """Sharded operators: report a bounded wait of the IPC all-reduce that ran out (Reducer.check) — the kernel has already
+    poisoned the result with NaN; this turns it into an exception on the rank that saw it."""
+    for sh in (getattr(op, "shard", None), getattr(op, "row_shard", None)):
+        if sh is not None and getattr(sh, "world_size", 1) > 1:
+            sh.reducer.check()
+
+
 def use_cholesky(N):
     return N <= settings.max_cholesky_size.value() or not settings.fast_computations.log_prob()
 
@@ -137,6 +145,8 @@ class InvQuadLogDet(torch.autograd.Function):
         ctx.num_probes = num_probes
         probe_solves = solves[:, :num_probes] * probe_norms          # Khat^-1 z_p
         ctx.save_for_backward(probe_solves, probes, alpha)
+        if sharded:
+            _check_comm(op)
         return inv_quad, logdet
 
     @staticmethod
@@ -177,6 +187,7 @@ class InvQuadLogDet(torch.autograd.Function):
             gn = gn.reshape(())
         if gw is not None:
             gw = gw.reshape(ctx.op.comp_weights.shape).to(ctx.op.comp_weights.dtype)
+        _check_comm(op)
         return gZ, gs, gn, gr, None, gw
 
 
@@ -239,6 +250,7 @@ def _row_sharded_forward(ctx, Z, noise, r, op, num_probes):
     ctx.pre = pre
     ctx.num_probes = num_probes
     ctx.save_for_backward(solves[:, :num_probes] * probe_norms, probes, alpha)
+    _check_comm(op)
     return inv_quad, logdet
 
 
@@ -268,6 +280,7 @@ def _row_sharded_backward(ctx, g_inv_quad, g_logdet):
         gn = gn.reshape(())
     if gw is not None:
         gw = gw.reshape(op.comp_weights.shape).to(op.comp_weights.dtype)
+    _check_comm(op)
     return gZ, gs, gn, gr, None, gw
 
 

@@ -973,6 +973,11 @@ def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_ev
                                  float(sigma2), red_ref,
                                  ah.ctypes.data, bh.ctypes.data, ctypes.byref(iters), ctypes.byref(mres),
                                  ws.data_ptr(), ws.numel(), _stream())
+    if sharding is not None:
+        # the executor has synchronised: the reducer's workspace reference can go, and a bounded wait of the IPC backend
+        # that ran out (a peer stalled on the host for longer than the bound) surfaces HERE, not as silently wrong numbers
+        sharding[1].release_workspace()
+        sharding[1].check()
     if rc == _lib.RPGP_ENUMERIC:
         raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
     _lib.check(rc, "rpgp_mbcg_solve")

@@ -94,7 +94,11 @@ def test_predictive_mean_and_variance(gpu_device, N, chol):
     from rpgp_amd import settings
     prob, model, lik, mll = _gpu_model(gpu_device, N, 8, 20, 2, 0.15)
     X, y, P, ls, noise, s = prob
-    ref = _oracle_gp(X, y, P, ls, noise, s)
+    # the oracle at the hyper-parameters as the float32 model holds them (softplus of float32 raw values): a predictive
+    # variance is a difference of O(1) terms cancelling to ~1e-2, so a 1e-7 difference in sigma^2 would show at 1e-5
+    ref = orc.DenseExactGP(X.numpy(), y.numpy(), P.numpy(),
+                           model.covar_module.base_kernel.lengthscale.detach().double().cpu().reshape(-1).numpy(),
+                           float(model.covar_module.outputscale), float(lik.noise), mean=float(model.mean_module.constant))
     Xs = torch.randn(101, 8, generator=torch.Generator().manual_seed(5))
     ys = torch.sin(Xs).sum(1)
     mean_ref, cov_ref = ref.predict(Xs.numpy(), full_cov=True)
@@ -105,7 +109,9 @@ def test_predictive_mean_and_variance(gpu_device, N, chol):
         var = out.variance.cpu().numpy()
         nll = -mll(out, ys.to(gpu_device)).item()
     assert np.linalg.norm(mean - mean_ref) / np.linalg.norm(mean_ref) < 1e-4
-    assert np.linalg.norm(var - np.diag(cov_ref)) / np.linalg.norm(np.diag(cov_ref)) < 1e-4 * (1 if chol else 5)
+    # north_star's 1e-4 in BOTH regimes (round 3 accepted 5e-4 in the CG regime; tests/test_baseline_sizes_gpu.py holds the
+    # same gate at the BASELINE sizes)
+    assert np.linalg.norm(var - np.diag(cov_ref)) / np.linalg.norm(np.diag(cov_ref)) < 1e-4
     assert abs(nll - ref.test_nll(Xs.numpy(), ys.numpy())) < 1e-3 * abs(nll) + 1e-4
 
 

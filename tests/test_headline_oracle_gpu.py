@@ -1,6 +1,7 @@
 """What bench.py times, oracle-checked at the size it times it (BASELINE config C4: N = 50 000, d = 20, J = 20, bench
 seeds).  Three 256-row blocks of  K[rows, :] @ V + sigma^2 V[rows]  — first, middle (straddling a 512-row tile
-boundary) and last (the ragged tail: 50 000 = 97 * 512 + 336) — are evaluated in FLOAT64 numpy from the reference's
+boundary) and last (the ragged tail: 50 000 = 97 * 512 + 336) — plus a seeded random sample of 256 rows spread over
+every row-block class (so that no interior tile can be wrong unseen) are evaluated in FLOAT64 numpy from the reference's
 formula (gp_models/kernels/memory_efficient_gam_kernel.py:20-30: sum_j exp(-0.5 (z_ij - z_i'j)^2)) and every product on the
 path is compared with them through the C-ABI: the prepared kernel `mvm_fact_kernel` (T = 1: the benchmark's launch, and
 the T = 11 training block), the direct kernel, the packed symmetric cache in both layouts, the dense cached-K stream, and
@@ -17,6 +18,8 @@ pytestmark = pytest.mark.gpu
 N, D, J = 50000, 20, 20
 SCALE, NOISE = 1.0 / J, 0.1
 BLOCKS = [(0, 256), (24960, 25216), (N - 256, N)]
+RANDOM_ROWS = np.sort(np.random.default_rng(20250104).choice(N, size=256, replace=False))
+ROW_SETS = [np.arange(a, b) for a, b in BLOCKS] + [RANDOM_ROWS]
 
 
 def _rows_ref(Zh, rows, V):
@@ -45,8 +48,7 @@ def c4(gpu_device):
     Zh = Z.double().cpu().numpy()                       # the oracle runs on the SAME projected inputs as the kernels
     Vh = V.double().cpu().numpy()
     refs = []
-    for a, b in BLOCKS:
-        rows = np.arange(a, b)
+    for rows in ROW_SETS:
         ref, _ = _rows_ref(Zh, rows, Vh)
         refs.append((rows, ref))
     return {"Z": Z, "V": V, "Zh": Zh, "Vh": Vh, "refs": refs}
@@ -70,6 +72,22 @@ def test_prepared_kernel_bench_launch_t1_and_t11(c4):
     V = c4["V"]
     _check(ops.mvm_sym_prepared(prep, V[:, :1].contiguous(), SCALE, NOISE), c4["refs"], slice(0, 1), "prepared T=1")
     _check(ops.mvm_sym_prepared(prep, V, SCALE, NOISE), c4["refs"], slice(0, 11), "prepared T=11")
+
+
+def test_bench_launch_every_row_against_the_c_oracle(c4):
+    """ALL 50 000 output rows of the benchmark's launch against the float64 C/OpenMP restatement (oracle/cmvm.c: the full
+    2.5e9-entry kernel matrix, 5e10 exponentials — seconds on the GPU box's host cores): no tile of the decomposition is
+    left unchecked."""
+    from oracle import cmvm
+    from rpgp_amd import ops
+    ref = cmvm.mvm(c4["Zh"], c4["Zh"], c4["Vh"][:, :1], SCALE, NOISE)
+    prep = ops.Prepared(c4["Z"])
+    out = ops.mvm_sym_prepared(prep, c4["V"][:, :1].contiguous(), SCALE, NOISE).double().cpu().numpy()
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 1e-5
+    assert np.abs(out - ref).max() < 1e-5 * np.abs(ref).max()
+    # ... and the row subsets used by the other tests are the same numbers the numpy formula gives
+    for rows, r in c4["refs"]:
+        assert np.abs(ref[rows] - r[:, :1]).max() < 1e-11 * np.abs(r).max()
 
 
 def test_direct_kernel_t1_and_t11(c4):
@@ -112,9 +130,10 @@ def test_dense_cached_k_stream(c4):
     from rpgp_amd import ops
     Kd = ops.dense(c4["Z"], c4["Z"], SCALE, pad=True)
     # the stored entries themselves on the three row blocks
-    for (rows, _), (a, b) in zip(c4["refs"], BLOCKS):
+    for rows, _ in c4["refs"]:
         _, K = _rows_ref(c4["Zh"], rows[:32], c4["Vh"])
-        assert np.abs(Kd[a:a + 32].double().cpu().numpy() - SCALE * K).max() < 2e-6
+        got = Kd.index_select(0, torch.from_numpy(rows[:32]).to(Kd.device))[:, :N]
+        assert np.abs(got.double().cpu().numpy() - SCALE * K).max() < 2e-6
     V = c4["V"]
     _check(ops.dense_mvm(Kd, V[:, :1].contiguous(), NOISE), c4["refs"], slice(0, 1), "dense T=1")
     _check(ops.dense_mvm(Kd, V, NOISE), c4["refs"], slice(0, 11), "dense T=11")

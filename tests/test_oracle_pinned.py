@@ -144,3 +144,28 @@ def test_ski_sparse_oracle_equals_dense_oracle():
     Z1 = rng.standard_normal((90, J)) * 0.5
     Kr = sko.dense_kernel(Z1, Z, 0.7, G, grid)
     np.testing.assert_allclose(sko.mvm_sparse(Z1, Z, V, 0.7, G, grid), Kr @ V, rtol=1e-11, atol=1e-11)
+
+
+def test_c_oracle_matches_reference_golden_and_numpy_oracle():
+    """oracle/cmvm.c (the C/OpenMP restatement the BASELINE-size GPU parity tests call) reproduces the reference-generated
+    GAMFunction golden matrices and the numpy oracle's products; the dense-GP oracle's switch to it does not change K."""
+    from oracle import cmvm
+    g = np.load(os.path.join(GOLD, "gam.npz"))
+    for name in g["names"]:
+        x1, x2, ls = g[name + "_x1"], g[name + "_x2"], np.asarray(g[name + "_ls"], dtype=np.float64).reshape(1, -1)
+        np.testing.assert_allclose(cmvm.kernel(x1 / ls, x2 / ls), g[name + "_K"], rtol=1e-12, atol=1e-14)
+    rng = np.random.default_rng(11)
+    Z, Z2 = rng.standard_normal((1300, 20)), rng.standard_normal((411, 20))       # spans the 1024-column tile edge
+    V = rng.standard_normal((1300, 5))
+    np.testing.assert_allclose(cmvm.kernel(Z2, Z, 0.3), 0.3 * orc.additive_rbf(Z2, Z), rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(cmvm.mvm(Z, Z, V, 0.05, 0.1), orc.mvm(Z, Z, V, 0.05, 0.1), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(cmvm.mvm(Z2, Z, V[:, 0], 0.05), orc.mvm(Z2, Z, V[:, :1], 0.05)[:, 0], rtol=1e-12, atol=1e-12)
+    X, P, ls = rng.standard_normal((600, 6)), rng.standard_normal((6, 7)), rng.uniform(1, 2, 6)
+    big = orc.BIG_PAIR_TERMS
+    try:
+        K_np = orc.kernel_matrix(X, X, P, ls, 0.9, weight=1.0, inner_lengthscale=np.log(2.0))
+        orc.BIG_PAIR_TERMS = 0.0
+        K_c = orc.kernel_matrix(X, X, P, ls, 0.9, weight=1.0, inner_lengthscale=np.log(2.0))
+    finally:
+        orc.BIG_PAIR_TERMS = big
+    np.testing.assert_allclose(K_c, K_np, rtol=1e-13, atol=1e-14)

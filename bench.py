@@ -6,6 +6,11 @@ inputs (Z = projected inputs, v) resident in HBM.  With --gpus N>1 (launched thr
 per GPU) the J=20 additive terms are sharded across ranks and the length-N partials are summed with one RCCL
 all-reduce per step (north_star): total work is fixed -> "scaling": "strong".
 
+`--comm ipc` sums the partials with rpgp_comm (one-shot kernel over IPC-mapped peer buffers) instead of RCCL, and
+`--all-ranks-on-device 0` puts every rank on ONE GPU (gloo bootstrap + rpgp_comm — RCCL refuses two ranks per device): the
+complete N>1 path (rank launch, sharded kernels, all-reduce, MAX-reduced timings, the JSON line with per-rank kernel and
+all-reduce times) runs on the one-GPU test box (tests/test_bench_multirank_gpu.py), labelled "not a scaling measurement".
+
 One JSON line is printed by rank 0.  Extra objects:
   roofline     : dense-equivalent algorithmic bytes B_alg = 4N^2 + 4N(d+2T) / mean duration of the
                  dominant kernel (mvm_tile_kernel), measured with HIP events on the launch stream (rpgp_profile_*).
@@ -48,6 +53,16 @@ def main():
     ap.add_argument("--direct", action="store_true", help="use the exact direct kernel instead of the factorised path")
     ap.add_argument("--no-extras", action="store_true", help="skip the T=11 block / full-solve context numbers")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
+    ap.add_argument("--comm", choices=["rccl", "ipc"], default=None,
+                    help="all-reduce of the sharded step: rccl (torch.distributed 'nccl' = RCCL over xGMI; default on a "
+                         "multi-GPU node) or ipc (rpgp_comm: one-shot kernel over IPC-mapped peer buffers; the default — and "
+                         "the only choice — with --all-ranks-on-device, because RCCL refuses two ranks per device)")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None, metavar="D",
+                    help="run every rank on device D (one-GPU box): exercises the complete --gpus N code path — rank launch, "
+                         "sharded kernels, all-reduce, MAX-reduced timings — but the ranks SHARE one GPU, so the line is marked "
+                         "'not a scaling measurement'")
+    ap.add_argument("--dump-result", default=None, metavar="PATH",
+                    help="rank 0 saves the (all-reduced) product of the last step as .npy (tests/ compare it with the oracle)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (gloo, no GPU work): every rank joins, one all-reduce, rank 0 prints the world "
                          "size; used by tests/ to cover the --gpus launcher on machines without GPUs")
@@ -83,17 +98,26 @@ def main():
             print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "allreduce": float(t[0])}))
         dist.destroy_process_group()
         return
+    one_dev = args.all_ranks_on_device
+    comm = args.comm or ("ipc" if one_dev is not None else "rccl")
+    if one_dev is not None and comm != "ipc":
+        raise SystemExit("bench.py: --all-ranks-on-device needs --comm ipc (RCCL refuses several ranks on one device)")
+    dev_index = one_dev if one_dev is not None else (local_rank if world > 1 else 0)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if one_dev is not None:
+            # bootstrap / barrier / MAX-reduce of the timings over gloo (host); the data path is rpgp_comm on the device
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
     from rpgp_amd import ops, _lib
-    from rpgp_amd.distributed import JShard
+    from rpgp_amd.distributed import JShard, Reducer
 
     N, d, J, T = args.n, args.d, args.J, args.T
     X, P, ls, V = make_inputs(N, d, J, T, device)
@@ -119,16 +143,34 @@ def main():
             return ops.mvm_sym_prepared(prep, V, scale, nz, j0=j0, j1=j1, out=o, shard=ps)
         return ops.mvm_sym(Z, V, scale, nz, j0=j0, j1=j1, out=o, shard=ps)
 
-    def step():
+    # the all-reduce of the sharded step: RCCL through torch.distributed, or rpgp_comm (csrc/rpgp_comm.hip)
+    reducer = None
+    if world > 1:
+        reducer = Reducer(backend=comm, max_bytes=max(1 << 22, 4 * N * T), device=device)
+    ar_events = []
+
+    def step(timed=False):
         if world == 1:
             return local(0, J, noise, out)
-        return shard.sharded_mvm(lambda j0, j1, nz: local(j0, j1, nz), V, noise)
+        # this rank's partial (its J-slice or its share of the tile pairs; the noise term on rank 0 only), then ONE
+        # all-reduce of the N x T partial on the same stream
+        partial = local(shard.j0, shard.j1, noise if rank == 0 else 0.0)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reducer.all_reduce_(partial)
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            reducer.all_reduce_(partial)
+        return partial
 
     for _ in range(args.warmup):
         res = step()
 
     def fence():
         if world > 1:
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -137,18 +179,30 @@ def main():
     _lib.check(lib.rpgp_profile_begin(), "rpgp_profile_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        res = step(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
     import ctypes
     avg_ms, cnt = ctypes.c_float(0), ctypes.c_int(0)
     _lib.check(lib.rpgp_profile_end(ctypes.byref(avg_ms), ctypes.byref(cnt)), "rpgp_profile_end")
+    per_rank = None
     if world > 1:
-        tt = torch.tensor([elapsed, avg_ms.value], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(tt[0]), float(tt[1])
+        if reducer is not None:
+            reducer.check()
+        ar_us = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) * 1e3
+        on = device if one_dev is None else torch.device("cpu")       # (gloo group: host tensors)
+        mine = torch.tensor([elapsed, avg_ms.value, ar_us], device=on, dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        tt = torch.stack(allv).cpu()
+        elapsed, kernel_ms = float(tt[:, 0].max()), float(tt[:, 1].max())         # MAX over ranks
+        per_rank = {"kernel_ms": [round(float(v), 4) for v in tt[:, 1]], "allreduce_us": [round(float(v), 1) for v in tt[:, 2]],
+                    "elapsed_s": [round(float(v), 5) for v in tt[:, 0]]}
     else:
         kernel_ms = avg_ms.value
+    if args.dump_result and rank == 0:
+        import numpy as np
+        np.save(args.dump_result, res.detach().cpu().numpy())
 
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed
@@ -159,12 +213,16 @@ def main():
     achieved = b_alg / (kernel_ms * 1e-3)
 
     # literal HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected live); reported only
-    # when the profile was taken on the same kernel + workload as this run
+    # when the profile was taken on the same kernel + workload as this run AND on the kernel source this run was built
+    # from (tools/collect_pmc.py stamps the sha256 of rpgp_kernels.hip into the file; a stale profile gives null)
     traffic = None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters_current.json")))
+        import hashlib
+        ksrc = os.path.join(ROOT, "randomly-projected-additive-gps_amd", "csrc", "rpgp_kernels.hip")
+        same_source = prof.get("kernel_source_sha256") == hashlib.sha256(open(ksrc, "rb").read()).hexdigest()
         if prof.get("N") == N and prof.get("J") == J and prof.get("T") == T and world == 1 and \
-                prof.get("fast") == fast:
+                prof.get("fast") == fast and same_source:
             traffic = prof["hbm_bytes_high"]
     except Exception:
         traffic = None
@@ -203,6 +261,24 @@ def main():
                      "note": "dense-equivalent bytes (4N^2+4N(d+2T)); the fused kernel is VALU/transcendental-bound, "
                              "its literal HBM traffic is ~MBs (see DESIGN.md)"},
     }
+
+    if world > 1:
+        result["config"]["split"] = ("pairs: every rank an equal share of the (row block, column chunk) tiles, all J terms"
+                                     if args.shard == "pairs" else
+                                     "j: rank r owns projections [%s] (north_star's split)" % ", ".join(
+                                         "%d:%d" % ab for ab in __import__("rpgp_amd.distributed", fromlist=["j_partition"]).j_partition(J, world)))
+        result["config"]["comm"] = ("rpgp_comm one-shot all-reduce over IPC-mapped peer buffers" if comm == "ipc"
+                                    else "RCCL all-reduce (torch.distributed nccl)")
+        result["multi_gpu"] = {"per_rank_kernel_ms": per_rank["kernel_ms"], "per_rank_allreduce_us": per_rank["allreduce_us"],
+                               "allreduce_us": max(per_rank["allreduce_us"]), "allreduce_bytes": 4 * N * T,
+                               "per_rank_elapsed_s": per_rank["elapsed_s"],
+                               "allreduce_timing": "HIP events around the collective on the launch stream (includes waiting "
+                                                   "for the slowest peer's partial)"}
+        if one_dev is not None:
+            result["multi_gpu"]["all_ranks_on_device"] = one_dev
+            result["multi_gpu"]["note"] = ("NOT a scaling measurement: the %d ranks share ONE GPU (their kernels time-slice "
+                                           "it); this run proves the N>1 code path end to end, nothing about speed-up" % world)
+            result["scaling"] = "strong"
 
     if world == 1 and not args.no_extras:
         # context numbers (not part of `value`): the T=11 block the training solve uses (10 probes + residual), and one
@@ -376,6 +452,8 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        if reducer is not None:
+            reducer.close()
         dist.destroy_process_group()
 
 

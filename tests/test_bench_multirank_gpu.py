@@ -1,0 +1,58 @@
+"""`bench.py --gpus N` END TO END on the one-GPU test box: the ranks are started by bench.py itself, all on device 0
+(`--all-ranks-on-device 0`: gloo bootstrap, rpgp_comm all-reduce — RCCL refuses two ranks per device), each runs its share
+of the sharded MVM, the partials are all-reduced on the launch stream, the timings are MAX-reduced and rank 0 prints the
+JSON line.  The reduced product is checked against the float64 oracle (oracle/cmvm.c) on a seeded row sample, the JSON
+against the driver's contract (n_gpus, config.parallelism / split / comm, per-rank kernel and all-reduce times).  On a real
+multi-GPU node the same command without `--all-ranks-on-device` runs one rank per GPU over RCCL — this test exists so
+that the first 8-GPU run is not the first run of that code (replaces `MultiDeviceKernel`, training_routines.py:407-408;
+3-device run script run_scripts/additive_spread_prescale_Jd.sh:6)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, D, J = 20000, 20, 20
+
+
+def _oracle_rows(rows):
+    import torch
+    import bench
+    from oracle import cmvm, dense_gp as orc
+    X, P, ls, V = bench.make_inputs(N, D, J, 1, torch.device("cpu"))
+    Z = orc.project(X.numpy(), P.numpy(), ls.numpy())
+    Vh = V.double().numpy()
+    return cmvm.mvm(Z[rows], Z, Vh, 1.0 / J) + 0.1 * Vh[rows]
+
+
+@pytest.mark.parametrize("world,shard", [(2, "pairs"), (4, "j"), (3, "pairs")])
+def test_bench_gpus_n_runs_on_one_device(gpu_device, tmp_path, world, shard):
+    dump = str(tmp_path / "res.npy")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--all-ranks-on-device", "0", "--shard", shard,
+           "--n", str(N), "--steps", "5", "--warmup", "2", "--no-extras", "--cpu-budget", "0", "--dump-result", dump]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == world and res["steps"] == 5 and res["warmup"] == 2 and res["unit"] == "MVM/s"
+    assert res["value"] > 0 and abs(res["value"] * res["ms_per_step"] / 1e3 - 1.0) < 1e-3
+    assert res["config"]["parallelism"] == "%s-shard x%d + all-reduce" % (shard, world)
+    assert res["config"]["split"].startswith(shard) and "rpgp_comm" in res["config"]["comm"]
+    mg = res["multi_gpu"]
+    assert len(mg["per_rank_kernel_ms"]) == world and all(k > 0 for k in mg["per_rank_kernel_ms"])
+    assert len(mg["per_rank_allreduce_us"]) == world and mg["allreduce_us"] > 0 and mg["allreduce_bytes"] == 4 * N
+    assert mg["all_ranks_on_device"] == 0 and "NOT a scaling measurement" in mg["note"]
+    assert abs(res["roofline"]["kernel_ms"] - max(mg["per_rank_kernel_ms"])) < 1e-3
+    assert res["roofline"]["traffic"] is None and "cpu_baseline" not in res
+    # the all-reduced product of the last step against the oracle (identical inputs: bench.make_inputs seeds)
+    out = np.load(dump).astype(np.float64)
+    assert out.shape == (N, 1)
+    rows = np.sort(np.random.default_rng(world).choice(N, size=384, replace=False))
+    ref = _oracle_rows(rows)
+    assert np.linalg.norm(out[rows] - ref) / np.linalg.norm(ref) < 1e-5

@@ -1,7 +1,10 @@
 """Summarise rocprofv3 --pmc passes (counter_collection CSVs under the given directories) for the dominant fused MVM
 kernel into profiles/pmc_counters_current.json (read by bench.py for roofline.traffic).
 usage: collect_pmc.py <out.json> <dir> [<dir> ...]"""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KSRC = os.path.join(ROOT, "randomly-projected-additive-gps_amd", "csrc", "rpgp_kernels.hip")
 
 out, dirs = sys.argv[1], sys.argv[2:]
 sums, counts, kname = {}, {}, None
@@ -17,7 +20,10 @@ for d in dirs:
             counts[c] = counts.get(c, 0) + 1
 means = {c: sums[c] / counts[c] for c in sorted(sums)}
 res = {"kernel": kname, "workload": "N=50000 J=20 T=1 (bench.py default, factorised prepared path)", "N": 50000, "J": 20,
-       "T": 1, "fast": kname is not None and "fact" in kname, "launches_per_counter": counts, "per_launch_means": means,
+       "T": 1, "fast": kname is not None and "fact" in kname,
+       # ties this file to the kernel source it was measured on: bench.py reports roofline.traffic only when the sha256 of
+       # the rpgp_kernels.hip it runs equals this one
+       "kernel_source_sha256": hashlib.sha256(open(KSRC, "rb").read()).hexdigest(), "launches_per_counter": counts, "per_launch_means": means,
        "notes": "rocprofv3 --pmc, separate passes (FETCH_SIZE / WRITE_SIZE / SQ+GRBM), gfx950. FETCH_SIZE and WRITE_SIZE are "
                 "in KB. MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, so hbm_bytes is "
                 "bracketed as [(FETCH+WRITE)*1024, (2*FETCH+WRITE)*1024]."}

@@ -66,7 +66,10 @@ def main():
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (gloo, no GPU work): every rank joins, one all-reduce, rank 0 prints the world "
                          "size; used by tests/ to cover the --gpus launcher on machines without GPUs")
-    args = ap.parse_args()
+    # (ranks started by this script's own launcher below get their flags through the environment: torch.distributed.run's
+    #  parser abbreviation-matches flags such as --n against its own --nnodes / --nproc-per-node before it reaches the script)
+    argv = json.loads(os.environ["RPGP_BENCH_ARGV"]) if ("RPGP_BENCH_ARGV" in os.environ and len(sys.argv) == 1) else None
+    args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) through
@@ -80,8 +83,9 @@ def main():
             port = sk.getsockname()[1]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["RPGP_BENCH_ARGV"] = json.dumps(sys.argv[1:])
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
         sys.exit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

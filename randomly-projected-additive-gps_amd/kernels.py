@@ -183,6 +183,24 @@ class ScaledProjectionKernel(Kernel):
     def project(self, x):
         return _Project.apply(x.contiguous(), self.effective_projection())
 
+    def float64_operator(self, x, outputscale):
+        """The symmetric train-train operator of a FLOAT32 model evaluated in float64 at the hyper-parameters exactly as
+        the model holds them (lengthscale / outputscale = float32 softplus values, widened): the operator the mixed-precision
+        refinement of the prediction solves takes its residuals with (models.PredictionStrategy).  None when the base kernel
+        has no float64 form (grid interpolation, non-RBF / grouped sub-kernels)."""
+        bk = self.base_kernel
+        if not isinstance(bk, AdditiveStructureRBFKernel) or bk.ski or bk.kernel_type != "RBF" or bk.group != 1 or \
+                type(bk).operator is not AdditiveStructureRBFKernel.operator:
+            return None
+        P = self.projection_module.weight.detach().t().double()
+        ls = self.lengthscale.detach().reshape(-1).double()
+        if self.prescale:
+            Peff = P / (ls.reshape(-1, 1) if ls.numel() > 1 else ls)
+        else:
+            Peff = P / (ls.reshape(1, -1) if ls.numel() > 1 else ls)
+        z = _backend.get_backend().project(x.detach().double().contiguous(), Peff.contiguous())
+        return bk.operator(z, None, outputscale=outputscale.detach().double())
+
     def forward(self, x1, x2, outputscale=None, shard=None, **params):
         # the reference decides with torch.equal(x1, x2) (host sync per call, scaled_projection_kernel.py:22);
         # identity of the tensor objects is enough for every call site on the path
@@ -340,6 +358,13 @@ class ScaleKernel(Kernel):
 
     def forward(self, x1, x2, **params):
         return self.base_kernel.forward(x1, x2, outputscale=self.outputscale, shard=self.shard, **params)
+
+    def float64_operator(self, x):
+        """float64 twin of the train-train operator (see ScaledProjectionKernel.float64_operator), or None."""
+        f = getattr(self.base_kernel, "float64_operator", None)
+        if f is None or (self.shard is not None and getattr(self.shard, "world_size", 1) > 1):
+            return None
+        return f(x, self.outputscale)
 
 
 class RBFKernel(Kernel):

@@ -1,0 +1,167 @@
+// rpgp_fact_asm.hip — the factorised fused symmetric MVM (JT = 20 projections, T = 1, two rows per lane: the launch of
+// bench.py and of every T = 1 solve at J = 20) with a HAND-SCHEDULED gfx950 inner loop.
+//
+// Same algorithm, tiling, slabs and determinism as mvm_fact_kernel<20, 1, 2> (rpgp_kernels.hip; reference semantics:
+// gp_models/kernels/memory_efficient_gam_kernel.py:20-30, the `_matmul` that linear_cg calls, fitting/optimizing.py:67-71):
+//   exp2(-(a - b)^2) = exp2(-a^2) * exp2(2ab - b^2);  per pair-term  t = a * 2b - b^2,  e = exp2(t),  K += e * Ea.
+// What differs is who schedules the 64-step rotation loop (tools/gen_fact_asm.py -> rpgp_fact_asm_loop.inc):
+//   * packed lanes run over the lane's TWO ROWS (column operands broadcast with op_sel): no horizontal add;
+//   * the 64 column records of a subtile are followed in LDS by a copy of the first 63, so "column (lane + s) mod 64" is a
+//     running pointer plus immediate offsets: no per-step v_and_or / v_lshlrev / v_mul / v_add;
+//   * the column's v rides in the record (one pointer), every ds_read of step s+1 is issued a full step ahead, K-FMAs trail
+//     their exponentials by one quad (no s_nop, no dependent-issue bubble), the finish of a step rides inside the next.
+// Per step and lane: 20 + 40 + 20 floor instructions + 4 (row product, two transposed FMAs, DPP rotation) = 12.93 issue
+// cycles per 64 pair-terms by the measured costs against 13.3 for the compiler's loop.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rpgp.h"
+#include "rpgp_internal.h"
+#include "rpgp_fact_asm_loop.inc"
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef float v32f __attribute__((ext_vector_type(32)));
+
+constexpr int kJT = 20;
+constexpr int kBR = 512;                 // rows per workgroup: 4 waves x 2 rows per lane
+constexpr int kSC = 128;                 // columns staged per barrier round = 2 rotation subtiles
+constexpr int kRecFloats = 44;           // 10 quads {2b_e, -b_e^2, 2b_o, -b_o^2} + v_col + 3 pad  (176 B, 176/16 odd)
+constexpr int kSubRecs = 127;            // 64 records + a copy of the first 63
+constexpr int kLdsFloats = (2 * kSubRecs + 1) * kRecFloats;   // + one record: the loop's look-ahead reads one past the end
+
+__device__ __forceinline__ void wg_to_tile_sym(int lin, int N, int BR, int chunk, int &rb, int &kchunk) {
+  int b = 0, acc = 0;
+  for (;;) {
+    const int cb = (N - b * BR + chunk - 1) / chunk;
+    if (lin < acc + cb) break;
+    acc += cb;
+    ++b;
+  }
+  rb = b;
+  kchunk = lin - acc;
+}
+
+__global__ __launch_bounds__(256) void mvm_fact_asm_kernel(const v2f *__restrict__ rowdat, const v4f *__restrict__ coldat4,
+                                                           const float *__restrict__ V, float *__restrict__ slabR,
+                                                           float *__restrict__ slabT, int N, int ldv, int t0,
+                                                           int chunk_cols, int accumulate, int w0, int rb_first,
+                                                           int slab_row0, int slab_rows) {
+  __shared__ __attribute__((aligned(16))) float sB[kLdsFloats];
+  __shared__ __attribute__((aligned(16))) float sT[4 * kSC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int rb, kchunk;
+  wg_to_tile_sym(blockIdx.x + w0, N, kBR, chunk_cols, rb, kchunk);
+  const int r0 = rb * kBR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+
+  // row side: A[j] = {a_row0, a_row1}, E[j] = {Ea_row0, Ea_row1}; rows past N: Ea = 0 -> K = 0 (loads from a clamped row:
+  // unconditional, so they are issued together)
+  v32f A0, E0;
+  v8f A1, E1;
+  v2f vrow;
+  {
+    const int row0 = r0 + wave * 128 + lane, row1 = row0 + 64;
+    const int rc0 = row0 < N ? row0 : N - 1, rc1 = row1 < N ? row1 : N - 1;
+    const float m0 = row0 < N ? 1.f : 0.f, m1 = row1 < N ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < kJT; ++j) {
+      const v2f x0 = rowdat[(size_t)rc0 * kJT + j], x1 = rowdat[(size_t)rc1 * kJT + j];
+      if (j < 16) {
+        A0[2 * j] = x0.x; A0[2 * j + 1] = x1.x;
+        E0[2 * j] = x0.y * m0; E0[2 * j + 1] = x1.y * m1;
+      } else {
+        A1[2 * (j - 16)] = x0.x; A1[2 * (j - 16) + 1] = x1.x;
+        E1[2 * (j - 16)] = x0.y * m0; E1[2 * (j - 16) + 1] = x1.y * m1;
+      }
+    }
+    vrow.x = V[(size_t)rc0 * ldv + t0] * m0;
+    vrow.y = V[(size_t)rc1 * ldv + t0] * m1;
+  }
+  v2f accR = {0.f, 0.f};
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)sB;      // LDS byte address
+
+  for (int c0 = c_begin; c0 < c_end; c0 += kSC) {
+    __syncthreads();
+    {
+      // staging: thread = (column, half record); a column's 20 {2b, -b^2} pairs are 160 contiguous bytes of coldat
+      const int c = tid >> 1, h = tid & 1;
+      const int col = c0 + c;
+      const bool cv = col < c_end;
+      const int colc = cv ? col : N - 1;
+      v4f q[5];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) q[p] = coldat4[(size_t)colc * (kJT / 2) + 5 * h + p];
+      const float vv = V[(size_t)colc * ldv + t0];
+      if (!cv) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) q[p] = v4f{0.f, -1.0e30f, 0.f, -1.0e30f};       // padded column: exp2(-1e30) = 0
+      }
+      const int sub = c >> 6, k = c & 63;
+      float *rec = sB + (sub * kSubRecs + k) * kRecFloats + 20 * h;
+#pragma unroll
+      for (int p = 0; p < 5; ++p) *reinterpret_cast<v4f *>(rec + 4 * p) = q[p];
+      if (h) rec[20] = cv ? vv : 0.f;                                               // float 40 of the record
+      if (k < 63) {
+        float *dup = rec + 64 * kRecFloats;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) *reinterpret_cast<v4f *>(dup + 4 * p) = q[p];
+        if (h) dup[20] = cv ? vv : 0.f;
+      }
+    }
+    __syncthreads();
+    const int ncol = c_end - c0;
+    const int nsub = ncol >= kSC ? kSC / 64 : (ncol + 63) / 64;
+    for (int sub = 0; sub < nsub; ++sub) {
+      unsigned ptr = lds_base + (unsigned)((sub * kSubRecs + lane) * kRecFloats * 4);
+      float accT;
+      int cnt;
+      asm volatile(
+          "s_waitcnt lgkmcnt(0)\n" RPGP_FACT_ASM_LOOP
+          : "+{v[90:91]}"(accR), "+{v94}"(ptr), "={v95}"(accT), [cnt] "=s"(cnt)
+          : "{v[10:41]}"(A0), "{v[42:49]}"(A1), "{v[50:81]}"(E0), "{v[82:89]}"(E1), "{v[92:93]}"(vrow)
+          : RPGP_FACT_ASM_CLOBBERS, "v96", "memory");
+      // (subtiles inside the row block: every pair of the block is swept from both sides, the transposed sums are dropped)
+      sT[wave * kSC + sub * 64 + lane] = accT;
+    }
+    __syncthreads();
+    {
+      const int col = c0 + tid;
+      if (tid < kSC && col < c_end && col >= r0 + kBR) {
+        const float sum = sT[0 * kSC + tid] + sT[1 * kSC + tid] + sT[2 * kSC + tid] + sT[3 * kSC + tid];
+        float *dst = slabT + ((size_t)(rb - rb_first) * N + col) * ldv + t0;
+        *dst = accumulate ? *dst + sum : sum;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = r0 + wave * 128 + r * 64 + lane;
+    if (row < N) {
+      float *dst = slabR + ((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0;
+      const float a = r == 0 ? accR.x : accR.y;
+      *dst = accumulate ? *dst + a : a;
+    }
+  }
+}
+
+}  // namespace
+
+namespace rpgp_internal {
+
+int launch_mvm_fact_asm(const void *rowdat, const void *coldat, const float *V, float *slabR, float *slabT, int N, int ldv,
+                        int t0, int chunk_cols, int accumulate, int w0, int nwg, int rb_first, int slab_row0, int slab_rows,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(mvm_fact_asm_kernel, dim3((unsigned)nwg), dim3(256), 0, st, reinterpret_cast<const v2f *>(rowdat),
+                     reinterpret_cast<const v4f *>(coldat), V, slabR, slabT, N, ldv, t0, chunk_cols, accumulate, w0, rb_first,
+                     slab_row0, slab_rows);
+  return (int)hipGetLastError();
+}
+
+}  // namespace rpgp_internal

@@ -3702,6 +3702,15 @@ int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *col
       return launch_status();
     }
   }
+  if constexpr (TT == 1 && JT == 20) {
+    // the hand-scheduled loop (rpgp_fact_asm.hip): the whole J = 20 operator, one right-hand side, two rows per lane, and
+    // the rotation direction its LDS image assumes; RPGP_FACT_ASM=0 keeps the compiler-scheduled kernel (A/B runs, tests)
+    const char *env_asm = getenv("RPGP_FACT_ASM");            // (read per launch: A/B pairs alternate inside one process)
+    const int use_asm = env_asm ? atoi(env_asm) : 1;
+    if (use_asm && p.R == 2 && tcnt == 1 && J == 20 && j0 == 0 && g_rotdir == 1)
+      return rpgp_internal::launch_mvm_fact_asm(rowdat, coldat, V, slabR, slabT, N, ldv, t0, p.chunk_cols, accumulate, p.w0,
+                                                p.w1 - p.w0, p.rb0, p.row0, p.rows, st);
+  }
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 2>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
                        j0, t0, tcnt, p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);

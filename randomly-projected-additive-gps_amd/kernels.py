@@ -183,11 +183,12 @@ class ScaledProjectionKernel(Kernel):
     def project(self, x):
         return _Project.apply(x.contiguous(), self.effective_projection())
 
-    def float64_operator(self, x, outputscale):
-        """The symmetric train-train operator of a FLOAT32 model evaluated in float64 at the hyper-parameters exactly as
-        the model holds them (lengthscale / outputscale = float32 softplus values, widened): the operator the mixed-precision
-        refinement of the prediction solves takes its residuals with (models.PredictionStrategy).  None when the base kernel
-        has no float64 form (grid interpolation, non-RBF / grouped sub-kernels)."""
+    def float64_operator(self, x1, x2, outputscale):
+        """The operator of a FLOAT32 model evaluated in float64 at the hyper-parameters exactly as the model holds them
+        (lengthscale / outputscale = float32 softplus values, widened); x2 None = the symmetric train-train operator.  What
+        the mixed-precision refinement of the prediction solves takes its residuals with, and what the predictive mean is
+        summed with (models.PredictionStrategy).  None when the base kernel has no float64 form (grid interpolation,
+        non-RBF / grouped sub-kernels)."""
         bk = self.base_kernel
         if not isinstance(bk, AdditiveStructureRBFKernel) or bk.ski or bk.kernel_type != "RBF" or bk.group != 1 or \
                 type(bk).operator is not AdditiveStructureRBFKernel.operator:
@@ -195,11 +196,13 @@ class ScaledProjectionKernel(Kernel):
         P = self.projection_module.weight.detach().t().double()
         ls = self.lengthscale.detach().reshape(-1).double()
         if self.prescale:
-            Peff = P / (ls.reshape(-1, 1) if ls.numel() > 1 else ls)
+            Peff = (P / (ls.reshape(-1, 1) if ls.numel() > 1 else ls)).contiguous()
         else:
-            Peff = P / (ls.reshape(1, -1) if ls.numel() > 1 else ls)
-        z = _backend.get_backend().project(x.detach().double().contiguous(), Peff.contiguous())
-        return bk.operator(z, None, outputscale=outputscale.detach().double())
+            Peff = (P / (ls.reshape(1, -1) if ls.numel() > 1 else ls)).contiguous()
+        be = _backend.get_backend()
+        z1 = be.project(x1.detach().double().contiguous(), Peff)
+        z2 = None if x2 is None else be.project(x2.detach().double().contiguous(), Peff)
+        return bk.operator(z1, z2, outputscale=outputscale.detach().double())
 
     def forward(self, x1, x2, outputscale=None, shard=None, **params):
         # the reference decides with torch.equal(x1, x2) (host sync per call, scaled_projection_kernel.py:22);
@@ -359,12 +362,12 @@ class ScaleKernel(Kernel):
     def forward(self, x1, x2, **params):
         return self.base_kernel.forward(x1, x2, outputscale=self.outputscale, shard=self.shard, **params)
 
-    def float64_operator(self, x):
-        """float64 twin of the train-train operator (see ScaledProjectionKernel.float64_operator), or None."""
+    def float64_operator(self, x1, x2=None):
+        """float64 twin of the operator on (x1, x2) (see ScaledProjectionKernel.float64_operator), or None."""
         f = getattr(self.base_kernel, "float64_operator", None)
         if f is None or (self.shard is not None and getattr(self.shard, "world_size", 1) > 1):
             return None
-        return f(x, self.outputscale)
+        return f(x1, x2, self.outputscale)
 
 
 class RBFKernel(Kernel):

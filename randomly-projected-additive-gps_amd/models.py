@@ -118,10 +118,12 @@ class PredictionStrategy:
 
     def _refine_mean_cache(self, model, x):
         """Mixed-precision refinement of alpha = Khat^-1 (y - c) (settings.solve_refinement): residuals with the float64 twin
-        of the fused operator (float64 projection, float64 exponentials: rpgp_mvm_f64), corrections by the float32 solver.
-        float32 CG stalls at a TRUE residual of ~1e-4 at N = 50 000; one round reaches ~1e-8.  The refined solution is kept as
-        a float32 pair (alpha, alpha_lo) so that the cross-covariance product stays on the float32 kernels."""
-        self.alpha_lo = None
+        of the fused operator (float64 projection, float64 exponentials: rpgp_mvm_f64; 41 ms at N = 50 000), corrections by
+        the float32 solver.  float32 CG stalls at a TRUE residual of ~1e-4 at N = 50 000 (measured against the float64
+        oracle); one round reaches 4e-8.  The refined solution is kept in float64 (`alpha64`) and the predictive mean is
+        summed with the float64 cross-covariance operator: with an exact alpha the float32 sum of 50 000 cancelling terms
+        was still 1.7e-4 off."""
+        self.alpha64 = None
         rounds = settings.solve_refinement.value()
         N = x.shape[0]
         if rounds <= 0 or x.dtype != torch.float32 or not x.is_cuda or N < settings.solve_refinement_min_size.value():
@@ -146,7 +148,7 @@ class PredictionStrategy:
                 break
             a64 = a64 + self._solve_thin((res / scale).float()).double() * scale
         self.alpha = a64.float()
-        self.alpha_lo = (a64 - self.alpha.double()).float()
+        self.alpha64 = a64
 
     # ---- mixed-precision solve of the N_test-wide covariance block (settings.solve_refinement) ----------------------------
     def _mixed_precision_ready(self, like, n_train, n_test):
@@ -297,8 +299,9 @@ class PredictionStrategy:
         model = self.model
         with torch.no_grad():
             cross = model.covar_module(xs, model.train_inputs)      # K(X*, X) operator
-            if getattr(self, "alpha_lo", None) is not None:       # refined mean cache: float64 alpha as a float32 pair
-                mean = cross._matmul(torch.cat([self.alpha, self.alpha_lo], dim=1)).sum(dim=1) + model.mean_module(xs)
+            if getattr(self, "alpha64", None) is not None:        # refined mean cache: the sum in float64 as well
+                cross64 = model.covar_module.float64_operator(xs, model.train_inputs)
+                mean = cross64._matmul(self.alpha64).reshape(-1).to(xs.dtype) + model.mean_module(xs)
             else:
                 mean = cross._matmul(self.alpha).reshape(-1) + model.mean_module(xs)
             if settings.skip_posterior_variances.on():

@@ -106,10 +106,12 @@ cholesky_precond_size = _setting("cholesky_precond_size", 65536)
 # predictive covariance): `solve_refinement` rounds of  x <- x + solve32(b - Khat_64 x)  with the residual taken in float64
 # (the float64 twin of the fused operator for thin blocks, a float64 copy of the stored dense matrix for wide ones) and the
 # correction by the float32 solver.  float32 CG stalls at a TRUE relative residual of ~1e-4 at N = 50 000 (measured against the
-# float64 oracle: predictive mean 1.8e-4, variance 8.7e-4 off); one round brings both below 1e-6.  0 = GPyTorch's behaviour.
+# float64 oracle: predictive mean 1.8e-4, variance 8.7e-4 off); one round brings the solution to 5e-8 and the variance to 1e-5; the
+# predictive mean is then summed with the float64 cross-covariance operator as well.  0 = GPyTorch's behaviour.
 solve_refinement = _setting("solve_refinement", 1)
-# ... only above this size (below it the dense float64 paths already apply)
-solve_refinement_min_size = _setting("solve_refinement_min_size", 20001)
+# ... the mean cache from this size up (every CG-regime model; the float64 twin product costs 4 ms at N = 15 000, 41 ms at
+# 50 000); the wide block additionally only above `dense_solve_size`, where the float64 direct solve stops
+solve_refinement_min_size = _setting("solve_refinement_min_size", 0)
 # the all-reduce of the sharded multi-GPU solve: "rccl" (torch.distributed, backend nccl = RCCL over xGMI) or "ipc" (one-shot
 # kernel over IPC-mapped peer buffers, csrc/rpgp_comm.hip); the environment variable RPGP_COMM overrides it
 comm_backend = _setting("comm_backend", "rccl")

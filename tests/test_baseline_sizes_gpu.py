@@ -290,9 +290,9 @@ def c4(gpu_device):
         mean = model(Xs.to(gpu_device)).mean.double().cpu().numpy()
     strat = model.prediction_strategy
     # the product's mean cache after its mixed-precision refinement (settings.solve_refinement, default one round): the
-    # float64 solution is kept as a float32 pair
-    assert strat.alpha_lo is not None
-    alpha_hip = (strat.alpha.double() + strat.alpha_lo.double()).cpu().numpy().reshape(-1)
+    # solution is kept in float64
+    assert strat.alpha64 is not None
+    alpha_hip = strat.alpha64.cpu().numpy().reshape(-1)
 
     def khat(v):                      # float64 oracle product with the full 50 000 x 50 000 matrix
         return cmvm.mvm(Z, Z, v, sd / J4, nd)

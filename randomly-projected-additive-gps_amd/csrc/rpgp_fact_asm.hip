@@ -33,11 +33,16 @@ constexpr int kRecFloats = 44;           // 10 quads {2b_e, -b_e^2, 2b_o, -b_o^2
 constexpr int kSubRecs = 127;            // 64 records + a copy of the first 63
 constexpr int kLdsFloats = (2 * kSubRecs + 1) * kRecFloats;   // + one record: the loop's look-ahead reads one past the end
 
-__device__ __forceinline__ void wg_to_tile_sym(int lin, int N, int BR, int chunk, int &rb, int &kchunk) {
+__device__ __forceinline__ void wg_to_tile_sym(int lin, int N, int BR, int chunk, rpgp_internal::Taper tp, int &rb,
+                                               int &kchunk, int &chunk_b) {
   int b = 0, acc = 0;
   for (;;) {
-    const int cb = (N - b * BR + chunk - 1) / chunk;
-    if (lin < acc + cb) break;
+    const int cbk = rpgp_internal::taper_chunk(b, chunk, tp.tb1, tp.tb2, tp.tb3);
+    const int cb = (N - b * BR + cbk - 1) / cbk;
+    if (lin < acc + cb) {
+      chunk_b = cbk;
+      break;
+    }
     acc += cb;
     ++b;
   }
@@ -48,18 +53,18 @@ __device__ __forceinline__ void wg_to_tile_sym(int lin, int N, int BR, int chunk
 __global__ __launch_bounds__(256) void mvm_fact_asm_kernel(const v2f *__restrict__ rowdat, const v4f *__restrict__ coldat4,
                                                            const float *__restrict__ V, float *__restrict__ slabR,
                                                            float *__restrict__ slabT, int N, int ldv, int t0,
-                                                           int chunk_cols, int accumulate, int w0, int rb_first,
-                                                           int slab_row0, int slab_rows) {
+                                                           int chunk_cols, rpgp_internal::Taper taper, int accumulate,
+                                                           int w0, int rb_first, int slab_row0, int slab_rows) {
   __shared__ __attribute__((aligned(16))) float sB[kLdsFloats];
   __shared__ __attribute__((aligned(16))) float sT[4 * kSC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int rb, kchunk;
-  wg_to_tile_sym(blockIdx.x + w0, N, kBR, chunk_cols, rb, kchunk);
+  int rb, kchunk, chunk_b;
+  wg_to_tile_sym(blockIdx.x + w0, N, kBR, chunk_cols, taper, rb, kchunk, chunk_b);
   const int r0 = rb * kBR;
-  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_b;
   if (cb >= N) return;
   const int c_begin = (int)cb;
-  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+  const int c_end = (c_begin + chunk_b < N) ? c_begin + chunk_b : N;
 
   // row side: A[j] = {a_row0, a_row1}, E[j] = {Ea_row0, Ea_row1}; rows past N: Ea = 0 -> K = 0 (loads from a clamped row:
   // unconditional, so they are issued together)
@@ -156,11 +161,11 @@ __global__ __launch_bounds__(256) void mvm_fact_asm_kernel(const v2f *__restrict
 namespace rpgp_internal {
 
 int launch_mvm_fact_asm(const void *rowdat, const void *coldat, const float *V, float *slabR, float *slabT, int N, int ldv,
-                        int t0, int chunk_cols, int accumulate, int w0, int nwg, int rb_first, int slab_row0, int slab_rows,
-                        hipStream_t st) {
+                        int t0, int chunk_cols, Taper taper, int accumulate, int w0, int nwg, int rb_first, int slab_row0,
+                        int slab_rows, hipStream_t st) {
   hipLaunchKernelGGL(mvm_fact_asm_kernel, dim3((unsigned)nwg), dim3(256), 0, st, reinterpret_cast<const v2f *>(rowdat),
-                     reinterpret_cast<const v4f *>(coldat), V, slabR, slabT, N, ldv, t0, chunk_cols, accumulate, w0, rb_first,
-                     slab_row0, slab_rows);
+                     reinterpret_cast<const v4f *>(coldat), V, slabR, slabT, N, ldv, t0, chunk_cols, taper, accumulate, w0,
+                     rb_first, slab_row0, slab_rows);
   return (int)hipGetLastError();
 }
 

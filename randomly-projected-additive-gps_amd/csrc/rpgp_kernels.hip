@@ -883,7 +883,8 @@ constexpr int kRedOutputs = 32;
 __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict__ slabR, const float *__restrict__ slabT,
                                   const float *__restrict__ V, float *__restrict__ out, int M, int N, int T,
                                   int BR, int chunk_cols, int sym, float scale, float noise,
-                                  const int *__restrict__ guard, int rb0, int rb1, int slab_row0, int slab_rows) {
+                                  const int *__restrict__ guard, int rb0, int rb1, int slab_row0, int slab_rows,
+                                  rpgp_internal::Taper taper = rpgp_internal::Taper{0x7fffffff, 0x7fffffff, 0x7fffffff}) {
   __shared__ double sacc[kRedGroups][kRedOutputs];   // float64: ~150 slab entries per output, free at this size
   const int o = threadIdx.x & (kRedOutputs - 1), g = threadIdx.x / kRedOutputs;
   const size_t gid = (size_t)blockIdx.x * kRedOutputs + o;
@@ -893,7 +894,8 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
     const int row = (int)(gid / T);
     const int rb = row / BR;
     const int cbase = sym ? rb * BR : 0;
-    const int nk = (N - cbase + chunk_cols - 1) / chunk_cols;
+    const int chunk_b = rpgp_internal::taper_chunk(rb, chunk_cols, taper.tb1, taper.tb2, taper.tb3);
+    const int nk = (N - cbase + chunk_b - 1) / chunk_b;
     if (rb >= rb0 && rb < rb1) {                    // row products exist only for this call's row blocks
       const size_t lid = gid - (size_t)slab_row0 * T;
       for (int k = g; k < nk; k += kRedGroups) acc += (double)slabR[(size_t)k * slab_rows * T + lid];
@@ -3511,8 +3513,9 @@ struct TilePlan {
   int w0, w1;      // workgroup range of this call (pair-sharding); default = all
   int rb0, rb1;    // row blocks touched by that range
   int row0, rows;  // first row / number of rows of those row blocks (slab addressing)
-  int maxchunks;   // chunk slabs per row (chunks of the first touched row block)
+  int maxchunks;   // chunk slabs per row (the most chunks any touched row block has)
   bool partial;    // the range is a strict subset: slabs are zero-initialised before the sweep
+  rpgp_internal::Taper taper;   // first row blocks of the half / quarter / eighth-size chunks (nrb = none; rpgp_internal.h)
 };
 
 inline int plan_chunk(double pairs, int BR, bool big, double target_wgs = 4608.0) {
@@ -3528,13 +3531,14 @@ inline int plan_chunk(double pairs, int BR, bool big, double target_wgs = 4608.0
 
 inline int chunks_of(const TilePlan &p, int64_t N, bool sym, int b) {
   const long long cbase = sym ? (long long)b * p.BR : 0;
-  return (int)((N - cbase + p.chunk_cols - 1) / p.chunk_cols);
+  const int cb = rpgp_internal::taper_chunk(b, p.chunk_cols, p.taper.tb1, p.taper.tb2, p.taper.tb3);
+  return (int)((N - cbase + cb - 1) / cb);
 }
 
 // `world`-way split: the chunk size is chosen for the per-rank share of the pairs so that every rank still launches
 // a few thousand workgroups; rank r gets workgroups [total*r/world, total*(r+1)/world).
 inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0, bool r1 = false,
-                          int br_override = 0, double target_wgs = 4608.0) {
+                          int br_override = 0, double target_wgs = 4608.0, bool taper = false) {
   TilePlan p;
   // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
   // measured (tools/time_small.py): with T > 4 right-hand sides two rows per lane win from N ~ 4k up (362 vs 429 us at
@@ -3549,6 +3553,21 @@ inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, 
   p.nrb = (int)((M + p.BR - 1) / p.BR);
   const double pairs = (sym ? 0.5 * (double)M * (double)N : (double)M * (double)N) / (double)(world > 0 ? world : 1);
   p.chunk_cols = plan_chunk(pairs, p.BR, M >= 16384, target_wgs);
+  p.taper = rpgp_internal::Taper{p.nrb, p.nrb, p.nrb};
+  if (taper && sym && world <= 1 && M == N && p.chunk_cols >= 256) {
+    // remaining share of the pairs after row block b is ((N - b BR) / N)^2: half-size chunks for the last 20 % of the work,
+    // quarter-size for the last 6 %, eighth-size for the last 1.5 % (single GPU only: pair-sharding splits by workgroup COUNT)
+    const double fr[3] = {0.20, 0.06, 0.015};
+    int tb[3];
+    for (int l = 0; l < 3; ++l) {
+      const double cols = std::sqrt(fr[l]) * (double)N;
+      int b = (int)(((double)N - cols) / (double)p.BR);
+      if (b < 0) b = 0;
+      if (b > p.nrb) b = p.nrb;
+      tb[l] = b;
+    }
+    p.taper = rpgp_internal::Taper{tb[0], tb[1], tb[2]};
+  }
   long long total = 0;
   for (int b = 0; b < p.nrb; ++b) total += chunks_of(p, N, sym, b);
   p.total_wg = (int)total;
@@ -3575,7 +3594,11 @@ inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, 
   p.row0 = p.rb0 * p.BR;
   const long long rend = (long long)p.rb1 * p.BR < M ? (long long)p.rb1 * p.BR : M;
   p.rows = (int)(rend - p.row0 > 0 ? rend - p.row0 : 0);
-  p.maxchunks = p.rb1 > p.rb0 ? chunks_of(p, N, sym, sym ? p.rb0 : 0) : 1;
+  p.maxchunks = 1;
+  for (int b = p.rb0; b < p.rb1; ++b) {
+    const int cb = chunks_of(p, N, sym, sym ? b : 0);
+    if (cb > p.maxchunks) p.maxchunks = cb;
+  }
   return p;
 }
 
@@ -3634,6 +3657,10 @@ inline bool use_mfma_plan(int64_t N, int T) { return T == 1 && N >= 2048; }
 
 inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int world = 1, int rank = 0, bool r1 = false) {
   size_t f = plan_workspace_floats(make_plan(M, N, sym, T, world, rank, r1), N, T, sym);
+  if (sym && !r1 && M == N && world <= 1) {       // the tapered plan of the single-GPU T = 1 prepared path (more chunk slabs)
+    const size_t g = plan_workspace_floats(make_plan(M, N, sym, T, world, rank, false, 0, 4608.0, true), N, T, sym);
+    if (g > f) f = g;
+  }
   if (sym && !r1 && M == N && use_mfma_plan(N, T)) {
     // the prepared path may run the matrix-core plan (smaller row blocks -> more transposed slabs): one workspace
     // size serves both plans
@@ -3687,6 +3714,15 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
   return launch_status();
 }
 
+// Does the hand-scheduled kernel (rpgp_fact_asm.hip) serve this call?  The whole J = 20 operator, ONE right-hand side, two
+// rows per lane, and the rotation direction its LDS image assumes; RPGP_FACT_ASM=0 keeps the compiler-scheduled kernel
+// (read per launch: A/B pairs alternate inside one process).
+inline bool fact_asm_applies(const TilePlan &p, int T, int J, int j0, int j1) {
+  const char *env_asm = getenv("RPGP_FACT_ASM");
+  if (env_asm && atoi(env_asm) == 0) return false;
+  return p.R == 2 && T == 1 && J == 20 && j0 == 0 && j1 == 20 && g_rotdir == 1;
+}
+
 // ---- prepared (factorised) path -----------------------------------------------------------------
 template <int JT, int TT>
 int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *coldat, const float *V, float *slabR,
@@ -3703,13 +3739,9 @@ int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *col
     }
   }
   if constexpr (TT == 1 && JT == 20) {
-    // the hand-scheduled loop (rpgp_fact_asm.hip): the whole J = 20 operator, one right-hand side, two rows per lane, and
-    // the rotation direction its LDS image assumes; RPGP_FACT_ASM=0 keeps the compiler-scheduled kernel (A/B runs, tests)
-    const char *env_asm = getenv("RPGP_FACT_ASM");            // (read per launch: A/B pairs alternate inside one process)
-    const int use_asm = env_asm ? atoi(env_asm) : 1;
-    if (use_asm && p.R == 2 && tcnt == 1 && J == 20 && j0 == 0 && g_rotdir == 1)
-      return rpgp_internal::launch_mvm_fact_asm(rowdat, coldat, V, slabR, slabT, N, ldv, t0, p.chunk_cols, accumulate, p.w0,
-                                                p.w1 - p.w0, p.rb0, p.row0, p.rows, st);
+    if (tcnt == 1 && fact_asm_applies(p, 1, J, j0, j0 + 20))
+      return rpgp_internal::launch_mvm_fact_asm(rowdat, coldat, V, slabR, slabT, N, ldv, t0, p.chunk_cols, p.taper, accumulate,
+                                                p.w0, p.w1 - p.w0, p.rb0, p.row0, p.rows, st);
   }
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 2>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,
@@ -4245,7 +4277,12 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
     }
     j += jt;
   }
-  const TilePlan p = make_plan(N, N, true, T, world, rank, false, mfma ? rpgp_internal::kMfmaBR : 0);
+  TilePlan p = make_plan(N, N, true, T, world, rank, false, mfma ? rpgp_internal::kMfmaBR : 0);
+  if (!mfma && fact_asm_applies(p, T, J, j0, j1)) {
+    // the hand-scheduled kernel (rpgp_fact_asm.hip) understands tapered chunks: smaller workgroups at the end of the sweep
+    const char *env_tp = getenv("RPGP_TAPER");
+    if (!env_tp || atoi(env_tp) != 0) p = make_plan(N, N, true, T, world, rank, false, 0, 4608.0, true);
+  }
   PrepLayout L = prep_layout(const_cast<void *>(prep), N, J);
   float *slabR = reinterpret_cast<float *>(workspace);
   float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
@@ -4276,7 +4313,7 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
   const size_t total = (size_t)N * T;
   hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st, slabR, slabT, V, out,
                      (int)N, (int)N, T, p.BR, p.chunk_cols, 1, scale, noise,
-                     reinterpret_cast<const int *>(L.header), p.rb0, p.rb1, p.row0, p.rows);
+                     reinterpret_cast<const int *>(L.header), p.rb0, p.rb1, p.row0, p.rows, p.taper);
   return launch_status();
 }
 

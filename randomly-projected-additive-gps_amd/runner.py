@@ -129,65 +129,83 @@ def _normalize_by_train(train, test):
     return train, test
 
 
+class _Progress:
+    """Console line per finished fit with the remaining-time estimate (the reference prints the same fields)."""
+
+    def __init__(self, total_fits, enabled):
+        self.total, self.enabled, self.t0 = total_fits, enabled, time.time()
+
+    def fit_done(self, fold, repeat, done, row):
+        if not self.enabled:
+            return
+        eta = datetime.timedelta(seconds=(time.time() - self.t0) / done * (self.total - done))
+        shown = {k: v for k, v in row.items() if k != "test_pred_z_score"}
+        print("{}, fold={}, rep={}, eta={} \n{}".format(datetime.datetime.now(), fold, repeat, format_timedelta(eta), shown))
+
+
+def _fold_tensors(train, test, features):
+    """float32 contiguous tensors of one fold (gp_experiment_runner.py:164-167)."""
+    def t(frame, cols):
+        return torch.tensor(frame[cols].values, dtype=torch.float).contiguous()
+    return t(train, features), t(train, "target"), t(test, features), t(test, "target")
+
+
+def _fit_row(training_routine, training_options, tensors, addl_metrics, base):
+    """One fit -> one result row: the routine's metrics next to mse / rmse / wall time and any additional metric."""
+    row = dict(base)
+    tic = time.perf_counter()
+    model_metrics, ypred = training_routine(*tensors, **training_options)[:2]
+    row["train_time"] = time.perf_counter() - tic
+    testY = tensors[3]
+    row["mse"] = mean_squared_error(ypred, testY)
+    row["rmse"] = np.sqrt(row["mse"])
+    # column order of the reference's rows: mse, rmse, train_time, then the routine's metrics, then the additional ones
+    row = {**{k: row[k] for k in base}, "mse": row["mse"], "rmse": row["rmse"], "train_time": row["train_time"]}
+    row.update(model_metrics)
+    row.update({name: fn(ypred, testY) for name, fn in addl_metrics.items()})
+    return row
+
+
 def run_experiment(training_routine, training_options, dataset, split, cv, addl_metrics={}, repeats=1,
                    error_repeats=10, normalize_using_train=True, chosen_fold=0, print_to_console=True):
-    """Run a training routine over the folds of a dataset (gp_experiment_runner.py:105-219).
+    """Run a training routine over the folds of a dataset (counterpart of gp_experiment_runner.py:105-219; same columns,
+    retry rule and console output).
 
-    Folds are contiguous blocks (`_determine_folds`); without `cv` only `chosen_fold` is run.  Each fold is fitted
-    `repeats` times on the same tensors.  Any exception inside a fit is recorded as a row (traceback in `error`) and
-    the fold is retried until it succeeds or `error_repeats` errors were seen.  Returns a DataFrame of result rows."""
+    Folds are contiguous blocks (`_determine_folds`); without `cv` only `chosen_fold` is run.  A fold is fitted `repeats`
+    times on the same tensors.  An exception anywhere inside a fold's fits becomes a row of its own (traceback under
+    `error`; `d` two less than the feature count and NaN scores, as the reference records it) and a fold without a finished
+    fit starts over, at most `error_repeats` times.  Returns the rows as a DataFrame."""
     if isinstance(dataset, str):
         dataset = load_dataset(dataset)
-    cols = list(dataset.columns)
-    features = [x for x in cols if (x != "target" and x.lower() != "index")]
+    features = [c for c in dataset.columns if c != "target" and c.lower() != "index"]
     fold_starts = _determine_folds(split, dataset)
     n_folds = len(fold_starts) - 1
-    results_list = []
-    t0 = time.time()
-    for fold in range(n_folds):
-        if not cv and fold != chosen_fold:
-            continue
+    folds = range(n_folds) if cv else [f for f in range(n_folds) if f == chosen_fold]
+    progress = _Progress(n_folds * repeats, print_to_console)
+    rows = []
+    for fold in folds:
         train, test = _access_fold(dataset, fold_starts, fold)
         if normalize_using_train:
             train, test = _normalize_by_train(train, test)
-        succeed, n_errors = False, 0
-        while not succeed and n_errors < error_repeats:
+        failures, fitted = 0, False
+        while failures < error_repeats and not fitted:
             try:
-                trainX = torch.tensor(train[features].values, dtype=torch.float).contiguous()
-                trainY = torch.tensor(train["target"].values, dtype=torch.float).contiguous()
-                testX = torch.tensor(test[features].values, dtype=torch.float).contiguous()
-                testY = torch.tensor(test["target"].values, dtype=torch.float).contiguous()
+                tensors = _fold_tensors(train, test, features)
                 for repeat in range(repeats):
-                    result_dict = {"fold": fold, "repeat": repeat, "n": len(dataset), "d": len(features)}
-                    start = time.perf_counter()
-                    ret = training_routine(trainX, trainY, testX, testY, **training_options)
-                    model_metrics, ypred = ret[0], ret[1]
-                    end = time.perf_counter()
-                    result_dict["mse"] = mean_squared_error(ypred, testY)
-                    result_dict["rmse"] = np.sqrt(result_dict["mse"])
-                    result_dict["train_time"] = end - start
-                    for name, value in model_metrics.items():
-                        result_dict[name] = value
-                    for name, fxn in addl_metrics.items():
-                        result_dict[name] = fxn(ypred, testY)
-                    results_list.append(result_dict)
-                    succeed = True
-                    num_finished = fold * repeats + repeat + 1
-                    num_remaining = n_folds * repeats - num_finished
-                    eta = datetime.timedelta(seconds=(time.time() - t0) / num_finished * num_remaining)
-                    if print_to_console:
-                        shown = {k: v for k, v in result_dict.items() if k != "test_pred_z_score"}
-                        print("{}, fold={}, rep={}, eta={} \n{}".format(datetime.datetime.now(), fold, repeat,
-                                                                        format_timedelta(eta), shown))
-            except Exception:                           # the reference retries on ANY exception (:205-215)
-                result_dict = dict(error=traceback.format_exc(), fold=fold, n=len(dataset), d=len(features) - 2,
-                                   mse=np.nan, rmse=np.nan)
-                print(result_dict)
+                    row = _fit_row(training_routine, training_options, tensors, addl_metrics,
+                                   {"fold": fold, "repeat": repeat, "n": len(dataset), "d": len(features)})
+                    rows.append(row)
+                    fitted = True                       # (as in the reference: one finished fit ends the fold's retries,
+                    progress.fit_done(fold, repeat, fold * repeats + repeat + 1, row)   # even if a later repeat raises)
+            except Exception:                           # ANY exception: record it; an unfitted fold runs again
+                failures += 1
+                row = dict(error=traceback.format_exc(), fold=fold, n=len(dataset), d=len(features) - 2, mse=np.nan,
+                           rmse=np.nan)
+                print(row)
                 traceback.print_exc()
-                results_list.append(result_dict)
-                n_errors += 1
-                print("errors: ", n_errors)
-    results = pd.DataFrame(results_list)
+                rows.append(row)
+                print("errors: ", failures)
+    results = pd.DataFrame(rows)
     if print_to_console and "rmse" in results:
         print("Mean RMSE = {}".format(results["rmse"].mean()))
     return results

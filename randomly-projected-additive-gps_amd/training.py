@@ -156,7 +156,9 @@ def create_general_rp_poly_kernel(d, degrees, learn_proj=False, weighted=False, 
 
 def create_multi_additive_kernel(d, max_degree, weighted=False, kernel_type="RBF", init_lengthscale_range=(1.0, 1.0),
                                  init_mixin_range=(1.0, 1.0), ski=False, ski_options=None, X=None, keops=False):
-    """training_routines.py:247-258: an additive kernel over EVERY feature subset of size 1..max_degree (the group order
+    """EXTRA — outside the hot-path scope table (SURVEY.md §2.1 marks the reference's `create_multi_*` factories out of
+    scope; no served spec reaches it).  Kept because it is ten lines over `CustomAdditiveKernel`.
+    training_routines.py:247-258: an additive kernel over EVERY feature subset of size 1..max_degree (the group order
     inside one size follows the reference's `list(set(combinations(...)))`, so the same torch RNG stream initialises the
     same groups)."""
     from itertools import combinations
@@ -299,103 +301,125 @@ def _save_state_dict(model):
     return fname
 
 
-def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwargs, devices=("cpu",),
-                   skip_posterior_variances=False, skip_random_restart=False, evaluate_on_train=True,
-                   output_device=None, record_pred_unc=False, double=False):
-    """Create and train an exact GP with the given options (training_routines.py:469-585).
-    Returns (model_metrics, pred_mean [cpu float32], model)."""
-    from . import settings
-    model_kwargs = copy.copy(model_kwargs)
-    train_kwargs = copy.copy(train_kwargs)
-    d = trainX.shape[-1]
-    devices = [torch.device(device) for device in devices]
-    output_device = devices[0] if output_device is None else torch.device(output_device)
-    if double and model_kwargs.get("ski", False):
+def _check_double_supported(kind, model_kwargs):
+    """`--double` (training_routines.py:481) is served by the float64 parity kernels of the RBF hot path."""
+    if model_kwargs.get("ski", False):
         raise NotImplementedError("--double is not available for the SKI operator (fp32 kernels only)")
-    if double and (kind in ("rp_poly", "additive", "general_rp_poly") or (kind == "strictly_additive" and not model_kwargs.get("memory_efficient"))
-                   or (kind == "additive_rp" and (model_kwargs.get("kernel_type", "RBF") != "RBF" or model_kwargs.get("k", 1) > 1))):
+    outside = kind in ("rp_poly", "additive", "general_rp_poly") or \
+        (kind == "strictly_additive" and not model_kwargs.get("memory_efficient")) or \
+        (kind == "additive_rp" and (model_kwargs.get("kernel_type", "RBF") != "RBF" or model_kwargs.get("k", 1) > 1))
+    if outside:
         raise NotImplementedError("--double is served by the float64 parity kernels of the RBF hot path only "
                                   "(additive_rp with 1-D RBF sub-kernels, the memory-efficient GAM, kind full)")
-    type_ = torch.double if double else torch.float
-    trainX = trainX.to(output_device, type_).contiguous()
-    trainY = trainY.to(output_device, type_).contiguous()
-    testX = testX.to(output_device, type_).contiguous()
-    testY = testY.to(output_device, type_).contiguous()
 
-    for k, v in list(model_kwargs.items()):
-        if isinstance(v, str) and v == "d":
-            model_kwargs[k] = d
 
-    random_restarts = train_kwargs.pop("random_restarts", 1)
-    init_iters = train_kwargs.pop("init_iters", 20)
-    optimizer_ = _map_to_optim(train_kwargs.pop("optimizer"))
-    rr_check_conv = train_kwargs.pop("rr_check_conv", False)
-    initial_train_kwargs = copy.copy(train_kwargs)
-    initial_train_kwargs["max_iter"] = init_iters
-    initial_train_kwargs["check_conv"] = rr_check_conv
+class _ExactGPFactory:
+    """Builds (model, likelihood, mll) on the output device; under a process group every rank starts from rank 0's
+    parameters (projection draw, lengthscale / noise initialisation)."""
 
-    def new_model():
-        model, likelihood = create_exact_gp(trainX, trainY, kind, devices=devices, **model_kwargs)
-        model = model.to(output_device, type_)
+    def __init__(self, trainX, trainY, kind, model_kwargs, devices, output_device, dtype):
+        self.args = (trainX, trainY, kind)
+        self.model_kwargs, self.devices, self.output_device, self.dtype = model_kwargs, devices, output_device, dtype
+
+    def __call__(self):
+        trainX, trainY, kind = self.args
+        model, likelihood = create_exact_gp(trainX, trainY, kind, devices=self.devices, **self.model_kwargs)
+        model = model.to(self.output_device, self.dtype)
         if is_distributed():
-            # every rank must start from identical parameters (projection draw, lengthscale / noise init).  The
-            # broadcast runs AFTER the move to the output device: RCCL ("nccl") has no backend for CPU tensors.
+            # (after the move to the output device: RCCL ("nccl") has no backend for CPU tensors)
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
         return model, likelihood, ExactMarginalLogLikelihood(likelihood, model)
 
-    best_model, best_likelihood, best_mll, best_loss = None, None, None, np.inf
-    if not skip_random_restart:
-        for _ in range(random_restarts):
-            model, likelihood, mll = new_model()
-            train_to_convergence(model, trainX, trainY, optimizer=optimizer_, objective=mll, isloss=False,
-                                 **initial_train_kwargs)
-            model.train()
-            with torch.no_grad():
-                loss = -mll(model(trainX), trainY).item()
-            if loss < best_loss or best_model is None:
-                best_loss, best_model, best_likelihood, best_mll = loss, model, likelihood, mll
-        model, likelihood, mll = best_model, best_likelihood, best_mll
-    else:
-        model, likelihood, mll = new_model()
 
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        trained_epochs = train_to_convergence(model, trainX, trainY, optimizer=optimizer_, objective=mll,
-                                              isloss=False, **train_kwargs)
+def _best_of_restarts(factory, trainX, trainY, optimizer_, n_restarts, restart_kwargs):
+    """`random_restarts` short fits from fresh initialisations; the one with the lowest negative MLL is trained on
+    (training_routines.py:507-528)."""
+    best, best_loss = None, np.inf
+    for _ in range(n_restarts):
+        candidate = factory()
+        model, _, mll = candidate
+        train_to_convergence(model, trainX, trainY, optimizer=optimizer_, objective=mll, isloss=False, **restart_kwargs)
+        model.train()
+        with torch.no_grad():
+            loss = -mll(model(trainX), trainY).item()
+        if best is None or loss < best_loss:
+            best, best_loss = candidate, loss
+    return best
 
-    model.eval()
-    likelihood.eval()
-    mll.eval()
-    model_metrics = dict()
-    model_metrics["trained_epochs"] = trained_epochs
-    w2 = []
+
+def _evaluate_exact_gp(model, likelihood, mll, trainX, trainY, testX, testY, skip_posterior_variances, evaluate_on_train,
+                       record_pred_unc):
+    """The metric block of training_routines.py:543-583: prior train NMLL (train mode), then posterior quantities in eval
+    mode — train MSE / NLL when `evaluate_on_train`, test NLL, fraction of targets inside the +-2 sigma region, z-scores."""
+    from . import settings
+    metrics, test_warnings = {}, []
     with torch.no_grad():
         model.train()
         likelihood.train()
-        model_metrics["prior_train_nmll"] = -mll(model(trainX), trainY).item()
+        metrics["prior_train_nmll"] = -mll(model(trainX), trainY).item()
         with settings.skip_posterior_variances(skip_posterior_variances):
             model.eval()
             likelihood.eval()
+            train_outputs = model(trainX) if evaluate_on_train else None
             if evaluate_on_train:
-                train_outputs = model(trainX)
-                model_metrics["train_mse"] = mean_squared_error(train_outputs.mean, trainY)
-            with warnings.catch_warnings(record=True) as w2:
+                metrics["train_mse"] = mean_squared_error(train_outputs.mean, trainY)
+            with warnings.catch_warnings(record=True) as test_warnings:
                 warnings.simplefilter("always")
                 test_outputs = model(testX)
                 pred_mean = test_outputs.mean
             if not skip_posterior_variances:
                 if evaluate_on_train:
-                    model_metrics["train_nll"] = -mll(train_outputs, trainY).item()
-                model_metrics["test_nll"] = -mll(test_outputs, testY).item()
-                distro = likelihood(test_outputs)
-                lower, upper = distro.confidence_region()
-                frac = ((testY > lower) * (testY < upper)).to(torch.float).mean().item()
-                model_metrics["test_pred_frac_in_cr"] = frac
+                    metrics["train_nll"] = -mll(train_outputs, trainY).item()
+                metrics["test_nll"] = -mll(test_outputs, testY).item()
+                noisy = likelihood(test_outputs)
+                lower, upper = noisy.confidence_region()
+                metrics["test_pred_frac_in_cr"] = ((testY > lower) * (testY < upper)).to(torch.float).mean().item()
                 if record_pred_unc:
-                    model_metrics["test_pred_z_score"] = (testY - distro.mean) / distro.stddev
-    model_metrics["training_warnings"] = len(w)
-    model_metrics["testing_warning"] = "" if len(w2) == 0 else w2[-1].message
+                    metrics["test_pred_z_score"] = (testY - noisy.mean) / noisy.stddev
+    return metrics, pred_mean, test_warnings
+
+
+def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwargs, devices=("cpu",),
+                   skip_posterior_variances=False, skip_random_restart=False, evaluate_on_train=True,
+                   output_device=None, record_pred_unc=False, double=False):
+    """Create and train an exact GP with the given options (counterpart of training_routines.py:469-585: same arguments,
+    same metric names, same return triple).  Returns (model_metrics, pred_mean [cpu float32], model)."""
+    model_kwargs, train_kwargs = copy.copy(model_kwargs), copy.copy(train_kwargs)
+    if double:
+        _check_double_supported(kind, model_kwargs)
+    dtype = torch.double if double else torch.float
+    devices = [torch.device(dev) for dev in devices]
+    output_device = devices[0] if output_device is None else torch.device(output_device)
+    trainX, trainY, testX, testY = (t.to(output_device, dtype).contiguous() for t in (trainX, trainY, testX, testY))
+    n_features = trainX.shape[-1]
+    model_kwargs = {k: (n_features if isinstance(v, str) and v == "d" else v) for k, v in model_kwargs.items()}
+
+    n_restarts = train_kwargs.pop("random_restarts", 1)
+    restart_iters = train_kwargs.pop("init_iters", 20)
+    optimizer_ = _map_to_optim(train_kwargs.pop("optimizer"))
+    restart_check_conv = train_kwargs.pop("rr_check_conv", False)
+    restart_kwargs = dict(train_kwargs, max_iter=restart_iters, check_conv=restart_check_conv)
+
+    factory = _ExactGPFactory(trainX, trainY, kind, model_kwargs, devices, output_device, dtype)
+    if skip_random_restart:
+        model, likelihood, mll = factory()
+    else:
+        model, likelihood, mll = _best_of_restarts(factory, trainX, trainY, optimizer_, n_restarts, restart_kwargs)
+
+    with warnings.catch_warnings(record=True) as fit_warnings:
+        warnings.simplefilter("always")
+        trained_epochs = train_to_convergence(model, trainX, trainY, optimizer=optimizer_, objective=mll, isloss=False,
+                                              **train_kwargs)
+    model.eval()
+    likelihood.eval()
+    mll.eval()
+    model_metrics = {"trained_epochs": trained_epochs}
+    evaluated, pred_mean, test_warnings = _evaluate_exact_gp(model, likelihood, mll, trainX, trainY, testX, testY,
+                                                             skip_posterior_variances, evaluate_on_train, record_pred_unc)
+    model_metrics.update(evaluated)
+    model_metrics["training_warnings"] = len(fit_warnings)
+    model_metrics["testing_warning"] = "" if len(test_warnings) == 0 else test_warnings[-1].message
     model_metrics["state_dict_file"] = _save_state_dict(model)
     return model_metrics, pred_mean.to("cpu", torch.float), model
 

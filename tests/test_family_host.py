@@ -345,20 +345,3 @@ def test_model_average_weights_and_routine(oracle_backend, tmp_path):
     json.dump(spec, open(f, "w"))
     df = runner.main(["-m", str(f), "-d", "synthetic:tiny", "-o", str(tmp_path / "ma.csv"), "--no_cv"])
     assert np.isfinite(df.iloc[0]["normal_mean_mse"]) and np.isfinite(df.iloc[0]["rmse"])
-
-
-def test_introspection_helpers():
-    """utils.get_lengthscales / get_mixins / get_outputscale / format_for_str (reference utils.py:7-52)."""
-    from rpgp_amd import utils
-    from rpgp_amd.kernels import ScaleKernel
-    from rpgp_amd.training import create_additive_rp_kernel, create_general_rp_poly_kernel
-    torch.manual_seed(0)
-    g = ScaleKernel(create_general_rp_poly_kernel(5, [1, 2, 1], weighted=True, init_lengthscale_range=(0.5, 2.0)))
-    ls = utils.get_lengthscales(g)
-    assert [len(c) for c in ls] == [1, 2, 1] and all(0.5 <= v <= 2.0 for c in ls for v in c)
-    mix = utils.get_mixins(g)
-    assert len(mix) == 3 and abs(sum(mix) - 1.0) < 1e-6
-    assert float(utils.get_outputscale(g)) == float(g.outputscale) and utils.get_outputscale(g.base_kernel) is None
-    a = ScaleKernel(create_additive_rp_kernel(5, 4, prescale=True))
-    assert utils.get_lengthscales(a).shape[-1] == 5 and utils.get_mixins(a) is None
-    assert utils.format_for_str(torch.tensor([1.23456, 2.0])) == [1.235, 2.0] and utils.format_for_str("x") == ""

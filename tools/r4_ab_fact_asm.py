@@ -15,8 +15,9 @@ lib = _lib.load()
 out = torch.empty_like(V)
 
 
-def run(flag, reps=20):
+def run(flag, reps=20, taper="1"):
     os.environ["RPGP_FACT_ASM"] = flag
+    os.environ["RPGP_TAPER"] = taper
     for _ in range(3):
         ops.mvm_sym_prepared(prep, V, 1.0 / J, 0.1, out=out)
     torch.cuda.synchronize()
@@ -35,9 +36,12 @@ def run(flag, reps=20):
 res = {"N": N, "pairs": []}
 for _ in range(4):
     a = run("1")
+    u = run("1", taper="0")
     c = run("0")
-    res["pairs"].append({"asm_kernel_ms": a[0], "asm_step_ms": a[1], "compiler_kernel_ms": c[0], "compiler_step_ms": c[1]})
+    res["pairs"].append({"asm_tapered_kernel_ms": a[0], "asm_tapered_step_ms": a[1], "asm_uniform_kernel_ms": u[0],
+                         "compiler_kernel_ms": c[0], "compiler_step_ms": c[1]})
 o1 = None
+os.environ["RPGP_TAPER"] = "1"
 os.environ["RPGP_FACT_ASM"] = "1"; oa = ops.mvm_sym_prepared(prep, V, 1.0 / J, 0.1).clone()
 os.environ["RPGP_FACT_ASM"] = "0"; oc = ops.mvm_sym_prepared(prep, V, 1.0 / J, 0.1).clone()
 res["rel_diff_asm_vs_compiler"] = float((oa - oc).norm() / oc.norm())

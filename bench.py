@@ -216,6 +216,12 @@ def main():
     # those of one dense-equivalent MVM, attributed to the slowest rank's kernel time
     achieved = b_alg / (kernel_ms * 1e-3)
 
+    tt = 1 if T == 1 else (4 if T <= 4 else 12)
+    if not fast:
+        kernel_name = "mvm_tile_kernel<20,%d,2,sym>" % tt
+    else:
+        kid = lib.rpgp_prepared_kernel_id(N, J, T) if world == 1 else 0
+        kernel_name = {1: "mvm_fact_asm_kernel", 2: "mvm_mfma_kernel<20,1>"}.get(kid, "mvm_fact_kernel<20,%d,2>" % tt)
     # literal HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected live); reported only
     # when the profile was taken on the same kernel + workload as this run AND on the kernel source this run was built
     # from (tools/collect_pmc.py stamps the sha256 of rpgp_kernels.hip into the file; a stale profile gives null)
@@ -226,7 +232,7 @@ def main():
         ksrc = os.path.join(ROOT, "randomly-projected-additive-gps_amd", "csrc", "rpgp_kernels.hip")
         same_source = prof.get("kernel_source_sha256") == hashlib.sha256(open(ksrc, "rb").read()).hexdigest()
         if prof.get("N") == N and prof.get("J") == J and prof.get("T") == T and world == 1 and \
-                prof.get("fast") == fast and same_source:
+                prof.get("fast") == fast and same_source and prof.get("kernel") == kernel_name:
             traffic = prof["hbm_bytes_high"]
     except Exception:
         traffic = None
@@ -259,7 +265,7 @@ def main():
                                         "in this run") if traffic is not None else None,
                      "limiter": "VALU + transcendental issue (v_exp_f32 at quarter rate); neither HBM nor the matrix "
                                 "pipe is saturated",
-                     "kernel": ("mvm_fact_kernel<20,%d,2>" if fast else "mvm_tile_kernel<20,%d,2,sym>") % (1 if T == 1 else (4 if T <= 4 else 12)), "kernel_ms": round(kernel_ms, 4),
+                     "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes": b_alg,
                      "pair_terms_per_s": round(0.5 * N * N * J / (kernel_ms * 1e-3), 1),
                      "note": "dense-equivalent bytes (4N^2+4N(d+2T)); the fused kernel is VALU/transcendental-bound, "

@@ -488,6 +488,12 @@ int rpgp_bilinear_grad_dense_f64(const double *Z, const double *S, double *gZ, d
 int rpgp_profile_begin(void);
 int rpgp_profile_end(float *avg_ms_host, int *count_host);
 
+/* Which kernel `rpgp_mvm_sym_prepared` launches for a single-GPU N x N operator with J projections and T right-hand sides on
+ * THIS process' settings (benchmark / profile labelling only; no reference counterpart — GPyTorch has one `_matmul`):
+ *   0 = mvm_fact_kernel (compiler-scheduled), 1 = mvm_fact_asm_kernel (hand-scheduled loop, rpgp_fact_asm.hip),
+ *   2 = mvm_mfma_kernel (RPGP_MFMA=1).  Negative: RPGP_EINVAL. */
+int rpgp_prepared_kernel_id(int64_t N, int J, int T);
+
 #ifdef __cplusplus
 }
 #endif

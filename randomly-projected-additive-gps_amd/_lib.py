@@ -106,6 +106,7 @@ SIGNATURES = {
     "rpgp_woodbury_setup": (_int, [_vp, _f64, _int, _vp, _vp, _vp, _vp]),
     "rpgp_profile_begin": (_int, []),
     "rpgp_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
+    "rpgp_prepared_kernel_id": (_int, [ctypes.c_int64, _int, _int]),
 }
 
 class RpgpOperator(ctypes.Structure):

@@ -4126,6 +4126,14 @@ int rpgp_init(void) {
   return 0;
 }
 
+int rpgp_prepared_kernel_id(int64_t N, int J, int T) {
+  if (N <= 0 || J <= 0 || T <= 0) return -RPGP_EINVAL;
+  if (rpgp_init()) return -RPGP_EINVAL;
+  if (use_mfma_plan(N, T) && mfma_requested() && rpgp_internal::mfma_supported(next_j_piece(J), next_t_piece(T))) return 2;
+  const TilePlan p = make_plan(N, N, true, T);
+  return fact_asm_applies(p, T, J, 0, J) ? 1 : 0;
+}
+
 int rpgp_profile_begin(void) {
   if (!g_prof_on) {
     for (int i = 0; i < 2 * kProfMax; ++i)

@@ -12,9 +12,14 @@ for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            if "mvm_fact_kernel<20, 1, 2>" not in n and "mvm_tile_kernel<20, 1, 2, true" not in n:
+            if "mvm_fact_asm_kernel" in n:
+                kname = "mvm_fact_asm_kernel"
+            elif "mvm_fact_kernel<20, 1, 2>" in n:
+                kname = "mvm_fact_kernel<20,1,2>"
+            elif "mvm_tile_kernel<20, 1, 2, true" in n:
+                kname = "mvm_tile_kernel<20,1,2,sym>"
+            else:
                 continue
-            kname = "mvm_fact_kernel<20,1,2>" if "mvm_fact" in n else "mvm_tile_kernel<20,1,2,sym>"
             c = r["Counter_Name"]
             sums[c] = sums.get(c, 0.0) + float(r["Counter_Value"])
             counts[c] = counts.get(c, 0) + 1
@@ -34,6 +39,9 @@ if "SQ_INSTS_VALU_TRANS_F32" in means and "SQ_INSTS_VALU" in means and "GRBM_GUI
     trans, valu = means["SQ_INSTS_VALU_TRANS_F32"], means["SQ_INSTS_VALU"]
     other = valu - trans
     need = (trans * 8.2 + other * 4.4) / 1024.0          # SIMD-cycles by the measured issue costs (packed VALU: 4.4)
+    if kname == "mvm_fact_asm_kernel":
+        # the generated loop's own mix per step (tools/gen_fact_asm.py): 40 exp, 41 packed, 2 v_fmac (2.2), 1 DPP move (4.4)
+        need = (trans * 8.2 + (other - trans * 2.0 / 40.0) * 4.4 + trans * 2.0 / 40.0 * 2.2) / 1024.0
     have = means["GRBM_GUI_ACTIVE"] / 8.0                 # the counter is summed over the 8 XCDs
     res["trans_wave_instr_expected"] = 50000.0 * 50000.0 * 20 / 2 / 64
     res["issue_model"] = "%.4g trans x 8.2 cyc + %.4g other VALU x 4.4 cyc = %.4g SIMD-cycles per SIMD; GRBM_GUI_ACTIVE/8 = " \

@@ -224,13 +224,17 @@ def main():
         kernel_name = {1: "mvm_fact_asm_kernel", 2: "mvm_mfma_kernel<20,1>"}.get(kid, "mvm_fact_kernel<20,%d,2>" % tt)
     # literal HBM bytes per launch from the committed rocprofv3 --pmc passes (cannot be collected live); reported only
     # when the profile was taken on the same kernel + workload as this run AND on the kernel source this run was built
-    # from (tools/collect_pmc.py stamps the sha256 of rpgp_kernels.hip into the file; a stale profile gives null)
+    # from (tools/collect_pmc.py stamps the sha256 of the kernel's source files into the file; a stale profile gives null)
     traffic = None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters_current.json")))
         import hashlib
-        ksrc = os.path.join(ROOT, "randomly-projected-additive-gps_amd", "csrc", "rpgp_kernels.hip")
-        same_source = prof.get("kernel_source_sha256") == hashlib.sha256(open(ksrc, "rb").read()).hexdigest()
+        csrc = os.path.join(ROOT, "randomly-projected-additive-gps_amd", "csrc")
+        files = ["rpgp_fact_asm.hip", "rpgp_fact_asm_loop.inc"] if kernel_name == "mvm_fact_asm_kernel" else ["rpgp_kernels.hip"]
+        hsh = hashlib.sha256()
+        for f in files:
+            hsh.update(open(os.path.join(csrc, f), "rb").read())
+        same_source = prof.get("kernel_source_sha256") == hsh.hexdigest()
         if prof.get("N") == N and prof.get("J") == J and prof.get("T") == T and world == 1 and \
                 prof.get("fast") == fast and same_source and prof.get("kernel") == kernel_name:
             traffic = prof["hbm_bytes_high"]

@@ -56,6 +56,8 @@ class GaussianLikelihood(nn.Module):
     def forward(self, dist):
         """p(y | f): adds the observation noise to the covariance."""
         noise = self.noise.reshape(())
+        if hasattr(dist, "with_observation_noise"):     # models.TrainPosterior: the covariance stays implicit
+            return dist.with_observation_noise(noise.detach())
         cov = dist.covariance
         if isinstance(cov, LinearOperator):
             return MultivariateNormal(dist.mean, cov.add_diag(noise))

@@ -231,6 +231,59 @@ class PredictionStrategy:
                     cov64[r0:r0 + ridx.numel(), c0:c0 + idx.numel()] -= rows.double() @ S
         return cov64.to(cov.dtype)
 
+    # ---- posterior at the training inputs in closed form -----------------------------------------------------------------
+    def _train_closed_form_ready(self, like):
+        """Closed form available: the dense (Cholesky) regime, or the CG regime where the float32 factor + float64 copy of
+        the mixed-precision solve exist / fit (settings.solve_refinement on)."""
+        if self.dense_path:
+            return True
+        n = self.r.shape[0]
+        return self._mixed_precision_ready(like, n, 1)
+
+    def train_log_prob(self, target):
+        """log N(target | mu_train, Sigma_train + sigma^2 I) with Sigma_train = K - K Khat^-1 K = sigma^2 (I - sigma^2 Khat^-1):
+             C := Sigma_train + sigma^2 I = 2 sigma^2 I - sigma^4 Khat^-1 = sigma^2 Khat^-1 B,   B := 2 K + sigma^2 I
+             C^-1 = B^-1 Khat / sigma^2 ,   log|C| = N log sigma^2 - log|Khat| + log|B|
+        i.e. one more factorisation (of B, same kernel matrix with another diagonal) instead of the N x N posterior
+        covariance, its N^3 products and a float64 Cholesky of it.  Replaces `mll(train_outputs, trainY)` of
+        training_routines.py:567-569 for the train set."""
+        N = self.r.shape[0]
+        s2 = float(self.noise)
+        mean = (self.model.train_targets.double().reshape(-1, 1) - s2 *
+                (self.alpha64 if getattr(self, "alpha64", None) is not None else self.alpha.double()))
+        d = target.double().reshape(-1, 1) - mean
+        if self.dense_path:
+            Lk = self.chol.double()
+            Khat = Lk @ Lk.t()
+            B = 2.0 * Khat
+            B.diagonal().sub_(s2)
+            Lb = psd_safe_cholesky(B)
+            w = torch.cholesky_solve(d, Lb)
+            quad = float((d * (Khat @ w)).sum()) / s2
+            logdet = N * math.log(s2) - 2.0 * float(torch.log(Lk.diagonal()).sum()) + 2.0 * float(torch.log(Lb.diagonal()).sum())
+            return -0.5 * (quad + logdet + N * LOG2PI)
+        Lc, K64 = self._mp                                       # float32 factor and float64 copy of Khat
+        logdet_khat = 2.0 * float(torch.log(Lc.diagonal().double()).sum())
+        B64 = 2.0 * K64
+        B64.diagonal().sub_(s2)
+        Lb, info = torch.linalg.cholesky_ex(B64.float())
+        if int(info) != 0:
+            raise RuntimeError("2 K + sigma^2 I is not positive definite in float32")
+        logdet_b = 2.0 * float(torch.log(Lb.diagonal().double()).sum())
+        w = torch.cholesky_solve(d.float(), Lb).double()
+        dn = float(d.norm())
+        for _ in range(4):                                       # float64 residuals against B, float32 factor corrections
+            res = d - B64 @ w
+            if float(res.norm()) < 1e-9 * dn:
+                break
+            scale = float(res.abs().max())
+            w = w + torch.cholesky_solve((res / scale).float(), Lb).double() * scale
+        del Lb
+        quad = float((d * (K64 @ w)).sum()) / s2
+        del B64
+        logdet = N * math.log(s2) - logdet_khat + logdet_b
+        return -0.5 * (quad + logdet + N * LOG2PI)
+
     def solve(self, B):
         if self.dense_path:
             return torch.cholesky_solve(B, self.chol)
@@ -296,6 +349,22 @@ class PredictionStrategy:
         return self._chol64
 
     def predict(self, xs):
+        model = self.model
+        at_train = xs is model.train_inputs or (xs.shape == model.train_inputs.shape and
+                                                xs.data_ptr() == model.train_inputs.data_ptr())
+        with torch.no_grad():
+            if at_train and self._train_closed_form_ready(xs):
+                # the posterior AT the training inputs (`evaluate_on_train`, training_routines.py:551-556): the mean is
+                # y - sigma^2 alpha, and log N(y | mu, Sigma + sigma^2 I) has a closed form in Khat — no N x N posterior
+                # covariance is formed unless somebody asks for it (C4: 19 s of library GEMMs + a 50 000^2 float64 Cholesky)
+                a = self.alpha64 if getattr(self, "alpha64", None) is not None else self.alpha.double()
+                mean = (model.train_targets.double().reshape(-1, 1) - float(self.noise) * a).reshape(-1).to(xs.dtype)
+                if settings.skip_posterior_variances.on():
+                    return MultivariateNormal(mean, torch.zeros_like(mean), diagonal_only=True)
+                return TrainPosterior(mean, self, xs)
+            return self._predict_general(xs)
+
+    def _predict_general(self, xs):
         model = self.model
         with torch.no_grad():
             cross = model.covar_module(xs, model.train_inputs)      # K(X*, X) operator
@@ -373,6 +442,37 @@ class PredictionStrategy:
                 cov -= BtS + BtS.t() - S.t() @ KS
             cov = 0.5 * (cov + cov.t())
         return MultivariateNormal(mean, cov)
+
+
+class TrainPosterior(MultivariateNormal):
+    """Posterior at the training inputs.  `mean` is exact (y - sigma^2 alpha); the log-density of the noisy version comes from
+    the strategy's closed form; the N x N covariance (or its diagonal) is only computed when somebody reads it."""
+
+    def __init__(self, mean, strategy, xs, noise=None):
+        self.mean = mean
+        self.diagonal_only = False
+        self._strategy, self._xs, self._noise, self._cov = strategy, xs, noise, None
+
+    @property
+    def covariance(self):
+        if self._cov is None:
+            cov = self._strategy._predict_general(self._xs).covariance
+            if self._noise is not None:
+                cov = cov.clone()
+                cov.diagonal().add_(self._noise)
+            self._cov = cov
+        return self._cov
+
+    def with_observation_noise(self, noise):
+        """p(y | f) at the training inputs (what `likelihood(train_outputs)` returns)."""
+        return TrainPosterior(self.mean, self._strategy, self._xs, noise=noise)
+
+    def log_prob(self, value):
+        strategy = self._strategy
+        same_noise = self._noise is not None and abs(float(self._noise) - float(strategy.noise)) <= 1e-12 * float(strategy.noise)
+        if not same_noise:
+            return super().log_prob(value)
+        return torch.as_tensor(strategy.train_log_prob(value), dtype=value.dtype, device=value.device)
 
 
 class ExactGP(nn.Module):
@@ -454,8 +554,11 @@ class ExactMarginalLogLikelihood(nn.Module):
 
     def forward(self, output, target):
         n = target.shape[0]
-        cov = output.covariance
         noise = self.likelihood.noise.reshape(())
+        if isinstance(output, TrainPosterior):
+            res = self.likelihood(output).log_prob(target) + self.likelihood.log_prior().to(target.dtype)
+            return res / n
+        cov = output.covariance
         if isinstance(cov, AdditiveRPOperator):
             r = target - output.mean
             inv_quad, logdet = inv_quad_logdet(cov, noise, r)

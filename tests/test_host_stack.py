@@ -517,3 +517,27 @@ def test_row_sharded_woodbury_and_wide_blocks_keep_the_cancellation_in_float64()
         assert abs(a - b) < 1e-6 * max(abs(a), abs(b))
     sh = RowShardedWoodbury(L, noise, RowShard(N))
     assert abs(sh.logdet() - WoodburyPreconditioner(L, noise).logdet()) < 1e-9 * N
+
+
+def test_train_posterior_closed_form_matches_explicit_covariance(oracle_backend):
+    """`evaluate_on_train` (training_routines.py:551-556,567-569): the posterior at the training inputs comes back as
+    models.TrainPosterior — mean y - sigma^2 alpha, log-density of the noisy version from the closed form in Khat — and
+    equals what the explicit N x N posterior covariance gives (the oracle's test_nll evaluated on the train set)."""
+    from rpgp_amd.models import TrainPosterior
+    X, y, P, ls, noise, s = _problem(N=150, d=5, J=7, seed=3, noise=0.2)
+    model, lik, mll = _build_model(X, y, P, ls, noise, s)
+    ref = _oracle_gp(X, y, P, ls, noise, s)
+    model.eval()
+    with torch.no_grad():
+        out = model(X)
+        assert isinstance(out, TrainPosterior)
+        nll = -mll(out, y).item()
+        mean_ref, cov_ref = ref.predict(X.numpy(), full_cov=True)
+        assert np.linalg.norm(out.mean.numpy() - mean_ref) / np.linalg.norm(mean_ref) < 1e-4
+        assert abs(nll - ref.test_nll(X.numpy(), y.numpy())) < 1e-4 * abs(nll) + 1e-5
+        # the lazily formed covariance is the general path's
+        assert np.abs(out.variance.numpy() - np.diag(cov_ref)).max() < 1e-4
+        # another tensor with the same values is NOT the training set object: the general path answers, same numbers
+        out2 = model(X.clone())
+        assert not isinstance(out2, TrainPosterior)
+        assert abs(-mll(out2, y).item() - nll) < 1e-4 * abs(nll) + 1e-5

@@ -4,7 +4,17 @@ usage: collect_pmc.py <out.json> <dir> [<dir> ...]"""
 import csv, glob, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KSRC = os.path.join(ROOT, "randomly-projected-additive-gps_amd", "csrc", "rpgp_kernels.hip")
+CSRC = os.path.join(ROOT, "randomly-projected-additive-gps_amd", "csrc")
+
+
+def kernel_source_sha256(kernel_name):
+    """sha256 over the source files the measured kernel is compiled from (bench.py recomputes it: a profile of another
+    source gives roofline.traffic = null)."""
+    files = ["rpgp_fact_asm.hip", "rpgp_fact_asm_loop.inc"] if kernel_name == "mvm_fact_asm_kernel" else ["rpgp_kernels.hip"]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
 
 out, dirs = sys.argv[1], sys.argv[2:]
 sums, counts, kname = {}, {}, None
@@ -28,7 +38,7 @@ res = {"kernel": kname, "workload": "N=50000 J=20 T=1 (bench.py default, factori
        "T": 1, "fast": kname is not None and "fact" in kname,
        # ties this file to the kernel source it was measured on: bench.py reports roofline.traffic only when the sha256 of
        # the rpgp_kernels.hip it runs equals this one
-       "kernel_source_sha256": hashlib.sha256(open(KSRC, "rb").read()).hexdigest(), "launches_per_counter": counts, "per_launch_means": means,
+       "kernel_source_sha256": kernel_source_sha256(kname), "launches_per_counter": counts, "per_launch_means": means,
        "notes": "rocprofv3 --pmc, separate passes (FETCH_SIZE / WRITE_SIZE / SQ+GRBM), gfx950. FETCH_SIZE and WRITE_SIZE are "
                 "in KB. MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, so hbm_bytes is "
                 "bracketed as [(FETCH+WRITE)*1024, (2*FETCH+WRITE)*1024]."}

@@ -37,6 +37,14 @@ for rounds in (0, 1, 0, 1):
         res["refine=%d tol=%g" % (rounds, tol)] = {"mean_pred_s": t_mean, "full_cov_s": t_full, "nll_s": t_nll, "test_nll": nll,
                                                    "thin_hist": getattr(st, "refinement_residuals", None),
                                                    "wide_hist": getattr(st, "wide_refinement_residuals", None)}
+# evaluate-on-train (training_routines.py:551-556,567-569): posterior at the 50 000 training inputs + its NLL
+model.train(); model.eval()
+with torch.no_grad(), settings.eval_cg_tolerance(0.01):
+    t_tr, tr_out = timed(lambda: model(model.train_inputs))
+    t_mse, mse = timed(lambda: float(((tr_out.mean - model.train_targets) ** 2).mean()))
+    t_tnll, tnll = timed(lambda: -mll(tr_out, model.train_targets).item())
+res["evaluate_on_train"] = {"posterior_s": t_tr, "train_mse": mse, "train_nll_s": t_tnll, "train_nll": tnll,
+                            "kind": type(tr_out).__name__}
 f64 = model.covar_module.float64_operator(model.train_inputs)
 v = torch.randn(N4, 1, dtype=torch.float64, device=dev)
 f64._matmul(v, 0.1)

@@ -264,23 +264,25 @@ class PredictionStrategy:
             return -0.5 * (quad + logdet + N * LOG2PI)
         Lc, K64 = self._mp                                       # float32 factor and float64 copy of Khat
         logdet_khat = 2.0 * float(torch.log(Lc.diagonal().double()).sum())
-        B64 = 2.0 * K64
-        B64.diagonal().sub_(s2)
-        Lb, info = torch.linalg.cholesky_ex(B64.float())
+        # B in float32 from the stored kernel matrix (one N x N float32 block, factorised); B w in float64 is
+        # 2 Khat_64 w - sigma^2 w: no float64 copy of B
+        Bf = self._dense_khat.Kd[:, :N] * 2.0
+        Bf.diagonal().add_(s2)
+        Lb, info = torch.linalg.cholesky_ex(Bf)
+        del Bf
         if int(info) != 0:
             raise RuntimeError("2 K + sigma^2 I is not positive definite in float32")
         logdet_b = 2.0 * float(torch.log(Lb.diagonal().double()).sum())
         w = torch.cholesky_solve(d.float(), Lb).double()
         dn = float(d.norm())
         for _ in range(4):                                       # float64 residuals against B, float32 factor corrections
-            res = d - B64 @ w
+            res = d - (2.0 * (K64 @ w) - s2 * w)
             if float(res.norm()) < 1e-9 * dn:
                 break
             scale = float(res.abs().max())
             w = w + torch.cholesky_solve((res / scale).float(), Lb).double() * scale
         del Lb
         quad = float((d * (K64 @ w)).sum()) / s2
-        del B64
         logdet = N * math.log(s2) - logdet_khat + logdet_b
         return -0.5 * (quad + logdet + N * LOG2PI)
 

@@ -11,6 +11,7 @@ Two regimes, switched like GPyTorch does (Appendix B.1):
 import torch
 
 from . import settings
+from .hostvals import host_float
 from .linear_cg import linear_cg
 from .operators import AddedDiagOperator, DenseOperator, SKIAdditiveOperator, SymCachedOperator
 from .precond import build_preconditioner
@@ -81,6 +82,7 @@ class InvQuadLogDet(torch.autograd.Function):
         r = rhs.detach().reshape(N, 1)
         ctx.op = op
         ctx.N = N
+        noise_f = op._noise_host if getattr(op, "_noise_host", None) is not None else host_float(noise)
         if use_cholesky(N):
             Kd = khat.to_dense()
             Lc = psd_safe_cholesky(Kd)
@@ -94,14 +96,12 @@ class InvQuadLogDet(torch.autograd.Function):
         num_probes = settings.num_trace_samples.value()
         if getattr(op, "row_shard", None) is not None:
             return _row_sharded_forward(ctx, Z, noise, r, op, num_probes)
-        pre = build_preconditioner(op, float(noise.detach()), settings)
+        pre = build_preconditioner(op, noise_f, settings)
         gen = _probe_generator(Z.device)
         if pre is not None:
             probes = pre.sample(num_probes, generator=gen)
-            logdet_correction = pre.logdet()
         else:
             probes = torch.randn(N, num_probes, generator=gen, device=Z.device, dtype=Z.dtype)
-            logdet_correction = 0.0
         if op.shard is not None and op.shard.world_size > 1:
             # every rank must run the identical CG recurrences: rank 0's probes are broadcast
             import torch.distributed as dist
@@ -123,11 +123,11 @@ class InvQuadLogDet(torch.autograd.Function):
             cache = op.to_symcache(wide=full_rhs.shape[1] > 4) if hasattr(op, "to_symcache") and \
                 settings.use_cached_kernel(N, Z.device, per_rank) else None
             if cache is not None:
-                native_op = SymCachedOperator(cache, op._scale, float(noise.detach()),
+                native_op = SymCachedOperator(cache, op._scale, noise_f,
                                               diag_value=op._scale * op.num_projections, shard=op.shard if sharded else None)
                 matmul = native_op._matmul
             elif not sharded and settings.use_cached_kernel(N, Z.device):
-                native_op = DenseOperator(op.to_dense_cached(), float(noise.detach()))
+                native_op = DenseOperator(op.to_dense_cached(), noise_f)
                 matmul = native_op._matmul
         solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes, operator=native_op,
                                   tolerance=settings.cg_tolerance.value(),
@@ -139,7 +139,10 @@ class InvQuadLogDet(torch.autograd.Function):
         if settings.skip_logdet_forward.on():
             logdet = torch.zeros((), dtype=Z.dtype, device=Z.device)
         else:
-            logdet = torch.as_tensor(float(slq_logdet(t_mat, N)) + logdet_correction, dtype=Z.dtype, device=Z.device)
+            # log|M| of the preconditioner is read AFTER the solve (whose end is a synchronisation anyway: a short copy, no
+            # idle device in front of it); the value goes back as a fill, not as a host-to-device copy
+            logdet_correction = pre.logdet() if pre is not None else 0.0
+            logdet = torch.full((), float(slq_logdet(t_mat, N)) + logdet_correction, dtype=Z.dtype, device=Z.device)
         ctx.mode = "cg"
         ctx.pre = pre
         ctx.num_probes = num_probes
@@ -287,5 +290,6 @@ def _row_sharded_backward(ctx, g_inv_quad, g_logdet):
 def inv_quad_logdet(op, noise, rhs):
     """op: symmetric AdditiveRPOperator on (Z, outputscale) (both may require grad); noise: 0-dim tensor; rhs: (N,)."""
     noise_t = noise.reshape(())
+    op._noise_host = getattr(noise, "_host_value", None)      # (set by hostvals.prefetch in the marginal log-likelihood)
     gr = InvQuadLogDet.apply(op.Z1, op.outputscale, noise_t, rhs, op, getattr(op, "comp_weights", None))
     return gr

@@ -105,8 +105,17 @@ class AdditiveStructureRBFKernel(Kernel):
             raise ValueError("only 1-D grid interpolation per projection is supported (ski_options.num_dims == 1)")
         self.grid_size = int(opts.get("grid_size", 1024))
 
+    def _constants(self):
+        """(weight, inner lengthscale) as Python floats: frozen buffers, read from the device ONCE (not once per step)."""
+        c = getattr(self, "_const_cache", None)
+        key = (self.weight.data_ptr(), self.weight._version, self.inner_lengthscale.data_ptr(), self.inner_lengthscale._version)
+        if c is None or c[0] != key:
+            c = (key, float(self.weight), float(self.inner_lengthscale))
+            self._const_cache = c
+        return c[1], c[2]
+
     def operator(self, Z1, Z2, outputscale=None, shard=None):
-        il = float(self.inner_lengthscale)
+        weight_f, il = self._constants()
         if il != 1.0:
             Z1 = Z1 / il
             Z2 = None if Z2 is None else Z2 / il
@@ -114,13 +123,13 @@ class AdditiveStructureRBFKernel(Kernel):
             if self.ski:
                 raise NotImplementedError("grid interpolation is built for the 1-D RBF sub-kernels only")
             ncomp = Z1.shape[1] // self.group
-            w = torch.full((ncomp,), float(self.weight), dtype=Z1.dtype, device=Z1.device)
+            w = torch.full((ncomp,), weight_f, dtype=Z1.dtype, device=Z1.device)
             return FamilyAdditiveOperator(Z1, Z2, outputscale=outputscale, comp_weights=w, kind=self.kernel_type,
                                           group=self.group)
         if self.ski:
-            return SKIAdditiveOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight),
+            return SKIAdditiveOperator(Z1, Z2, outputscale=outputscale, weight=weight_f,
                                        grid_size=self.grid_size, row_shard=shard if isinstance(shard, RowShard) else None)
-        return AdditiveRPOperator(Z1, Z2, outputscale=outputscale, weight=float(self.weight),
+        return AdditiveRPOperator(Z1, Z2, outputscale=outputscale, weight=weight_f,
                                   shard=shard if isinstance(shard, JShard) else None)
 
     def forward(self, z1, z2, **params):

@@ -11,6 +11,7 @@ from . import settings
 from .dense_ops import DenseKernelOperator
 from .inv_quad_logdet import inv_quad_logdet, psd_safe_cholesky, use_cholesky
 from .likelihoods import ConstantMean, GaussianLikelihood, MultivariateNormal, LOG2PI
+from .hostvals import host_float, prefetch
 from .linear_cg import linear_cg
 from .operators import AddedDiagOperator, AdditiveRPOperator, DenseOperator, SKIAdditiveOperator, SymCachedOperator
 from .precond import build_preconditioner
@@ -75,7 +76,7 @@ class PredictionStrategy:
                 from .operators import row_sharded_preconditioner
                 self.chol = None
                 rs = self.op.row_shard
-                sop = self.op.row_sharded(float(self.noise))
+                sop = self.op.row_sharded(host_float(self.noise))
                 rank_k = settings.max_preconditioner_size.value()
                 pre_sh = row_sharded_preconditioner(sop, rank_k) \
                     if (N >= settings.min_preconditioning_size.value() and rank_k > 0) else None
@@ -86,7 +87,7 @@ class PredictionStrategy:
                 self.alpha[rs.r0:rs.r1] = a_loc
                 rs.all_reduce_(self.alpha, "sum")
                 self.khat = AddedDiagOperator(self.op, self.noise)
-                self.pre = build_preconditioner(self.op, float(self.noise), settings)
+                self.pre = build_preconditioner(self.op, host_float(self.noise), settings)
             else:
                 self.chol = None
                 shard = getattr(self.op, "shard", None)
@@ -98,15 +99,15 @@ class PredictionStrategy:
                 if cache is not None:
                     # thin solves (the mean cache, LOVE's Lanczos) stream the packed symmetric cache: half the bytes of
                     # the dense matrix; the N_test-wide covariance solve builds the dense matrix on demand (solve())
-                    self.khat = SymCachedOperator(cache, self.op._scale, float(self.noise),
+                    self.khat = SymCachedOperator(cache, self.op._scale, host_float(self.noise),
                                                   diag_value=self.op._scale * self.op.num_projections,
                                                   shard=shard if sharded else None)
                 elif cacheable and not sharded and settings.use_cached_kernel(N, x.device):
-                    self.khat = DenseOperator(self.op.to_dense_cached(), float(self.noise))
+                    self.khat = DenseOperator(self.op.to_dense_cached(), host_float(self.noise))
                     self._dense_khat = self.khat
                 else:
                     self.khat = AddedDiagOperator(self.op, self.noise)
-                self.pre = build_preconditioner(self.op, float(self.noise), settings)
+                self.pre = build_preconditioner(self.op, host_float(self.noise), settings)
                 self.alpha = self._solve_thin(self.r)
                 if not sharded:
                     self._refine_mean_cache(model, x)
@@ -132,7 +133,7 @@ class PredictionStrategy:
         op64 = f64(x) if f64 is not None else None
         if op64 is None:
             return
-        noise64 = float(self.noise)
+        noise64 = host_float(self.noise)
         r64 = self.r.double()
         a64 = self.alpha.double()
         rnorm = float(r64.norm())
@@ -171,7 +172,7 @@ class PredictionStrategy:
         if getattr(self, "_mp", None) is None:
             if getattr(self, "_dense_khat", None) is None:
                 self._dense_khat = DenseOperator(self.op.to_dense_cached() if hasattr(self.op, "to_dense_cached")
-                                                 else self.op.to_dense(), float(self.noise))
+                                                 else self.op.to_dense(), host_float(self.noise))
             Kh = self._dense_khat.to_dense()                       # float32, noise on the diagonal
             K64 = Kh.double()
             Lc, info = torch.linalg.cholesky_ex(Kh)
@@ -248,7 +249,7 @@ class PredictionStrategy:
         covariance, its N^3 products and a float64 Cholesky of it.  Replaces `mll(train_outputs, trainY)` of
         training_routines.py:567-569 for the train set."""
         N = self.r.shape[0]
-        s2 = float(self.noise)
+        s2 = host_float(self.noise)
         mean = (self.model.train_targets.double().reshape(-1, 1) - s2 *
                 (self.alpha64 if getattr(self, "alpha64", None) is not None else self.alpha.double()))
         d = target.double().reshape(-1, 1) - mean
@@ -301,7 +302,7 @@ class PredictionStrategy:
                 fits = False
             if fits:
                 if getattr(self, "_dense_khat", None) is None:
-                    self._dense_khat = DenseOperator(self.op.to_dense_cached() if hasattr(self.op, "to_dense_cached") else self.op.to_dense(), float(self.noise))
+                    self._dense_khat = DenseOperator(self.op.to_dense_cached() if hasattr(self.op, "to_dense_cached") else self.op.to_dense(), host_float(self.noise))
                 khat = self._dense_khat
                 if N <= settings.dense_solve_size.value():
                     # with Khat in HBM anyway, a float64 Cholesky (rocSOLVER) solves the N_test-wide block exactly and
@@ -345,7 +346,7 @@ class PredictionStrategy:
             return None
         if getattr(self, "_dense_khat", None) is None:
             self._dense_khat = DenseOperator(self.op.to_dense_cached() if hasattr(self.op, "to_dense_cached")
-                                             else self.op.to_dense(), float(self.noise))
+                                             else self.op.to_dense(), host_float(self.noise))
         if getattr(self, "_chol64", None) is None:
             self._chol64 = psd_safe_cholesky(self._dense_khat.to_dense().double())
         return self._chol64
@@ -360,7 +361,7 @@ class PredictionStrategy:
                 # y - sigma^2 alpha, and log N(y | mu, Sigma + sigma^2 I) has a closed form in Khat — no N x N posterior
                 # covariance is formed unless somebody asks for it (C4: 19 s of library GEMMs + a 50 000^2 float64 Cholesky)
                 a = self.alpha64 if getattr(self, "alpha64", None) is not None else self.alpha.double()
-                mean = (model.train_targets.double().reshape(-1, 1) - float(self.noise) * a).reshape(-1).to(xs.dtype)
+                mean = (model.train_targets.double().reshape(-1, 1) - host_float(self.noise) * a).reshape(-1).to(xs.dtype)
                 if settings.skip_posterior_variances.on():
                     return MultivariateNormal(mean, torch.zeros_like(mean), diagonal_only=True)
                 return TrainPosterior(mean, self, xs)
@@ -563,6 +564,8 @@ class ExactMarginalLogLikelihood(nn.Module):
         cov = output.covariance
         if isinstance(cov, AdditiveRPOperator):
             r = target - output.mean
+            # the two scalars the kernels take by value, in ONE device-to-host copy per step (hostvals)
+            prefetch(cov.outputscale, noise)
             inv_quad, logdet = inv_quad_logdet(cov, noise, r)
             log_prob = -0.5 * (inv_quad + logdet + n * LOG2PI)
         elif isinstance(cov, DenseKernelOperator):

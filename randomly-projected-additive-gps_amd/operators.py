@@ -9,6 +9,7 @@ reference's dependency.  All arithmetic goes through the compute backend (HIP li
 import torch
 
 from . import backend as _backend
+from .hostvals import host_float
 from . import settings
 
 
@@ -99,9 +100,20 @@ class AdditiveRPOperator(LinearOperator):
         self.outputscale = outputscale
         self.weight = float(weight)
         self.shard = shard
-        # one host sync per construction (= per optimiser step); kernels take the scale by value
-        self._scale = float(outputscale.detach()) * self.weight
+        # kernels take the scale by value: fetched on first use (hostvals: the marginal log-likelihood prefetches it together
+        # with the noise in ONE device-to-host copy per optimiser step)
+        self._scale_value = None
         self._prep = None          # rpgp_prepare tables for the factorised fast path (built on first use)
+
+    @property
+    def _scale(self):
+        if self._scale_value is None:
+            self._scale_value = host_float(self.outputscale) * self.weight
+        return self._scale_value
+
+    @_scale.setter
+    def _scale(self, value):
+        self._scale_value = float(value)
 
     # ---- protocol -------------------------------------------------------------------------------------------
     def _size(self):

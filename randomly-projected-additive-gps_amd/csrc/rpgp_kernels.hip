@@ -3834,6 +3834,13 @@ int launch_bilinear_sym(int tt, const TilePlan &p, const float *Z, const float *
       const long long total = (long long)N * JT;
       hipLaunchKernelGGL(scale_columns_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256),
                          0, st, Z, Zs, (long long)N, ldz, j0, JT);
+      if constexpr (JT == 20) {
+        // the hand-scheduled loop (rpgp_bil_asm.hip) for the training block (5 .. 12 right-hand-side slots) of the whole
+        // J = 20 operator; RPGP_BIL_ASM=0 keeps the compiler-scheduled kernel (A/B runs, tests)
+        const char *ea = getenv("RPGP_BIL_ASM");
+        if (tt > 4 && T <= 12 && g_rotdir == 1 && !(ea && ea[0] == '0'))
+          return rpgp_internal::launch_bilinear_sym_asm(Zs, L, R, slabR, slabT, N, T, p.chunk_cols, p.total_wg, st);
+      }
       if (tt <= 4)
         hipLaunchKernelGGL((bilinear_sym_kernel<JT, 4, true>), grid, block, 0, st, Zs, L, R, slabR, slabT, N, JT, T, 0,
                            p.chunk_cols, g_rotdir, 0, 0, 0, N);

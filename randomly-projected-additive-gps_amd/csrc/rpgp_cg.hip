@@ -192,11 +192,55 @@ __device__ __forceinline__ void block_ltsum(const floatx4m &acc, float *__restri
   dst[e] = ((sh[e] + sh[256 + e]) + sh[512 + e]) + sh[768 + e];
 }
 
+// ---- the reduction folded into the producing pass ------------------------------------------------------------------------
+// With few partial slabs (small N: 29 at C2, 59 at C3) a k_reduce launch between two passes costs more than the sums
+// themselves (5 us kernel + a launch boundary, 45 times per optimiser step).  Instead the LAST workgroup of the pass to finish
+// adds up all the slabs — per entry in slab order, float64: a fixed order whoever comes last, so the result stays bitwise
+// reproducible.  Hand-off per MI355X_MICROARCH.md (Valid forms): every storing wave drains its stores, workgroup barrier,
+// lane 0: agent-scope release, arrive on the counter; the last arriver: agent-scope acquire, drain, workgroup barrier, plain
+// loads.  The counter returns to 0 for the next pass (ordered by the kernel boundary).  `counter == nullptr`: no fold.
+constexpr int kFoldMaxParts = 128;
+__device__ __forceinline__ void fold_reduce(const float *__restrict__ part, int nparts, double *__restrict__ red,
+                                            unsigned *__restrict__ counter) {
+  if (!counter) return;
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == gridDim.x - 1;
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int e = threadIdx.x; e < kRedW; e += 256) {
+    double acc = 0.0;
+    int q = 0;
+    for (; q + 7 < nparts; q += 8) {             // eight loads in flight, added in slab order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(q + u) * kRedW + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; q < nparts; ++q) acc += (double)part[(size_t)q * kRedW + e];
+    red[e] = acc;
+  }
+}
+
 // ---- pass A: partial p.Ap per column, partial L^T (Ap) ------------------------------------------------------------
 // part[blk][0..15] = sum over the workgroup's rows of a*b per column; part[blk][32 + kk*16 + t] = sum L[row][kk] b[row][t]
 template <int TT>
 __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, const float *__restrict__ b,
-                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K) {
+                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K,
+                                                double *__restrict__ red_out = nullptr, unsigned *__restrict__ fold_counter = nullptr) {
   __shared__ float sh[1024];
   const Lane ln;
   float dot = 0.f;
@@ -238,6 +282,7 @@ __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, con
   block_colsum(dot, sh, dst, ln);
   if (threadIdx.x < 16) dst[16 + threadIdx.x] = 0.f;
   block_ltsum(lt, sh, dst + kRedLt, ln);
+  fold_reduce(part, (int)gridDim.x, red_out, fold_counter);
 }
 
 // red[e] = sum over the slabs of part[.][e] in float64, fixed order: workgroup b owns entries 8 b .. 8 b + 7, its 32
@@ -272,7 +317,8 @@ template <int TT>
 __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, const double *__restrict__ red_sq,
                                               float *__restrict__ r, float *__restrict__ x, float *__restrict__ p,
                                               float *__restrict__ Ap, const float *__restrict__ L,
-                                              float *__restrict__ part, CgState *__restrict__ st, long long N, int K) {
+                                              float *__restrict__ part, CgState *__restrict__ st, long long N, int K,
+                                              double *__restrict__ red_out = nullptr, unsigned *__restrict__ fold_counter = nullptr) {
   __shared__ float sh[1024];
   __shared__ float snrm[kMaxT];
   const Lane ln;
@@ -337,6 +383,7 @@ __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, con
   __syncthreads();
   if (threadIdx.x < 32) dst[threadIdx.x] = 0.f;
   block_ltsum(lt, sh, dst + kRedLt, ln);
+  fold_reduce(part, (int)gridDim.x, red_out, fold_counter);
 }
 
 // ---- pass B -----------------------------------------------------------------------------------------------------------
@@ -350,7 +397,9 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
                                                 const double *__restrict__ redA, const double *__restrict__ redB,
                                                 float *__restrict__ part, const CgState *__restrict__ st,
                                                 float *__restrict__ alpha_out, long long N, int K, float sigma2,
-                                                float eps, float stop_after, int cur, int first) {
+                                                float eps, float stop_after, int cur, int first,
+                                                double *__restrict__ red_out = nullptr,
+                                                unsigned *__restrict__ fold_counter = nullptr) {
   __shared__ float sh[1024];
   __shared__ double sW[256];
   __shared__ double sTv[256];
@@ -482,6 +531,9 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
   block_colsum(acc_rr, sh, dst, ln);
   block_colsum(acc_rz, sh, dst + 16, ln);
   block_ltsum(lt2[0] + lt2[1], sh, dst + kRedLt, ln);
+  // (pass B reads `redB` in its prologue and the fold overwrites it: every workgroup has long consumed it by the time the
+  //  LAST one arrives — the arrive is behind each workgroup's own prologue loads)
+  fold_reduce(part, (int)gridDim.x, red_out, fold_counter);
 }
 
 // ---- pass C -----------------------------------------------------------------------------------------------------------
@@ -844,6 +896,7 @@ size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_ran
   total += align256(sizeof(CgState));
   total += align256((size_t)kMaxBlocks * kRedW * sizeof(float));               // per-workgroup partials
   total += 2 * align256((size_t)kRedW * sizeof(double));                       // reduced vectors A / B
+  total += 256;                                                                // arrival counter of the folded reductions
   total += 2 * align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));       // alpha / beta history
   total += ski_stage_bytes(op, T);
   total += align256(operator_workspace(op, T));
@@ -895,6 +948,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   float *part = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kRedW * sizeof(float));
   double *redA = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
   double *redB = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
+  unsigned *fold_cnt = reinterpret_cast<unsigned *>(w); w += 256;
   float *alpha_d = reinterpret_cast<float *>(w); w += align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));
   float *beta_d = reinterpret_cast<float *>(w); w += align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));
   if (op->kind == RPGP_OP_SKI) {
@@ -919,9 +973,16 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   // with the identity preconditioner z IS r: pass B skips the store and pass C reads r
   float *zsrc = K > 0 ? z : r;
 
+  // Few slabs (small N) and no all-reduce between the sums and their consumer: the producing pass's LAST workgroup does the
+  // reduction itself (fold_reduce) — 45 launches fewer per optimiser step at the C2 / C3 shapes; RPGP_CG_FOLD=0 disables.
+  const char *env_fold = getenv("RPGP_CG_FOLD");
+  const bool fold_ok = !rows && !(env_fold && env_fold[0] == '0');
+  auto fold_for = [&](int nparts) -> unsigned * { return (fold_ok && nparts <= kFoldMaxParts) ? fold_cnt : nullptr; };
+  if (fold_ok) CG_CHECK(hipMemsetAsync(fold_cnt, 0, sizeof(unsigned), st));
+
 #define CG_REDUCE(dst_, nparts_)                                                                     \
   do {                                                                                               \
-    hipLaunchKernelGGL(k_reduce, dim3(nred), dim3(256), 0, st, part, nparts_, dst_);                 \
+    if (!fold_for(nparts_)) hipLaunchKernelGGL(k_reduce, dim3(nred), dim3(256), 0, st, part, nparts_, dst_);   \
     if (rows) {                                                                                      \
       const int rrc_ = sh.reduce(dst_, kRedW, RPGP_F64, stream);                                     \
       if (rrc_) return rrc_;                                                                         \
@@ -929,12 +990,13 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   } while (0)
 
   // set-up: |rhs| per column; r = rhs / |rhs|, x = p = Ap = 0, w0 = L^T r0; z0 = M^-1 r0, rz0; p0 = z0
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, rhs, rhs, L, part, N, 0));
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, rhs, rhs, L, part, N, 0, redA, fold_for(nba)));
   CG_REDUCE(redA, nba);
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_init<TT>), dim3(nba), dim3(256), 0, st, rhs, redA, r, x, p, Ap, L, part, state, N, K));
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_init<TT>), dim3(nba), dim3(256), 0, st, rhs, redA, r, x, p, Ap, L, part, state, N, K,
+                                      redB, fold_for(nba)));
   CG_REDUCE(redB, nba);
   CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nbb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB, part,
-                                      state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1));
+                                      state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1, redB, fold_for(nbb)));
   CG_REDUCE(redB, nbb);
   CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nbc), dim3(256), 0, st, z, p, redB, state, beta_d, N, eps, 0, 1, 0,
                                       tolerance, 0, 0, x, x_best, (CgPoll *)nullptr));
@@ -953,12 +1015,12 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   for (it = 0; it < n_iter; ++it) {
     int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, part, N, K));
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, part, N, K, redA, fold_for(nba)));
     CG_REDUCE(redA, nba);
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
     CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nbb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB,
                                         part, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2, eps,
-                                        stop_after, it & 1, 0));
+                                        stop_after, it & 1, 0, redB, fold_for(nbb)));
     CG_REDUCE(redB, nbb);
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);

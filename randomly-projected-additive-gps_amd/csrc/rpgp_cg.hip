@@ -193,8 +193,9 @@ __device__ __forceinline__ void block_ltsum(const floatx4m &acc, float *__restri
 }
 
 // ---- the reduction folded into the producing pass ------------------------------------------------------------------------
-// With few partial slabs (small N: 29 at C2, 59 at C3) a k_reduce launch between two passes costs more than the sums
-// themselves (5 us kernel + a launch boundary, 45 times per optimiser step).  Instead the LAST workgroup of the pass to finish
+// (Opt-in experiment, RPGP_CG_FOLD=1 — measured slower than the separate launch, see rpgp_mbcg_solve.)  With few partial
+// slabs (small N: 29 at C2, 59 at C3) a k_reduce launch between two passes is 5 us of kernel + a launch boundary, 45 times
+// per optimiser step.  Here the LAST workgroup of the pass to finish
 // adds up all the slabs — per entry in slab order, float64: a fixed order whoever comes last, so the result stays bitwise
 // reproducible.  Hand-off per MI355X_MICROARCH.md (Valid forms): every storing wave drains its stores, workgroup barrier,
 // lane 0: agent-scope release, arrive on the counter; the last arriver: agent-scope acquire, drain, workgroup barrier, plain
@@ -973,10 +974,13 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   // with the identity preconditioner z IS r: pass B skips the store and pass C reads r
   float *zsrc = K > 0 ? z : r;
 
-  // Few slabs (small N) and no all-reduce between the sums and their consumer: the producing pass's LAST workgroup does the
-  // reduction itself (fold_reduce) — 45 launches fewer per optimiser step at the C2 / C3 shapes; RPGP_CG_FOLD=0 disables.
+  // Few slabs (small N) and no all-reduce between the sums and their consumer: the producing pass's LAST workgroup can do the
+  // reduction itself (fold_reduce) — 45 launches fewer per optimiser step at the C2 / C3 shapes.  MEASURED SLOWER (round 4,
+  // same box, tools/solve_bench.py): C2 3.64 -> 3.99 ms per step, C3 5.78 -> 6.13: the agent-scope release every workgroup
+  // pays before it arrives (an L2 write-back) costs more than the 5 us k_reduce launch it replaces — the guide's price list
+  // says as much (barrier-counter 7.4 us against a 1.5 us kernel boundary).  Kept as an opt-in experiment: RPGP_CG_FOLD=1.
   const char *env_fold = getenv("RPGP_CG_FOLD");
-  const bool fold_ok = !rows && !(env_fold && env_fold[0] == '0');
+  const bool fold_ok = !rows && env_fold && env_fold[0] == '1';
   auto fold_for = [&](int nparts) -> unsigned * { return (fold_ok && nparts <= kFoldMaxParts) ? fold_cnt : nullptr; };
   if (fold_ok) CG_CHECK(hipMemsetAsync(fold_cnt, 0, sizeof(unsigned), st));
 

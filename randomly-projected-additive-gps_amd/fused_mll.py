@@ -1,0 +1,143 @@
+"""One autograd node for the training objective of the flagship model.
+
+`-mll(model(X), y)` of fitting/optimizing.py:67-72 walks, in the generic stack, ~20 autograd nodes (softplus x3, the
+lengthscale division, the projection, the operator's inv_quad / log-det function, the prior, the arithmetic of the
+marginal log-likelihood) with one to three tiny launches each way: outside the solve the optimiser step is bound by the
+HOST time of ~130 such launches (profiles/r4_step_C2_step_gaps.txt), not by the device.  For the model every served
+`additive_rp` specification builds —
+
+    ExactGPModel( ConstantMean,  ScaleKernel( ScaledProjectionKernel( frozen Linear, AdditiveStructureRBFKernel ) ) ),
+    GaussianLikelihood with (or without) the SmoothedBoxPrior on the noise                  (training_routines.py:131-189,
+                                                                                              325-410; models.py:10-20)
+
+— the objective has FOUR trainable tensors (raw lengthscale, raw outputscale, raw noise, the constant mean) and its
+gradient is a handful of closed-form chain-rule lines around the same native calls.  `evaluate`
+runs it as ONE `torch.autograd.Function`: forward and backward call `InvQuadLogDet`'s own forward / backward (same
+preconditioner, probes, solve, SLQ, bilinear derivative — same numbers) without the autograd bookkeeping around them, the
+prior and the constants are host arithmetic, and the hyper-parameter scalars reach the host in one copy.
+Anything outside that shape (learned projections, component weights, sharded kernels, dense `full` kernels, the older
+family) takes the generic path unchanged; `settings.fused_training(False)` forces it."""
+import math
+
+import torch
+from torch.nn import functional as F
+
+from . import backend as _backend
+from . import settings
+from .hostvals import host_float, prefetch
+
+LOG2PI = math.log(2.0 * math.pi)
+
+
+class _Ctx:
+    """What `InvQuadLogDet.forward / backward` need from an autograd context."""
+
+    needs_input_grad = (True, True, True, True, False, False)
+    saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def applicable(model, likelihood=None):
+    """Is `model` the flagship structure on one device?"""
+    if not settings.fused_training.on():
+        return False
+    from .kernels import AdditiveStructureRBFKernel, ScaledProjectionKernel, ScaleKernel
+    from .likelihoods import ConstantMean, GaussianLikelihood, SmoothedBoxPrior
+    from .models import ExactGPModel
+    if type(model) is not ExactGPModel or not isinstance(getattr(model, "mean_module", None), ConstantMean):
+        return False
+    lik = model.likelihood if likelihood is None else likelihood
+    if lik is not model.likelihood or type(lik) is not GaussianLikelihood:
+        return False
+    if lik.noise_prior is not None and type(lik.noise_prior) is not SmoothedBoxPrior:
+        return False
+    sk = model.covar_module
+    if type(sk) is not ScaleKernel or (sk.shard is not None and getattr(sk.shard, "world_size", 1) > 1):
+        return False
+    pk = sk.base_kernel
+    if type(pk) is not ScaledProjectionKernel or pk.learn_proj:
+        return False
+    bk = pk.base_kernel
+    if type(bk) is not AdditiveStructureRBFKernel or bk.kernel_type != "RBF" or bk.group != 1:
+        return False
+    if not isinstance(pk.projection_module, torch.nn.Linear) or pk.projection_module.bias is not None:
+        return False
+    x = model.train_inputs
+    return torch.is_tensor(x) and x.dim() == 2 and x.dtype in (torch.float32, torch.float64)
+
+
+def _prior(likelihood, noise_f):
+    """(log p(sigma^2), d log p / d sigma^2) of the SmoothedBoxPrior in host arithmetic (likelihoods.SmoothedBoxPrior)."""
+    pr = likelihood.noise_prior
+    if pr is None:
+        return 0.0, 0.0
+    center, radius = 0.5 * (pr.a + pr.b), 0.5 * (pr.b - pr.a)
+    dist = max(abs(noise_f - center) - radius, 0.0)
+    m = 1.0 + (pr.b - pr.a) / (math.sqrt(2.0 * math.pi) * pr.sigma)
+    lp = -0.5 * (dist / pr.sigma) ** 2 - math.log(pr.sigma) - 0.5 * LOG2PI - math.log(m)
+    dlp = 0.0 if dist == 0.0 else -(dist / pr.sigma ** 2) * (1.0 if noise_f > center else -1.0)
+    return lp, dlp
+
+
+class _FusedMLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target):
+        from .inv_quad_logdet import InvQuadLogDet
+        pk = model.covar_module.base_kernel
+        bk = pk.base_kernel
+        X = model.train_inputs
+        n = X.shape[0]
+        with torch.no_grad():
+            ls = F.softplus(raw_ls).reshape(-1)
+            os_ = F.softplus(raw_os).reshape(())
+            noise = (F.softplus(raw_noise) + likelihood.MIN_NOISE).reshape(())
+            prefetch(os_, noise)                                   # the two scalars the kernels take by value: ONE copy
+            noise_f = host_float(noise)
+            P = pk.projection_module.weight.t()                    # d x J  (Linear.weight is J x d)
+            col = ls.reshape(-1, 1) if (pk.prescale and ls.numel() > 1) else (ls.reshape(1, -1) if ls.numel() > 1 else ls)
+            Peff = (P / col).contiguous()
+            Z = _backend.get_backend().project(X.contiguous(), Peff)
+            op = bk.operator(Z, None, outputscale=os_, shard=None)
+            op._noise_host = noise_f
+            r = target - mean_c
+            st = _Ctx()
+            inv_quad, logdet = InvQuadLogDet.forward(st, Z, os_, noise, r, op, None)
+            lp, dlp = _prior(likelihood, noise_f)
+            # mll = (-0.5 (inv_quad + logdet + n log 2 pi) + log p(sigma^2)) / n      (models.ExactMarginalLogLikelihood)
+            value = (inv_quad + logdet) * (-0.5 / n) + ((-0.5 * n * LOG2PI + lp) / n)
+        ctx.st, ctx.n, ctx.dlp, ctx.prescale = st, n, dlp, pk.prescale
+        ctx.X, ctx.P, ctx.ls, ctx.col = X, P, ls, col
+        ctx.save_for_backward(raw_ls, raw_os, raw_noise)
+        return value.to(raw_ls.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .inv_quad_logdet import InvQuadLogDet
+        raw_ls, raw_os, raw_noise = ctx.saved_tensors
+        n = ctx.n
+        with torch.no_grad():
+            gq = g.reshape(()) * (-0.5 / n)                        # d mll / d inv_quad = d mll / d logdet
+            gZ, gs, gn, gr, _, _ = InvQuadLogDet.backward(ctx.st, gq, gq)
+            be = _backend.get_backend()
+            dPeff = be.project_grad(ctx.X.contiguous(), gZ.contiguous())             # d x J:  Z = X Peff
+            # Peff = P / l (rows for the prescale form, columns for the postscale form):  dl = -sum(dPeff * P) / l^2
+            t = dPeff * ctx.P
+            if ctx.ls.numel() > 1:
+                g_ls = -(t.sum(dim=1) if ctx.prescale else t.sum(dim=0)) / (ctx.ls * ctx.ls)
+            else:
+                g_ls = -t.sum().reshape(1) / (ctx.ls * ctx.ls)
+            g_raw_ls = (g_ls * torch.sigmoid(raw_ls.reshape(-1))).reshape(raw_ls.shape)
+            g_raw_os = (gs.reshape(()) * torch.sigmoid(raw_os.reshape(()))).reshape(raw_os.shape)
+            g_noise = gn.reshape(()) + g.reshape(()) * (ctx.dlp / n) if ctx.dlp != 0.0 else gn.reshape(())
+            g_raw_noise = (g_noise * torch.sigmoid(raw_noise.reshape(()))).reshape(raw_noise.shape)
+            g_mean = (-gr.sum()).reshape(1)                         # r = y - c
+        return g_raw_ls, g_raw_os, g_raw_noise, g_mean, None, None, None
+
+
+def evaluate(model, likelihood, target):
+    """mll(model(X), y) per datum (ExactMarginalLogLikelihood's value) as one autograd node."""
+    pk = model.covar_module.base_kernel
+    return _FusedMLL.apply(pk.raw_lengthscale, model.covar_module.raw_outputscale, likelihood.raw_noise,
+                           model.mean_module.constant, model, likelihood, target)

@@ -478,6 +478,32 @@ class TrainPosterior(MultivariateNormal):
         return torch.as_tensor(strategy.train_log_prob(value), dtype=value.dtype, device=value.device)
 
 
+class LazyPrior(MultivariateNormal):
+    """Train-mode output of a model whose objective has a fused form (fused_mll): nothing is evaluated until somebody reads
+    `mean` / `covariance` — the marginal log-likelihood recognises the object and runs the fused node instead."""
+
+    def __init__(self, model):
+        self.diagonal_only = False
+        self._model, self._mvn = model, None
+
+    def _materialize(self):
+        if self._mvn is None:
+            self._mvn = self._model.forward(self._model.train_inputs)
+        return self._mvn
+
+    @property
+    def materialized(self):
+        return self._mvn is not None
+
+    @property
+    def mean(self):
+        return self._materialize().mean
+
+    @property
+    def covariance(self):
+        return self._materialize().covariance
+
+
 class ExactGP(nn.Module):
     """Train mode: `model(train_x)` returns the prior MultivariateNormal(mean, K operator).
     Eval mode: `model(x)` returns the posterior at x (prediction strategy cached across calls, B.7)."""
@@ -501,6 +527,9 @@ class ExactGP(nn.Module):
         if self.training:
             if not (x is self.train_inputs or (x.shape == self.train_inputs.shape and torch.equal(x, self.train_inputs))):
                 raise RuntimeError("You must train on the training inputs!")
+            from . import fused_mll
+            if fused_mll.applicable(self):
+                return LazyPrior(self)
             return self.forward(self.train_inputs)
         if self.prediction_strategy is None:
             self.prediction_strategy = PredictionStrategy(self)
@@ -557,6 +586,10 @@ class ExactMarginalLogLikelihood(nn.Module):
 
     def forward(self, output, target):
         n = target.shape[0]
+        if isinstance(output, LazyPrior) and not output.materialized:
+            from . import fused_mll
+            if fused_mll.applicable(self.model, self.likelihood) and output._model is self.model:
+                return fused_mll.evaluate(self.model, self.likelihood, target)
         noise = self.likelihood.noise.reshape(())
         if isinstance(output, TrainPosterior):
             res = self.likelihood(output).log_prob(target) + self.likelihood.log_prior().to(target.dtype)

@@ -112,6 +112,10 @@ solve_refinement = _setting("solve_refinement", 1)
 # ... the mean cache from this size up (every CG-regime model; the float64 twin product costs 4 ms at N = 15 000, 41 ms at
 # 50 000); the wide block additionally only above `dense_solve_size`, where the float64 direct solve stops
 solve_refinement_min_size = _setting("solve_refinement_min_size", 0)
+# The training objective of the flagship model (ExactGPModel + ScaleKernel(ScaledProjectionKernel(additive RBF)) + Gaussian
+# likelihood) as ONE autograd node (fused_mll.py): same native calls, ~60 fewer small launches per optimiser step.  False =
+# the generic operator-by-operator autograd path for every model.
+fused_training = _setting("fused_training", True, flag=True)
 # the all-reduce of the sharded multi-GPU solve: "rccl" (torch.distributed, backend nccl = RCCL over xGMI) or "ipc" (one-shot
 # kernel over IPC-mapped peer buffers, csrc/rpgp_comm.hip); the environment variable RPGP_COMM overrides it
 comm_backend = _setting("comm_backend", "rccl")

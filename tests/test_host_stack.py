@@ -541,3 +541,42 @@ def test_train_posterior_closed_form_matches_explicit_covariance(oracle_backend)
         out2 = model(X.clone())
         assert not isinstance(out2, TrainPosterior)
         assert abs(-mll(out2, y).item() - nll) < 1e-4 * abs(nll) + 1e-5
+
+
+@pytest.mark.parametrize("prescale,regime", [(True, "chol"), (False, "chol"), (True, "cg")])
+def test_fused_objective_equals_generic_path(oracle_backend, prescale, regime):
+    """fused_mll (one autograd node for -mll of the flagship model, fitting/optimizing.py:67-72) against the generic
+    operator-by-operator autograd path: same value, same four gradients (same probes in the CG regime)."""
+    from rpgp_amd import settings, fused_mll
+    from rpgp_amd.models import LazyPrior
+    X, y, P, ls, noise, s = _problem(N=140, d=5, J=7, seed=11, noise=0.25)
+    if not prescale:
+        ls = torch.rand(P.shape[1], generator=torch.Generator().manual_seed(5)) + 1.0
+    res = {}
+    for fused in (True, False):
+        model, lik, mll = _build_model(X, y, P, ls, noise, s, prescale)
+        model.train()
+        ctxs = [settings.fused_training(fused), settings.deterministic_probes(True)]
+        if regime == "cg":
+            ctxs += [settings.max_cholesky_size(10), settings.min_preconditioning_size(50), settings.cg_tolerance(1e-8),
+                     settings.max_cg_iterations(500)]
+        import contextlib
+        with contextlib.ExitStack() as es:
+            for c in ctxs:
+                es.enter_context(c)
+            out = model(X)
+            assert isinstance(out, LazyPrior) == fused and fused_mll.applicable(model) == fused
+            loss = -mll(out, y)
+            loss.backward()
+        res[fused] = (loss.item(), [p.grad.clone() for p in (model.covar_module.base_kernel.raw_lengthscale,
+                                                              model.covar_module.raw_outputscale, lik.raw_noise,
+                                                              model.mean_module.constant)])
+    assert abs(res[True][0] - res[False][0]) < 1e-6 * abs(res[False][0]) + 1e-7
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.allclose(a.reshape(-1), b.reshape(-1), rtol=2e-5, atol=1e-7), (a, b)
+    # a lazily returned prior still answers like the generic one when somebody reads it
+    model, lik, mll = _build_model(X, y, P, ls, noise, s, prescale)
+    model.train()
+    out = model(X)
+    assert out.mean.shape == (X.shape[0],) and out.covariance.shape[0] == X.shape[0] and out.materialized
+    assert abs(-mll(out, y).item() - res[False][0]) < (5e-2 if regime == "cg" else 1e-6) * abs(res[False][0]) + 1e-7

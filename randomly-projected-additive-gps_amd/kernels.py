@@ -124,8 +124,21 @@ class AdditiveStructureRBFKernel(Kernel):
                 raise NotImplementedError("grid interpolation is built for the 1-D RBF sub-kernels only")
             ncomp = Z1.shape[1] // self.group
             w = torch.full((ncomp,), weight_f, dtype=Z1.dtype, device=Z1.device)
+            group = self.group
+            if self.kernel_type == "RBF" and group > 1 and padded_group_size(group) != group:
+                # ANY k (training_routines.py:172-174; the runner's `--k` ablation, gp_experiment_runner.py:343-354): a
+                # k-dimensional RBF is the g-dimensional RBF of the same coordinates padded with g - k zero columns
+                # (zero differences contribute exp(0)); g = the next instantiated group size.  The padding is a
+                # differentiable torch op, so the derivative w.r.t. the real columns comes back through autograd.
+                g = padded_group_size(group)
+
+                def pad(Z):
+                    if Z is None:
+                        return None
+                    return F.pad(Z.reshape(Z.shape[0], ncomp, group), (0, g - group)).reshape(Z.shape[0], ncomp * g)
+                Z1, Z2, group = pad(Z1), pad(Z2), g
             return FamilyAdditiveOperator(Z1, Z2, outputscale=outputscale, comp_weights=w, kind=self.kernel_type,
-                                          group=self.group)
+                                          group=group)
         if self.ski:
             return SKIAdditiveOperator(Z1, Z2, outputscale=outputscale, weight=weight_f,
                                        grid_size=self.grid_size, row_shard=shard if isinstance(shard, RowShard) else None)

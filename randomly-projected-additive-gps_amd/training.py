@@ -43,8 +43,9 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
                               batch_kernel=True, mem_efficient=False, k=1, keops=False):
     """Additive randomly-projected kernel (RPA-GP; DPA-GP when `space_proj`).  Same options and validation errors as
     training_routines.py:131-189.  `ski=True` selects the 1-D grid-interpolation operator.
-    Sub-kernels other than 1-D RBF and k > 1 are outside the MI355X hot path and raise
-    NotImplementedError."""
+    k > 1 RBF sub-kernels of ANY k <= 20 run on the family kernels (k outside (2, 3, 4, 5, 8, 10, 20) zero-padded to the next
+    instantiated group size: the same function); k > 1 with Matern / InverseMQ / Cosine sub-kernels raises
+    NotImplementedError (no reference specification uses it)."""
     if k > 1 and (mem_efficient or batch_kernel or space_proj):
         raise ValueError("Can't have k > 1 with memory efficient GAM kernel or a batch kernel or spaced projections.")
     if mem_efficient:
@@ -58,8 +59,9 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
         raise ValueError("Unknown kernel type")
     if k > 1 and kernel_type != "RBF":
         raise NotImplementedError("k > 1 sub-kernels are built for the RBF only")
-    if k > 1 and k not in (2, 3, 4, 5, 8, 10, 20):
-        raise NotImplementedError("k-dimensional sub-kernels are instantiated for k in (2, 3, 4, 5, 8, 10, 20)")
+    if k > 20:
+        raise NotImplementedError("k-dimensional RBF sub-kernels are built up to k = 20 (the reference's largest: "
+                                  "additive_rp_prescale_J1_K20.json); other k are padded to the next instantiated size")
     if ski and (k > 1 or kernel_type != "RBF"):
         raise NotImplementedError("grid interpolation is built for the 1-D RBF sub-kernels only")
     if keops:

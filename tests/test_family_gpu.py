@@ -114,6 +114,8 @@ def test_family_errors(gpu_device):
 @pytest.mark.parametrize("kind,model_kwargs", [
     ("additive_rp", dict(J=20, kernel_type="Matern", prescale=True)),
     ("additive_rp", dict(J=4, k=5, batch_kernel=False, prescale=True)),
+    ("additive_rp", dict(J=3, k=6, batch_kernel=False, prescale=True)),          # any k: zero-padded to the 8-wide kernel
+    ("additive_rp", dict(J=2, k=7, batch_kernel=False, prescale=False)),
     ("rp_poly", dict(J=8, k=1, weighted=True, kernel_type="RBF")),
     ("strictly_additive", dict(weighted=True, kernel_type="InverseMQ")),
 ])

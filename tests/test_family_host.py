@@ -64,6 +64,9 @@ def _problem(n=60, d=5, seed=0):
     ("additive_rp", dict(J=4, kernel_type="InverseMQ", prescale=False)),
     ("additive_rp", dict(J=4, kernel_type="Cosine", prescale=True, init_lengthscale_range=(3.0, 3.0))),
     ("additive_rp", dict(J=3, k=2, batch_kernel=False, prescale=True)),
+    ("additive_rp", dict(J=2, k=6, batch_kernel=False, prescale=True)),                      # any k: 6 -> the 8-wide kernel
+    ("additive_rp", dict(J=1, k=7, batch_kernel=False, prescale=False)),                     # ... 7 -> 8, postscale
+    ("additive_rp", dict(J=1, k=13, batch_kernel=False, prescale=True)),                     # ... 13 -> 20
     ("rp_poly", dict(J=5, k=1, weighted=True, kernel_type="RBF")),
     ("rp_poly", dict(J=3, k=2, weighted=True, kernel_type="RBF")),
     ("rp_poly", dict(J=4, k=1, weighted=False, kernel_type="Matern")),
@@ -173,8 +176,9 @@ def test_family_validation_errors():
     from rpgp_amd.training import create_additive_rp_kernel, create_rp_poly_kernel, create_exact_gp
     with pytest.raises(NotImplementedError):
         create_additive_rp_kernel(6, 3, k=2, batch_kernel=False, kernel_type="Matern")
+    create_additive_rp_kernel(6, 3, k=7, batch_kernel=False)            # any k <= 20 is served (padded group)
     with pytest.raises(NotImplementedError):
-        create_additive_rp_kernel(6, 3, k=7, batch_kernel=False)
+        create_additive_rp_kernel(6, 1, k=21, batch_kernel=False)
     with pytest.raises(NotImplementedError):
         create_additive_rp_kernel(6, 3, kernel_type="Matern", ski=True, ski_options={"grid_size": 64})
     with pytest.raises(ValueError):

@@ -6,7 +6,8 @@ marginal log-likelihood) with one to three tiny launches each way: outside the s
 HOST time of ~130 such launches (profiles/r4_step_C2_step_gaps.txt), not by the device.  For the model every served
 `additive_rp` specification builds —
 
-    ExactGPModel( ConstantMean,  ScaleKernel( ScaledProjectionKernel( frozen Linear, AdditiveStructureRBFKernel ) ) ),
+    ExactGPModel( ConstantMean,  ScaleKernel( ScaledProjectionKernel( frozen Linear, AdditiveStructureRBFKernel or the
+                                                                      frozen MemoryEfficientGamKernel ) ) ),
     GaussianLikelihood with (or without) the SmoothedBoxPrior on the noise                  (training_routines.py:131-189,
                                                                                               325-410; models.py:10-20)
 
@@ -60,7 +61,10 @@ def applicable(model, likelihood=None):
     if type(pk) is not ScaledProjectionKernel or pk.learn_proj:
         return False
     bk = pk.base_kernel
-    if type(bk) is not AdditiveStructureRBFKernel or bk.kernel_type != "RBF" or bk.group != 1:
+    from .kernels import MemoryEfficientGamKernel
+    if type(bk) not in (AdditiveStructureRBFKernel, MemoryEfficientGamKernel) or bk.kernel_type != "RBF" or bk.group != 1:
+        return False
+    if bk.input_scale_factor() is None or any(p.requires_grad for p in bk.parameters()):
         return False
     if not isinstance(pk.projection_module, torch.nn.Linear) or pk.projection_module.bias is not None:
         return False
@@ -108,6 +112,7 @@ class _FusedMLL(torch.autograd.Function):
             # mll = (-0.5 (inv_quad + logdet + n log 2 pi) + log p(sigma^2)) / n      (models.ExactMarginalLogLikelihood)
             value = (inv_quad + logdet) * (-0.5 / n) + ((-0.5 * n * LOG2PI + lp) / n)
         ctx.st, ctx.n, ctx.dlp, ctx.prescale = st, n, dlp, pk.prescale
+        ctx.zfac = bk.input_scale_factor()            # the operator acts on zfac * Z (inner lengthscale of the base kernel)
         ctx.X, ctx.P, ctx.ls, ctx.col = X, P, ls, col
         ctx.save_for_backward(raw_ls, raw_os, raw_noise)
         return value.to(raw_ls.dtype)
@@ -121,6 +126,8 @@ class _FusedMLL(torch.autograd.Function):
             gq = g.reshape(()) * (-0.5 / n)                        # d mll / d inv_quad = d mll / d logdet
             gZ, gs, gn, gr, _, _ = InvQuadLogDet.backward(ctx.st, gq, gq)
             be = _backend.get_backend()
+            if ctx.zfac != 1.0:
+                gZ = gZ * ctx.zfac
             dPeff = be.project_grad(ctx.X.contiguous(), gZ.contiguous())             # d x J:  Z = X Peff
             # Peff = P / l (rows for the prescale form, columns for the postscale form):  dl = -sum(dPeff * P) / l^2
             t = dPeff * ctx.P

@@ -114,6 +114,11 @@ class AdditiveStructureRBFKernel(Kernel):
             self._const_cache = c
         return c[1], c[2]
 
+    def input_scale_factor(self):
+        """The constant c with operator(Z) acting on c Z (fused_mll's chain rule: dZ = c d(cZ)); None when it is not one
+        frozen scalar."""
+        return 1.0 / self._constants()[1]
+
     def operator(self, Z1, Z2, outputscale=None, shard=None):
         weight_f, il = self._constants()
         if il != 1.0:
@@ -162,6 +167,16 @@ class MemoryEfficientGamKernel(AdditiveStructureRBFKernel):
         super().__init__(n, weight=1.0, inner_lengthscale=1.0)
         self.ard_num_dims = ard_num_dims
         self.raw_lengthscale = nn.Parameter(torch.zeros(1, ard_num_dims if ard_num_dims else 1))
+
+    def input_scale_factor(self):
+        if self.raw_lengthscale.requires_grad or self.raw_lengthscale.numel() != 1:
+            return None
+        c = getattr(self, "_ls_cache", None)
+        key = (self.raw_lengthscale.data_ptr(), self.raw_lengthscale._version)
+        if c is None or c[0] != key:
+            c = (key, float(self.lengthscale.detach().reshape(-1)[0]))
+            self._ls_cache = c
+        return 1.0 / c[1]
 
     def operator(self, Z1, Z2, outputscale=None, shard=None):
         ls = self.lengthscale

@@ -543,6 +543,32 @@ def test_train_posterior_closed_form_matches_explicit_covariance(oracle_backend)
         assert abs(-mll(out2, y).item() - nll) < 1e-4 * abs(nll) + 1e-5
 
 
+def test_fused_objective_mem_efficient_gam(oracle_backend):
+    """The frozen MemoryEfficientGamKernel base (additive_spread_prescale_Jd.json: inner lengthscale ln 2, no 1/J): fused
+    node against the generic path."""
+    from rpgp_amd import settings, fused_mll
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    X, y, P, ls, noise, s = _problem(N=130, d=6, J=6, seed=21, noise=0.25)
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(4)
+        np.random.seed(4)
+        model, lik = create_exact_gp(X, y, "additive_rp", J=6, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                     prescale=True, space_proj=True, mem_efficient=True, batch_kernel=False)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        model.train()
+        with settings.fused_training(fused):
+            assert fused_mll.applicable(model) == fused
+            loss = -mll(model(X), y)
+            loss.backward()
+        res[fused] = (loss.item(), [p.grad.clone() for p in model.parameters() if p.requires_grad])
+    assert abs(res[True][0] - res[False][0]) < 1e-6 * abs(res[False][0]) + 1e-7
+    assert len(res[True][1]) == len(res[False][1]) == 4
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.allclose(a.reshape(-1), b.reshape(-1), rtol=2e-5, atol=1e-7), (a, b)
+
+
 @pytest.mark.parametrize("prescale,regime", [(True, "chol"), (False, "chol"), (True, "cg")])
 def test_fused_objective_equals_generic_path(oracle_backend, prescale, regime):
     """fused_mll (one autograd node for -mll of the flagship model, fitting/optimizing.py:67-72) against the generic

@@ -296,11 +296,70 @@ def _save_state_dict(model):
     base = os.environ.get("RPGP_MODEL_BASE_PATH")
     if not base:
         return ""
-    d = model.state_dict()
+    # RPGP_STATE_DICT_LAYOUT=gpytorch writes the reference's key layout (gpytorch_state_dict above, [GPT-mem])
+    d = gpytorch_state_dict(model) if os.environ.get("RPGP_STATE_DICT_LAYOUT", "") == "gpytorch" else model.state_dict()
     fname = "model_state_dict_{}.pkl".format(hash(str(d)))
     os.makedirs(os.path.join(base, "models"), exist_ok=True)
     torch.save(d, os.path.join(base, "models", fname))
     return fname
+
+
+# ---- GPyTorch-layout checkpoints -------------------------------------------------------------------------------------
+# [GPT-mem] (GPyTorch 1.0 - 1.2, from memory; unverifiable in this image): the reference's checkpoints
+# (training_routines.py:37-44) are `model.state_dict()` of a GPyTorch ExactGP, whose keys for the `additive_rp` model are
+#     likelihood.noise_covar.raw_noise                                   (1,)      <->  likelihood.raw_noise
+#     mean_module.constant                                               (1,)      <->  mean_module.constant
+#     covar_module.raw_outputscale                                       ()        <->  covar_module.raw_outputscale
+#     covar_module.base_kernel.raw_lengthscale                           (1, ard)  <->  covar_module.base_kernel.raw_lengthscale
+#     covar_module.base_kernel.projection_module.weight                  (J k, d)  <->  ...projection_module.weight
+#     covar_module.base_kernel.base_kernel.base_kernel.raw_outputscale   ()        frozen inner ScaleKernel: softplus^-1(weight)
+#     covar_module.base_kernel.base_kernel.base_kernel.base_kernel.raw_lengthscale (1, 1)   frozen inner RBF: softplus^-1(l_b)
+# (batch `AdditiveStructureKernel(ScaleKernel(RBFKernel))`, training_routines.py:148-159; the memory-efficient GAM kernel has
+# `covar_module.base_kernel.base_kernel.raw_lengthscale` on both sides).  The two functions translate between that layout and
+# this package's own for the flagship structure; prior buffers are not translated.
+_GPY_INNER_OS = "covar_module.base_kernel.base_kernel.base_kernel.raw_outputscale"
+_GPY_INNER_LS = "covar_module.base_kernel.base_kernel.base_kernel.base_kernel.raw_lengthscale"
+
+
+def gpytorch_state_dict(model):
+    """`model.state_dict()` re-keyed to the GPyTorch layout above (flagship `additive_rp` structure)."""
+    from .kernels import inv_softplus
+    out = {}
+    for k, v in model.state_dict().items():
+        if k == "likelihood.raw_noise":
+            out["likelihood.noise_covar.raw_noise"] = v
+        elif k == "covar_module.base_kernel.base_kernel.weight":
+            out[_GPY_INNER_OS] = inv_softplus(v.double()).to(torch.float32).reshape(())
+        elif k == "covar_module.base_kernel.base_kernel.inner_lengthscale":
+            out[_GPY_INNER_LS] = inv_softplus(v.double()).to(torch.float32).reshape(1, 1)
+        else:
+            out[k] = v
+    return out
+
+
+def load_gpytorch_state_dict(model, state):
+    """Load a GPyTorch-layout state dict (see above) into an rpgp_amd model of the same structure; prior / unknown keys are
+    ignored, the frozen inner-kernel entries are checked against the model's constants."""
+    own = model.state_dict()
+    mapped = {}
+    for k, v in state.items():
+        if k == "likelihood.noise_covar.raw_noise":
+            mapped["likelihood.raw_noise"] = v.reshape(own["likelihood.raw_noise"].shape)
+        elif k == _GPY_INNER_OS:
+            w = torch.nn.functional.softplus(v.double()).reshape(())
+            if "covar_module.base_kernel.base_kernel.weight" in own and \
+                    abs(float(w) - float(own["covar_module.base_kernel.base_kernel.weight"])) > 1e-5:
+                raise ValueError("inner outputscale %g differs from the model's 1/J weight" % float(w))
+        elif k == _GPY_INNER_LS:
+            continue
+        elif k in own:
+            mapped[k] = v.reshape(own[k].shape)
+    missing = [k for k in own if k not in mapped and not k.endswith((".weight", ".inner_lengthscale")) or
+               (k.endswith("projection_module.weight") and k not in mapped)]
+    if missing:
+        raise KeyError("state dict lacks %s" % missing)
+    model.load_state_dict({**own, **mapped})
+    return model
 
 
 def locality_order(X, bits=10):

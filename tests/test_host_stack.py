@@ -606,3 +606,23 @@ def test_fused_objective_equals_generic_path(oracle_backend, prescale, regime):
     out = model(X)
     assert out.mean.shape == (X.shape[0],) and out.covariance.shape[0] == X.shape[0] and out.materialized
     assert abs(-mll(out, y).item() - res[False][0]) < (5e-2 if regime == "cg" else 1e-6) * abs(res[False][0]) + 1e-7
+
+
+def test_gpytorch_layout_state_dict_round_trip():
+    """training.gpytorch_state_dict / load_gpytorch_state_dict: the reference's checkpoint key layout
+    (training_routines.py:37-44; keys from memory of GPyTorch, see the table in training.py) round-trips."""
+    from rpgp_amd.training import create_exact_gp, gpytorch_state_dict, load_gpytorch_state_dict
+    X, y = torch.randn(40, 5), torch.randn(40)
+    torch.manual_seed(0)
+    a, _ = create_exact_gp(X, y, "additive_rp", J=4, noise_prior=True, kernel_type="RBF", learn_proj=False, prescale=True)
+    with torch.no_grad():
+        for p in a.parameters():
+            p.add_(torch.randn_like(p) * 0.1)
+    sd = gpytorch_state_dict(a)
+    assert "likelihood.noise_covar.raw_noise" in sd and "likelihood.raw_noise" not in sd
+    assert abs(float(torch.nn.functional.softplus(sd["covar_module.base_kernel.base_kernel.base_kernel.raw_outputscale"])) - 0.25) < 1e-6
+    torch.manual_seed(1)
+    b, _ = create_exact_gp(X, y, "additive_rp", J=4, noise_prior=True, kernel_type="RBF", learn_proj=False, prescale=True)
+    load_gpytorch_state_dict(b, sd)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.allclose(va.double(), vb.double()), ka

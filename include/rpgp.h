@@ -320,7 +320,7 @@ int rpgp_ski_bilinear_finish(const float *Z, const float *grid_params, const dou
  * `weights` (DEVICE, ncomp floats, required) are the per-component output scales (the `weighted` ScaleKernels of
  * polynomial_projection_kernels.py:88-98; all 1/J for additive_rp).  Z holds ncomp*group columns, already divided by
  * the lengthscales.  Same tile / dense kernels as the hot path with a different kernel-function policy; no factorised
- * fast path, no float64 variant.
+ * fast path; float64 and the combinations not instantiated here: rpgp_family_generic_* below.
  * rpgp_family_bilinear_grad*: gZ as rpgp_bilinear_grad; gcomp[c] (DEVICE, ncomp) = 0.5 sum_ii' S_ii' phi_c(i,i'), the
  * unweighted per-component sums (d/d weights[c] = scale * gcomp[c]; d/d scale = sum_c weights[c] gcomp[c]).
  */
@@ -349,6 +349,27 @@ int rpgp_family_bilinear_grad_dense(const rpgp_family *fam, const float *Z, cons
                                     size_t workspace_bytes, void *stream);
 int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *L, float *diag_work, int64_t N,
                                  int ldz, int rank, float scale, float weight_sum, void *stream);
+
+/* The same family with RUNTIME (kind, group) in float32 or float64 (csrc/rpgp_family_generic.hip) — what the templated
+ * kernels above do not instantiate: `--double` (training_routines.py:481) for every member, k > 1 sub-kernels of the
+ * non-RBF types in the RADIAL form `additive_rp` builds (training_routines.py:172-174: kernel(active_dims = a group of k
+ * columns); imq_kernel.py:8-9), any group size <= 32 (ncomp * group <= 64).  `dtype`: RPGP_F32 / RPGP_F64 selects the element
+ * type of EVERY pointer argument (weights, Z, V, L, R, S, outputs).  Parity path: lane-owns-row, library transcendental
+ * functions, one writer per output (bitwise reproducible).
+ *   mvm:      out (M x T) = scale * K(Z1, Z2) V (+ noise V when Z2 == NULL: the symmetric operator on Z1, M == N); T <= 16
+ *   dense:    out (M x N, leading dimension ldo) = scale * K(Z1, Z2)
+ *   bilinear: gZ / gcomp exactly as rpgp_family_bilinear_grad (S == NULL: weights S = L R^T + R L^T from the N x T factors)
+ *             or rpgp_family_bilinear_grad_dense (S: explicit symmetric N x N matrix, leading dimension lds).
+ */
+int rpgp_family_generic_mvm(int dtype, int kind, int group, int ncomp, const void *weights, const void *Z1, const void *Z2,
+                            const void *V, void *out, int64_t M, int64_t N, int ldz1, int ldz2, int T, double scale,
+                            double noise, void *stream);
+int rpgp_family_generic_dense(int dtype, int kind, int group, int ncomp, const void *weights, const void *Z1, const void *Z2,
+                              void *out, int64_t M, int64_t N, int ldz1, int ldz2, int64_t ldo, double scale, void *stream);
+size_t rpgp_family_generic_bilinear_workspace_bytes(int dtype, int64_t N, int ncomp);
+int rpgp_family_generic_bilinear(int dtype, int kind, int group, int ncomp, const void *weights, const void *Z, const void *L,
+                                 const void *R, const void *S, void *gZ, void *gcomp, int64_t N, int ldz, int ldg, int T,
+                                 int64_t lds, double scale, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Native mBCG executor (replaces gpytorch.utils.linear_cg as configured at gp_experiment_runner.py:324-329; algorithm in

@@ -20,7 +20,7 @@ KINDS = ("RBF", "Matern", "InverseMQ", "Cosine")
 
 
 def _phi(kind, d2):
-    """1-D (or radial, RBF only) stationary function of the squared distance d2."""
+    """Stationary function of the squared distance d2 over the group's columns (1-D, or radial for a group of k columns)."""
     if kind == "RBF":
         return np.exp(-0.5 * d2)
     r = np.sqrt(d2)
@@ -37,8 +37,8 @@ def component_matrices(Z1, Z2, kind, group):
     """[ncomp] list of M x N float64 matrices phi_c(Z1, Z2)."""
     Z1 = np.asarray(Z1, dtype=np.float64)
     Z2 = np.asarray(Z2, dtype=np.float64)
-    if group > 1 and kind != "RBF":
-        raise ValueError("multi-dimensional sub-kernels are restated for the RBF only")
+    # group > 1 with a non-RBF kind: the RADIAL k-dimensional kernel of `additive_rp` (training_routines.py:172-174:
+    # kernel(active_dims = the group's columns)); the product-of-1-D form of the rp_poly kind is not restated
     ncomp = Z1.shape[1] // group
     out = []
     for c in range(ncomp):

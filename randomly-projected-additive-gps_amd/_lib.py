@@ -83,6 +83,12 @@ SIGNATURES = {
     "rpgp_family_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "rpgp_family_bilinear_grad_dense": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _f32, _vp, _sz, _vp]),
     "rpgp_family_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _f32, _f32, _vp]),
+    "rpgp_family_generic_mvm": (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _f64, _f64,
+                                       _vp]),
+    "rpgp_family_generic_dense": (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _f64, _vp]),
+    "rpgp_family_generic_bilinear_workspace_bytes": (_sz, [_int, _i64, _int]),
+    "rpgp_family_generic_bilinear": (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int,
+                                            _i64, _f64, _vp, _sz, _vp]),
     "rpgp_ski_bilinear_grad_comp": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp,
                                            _sz, _vp, _vp]),
     "rpgp_mbcg_workspace_bytes": (_sz, [_vp, _int, _int]),

@@ -743,8 +743,12 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
         if comp_weights is None:
             comp_weights = torch.full((ncomp,), 1.0 / ncomp, dtype=Z1.dtype, device=Z1.device)
         self.comp_weights = comp_weights
-        w = comp_weights.detach().to(device=Z1.device, dtype=torch.float32).reshape(-1).contiguous()
+        # float64 operators (`--double`) keep float64 weights: the backend then serves them with the runtime-(kind, group)
+        # kernels (csrc/rpgp_family_generic.hip), as it does k > 1 sub-kernels of the non-RBF types
+        wdt = torch.float64 if Z1.dtype == torch.float64 else torch.float32
+        w = comp_weights.detach().to(device=Z1.device, dtype=wdt).reshape(-1).contiguous()
         self.fam = _backend.get_backend().make_family(kind, self.group, w)
+        self._generic = bool(getattr(self.fam, "generic", False))
         self._wsum = float(w.sum())                 # one host sync per construction (= per optimiser step)
 
     def _local_matmul(self, rhs, noise=0.0):
@@ -761,14 +765,15 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
 
     def fused_pivoted_cholesky(self, rank):
         be = _backend.get_backend()
-        if not self.symmetric or not hasattr(be, "family_pivoted_cholesky") or self.Z1.shape[1] > 64 or rank > 64:
+        if not self.symmetric or not hasattr(be, "family_pivoted_cholesky") or self.Z1.shape[1] > 64 or rank > 64 or \
+                self._generic:
             return None
         return be.family_pivoted_cholesky(self.fam, self.Z1.detach().contiguous(), self._scale,
                                           min(rank, self.Z1.shape[0]), self._wsum)
 
     def native_descriptor(self, noise=0.0):
         be = _backend.get_backend()
-        if not self.symmetric or not hasattr(be, "mbcg_solve"):
+        if not self.symmetric or not hasattr(be, "mbcg_solve") or self._generic:
             return None
         from . import _lib
         z1 = self.Z1.detach().contiguous()

@@ -767,19 +767,31 @@ FAMILY_GROUPS = (1, 2, 3, 4, 5, 8, 10, 20)
 
 class Family:
     """`struct rpgp_family`: kind (name of training_routines.py:47-88 or RPGP_KIND_*), group size, per-component
-    weights (device float32 tensor, kept alive here)."""
+    weights (device tensor, kept alive here).  `generic`: served by the runtime-(kind, group) kernels of
+    csrc/rpgp_family_generic.hip instead of the templated fast kernels — float64 weights (`--double`), k > 1 sub-kernels of
+    the non-RBF types (radial form), group sizes that are not instantiated."""
 
     def __init__(self, kind, group, weights):
         import ctypes
         self.kind = KINDS[kind] if isinstance(kind, str) else int(kind)
         self.group = int(group)
-        self.weights = _require(weights.detach().reshape(-1), "weights", 1)
+        w = weights.detach().reshape(-1)
+        self.dtype = torch.float64 if w.dtype == torch.float64 else torch.float32
+        if not w.is_cuda:
+            raise TypeError("weights must live on a HIP device (there is no CPU fallback)")
+        self.weights = w.to(self.dtype).contiguous()
         self.ncomp = self.weights.numel()
-        if self.group not in FAMILY_GROUPS or (self.group > 1 and self.kind != _lib.RPGP_KIND_RBF):
-            raise ValueError("unsupported family member: kind %s with %d-dimensional sub-kernels (RBF groups of %s; "
-                             "other kernel types with 1-D sub-kernels)" % (kind, self.group, FAMILY_GROUPS))
-        self.struct = _lib.RpgpFamily(self.kind, self.group, self.ncomp, self.weights.data_ptr())
-        self.ref = ctypes.byref(self.struct)
+        fast = self.group in FAMILY_GROUPS and not (self.group > 1 and self.kind != _lib.RPGP_KIND_RBF)
+        self.generic = self.dtype == torch.float64 or not fast
+        if self.generic and (self.group < 1 or self.group > 32 or self.group * self.ncomp > 64):
+            raise ValueError("unsupported family member: %d components of %d-dimensional sub-kernels (the generic kernels take "
+                             "groups of at most 32 and 64 columns in all)" % (self.ncomp, self.group))
+        if not self.generic:
+            self.struct = _lib.RpgpFamily(self.kind, self.group, self.ncomp, self.weights.data_ptr())
+            self.ref = ctypes.byref(self.struct)
+        else:
+            self.struct = self.ref = None
+        self.code = _lib.RPGP_F64 if self.dtype == torch.float64 else _lib.RPGP_F32
 
     @property
     def ncols(self):
@@ -787,16 +799,49 @@ class Family:
 
 
 def _family_cols(fam, Z, name):
-    Z = _require(Z, name, 2)
+    if fam.generic:
+        if not (torch.is_tensor(Z) and Z.is_cuda and Z.dim() == 2 and Z.dtype == fam.dtype):
+            raise TypeError("%s must be a 2-D %s tensor on a HIP device" % (name, fam.dtype))
+        Z = Z.contiguous()
+    else:
+        Z = _require(Z, name, 2)
     if Z.shape[1] != fam.ncols:
         raise ValueError("%s must have ncomp * group = %d columns (got %d)" % (name, fam.ncols, Z.shape[1]))
     return Z
+
+
+def _generic_matrix(fam, V, rows, name):
+    squeeze = V.dim() == 1
+    V2 = (V.reshape(-1, 1) if squeeze else V).to(fam.dtype).contiguous()
+    if V2.shape[0] != rows or not V2.is_cuda:
+        raise ValueError("%s must have %d rows on the device" % (name, rows))
+    return V2, squeeze
+
+
+def _generic_mvm(fam, Z1, Z2, V, scale, noise):
+    lib = _lib.load()
+    M, J = Z1.shape
+    N = M if Z2 is None else Z2.shape[0]
+    V2, squeeze = _generic_matrix(fam, V, N, "V")
+    out = torch.empty((M, V2.shape[1]), dtype=fam.dtype, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        for t0 in range(0, V2.shape[1], 16):
+            Vc = V2[:, t0:t0 + 16].contiguous()
+            oc = torch.empty((M, Vc.shape[1]), dtype=fam.dtype, device=Z1.device)
+            _lib.check(lib.rpgp_family_generic_mvm(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(), Z1.data_ptr(),
+                                                   None if Z2 is None else Z2.data_ptr(), Vc.data_ptr(), oc.data_ptr(), M, N, J, J,
+                                                   Vc.shape[1], float(scale), float(noise), _stream()),
+                       "rpgp_family_generic_mvm")
+            out[:, t0:t0 + 16] = oc
+    return out.squeeze(1) if squeeze else out
 
 
 def family_mvm_sym(fam, Z, V, scale, noise=0.0):
     """out = scale * sum_c w_c K_c(Z,Z) @ V + noise * V for a member of the generalised family."""
     lib = _lib.load()
     Z = _family_cols(fam, Z, "Z")
+    if fam.generic:
+        return _generic_mvm(fam, Z, None, V, scale, noise)
     N, J = Z.shape
     V2, squeeze = _as_matrix(V, N, "V")
     T = V2.shape[1]
@@ -813,6 +858,8 @@ def family_mvm_rect(fam, Z1, Z2, V, scale):
     lib = _lib.load()
     Z1 = _family_cols(fam, Z1, "Z1")
     Z2 = _family_cols(fam, Z2, "Z2")
+    if fam.generic:
+        return _generic_mvm(fam, Z1, Z2, V, scale, 0.0)
     M, J = Z1.shape
     N = Z2.shape[0]
     V2, squeeze = _as_matrix(V, N, "V")
@@ -833,11 +880,42 @@ def family_dense(fam, Z1, Z2, scale):
     Z2 = _family_cols(fam, Z2, "Z2")
     M, J = Z1.shape
     N = Z2.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32, device=Z1.device)
+    out = torch.empty((M, N), dtype=fam.dtype, device=Z1.device)
     with torch.cuda.device(Z1.device):
-        _lib.check(lib.rpgp_family_dense(fam.ref, Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N,
-                                         float(scale), _stream()), "rpgp_family_dense")
+        if fam.generic:
+            _lib.check(lib.rpgp_family_generic_dense(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
+                                                     Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, float(scale),
+                                                     _stream()), "rpgp_family_generic_dense")
+        else:
+            _lib.check(lib.rpgp_family_dense(fam.ref, Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N,
+                                             float(scale), _stream()), "rpgp_family_dense")
     return out
+
+
+def _generic_bilinear(fam, Z, L, R, S, scale):
+    lib = _lib.load()
+    N, J = Z.shape
+    gZ = torch.zeros((N, J), dtype=fam.dtype, device=Z.device)
+    gc = torch.zeros(fam.ncomp, dtype=fam.dtype, device=Z.device)
+    with torch.cuda.device(Z.device):
+        ws = _workspace(Z.device, lib.rpgp_family_generic_bilinear_workspace_bytes(fam.code, N, fam.ncomp))
+        if S is not None:
+            S = S.to(fam.dtype).contiguous()
+            _lib.check(lib.rpgp_family_generic_bilinear(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
+                                                        Z.data_ptr(), None, None, S.data_ptr(), gZ.data_ptr(), gc.data_ptr(), N, J,
+                                                        J, 0, N, float(scale), ws.data_ptr(), ws.numel(), _stream()),
+                       "rpgp_family_generic_bilinear")
+            return gZ, gc
+        gZp, gcp = torch.empty_like(gZ), torch.empty_like(gc)
+        for t0 in range(0, L.shape[1], 16):      # the derivative is additive over the columns of L, R
+            Lc, Rc = L[:, t0:t0 + 16].contiguous(), R[:, t0:t0 + 16].contiguous()
+            _lib.check(lib.rpgp_family_generic_bilinear(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
+                                                        Z.data_ptr(), Lc.data_ptr(), Rc.data_ptr(), None, gZp.data_ptr(),
+                                                        gcp.data_ptr(), N, J, J, Lc.shape[1], 0, float(scale), ws.data_ptr(),
+                                                        ws.numel(), _stream()), "rpgp_family_generic_bilinear")
+            gZ += gZp
+            gc += gcp
+    return gZ, gc
 
 
 def family_bilinear_grad(fam, Z, L, R, scale):
@@ -845,6 +923,12 @@ def family_bilinear_grad(fam, Z, L, R, scale):
     lib = _lib.load()
     Z = _family_cols(fam, Z, "Z")
     N, J = Z.shape
+    if fam.generic:
+        L2, _ = _generic_matrix(fam, L, N, "L")
+        R2, _ = _generic_matrix(fam, R, N, "R")
+        if L2.shape != R2.shape:
+            raise ValueError("L and R must have the same shape")
+        return _generic_bilinear(fam, Z, L2, R2, None, scale)
     L2, _ = _as_matrix(L, N, "L")
     R2, _ = _as_matrix(R, N, "R")
     if L2.shape != R2.shape:
@@ -869,10 +953,12 @@ def family_bilinear_grad_dense(fam, Z, S, scale):
     """(gZ, gcomp) for 0.5 * sum(S * K) with an explicit symmetric N x N weight matrix S."""
     lib = _lib.load()
     Z = _family_cols(fam, Z, "Z")
-    S = _require(S, "S", 2)
     N, J = Z.shape
     if S.shape != (N, N):
         raise ValueError("S must be %d x %d" % (N, N))
+    if fam.generic:
+        return _generic_bilinear(fam, Z, None, None, S, scale)
+    S = _require(S, "S", 2)
     gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
     gc = torch.zeros(fam.ncomp, dtype=torch.float32, device=Z.device)
     with torch.cuda.device(Z.device):

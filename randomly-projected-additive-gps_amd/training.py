@@ -57,8 +57,9 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
             raise ValueError("Memory efficient GAM with alternative sub-kernels not implemented yet.")
     if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
         raise ValueError("Unknown kernel type")
-    if k > 1 and kernel_type != "RBF":
-        raise NotImplementedError("k > 1 sub-kernels are built for the RBF only")
+    if k > 1 and kernel_type != "RBF" and (batch_kernel or k > 32 or J * k > 64):
+        raise NotImplementedError("k > 1 sub-kernels of the non-RBF types: the radial form of the per-dimension AdditiveKernel "
+                                  "(batch_kernel=False), k <= 32 and J k <= 64 columns")
     if k > 20:
         raise NotImplementedError("k-dimensional RBF sub-kernels are built up to k = 20 (the reference's largest: "
                                   "additive_rp_prescale_J1_K20.json); other k are padded to the next instantiated size")
@@ -388,15 +389,10 @@ def locality_order(X, bits=10):
 
 
 def _check_double_supported(kind, model_kwargs):
-    """`--double` (training_routines.py:481) is served by the float64 parity kernels of the RBF hot path."""
+    """`--double` (training_routines.py:481): float64 parity kernels serve the RBF hot path (rpgp_f64.hip) and every member
+    of the generalised family (rpgp_family_generic.hip); the grid-interpolation operator stays float32."""
     if model_kwargs.get("ski", False):
         raise NotImplementedError("--double is not available for the SKI operator (fp32 kernels only)")
-    outside = kind in ("rp_poly", "additive", "general_rp_poly") or \
-        (kind == "strictly_additive" and not model_kwargs.get("memory_efficient")) or \
-        (kind == "additive_rp" and (model_kwargs.get("kernel_type", "RBF") != "RBF" or model_kwargs.get("k", 1) > 1))
-    if outside:
-        raise NotImplementedError("--double is served by the float64 parity kernels of the RBF hot path only "
-                                  "(additive_rp with 1-D RBF sub-kernels, the memory-efficient GAM, kind full)")
 
 
 class _ExactGPFactory:

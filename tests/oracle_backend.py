@@ -122,8 +122,6 @@ class OracleBackend:
             self.ncomp = self.w.size
 
     def make_family(self, kind, group, weights):
-        if group > 1 and kind != "RBF":
-            raise ValueError("unsupported family member")
         return OracleBackend._Fam(kind, group, weights)
 
     def family_mvm_sym(self, fam, Z, V, scale, noise=0.0):

@@ -99,10 +99,11 @@ def test_family_group1_rbf_equals_hot_path(gpu_device):
 def test_family_errors(gpu_device):
     from rpgp_amd import ops
     w = torch.ones(3, device=gpu_device)
+    assert ops.Family("Matern", 2, w).generic and ops.Family("RBF", 7, w).generic and not ops.Family("RBF", 2, w).generic
     with pytest.raises(ValueError):
-        ops.Family("Matern", 2, w)
+        ops.Family("RBF", 40, w)                                   # groups of at most 32 columns
     with pytest.raises(ValueError):
-        ops.Family("RBF", 7, w)
+        ops.Family("Matern", 30, w)                                # ... and 64 columns in all
     fam = ops.Family("RBF", 2, w)
     with pytest.raises(ValueError):
         ops.family_mvm_sym(fam, torch.zeros(10, 5, device=gpu_device), torch.zeros(10, 1, device=gpu_device), 1.0)
@@ -111,11 +112,55 @@ def test_family_errors(gpu_device):
                            torch.zeros(10, 1, device=gpu_device), 1.0)
 
 
+# what the templated kernels do not instantiate: float64 members, radial k > 1 groups of the non-RBF types, other group sizes
+GENERIC = [("Matern", 2, 6, "f32"), ("InverseMQ", 3, 9, "f32"), ("Cosine", 2, 4, "f32"), ("RBF", 6, 12, "f32"),
+           ("RBF", 1, 20, "f64"), ("Matern", 1, 7, "f64"), ("InverseMQ", 4, 8, "f64"), ("Cosine", 1, 5, "f64"),
+           ("RBF", 20, 20, "f64")]
+
+
+@pytest.mark.parametrize("kind,group,cols,prec", GENERIC)
+def test_generic_family_kernels_match_oracle(gpu_device, kind, group, cols, prec):
+    """csrc/rpgp_family_generic.hip through the C-ABI: product (symmetric with noise, rectangular, T = 1 / 11 / 19), dense
+    block, both forms of the derivative — against oracle/family.py; float64 at 1e-11, float32 at 2e-5; bitwise reproducible."""
+    from rpgp_amd import ops
+    dt = torch.float64 if prec == "f64" else torch.float32
+    npdt = np.float64 if prec == "f64" else np.float32
+    tol = 1e-11 if prec == "f64" else 2e-5
+    rng = np.random.default_rng(cols * 7 + group)
+    N, M = 411, 97
+    sz = 0.5 if group >= 8 else 1.0
+    Z, Z1 = (rng.normal(size=(N, cols)) * sz).astype(npdt), (rng.normal(size=(M, cols)) * sz).astype(npdt)
+    w = rng.uniform(0.3, 1.2, size=cols // group).astype(npdt)
+    fam = ops.Family(kind, group, torch.from_numpy(w).to(gpu_device))
+    assert fam.generic and fam.dtype == dt
+    Zt, Z1t = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(Z1).to(gpu_device)
+    for T in (1, 11, 19):
+        V = rng.normal(size=(N, T)).astype(npdt)
+        Vt = torch.from_numpy(V).to(gpu_device)
+        got = ops.family_mvm_sym(fam, Zt, Vt, 0.7, 0.13)
+        assert got.dtype == dt and torch.equal(got, ops.family_mvm_sym(fam, Zt, Vt, 0.7, 0.13))
+        assert _rel(got.cpu().numpy(), fmo.mvm(Z, Z, V, kind, group, w, 0.7, 0.13)) < tol
+        got_r = ops.family_mvm_rect(fam, Z1t, Zt, Vt, 0.7).cpu().numpy()
+        assert _rel(got_r, fmo.mvm(Z1, Z, V, kind, group, w, 0.7)) < tol
+    Kd = ops.family_dense(fam, Z1t, Zt, 1.3).cpu().numpy()
+    assert np.abs(Kd - fmo.kernel_matrix(Z1, Z, kind, group, w, 1.3)).max() < tol * 10
+    L, R = rng.normal(size=(N, 3)).astype(npdt), rng.normal(size=(N, 3)).astype(npdt)
+    gZ, gc = ops.family_bilinear_grad(fam, Zt, torch.from_numpy(L).to(gpu_device), torch.from_numpy(R).to(gpu_device), 1.3)
+    rZ, rc = fmo.bilinear_grad(Z.astype(np.float64), L, R, kind, group, w, 1.3)
+    assert _rel(gZ.cpu().numpy(), rZ) < tol * 2 and _rel(gc.cpu().numpy(), rc) < tol * 2
+    S = rng.normal(size=(N, N)).astype(npdt)
+    S = (S + S.T) / 2
+    gZ2, gc2 = ops.family_bilinear_grad_dense(fam, Zt, torch.from_numpy(S).to(gpu_device), 1.3)
+    rZ2, rc2 = fmo.bilinear_grad_dense(Z.astype(np.float64), S, kind, group, w, 1.3)
+    assert _rel(gZ2.cpu().numpy(), rZ2) < tol * 2 and _rel(gc2.cpu().numpy(), rc2) < tol * 2
+
+
 @pytest.mark.parametrize("kind,model_kwargs", [
     ("additive_rp", dict(J=20, kernel_type="Matern", prescale=True)),
     ("additive_rp", dict(J=4, k=5, batch_kernel=False, prescale=True)),
     ("additive_rp", dict(J=3, k=6, batch_kernel=False, prescale=True)),          # any k: zero-padded to the 8-wide kernel
     ("additive_rp", dict(J=2, k=7, batch_kernel=False, prescale=False)),
+    ("additive_rp", dict(J=3, k=2, batch_kernel=False, kernel_type="Matern", prescale=True)),   # radial non-RBF groups
     ("rp_poly", dict(J=8, k=1, weighted=True, kernel_type="RBF")),
     ("strictly_additive", dict(weighted=True, kernel_type="InverseMQ")),
 ])
@@ -274,3 +319,59 @@ def test_general_rp_poly_model_trains_on_gpu(gpu_device):
     assert np.isfinite(metrics["prior_train_nmll"]) and np.isfinite(metrics["test_nll"])
     rmse = float(((mean - y[800:]) ** 2).mean().sqrt())
     assert rmse < 0.6                  # far better than the unit-variance baseline after 15 steps
+
+
+@pytest.mark.parametrize("model_kwargs", [dict(J=6, kernel_type="Matern", prescale=True),
+                                          dict(J=3, k=2, batch_kernel=False, kernel_type="InverseMQ", prescale=False),
+                                          dict(J=4, k=3, batch_kernel=False, prescale=True)])
+def test_double_family_model_parity(gpu_device, model_kwargs):
+    """`--double` (training_routines.py:481) for family members: float64 model through the runtime-(kind, group) kernels —
+    MLL (Cholesky and CG regime, inv-quad part), gradients finite, predictive mean / variance against the dense float64
+    computation at 1e-8 (the float32 path's gates are 1e-4)."""
+    from rpgp_amd import settings
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    from rpgp_amd.training import create_exact_gp
+    N, d = 700, 5
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N, d, generator=g).double()
+    y = (torch.sin(X).sum(1) + 0.05 * torch.randn(N, generator=g).double())
+    y = (y - y.mean()) / y.std()
+    Xs = torch.randn(30, d, generator=g).double()
+    torch.manual_seed(1)
+    model, lik = create_exact_gp(X.float(), y.float(), "additive_rp", noise_prior=True, learn_proj=False, **model_kwargs)
+    model, lik = model.to(gpu_device, torch.float64), lik.to(gpu_device, torch.float64)
+    lik.noise = 0.05
+    model.train_inputs, model.train_targets = X.to(gpu_device), y.to(gpu_device)
+    mll = ExactMarginalLogLikelihood(lik, model)
+    base = model.covar_module.base_kernel
+    P = base.projection_module.weight.detach().double().cpu().t()
+    ls = base.lengthscale.detach().double().cpu().reshape(-1)
+    tr = lambda A: (((A / ls) @ P) if base.prescale else ((A @ P) / ls)).numpy()
+    ktype, group = base.base_kernel.kernel_type, base.base_kernel.group
+    w = np.full(P.shape[1] // group, float(base.base_kernel.weight))
+    s, noise, c = float(model.covar_module.outputscale), float(lik.noise), float(model.mean_module.constant)
+    Z, Zs = tr(X), tr(Xs)
+    K = fmo.kernel_matrix(Z, Z, ktype, group, w, s) + noise * np.eye(N)
+    r = y.numpy() - c
+    alpha = np.linalg.solve(K, r)
+    ref_mll = (-0.5 * r @ alpha - 0.5 * np.linalg.slogdet(K)[1] - 0.5 * N * math.log(2 * math.pi)
+               + float(lik.log_prior().detach())) / N
+    model.train()
+    with settings.max_cholesky_size(4000):
+        val = mll(model(model.train_inputs), model.train_targets)
+        val.backward()
+    assert val.dtype == torch.float64 and abs(val.item() - ref_mll) < 1e-9 * max(1.0, abs(ref_mll))
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
+    with settings.max_cholesky_size(100), settings.cg_tolerance(1e-10), settings.skip_logdet_forward(True), \
+            settings.max_cg_iterations(3000), settings.min_preconditioning_size(100), torch.no_grad():
+        v2 = mll(model(model.train_inputs), model.train_targets).item()
+    expect = (-0.5 * r @ alpha - 0.5 * N * math.log(2 * math.pi) + float(lik.log_prior().detach())) / N
+    assert abs(v2 - expect) < 1e-8 * abs(expect)
+    model.eval()
+    with torch.no_grad(), settings.max_cholesky_size(100), settings.eval_cg_tolerance(1e-11), settings.max_cg_iterations(3000):
+        out = model(Xs.to(gpu_device))
+    Ks = fmo.kernel_matrix(Zs, Z, ktype, group, w, s)
+    mean = Ks @ alpha + c
+    cov = fmo.kernel_matrix(Zs, Zs, ktype, group, w, s) - Ks @ np.linalg.solve(K, Ks.T)
+    assert _rel(out.mean.cpu().numpy(), mean) < 1e-8
+    assert np.abs(out.variance.cpu().numpy() - np.diag(cov)).max() < 1e-8

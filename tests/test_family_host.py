@@ -48,8 +48,10 @@ def test_family_oracle_pinned_to_rbf_oracle_and_reference_formulas():
     # InverseMQ: dist.add_(1).pow_(-1/2) on the squared distance (imq_kernel.py:8-9)
     d2 = (Z1[:, :1] - Z2[:, :1].T) ** 2
     assert np.allclose(fmo.component_matrices(Z1, Z2, "InverseMQ", 1)[0], (d2 + 1) ** -0.5)
-    with pytest.raises(ValueError):
-        fmo.component_matrices(Z1, Z2, "Matern", 2)
+    # non-RBF groups are RADIAL (training_routines.py:172-174: kernel(active_dims = the group)): a function of the
+    # group's Euclidean distance, not the product of 1-D kernels
+    r = np.sqrt(((Z1[:, None, :2] - Z2[None, :, :2]) ** 2).sum(-1))
+    assert np.allclose(fmo.component_matrices(Z1, Z2, "Matern", 2)[0], (1 + np.sqrt(3) * r) * np.exp(-np.sqrt(3) * r))
 
 
 def _problem(n=60, d=5, seed=0):
@@ -67,6 +69,8 @@ def _problem(n=60, d=5, seed=0):
     ("additive_rp", dict(J=2, k=6, batch_kernel=False, prescale=True)),                      # any k: 6 -> the 8-wide kernel
     ("additive_rp", dict(J=1, k=7, batch_kernel=False, prescale=False)),                     # ... 7 -> 8, postscale
     ("additive_rp", dict(J=1, k=13, batch_kernel=False, prescale=True)),                     # ... 13 -> 20
+    ("additive_rp", dict(J=3, k=2, batch_kernel=False, kernel_type="Matern", prescale=True)),     # radial non-RBF groups
+    ("additive_rp", dict(J=2, k=3, batch_kernel=False, kernel_type="InverseMQ", prescale=False)),
     ("rp_poly", dict(J=5, k=1, weighted=True, kernel_type="RBF")),
     ("rp_poly", dict(J=3, k=2, weighted=True, kernel_type="RBF")),
     ("rp_poly", dict(J=4, k=1, weighted=False, kernel_type="Matern")),
@@ -174,8 +178,9 @@ def test_family_initialisation_follows_reference_order():
 
 def test_family_validation_errors():
     from rpgp_amd.training import create_additive_rp_kernel, create_rp_poly_kernel, create_exact_gp
+    create_additive_rp_kernel(6, 3, k=2, batch_kernel=False, kernel_type="Matern")     # radial k-dimensional Matern: served
     with pytest.raises(NotImplementedError):
-        create_additive_rp_kernel(6, 3, k=2, batch_kernel=False, kernel_type="Matern")
+        create_additive_rp_kernel(6, 3, k=40, batch_kernel=False, kernel_type="Matern")
     create_additive_rp_kernel(6, 3, k=7, batch_kernel=False)            # any k <= 20 is served (padded group)
     with pytest.raises(NotImplementedError):
         create_additive_rp_kernel(6, 1, k=21, batch_kernel=False)
@@ -259,16 +264,21 @@ def test_weighted_ski_kinds_track_the_exact_kernel(oracle_backend, kind, model_k
         assert gw0 is None and gw1 is None
 
 
-def test_double_is_refused_for_family_kinds(oracle_backend):
+def test_double_family_kinds_train_and_ski_is_refused(oracle_backend):
+    """`--double` (training_routines.py:481): every family member trains in float64 (runtime-(kind, group) kernels on the
+    device; here the CPU test double); only the grid-interpolation operator refuses."""
     from rpgp_amd.training import train_exact_gp
     X, y = _problem(30, 4)
     tk = {"verbose": False, "optimizer": "adam", "max_iter": 2, "lr": 0.1, "patience": 20, "smooth": True}
     for kind, mk in (("rp_poly", dict(J=3, k=1, noise_prior=True, weighted=True)),
                      ("additive_rp", dict(J=3, noise_prior=True, kernel_type="Matern", learn_proj=False, prescale=True)),
-                     ("additive_rp", dict(J=3, noise_prior=True, learn_proj=False, prescale=True, ski=True,
-                                          ski_options={"grid_size": 64, "num_dims": 1}))):
-        with pytest.raises(NotImplementedError):
-            train_exact_gp(X, y, X, y, kind, mk, tk, double=True)
+                     ("additive_rp", dict(J=2, k=2, batch_kernel=False, noise_prior=True, kernel_type="InverseMQ",
+                                          learn_proj=False, prescale=True))):
+        metrics, pred, model = train_exact_gp(X, y, X, y, kind, mk, tk, double=True, skip_random_restart=True)
+        assert all(p.dtype == torch.float64 for p in model.parameters()) and np.isfinite(metrics["test_nll"])
+    with pytest.raises(NotImplementedError):
+        train_exact_gp(X, y, X, y, "additive_rp", dict(J=3, noise_prior=True, learn_proj=False, prescale=True, ski=True,
+                                                      ski_options={"grid_size": 64, "num_dims": 1}), tk, double=True)
 
 
 def test_multi_additive_kernel_groups_and_operator(oracle_backend):

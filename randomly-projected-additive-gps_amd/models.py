@@ -264,6 +264,21 @@ class PredictionStrategy:
             logdet = N * math.log(s2) - 2.0 * float(torch.log(Lk.diagonal()).sum()) + 2.0 * float(torch.log(Lb.diagonal()).sum())
             return -0.5 * (quad + logdet + N * LOG2PI)
         Lc, K64 = self._mp                                       # float32 factor and float64 copy of Khat
+        if N <= settings.dense_solve_size.value():
+            # mid sizes: everything in float64 on the stored matrix (as the predictive covariance does below dense_solve_size).
+            # A confident fit (a GAM with sigma^2 ~ 1e-4 s) leaves 2K + sigma^2 I numerically indefinite in float32 — found by
+            # the round-4 soak over the served specifications; psd_safe_cholesky adds the float32-scale jitter the matrix's own
+            # rounding calls for.
+            c64 = self._chol64_factor(target)
+            if c64 is None:
+                c64 = psd_safe_cholesky(K64, jitter=1e-6)
+            B64 = 2.0 * K64
+            B64.diagonal().sub_(s2)
+            Lb = psd_safe_cholesky(B64, jitter=1e-6)
+            w = torch.cholesky_solve(d, Lb)
+            quad = float((d * (K64 @ w)).sum()) / s2
+            logdet = N * math.log(s2) - 2.0 * float(torch.log(c64.diagonal()).sum()) + 2.0 * float(torch.log(Lb.diagonal()).sum())
+            return -0.5 * (quad + logdet + N * LOG2PI)
         logdet_khat = 2.0 * float(torch.log(Lc.diagonal().double()).sum())
         # B in float32 from the stored kernel matrix (one N x N float32 block, factorised); B w in float64 is
         # 2 Khat_64 w - sigma^2 w: no float64 copy of B
@@ -475,7 +490,12 @@ class TrainPosterior(MultivariateNormal):
         same_noise = self._noise is not None and abs(float(self._noise) - float(strategy.noise)) <= 1e-12 * float(strategy.noise)
         if not same_noise:
             return super().log_prob(value)
-        return torch.as_tensor(strategy.train_log_prob(value), dtype=value.dtype, device=value.device)
+        try:
+            lp = strategy.train_log_prob(value)
+        except RuntimeError:
+            # (a factorisation of the closed form failed: the explicit posterior covariance and its jittered float64 factor)
+            return super().log_prob(value)
+        return torch.as_tensor(lp, dtype=value.dtype, device=value.device)
 
 
 class LazyPrior(MultivariateNormal):

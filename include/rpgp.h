@@ -437,6 +437,17 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
                     size_t workspace_bytes, void *stream);
 
 /*
+ * Stochastic Lanczos quadrature estimate of log|A| from the CG coefficient histories rpgp_mbcg_solve returns (HOST
+ * arithmetic, no device work): the first `num_probes` columns of alpha_hist / beta_hist ([iters][ld] floats) are unit-norm
+ * probe columns;  log|A| ~ (n / num_probes) sum_p sum_m Q_p[0][m]^2 log lambda_pm  over the Lanczos tridiagonals
+ * T[k][k] = 1/alpha_k + beta_{k-1}/alpha_{k-1}, T[k][k+1] = sqrt(beta_k)/alpha_k.  Replaces what GPyTorch's
+ * `inv_quad_logdet` does with the `t_mat` of `linear_cg` (lanczos_tridiag_to_diag + the log-det sum), reached from
+ * `-mll(output, train_y)` at /root/reference/fitting/optimizing.py:67-72.  RPGP_ENUMERIC: the QL iteration did not converge.
+ */
+int rpgp_slq_logdet(const float *alpha_hist, const float *beta_hist, int iters, int ld, int num_probes, double n,
+                    double *logdet_out);
+
+/*
  * Multi-GPU pieces (one process per GPU; replaces `MultiDeviceKernel(kernel, devices, devices[0])`,
  * training_routines.py:407-408).
  *

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rpgp_mbcg_workspace_bytes": (_sz, [_vp, _int, _int]),
     "rpgp_mbcg_solve": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _f32, _int, _vp, _vp, _f32, _vp, _vp, _vp,
                                _vp, _vp, _vp, _sz, _vp]),
+    "rpgp_slq_logdet": (_int, [_vp, _vp, _int, _int, _int, _f64, _vp]),
     "rpgp_project_f64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "rpgp_project_grad_f64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "rpgp_mvm_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f64, _f64, _vp]),

@@ -51,6 +51,7 @@ class HipBackend:
     make_operator_desc = staticmethod(ops.make_operator_desc)
     make_sum_operator_desc = staticmethod(ops.make_sum_operator_desc)
     mbcg_solve = staticmethod(ops.mbcg_solve)
+    slq_logdet_history = staticmethod(ops.slq_logdet_history)
 
 
 _backend = HipBackend()

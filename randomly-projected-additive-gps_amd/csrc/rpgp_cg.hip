@@ -32,6 +32,8 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
+#include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "../../include/rpgp.h"
@@ -77,7 +79,21 @@ struct CgPoll {             // copied to pinned host memory after the iterations
   int since_best;
   int snap_slot;            // which snap_resid entry is current
   float snap_cur;           // its value (mean residual of the iterate saved in x_best)
+  int seq;                  // host copies only: stamped LAST (the host spins on it, see wait_record)
 };
+// the record a kernel hands to the host: the fields, a system-scope fence, then the stamp
+__device__ __forceinline__ void publish_poll(CgPoll *__restrict__ host, const CgPoll &v, int stamp) {
+  host->mean_resid = v.mean_resid;
+  host->done = v.done;
+  host->iters = v.iters;
+  host->best_resid = v.best_resid;
+  host->since_best = v.since_best;
+  host->snap_slot = v.snap_slot;
+  host->snap_cur = v.snap_cur;
+  __threadfence_system();
+  *reinterpret_cast<volatile int *>(&host->seq) = stamp;
+  __threadfence_system();
+}
 struct CgState {
   float rz[2][kMaxT];       // r.z of the current iterate, ping-pong by iteration parity (no intra-kernel race)
   float rhs_norm[kMaxT];
@@ -192,47 +208,47 @@ __device__ __forceinline__ void block_ltsum(const floatx4m &acc, float *__restri
   dst[e] = ((sh[e] + sh[256 + e]) + sh[512 + e]) + sh[768 + e];
 }
 
-// ---- the reduction folded into the producing pass ------------------------------------------------------------------------
-// (Opt-in experiment, RPGP_CG_FOLD=1 — measured slower than the separate launch, see rpgp_mbcg_solve.)  With few partial
-// slabs (small N: 29 at C2, 59 at C3) a k_reduce launch between two passes is 5 us of kernel + a launch boundary, 45 times
-// per optimiser step.  Here the LAST workgroup of the pass to finish
-// adds up all the slabs — per entry in slab order, float64: a fixed order whoever comes last, so the result stays bitwise
-// reproducible.  Hand-off per MI355X_MICROARCH.md (Valid forms): every storing wave drains its stores, workgroup barrier,
-// lane 0: agent-scope release, arrive on the counter; the last arriver: agent-scope acquire, drain, workgroup barrier, plain
-// loads.  The counter returns to 0 for the next pass (ordered by the kernel boundary).  `counter == nullptr`: no fold.
-constexpr int kFoldMaxParts = 128;
-__device__ __forceinline__ void fold_reduce(const float *__restrict__ part, int nparts, double *__restrict__ red,
-                                            unsigned *__restrict__ counter) {
-  if (!counter) return;
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = prev == gridDim.x - 1;
-    if (last) {
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    s_last = last;
+// ---- the reduction on the CONSUMER side ------------------------------------------------------------------------------
+// With few partial slabs (N <= 16k: at most kDirectParts workgroups per pass: 29 at C2, 59 at C3) a k_reduce launch between
+// two passes is 5 us of kernel plus two launch boundaries, 45 times per optimiser step — a tenth of the step's device time.
+// Here the pass that NEEDS a reduced entry adds the slabs up itself at its head: the same float64 additions in the same order
+// as k_reduce (group g = slab g, then slab g + 32; the 32 group sums in order), so the numbers are bitwise those of the
+// separate launch, every workgroup forms the same values, and nothing but the kernel boundary orders producer and consumer
+// (no atomics, no fences: the round-4 "last workgroup folds" variant paid an agent-scope release per workgroup and was
+// slower than the launch it replaced).  All loads of a batch are in flight together: one or two L2 round trips.
+constexpr int kDirectParts = 64;
+template <int NQ>
+__device__ __forceinline__ void slab_sums(const float *const (&src)[NQ], const int (&np)[NQ], const int (&idx)[NQ],
+                                          double (&out)[NQ]) {
+  int nmax = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    out[q] = 0.0;
+    nmax = np[q] > nmax ? np[q] : nmax;
   }
-  __syncthreads();
-  if (!s_last) return;
-  for (int e = threadIdx.x; e < kRedW; e += 256) {
-    double acc = 0.0;
-    int q = 0;
-    for (; q + 7 < nparts; q += 8) {             // eight loads in flight, added in slab order
-      float v[8];
+#pragma unroll 1
+  for (int g0 = 0; g0 < 32 && g0 < nmax; g0 += 16) {
+    float v[NQ][16], w[NQ][16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(q + u) * kRedW + e];
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += (double)v[u];
-    }
-    for (; q < nparts; ++q) acc += (double)part[(size_t)q * kRedW + e];
-    red[e] = acc;
+      for (int u = 0; u < 16; ++u) {
+        // (unconditional loads from clamped slabs, masked afterwards: a load under a condition becomes a branch and a wait
+        //  of its own, and the 32 - 96 round trips of a batch then run one after the other)
+        const int g = g0 + u, last = np[q] - 1;
+        const int ga = g < last ? g : last, gb = g + 32 < last ? g + 32 : last;
+        const float x = src[q][(unsigned)ga * (unsigned)kRedW + (unsigned)idx[q]];
+        const float y = src[q][(unsigned)gb * (unsigned)kRedW + (unsigned)idx[q]];
+        v[q][u] = g <= last ? x : 0.f;
+        w[q][u] = g + 32 <= last ? y : 0.f;
+      }
+    // (nothing moves across: every load of the batch is issued before the first addition waits — left to itself the
+    //  scheduler interleaves six loads at a time with their additions to save registers)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) out[q] += (0.0 + (double)v[q][u]) + (double)w[q][u];
   }
 }
 
@@ -240,8 +256,7 @@ __device__ __forceinline__ void fold_reduce(const float *__restrict__ part, int 
 // part[blk][0..15] = sum over the workgroup's rows of a*b per column; part[blk][32 + kk*16 + t] = sum L[row][kk] b[row][t]
 template <int TT>
 __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, const float *__restrict__ b,
-                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K,
-                                                double *__restrict__ red_out = nullptr, unsigned *__restrict__ fold_counter = nullptr) {
+                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K) {
   __shared__ float sh[1024];
   const Lane ln;
   float dot = 0.f;
@@ -283,7 +298,6 @@ __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, con
   block_colsum(dot, sh, dst, ln);
   if (threadIdx.x < 16) dst[16 + threadIdx.x] = 0.f;
   block_ltsum(lt, sh, dst + kRedLt, ln);
-  fold_reduce(part, (int)gridDim.x, red_out, fold_counter);
 }
 
 // red[e] = sum over the slabs of part[.][e] in float64, fixed order: workgroup b owns entries 8 b .. 8 b + 7, its 32
@@ -314,17 +328,31 @@ __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ part, 
 
 // ---- set-up: r = rhs / |rhs| (columns with |rhs| < 1e-10 are flagged zero and left unscaled), x = p = Ap = 0,
 // ---- partial L^T r ------------------------------------------------------------------------------------------------
-template <int TT>
+template <int TT, bool DIRECT = false>
 __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, const double *__restrict__ red_sq,
                                               float *__restrict__ r, float *__restrict__ x, float *__restrict__ p,
                                               float *__restrict__ Ap, const float *__restrict__ L,
                                               float *__restrict__ part, CgState *__restrict__ st, long long N, int K,
-                                              double *__restrict__ red_out = nullptr, unsigned *__restrict__ fold_counter = nullptr) {
+                                              const float *__restrict__ dir_sq = nullptr, int n_sq = 0) {
   __shared__ float sh[1024];
   __shared__ float snrm[kMaxT];
   const Lane ln;
+  // (dir_sq != nullptr: the |rhs|^2 sums are added up here from the slabs of the norm pass — see slab_sums)
+  double q_sq;
+  {
+    const int tcl = (int)threadIdx.x < TT ? (int)threadIdx.x : TT - 1;
+    if constexpr (DIRECT) {
+      const float *const src[1] = {dir_sq};
+      const int np[1] = {n_sq}, ix[1] = {tcl};
+      double o[1];
+      slab_sums<1>(src, np, ix, o);
+      q_sq = o[0];
+    } else {
+      q_sq = red_sq[tcl];
+    }
+  }
   if (threadIdx.x < kMaxT) {
-    float nrm = threadIdx.x < TT ? sqrtf((float)red_sq[threadIdx.x]) : 1.0f;
+    float nrm = threadIdx.x < TT ? sqrtf((float)q_sq) : 1.0f;
     const int zero = nrm < 1e-10f;
     if (zero) nrm = 1.0f;
     snrm[threadIdx.x] = nrm;
@@ -384,14 +412,13 @@ __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, con
   __syncthreads();
   if (threadIdx.x < 32) dst[threadIdx.x] = 0.f;
   block_ltsum(lt, sh, dst + kRedLt, ln);
-  fold_reduce(part, (int)gridDim.x, red_out, fold_counter);
 }
 
 // ---- pass B -----------------------------------------------------------------------------------------------------------
 // alpha = rz / pAp (guarded; 0 after convergence, so iterations the host had already enqueued leave x and r untouched);
 // x += alpha p; r -= alpha Ap; z = M^-1 r (Woodbury, float64 correction); partial |r|^2, r.z, L^T r.
 // first != 0: the set-up call (alpha = 0, w = L^T r0 as reduced by k_init).
-template <int TT, int NB = 1>
+template <int TT, int NB = 1, bool DIRECT = false>
 __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, const float *__restrict__ Ap,
                                                 float *__restrict__ x, float *__restrict__ r, float *__restrict__ z,
                                                 const float *__restrict__ L, const double *__restrict__ Cinv,
@@ -399,8 +426,8 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
                                                 float *__restrict__ part, const CgState *__restrict__ st,
                                                 float *__restrict__ alpha_out, long long N, int K, float sigma2,
                                                 float eps, float stop_after, int cur, int first,
-                                                double *__restrict__ red_out = nullptr,
-                                                unsigned *__restrict__ fold_counter = nullptr) {
+                                                const float *__restrict__ dirA = nullptr, int nA = 0,
+                                                const float *__restrict__ dirB = nullptr, int nB = 0) {
   __shared__ float sh[1024];
   __shared__ double sW[256];
   __shared__ double sTv[256];
@@ -413,9 +440,20 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
   const int tcl = (int)threadIdx.x < TT ? (int)threadIdx.x : TT - 1;
   const float q_rz = st->rz[cur][tcl], q_res = st->resid[tcl];
   const int q_zero = st->rhs_zero[tcl], q_done = st->poll.done;
-  const double q_pap = redA[tcl];
-  const double q_wb = redB[kRedLt + threadIdx.x];
-  const double q_wa = redA[kRedLt + threadIdx.x];
+  double q_pap, q_wb, q_wa;
+  if constexpr (DIRECT) {       // consumer-side reduction (slab_sums): pass A's slabs and the previous pass B's
+    const float *const src[3] = {dirA, dirB, dirA};
+    const int np[3] = {nA, nB, nA}, ix[3] = {tcl, kRedLt + (int)threadIdx.x, kRedLt + (int)threadIdx.x};
+    double o[3];
+    slab_sums<3>(src, np, ix, o);
+    q_pap = o[0];
+    q_wb = o[1];
+    q_wa = o[2];
+  } else {
+    q_pap = redA[tcl];
+    q_wb = redB[kRedLt + threadIdx.x];
+    q_wa = redA[kRedLt + threadIdx.x];
+  }
   double q_ci = 0.0;
   {
     const int kk0 = threadIdx.x >> 4, t0c = threadIdx.x & 15;
@@ -532,9 +570,6 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
   block_colsum(acc_rr, sh, dst, ln);
   block_colsum(acc_rz, sh, dst + 16, ln);
   block_ltsum(lt2[0] + lt2[1], sh, dst + kRedLt, ln);
-  // (pass B reads `redB` in its prologue and the fold overwrites it: every workgroup has long consumed it by the time the
-  //  LAST one arrives — the arrive is behind each workgroup's own prologue loads)
-  fold_reduce(part, (int)gridDim.x, red_out, fold_counter);
 }
 
 // ---- pass C -----------------------------------------------------------------------------------------------------------
@@ -544,13 +579,14 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
 // merely stall, its recurrence residual can GROW; the iterate with the smallest tested residual is kept in x_best (every
 // workgroup takes the same decision from the same reduced numbers) and returned when the tolerance is never reached.
 // first != 0: the set-up call (p = z, rz[0] = rz').
-template <int TT>
+template <int TT, bool DIRECT = false>
 __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, float *__restrict__ p,
                                                 const double *__restrict__ redB, CgState *__restrict__ st,
                                                 float *__restrict__ beta_out, long long N, float eps, int cur, int first,
                                                 int check_now, float tolerance, int iter_count, int stagnation_window,
                                                 const float *__restrict__ x, float *__restrict__ x_best,
-                                                CgPoll *__restrict__ poll_host) {
+                                                CgPoll *__restrict__ poll_host, const float *__restrict__ dirB = nullptr,
+                                                int nB = 0) {
   __shared__ float sbeta[kMaxT];
   __shared__ float sres[kMaxT];
   __shared__ float srzn[kMaxT];
@@ -560,7 +596,18 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
   const int tcl = (int)threadIdx.x < TT ? (int)threadIdx.x : TT - 1;
   const int done_raw = st->done_pp[cur];
   const float snap_prev = st->snap_resid[cur];
-  const double q_rzn = redB[16 + tcl], q_rr = redB[tcl];
+  double q_rzn, q_rr;
+  if constexpr (DIRECT) {
+    const float *const src[2] = {dirB, dirB};
+    const int np[2] = {nB, nB}, ix[2] = {16 + tcl, tcl};
+    double o[2];
+    slab_sums<2>(src, np, ix, o);
+    q_rzn = o[0];
+    q_rr = o[1];
+  } else {
+    q_rzn = redB[16 + tcl];
+    q_rr = redB[tcl];
+  }
   const float q_rz = st->rz[cur][tcl];
   const int q_zero = st->rhs_zero[tcl];
   asm volatile("" ::"v"(done_raw), "v"(snap_prev), "v"(q_rzn), "v"(q_rr), "v"(q_rz), "v"(q_zero));
@@ -568,10 +615,7 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
   // the poll record of a tested iteration goes straight to pinned host memory (a D2H copy per poll is a 4 us copy kernel)
   if (was_done && blockIdx.x == 0 && threadIdx.x == 0) {
     st->done_pp[cur ^ 1] = was_done;
-    if (check_now && poll_host) {
-      *poll_host = st->poll;
-      __threadfence_system();
-    }
+    if (check_now && poll_host) publish_poll(poll_host, st->poll, iter_count);
   }
   if (threadIdx.x < kMaxT) {
     float beta = 0.f, res = 0.f, rzn = 0.f;
@@ -656,10 +700,7 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
             st->poll.iters = iter_count;
           }
         }
-        if (poll_host) {
-          *poll_host = st->poll;
-          __threadfence_system();
-        }
+        if (poll_host) publish_poll(poll_host, st->poll, iter_count);
       }
       st->done_pp[cur ^ 1] = st->poll.done;
     }
@@ -669,9 +710,11 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
 // x *= |rhs| per column; when the tolerance was never reached and a better tested iterate was saved, return that one
 // (the reported mean residual is updated by the host from the same two numbers)
 __global__ __launch_bounds__(256) void k_unnormalise(float *__restrict__ x, const float *__restrict__ x_best,
-                                                     const CgState *__restrict__ st, long long N, int T) {
+                                                     const CgState *__restrict__ st, long long N, int T,
+                                                     CgPoll *__restrict__ poll_host) {
   const float snap = st->snap_resid[st->poll.snap_slot];
   const bool use_best = st->poll.done != 1 && snap < st->poll.mean_resid;
+  if (blockIdx.x == 0 && threadIdx.x == 0) publish_poll(poll_host, st->poll, 1);   // the final record: no copy behind the solve
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < N * T; e += (long long)gridDim.x * 256)
     x[e] = (use_best ? x_best[e] : x[e]) * st->rhs_norm[e % T];
 }
@@ -713,18 +756,24 @@ Grids grids_for(long long N) {
 // Pinned host landing zone for the lagged convergence polls (one per host thread; the executor keeps no other
 // state between calls).
 constexpr int kPollRing = 4;
+constexpr size_t kHistFloats = (size_t)(kMaxHist + 1) * kMaxT;       // one coefficient history (the last row is a scratch slot)
 struct PollCtx {
   CgPoll *host = nullptr;
   CgPoll *host_dev = nullptr;       // the same memory as the device sees it (pass C writes its poll record there)
+  float *hist = nullptr;            // alpha history, then beta history: written by passes B / C straight into pinned memory
+  float *hist_dev = nullptr;        //   (two D2H copies into pageable memory and a second synchronisation per solve otherwise)
   hipEvent_t ev[kPollRing];
   bool ok = false;
   int init() {
     if (ok) return 0;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), (kPollRing + 1) * sizeof(CgPoll),
+    const size_t poll_bytes = ((kPollRing + 1) * sizeof(CgPoll) + 255) & ~(size_t)255;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), poll_bytes + 2 * kHistFloats * sizeof(float),
                                  hipHostMallocMapped | hipHostMallocPortable);
     if (e != hipSuccess) return (int)e;
     e = hipHostGetDevicePointer(reinterpret_cast<void **>(&host_dev), host, 0);
     if (e != hipSuccess) return (int)e;
+    hist = reinterpret_cast<float *>(reinterpret_cast<char *>(host) + poll_bytes);
+    hist_dev = reinterpret_cast<float *>(reinterpret_cast<char *>(host_dev) + poll_bytes);
     for (int i = 0; i < kPollRing; ++i) {
       e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
       if (e != hipSuccess) return (int)e;
@@ -734,6 +783,28 @@ struct PollCtx {
   }
 };
 thread_local PollCtx g_poll;
+
+// Wait for a record a kernel publishes into pinned memory (publish_poll): the host SPINS on the stamp — the record of a
+// 5 us pass arrives within microseconds of the pass finishing, where hipEventSynchronize / hipStreamSynchronize wake the
+// thread up ~50 - 150 us later (measured as an idle device in front of k_unnormalise, once per solve, and again behind it).
+// After ~20 ms without the stamp (a kernel that never ran: launch error, hung device) the caller falls back to the runtime's
+// own synchronisation, which reports such errors.
+inline bool wait_record(const CgPoll *rec, int stamp) {
+  static const bool spin = [] {
+    const char *e = getenv("RPGP_CG_SPIN");          // RPGP_CG_SPIN=0: the runtime's synchronisation (A/B measurements)
+    return !(e && e[0] == '0');
+  }();
+  if (!spin) return false;
+  const volatile int *p = &rec->seq;
+  for (long spins = 0; spins < 40000000L; ++spins) {
+    if (*p == stamp) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return true;
+    }
+    __builtin_ia32_pause();
+  }
+  return false;
+}
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -897,8 +968,6 @@ size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_ran
   total += align256(sizeof(CgState));
   total += align256((size_t)kMaxBlocks * kRedW * sizeof(float));               // per-workgroup partials
   total += 2 * align256((size_t)kRedW * sizeof(double));                       // reduced vectors A / B
-  total += 256;                                                                // arrival counter of the folded reductions
-  total += 2 * align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));       // alpha / beta history
   total += ski_stage_bytes(op, T);
   total += align256(operator_workspace(op, T));
   return total;
@@ -949,9 +1018,6 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   float *part = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kRedW * sizeof(float));
   double *redA = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
   double *redB = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
-  unsigned *fold_cnt = reinterpret_cast<unsigned *>(w); w += 256;
-  float *alpha_d = reinterpret_cast<float *>(w); w += align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));
-  float *beta_d = reinterpret_cast<float *>(w); w += align256((size_t)(kMaxHist + 1) * kMaxT * sizeof(float));
   if (op->kind == RPGP_OP_SKI) {
     const size_t nh = (size_t)op->J * op->G * T;
     sh.hist = reinterpret_cast<double *>(w); w += align256(nh * sizeof(double));
@@ -971,39 +1037,60 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     if (prc) return prc;
   }
   CgPoll *hpoll = g_poll.host;
+  float *alpha_d = g_poll.hist_dev, *beta_d = g_poll.hist_dev + kHistFloats;      // (pinned host memory, device view)
   // with the identity preconditioner z IS r: pass B skips the store and pass C reads r
   float *zsrc = K > 0 ? z : r;
 
-  // Few slabs (small N) and no all-reduce between the sums and their consumer: the producing pass's LAST workgroup can do the
-  // reduction itself (fold_reduce) — 45 launches fewer per optimiser step at the C2 / C3 shapes.  MEASURED SLOWER (round 4,
-  // same box, tools/solve_bench.py): C2 3.64 -> 3.99 ms per step, C3 5.78 -> 6.13: the agent-scope release every workgroup
-  // pays before it arrives (an L2 write-back) costs more than the 5 us k_reduce launch it replaces — the guide's price list
-  // says as much (barrier-counter 7.4 us against a 1.5 us kernel boundary).  Kept as an opt-in experiment: RPGP_CG_FOLD=1.
-  const char *env_fold = getenv("RPGP_CG_FOLD");
-  const bool fold_ok = !rows && env_fold && env_fold[0] == '1';
-  auto fold_for = [&](int nparts) -> unsigned * { return (fold_ok && nparts <= kFoldMaxParts) ? fold_cnt : nullptr; };
-  if (fold_ok) CG_CHECK(hipMemsetAsync(fold_cnt, 0, sizeof(unsigned), st));
+  // Few slabs and no all-reduce between the sums and their consumer: the consuming pass adds the slabs up itself (slab_sums)
+  // — 45 launches fewer per optimiser step at the C2 / C3 shapes.  Four slab areas: the A pass, the set-up pass, and the B
+  // pass ping-pong (pass B of iteration i reads the L^T r slabs of iteration i - 1 while it writes its own).
+  // RPGP_CG_DIRECT=0 keeps the separate k_reduce launches (A/B measurements).
+  const char *env_direct = getenv("RPGP_CG_DIRECT");
+  const bool direct = !rows && nba <= kDirectParts && nbb <= kDirectParts && !(env_direct && env_direct[0] == '0');
+  float *partA = part, *partI = part + (size_t)kDirectParts * kRedW;
+  float *partB[2] = {part + (size_t)2 * kDirectParts * kRedW, part + (size_t)3 * kDirectParts * kRedW};
+  static_assert(kMaxBlocks >= 4 * kDirectParts, "slab areas of the consumer-side reduction");
 
-#define CG_REDUCE(dst_, nparts_)                                                                     \
+#define CG_REDUCE(src_, dst_, nparts_)                                                               \
   do {                                                                                               \
-    if (!fold_for(nparts_)) hipLaunchKernelGGL(k_reduce, dim3(nred), dim3(256), 0, st, part, nparts_, dst_);   \
+    if (!direct) hipLaunchKernelGGL(k_reduce, dim3(nred), dim3(256), 0, st, src_, nparts_, dst_);    \
     if (rows) {                                                                                      \
       const int rrc_ = sh.reduce(dst_, kRedW, RPGP_F64, stream);                                     \
       if (rrc_) return rrc_;                                                                         \
     }                                                                                                \
   } while (0)
+  const float *nil = nullptr;
 
   // set-up: |rhs| per column; r = rhs / |rhs|, x = p = Ap = 0, w0 = L^T r0; z0 = M^-1 r0, rz0; p0 = z0
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, rhs, rhs, L, part, N, 0, redA, fold_for(nba)));
-  CG_REDUCE(redA, nba);
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_init<TT>), dim3(nba), dim3(256), 0, st, rhs, redA, r, x, p, Ap, L, part, state, N, K,
-                                      redB, fold_for(nba)));
-  CG_REDUCE(redB, nba);
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nbb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB, part,
-                                      state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1, redB, fold_for(nbb)));
-  CG_REDUCE(redB, nbb);
-  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nbc), dim3(256), 0, st, z, p, redB, state, beta_d, N, eps, 0, 1, 0,
-                                      tolerance, 0, 0, x, x_best, (CgPoll *)nullptr));
+  if (!direct) {
+    partI = part;
+    partB[0] = partB[1] = part;
+  }
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, rhs, rhs, L, partA, N, 0));
+  CG_REDUCE(partA, redA, nba);
+  if (direct) {
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_init<TT, true>), dim3(nba), dim3(256), 0, st, rhs, redA, r, x, p, Ap, L, partI, state,
+                                        N, K, partA, nba));
+  } else {
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_init<TT, false>), dim3(nba), dim3(256), 0, st, rhs, redA, r, x, p, Ap, L, partI, state,
+                                        N, K, nil, 0));
+  }
+  CG_REDUCE(partI, redB, nba);
+  // (the set-up pass B reads only the L^T r0 sums; its `A` source must merely be valid memory)
+#define CG_PASS_B(DIR_, ...) \
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT, 1, DIR_>), dim3(nbb), dim3(256), 0, st, __VA_ARGS__))
+#define CG_PASS_C(DIR_, ...) \
+  CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT, DIR_>), dim3(nbc), dim3(256), 0, st, __VA_ARGS__))
+  if (direct) {
+    CG_PASS_B(true, p, Ap, x, r, z, L, Cinv, redA, redB, partB[1], state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1,
+              partA, nba, partI, nba);
+    CG_PASS_C(true, z, p, redB, state, beta_d, N, eps, 0, 1, 0, tolerance, 0, 0, x, x_best, (CgPoll *)nullptr, partB[1], nbb);
+  } else {
+    CG_PASS_B(false, p, Ap, x, r, z, L, Cinv, redA, redB, partB[1], state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1,
+              nil, 0, nil, 0);
+    CG_REDUCE(partB[1], redB, nbb);
+    CG_PASS_C(false, z, p, redB, state, beta_d, N, eps, 0, 1, 0, tolerance, 0, 0, x, x_best, (CgPoll *)nullptr, nil, 0);
+  }
   CG_CHECK(hipGetLastError());
 
   int it = 0;
@@ -1019,21 +1106,28 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   for (it = 0; it < n_iter; ++it) {
     int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, part, N, K, redA, fold_for(nba)));
-    CG_REDUCE(redA, nba);
+    float *pb_new = partB[it & 1], *pb_old = partB[(it & 1) ^ 1];
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, partA, N, K));
+    CG_REDUCE(partA, redA, nba);
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_b<TT>), dim3(nbb), dim3(256), 0, st, p, Ap, x, r, z, L, Cinv, redA, redB,
-                                        part, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2, eps,
-                                        stop_after, it & 1, 0, redB, fold_for(nbb)));
-    CG_REDUCE(redB, nbb);
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_c<TT>), dim3(nbc), dim3(256), 0, st, zsrc, p, redB, state,
-                                        beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
-                                        it + 1, stagnation_window, x, x_best,
-                                        check_now ? g_poll.host_dev + (it % kPollRing) : (CgPoll *)nullptr));
+    CgPoll *poll_dst = check_now ? g_poll.host_dev + (it % kPollRing) : (CgPoll *)nullptr;
+    if (check_now) *reinterpret_cast<volatile int *>(&hpoll[it % kPollRing].seq) = 0;      // (stale stamp of an earlier solve)
+    if (direct) {
+      CG_PASS_B(true, p, Ap, x, r, z, L, Cinv, redA, redB, pb_new, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2,
+                eps, stop_after, it & 1, 0, partA, nba, pb_old, nbb);
+      CG_PASS_C(true, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
+                it + 1, stagnation_window, x, x_best, poll_dst, pb_new, nbb);
+    } else {
+      CG_PASS_B(false, p, Ap, x, r, z, L, Cinv, redA, redB, pb_new, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2,
+                eps, stop_after, it & 1, 0, nil, 0, nil, 0);
+      CG_REDUCE(pb_new, redB, nbb);
+      CG_PASS_C(false, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
+                it + 1, stagnation_window, x, x_best, poll_dst, nil, 0);
+    }
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
-      CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
+      if (!wait_record(&hpoll[polled_it % kPollRing], polled_it + 1)) CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
       last = hpoll[polled_it % kPollRing];
       polled_it = -1;
       if (last.done) {
@@ -1047,21 +1141,183 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     }
   }
 #undef CG_REDUCE
-  if (N > 0) hipLaunchKernelGGL(k_unnormalise, dim3(nbc), dim3(256), 0, st, x, x_best, state, N, T);
-  CG_CHECK(hipMemcpyAsync(&hpoll[kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
-  CG_CHECK(hipStreamSynchronize(st));
+#undef CG_PASS_B
+#undef CG_PASS_C
+  // x *= |rhs| (or the saved best iterate); the final poll record and the coefficient histories are already in pinned host
+  // memory when the ONE synchronisation behind the solve returns
+  // (the host needs the record and the histories, not x: what the caller enqueues next is ordered behind k_unnormalise on the
+  //  stream, so the solve returns as soon as the record lands — every earlier kernel's pinned writes are complete by then)
+  if (N > 0) {
+    *reinterpret_cast<volatile int *>(&hpoll[kPollRing].seq) = 0;
+    hipLaunchKernelGGL(k_unnormalise, dim3(nbc), dim3(256), 0, st, x, x_best, state, N, T, g_poll.host_dev + kPollRing);
+    CG_CHECK(hipGetLastError());
+    if (!wait_record(&hpoll[kPollRing], 1)) CG_CHECK(hipStreamSynchronize(st));
+  } else {
+    CG_CHECK(hipMemcpyAsync(&hpoll[kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
+    CG_CHECK(hipStreamSynchronize(st));
+  }
   last = hpoll[kPollRing];
   const int iters_done = last.done ? last.iters : it;
   const int nh = iters_done < hist_len ? iters_done : hist_len;
-  if (nh > 0) {   // history rows are kMaxT wide on the device, [hist_len][kMaxT] on the host
-    CG_CHECK(hipMemcpyAsync(alpha_hist_host, alpha_d, (size_t)nh * kMaxT * sizeof(float), hipMemcpyDeviceToHost, st));
-    CG_CHECK(hipMemcpyAsync(beta_hist_host, beta_d, (size_t)nh * kMaxT * sizeof(float), hipMemcpyDeviceToHost, st));
-    CG_CHECK(hipStreamSynchronize(st));
+  if (nh > 0) {   // history rows are kMaxT wide, [hist_len][kMaxT] on the caller's side
+    memcpy(alpha_hist_host, g_poll.hist, (size_t)nh * kMaxT * sizeof(float));
+    memcpy(beta_hist_host, g_poll.hist + kHistFloats, (size_t)nh * kMaxT * sizeof(float));
   }
   if (iterations_host) *iterations_host = iters_done;
   if (last.done != 1 && last.snap_cur < last.mean_resid) last.mean_resid = last.snap_cur;   // the saved iterate was returned
   if (mean_resid_host) *mean_resid_host = last.mean_resid;
   if (last.done == 2 || last.mean_resid != last.mean_resid) return RPGP_ENUMERIC;
+  return 0;
+}
+
+// ---- stochastic Lanczos quadrature from the coefficient histories (host arithmetic) -----------------------------------------
+// log|A| ~ (n / p) sum_probes sum_m (Q[0][m])^2 log(lambda_m) over the Lanczos tridiagonals the CG coefficients define
+// (GPyTorch's linear_cg bookkeeping):
+//   T[k][k] = 1 / alpha_k + beta_{k-1} / alpha_{k-1},   T[k][k+1] = sqrt(beta_k) / alpha_k,
+// a masked alpha (|alpha| <= 1e-30: converged column) counts as reciprocal 1 — the trailing block it decouples carries no
+// weight.  Eigenvalues and the FIRST components of the eigenvectors by the implicit-shift QL iteration on (diag, off-diag),
+// rotating only a first-row vector.  One probe's iteration is a chain of dependent divisions and square roots (~100 cycles
+// per plane rotation, ~500 rotations for 20 Lanczos steps); the probes are independent, so they advance ROUND-ROBIN, one
+// rotation each (QlProbe below): the out-of-order core overlaps the chains and ten 20 x 20 problems take ~30 us instead of
+// the ~150 us of one after the other (or of a batched LAPACK call through torch, plus ~100 us of numpy indexing to lay the
+// matrices out) — per optimiser step, on the host-bound stretch between the solve and the backward pass.
+}  // extern "C"
+
+namespace {
+
+struct QlProbe {
+  double *d, *e, *z;      // diagonal, off-diagonal (e[k] couples k and k + 1), first row of the eigenvector matrix
+  int m, l, mm, i, sweeps, phase;      // phase 0: deflation test / sweep set-up, 1: inside a sweep, 2: finished, 3: failed
+  double g, sn, cs, pp;
+};
+
+// one unit of work: the set-up of a sweep, or one plane rotation of it
+inline void ql_step(QlProbe &q) {
+  double *d = q.d, *e = q.e, *z = q.z;
+  if (q.phase == 0) {
+    const int m = q.m;
+    for (;;) {
+      if (q.l >= m) {
+        q.phase = 2;
+        return;
+      }
+      int mm = q.l;
+      for (; mm < m - 1; ++mm) {
+        const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+        if (fabs(e[mm]) <= 2.3e-16 * dd) break;
+      }
+      if (mm != q.l) {
+        q.mm = mm;
+        break;
+      }
+      ++q.l;                 // d[l] is an eigenvalue
+      q.sweeps = 0;
+    }
+    if (++q.sweeps > 80) {
+      q.phase = 3;
+      return;
+    }
+    const int l = q.l;
+    double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+    const double r = sqrt(g * g + 1.0);
+    q.g = d[q.mm] - d[l] + e[l] / (g + (g >= 0.0 ? r : -r));
+    q.sn = 1.0;
+    q.cs = 1.0;
+    q.pp = 0.0;
+    q.i = q.mm - 1;
+    q.phase = 1;
+    return;
+  }
+  const int i = q.i;
+  double f = q.sn * e[i];
+  const double b = q.cs * e[i];
+  double r = sqrt(f * f + q.g * q.g);      // (entries of a CG tridiagonal: no overflow to guard, libm's hypot is 10 x slower)
+  e[i + 1] = r;
+  if (r == 0.0) {                          // an exact zero inside the sweep: split and start over at the same l
+    d[i + 1] -= q.pp;
+    e[q.mm] = 0.0;
+    q.phase = 0;
+    return;
+  }
+  const double inv_r = 1.0 / r, sn = f * inv_r, cs = q.g * inv_r;
+  double g = d[i + 1] - q.pp;
+  r = (d[i] - g) * sn + 2.0 * cs * b;
+  const double pp = sn * r;
+  d[i + 1] = g + pp;
+  q.g = cs * r - b;
+  q.sn = sn;
+  q.cs = cs;
+  q.pp = pp;
+  f = z[i + 1];
+  z[i + 1] = sn * z[i] + cs * f;
+  z[i] = cs * z[i] - sn * f;
+  if (--q.i < q.l) {
+    d[q.l] -= pp;
+    e[q.l] = q.g;
+    e[q.mm] = 0.0;
+    q.phase = 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpgp_slq_logdet(const float *alpha_hist, const float *beta_hist, int iters, int ld, int num_probes, double n,
+                    double *logdet_out) {
+  if (!alpha_hist || !beta_hist || !logdet_out || iters <= 0 || iters > 4096 || num_probes <= 0 || num_probes > 1024 ||
+      ld < num_probes)
+    return RPGP_EINVAL;
+  const int m = iters;
+  double *buf = static_cast<double *>(malloc(sizeof(double) * 3 * (size_t)(m + 1) * num_probes));
+  QlProbe *qs = static_cast<QlProbe *>(malloc(sizeof(QlProbe) * num_probes));
+  if (!buf || !qs) {
+    free(buf);
+    free(qs);
+    return RPGP_EINVAL;
+  }
+  for (int pr = 0; pr < num_probes; ++pr) {
+    QlProbe &q = qs[pr];
+    q.d = buf + (size_t)pr * 3 * (m + 1);
+    q.e = q.d + (m + 1);
+    q.z = q.e + (m + 1);
+    double inv_prev = 1.0, beta_prev = 0.0;
+    for (int k = 0; k < m; ++k) {
+      const double a = alpha_hist[(size_t)k * ld + pr], b = beta_hist[(size_t)k * ld + pr];
+      const double inv_a = fabs(a) > 1e-30 ? 1.0 / a : 1.0;
+      q.d[k] = k == 0 ? inv_a : inv_a + beta_prev * inv_prev;
+      q.e[k] = sqrt(b > 0.0 ? b : 0.0) * inv_a;          // couples k and k + 1 (the last one is unused)
+      inv_prev = inv_a;
+      beta_prev = b;
+      q.z[k] = k == 0 ? 1.0 : 0.0;
+    }
+    q.e[m - 1] = 0.0;
+    q.m = m;
+    q.l = 0;
+    q.sweeps = 0;
+    q.phase = 0;
+  }
+  for (bool active = true; active;) {
+    active = false;
+    for (int pr = 0; pr < num_probes; ++pr)
+      if (qs[pr].phase < 2) {
+        ql_step(qs[pr]);
+        active = true;
+      }
+  }
+  double total = 0.0;
+  int rc = 0;
+  for (int pr = 0; pr < num_probes; ++pr) {
+    const QlProbe &q = qs[pr];
+    if (q.phase == 3) rc = RPGP_ENUMERIC;
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k) acc += q.z[k] * q.z[k] * log(q.d[k] > 1e-30 ? q.d[k] : 1e-30);
+    total += acc;
+  }
+  free(buf);
+  free(qs);
+  if (rc) return rc;
+  *logdet_out = n * total / num_probes;
   return 0;
 }
 

@@ -64,7 +64,11 @@ def psd_safe_cholesky(A, max_tries=4, jitter=None):
 
 
 def slq_logdet(t_mat, n):
-    """log|A| estimate from Lanczos tridiagonals of unit-norm probes:  (n/p) sum_p sum_m Q_p[0,m]^2 log lambda_pm."""
+    """log|A| estimate from Lanczos tridiagonals of unit-norm probes:  (n/p) sum_p sum_m Q_p[0,m]^2 log lambda_pm.
+    `t_mat`: the matrices [p x m x m], or the native executor's coefficient history (linear_cg.LanczosHistory: the
+    quadrature then runs in the library, rpgp_slq_logdet)."""
+    if hasattr(t_mat, "slq_logdet"):
+        return t_mat.slq_logdet(n)
     evals, evecs = torch.linalg.eigh(t_mat.double())
     evals = evals.clamp_min(1e-30)
     w = evecs[:, 0, :] ** 2
@@ -133,14 +137,14 @@ class InvQuadLogDet(torch.autograd.Function):
                                   tolerance=settings.cg_tolerance.value(),
                                   max_iter=settings.max_cg_iterations.value(),
                                   max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),
-                                  preconditioner=pre)
+                                  preconditioner=pre, lanczos="history")
         alpha = solves[:, num_probes:]
         inv_quad = (r * alpha).sum()
         if settings.skip_logdet_forward.on():
             logdet = torch.zeros((), dtype=Z.dtype, device=Z.device)
         else:
-            # log|M| of the preconditioner is read AFTER the solve (whose end is a synchronisation anyway: a short copy, no
-            # idle device in front of it); the value goes back as a fill, not as a host-to-device copy
+            # log|M| of the preconditioner is read AFTER the solve (its value went to pinned host memory when the preconditioner
+            # was built: no copy, no synchronisation here); the value goes back as a fill, not as a host-to-device copy
             logdet_correction = pre.logdet() if pre is not None else 0.0
             logdet = torch.full((), float(slq_logdet(t_mat, N)) + logdet_correction, dtype=Z.dtype, device=Z.device)
         ctx.mode = "cg"

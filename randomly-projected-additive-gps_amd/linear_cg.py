@@ -48,8 +48,24 @@ def _tridiag_from_history(alpha, beta, n_tridiag, dtype, device):
     return torch.from_numpy(t)
 
 
+class LanczosHistory:
+    """The CG coefficient history of the native executor ([iters x 16] float32 host arrays, the first `n_tridiag` columns
+    are the probe columns): what `linear_cg(..., lanczos="history")` returns in place of the tridiagonal matrices, for callers
+    that only want the quadrature (the optimiser step: `slq_logdet` runs in the library, no matrices are laid out)."""
+
+    def __init__(self, alpha, beta, n_tridiag, dtype, device):
+        self.alpha, self.beta, self.n_tridiag, self.dtype, self.device = alpha, beta, n_tridiag, dtype, device
+
+    def tridiagonals(self):
+        return _tridiag_from_history(self.alpha, self.beta, self.n_tridiag, self.dtype, self.device)
+
+    def slq_logdet(self, n):
+        from . import backend as _backend
+        return _backend.get_backend().slq_logdet_history(self.alpha, self.beta, self.n_tridiag, n)
+
+
 def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner, check_every,
-                      min_iter=10, row_sharded=False):
+                      min_iter=10, row_sharded=False, lanczos="tridiag"):
     """Route the solve through the native mBCG executor (rpgp_mbcg_solve) when everything it needs is available;
     returns None to fall through to the torch-op loop.  A sharded operator (`native_sharding()`) runs the same
     executor: its all-reduces are issued on the launch stream by the reducer's hook, the convergence flag stays on the
@@ -100,13 +116,14 @@ def _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag
             "number of CG iterations by running code in a rpgp_amd.settings.max_cg_iterations(value) context."
             .format(iters, mres, tolerance), NumericalWarning)
     if n_tridiag:
-        return x, _tridiag_from_history(ah, bh, n_tridiag, rhs.dtype, rhs.device)
+        hist_ = LanczosHistory(ah, bh, n_tridiag, rhs.dtype, rhs.device)
+        return x, (hist_ if lanczos == "history" else hist_.tridiagonals())
     return x
 
 
 def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_updating_after=1e-10, max_iter=None,
               max_tridiag_iter=None, initial_guess=None, preconditioner=None, check_every=1, operator=None,
-              reduce=None, global_size=None, min_iter=10):
+              reduce=None, global_size=None, min_iter=10, lanczos="tridiag"):
     """Solve A X = rhs for symmetric positive definite A given as `matmul_closure`.
 
     rhs: (N x T).  Returns X, or (X, tridiag [n_tridiag x k x k]) when n_tridiag > 0.
@@ -115,6 +132,8 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
     `reduce` (optional): in-place SUM all-reduce of a small tensor.  With it the vectors are a rank's LOCAL rows of a
     row-sharded system (operators.RowShardedSKIOperator): every column inner product / norm is all-reduced, so all ranks
     take identical steps and stop at the same iteration; `global_size` is the global N (iteration cap).
+    `lanczos="history"`: the native executor's coefficient history (LanczosHistory) instead of the tridiagonal matrices
+    (the torch-op loop below always returns matrices).
     """
     if rhs.dim() == 1:
         squeeze = True
@@ -129,7 +148,7 @@ def linear_cg(matmul_closure, rhs, n_tridiag=0, tolerance=None, eps=None, stop_u
         max_tridiag_iter = settings.max_lanczos_quadrature_iterations.value()
     if initial_guess is None and rhs.dim() == 2:
         res = _native_linear_cg(operator, rhs, n_tridiag, tolerance, max_iter, max_tridiag_iter, preconditioner,
-                                check_every, min_iter=min_iter, row_sharded=reduce is not None)
+                                check_every, min_iter=min_iter, row_sharded=reduce is not None, lanczos=lanczos)
         if res is not None:
             if squeeze:
                 return (res[0].squeeze(-1), res[1]) if n_tridiag else res.squeeze(-1)

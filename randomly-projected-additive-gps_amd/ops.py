@@ -1068,4 +1068,16 @@ def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_ev
         raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
     _lib.check(rc, "rpgp_mbcg_solve")
     h = min(hist_len, iters.value)
-    return x, ah[:h, :T].copy(), bh[:h, :T].copy(), iters.value, mres.value
+    return x, ah[:h, :T], bh[:h, :T], iters.value, mres.value        # (views of the [hist x 16] landing arrays)
+
+
+def slq_logdet_history(alpha_hist, beta_hist, num_probes, n):
+    """log|A| estimate from the coefficient histories `mbcg_solve` returns ([iters x 16] float32 host arrays; the first
+    `num_probes` columns are unit-norm probes): rpgp_slq_logdet (host arithmetic in the library)."""
+    import ctypes
+    lib = _lib.load()
+    out = ctypes.c_double(0.0)
+    _lib.check(lib.rpgp_slq_logdet(alpha_hist.ctypes.data, beta_hist.ctypes.data, int(alpha_hist.shape[0]),
+                                   int(alpha_hist.strides[0] // 4), int(num_probes), float(n), ctypes.byref(out)),
+               "rpgp_slq_logdet")
+    return out.value

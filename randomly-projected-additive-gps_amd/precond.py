@@ -70,10 +70,17 @@ class WoodburyPreconditioner:
         self._be = be if (L.dtype == torch.float32 and 0 < k <= 64 and hasattr(be, "gram_f64") and on_device) else None
         self._L64c = None
         cap = self._be.gram_f64(L, L) if self._be is not None else gram64(self._L64, self._L64)
-        self._cinv = self._logdet_cap = None
+        self._cinv = self._logdet_cap = self._logdet_host = None
         if self._be is not None and hasattr(self._be, "woodbury_setup"):
             # Cholesky factor, inverse and log-determinant of the capacitance matrix in one launch, no synchronisation
             self._cap_chol, self._cinv, self._logdet_cap = self._be.woodbury_setup(cap, self.noise)
+            if self._logdet_cap.is_cuda:
+                # the log-determinant starts its way to (pinned) host memory NOW: by the time somebody asks for it a solve has
+                # synchronised the stream and the read is free (a `float()` of the device scalar is a copy + a synchronisation)
+                self._logdet_host = torch.empty(self._logdet_cap.shape, dtype=self._logdet_cap.dtype, pin_memory=True)
+                self._logdet_host.copy_(self._logdet_cap, non_blocking=True)
+                self._logdet_ev = torch.cuda.Event()
+                self._logdet_ev.record()
         else:
             cap.diagonal().add_(self.noise)
             self._cap_chol = torch.linalg.cholesky(cap)               # k x k, float64 for a stable capacitance solve
@@ -121,7 +128,12 @@ class WoodburyPreconditioner:
 
     def logdet(self):
         """log|M| = log|noise I_k + L^T L| + (N - k) log noise."""
-        if self._logdet_cap is not None:
+        if self._logdet_host is not None:
+            self._logdet_ev.synchronize()                             # (long complete behind any solve)
+            ld_cap = float(self._logdet_host)
+            if ld_cap != ld_cap:
+                raise RuntimeError("the preconditioner's capacitance matrix is not positive definite")
+        elif self._logdet_cap is not None:
             ld_cap = float(self._logdet_cap)                          # (the only synchronisation of the preconditioner)
             if ld_cap != ld_cap:
                 raise RuntimeError("the preconditioner's capacitance matrix is not positive definite")

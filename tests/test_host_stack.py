@@ -626,3 +626,35 @@ def test_gpytorch_layout_state_dict_round_trip():
     load_gpytorch_state_dict(b, sd)
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.allclose(va.double(), vb.double()), ka
+
+
+def test_library_slq_matches_eigendecomposition():
+    """rpgp_slq_logdet (host arithmetic inside the library: implicit-shift QL on the Lanczos tridiagonals the CG coefficients
+    define) against the eigendecomposition of the same matrices, incl. a column whose late alphas are masked to zero."""
+    from rpgp_amd import ops, linear_cg as lcg
+    from rpgp_amd.inv_quad_logdet import slq_logdet
+    rng = np.random.default_rng(0)
+    n, m, p = 300, 25, 10
+    A = rng.standard_normal((n, n))
+    A = A @ A.T / n + 0.5 * np.eye(n)
+    B = rng.standard_normal((n, p))
+    B /= np.linalg.norm(B, axis=0)
+    X, R, P = np.zeros_like(B), B.copy(), B.copy()
+    rz = (R * R).sum(0)
+    ah, bh = np.zeros((m, 16), np.float32), np.zeros((m, 16), np.float32)
+    for k in range(m):
+        Ap = A @ P
+        a = rz / (P * Ap).sum(0)
+        X += a * P
+        R -= a * Ap
+        rzn = (R * R).sum(0)
+        ah[k, :p], bh[k, :p] = a, rzn / rz
+        P = R + (rzn / rz) * P
+        rz = rzn
+    ah[20:, 3] = 0.0
+    ref = float(slq_logdet(lcg._tridiag_from_history(ah[:, :p], bh[:, :p], p, torch.float32, "cpu"), n))
+    got = ops.slq_logdet_history(ah[:, :p], bh[:, :p], p, n)
+    assert abs(got - ref) < 1e-12 * abs(ref)
+    assert abs(got - np.linalg.slogdet(A)[1]) < 0.2 * abs(ref)        # (and it IS a log-determinant estimate)
+    hist = lcg.LanczosHistory(ah[:, :p], bh[:, :p], p, torch.float32, "cpu")
+    assert abs(float(slq_logdet(hist, n)) - ref) < 1e-12 * abs(ref)

@@ -226,3 +226,29 @@ def test_best_iterate_is_returned_when_fp32_cg_breaks_down(gpu_device):
         # (the recurrence residual may keep shrinking below the tolerance while the TRUE residual floors near
         # eps * cond: whether a non-convergence warning fires is not asserted, the quality of the returned iterate is)
         assert true_res < 0.05
+
+
+def test_history_quadrature_matches_tridiagonal_eigendecomposition(gpu_device):
+    """`linear_cg(..., lanczos="history")`: the library's quadrature on the executor's coefficient history against torch's
+    eigendecomposition of the tridiagonal matrices of the same history; the preconditioner's log-determinant through pinned
+    host memory against the device scalar."""
+    from rpgp_amd import linear_cg as lcg, settings
+    from rpgp_amd.inv_quad_logdet import slq_logdet
+    from rpgp_amd.operators import AddedDiagOperator, AdditiveRPOperator
+    from rpgp_amd.precond import build_preconditioner
+    torch.manual_seed(3)
+    N, J = 3000, 20
+    Z = (torch.randn(N, J) * 0.7).to(gpu_device)
+    op = AdditiveRPOperator(Z, None, outputscale=torch.tensor(0.9, device=gpu_device))
+    khat = AddedDiagOperator(op, torch.tensor(0.2, device=gpu_device))
+    pre = build_preconditioner(op, 0.2, settings)
+    probes = torch.randn(N, 10, device=gpu_device)
+    rhs = torch.cat([probes / probes.norm(dim=0, keepdim=True), torch.randn(N, 1, device=gpu_device)], dim=1)
+    x, hist = lcg.linear_cg(khat._matmul, rhs, n_tridiag=10, tolerance=1e-4, max_iter=500, preconditioner=pre,
+                            operator=khat, lanczos="history")
+    host = float(slq_logdet(hist, N))
+    eig = float(slq_logdet(hist.tridiagonals(), N))
+    assert abs(host - eig) < 1e-10 * abs(eig)
+    import math
+    ld = pre.logdet()
+    assert abs(ld - (float(pre._logdet_cap) + (N - pre.k) * math.log(0.2))) < 1e-9 * abs(ld)

@@ -27,5 +27,12 @@ print("per step: %d launches, %.1f us kernel time, %.1f us idle gaps, span %.1f 
 print("%-110s %8s %10s %12s" % ("kernel", "n/step", "us/step", "gap-before us/step"))
 for k,v in sorted(agg.items(), key=lambda kv:-(kv[1][1]+kv[1][2]))[:40]:
     print("%-110s %8.1f %10.1f %12.1f" % (k, v[0]/steps, v[1]/steps, v[2]/steps))
+# the last step as a timeline: gap before, duration, kernel
+n1=int(round(len(sel)/steps))
+with open("$R/gpurun_out/${L}_${C}_last_step_timeline.txt","w") as f:
+    pe=int(sel[-n1-1]["End_Timestamp"])
+    for r in sel[-n1:]:
+        s,e=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
+        f.write("%8.1f %8.1f  %s\n" % (max(0,(s-pe))/1e3,(e-s)/1e3,nm(r)[:90])); pe=max(pe,e)
 PY
 rm -rf $R/gpurun_out/${L}_trace_$C

@@ -5,7 +5,7 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rpgp_amd import settings, linear_cg as lcg
-from rpgp_amd.training import create_exact_gp
+from rpgp_amd.training import create_exact_gp, make_optimizer
 from rpgp_amd.models import ExactMarginalLogLikelihood
 
 
@@ -24,7 +24,7 @@ def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol, ski=False, fu
                                  ski_options={"grid_size": 1024, "num_dims": 1} if ski else None)
     model = model.to(dev)
     mll = ExactMarginalLogLikelihood(lik, model)
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.1)
+    opt = make_optimizer(torch.optim.Adam, [p for p in model.parameters() if p.requires_grad], 0.1)
     res = {"config": name, "N": N, "d": d, "J": J, "N_test": ntest, "ski": ski}
     with settings.cg_tolerance(cg_tol), settings.eval_cg_tolerance(eval_tol), settings.max_cg_iterations(10000):
         model.train()

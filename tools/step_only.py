@@ -3,7 +3,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rpgp_amd import settings
-from rpgp_amd.training import create_exact_gp
+from rpgp_amd.training import create_exact_gp, make_optimizer
 from rpgp_amd.models import ExactMarginalLogLikelihood
 SHAPES = {"C2": (7372, 8, 20, False, False), "C3": (14939, 18, 20, True, False), "C4": (50000, 20, 20, False, False),
           "C5": (391386, 3, 3, True, True)}
@@ -19,7 +19,7 @@ np.random.seed(0)
 model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False, prescale=True,
                              space_proj=sp, ski=ski, ski_options={"grid_size": 1024, "num_dims": 1} if ski else None)
 model = model.to(dev); mll = ExactMarginalLogLikelihood(lik, model)
-opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.0)      # lr 0: every step is the same problem
+opt = make_optimizer(torch.optim.Adam, [p for p in model.parameters() if p.requires_grad], 0.0)      # lr 0: every step is the same problem
 with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
     model.train()
     for it in range(warm):

@@ -52,6 +52,11 @@ class HipBackend:
     make_sum_operator_desc = staticmethod(ops.make_sum_operator_desc)
     mbcg_solve = staticmethod(ops.mbcg_solve)
     slq_logdet_history = staticmethod(ops.slq_logdet_history)
+    step_hyper = staticmethod(ops.step_hyper)
+    step_probes = staticmethod(ops.step_probes)
+    step_value = staticmethod(ops.step_value)
+    step_lr = staticmethod(ops.step_lr)
+    step_hyper_backward = staticmethod(ops.step_hyper_backward)
 
 
 _backend = HipBackend()

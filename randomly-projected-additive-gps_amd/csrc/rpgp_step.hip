@@ -1,0 +1,349 @@
+// rpgp_step.hip — the small kernels AROUND the solve of one optimiser step of the flagship model.
+//
+// One step of `-mll(model(X), y); loss.backward(); optimizer.step()` (fitting/optimizing.py:65-76) on the model every served
+// `additive_rp` specification builds (training_routines.py:131-189, 325-410; models.py:10-20) is, outside the CG solve and the
+// derivative sweep, a chain of ~90 one-to-four-microsecond element-wise launches on d + 3 scalars and a handful of N x 11 blocks:
+// softplus and its derivative, the lengthscale division, the probe draw z = L e1 + sigma e2 and its normalisation, the
+// concatenations that lay out [probes | y - c] and the two sides of the bilinear derivative, the reductions r.alpha,
+// sum(L * R), sum(alpha), the chain rule back to the raw parameters.  The device needs ~0.2 ms for them, the host ~0.9 ms to
+// issue them (profiles/r4_step_C2_step_gaps.txt): the step is HOST-bound there.  Each entry point below is one launch (two for
+// the probes) for one such stretch; the arithmetic is the one the torch operations perform (fp32, the same formulas), the
+// reductions are fixed-order (bitwise reproducible).  rpgp_amd/fused_mll.py is the caller.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/rpgp.h"
+
+namespace {
+
+#define STEP_CHECK(expr)                         \
+  do {                                           \
+    hipError_t _e = (expr);                      \
+    if (_e != hipSuccess) return (int)_e;        \
+  } while (0)
+
+// F.softplus(x) (beta 1, threshold 20) and its derivative
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// pinned landing zone of the three scalars the C-ABI kernels take by value (one per host thread)
+struct HyperHost {
+  float *host = nullptr, *dev = nullptr;       // [0] outputscale, [1] noise, [2] mean, [3] stamp
+  bool ok = false;
+  int init() {
+    if (ok) return 0;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), 64, hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) return (int)e;
+    e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0);
+    if (e != hipSuccess) return (int)e;
+    ok = true;
+    return 0;
+  }
+};
+thread_local HyperHost g_hyper;
+
+// ---- hyper-parameters -> what the step needs ---------------------------------------------------------------------------------
+// dev_out: [0] outputscale  [1] noise  [2] mean  [3] sigmoid(raw_os)  [4] sigmoid(raw_noise)  [8 ..) ls[n_ls]  then sigmoid(raw_ls)[n_ls]
+// Peff[i][j] = W[j][i] / ls[i] (prescale, n_ls = d) | / ls[j] (n_ls = J) | / ls[0] (n_ls = 1)       (W: the Linear weight, J x d)
+__global__ __launch_bounds__(256) void k_step_hyper(const float *__restrict__ raw_ls, int n_ls, const float *__restrict__ raw_os,
+                                                    const float *__restrict__ raw_noise, const float *__restrict__ mean,
+                                                    const float *__restrict__ W, int d, int J, int prescale, float min_noise,
+                                                    float *__restrict__ Peff, float *__restrict__ dev_out,
+                                                    float *__restrict__ host_out, float stamp) {
+  __shared__ float sls[1024];
+  for (int i = threadIdx.x; i < n_ls; i += 256) {
+    const float x = raw_ls[i];
+    const float l = softplus_f(x);
+    sls[i] = l;
+    dev_out[8 + i] = l;
+    dev_out[8 + n_ls + i] = sigmoid_f(x);
+  }
+  if (threadIdx.x == 0) {
+    const float os = softplus_f(raw_os[0]), nz = softplus_f(raw_noise[0]) + min_noise, mu = mean[0];
+    dev_out[0] = os;
+    dev_out[1] = nz;
+    dev_out[2] = mu;
+    dev_out[3] = sigmoid_f(raw_os[0]);
+    dev_out[4] = sigmoid_f(raw_noise[0]);
+    host_out[0] = os;
+    host_out[1] = nz;
+    host_out[2] = mu;
+    __threadfence_system();
+    *reinterpret_cast<volatile float *>(host_out + 3) = stamp;
+    __threadfence_system();
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < d * J; e += 256) {
+    const int i = e / J, j = e - i * J;
+    const float l = n_ls == 1 ? sls[0] : (prescale ? sls[i] : sls[j]);
+    Peff[e] = W[(size_t)j * d + i] / l;
+  }
+}
+
+// ---- probes z = L e1 + sqrt(sigma^2) e2 (WoodburyPreconditioner.sample), their column norms, [z / |z| | y - c] ---------------
+constexpr int kMaxP = 16, kMaxKp = 64, kProbeBlocks = 512;
+// element (row, c) per thread, `rows_per_block` rows per block iteration; partial column sums of squares per block (fixed order)
+__global__ __launch_bounds__(256) void k_step_probes(const float *__restrict__ L, int k, const float *__restrict__ e1,
+                                                     const float *__restrict__ e2, float sqrt_noise, long long N, int p,
+                                                     float *__restrict__ probes, float *__restrict__ part) {
+  __shared__ float se1[kMaxKp * kMaxP];
+  __shared__ float sq[256];
+  for (int e = threadIdx.x; e < k * p; e += 256) se1[e] = e1[e];
+  __syncthreads();
+  const int rpb = 256 / p;                              // rows per block iteration
+  const int rr = threadIdx.x / p, c = threadIdx.x - rr * p;
+  const bool lane_ok = rr < rpb;
+  float acc = 0.f;                                      // (thread c < p accumulates column c over the block's iterations)
+  for (long long r0 = (long long)blockIdx.x * rpb; r0 < N; r0 += (long long)gridDim.x * rpb) {
+    const long long row = r0 + rr;
+    float v = 0.f;
+    if (lane_ok && row < N) {
+      float s = 0.f;
+      for (int kk = 0; kk < k; ++kk) s = __builtin_fmaf(L[row * k + kk], se1[kk * p + c], s);
+      v = s + sqrt_noise * e2[row * p + c];
+      probes[row * p + c] = v;
+    }
+    __syncthreads();
+    sq[threadIdx.x] = v * v;
+    __syncthreads();
+    if (threadIdx.x < p) {
+      float s = 0.f;
+      for (int q = 0; q < rpb; ++q) s += sq[q * p + threadIdx.x];
+      acc += s;
+    }
+  }
+  if (threadIdx.x < p) part[(size_t)blockIdx.x * kMaxP + threadIdx.x] = acc;
+}
+
+// norms from the partials (every block adds them up itself, fixed order); full_rhs = [probes / |probes| | y - mean]
+__global__ __launch_bounds__(256) void k_step_rhs(const float *__restrict__ probes, const float *__restrict__ part, int nparts,
+                                                  const float *__restrict__ y, const float *__restrict__ mean_dev, long long N,
+                                                  int p, float *__restrict__ full_rhs, float *__restrict__ norms) {
+  __shared__ float snorm[kMaxP];
+  if (threadIdx.x < p) {
+    double s = 0.0;
+    for (int q = 0; q < nparts; ++q) s += (double)part[(size_t)q * kMaxP + threadIdx.x];
+    const float nrm = sqrtf((float)s);
+    snorm[threadIdx.x] = nrm;
+    if (blockIdx.x == 0) norms[threadIdx.x] = nrm;
+  }
+  __syncthreads();
+  const float mu = mean_dev[0];
+  const int T = p + 1;
+  const long long total = N * T;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long row = e / T;
+    const int c = (int)(e - row * T);
+    full_rhs[e] = c < p ? probes[row * p + c] / snorm[c] : y[row] - mu;
+  }
+}
+
+// ---- value of the objective ------------------------------------------------------------------------------------------------
+// inv_quad = sum_i rhs[i][col] * sol[i][col];  out[0] = (inv_quad + logdet) * c1 + c2,  out[1] = inv_quad     (one workgroup,
+// fixed order: thread t adds rows t, t + 1024, ...; the 1024 sums are added by a tree)
+__global__ __launch_bounds__(1024) void k_step_value(const float *__restrict__ rhs, const float *__restrict__ sol, long long N,
+                                                     int T, int col, double logdet, double c1, double c2,
+                                                     float *__restrict__ out) {
+  __shared__ double sh[1024];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < N; i += 1024) s += (double)rhs[i * T + col] * (double)sol[i * T + col];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = (float)((sh[0] + logdet) * c1 + c2);
+    out[1] = (float)sh[0];
+  }
+}
+
+// ---- the two sides of the bilinear derivative ---------------------------------------------------------------------------------
+// left = [Khat^-1 z_p * (g_ld / p) | -g_iq alpha],  right = [M^-1 z_p | alpha]   with Khat^-1 z_p = sol[:, c] * norms[c];
+// g_iq = g_ld = g[0] * gscale (the incoming gradient is a device scalar).  Per block: partial sum(left * right), sum(alpha).
+constexpr int kLrBlocks = 512;
+__global__ __launch_bounds__(256) void k_step_lr(const float *__restrict__ sol, const float *__restrict__ norms,
+                                                 const float *__restrict__ pre_probes, const float *__restrict__ g,
+                                                 float gscale, long long N, int p, float *__restrict__ left,
+                                                 float *__restrict__ right, float *__restrict__ part) {
+  __shared__ float snorm[kMaxP];
+  __shared__ float s1[256], s2[256];
+  if (threadIdx.x < p) snorm[threadIdx.x] = norms[threadIdx.x];
+  __syncthreads();
+  const float gq = g[0] * gscale;
+  const float gp = gq / (float)p;
+  const int T = p + 1;
+  const long long total = N * T;
+  float a1 = 0.f, a2 = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long row = e / T;
+    const int c = (int)(e - row * T);
+    const float sv = sol[e];
+    float l, r;
+    if (c < p) {
+      l = sv * snorm[c] * gp;
+      r = pre_probes[row * p + c];
+    } else {
+      l = -gq * sv;
+      r = sv;
+      a2 += sv;
+    }
+    left[e] = l;
+    right[e] = r;
+    a1 = __builtin_fmaf(l, r, a1);
+  }
+  s1[threadIdx.x] = a1;
+  s2[threadIdx.x] = a2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      s1[threadIdx.x] += s1[threadIdx.x + w];
+      s2[threadIdx.x] += s2[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = s1[0];
+    part[2 * blockIdx.x + 1] = s2[0];
+  }
+}
+
+// ---- chain rule back to the raw parameters -------------------------------------------------------------------------------------
+// dPeff: d x J (gradient w.r.t. Peff = P / l);  g_l = -sum(dPeff * P) / l^2 over the row (prescale) / column / everything;
+// g_raw_ls = g_l sigmoid(raw_ls);  g_raw_os = gs sigmoid(raw_os);  g_raw_noise = (gn + g[0] dlp_over_n) sigmoid(raw_noise) with
+// gn = sum of the partials;  g_mean = -2 g_iq sum(alpha).   hyp = the dev_out block of k_step_hyper.
+__global__ __launch_bounds__(256) void k_step_hyper_backward(const float *__restrict__ dPeff, const float *__restrict__ W, int d,
+                                                             int J, int n_ls, int prescale, float zfac,
+                                                             const float *__restrict__ hyp, const float *__restrict__ gs,
+                                                             const float *__restrict__ part, int nparts,
+                                                             const float *__restrict__ g, float gscale, float dlp_over_n,
+                                                             float *__restrict__ g_raw_ls, float *__restrict__ g_raw_os,
+                                                             float *__restrict__ g_raw_noise, float *__restrict__ g_mean) {
+  const float *ls = hyp + 8, *sig_ls = hyp + 8 + n_ls;
+  if (n_ls > 1) {
+    for (int i = threadIdx.x; i < n_ls; i += 256) {
+      float s = 0.f;
+      if (prescale) {
+        for (int j = 0; j < J; ++j) s = __builtin_fmaf(dPeff[(size_t)i * J + j], W[(size_t)j * d + i], s);
+      } else {
+        for (int r = 0; r < d; ++r) s = __builtin_fmaf(dPeff[(size_t)r * J + i], W[(size_t)i * d + r], s);
+      }
+      g_raw_ls[i] = -(s * zfac) / (ls[i] * ls[i]) * sig_ls[i];
+    }
+  } else if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int e = 0; e < d * J; ++e) {
+      const int i = e / J, j = e - i * J;
+      s = __builtin_fmaf(dPeff[e], W[(size_t)j * d + i], s);
+    }
+    g_raw_ls[0] = -(s * zfac) / (ls[0] * ls[0]) * sig_ls[0];
+  }
+  if (threadIdx.x == 32) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < nparts; ++q) {
+      a += (double)part[2 * q];
+      b += (double)part[2 * q + 1];
+    }
+    const float gq = g[0] * gscale;
+    g_raw_os[0] = gs[0] * hyp[3];
+    g_raw_noise[0] = ((float)a + g[0] * dlp_over_n) * hyp[4];
+    g_mean[0] = -(2.f * gq * (float)b);
+  }
+}
+
+inline bool spin_stamp(const volatile float *p, float stamp) {
+  for (long spins = 0; spins < 40000000L; ++spins) {
+    if (*p == stamp) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return true;
+    }
+    __builtin_ia32_pause();
+  }
+  return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpgp_step_hyper(const float *raw_ls, int n_ls, const float *raw_os, const float *raw_noise, const float *mean,
+                    const float *W, int d, int J, int prescale, float min_noise, float *Peff, float *dev_out,
+                    float *outputscale_host, float *noise_host, float *mean_host, void *stream) {
+  if (!raw_ls || !raw_os || !raw_noise || !mean || !W || !Peff || !dev_out || n_ls < 1 || n_ls > 1024 || d < 1 || J < 1 ||
+      (n_ls != 1 && n_ls != (prescale ? d : J)))
+    return RPGP_EINVAL;
+  const int rc = g_hyper.init();
+  if (rc) return rc;
+  static thread_local float counter = 0.f;
+  counter = counter >= 1.0e6f ? 1.f : counter + 1.f;           // a stamp no earlier call left behind
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_step_hyper, dim3(1), dim3(256), 0, st, raw_ls, n_ls, raw_os, raw_noise, mean, W, d, J, prescale, min_noise,
+                     Peff, dev_out, g_hyper.dev, counter);
+  STEP_CHECK(hipGetLastError());
+  if (!spin_stamp(g_hyper.host + 3, counter)) STEP_CHECK(hipStreamSynchronize(st));
+  if (outputscale_host) *outputscale_host = g_hyper.host[0];
+  if (noise_host) *noise_host = g_hyper.host[1];
+  if (mean_host) *mean_host = g_hyper.host[2];
+  return 0;
+}
+
+size_t rpgp_step_probes_workspace_bytes(void) { return (size_t)kProbeBlocks * kMaxP * sizeof(float); }
+
+int rpgp_step_probes(const float *L, int k, const float *e1, const float *e2, float sqrt_noise, const float *y,
+                     const float *mean_dev, int64_t N, int p, float *probes, float *full_rhs, float *norms, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+  if (!L || !e1 || !e2 || !y || !mean_dev || !probes || !full_rhs || !norms || N < 1 || p < 1 || p > kMaxP || k < 1 ||
+      k > kMaxKp)
+    return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_step_probes_workspace_bytes()) return RPGP_EWORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float *part = reinterpret_cast<float *>(workspace);
+  const int rpb = 256 / p;
+  long long nb = (N + rpb - 1) / rpb;
+  if (nb > kProbeBlocks) nb = kProbeBlocks;
+  hipLaunchKernelGGL(k_step_probes, dim3((unsigned)nb), dim3(256), 0, st, L, k, e1, e2, sqrt_noise, (long long)N, p, probes, part);
+  long long nb2 = (N * (p + 1) + 255) / 256;
+  if (nb2 > 2048) nb2 = 2048;
+  hipLaunchKernelGGL(k_step_rhs, dim3((unsigned)nb2), dim3(256), 0, st, probes, part, (int)nb, y, mean_dev, (long long)N, p,
+                     full_rhs, norms);
+  return (int)hipGetLastError();
+}
+
+int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T, int col, double logdet, double c1, double c2,
+                    float *out2, void *stream) {
+  if (!full_rhs || !solves || !out2 || N < 1 || T < 1 || col < 0 || col >= T) return RPGP_EINVAL;
+  hipLaunchKernelGGL(k_step_value, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), full_rhs, solves, (long long)N,
+                     T, col, logdet, c1, c2, out2);
+  return (int)hipGetLastError();
+}
+
+size_t rpgp_step_lr_workspace_bytes(void) { return (size_t)kLrBlocks * 2 * sizeof(float); }
+
+int rpgp_step_lr(const float *solves, const float *norms, const float *pre_probes, const float *g, float gscale, int64_t N,
+                 int p, float *left, float *right, float *partials, int *nparts_out, void *stream) {
+  if (!solves || !norms || !pre_probes || !g || !left || !right || !partials || !nparts_out || N < 1 || p < 1 || p > kMaxP)
+    return RPGP_EINVAL;
+  long long nb = (N * (p + 1) + 255) / 256;
+  if (nb > kLrBlocks) nb = kLrBlocks;
+  hipLaunchKernelGGL(k_step_lr, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), solves, norms,
+                     pre_probes, g, gscale, (long long)N, p, left, right, partials);
+  *nparts_out = (int)nb;
+  return (int)hipGetLastError();
+}
+
+int rpgp_step_hyper_backward(const float *dPeff, const float *W, int d, int J, int n_ls, int prescale, float zfac,
+                             const float *hyper_dev, const float *gs, const float *partials, int nparts, const float *g,
+                             float gscale, float dlp_over_n, float *g_raw_ls, float *g_raw_os, float *g_raw_noise,
+                             float *g_mean, void *stream) {
+  if (!dPeff || !W || !hyper_dev || !gs || !partials || !g || !g_raw_ls || !g_raw_os || !g_raw_noise || !g_mean || d < 1 ||
+      J < 1 || n_ls < 1 || nparts < 1 || (n_ls != 1 && n_ls != (prescale ? d : J)))
+    return RPGP_EINVAL;
+  hipLaunchKernelGGL(k_step_hyper_backward, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dPeff, W, d, J, n_ls,
+                     prescale, zfac, hyper_dev, gs, partials, nparts, g, gscale, dlp_over_n, g_raw_ls, g_raw_os, g_raw_noise,
+                     g_mean);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

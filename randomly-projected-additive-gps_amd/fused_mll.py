@@ -85,9 +85,28 @@ def _prior(likelihood, noise_f):
     return lp, dlp
 
 
+def _native_step_ok(model, target, raw_ls):
+    """May the step run on the step kernels (csrc/rpgp_step.hip)?  The HIP library, float32 device tensors, the CG regime,
+    probes drawn from the Woodbury preconditioner, the log-det wanted: the configuration of every timed step.  Everything else
+    (float64, the Cholesky regime, a test double as backend, no preconditioner) runs the same arithmetic as torch operations."""
+    from .inv_quad_logdet import use_cholesky
+    be = _backend.get_backend()
+    X = model.train_inputs
+    return (hasattr(be, "step_hyper") and X.is_cuda and X.dtype == torch.float32 and target.dtype == torch.float32
+            and raw_ls.dtype == torch.float32 and target.dim() == 1 and target.is_contiguous()
+            and not use_cholesky(X.shape[0]) and not settings.skip_logdet_forward.on()
+            and X.shape[0] >= settings.min_preconditioning_size.value() and settings.max_preconditioner_size.value() > 0
+            and settings.num_trace_samples.value() <= 15 and settings.step_kernels.on())
+
+
 class _FusedMLL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target):
+        if _native_step_ok(model, target, raw_ls):
+            done = _FusedMLL._forward_native(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target)
+            if done is not None:
+                return done
+        ctx.native = False
         from .inv_quad_logdet import InvQuadLogDet
         pk = model.covar_module.base_kernel
         bk = pk.base_kernel
@@ -118,7 +137,70 @@ class _FusedMLL(torch.autograd.Function):
         return value.to(raw_ls.dtype)
 
     @staticmethod
+    def _forward_native(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target):
+        """The same objective with the stretches around the solve as single launches (csrc/rpgp_step.hip)."""
+        from .inv_quad_logdet import AddedDiagOperator, _probe_generator, slq_logdet, solve_operator
+        from .linear_cg import linear_cg
+        from .precond import WoodburyPreconditioner, build_preconditioner
+        be = _backend.get_backend()
+        pk = model.covar_module.base_kernel
+        bk = pk.base_kernel
+        X = model.train_inputs.contiguous()
+        n = X.shape[0]
+        W = pk.projection_module.weight                            # J x d
+        p = settings.num_trace_samples.value()
+        with torch.no_grad():
+            Peff, hyp, os_f, noise_f, _ = be.step_hyper(raw_ls.reshape(-1), raw_os.reshape(-1), raw_noise.reshape(-1),
+                                                        mean_c.reshape(-1), W, pk.prescale, likelihood.MIN_NOISE)
+            os_, noise = hyp[0], hyp[1]                            # 0-dim views; their host values are known
+            os_._host_value, noise._host_value = os_f, noise_f
+            Z = be.project(X, Peff)
+            op = bk.operator(Z, None, outputscale=os_, shard=None)
+            op._noise_host = noise_f
+            pre = build_preconditioner(op, noise_f, settings)
+            if not isinstance(pre, WoodburyPreconditioner) or pre.L.dtype != torch.float32 or pre.k > 64:
+                return None
+            gen = _probe_generator(Z.device)
+            e1 = torch.randn(pre.k, p, generator=gen, device=Z.device, dtype=Z.dtype)      # (the draws of pre.sample, same order)
+            e2 = torch.randn(n, p, generator=gen, device=Z.device, dtype=Z.dtype)
+            probes, full_rhs, norms = be.step_probes(pre.L, e1, e2, math.sqrt(noise_f), target, hyp[2:3])
+            khat = AddedDiagOperator(op, noise)
+            matmul, native_op, _ = solve_operator(op, khat, Z, noise_f, p + 1)
+            solves, hist = linear_cg(matmul, full_rhs, n_tridiag=p, operator=native_op,
+                                     tolerance=settings.cg_tolerance.value(), max_iter=settings.max_cg_iterations.value(),
+                                     max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),
+                                     preconditioner=pre, lanczos="history")
+            logdet = float(slq_logdet(hist, n)) + pre.logdet()
+            lp, dlp = _prior(likelihood, noise_f)
+            # mll = (-0.5 (inv_quad + logdet + n log 2 pi) + log p(sigma^2)) / n      (models.ExactMarginalLogLikelihood)
+            out = be.step_value(full_rhs, solves, p, logdet, -0.5 / n, (-0.5 * n * LOG2PI + lp) / n)
+        ctx.native = True
+        ctx.n, ctx.dlp, ctx.prescale, ctx.zfac = n, dlp, pk.prescale, bk.input_scale_factor()
+        ctx.X, ctx.W, ctx.hyp, ctx.op, ctx.pre = X, W, hyp, op, pre
+        ctx.solves, ctx.norms, ctx.probes = solves, norms, probes
+        ctx.shapes = (raw_ls.shape, raw_os.shape, raw_noise.shape, mean_c.shape)
+        return out[0]
+
+    @staticmethod
+    def _backward_native(ctx, g):
+        be = _backend.get_backend()
+        n = ctx.n
+        with torch.no_grad():
+            g = g.reshape(1).contiguous()
+            pre_probes = ctx.pre.solve(ctx.probes)
+            left, right, part, nparts = be.step_lr(ctx.solves, ctx.norms, pre_probes, g, -0.5 / n)
+            gZ, gs = ctx.op._bilinear_derivative(left, right)
+            dPeff = be.project_grad(ctx.X, gZ.contiguous())                              # d x J:  Z = X Peff
+            n_ls = (ctx.hyp.numel() - 8) // 2
+            g_ls, g_os, g_nz, g_mu = be.step_hyper_backward(dPeff, ctx.W, n_ls, ctx.prescale, ctx.zfac, ctx.hyp,
+                                                            gs.reshape(1), part, nparts, g, -0.5 / n, ctx.dlp / n)
+        s_ls, s_os, s_nz, s_mu = ctx.shapes
+        return g_ls.reshape(s_ls), g_os.reshape(s_os), g_nz.reshape(s_nz), g_mu.reshape(s_mu), None, None, None
+
+    @staticmethod
     def backward(ctx, g):
+        if ctx.native:
+            return _FusedMLL._backward_native(ctx, g)
         from .inv_quad_logdet import InvQuadLogDet
         raw_ls, raw_os, raw_noise = ctx.saved_tensors
         n = ctx.n

@@ -75,6 +75,31 @@ def slq_logdet(t_mat, n):
     return float(n) * (w * torch.log(evals)).sum(-1).mean()
 
 
+def solve_operator(op, khat, Z, noise_f, width):
+    """(matmul closure, operator for the native executor, sharded?) of the CG solve on Khat: the cached forms when they fit.
+    cached-K mode: evaluate the kernel once per hyper-parameter step so each CG iteration on the
+    T = 11 block is one HBM-bound pass over stored values; the backward pass stays fused.  Preferred form: the packed
+    symmetric cache (every unordered pair once, half the bytes and half the build); otherwise the dense matrix (rpgp_dense).
+    Multi-GPU (pair-sharding): every rank caches its own 1/world of the pairs and the partial products are summed by the same
+    single all-reduce per MVM as the fused sharded sweep."""
+    N = Z.shape[0]
+    matmul = khat._matmul
+    native_op = khat
+    sharded = op.shard is not None and op.shard.world_size > 1
+    if not isinstance(op, SKIAdditiveOperator) and Z.dtype == torch.float32:
+        per_rank = 2.0 / (op.shard.world_size if sharded else 1)
+        cache = op.to_symcache(wide=width > 4) if hasattr(op, "to_symcache") and \
+            settings.use_cached_kernel(N, Z.device, per_rank) else None
+        if cache is not None:
+            native_op = SymCachedOperator(cache, op._scale, noise_f,
+                                          diag_value=op._scale * op.num_projections, shard=op.shard if sharded else None)
+            matmul = native_op._matmul
+        elif not sharded and settings.use_cached_kernel(N, Z.device):
+            native_op = DenseOperator(op.to_dense_cached(), noise_f)
+            matmul = native_op._matmul
+    return matmul, native_op, sharded
+
+
 class InvQuadLogDet(torch.autograd.Function):
     """(inv_quad, logdet) = (r^T Khat^-1 r, log|Khat|) for Khat = K(Z) * outputscale + noise I."""
 
@@ -113,26 +138,7 @@ class InvQuadLogDet(torch.autograd.Function):
         probe_norms = probes.norm(2, dim=0, keepdim=True)
         probes_n = probes / probe_norms
         full_rhs = torch.cat([probes_n, r], dim=1)
-        matmul = khat._matmul
-        native_op = khat
-        sharded = op.shard is not None and op.shard.world_size > 1
-        if not isinstance(op, SKIAdditiveOperator) and Z.dtype == torch.float32:
-            # cached-K mode: evaluate the kernel once per hyper-parameter step so each CG
-            # iteration on the T = 11 block is one HBM-bound pass over stored values; the backward pass stays fused.
-            # Preferred form: the packed symmetric cache (every unordered pair once, half the bytes and half the build);
-            # otherwise the dense matrix (rpgp_dense).
-            # Multi-GPU (pair-sharding): every rank caches its own 1/world of the pairs and the partial products are
-            # summed by the same single all-reduce per MVM as the fused sharded sweep.
-            per_rank = 2.0 / (op.shard.world_size if sharded else 1)
-            cache = op.to_symcache(wide=full_rhs.shape[1] > 4) if hasattr(op, "to_symcache") and \
-                settings.use_cached_kernel(N, Z.device, per_rank) else None
-            if cache is not None:
-                native_op = SymCachedOperator(cache, op._scale, noise_f,
-                                              diag_value=op._scale * op.num_projections, shard=op.shard if sharded else None)
-                matmul = native_op._matmul
-            elif not sharded and settings.use_cached_kernel(N, Z.device):
-                native_op = DenseOperator(op.to_dense_cached(), noise_f)
-                matmul = native_op._matmul
+        matmul, native_op, sharded = solve_operator(op, khat, Z, noise_f, full_rhs.shape[1])
         solves, t_mat = linear_cg(matmul, full_rhs, n_tridiag=num_probes, operator=native_op,
                                   tolerance=settings.cg_tolerance.value(),
                                   max_iter=settings.max_cg_iterations.value(),

@@ -607,8 +607,9 @@ class ExactMarginalLogLikelihood(nn.Module):
     def forward(self, output, target):
         n = target.shape[0]
         if isinstance(output, LazyPrior) and not output.materialized:
-            from . import fused_mll
-            if fused_mll.applicable(self.model, self.likelihood) and output._model is self.model:
+            # (a LazyPrior only exists because fused_mll.applicable(model) held a moment ago, with the model's own likelihood)
+            from . import fused_mll, settings
+            if output._model is self.model and self.likelihood is self.model.likelihood and settings.fused_training.on():
                 return fused_mll.evaluate(self.model, self.likelihood, target)
         noise = self.likelihood.noise.reshape(())
         if isinstance(output, TrainPosterior):

@@ -286,7 +286,7 @@ class AdditiveRPOperator(LinearOperator):
             gs = gs.reshape(1)
             all_reduce_sum_(gs, self.shard.group)
             gs = gs.reshape(())
-        return gZ, gs * self.weight
+        return gZ, (gs if self.weight == 1.0 else gs * self.weight)
 
     _quad_form_derivative = _bilinear_derivative
 

@@ -1081,3 +1081,93 @@ def slq_logdet_history(alpha_hist, beta_hist, num_probes, n):
                                    int(alpha_hist.strides[0] // 4), int(num_probes), float(n), ctypes.byref(out)),
                "rpgp_slq_logdet")
     return out.value
+
+
+# ---- the small kernels around the solve of one optimiser step (csrc/rpgp_step.hip; caller: fused_mll.py) -------------------
+def step_hyper(raw_ls, raw_os, raw_noise, mean, W, prescale, min_noise):
+    """Raw parameters -> (Peff [d x J], dev [8 + 2 n_ls floats: outputscale, noise, mean, sigmoid(raw_os), sigmoid(raw_noise),
+    ..., ls, sigmoid(raw_ls)], outputscale, noise, mean as host floats): rpgp_step_hyper, one launch; the three floats come
+    back through pinned memory (no copy, no stream synchronisation)."""
+    import ctypes
+    lib = _lib.load()
+    W = _require(W, "W", 2)
+    J, d = W.shape
+    n_ls = raw_ls.numel()
+    for t in (raw_ls, raw_os, raw_noise, mean):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("step_hyper: parameters must be contiguous float32 device tensors")
+    Peff = torch.empty((d, J), dtype=torch.float32, device=W.device)
+    dev = torch.empty(8 + 2 * n_ls, dtype=torch.float32, device=W.device)
+    os_h, nz_h, mu_h = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
+    with torch.cuda.device(W.device):
+        _lib.check(lib.rpgp_step_hyper(raw_ls.data_ptr(), n_ls, raw_os.data_ptr(), raw_noise.data_ptr(), mean.data_ptr(),
+                                       W.data_ptr(), d, J, 1 if prescale else 0, float(min_noise), Peff.data_ptr(),
+                                       dev.data_ptr(), ctypes.byref(os_h), ctypes.byref(nz_h), ctypes.byref(mu_h), _stream()),
+                   "rpgp_step_hyper")
+    return Peff, dev, os_h.value, nz_h.value, mu_h.value
+
+
+def step_probes(L, e1, e2, sqrt_noise, y, mean_dev):
+    """z = L e1 + sqrt_noise e2, norms = |z_c|, full_rhs = [z_c / |z_c| | y - mean]: rpgp_step_probes (two launches).
+    Returns (probes [N x p], full_rhs [N x (p + 1)], norms [p])."""
+    lib = _lib.load()
+    L = _require(L, "L", 2)
+    e1 = _require(e1, "e1", 2)
+    e2 = _require(e2, "e2", 2)
+    N, k = L.shape
+    p = e1.shape[1]
+    if e1.shape[0] != k or e2.shape != (N, p) or y.shape != (N,) or y.dtype != torch.float32 or not y.is_contiguous():
+        raise ValueError("step_probes: e1 is k x p, e2 is N x p, y has N float32 entries")
+    probes = torch.empty((N, p), dtype=torch.float32, device=L.device)
+    full_rhs = torch.empty((N, p + 1), dtype=torch.float32, device=L.device)
+    norms = torch.empty(p, dtype=torch.float32, device=L.device)
+    with torch.cuda.device(L.device):
+        ws = _workspace(L.device, lib.rpgp_step_probes_workspace_bytes())
+        _lib.check(lib.rpgp_step_probes(L.data_ptr(), k, e1.data_ptr(), e2.data_ptr(), float(sqrt_noise), y.data_ptr(),
+                                        mean_dev.data_ptr(), N, p, probes.data_ptr(), full_rhs.data_ptr(), norms.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream()), "rpgp_step_probes")
+    return probes, full_rhs, norms
+
+
+def step_value(full_rhs, solves, col, logdet, c1, c2):
+    """out[0] = (sum_i full_rhs[i][col] solves[i][col] + logdet) c1 + c2, out[1] = the inner product: rpgp_step_value."""
+    lib = _lib.load()
+    N, T = full_rhs.shape
+    out = torch.empty(2, dtype=torch.float32, device=full_rhs.device)
+    with torch.cuda.device(full_rhs.device):
+        _lib.check(lib.rpgp_step_value(full_rhs.data_ptr(), solves.data_ptr(), N, T, int(col), float(logdet), float(c1), float(c2),
+                                       out.data_ptr(), _stream()), "rpgp_step_value")
+    return out
+
+
+def step_lr(solves, norms, pre_probes, g, gscale):
+    """The two sides of the bilinear derivative (rpgp_step_lr): (left, right, partials, nparts)."""
+    import ctypes
+    lib = _lib.load()
+    N, T = solves.shape
+    p = T - 1
+    left = torch.empty_like(solves)
+    right = torch.empty_like(solves)
+    part = torch.empty(lib.rpgp_step_lr_workspace_bytes() // 4, dtype=torch.float32, device=solves.device)
+    nparts = ctypes.c_int(0)
+    with torch.cuda.device(solves.device):
+        _lib.check(lib.rpgp_step_lr(solves.data_ptr(), norms.data_ptr(), pre_probes.data_ptr(), g.data_ptr(), float(gscale), N, p,
+                                    left.data_ptr(), right.data_ptr(), part.data_ptr(), ctypes.byref(nparts), _stream()),
+                   "rpgp_step_lr")
+    return left, right, part, nparts.value
+
+
+def step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyper_dev, gs, partials, nparts, g, gscale, dlp_over_n):
+    """Gradients of the raw parameters (rpgp_step_hyper_backward): (g_raw_ls [n_ls], g_raw_os, g_raw_noise, g_mean) as views of
+    one buffer."""
+    lib = _lib.load()
+    J, d = W.shape
+    out = torch.empty(n_ls + 3, dtype=torch.float32, device=W.device)
+    base = out.data_ptr()
+    with torch.cuda.device(W.device):
+        _lib.check(lib.rpgp_step_hyper_backward(dPeff.data_ptr(), W.data_ptr(), d, J, int(n_ls), 1 if prescale else 0, float(zfac),
+                                                hyper_dev.data_ptr(), gs.data_ptr(), partials.data_ptr(), int(nparts),
+                                                g.data_ptr(), float(gscale), float(dlp_over_n), base, base + 4 * n_ls,
+                                                base + 4 * (n_ls + 1), base + 4 * (n_ls + 2), _stream()),
+                   "rpgp_step_hyper_backward")
+    return out[:n_ls], out[n_ls:n_ls + 1], out[n_ls + 1:n_ls + 2], out[n_ls + 2:n_ls + 3]

@@ -129,7 +129,9 @@ class WoodburyPreconditioner:
     def logdet(self):
         """log|M| = log|noise I_k + L^T L| + (N - k) log noise."""
         if self._logdet_host is not None:
-            self._logdet_ev.synchronize()                             # (long complete behind any solve)
+            # (long complete behind any solve; hipEventSynchronize costs ~200 us even then — profiles/r4_step_C2_*: ask first)
+            if not self._logdet_ev.query():
+                self._logdet_ev.synchronize()
             ld_cap = float(self._logdet_host)
             if ld_cap != ld_cap:
                 raise RuntimeError("the preconditioner's capacitance matrix is not positive definite")

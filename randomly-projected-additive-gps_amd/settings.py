@@ -116,6 +116,10 @@ solve_refinement_min_size = _setting("solve_refinement_min_size", 0)
 # likelihood) as ONE autograd node (fused_mll.py): same native calls, ~60 fewer small launches per optimiser step.  False =
 # the generic operator-by-operator autograd path for every model.
 fused_training = _setting("fused_training", True, flag=True)
+# ... and inside that node the stretches around the solve (hyper-parameter transforms, probe draw and normalisation, the value,
+# the two sides of the derivative, the chain rule back to the raw parameters) as single launches (csrc/rpgp_step.hip) instead of
+# chains of element-wise torch launches: the step is host-bound there.  False = the torch operations (same arithmetic).
+step_kernels = _setting("step_kernels", True, flag=True)
 # the all-reduce of the sharded multi-GPU solve: "rccl" (torch.distributed, backend nccl = RCCL over xGMI) or "ipc" (one-shot
 # kernel over IPC-mapped peer buffers, csrc/rpgp_comm.hip); the environment variable RPGP_COMM overrides it
 comm_backend = _setting("comm_backend", "rccl")

@@ -325,3 +325,40 @@ def test_train_posterior_confident_fit_cg_regime(gpu_device):
     assert np.isfinite(nll)
     nll_ref = ref.test_nll(X.numpy(), y.numpy())
     assert abs(nll - nll_ref) < 2e-2 * abs(nll_ref)                # (condition number ~1e7: float32 kernel entries)
+
+
+@pytest.mark.parametrize("ski", [False, True])
+def test_step_kernels_match_torch_operations_and_generic_path(gpu_device, ski):
+    """One optimiser step's objective and gradients three ways — the fused node on the step kernels (csrc/rpgp_step.hip), the
+    fused node on torch operations, the generic operator-by-operator autograd path — with the same probe draws."""
+    from rpgp_amd import settings, fused_mll
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    gen = torch.Generator().manual_seed(5)
+    N, d, J = 3500, 6, (3 if ski else 12)
+    X = torch.randn(N, d, generator=gen)
+    y = torch.sin(X).sum(1) + 0.1 * torch.randn(N, generator=gen)
+    X, y = X.to(gpu_device), ((y - y.mean()) / y.std()).to(gpu_device)
+    res = {}
+    for mode in ("kernels", "torch", "generic"):
+        torch.manual_seed(4)
+        np.random.seed(4)
+        model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                     prescale=True, space_proj=True, ski=ski,
+                                     ski_options={"grid_size": 512, "num_dims": 1} if ski else None)
+        model = model.to(gpu_device)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        model.train()
+        with settings.fused_training(mode != "generic"), settings.step_kernels(mode == "kernels"), \
+                settings.deterministic_probes(True), settings.cg_tolerance(1e-3):
+            assert fused_mll.applicable(model) == (mode != "generic")
+            loss = -mll(model(X), y)
+            loss.backward()
+        res[mode] = (loss.item(), {k: p.grad.detach().cpu().double().reshape(-1) for k, p in model.named_parameters()
+                                    if p.grad is not None})
+    for mode in ("torch", "generic"):
+        assert abs(res["kernels"][0] - res[mode][0]) < 2e-6 * abs(res[mode][0])
+        assert res["kernels"][1].keys() == res[mode][1].keys()
+        for k, gref in res[mode][1].items():
+            gk = res["kernels"][1][k]
+            assert (gk - gref).abs().max() < 2e-4 * gref.abs().max() + 1e-7, (mode, k)

@@ -588,3 +588,63 @@ def test_woodbury_setup_matches_numpy(gpu_device, K):
     assert np.isnan(float(ld_b)) and np.isnan(cinv_b.cpu().numpy()).all()
     with pytest.raises(TypeError):
         ops.woodbury_setup(torch.zeros(65, 65, dtype=torch.float64, device=gpu_device), 1.0)
+
+
+def test_step_kernels_against_torch_formulas(gpu_device):
+    """csrc/rpgp_step.hip, each entry point against the torch operations it replaces in the optimiser step (fused_mll.py)."""
+    import math
+    from torch.nn import functional as F
+    from rpgp_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for d, J, prescale, n_ls in ((8, 20, True, 8), (6, 5, False, 5), (7, 3, True, 1)):
+        raw_ls = torch.randn(n_ls, generator=g).to(gpu_device)
+        raw_os, raw_nz, mean = (torch.randn(1, generator=g).to(gpu_device) for _ in range(3))
+        W = torch.randn(J, d, generator=g).to(gpu_device)
+        Peff, hyp, os_f, nz_f, mu_f = ops.step_hyper(raw_ls, raw_os, raw_nz, mean, W, prescale, 1e-4)
+        ls = F.softplus(raw_ls)
+        col = ls if n_ls == 1 else (ls.reshape(-1, 1) if prescale else ls.reshape(1, -1))
+        assert torch.allclose(Peff, W.t() / col, rtol=2e-6, atol=0)
+        assert abs(os_f - float(F.softplus(raw_os))) < 2e-6 * abs(os_f) and abs(nz_f - float(F.softplus(raw_nz) + 1e-4)) < 2e-6 * nz_f
+        assert mu_f == float(mean)
+        assert torch.allclose(hyp[:3].cpu(), torch.tensor([os_f, nz_f, mu_f]))
+        assert torch.allclose(hyp[3:5], torch.sigmoid(torch.cat([raw_os, raw_nz])), rtol=2e-6)
+        assert torch.allclose(hyp[8:8 + n_ls], ls, rtol=2e-6) and torch.allclose(hyp[8 + n_ls:], torch.sigmoid(raw_ls), rtol=2e-6)
+        # chain rule back
+        dPeff = torch.randn(d, J, generator=g).to(gpu_device)
+        gs, gten = torch.randn(1, generator=g).to(gpu_device), torch.tensor([-1.0], device=gpu_device)
+        part = torch.randn(2 * 37, generator=g).to(gpu_device)
+        zfac, gscale, dlp_n = 0.83, -0.5 / 1234, 0.017
+        g_ls, g_os, g_nz, g_mu = ops.step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyp, gs, part, 37, gten, gscale, dlp_n)
+        t = dPeff * zfac * W.t()
+        ref_ls = -(t.sum() if n_ls == 1 else (t.sum(1) if prescale else t.sum(0))) / (ls * ls) * torch.sigmoid(raw_ls)
+        assert torch.allclose(g_ls, ref_ls.reshape(-1), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(g_os, gs * torch.sigmoid(raw_os), rtol=1e-6)
+        gq = float(gten) * gscale
+        assert abs(float(g_nz) - (float(part[0::2].double().sum()) + float(gten) * dlp_n) * float(torch.sigmoid(raw_nz))) < 1e-5
+        assert abs(float(g_mu) + 2 * gq * float(part[1::2].double().sum())) < 1e-6
+    for N, k, p in ((3001, 15, 10), (70000, 9, 7)):
+        L = torch.randn(N, k, generator=g).to(gpu_device)
+        e1, e2 = torch.randn(k, p, generator=g).to(gpu_device), torch.randn(N, p, generator=g).to(gpu_device)
+        y, mean = torch.randn(N, generator=g).to(gpu_device), torch.tensor([0.3], device=gpu_device)
+        probes, full_rhs, norms = ops.step_probes(L, e1, e2, math.sqrt(0.2), y, mean)
+        ref = L.double() @ e1.double() + math.sqrt(0.2) * e2.double()
+        assert (probes.double() - ref).abs().max() < 1e-5 * ref.abs().max()
+        assert torch.allclose(norms.double(), ref.norm(dim=0), rtol=1e-6)
+        assert (full_rhs[:, :p].double() - ref / ref.norm(dim=0)).abs().max() < 1e-6
+        assert torch.equal(full_rhs[:, p], y - 0.3)
+        again = ops.step_probes(L, e1, e2, math.sqrt(0.2), y, mean)
+        assert all(torch.equal(a, b) for a, b in zip(again, (probes, full_rhs, norms)))          # fixed-order sums
+        sol = torch.randn(N, p + 1, generator=g).to(gpu_device)
+        out = ops.step_value(full_rhs, sol, p, 12.5, -0.5 / N, 0.75)
+        iq = float((full_rhs[:, p].double() * sol[:, p].double()).sum())
+        assert abs(float(out[1]) - iq) < 1e-6 * max(1.0, abs(iq)) * 10
+        assert abs(float(out[0]) - ((iq + 12.5) * (-0.5 / N) + 0.75)) < 1e-6
+        pre_probes, gten = torch.randn(N, p, generator=g).to(gpu_device), torch.tensor([-1.0], device=gpu_device)
+        left, right, part, nparts = ops.step_lr(sol, norms, pre_probes, gten, -0.5 / N)
+        gq = -1.0 * (-0.5 / N)
+        assert torch.allclose(left[:, :p], sol[:, :p] * norms * (gq / p), rtol=2e-6, atol=1e-12)
+        assert torch.allclose(left[:, p], -gq * sol[:, p], rtol=2e-6) and torch.equal(right[:, :p], pre_probes)
+        assert torch.equal(right[:, p], sol[:, p])
+        lr = float((left.double() * right.double()).sum())
+        assert abs(float(part[:2 * nparts][0::2].double().sum()) - lr) < 1e-5 * max(abs(lr), 1e-6) + 1e-9
+        assert abs(float(part[:2 * nparts][1::2].double().sum()) - float(sol[:, p].double().sum())) < 1e-3

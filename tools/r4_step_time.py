@@ -25,7 +25,8 @@ def run(n):
         opt.zero_grad(); loss = -mll(model(X), y); loss.backward(); opt.step(); v = loss.item()   # (.item(): fitting/optimizing.py:74)
     return v
 ts = []
-with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
+with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000), \
+        settings.step_kernels(os.environ.get("RPGP_STEP_KERNELS", "1") != "0"):
     model.train(); run(10); torch.cuda.synchronize()
     for r in range(rounds):
         t0 = time.perf_counter(); v = run(steps); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / steps * 1e6)

@@ -461,7 +461,8 @@ int rpgp_slq_logdet(const float *alpha_hist, const float *beta_hist, int iters, 
  * rpgp_step_probes: z = L e1 + sqrt_noise e2 (L: N x k, e1: k x p, e2: N x p standard normal draws — GPyTorch's preconditioner-
  *   distributed probe vectors), norms[c] = |z_c|, full_rhs[N x (p + 1)] = [z_c / |z_c| | y - *mean_dev].  p <= 16, k <= 64.
  * rpgp_step_value: inv_quad = sum_i full_rhs[i][col] solves[i][col] (N x T blocks);  out2[0] = (inv_quad + logdet) c1 + c2,
- *   out2[1] = inv_quad.
+ *   out2[1] = inv_quad.  The workspace's first 4 bytes are an arrival counter: ZERO on entry (zero the buffer once), zero
+ *   again on exit; it must not be shared between streams.
  * rpgp_step_lr: the two sides of the bilinear derivative from the solve of [probes | r] (solves: N x (p + 1)):
  *   left = [solves_c norms[c] gq / p | -gq alpha], right = [pre_probes | alpha], gq = g[0] * gscale (g: device scalar, the
  *   incoming gradient); partials[2 b], partials[2 b + 1] = workgroup b's sum(left * right), sum(alpha); *nparts_out workgroups.
@@ -476,8 +477,9 @@ size_t rpgp_step_probes_workspace_bytes(void);
 int rpgp_step_probes(const float *L, int k, const float *e1, const float *e2, float sqrt_noise, const float *y,
                      const float *mean_dev, int64_t N, int p, float *probes, float *full_rhs, float *norms, void *workspace,
                      size_t workspace_bytes, void *stream);
+size_t rpgp_step_value_workspace_bytes(void);
 int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T, int col, double logdet, double c1, double c2,
-                    float *out2, void *stream);
+                    float *out2, void *workspace, size_t workspace_bytes, void *stream);
 size_t rpgp_step_lr_workspace_bytes(void);
 int rpgp_step_lr(const float *solves, const float *norms, const float *pre_probes, const float *g, float gscale, int64_t N,
                  int p, float *left, float *right, float *partials, int *nparts_out, void *stream);

@@ -83,47 +83,65 @@ __global__ __launch_bounds__(256) void k_step_hyper(const float *__restrict__ ra
 
 // ---- probes z = L e1 + sqrt(sigma^2) e2 (WoodburyPreconditioner.sample), their column norms, [z / |z| | y - c] ---------------
 constexpr int kMaxP = 16, kMaxKp = 64, kProbeBlocks = 512;
-// element (row, c) per thread, `rows_per_block` rows per block iteration; partial column sums of squares per block (fixed order)
+// one ROW per thread (a wave reads 64 consecutive rows of L and e2: whole cache lines), the p <= 16 results in registers; the
+// column sums of squares are carried per thread over its rows and added up ONCE per workgroup, in a fixed order
 __global__ __launch_bounds__(256) void k_step_probes(const float *__restrict__ L, int k, const float *__restrict__ e1,
                                                      const float *__restrict__ e2, float sqrt_noise, long long N, int p,
                                                      float *__restrict__ probes, float *__restrict__ part) {
-  __shared__ float se1[kMaxKp * kMaxP];
-  __shared__ float sq[256];
-  for (int e = threadIdx.x; e < k * p; e += 256) se1[e] = e1[e];
-  __syncthreads();
-  const int rpb = 256 / p;                              // rows per block iteration
-  const int rr = threadIdx.x / p, c = threadIdx.x - rr * p;
-  const bool lane_ok = rr < rpb;
-  float acc = 0.f;                                      // (thread c < p accumulates column c over the block's iterations)
-  for (long long r0 = (long long)blockIdx.x * rpb; r0 < N; r0 += (long long)gridDim.x * rpb) {
-    const long long row = r0 + rr;
-    float v = 0.f;
-    if (lane_ok && row < N) {
-      float s = 0.f;
-      for (int kk = 0; kk < k; ++kk) s = __builtin_fmaf(L[row * k + kk], se1[kk * p + c], s);
-      v = s + sqrt_noise * e2[row * p + c];
-      probes[row * p + c] = v;
-    }
-    __syncthreads();
-    sq[threadIdx.x] = v * v;
-    __syncthreads();
-    if (threadIdx.x < p) {
-      float s = 0.f;
-      for (int q = 0; q < rpb; ++q) s += sq[q * p + threadIdx.x];
-      acc += s;
-    }
+  __shared__ float se1[kMaxKp * kMaxP];                 // e1 padded to 16 columns
+  __shared__ float sq[256 * (kMaxP + 1)];
+  for (int e = threadIdx.x; e < k * kMaxP; e += 256) {
+    const int kk = e / kMaxP, c = e - kk * kMaxP;
+    se1[e] = c < p ? e1[kk * p + c] : 0.f;
   }
-  if (threadIdx.x < p) part[(size_t)blockIdx.x * kMaxP + threadIdx.x] = acc;
+  __syncthreads();
+  float ssq[kMaxP];
+#pragma unroll
+  for (int c = 0; c < kMaxP; ++c) ssq[c] = 0.f;
+  for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < N; row += (long long)gridDim.x * 256) {
+    float acc[kMaxP];
+#pragma unroll
+    for (int c = 0; c < kMaxP; ++c) acc[c] = 0.f;
+    for (int kk = 0; kk < k; ++kk) {
+      const float l = L[row * k + kk];
+#pragma unroll
+      for (int c = 0; c < kMaxP; ++c) acc[c] = __builtin_fmaf(l, se1[kk * kMaxP + c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxP; ++c)
+      if (c < p) {
+        const float v = acc[c] + sqrt_noise * e2[row * p + c];
+        probes[row * p + c] = v;
+        ssq[c] = __builtin_fmaf(v, v, ssq[c]);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxP; ++c) sq[threadIdx.x * (kMaxP + 1) + c] = ssq[c];
+  __syncthreads();
+  if (threadIdx.x < p) {
+    float s = 0.f;
+    for (int t = 0; t < 256; ++t) s += sq[t * (kMaxP + 1) + threadIdx.x];
+    part[(size_t)blockIdx.x * kMaxP + threadIdx.x] = s;
+  }
 }
 
-// norms from the partials (every block adds them up itself, fixed order); full_rhs = [probes / |probes| | y - mean]
+// norms from the partials (every workgroup adds them up itself: 16 groups of every 16th slab, then the groups in order);
+// full_rhs = [probes / |probes| | y - mean]
 __global__ __launch_bounds__(256) void k_step_rhs(const float *__restrict__ probes, const float *__restrict__ part, int nparts,
                                                   const float *__restrict__ y, const float *__restrict__ mean_dev, long long N,
                                                   int p, float *__restrict__ full_rhs, float *__restrict__ norms) {
+  __shared__ double sg[16][kMaxP];
   __shared__ float snorm[kMaxP];
+  {
+    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    double s = 0.0;
+    for (int q = grp; q < nparts; q += 16) s += (double)part[(size_t)q * kMaxP + c];
+    sg[grp][c] = s;
+  }
+  __syncthreads();
   if (threadIdx.x < p) {
     double s = 0.0;
-    for (int q = 0; q < nparts; ++q) s += (double)part[(size_t)q * kMaxP + threadIdx.x];
+    for (int q = 0; q < 16; ++q) s += sg[q][threadIdx.x];
     const float nrm = sqrtf((float)s);
     snorm[threadIdx.x] = nrm;
     if (blockIdx.x == 0) norms[threadIdx.x] = nrm;
@@ -140,23 +158,42 @@ __global__ __launch_bounds__(256) void k_step_rhs(const float *__restrict__ prob
 }
 
 // ---- value of the objective ------------------------------------------------------------------------------------------------
-// inv_quad = sum_i rhs[i][col] * sol[i][col];  out[0] = (inv_quad + logdet) * c1 + c2,  out[1] = inv_quad     (one workgroup,
-// fixed order: thread t adds rows t, t + 1024, ...; the 1024 sums are added by a tree)
-__global__ __launch_bounds__(1024) void k_step_value(const float *__restrict__ rhs, const float *__restrict__ sol, long long N,
-                                                     int T, int col, double logdet, double c1, double c2,
-                                                     float *__restrict__ out) {
-  __shared__ double sh[1024];
+// inv_quad = sum_i rhs[i][col] * sol[i][col];  out[0] = (inv_quad + logdet) * c1 + c2,  out[1] = inv_quad.  Up to kValueBlocks
+// workgroups write a float64 partial each; the LAST one to finish adds them in index order (bitwise reproducible whoever it is)
+// — once per optimiser step, so the hand-off (every wave drains its stores, workgroup barrier, agent-scope release, arrive on
+// the counter; the last arriver: agent-scope acquire, plain loads — MI355X_MICROARCH.md "valid forms") costs nothing that
+// matters.  ws: [0] arrival counter (0 on entry, 0 again on exit), doubles from byte 256.
+constexpr int kValueBlocks = 256;
+__global__ __launch_bounds__(256) void k_step_value(const float *__restrict__ rhs, const float *__restrict__ sol, long long N,
+                                                    int T, int col, double logdet, double c1, double c2,
+                                                    float *__restrict__ out, unsigned *__restrict__ counter,
+                                                    double *__restrict__ part) {
+  __shared__ double sh[256];
   double s = 0.0;
-  for (long long i = threadIdx.x; i < N; i += 1024) s += (double)rhs[i * T + col] * (double)sol[i * T + col];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
+    s += (double)rhs[i * T + col] * (double)sol[i * T + col];
   sh[threadIdx.x] = s;
   __syncthreads();
-  for (int w = 512; w > 0; w >>= 1) {
+  for (int w = 128; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    out[0] = (float)((sh[0] + logdet) * c1 + c2);
-    out[1] = (float)sh[0];
+    part[blockIdx.x] = sh[0];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == gridDim.x - 1;
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      double tot = 0.0;
+      for (unsigned q = 0; q < gridDim.x; ++q) tot += part[q];
+      out[0] = (float)((tot + logdet) * c1 + c2);
+      out[1] = (float)tot;
+    }
   }
 }
 
@@ -311,11 +348,17 @@ int rpgp_step_probes(const float *L, int k, const float *e1, const float *e2, fl
   return (int)hipGetLastError();
 }
 
+size_t rpgp_step_value_workspace_bytes(void) { return 256 + (size_t)kValueBlocks * sizeof(double); }
+
 int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T, int col, double logdet, double c1, double c2,
-                    float *out2, void *stream) {
+                    float *out2, void *workspace, size_t workspace_bytes, void *stream) {
   if (!full_rhs || !solves || !out2 || N < 1 || T < 1 || col < 0 || col >= T) return RPGP_EINVAL;
-  hipLaunchKernelGGL(k_step_value, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), full_rhs, solves, (long long)N,
-                     T, col, logdet, c1, c2, out2);
+  if (!workspace || workspace_bytes < rpgp_step_value_workspace_bytes()) return RPGP_EWORKSPACE;
+  long long nb = (N + 1023) / 1024;                  // ~4 rows per thread
+  if (nb > kValueBlocks) nb = kValueBlocks;
+  hipLaunchKernelGGL(k_step_value, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), full_rhs, solves,
+                     (long long)N, T, col, logdet, c1, c2, out2, reinterpret_cast<unsigned *>(workspace),
+                     reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + 256));
   return (int)hipGetLastError();
 }
 

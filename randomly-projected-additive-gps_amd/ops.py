@@ -1129,14 +1129,21 @@ def step_probes(L, e1, e2, sqrt_noise, y, mean_dev):
     return probes, full_rhs, norms
 
 
+_value_ws = {}
+
+
 def step_value(full_rhs, solves, col, logdet, c1, c2):
     """out[0] = (sum_i full_rhs[i][col] solves[i][col] + logdet) c1 + c2, out[1] = the inner product: rpgp_step_value."""
     lib = _lib.load()
     N, T = full_rhs.shape
     out = torch.empty(2, dtype=torch.float32, device=full_rhs.device)
+    key = (full_rhs.device.index, int(_stream() or 0))
+    ws = _value_ws.get(key)
+    if ws is None:              # (zeroed ONCE: the kernel leaves its arrival counter at zero; one buffer per stream)
+        ws = _value_ws[key] = torch.zeros(lib.rpgp_step_value_workspace_bytes(), dtype=torch.uint8, device=full_rhs.device)
     with torch.cuda.device(full_rhs.device):
         _lib.check(lib.rpgp_step_value(full_rhs.data_ptr(), solves.data_ptr(), N, T, int(col), float(logdet), float(c1), float(c2),
-                                       out.data_ptr(), _stream()), "rpgp_step_value")
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "rpgp_step_value")
     return out
 
 

@@ -293,6 +293,29 @@ int rpgp_ski_bilinear_grad_comp(const float *Z, const float *grid_params, const 
                                 void *stream);
 
 /*
+ * float64 parity kernels of the SKI operator (csrc/rpgp_ski_f64.hip): `--double` (/root/reference/training_routines.py:481) for
+ * the `ski: true` specifications (/root/reference/training_routines.py:157-158).  Same operator and grid-parameter layout as the
+ * float32 entry points above, every array float64 (grid_params included: [g0, h, 1/h, flags, w_j .., (g0_j, h_j, 1/h_j) ..]);
+ * a thread per output element, the scatter with float64 hardware atomics (sums differ in the last bits between runs), the
+ * Toeplitz stage a plain O(G^2) sum — written for clarity, not speed.  Any T (the host passes <= 64 columns per call).
+ *   rpgp_ski_f64_mvm           out (M x T) = scale sum_j w_j W1_j Tm_j W2_j^T V (+ noise V: square operator only)
+ *   rpgp_ski_f64_diag / _dense the diagonal / a dense block K_ski(Z1, Z2)
+ *   rpgp_ski_f64_bilinear_grad d/dZ, d/dscale (device scalar) and (gcomp != NULL, J doubles) the per-projection parts of d/dscale
+ *                              (each carries its w_j) of sum((L R^T) * K_ski(Z, Z))
+ */
+size_t rpgp_ski_f64_workspace_bytes(int J, int G, int T);
+int rpgp_ski_f64_mvm(const double *Z1, const double *Z2, const double *grid_params, const double *V, double *out, int64_t M,
+                     int64_t N, int ldz1, int ldz2, int J, int G, int T, double scale, double noise, void *workspace,
+                     size_t workspace_bytes, void *stream);
+int rpgp_ski_f64_diag(const double *Z, const double *grid_params, double *diag, int64_t N, int ldz, int J, int G, double scale,
+                      void *stream);
+int rpgp_ski_f64_dense(const double *Z1, const double *Z2, const double *grid_params, double *out, int64_t M, int64_t N, int ldz1,
+                       int ldz2, int64_t ldo, int J, int G, double scale, void *stream);
+int rpgp_ski_f64_bilinear_grad(const double *Z, const double *grid_params, const double *L, const double *R, double *gZ,
+                               double *gscale, double *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T, double scale,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * The derivative in two stages for the row-sharded SKI operator (MLL backward of a model whose rows are split over ranks):
  *   rpgp_ski_bilinear_scatter : hist2[j][g][0..T) = W_j^T L, hist2[j][g][T..2T) = W_j^T R over the N LOCAL rows (float64,
  *                               J * G * 2T) — all-reduce it over the ranks —

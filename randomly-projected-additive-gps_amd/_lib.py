@@ -95,6 +95,12 @@ SIGNATURES = {
     "rpgp_mbcg_solve": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _f32, _int, _vp, _vp, _f32, _vp, _vp, _vp,
                                _vp, _vp, _vp, _sz, _vp]),
     "rpgp_slq_logdet": (_int, [_vp, _vp, _int, _int, _int, _f64, _vp]),
+    "rpgp_ski_f64_workspace_bytes": (_sz, [_int, _int, _int]),
+    "rpgp_ski_f64_mvm": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _f64, _f64, _vp, _sz, _vp]),
+    "rpgp_ski_f64_diag": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f64, _vp]),
+    "rpgp_ski_f64_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f64, _vp]),
+    "rpgp_ski_f64_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f64, _vp, _sz,
+                                          _vp]),
     "rpgp_step_hyper": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rpgp_step_probes_workspace_bytes": (_sz, []),
     "rpgp_step_probes": (_int, [_vp, _int, _vp, _vp, _f32, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),

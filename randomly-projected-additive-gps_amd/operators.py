@@ -332,7 +332,8 @@ class SKIAdditiveOperator(AdditiveRPOperator):
 
     def fused_pivoted_cholesky(self, rank):
         be = _backend.get_backend()
-        if not self.symmetric or not hasattr(be, "ski_pivoted_cholesky") or self.Z1.shape[1] > 64 or rank > 64:
+        if not self.symmetric or not hasattr(be, "ski_pivoted_cholesky") or self.Z1.shape[1] > 64 or rank > 64 or \
+                self.Z1.dtype != torch.float32:            # (float64 parity path: the generic greedy factor on _get_rows)
             return None
         return be.ski_pivoted_cholesky(self.Z1.detach().contiguous(), self.gp, self._scale,
                                        min(rank, self.Z1.shape[0]), self.grid_size)
@@ -358,7 +359,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
 
     def native_descriptor(self, noise=0.0):
         be = _backend.get_backend()
-        if not self.symmetric or not hasattr(be, "mbcg_solve"):
+        if not self.symmetric or not hasattr(be, "mbcg_solve") or self.Z1.dtype != torch.float32:
             return None
         from . import _lib
         z1 = self.Z1.detach().contiguous()

@@ -389,7 +389,12 @@ def ski_grid(Z1, Z2=None, grid_size=1024, weights=None, rule="shared"):
         [g0, h, 1/h, flags, (w_0 .. w_{J-1})];
     rule "reference" (polynomial_projection_kernels.py:54-63, the rp_poly / strictly_additive / additive kinds): a grid
         per projection, [., ., ., flags, w_0 .. w_{J-1}, (g0_j, h_j, 1/h_j) x J].
-    `weights` (J per-projection output scales) switches every SKI entry point to the weighted sum (flags |= 1)."""
+    `weights` (J per-projection output scales) switches every SKI entry point to the weighted sum (flags |= 1).
+    float64 coordinates get the float64 twin of the block (the float64 parity path, rpgp_ski_f64.hip)."""
+    if rule not in ("shared", "reference"):
+        raise ValueError("unknown SKI grid rule %r (shared | reference)" % (rule,))
+    if Z1.dtype == torch.float64:
+        return _ski64_grid(Z1, Z2, grid_size, weights, rule)
     lib = _lib.load()
     Z1 = _require(Z1, "Z1", 2)
     N1, J = Z1.shape
@@ -448,6 +453,8 @@ def ski_plan(Z, gp, grid_size=1024):
 def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024, plan=None):
     """out = scale * sum_j W1_j Tm W2_j^T V (+ noise V);  Z2 may be Z1 (square operator).  `plan` (SkiPlan of Z1, square
     operator only): the planned product for blocks of up to 12 columns."""
+    if Z1.dtype == torch.float64:
+        return _ski64_mvm(Z1, Z2, gp, V, scale, noise, grid_size)
     lib = _lib.load()
     Z1 = _require(Z1, "Z1", 2)
     Z2 = _require(Z2, "Z2", 2)
@@ -560,6 +567,8 @@ def ski_pivoted_cholesky(Z, gp, scale, rank, grid_size=1024):
 
 def ski_dense(Z1, Z2, gp, scale, grid_size=1024):
     """Dense block K_ski(Z1, Z2) (M x N) of the SKI operator."""
+    if Z1.dtype == torch.float64:
+        return _ski64_dense(Z1, Z2, gp, scale, grid_size)
     lib = _lib.load()
     Z1 = _require(Z1, "Z1", 2)
     Z2 = _require(Z2, "Z2", 2)
@@ -573,6 +582,8 @@ def ski_dense(Z1, Z2, gp, scale, grid_size=1024):
 
 
 def ski_diag(Z, gp, scale, grid_size=1024):
+    if Z.dtype == torch.float64:
+        return _ski64_diag(Z, gp, scale, grid_size)
     lib = _lib.load()
     Z = _require(Z, "Z", 2)
     N, J = Z.shape
@@ -585,6 +596,8 @@ def ski_diag(Z, gp, scale, grid_size=1024):
 
 def ski_bilinear_grad(Z, gp, L, R, scale, grid_size=1024):
     """(gZ, gscale) of sum((L R^T) * K_ski(Z,Z)); wide blocks are processed 12 columns at a time."""
+    if Z.dtype == torch.float64:
+        return _ski64_bilinear(Z, gp, L, R, scale, grid_size)[:2]
     lib = _lib.load()
     Z = _require(Z, "Z", 2)
     N, J = Z.shape
@@ -612,6 +625,8 @@ def ski_bilinear_grad(Z, gp, L, R, scale, grid_size=1024):
 
 def ski_bilinear_grad_comp(Z, gp, L, R, scale, grid_size=1024):
     """(gZ, gscale, gcomp [J]) for the weighted SKI operator: gcomp[j] is projection j's part of gscale (it carries w_j)."""
+    if Z.dtype == torch.float64:
+        return _ski64_bilinear(Z, gp, L, R, scale, grid_size)
     lib = _lib.load()
     Z = _require(Z, "Z", 2)
     N, J = Z.shape
@@ -1178,3 +1193,109 @@ def step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyper_dev, gs, partials,
                                                 base + 4 * (n_ls + 1), base + 4 * (n_ls + 2), _stream()),
                    "rpgp_step_hyper_backward")
     return out[:n_ls], out[n_ls:n_ls + 1], out[n_ls + 1:n_ls + 2], out[n_ls + 2:n_ls + 3]
+
+
+# ---- float64 parity path of the SKI operator (csrc/rpgp_ski_f64.hip): `--double` for the `ski: true` specifications --------
+def _ski64_grid(Z1, Z2, grid_size, weights, rule):
+    """The float64 twin of the grid-parameter block, from the same rules (rpgp_ski_grid / rpgp_ski_grid_per_projection), as
+    torch operations on the device (a dozen scalars per hyper-parameter step)."""
+    G = int(grid_size)
+    J = Z1.shape[1]
+    z = Z1 if Z2 is None else torch.cat([Z1, Z2], dim=0)
+    if rule == "shared":
+        mn, mx = z.amin(), z.amax()
+        rng = (mx - mn).clamp_min(1e-12)
+        h = rng / (G - 5)
+        head = torch.stack([mn - 2.0 * h, h, 1.0 / h, torch.zeros_like(h)])
+        if weights is None:
+            return head.contiguous()
+        w = weights.detach().to(device=Z1.device, dtype=torch.float64).reshape(-1)
+        if w.numel() != J:
+            raise ValueError("weights must have one entry per projection (%d)" % J)
+        head[3] = 1.0
+        return torch.cat([head, w]).contiguous()
+    mn, mx = z.amin(dim=0), z.amax(dim=0)
+    rng = (mx - mn).clamp_min(1e-12)
+    spacing = rng / (G - 4)
+    b0 = mn - 2.01 * spacing
+    h = spacing * ((G - 4) + 4.02) / (G - 1)
+    h = torch.maximum(h, torch.maximum(mn.abs(), mx.abs()) * 4.5e-16)
+    w = torch.ones(J, dtype=torch.float64, device=Z1.device) if weights is None else \
+        weights.detach().to(device=Z1.device, dtype=torch.float64).reshape(-1)
+    if w.numel() != J:
+        raise ValueError("weights must have one entry per projection (%d)" % J)
+    head = torch.tensor([0.0, 1.0, 1.0, 2.0 if weights is None else 3.0], dtype=torch.float64, device=Z1.device)
+    return torch.cat([head, w, torch.stack([b0, h, 1.0 / h], dim=1).reshape(-1)]).contiguous()
+
+
+def _ski64_mvm(Z1, Z2, gp, V, scale, noise, grid_size):
+    lib = _lib.load()
+    Z1 = _require(Z1, "Z1", 2, allow64=True)
+    Z2 = _require(Z2, "Z2", 2, allow64=True)
+    M, J = Z1.shape
+    N = Z2.shape[0]
+    V2, squeeze = _as_matrix(V, N, "V", allow64=True)
+    T = V2.shape[1]
+    out = torch.empty((M, T), dtype=torch.float64, device=Z1.device)
+    same = Z1.data_ptr() == Z2.data_ptr() and M == N
+    with torch.cuda.device(Z1.device):
+        for t0 in range(0, T, 64):                       # (column pieces bound the J x G x T workspace)
+            Vc = V2[:, t0:t0 + 64].contiguous()
+            oc = torch.empty((M, Vc.shape[1]), dtype=torch.float64, device=Z1.device)
+            ws = _workspace(Z1.device, lib.rpgp_ski_f64_workspace_bytes(J, int(grid_size), Vc.shape[1]))
+            _lib.check(lib.rpgp_ski_f64_mvm(Z1.data_ptr(), Z2.data_ptr(), gp.data_ptr(), Vc.data_ptr(), oc.data_ptr(), M, N, J, J,
+                                            J, int(grid_size), Vc.shape[1], float(scale), float(noise) if same else 0.0,
+                                            ws.data_ptr(), ws.numel(), _stream()), "rpgp_ski_f64_mvm")
+            out[:, t0:t0 + 64] = oc
+    return out.squeeze(1) if squeeze else out
+
+
+def _ski64_dense(Z1, Z2, gp, scale, grid_size):
+    lib = _lib.load()
+    Z1 = _require(Z1, "Z1", 2, allow64=True)
+    Z2 = _require(Z2, "Z2", 2, allow64=True)
+    M, J = Z1.shape
+    N = Z2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float64, device=Z1.device)
+    with torch.cuda.device(Z1.device):
+        _lib.check(lib.rpgp_ski_f64_dense(Z1.data_ptr(), Z2.data_ptr(), gp.data_ptr(), out.data_ptr(), M, N, J, J, N, J,
+                                          int(grid_size), float(scale), _stream()), "rpgp_ski_f64_dense")
+    return out
+
+
+def _ski64_diag(Z, gp, scale, grid_size):
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2, allow64=True)
+    N, J = Z.shape
+    out = torch.empty(N, dtype=torch.float64, device=Z.device)
+    with torch.cuda.device(Z.device):
+        _lib.check(lib.rpgp_ski_f64_diag(Z.data_ptr(), gp.data_ptr(), out.data_ptr(), N, J, J, int(grid_size), float(scale),
+                                         _stream()), "rpgp_ski_f64_diag")
+    return out
+
+
+def _ski64_bilinear(Z, gp, L, R, scale, grid_size):
+    """(gZ, gscale, gcomp) in float64 (rpgp_ski_f64_bilinear_grad), 64 columns per piece."""
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2, allow64=True)
+    N, J = Z.shape
+    L2, _ = _as_matrix(L, N, "L", allow64=True)
+    R2, _ = _as_matrix(R, N, "R", allow64=True)
+    T = L2.shape[1]
+    gZ = torch.zeros((N, J), dtype=torch.float64, device=Z.device)
+    gs = torch.zeros((), dtype=torch.float64, device=Z.device)
+    gc = torch.zeros(J, dtype=torch.float64, device=Z.device)
+    gZp, gsp, gcp = torch.empty_like(gZ), torch.empty_like(gs), torch.empty_like(gc)
+    with torch.cuda.device(Z.device):
+        for t0 in range(0, T, 64):
+            Lc = L2[:, t0:t0 + 64].contiguous()
+            Rc = R2[:, t0:t0 + 64].contiguous()
+            ws = _workspace(Z.device, lib.rpgp_ski_f64_workspace_bytes(J, int(grid_size), Lc.shape[1]))
+            _lib.check(lib.rpgp_ski_f64_bilinear_grad(Z.data_ptr(), gp.data_ptr(), Lc.data_ptr(), Rc.data_ptr(), gZp.data_ptr(),
+                                                      gsp.data_ptr(), gcp.data_ptr(), N, J, J, J, int(grid_size), Lc.shape[1],
+                                                      float(scale), ws.data_ptr(), ws.numel(), _stream()),
+                       "rpgp_ski_f64_bilinear_grad")
+            gZ += gZp
+            gs += gsp
+            gc += gcp
+    return gZ, gs, gc

@@ -402,10 +402,11 @@ def locality_order(X, bits=10):
 
 
 def _check_double_supported(kind, model_kwargs):
-    """`--double` (training_routines.py:481): float64 parity kernels serve the RBF hot path (rpgp_f64.hip) and every member
-    of the generalised family (rpgp_family_generic.hip); the grid-interpolation operator stays float32."""
-    if model_kwargs.get("ski", False):
-        raise NotImplementedError("--double is not available for the SKI operator (fp32 kernels only)")
+    """`--double` (training_routines.py:481): float64 parity kernels serve the RBF hot path (rpgp_f64.hip), every member of the
+    generalised family (rpgp_family_generic.hip) and the grid-interpolation operator (rpgp_ski_f64.hip) — single device; the
+    row-sharded multi-GPU SKI solve stays float32."""
+    if model_kwargs.get("ski", False) and is_distributed():
+        raise NotImplementedError("--double is not available for the row-sharded SKI operator (one process per GPU)")
 
 
 class _ExactGPFactory:

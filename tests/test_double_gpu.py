@@ -93,3 +93,82 @@ def test_train_exact_gp_double_flag(gpu_device):
     metrics, pred, model = train_exact_gp(X, y, Xs, ys, "additive_rp", mk, tk, devices=("cuda:0",), double=True)
     assert model.covar_module.base_kernel.raw_lengthscale.dtype == torch.float64
     assert pred.dtype == torch.float32 and np.isfinite(metrics["test_nll"])
+
+
+@pytest.mark.parametrize("rule,weighted", [("shared", False), ("shared", True), ("reference", False), ("reference", True)])
+def test_ski_float64_kernels_match_oracle(gpu_device, rule, weighted):
+    """rpgp_ski_f64_* (the `--double` path of the `ski: true` specifications) against the float64 dense SKI oracle: product
+    (square with noise, rectangular), diagonal, dense block, bilinear derivative incl. the per-projection parts — at float64
+    accuracy, for both grid rules and with per-projection output scales."""
+    from oracle import ski as sko
+    from rpgp_amd import ops
+    from tests.oracle_backend import OracleBackend
+    rng = np.random.default_rng(7)
+    N, M, J, T, G = 900, 300, 4, 5, 128
+    Z = rng.standard_normal((N, J)) * np.array([1.0, 0.5, 2.0, 1.3])
+    Zs = rng.standard_normal((M, J)) * 0.8
+    V, w = rng.standard_normal((N, T)), (rng.uniform(0.3, 1.4, size=J) if weighted else None)
+    Zt, Zst, Vt = (torch.from_numpy(a).to(gpu_device) for a in (Z, Zs, V))
+    wt = None if w is None else torch.from_numpy(w).to(gpu_device)
+    gp = ops.ski_grid(Zt, Zst, G, weights=wt, rule=rule)
+    assert gp.dtype == torch.float64
+    grid = sko.grid_params(Z, Zs, G) if rule == "shared" else sko.grid_params_reference(Z, Zs, G)
+    K = sko.dense_kernel(Z, Z, 0.7, G, grid, w)
+    Kx = sko.dense_kernel(Zs, Z, 0.7, G, grid, w)
+    out = ops.ski_mvm(Zt, Zt, gp, Vt, 0.7, 0.2, G)
+    assert out.dtype == torch.float64 and _rel(out.cpu().numpy(), K @ V + 0.2 * V) < 1e-12
+    assert _rel(ops.ski_mvm(Zst, Zt, gp, Vt, 0.7, 0.0, G).cpu().numpy(), Kx @ V) < 1e-12
+    assert _rel(ops.ski_diag(Zt, gp, 0.7, G).cpu().numpy(), np.diag(K)) < 1e-12
+    assert _rel(ops.ski_dense(Zst, Zt, gp, 0.7, G).cpu().numpy(), Kx) < 1e-12
+    L, R = rng.standard_normal((N, T)), rng.standard_normal((N, T))
+    gZ, gs, gc = ops.ski_bilinear_grad_comp(Zt, gp, torch.from_numpy(L).to(gpu_device), torch.from_numpy(R).to(gpu_device), 0.7, G)
+    obj = sko.bilinear_objective(Z, L, R, 0.7, G, grid, w)
+    assert abs(float(gs) - obj / 0.7) < 1e-10 * abs(obj / 0.7) + 1e-9
+    assert abs(float(gc.sum()) - float(gs)) < 1e-10 * abs(float(gs)) + 1e-9
+    eps = 1e-6
+    for (i, j) in [(0, 0), (N // 2, J - 1), (N - 1, 1)]:
+        Zp, Zm = Z.copy(), Z.copy()
+        Zp[i, j] += eps
+        Zm[i, j] -= eps
+        fd = (sko.bilinear_objective(Zp, L, R, 0.7, G, grid, w) - sko.bilinear_objective(Zm, L, R, 0.7, G, grid, w)) / (2 * eps)
+        assert abs(float(gZ[i, j]) - fd) < 1e-5 * abs(fd) + 1e-6
+
+
+def test_ski_model_in_double_matches_the_float32_model(gpu_device):
+    """`--double` with `ski: true` end to end (train_exact_gp, CG regime): the float64 model's objective, gradients and
+    predictions against the float32 model's at the same parameters (interpolation and solver tolerances apart, the same GP)."""
+    from rpgp_amd import settings
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    gen = torch.Generator().manual_seed(2)
+    N, d, J = 2500, 5, 3
+    X = torch.randn(N, d, generator=gen)
+    y = torch.sin(X).sum(1) + 0.1 * torch.randn(N, generator=gen)
+    y = (y - y.mean()) / y.std()
+    Xs = torch.randn(40, d, generator=gen)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        torch.manual_seed(4)
+        np.random.seed(4)
+        model, lik = create_exact_gp(X.to(gpu_device, dt), y.to(gpu_device, dt), "additive_rp", J=J, noise_prior=True,
+                                     kernel_type="RBF", learn_proj=False, prescale=True, space_proj=True, ski=True,
+                                     ski_options={"grid_size": 256, "num_dims": 1})
+        model = model.to(gpu_device, dt)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        model.train()
+        with settings.deterministic_probes(True), settings.cg_tolerance(1e-5), settings.max_cg_iterations(2000):
+            loss = -mll(model(model.train_inputs), model.train_targets)
+            loss.backward()
+        grads = {k: p.grad.detach().double().cpu().reshape(-1) for k, p in model.named_parameters() if p.grad is not None}
+        model.eval()
+        with torch.no_grad(), settings.eval_cg_tolerance(1e-6), settings.max_cg_iterations(2000):
+            out = model(Xs.to(gpu_device, dt))
+            res[dt] = (loss.item(), grads, out.mean.double().cpu(), out.variance.double().cpu())
+        assert all(p.dtype == dt for p in model.parameters())
+    a, b = res[torch.float32], res[torch.float64]
+    assert abs(a[0] - b[0]) < 2e-2 * abs(b[0])          # (SLQ with ten float32 / float64 probe draws: different random numbers)
+    assert (a[2] - b[2]).norm() < 2e-3 * b[2].norm() and (a[3] - b[3]).abs().max() < 2e-3 * b[3].abs().max() + 1e-4
+    for k in b[1]:
+        if "noise" in k or "outputscale" in k or "constant" in k:
+            continue                                    # (log-det gradients carry the probe noise)
+        assert (a[1][k] - b[1][k]).norm() < 0.15 * b[1][k].norm() + 1e-3

@@ -264,9 +264,9 @@ def test_weighted_ski_kinds_track_the_exact_kernel(oracle_backend, kind, model_k
         assert gw0 is None and gw1 is None
 
 
-def test_double_family_kinds_train_and_ski_is_refused(oracle_backend):
+def test_double_family_kinds_and_ski_train(oracle_backend):
     """`--double` (training_routines.py:481): every family member trains in float64 (runtime-(kind, group) kernels on the
-    device; here the CPU test double); only the grid-interpolation operator refuses."""
+    device; here the CPU test double)."""
     from rpgp_amd.training import train_exact_gp
     X, y = _problem(30, 4)
     tk = {"verbose": False, "optimizer": "adam", "max_iter": 2, "lr": 0.1, "patience": 20, "smooth": True}
@@ -276,9 +276,12 @@ def test_double_family_kinds_train_and_ski_is_refused(oracle_backend):
                                           learn_proj=False, prescale=True))):
         metrics, pred, model = train_exact_gp(X, y, X, y, kind, mk, tk, double=True, skip_random_restart=True)
         assert all(p.dtype == torch.float64 for p in model.parameters()) and np.isfinite(metrics["test_nll"])
-    with pytest.raises(NotImplementedError):
-        train_exact_gp(X, y, X, y, "additive_rp", dict(J=3, noise_prior=True, learn_proj=False, prescale=True, ski=True,
-                                                      ski_options={"grid_size": 64, "num_dims": 1}), tk, double=True)
+    # ... and (round 4) the grid-interpolation operator: float64 parity kernels (rpgp_ski_f64.hip)
+    metrics, pred, model = train_exact_gp(X, y, X, y, "additive_rp",
+                                          dict(J=3, noise_prior=True, learn_proj=False, prescale=True, ski=True,
+                                               ski_options={"grid_size": 64, "num_dims": 1}), tk, double=True,
+                                          skip_random_restart=True)
+    assert all(p.dtype == torch.float64 for p in model.parameters()) and np.isfinite(metrics["test_nll"])
 
 
 def test_multi_additive_kernel_groups_and_operator(oracle_backend):

@@ -30,6 +30,9 @@ CASES = [
     ("GAM_spec", "synthetic:kin8nm", ["--double"]),
     ("additive_rp_prescale_J1_K20", "synthetic:kin8nm", ["--ablation", "--k", "3", "6", "7"]),
     ("additive_spread_prescale_Jd", "synthetic:kin8nm", ["--double"]),
+    # ... and for the grid-interpolation operator (rpgp_ski_f64.hip)
+    ("additive_spread_prescale_Jd_ski", "synthetic:kin8nm", ["--double"]),
+    ("additive_rp_J20_K1_ski", "synthetic:kin8nm", ["--double"]),
 ]
 out = open(os.path.join("gpurun_out", "r4_runner_flags_soak.jsonl"), "w")
 bad = 0

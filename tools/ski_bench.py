@@ -6,7 +6,7 @@ import torch
 from rpgp_amd import ops
 dev = torch.device("cuda:0")
 reps = int(os.environ.get("SKI_REPS", "50"))
-for (N, J) in [(391386, 3), (50000, 20)]:
+for (N, J) in [(391386, 3), (50000, 20)][:int(os.environ.get("SKI_SHAPES", "2"))]:
     g = torch.Generator().manual_seed(0)
     Z = torch.randn(N, J, generator=g).to(dev)
     gp = ops.ski_grid(Z, None, 1024)
@@ -19,7 +19,7 @@ for (N, J) in [(391386, 3), (50000, 20)]:
             ops.SkiPlan(Z, gp, 1024)
         e1.record(); torch.cuda.synchronize()
         print(json.dumps({"workload": "SKI plan N=%d J=%d G=1024" % (N, J), "ms_per_plan": round(e0.elapsed_time(e1) / 5, 4)}), flush=True)
-    for T in (1, 11):
+    for T in [int(t) for t in os.environ.get("SKI_TS", "1,11").split(",")]:
         V = torch.randn(N, T, generator=g).to(dev)
         out = ops.ski_mvm(Z, Z, gp, V, 1.0 / J, 0.1, 1024, plan=plan)
         torch.cuda.synchronize()

@@ -234,6 +234,121 @@ __global__ __launch_bounds__(256) void ski_scatter_sorted_kernel(const int *__re
   }
 }
 
+// ---- scatter, one workgroup per CELL (round 4) ------------------------------------------------------------------------------
+// The item form above starts ~7 600 short workgroups (<= 256 points each) whose lifetime is a chain of dependent loads (item
+// record -> point indices -> V rows), and leaves the per-cell sums to a second kernel that walks the items of four neighbouring
+// cells per output.  Here a workgroup owns one interpolation cell of one projection and walks ALL its points, 256 per round
+// (wave w takes 64 of them), with the next round's point indices requested before the current round's V rows are consumed:
+// cell bounds -> indices -> rows is paid once per cell, not once per 256 points; the four taps' sums of the whole cell leave in
+// one record (cellpart[cell][tap][t]), so the histogram is four shifted reads per entry (ski_cellsum4_kernel) — no item
+// lists.  Sums: per lane over the rounds, then the lanes of a wave (xor tree), then the four waves in order: fixed order,
+// bitwise reproducible.  Same lane layout as the item kernel.
+template <int LPP, int CPL>
+__global__ __launch_bounds__(256) void ski_scatter_cell_kernel(const int *__restrict__ perm, const float4 *__restrict__ wsort,
+                                                               const int *__restrict__ cell_start, const float *__restrict__ V,
+                                                               float *__restrict__ cellpart, int T, int t0, int tcnt) {
+  constexpr int TT = LPP * CPL;
+  constexpr int PPW = 64 / LPP;
+  constexpr int STEPS = 64 / PPW;
+  __shared__ float sP[4][4][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cell = blockIdx.x;
+  const int sb = cell_start[cell], se = cell_start[cell + 1];
+  const int c = lane % LPP, pg = lane / LPP;
+  float acc[4][CPL];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < CPL; ++r) acc[k][r] = 0.f;
+  int base = sb + wave * 64;
+  int pin[STEPS];
+  if (base < se) {
+    const int cnt = se - base < 64 ? se - base : 64;
+#pragma unroll
+    for (int m = 0; m < STEPS; ++m) {
+      const int src = m * PPW + pg;
+      pin[m] = perm[base + (src < cnt ? src : 0)];
+    }
+  }
+  for (; base < se; base += 256) {
+    const int cnt = se - base < 64 ? se - base : 64;
+    int pi[STEPS];
+#pragma unroll
+    for (int m = 0; m < STEPS; ++m) pi[m] = pin[m];
+    const int nbase = base + 256;
+    if (nbase < se) {                          // next round's indices: in flight while this round's rows arrive
+      const int ncnt = se - nbase < 64 ? se - nbase : 64;
+#pragma unroll
+      for (int m = 0; m < STEPS; ++m) {
+        const int src = m * PPW + pg;
+        pin[m] = perm[nbase + (src < ncnt ? src : 0)];
+      }
+    }
+    float v[STEPS][CPL];
+    float4 w[STEPS];
+#pragma unroll
+    for (int m = 0; m < STEPS; ++m) {
+      const int src = m * PPW + pg;
+      w[m] = wsort[base + (src < cnt ? src : 0)];
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) {
+        const int col = c + LPP * r;
+        const bool ok = src < cnt && col < tcnt;
+        const float x = V[ok ? (size_t)pi[m] * T + t0 + col : 0];
+        v[m][r] = ok ? x : 0.f;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < STEPS; ++m) {
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) {
+        acc[0][r] = __builtin_fmaf(w[m].x, v[m][r], acc[0][r]);
+        acc[1][r] = __builtin_fmaf(w[m].y, v[m][r], acc[1][r]);
+        acc[2][r] = __builtin_fmaf(w[m].z, v[m][r], acc[2][r]);
+        acc[3][r] = __builtin_fmaf(w[m].w, v[m][r], acc[3][r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = LPP; off < 64; off <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) acc[k][r] += __shfl_xor(acc[k][r], off, 64);
+  }
+  if (lane < LPP) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) sP[wave][k][c + LPP * r] = acc[k][r];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * TT) {
+    const int k = threadIdx.x / TT, tt = threadIdx.x % TT;
+    if (tt < tcnt) cellpart[((size_t)cell * 4 + k) * TT + tt] = ((sP[0][k][tt] + sP[1][k][tt]) + sP[2][k][tt]) + sP[3][k][tt];
+  }
+}
+
+// hist[j][g][hoff + t] (row stride HT, float64) = sum_k cellpart[cell (j, g - k)][k][t]   (cells 0 .. G - 4)
+__global__ __launch_bounds__(256) void ski_cellsum4_kernel(const float *__restrict__ cellpart, double *__restrict__ hist, int J,
+                                                           int G, int TT, int tcnt, int HT, int hoff) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)J * G * TT) return;
+  const int t = (int)(e % TT);
+  const long long jg = e / TT;
+  const int g = (int)(jg % G), j = (int)(jg / G);
+  if (t >= tcnt) return;
+  float x[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = g - k;
+    const bool ok = !(cc < 0 || cc > G - 4);
+    const float y = cellpart[(((size_t)j * G + (ok ? cc : 0)) * 4 + k) * TT + t];
+    x[k] = ok ? y : 0.f;
+  }
+  hist[jg * HT + hoff + t] = (((double)x[0] + (double)x[1]) + (double)x[2]) + (double)x[3];
+}
+
 // hist[j][g][hoff + t] (row stride HT, float64) = sum_k sum_{items of cell (j, g - k)} partial[item][k][t]
 __global__ __launch_bounds__(256) void ski_cellsum_kernel(const float *__restrict__ partial, const int *__restrict__ item_start,
                                                           double *__restrict__ hist, int J, int G, int TT, int tcnt, int HT,
@@ -409,9 +524,31 @@ int scatter_planned(const PlanView &pv, const float *V, double *hist, float *par
   const int cells = J * G;
   const long long items = max_items(N, J, G);
   const unsigned nb = (unsigned)items;
+  // one workgroup per cell + four shifted reads (round 4), or the item form + item-walking cell sums (RPGP_SKI_SCATTER=item)
+  static const bool by_cell = [] {
+    const char *e = getenv("RPGP_SKI_SCATTER");
+    return !(e && e[0] == 'i');
+  }();
   for (int t0 = 0; t0 < T;) {
     const int tt = ski_tpiece(T - t0);
     const int tcnt = (T - t0 < tt) ? T - t0 : tt;
+    const long long n = (long long)J * G * tt;
+    if (by_cell) {
+      if (tt == 1)
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<1, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.perm, pv.wsort, pv.cell_start, V, partial, T, t0, tcnt);
+      else if (tt == 4)
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.perm, pv.wsort, pv.cell_start, V, partial, T, t0, tcnt);
+      else
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 3>), dim3((unsigned)cells), dim3(256), 0, st, pv.perm, pv.wsort, pv.cell_start, V, partial, T, t0, tcnt);
+      int rc = launch_status();
+      if (rc) return rc;
+      hipLaunchKernelGGL(ski_cellsum4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, hist, J, G, tt, tcnt,
+                         HT, hoff + t0);
+      rc = launch_status();
+      if (rc) return rc;
+      t0 += tcnt;
+      continue;
+    }
     if (tt == 1)
       hipLaunchKernelGGL((ski_scatter_sorted_kernel<1, 1>), dim3(nb), dim3(256), 0, st, pv.perm, pv.wsort, pv.item_info, pv.item_start, cells, V, partial, T, t0, tcnt);
     else if (tt == 4)
@@ -420,7 +557,6 @@ int scatter_planned(const PlanView &pv, const float *V, double *hist, float *par
       hipLaunchKernelGGL((ski_scatter_sorted_kernel<4, 3>), dim3(nb), dim3(256), 0, st, pv.perm, pv.wsort, pv.item_info, pv.item_start, cells, V, partial, T, t0, tcnt);
     int rc = launch_status();
     if (rc) return rc;
-    const long long n = (long long)J * G * tt;
     hipLaunchKernelGGL(ski_cellsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, pv.item_start, hist, J,
                        G, tt, tcnt, HT, hoff + t0);
     rc = launch_status();

@@ -23,7 +23,29 @@ def _require(t, name, ndim=None, allow64=False):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the current stream of the current device.  (`torch.cuda.current_stream().cuda_stream` is the same value
+    through ~10 us of Python — 13 calls per optimiser step; the step is host-bound between its launches)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(device):
+    """`torch.cuda.device(device)` — entered only when `device` is not the current device already (the context manager reads and
+    restores the device through several Python layers: ~8 us per entry, ~20 entries per optimiser step)."""
+    idx = device.index
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def _workspace(device, nbytes):
@@ -47,7 +69,7 @@ def space_equally(P, lr, niter):
     Q = _require(P.detach().clone(), "P", 2)
     J, d = Q.shape
     loss = torch.empty(1, dtype=torch.float32, device=Q.device)
-    with torch.cuda.device(Q.device):
+    with _on(Q.device):
         _lib.check(lib.rpgp_space_equally(Q.data_ptr(), J, d, float(lr), int(niter), loss.data_ptr(), _stream()),
                    "rpgp_space_equally")
     return Q, loss.reshape(1, 1)
@@ -64,7 +86,7 @@ def project(X, Peff):
     J = Peff.shape[1]
     Z = torch.empty((N, J), dtype=X.dtype, device=X.device)
     fn = lib.rpgp_project_f64 if X.dtype == torch.float64 else lib.rpgp_project
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         _lib.check(fn(X.data_ptr(), Peff.data_ptr(), Z.data_ptr(), N, d, J, _stream()), "rpgp_project")
     return Z
 
@@ -80,7 +102,7 @@ def project_grad(X, G):
     J = G.shape[1]
     out = torch.empty((d, J), dtype=X.dtype, device=X.device)
     fn = lib.rpgp_project_grad_f64 if X.dtype == torch.float64 else lib.rpgp_project_grad
-    with torch.cuda.device(X.device):
+    with _on(X.device):
         _lib.check(fn(X.data_ptr(), G.data_ptr(), out.data_ptr(), N, d, J, _stream()), "rpgp_project_grad")
     return out
 
@@ -109,11 +131,11 @@ def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None, shard=None):
     if Z.dtype == torch.float64:
         if V2.dtype != torch.float64 or world != 1:
             raise TypeError("float64 MVM needs float64 V (and does not support pair-sharding)")
-        with torch.cuda.device(Z.device):
+        with _on(Z.device):
             _lib.check(lib.rpgp_mvm_f64(Z.data_ptr(), Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, N, J, J, T, j0, j1,
                                         float(scale), float(noise), _stream()), "rpgp_mvm_f64")
         return out.squeeze(1) if squeeze else out
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, world, rank)
         ws = _workspace(Z.device, nbytes)
         _lib.check(lib.rpgp_mvm_sym_range(Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1, world, rank,
@@ -136,7 +158,7 @@ class Prepared:
         self.buf = None
         if self.J > 64:
             return
-        with torch.cuda.device(Z.device):
+        with _on(Z.device):
             nbytes = lib.rpgp_prepare_bytes(self.N, self.J)
             self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=Z.device)
             _lib.check(lib.rpgp_prepare(Z.data_ptr(), self.N, self.J, self.J, self.buf.data_ptr(), self.buf.numel(),
@@ -161,7 +183,7 @@ def mvm_sym_prepared(prep, V, scale, noise=0.0, j0=0, j1=None, out=None, shard=N
     T = V2.shape[1]
     if out is None:
         out = torch.empty_like(V2)
-    with torch.cuda.device(prep.device):
+    with _on(prep.device):
         nbytes = lib.rpgp_mvm_sym_range_workspace_bytes(N, T, world, rank)
         ws = _workspace(prep.device, nbytes)
         _lib.check(lib.rpgp_mvm_sym_prepared_range(prep.buf.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, j0, j1,
@@ -184,11 +206,11 @@ def mvm_rect(Z1, Z2, V, scale, j0=0, j1=None):
     T = V2.shape[1]
     out = torch.empty((M, T), dtype=Z1.dtype, device=Z1.device)
     if Z1.dtype == torch.float64:
-        with torch.cuda.device(Z1.device):
+        with _on(Z1.device):
             _lib.check(lib.rpgp_mvm_f64(Z1.data_ptr(), Z2.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N, J, J, T, j0,
                                         j1, float(scale), 0.0, _stream()), "rpgp_mvm_f64")
         return out.squeeze(1) if squeeze else out
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         nbytes = lib.rpgp_mvm_rect_workspace_bytes(M, N, T)
         ws = _workspace(Z1.device, nbytes)
         _lib.check(lib.rpgp_mvm_rect(Z1.data_ptr(), Z2.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N, J, J, T,
@@ -211,7 +233,7 @@ def dense(Z1, Z2, scale, j0=0, j1=None, pad=False):
     j1 = J if j1 is None else j1
     if Z1.dtype == torch.float64:
         out = torch.empty((M, N), dtype=Z1.dtype, device=Z1.device)
-        with torch.cuda.device(Z1.device):
+        with _on(Z1.device):
             _lib.check(lib.rpgp_dense_f64(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, j0, j1,
                                           float(scale), _stream()), "rpgp_dense_f64")
         return out
@@ -219,7 +241,7 @@ def dense(Z1, Z2, scale, j0=0, j1=None, pad=False):
     out = torch.empty((M, ld), dtype=Z1.dtype, device=Z1.device)
     if ld != N:
         out = out[:, :N]
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         _lib.check(lib.rpgp_dense(Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, ld, j0, j1, float(scale),
                                   _stream()), "rpgp_dense")
     return out
@@ -240,12 +262,12 @@ def bilinear_grad(Z, L, R, scale, j0=0, j1=None):
     gs = torch.zeros((), dtype=Z.dtype, device=Z.device)
     if Z.dtype == torch.float64:
         scratch = torch.empty(N, dtype=torch.float64, device=Z.device)
-        with torch.cuda.device(Z.device):
+        with _on(Z.device):
             _lib.check(lib.rpgp_bilinear_grad_f64(Z.data_ptr(), L2.data_ptr(), R2.data_ptr(), gZ.data_ptr(), gs.data_ptr(),
                                                   N, J, J, T, j0, j1, float(scale), scratch.data_ptr(), _stream()),
                        "rpgp_bilinear_grad_f64")
         return gZ, gs
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         if T <= 12:
             nbytes = lib.rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)
             ws = _workspace(Z.device, nbytes)
@@ -282,12 +304,12 @@ def bilinear_grad_dense(Z, S, scale, j0=0, j1=None):
     gs = torch.zeros((), dtype=Z.dtype, device=Z.device)
     if Z.dtype == torch.float64:
         scratch = torch.empty(N, dtype=torch.float64, device=Z.device)
-        with torch.cuda.device(Z.device):
+        with _on(Z.device):
             _lib.check(lib.rpgp_bilinear_grad_dense_f64(Z.data_ptr(), S.data_ptr(), gZ.data_ptr(), gs.data_ptr(), N, J, J,
                                                         N, j0, j1, float(scale), scratch.data_ptr(), _stream()),
                        "rpgp_bilinear_grad_dense_f64")
         return gZ, gs
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         nbytes = lib.rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)
         ws = _workspace(Z.device, nbytes)
         _lib.check(lib.rpgp_bilinear_grad_dense(Z.data_ptr(), S.data_ptr(), gZ.data_ptr(), gs.data_ptr(), N, J, J, N,
@@ -303,7 +325,7 @@ def pivoted_cholesky(Z, scale, rank):
     N, J = Z.shape
     L = torch.empty((N, rank), dtype=torch.float32, device=Z.device)
     work = torch.empty(N + _lib.RPGP_PIVCHOL_SCRATCH, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         _lib.check(lib.rpgp_pivoted_cholesky(Z.data_ptr(), L.data_ptr(), work.data_ptr(), N, J, J, int(rank),
                                              float(scale), _stream()), "rpgp_pivoted_cholesky")
     return L
@@ -316,7 +338,7 @@ def family_pivoted_cholesky(fam, Z, scale, rank, weight_sum):
     N, J = Z.shape
     L = torch.empty((N, rank), dtype=torch.float32, device=Z.device)
     work = torch.empty(N + _lib.RPGP_PIVCHOL_SCRATCH, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         _lib.check(lib.rpgp_family_pivoted_cholesky(fam.ref, Z.data_ptr(), L.data_ptr(), work.data_ptr(), N, J, int(rank),
                                                     float(scale), float(weight_sum), _stream()),
                    "rpgp_family_pivoted_cholesky")
@@ -334,7 +356,7 @@ def dense_mvm(Kd, V, noise=0.0):
     V2, squeeze = _as_matrix(V, N, "V")
     T = V2.shape[1]
     out = torch.empty_like(V2)
-    with torch.cuda.device(Kd.device):
+    with _on(Kd.device):
         _lib.check(lib.rpgp_dense_mvm(Kd.data_ptr(), V2.data_ptr(), out.data_ptr(), N, Kd.stride(0), T, float(noise),
                                       _stream()), "rpgp_dense_mvm")
     return out.squeeze(1) if squeeze else out
@@ -358,7 +380,7 @@ class SymCache:
         self.buf = torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=Z.device)
         self.nbytes = nbytes
         self.layout = _lib.RPGP_SYMCACHE_WIDE if wide else _lib.RPGP_SYMCACHE_THIN
-        with torch.cuda.device(Z.device):
+        with _on(Z.device):
             _lib.check(lib.rpgp_symcache_build(Z.data_ptr(), self.buf.data_ptr(), nbytes, self.N, Z.stride(0), j0, j1,
                                                self.layout, self.world, self.rank, _stream()), "rpgp_symcache_build")
 
@@ -373,7 +395,7 @@ def symcache_mvm(cache, V, scale, noise=0.0):
     V2, squeeze = _as_matrix(V, cache.N, "V")
     T = V2.shape[1]
     out = torch.empty_like(V2)
-    with torch.cuda.device(cache.device):
+    with _on(cache.device):
         ws = _workspace(cache.device, lib.rpgp_symcache_workspace_bytes(cache.N, T, cache.world, cache.rank))
         _lib.check(lib.rpgp_symcache_mvm(cache.buf.data_ptr(), cache.nbytes, cache.layout, V2.data_ptr(), out.data_ptr(), cache.N, T,
                                          float(scale), float(noise), cache.world, cache.rank, ws.data_ptr(), ws.numel(),
@@ -403,7 +425,7 @@ def ski_grid(Z1, Z2=None, grid_size=1024, weights=None, rule="shared"):
     per_proj = rule == "reference"
     gp = torch.empty(4 + 4 * J if per_proj else (4 if weights is None else 4 + J), dtype=torch.float32, device=Z1.device)
     fn = lib.rpgp_ski_grid_per_projection if per_proj else lib.rpgp_ski_grid
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, 1))
         if Z2 is None:
             rc = fn(Z1.data_ptr(), N1, J, None, 0, 0, J, grid_size, gp.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
@@ -436,7 +458,7 @@ class SkiPlan:
         if nbytes == 0:
             return
         self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=Z.device)
-        with torch.cuda.device(Z.device):
+        with _on(Z.device):
             ws = _workspace(Z.device, lib.rpgp_ski_plan_workspace_bytes(self.N, self.J, self.G))
             _lib.check(lib.rpgp_ski_plan(Z.data_ptr(), gp.data_ptr(), self.N, Z.stride(0), self.J, self.G, self.buf.data_ptr(),
                                          self.buf.numel(), ws.data_ptr(), ws.numel(), _stream()), "rpgp_ski_plan")
@@ -464,14 +486,14 @@ def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024, plan=None):
     T = V2.shape[1]
     out = torch.empty((M, T), dtype=torch.float32, device=Z1.device)
     if plan is not None and plan.ok and T <= 12 and M == N and plan.N == N and plan.J == J and plan.G == grid_size:
-        with torch.cuda.device(Z1.device):
+        with _on(Z1.device):
             ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
             rc = lib.rpgp_ski_mvm_planned(plan.buf.data_ptr(), Z1.data_ptr(), gp.data_ptr(), V2.data_ptr(), out.data_ptr(), N,
                                           J, J, grid_size, T, float(scale), float(noise), ws.data_ptr(), ws.numel(), _stream())
         if rc != _lib.RPGP_EWORKSPACE:              # (too many points for the planned form: the plain product below)
             _lib.check(rc, "rpgp_ski_mvm_planned")
             return out.squeeze(1) if squeeze else out
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         ws = _workspace(Z1.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
         _lib.check(lib.rpgp_ski_mvm(Z1.data_ptr(), Z2.data_ptr(), gp.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N,
                                     J, J, J, grid_size, T, float(scale), float(noise), ws.data_ptr(), ws.numel(),
@@ -504,14 +526,14 @@ def ski_scatter(Z, gp, V, grid_size=1024, plan=None):
     T = V2.shape[1]
     hist = torch.empty((J, grid_size, T), dtype=torch.float64, device=Z.device)
     if plan is not None and plan.ok and T <= 12 and plan.N == N and plan.J == J and plan.G == grid_size:
-        with torch.cuda.device(Z.device):
+        with _on(Z.device):
             ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
             rc = lib.rpgp_ski_scatter_planned(plan.buf.data_ptr(), V2.data_ptr(), hist.data_ptr(), N, J, grid_size, T,
                                               ws.data_ptr(), ws.numel(), _stream())
         if rc != _lib.RPGP_EWORKSPACE:
             _lib.check(rc, "rpgp_ski_scatter_planned")
             return hist
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
         _lib.check(lib.rpgp_ski_scatter(Z.data_ptr(), gp.data_ptr(), V2.data_ptr(), hist.data_ptr(), N, J, J, grid_size,
                                         T, ws.data_ptr(), ws.numel(), _stream()), "rpgp_ski_scatter")
@@ -526,7 +548,7 @@ def ski_grid_product(hist, gp, grid_size=1024):
     hist = hist.contiguous()
     J, G, T = hist.shape
     H = torch.empty((J, G, T), dtype=torch.float32, device=hist.device)
-    with torch.cuda.device(hist.device):
+    with _on(hist.device):
         _lib.check(lib.rpgp_ski_grid_product(hist.data_ptr(), gp.data_ptr(), H.data_ptr(), J, G, T, _stream()),
                    "rpgp_ski_grid_product")
     return H
@@ -543,7 +565,7 @@ def ski_gather(Z, gp, H, V, scale, noise=0.0, grid_size=1024, plan=None):
     if noise:
         V2, _ = _as_matrix(V, M, "V")
     out = torch.empty((M, T), dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         pl = plan.buf.data_ptr() if (plan is not None and plan.ok and plan.N == M and plan.J == J and plan.G == grid_size) else None
         _lib.check(lib.rpgp_ski_gather_fast(pl, Z.data_ptr(), gp.data_ptr(), H.data_ptr(), None if V2 is None else V2.data_ptr(),
                                             out.data_ptr(), M, J, J, grid_size, T, float(scale), float(noise), _stream()),
@@ -558,7 +580,7 @@ def ski_pivoted_cholesky(Z, gp, scale, rank, grid_size=1024):
     N, J = Z.shape
     L = torch.empty((N, rank), dtype=torch.float32, device=Z.device)
     work = torch.empty(N + _lib.RPGP_PIVCHOL_SCRATCH, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         _lib.check(lib.rpgp_ski_pivoted_cholesky(Z.data_ptr(), gp.data_ptr(), L.data_ptr(), work.data_ptr(), N, J, J,
                                                  int(grid_size), int(rank), float(scale), _stream()),
                    "rpgp_ski_pivoted_cholesky")
@@ -575,7 +597,7 @@ def ski_dense(Z1, Z2, gp, scale, grid_size=1024):
     M, J = Z1.shape
     N = Z2.shape[0]
     out = torch.empty((M, N), dtype=torch.float32, device=Z1.device)
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         _lib.check(lib.rpgp_ski_dense(Z1.data_ptr(), Z2.data_ptr(), gp.data_ptr(), out.data_ptr(), M, N, J, J, N, J,
                                       int(grid_size), float(scale), _stream()), "rpgp_ski_dense")
     return out
@@ -588,7 +610,7 @@ def ski_diag(Z, gp, scale, grid_size=1024):
     Z = _require(Z, "Z", 2)
     N, J = Z.shape
     out = torch.empty(N, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         _lib.check(lib.rpgp_ski_diag(Z.data_ptr(), gp.data_ptr(), out.data_ptr(), N, J, J, grid_size, float(scale),
                                      _stream()), "rpgp_ski_diag")
     return out
@@ -609,7 +631,7 @@ def ski_bilinear_grad(Z, gp, L, R, scale, grid_size=1024):
     scratch = torch.empty(N, dtype=torch.float32, device=Z.device)
     gZp = torch.empty_like(gZ)
     gsp = torch.empty_like(gs)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, min(T, 12)))
         for t0 in range(0, T, 12):
             Lc = L2[:, t0:t0 + 12].contiguous()
@@ -638,7 +660,7 @@ def ski_bilinear_grad_comp(Z, gp, L, R, scale, grid_size=1024):
     gc = torch.zeros(J, dtype=torch.float32, device=Z.device)
     scratch = torch.empty(N * (J + 1), dtype=torch.float32, device=Z.device)
     gZp, gsp, gcp = torch.empty_like(gZ), torch.empty_like(gs), torch.empty_like(gc)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, min(T, 12)))
         for t0 in range(0, T, 12):
             Lc = L2[:, t0:t0 + 12].contiguous()
@@ -668,14 +690,14 @@ def ski_bilinear_scatter(Z, gp, L, R, grid_size=1024, plan=None):
     L2, _ = _as_matrix(L, N, "L")
     R2, _ = _as_matrix(R, N, "R")
     if plan is not None and plan.ok and plan.N == N and plan.J == J and plan.G == grid_size:
-        with torch.cuda.device(Z.device):
+        with _on(Z.device):
             ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
             rc = lib.rpgp_ski_bilinear_scatter_planned(plan.buf.data_ptr(), L2.data_ptr(), R2.data_ptr(), hist.data_ptr(), N,
                                                        J, grid_size, T, ws.data_ptr(), ws.numel(), _stream())
         if rc != _lib.RPGP_EWORKSPACE:
             _lib.check(rc, "rpgp_ski_bilinear_scatter_planned")
             return hist
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
         _lib.check(lib.rpgp_ski_bilinear_scatter(Z.data_ptr(), gp.data_ptr(), L2.data_ptr(), R2.data_ptr(), hist.data_ptr(),
                                                  N, J, J, grid_size, T, ws.data_ptr(), ws.numel(), _stream()),
@@ -698,7 +720,7 @@ def ski_bilinear_finish(Z, gp, hist2, L, R, scale, grid_size=1024, comp=False):
     R2, _ = _as_matrix(R, N, "R")
     hist2 = hist2.contiguous()
     scratch = torch.empty(N * (J + 1) if comp else N, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_ski_workspace_bytes(J, grid_size, T))
         _lib.check(lib.rpgp_ski_bilinear_finish(Z.data_ptr(), gp.data_ptr(), hist2.data_ptr(), L2.data_ptr(), R2.data_ptr(),
                                                 gZ.data_ptr(), gs.data_ptr(), None if gc is None else gc.data_ptr(), N, J, J,
@@ -729,7 +751,7 @@ def gram_f64(A, B):
     if B.shape[0] != N or K > 64 or T > 64 or K == 0 or T == 0:
         raise ValueError("gram_f64: N x K and N x T with 1 <= K, T <= 64 required")
     out = torch.empty((K, T), dtype=torch.float64, device=A.device)
-    with torch.cuda.device(A.device):
+    with _on(A.device):
         ws = _workspace(A.device, lib.rpgp_gram_f64_workspace_bytes(K, T))
         _lib.check(lib.rpgp_gram_f64(A.data_ptr(), lda, B.data_ptr(), ldb, N, K, T, out.data_ptr(), ws.data_ptr(),
                                      ws.numel(), _stream()), "rpgp_gram_f64")
@@ -748,7 +770,7 @@ def woodbury_apply(L, R, Tm, noise):
         raise ValueError("woodbury_apply: L N x K, R N x T, Tm K x T float64 with K, T <= 64 required")
     Tm = Tm.contiguous()
     out = torch.empty((N, T), dtype=torch.float32, device=L.device)
-    with torch.cuda.device(L.device):
+    with _on(L.device):
         _lib.check(lib.rpgp_woodbury_apply(L.data_ptr(), ldl, R.data_ptr(), ldr, Tm.data_ptr(), float(noise),
                                            out.data_ptr(), T, N, K, T, _stream()), "rpgp_woodbury_apply")
     return out
@@ -765,7 +787,7 @@ def woodbury_setup(gram, noise):
     K = gram.shape[0]
     out = torch.empty((2 * K * K + 1,), dtype=torch.float64, device=gram.device)
     chol, cinv, logdet = out[:K * K].view(K, K), out[K * K:2 * K * K].view(K, K), out[2 * K * K:]
-    with torch.cuda.device(gram.device):
+    with _on(gram.device):
         _lib.check(lib.rpgp_woodbury_setup(gram.data_ptr(), float(noise), K, chol.data_ptr(), cinv.data_ptr(),
                                            logdet.data_ptr(), _stream()), "rpgp_woodbury_setup")
     return chol, cinv, logdet
@@ -839,7 +861,7 @@ def _generic_mvm(fam, Z1, Z2, V, scale, noise):
     N = M if Z2 is None else Z2.shape[0]
     V2, squeeze = _generic_matrix(fam, V, N, "V")
     out = torch.empty((M, V2.shape[1]), dtype=fam.dtype, device=Z1.device)
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         for t0 in range(0, V2.shape[1], 16):
             Vc = V2[:, t0:t0 + 16].contiguous()
             oc = torch.empty((M, Vc.shape[1]), dtype=fam.dtype, device=Z1.device)
@@ -861,7 +883,7 @@ def family_mvm_sym(fam, Z, V, scale, noise=0.0):
     V2, squeeze = _as_matrix(V, N, "V")
     T = V2.shape[1]
     out = torch.empty_like(V2)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_family_mvm_workspace_bytes(N, N, T, 1))
         _lib.check(lib.rpgp_family_mvm_sym(fam.ref, Z.data_ptr(), V2.data_ptr(), out.data_ptr(), N, J, T, float(scale),
                                            float(noise), ws.data_ptr(), ws.numel(), _stream()), "rpgp_family_mvm_sym")
@@ -880,7 +902,7 @@ def family_mvm_rect(fam, Z1, Z2, V, scale):
     V2, squeeze = _as_matrix(V, N, "V")
     T = V2.shape[1]
     out = torch.empty((M, T), dtype=torch.float32, device=Z1.device)
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         ws = _workspace(Z1.device, lib.rpgp_family_mvm_workspace_bytes(M, N, T, 0))
         _lib.check(lib.rpgp_family_mvm_rect(fam.ref, Z1.data_ptr(), Z2.data_ptr(), V2.data_ptr(), out.data_ptr(), M, N,
                                             J, J, T, float(scale), ws.data_ptr(), ws.numel(), _stream()),
@@ -896,7 +918,7 @@ def family_dense(fam, Z1, Z2, scale):
     M, J = Z1.shape
     N = Z2.shape[0]
     out = torch.empty((M, N), dtype=fam.dtype, device=Z1.device)
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         if fam.generic:
             _lib.check(lib.rpgp_family_generic_dense(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
                                                      Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, float(scale),
@@ -912,7 +934,7 @@ def _generic_bilinear(fam, Z, L, R, S, scale):
     N, J = Z.shape
     gZ = torch.zeros((N, J), dtype=fam.dtype, device=Z.device)
     gc = torch.zeros(fam.ncomp, dtype=fam.dtype, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_family_generic_bilinear_workspace_bytes(fam.code, N, fam.ncomp))
         if S is not None:
             S = S.to(fam.dtype).contiguous()
@@ -951,7 +973,7 @@ def family_bilinear_grad(fam, Z, L, R, scale):
     T = L2.shape[1]
     gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
     gc = torch.zeros(fam.ncomp, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_family_bilinear_grad_workspace_bytes(N, J, fam.ncomp))
         gZp, gcp = torch.empty_like(gZ), torch.empty_like(gc)
         for t0 in range(0, T, 12):      # the derivative is additive over the columns of L, R
@@ -976,7 +998,7 @@ def family_bilinear_grad_dense(fam, Z, S, scale):
     S = _require(S, "S", 2)
     gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
     gc = torch.zeros(fam.ncomp, dtype=torch.float32, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         ws = _workspace(Z.device, lib.rpgp_family_bilinear_grad_workspace_bytes(N, J, fam.ncomp))
         _lib.check(lib.rpgp_family_bilinear_grad_dense(fam.ref, Z.data_ptr(), S.data_ptr(), gZ.data_ptr(), gc.data_ptr(),
                                                        N, J, J, N, float(scale), ws.data_ptr(), ws.numel(), _stream()),
@@ -1055,7 +1077,7 @@ def mbcg_solve(desc, rhs, tolerance, max_iter, min_iter=10, hist_len=0, check_ev
     ah = np.zeros((max(hist_len, 1), 16), dtype=np.float32)
     bh = np.zeros((max(hist_len, 1), 16), dtype=np.float32)
     iters, mres = ctypes.c_int(0), ctypes.c_float(0)
-    with torch.cuda.device(rhs.device):
+    with _on(rhs.device):
         nbytes = lib.rpgp_mbcg_workspace_bytes(ctypes.byref(desc), T, k)
         ws = _workspace(rhs.device, nbytes)
         red_ref = None
@@ -1114,7 +1136,7 @@ def step_hyper(raw_ls, raw_os, raw_noise, mean, W, prescale, min_noise):
     Peff = torch.empty((d, J), dtype=torch.float32, device=W.device)
     dev = torch.empty(8 + 2 * n_ls, dtype=torch.float32, device=W.device)
     os_h, nz_h, mu_h = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         _lib.check(lib.rpgp_step_hyper(raw_ls.data_ptr(), n_ls, raw_os.data_ptr(), raw_noise.data_ptr(), mean.data_ptr(),
                                        W.data_ptr(), d, J, 1 if prescale else 0, float(min_noise), Peff.data_ptr(),
                                        dev.data_ptr(), ctypes.byref(os_h), ctypes.byref(nz_h), ctypes.byref(mu_h), _stream()),
@@ -1136,7 +1158,7 @@ def step_probes(L, e1, e2, sqrt_noise, y, mean_dev):
     probes = torch.empty((N, p), dtype=torch.float32, device=L.device)
     full_rhs = torch.empty((N, p + 1), dtype=torch.float32, device=L.device)
     norms = torch.empty(p, dtype=torch.float32, device=L.device)
-    with torch.cuda.device(L.device):
+    with _on(L.device):
         ws = _workspace(L.device, lib.rpgp_step_probes_workspace_bytes())
         _lib.check(lib.rpgp_step_probes(L.data_ptr(), k, e1.data_ptr(), e2.data_ptr(), float(sqrt_noise), y.data_ptr(),
                                         mean_dev.data_ptr(), N, p, probes.data_ptr(), full_rhs.data_ptr(), norms.data_ptr(),
@@ -1156,7 +1178,7 @@ def step_value(full_rhs, solves, col, logdet, c1, c2):
     ws = _value_ws.get(key)
     if ws is None:              # (zeroed ONCE: the kernel leaves its arrival counter at zero; one buffer per stream)
         ws = _value_ws[key] = torch.zeros(lib.rpgp_step_value_workspace_bytes(), dtype=torch.uint8, device=full_rhs.device)
-    with torch.cuda.device(full_rhs.device):
+    with _on(full_rhs.device):
         _lib.check(lib.rpgp_step_value(full_rhs.data_ptr(), solves.data_ptr(), N, T, int(col), float(logdet), float(c1), float(c2),
                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "rpgp_step_value")
     return out
@@ -1172,7 +1194,7 @@ def step_lr(solves, norms, pre_probes, g, gscale):
     right = torch.empty_like(solves)
     part = torch.empty(lib.rpgp_step_lr_workspace_bytes() // 4, dtype=torch.float32, device=solves.device)
     nparts = ctypes.c_int(0)
-    with torch.cuda.device(solves.device):
+    with _on(solves.device):
         _lib.check(lib.rpgp_step_lr(solves.data_ptr(), norms.data_ptr(), pre_probes.data_ptr(), g.data_ptr(), float(gscale), N, p,
                                     left.data_ptr(), right.data_ptr(), part.data_ptr(), ctypes.byref(nparts), _stream()),
                    "rpgp_step_lr")
@@ -1186,7 +1208,7 @@ def step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyper_dev, gs, partials,
     J, d = W.shape
     out = torch.empty(n_ls + 3, dtype=torch.float32, device=W.device)
     base = out.data_ptr()
-    with torch.cuda.device(W.device):
+    with _on(W.device):
         _lib.check(lib.rpgp_step_hyper_backward(dPeff.data_ptr(), W.data_ptr(), d, J, int(n_ls), 1 if prescale else 0, float(zfac),
                                                 hyper_dev.data_ptr(), gs.data_ptr(), partials.data_ptr(), int(nparts),
                                                 g.data_ptr(), float(gscale), float(dlp_over_n), base, base + 4 * n_ls,
@@ -1238,7 +1260,7 @@ def _ski64_mvm(Z1, Z2, gp, V, scale, noise, grid_size):
     T = V2.shape[1]
     out = torch.empty((M, T), dtype=torch.float64, device=Z1.device)
     same = Z1.data_ptr() == Z2.data_ptr() and M == N
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         for t0 in range(0, T, 64):                       # (column pieces bound the J x G x T workspace)
             Vc = V2[:, t0:t0 + 64].contiguous()
             oc = torch.empty((M, Vc.shape[1]), dtype=torch.float64, device=Z1.device)
@@ -1257,7 +1279,7 @@ def _ski64_dense(Z1, Z2, gp, scale, grid_size):
     M, J = Z1.shape
     N = Z2.shape[0]
     out = torch.empty((M, N), dtype=torch.float64, device=Z1.device)
-    with torch.cuda.device(Z1.device):
+    with _on(Z1.device):
         _lib.check(lib.rpgp_ski_f64_dense(Z1.data_ptr(), Z2.data_ptr(), gp.data_ptr(), out.data_ptr(), M, N, J, J, N, J,
                                           int(grid_size), float(scale), _stream()), "rpgp_ski_f64_dense")
     return out
@@ -1268,7 +1290,7 @@ def _ski64_diag(Z, gp, scale, grid_size):
     Z = _require(Z, "Z", 2, allow64=True)
     N, J = Z.shape
     out = torch.empty(N, dtype=torch.float64, device=Z.device)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         _lib.check(lib.rpgp_ski_f64_diag(Z.data_ptr(), gp.data_ptr(), out.data_ptr(), N, J, J, int(grid_size), float(scale),
                                          _stream()), "rpgp_ski_f64_diag")
     return out
@@ -1286,7 +1308,7 @@ def _ski64_bilinear(Z, gp, L, R, scale, grid_size):
     gs = torch.zeros((), dtype=torch.float64, device=Z.device)
     gc = torch.zeros(J, dtype=torch.float64, device=Z.device)
     gZp, gsp, gcp = torch.empty_like(gZ), torch.empty_like(gs), torch.empty_like(gc)
-    with torch.cuda.device(Z.device):
+    with _on(Z.device):
         for t0 in range(0, T, 64):
             Lc = L2[:, t0:t0 + 64].contiguous()
             Rc = R2[:, t0:t0 + 64].contiguous()

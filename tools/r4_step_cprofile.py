@@ -27,7 +27,7 @@ with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
     t0 = time.perf_counter(); run(steps); torch.cuda.synchronize(); t1 = time.perf_counter()
     print("step %.1f us (no profiler)" % ((t1 - t0) / steps * 1e6))
     pr = cProfile.Profile(); pr.enable(); run(steps); torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); ps = pstats.Stats(pr, stream=s).sort_stats("tottime"); ps.print_stats(45)
+s = io.StringIO(); ps = pstats.Stats(pr, stream=s).sort_stats("tottime"); ps.print_stats(int(os.environ.get('TOPN', '45')))
 txt = s.getvalue()
 # per-step microseconds
 print("(tottime / cumtime below are totals over %d steps: divide by %d; 1 s total = %.0f us per step)" % (steps, steps, 1e6 / steps))

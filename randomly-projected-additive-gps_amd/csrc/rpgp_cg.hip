@@ -441,14 +441,24 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
   const float q_rz = st->rz[cur][tcl], q_res = st->resid[tcl];
   const int q_zero = st->rhs_zero[tcl], q_done = st->poll.done;
   double q_pap, q_wb, q_wa;
-  if constexpr (DIRECT) {       // consumer-side reduction (slab_sums): pass A's slabs and the previous pass B's
-    const float *const src[3] = {dirA, dirB, dirA};
-    const int np[3] = {nA, nB, nA}, ix[3] = {tcl, kRedLt + (int)threadIdx.x, kRedLt + (int)threadIdx.x};
-    double o[3];
-    slab_sums<3>(src, np, ix, o);
-    q_pap = o[0];
-    q_wb = o[1];
-    q_wa = o[2];
+  if constexpr (DIRECT) {       // consumer-side reduction (slab_sums): pass A's slabs; L^T r of the previous pass B from the
+    if (dirB) {                 // slabs of the set-up, afterwards from redB (written by workgroup 0 of the pass C in between)
+      const float *const src[3] = {dirA, dirB, dirA};
+      const int np[3] = {nA, nB, nA}, ix[3] = {tcl, kRedLt + (int)threadIdx.x, kRedLt + (int)threadIdx.x};
+      double o[3];
+      slab_sums<3>(src, np, ix, o);
+      q_pap = o[0];
+      q_wb = o[1];
+      q_wa = o[2];
+    } else {
+      const float *const src[2] = {dirA, dirA};
+      const int np[2] = {nA, nA}, ix[2] = {tcl, kRedLt + (int)threadIdx.x};
+      double o[2];
+      q_wb = redB[kRedLt + threadIdx.x];
+      slab_sums<2>(src, np, ix, o);
+      q_pap = o[0];
+      q_wa = o[1];
+    }
   } else {
     q_pap = redA[tcl];
     q_wb = redB[kRedLt + threadIdx.x];
@@ -586,7 +596,7 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
                                                 int check_now, float tolerance, int iter_count, int stagnation_window,
                                                 const float *__restrict__ x, float *__restrict__ x_best,
                                                 CgPoll *__restrict__ poll_host, const float *__restrict__ dirB = nullptr,
-                                                int nB = 0) {
+                                                int nB = 0, double *__restrict__ lt_out = nullptr) {
   __shared__ float sbeta[kMaxT];
   __shared__ float sres[kMaxT];
   __shared__ float srzn[kMaxT];
@@ -598,12 +608,24 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
   const float snap_prev = st->snap_resid[cur];
   double q_rzn, q_rr;
   if constexpr (DIRECT) {
-    const float *const src[2] = {dirB, dirB};
-    const int np[2] = {nB, nB}, ix[2] = {16 + tcl, tcl};
-    double o[2];
-    slab_sums<2>(src, np, ix, o);
-    q_rzn = o[0];
-    q_rr = o[1];
+    if (blockIdx.x == 0) {
+      // workgroup 0 also adds up the L^T r entries of this pass B for the NEXT pass B (its loads ride in the same batch as
+      // the two every workgroup needs: no extra round trip here, one slab sum fewer at the head of every pass B)
+      const float *const src[3] = {dirB, dirB, dirB};
+      const int np[3] = {nB, nB, nB}, ix[3] = {16 + tcl, tcl, kRedLt + (int)threadIdx.x};
+      double o[3];
+      slab_sums<3>(src, np, ix, o);
+      q_rzn = o[0];
+      q_rr = o[1];
+      lt_out[kRedLt + threadIdx.x] = o[2];
+    } else {
+      const float *const src[2] = {dirB, dirB};
+      const int np[2] = {nB, nB}, ix[2] = {16 + tcl, tcl};
+      double o[2];
+      slab_sums<2>(src, np, ix, o);
+      q_rzn = o[0];
+      q_rr = o[1];
+    }
   } else {
     q_rzn = redB[16 + tcl];
     q_rr = redB[tcl];
@@ -1084,7 +1106,8 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   if (direct) {
     CG_PASS_B(true, p, Ap, x, r, z, L, Cinv, redA, redB, partB[1], state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1,
               partA, nba, partI, nba);
-    CG_PASS_C(true, z, p, redB, state, beta_d, N, eps, 0, 1, 0, tolerance, 0, 0, x, x_best, (CgPoll *)nullptr, partB[1], nbb);
+    CG_PASS_C(true, z, p, redB, state, beta_d, N, eps, 0, 1, 0, tolerance, 0, 0, x, x_best, (CgPoll *)nullptr, partB[1], nbb,
+              redB);
   } else {
     CG_PASS_B(false, p, Ap, x, r, z, L, Cinv, redA, redB, partB[1], state, alpha_d, N, K, precond_sigma2, eps, stop_after, 0, 1,
               nil, 0, nil, 0);
@@ -1116,9 +1139,9 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     if (check_now) *reinterpret_cast<volatile int *>(&hpoll[it % kPollRing].seq) = 0;      // (stale stamp of an earlier solve)
     if (direct) {
       CG_PASS_B(true, p, Ap, x, r, z, L, Cinv, redA, redB, pb_new, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2,
-                eps, stop_after, it & 1, 0, partA, nba, pb_old, nbb);
+                eps, stop_after, it & 1, 0, partA, nba, nil, 0);
       CG_PASS_C(true, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
-                it + 1, stagnation_window, x, x_best, poll_dst, pb_new, nbb);
+                it + 1, stagnation_window, x, x_best, poll_dst, pb_new, nbb, redB);
     } else {
       CG_PASS_B(false, p, Ap, x, r, z, L, Cinv, redA, redB, pb_new, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2,
                 eps, stop_after, it & 1, 0, nil, 0, nil, 0);

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void k_step_hyper_backward(const float *__rest
                                                              const float *__restrict__ g, float gscale, float dlp_over_n,
                                                              float *__restrict__ g_raw_ls, float *__restrict__ g_raw_os,
                                                              float *__restrict__ g_raw_noise, float *__restrict__ g_mean) {
+  __shared__ double sa[256], sb[256];
   const float *ls = hyp + 8, *sig_ls = hyp + 8 + n_ls;
   if (n_ls > 1) {
     for (int i = threadIdx.x; i < n_ls; i += 256) {
@@ -277,16 +278,28 @@ __global__ __launch_bounds__(256) void k_step_hyper_backward(const float *__rest
     }
     g_raw_ls[0] = -(s * zfac) / (ls[0] * ls[0]) * sig_ls[0];
   }
-  if (threadIdx.x == 32) {
-    double a = 0.0, b = 0.0;
-    for (int q = 0; q < nparts; ++q) {
-      a += (double)part[2 * q];
-      b += (double)part[2 * q + 1];
+  // the two sums over the workgroups' partials of k_step_lr: thread t adds entries t, t + 256, ..., then a tree — fixed order
+  // (one thread walking ~600 partials was 25 us at N = 7 372: longer than every other kernel of the backward pass but one)
+  double a = 0.0, b = 0.0;
+  for (int q = threadIdx.x; q < nparts; q += 256) {
+    a += (double)part[2 * q];
+    b += (double)part[2 * q + 1];
+  }
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      sa[threadIdx.x] += sa[threadIdx.x + w];
+      sb[threadIdx.x] += sb[threadIdx.x + w];
     }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
     const float gq = g[0] * gscale;
     g_raw_os[0] = gs[0] * hyp[3];
-    g_raw_noise[0] = ((float)a + g[0] * dlp_over_n) * hyp[4];
-    g_mean[0] = -(2.f * gq * (float)b);
+    g_raw_noise[0] = ((float)sa[0] + g[0] * dlp_over_n) * hyp[4];
+    g_mean[0] = -(2.f * gq * (float)sb[0]);
   }
 }
 

@@ -450,6 +450,13 @@ def main():
                                                               "tolerance": 0.01, "cg_iterations": it_c,
                                                               "seconds": round(t_solve_c, 4), "relative_residual": resid_c}}
 
+        # one optimiser step (mBCG T = 11 + SLQ + backward + Adam) of the flagship model at the BASELINE shapes C2 / C3 / C5 —
+        # context for the solve the headline kernel serves, not part of `value`
+        try:
+            result["extras"]["optimiser_step_ms"] = _step_times(device)
+        except Exception as e:                       # (never let a context number take the benchmark line down)
+            result["extras"]["optimiser_step_ms"] = {"error": repr(e)[:200]}
+
     if rank == 0 and world == 1 and args.cpu_budget > 0:
         from oracle import cpu_path
         torch.set_num_threads(os.cpu_count() or 1)
@@ -469,6 +476,53 @@ def main():
         if reducer is not None:
             reducer.close()
         dist.destroy_process_group()
+
+
+def _step_times(device):
+    """Median time of one optimiser step (`-mll(model(X), y)`, backward, Adam, `loss.item()` — fitting/optimizing.py:65-76) of the
+    additive RP model at the C2 / C3 / C5 shapes on synthetic data, 3 rounds of 20 steps each after 8 untimed ones."""
+    import numpy as np
+    from rpgp_amd import settings
+    from rpgp_amd.training import create_exact_gp, make_optimizer
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    out = {"what": "ms per step: preconditioned mBCG on [10 probes | y - c] at cg_tolerance 0.05, SLQ log-det, fused derivative, "
+                   "Adam; median of 3 x 20 steps (tools/r4_step_time.py is the longer form)"}
+    shapes = {"C2 N=7372 d=8 J=20": (7372, 8, 20, False, False), "C3 N=14939 d=18 J=20 spread": (14939, 18, 20, True, False),
+              "C5 N=391386 d=3 J=3 spread ski": (391386, 3, 3, True, True)}
+    for name, (N, d, J, sp, ski) in shapes.items():
+        g = torch.Generator().manual_seed(0)
+        X = torch.randn(N, d, generator=g)
+        y = torch.sin(X).sum(1) + 0.05 * torch.randn(N, generator=g)
+        X, y = X.to(device), ((y - y.mean()) / y.std()).to(device)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                     prescale=True, space_proj=sp, ski=ski,
+                                     ski_options={"grid_size": 1024, "num_dims": 1} if ski else None)
+        model = model.to(device)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        opt = make_optimizer(torch.optim.Adam, [p for p in model.parameters() if p.requires_grad], 0.0)
+
+        def run(n):
+            for _ in range(n):
+                opt.zero_grad()
+                loss = -mll(model(X), y)
+                loss.backward()
+                opt.step()
+                loss.item()
+        ts = []
+        with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
+            model.train()
+            run(8)
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(20)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / 20 * 1e3)
+        out[name] = round(sorted(ts)[1], 3)
+        del model, lik, mll, opt, X, y
+    return out
 
 
 if __name__ == "__main__":

@@ -490,7 +490,7 @@ int rpgp_slq_logdet(const float *alpha_hist, const float *beta_hist, int iters, 
  *   left = [solves_c norms[c] gq / p | -gq alpha], right = [pre_probes | alpha], gq = g[0] * gscale (g: device scalar, the
  *   incoming gradient); partials[2 b], partials[2 b + 1] = workgroup b's sum(left * right), sum(alpha); *nparts_out workgroups.
  * rpgp_step_hyper_backward: dPeff (d x J, gradient w.r.t. Peff, to be scaled by zfac) -> gradients of the raw parameters:
- *   g_raw_ls = -sum(dPeff P) / ls^2 sigmoid(raw_ls) (per row / column / overall), g_raw_os = gs[0] sigmoid(raw_os),
+ *   g_raw_ls = -sum(dPeff P) / ls^2 sigmoid(raw_ls) (per row / column / overall), g_raw_os = gs_scale gs[0] sigmoid(raw_os),
  *   g_raw_noise = (sum partials[2 b] + g[0] dlp_over_n) sigmoid(raw_noise), g_mean = -2 gq sum partials[2 b + 1].
  */
 int rpgp_step_hyper(const float *raw_ls, int n_ls, const float *raw_os, const float *raw_noise, const float *mean,
@@ -508,8 +508,8 @@ int rpgp_step_lr(const float *solves, const float *norms, const float *pre_probe
                  int p, float *left, float *right, float *partials, int *nparts_out, void *stream);
 int rpgp_step_hyper_backward(const float *dPeff, const float *W, int d, int J, int n_ls, int prescale, float zfac,
                              const float *hyper_dev, const float *gs, const float *partials, int nparts, const float *g,
-                             float gscale, float dlp_over_n, float *g_raw_ls, float *g_raw_os, float *g_raw_noise,
-                             float *g_mean, void *stream);
+                             float gscale, float dlp_over_n, float gs_scale, float *g_raw_ls, float *g_raw_os,
+                             float *g_raw_noise, float *g_mean, void *stream);
 
 /*
  * Multi-GPU pieces (one process per GPU; replaces `MultiDeviceKernel(kernel, devices, devices[0])`,

@@ -3270,17 +3270,6 @@ __device__ __forceinline__ void block_argmax(float &bv, int &bi, float *sval, in
   }
 }
 
-// residual diagonal d = d0 everywhere; argmax partials of that (pivot 0)
-__global__ __launch_bounds__(256) void pivchol_init_kernel(float *__restrict__ dwork, float *__restrict__ pval,
-                                                           int *__restrict__ pidx, int N, float d0) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) dwork[i] = d0;
-  if (threadIdx.x == 0) {
-    const int first = blockIdx.x * 256;
-    pval[blockIdx.x] = first < N ? d0 : -1.f;
-    pidx[blockIdx.x] = first < N ? first : 0x7fffffff;
-  }
-}
-
 // argmax partials of an already filled residual diagonal (SKI: the diagonal is not constant)
 __global__ __launch_bounds__(256) void pivchol_init_from_diag_kernel(const float *__restrict__ dwork,
                                                                      float *__restrict__ pval, int *__restrict__ pidx,
@@ -3306,7 +3295,7 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
                                                            int *__restrict__ pidx_out, int nparts, int N, int ldz,
                                                            int ncols, int k, int m, float scale, float d0, int kind,
                                                            int group, int ncomp, const float *__restrict__ wts,
-                                                           const float *__restrict__ gp, int G) {
+                                                           const float *__restrict__ gp, int G, int const_diag = 0) {
   __shared__ float sval[4];
   __shared__ int sidx[4];
   __shared__ float szp[64];
@@ -3315,16 +3304,21 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
   __shared__ int spidx[64];
   __shared__ float sdp;
   __shared__ int spiv;
-  // pivot of this step from the previous launch's partials
+  // pivot of this step from the previous launch's partials; const_diag (step 0 of a stationary kernel): the residual diagonal
+  // is d0 everywhere and the first pivot is row 0 (ties -> smallest index) — no initialisation launch, no partials to read
   float bv = -1.f;
   int bi = 0x7fffffff;
-  for (int q = threadIdx.x; q < nparts; q += 256) {
-    const float v = pval_in[q];
-    const int ix = pidx_in[q];
-    if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+  if (const_diag) {
+    if (threadIdx.x == 0) { sdp = d0; spiv = 0; }
+  } else {
+    for (int q = threadIdx.x; q < nparts; q += 256) {
+      const float v = pval_in[q];
+      const int ix = pidx_in[q];
+      if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+    block_argmax(bv, bi, sval, sidx);
+    if (threadIdx.x == 0) { sdp = bv; spiv = bi; }
   }
-  block_argmax(bv, bi, sval, sidx);
-  if (threadIdx.x == 0) { sdp = bv; spiv = bi; }
   __syncthreads();
   const int piv = spiv;
   const float dp = sdp;
@@ -3381,7 +3375,7 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
       l = (row - corr) * inv_sq;
     }
     L[(size_t)i * k + m] = l;
-    float nd = dwork[i] - l * l;
+    float nd = (const_diag ? d0 : dwork[i]) - l * l;
     nd = nd < 0.f ? 0.f : nd;
     nd = (i == piv) ? 0.f : nd;
     dwork[i] = nd;
@@ -4652,13 +4646,12 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
     hipLaunchKernelGGL(ski_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, Z, gp, diag_work,
                        (long long)N, ldz, ncols, G, scale);
     hipLaunchKernelGGL(pivchol_init_from_diag_kernel, dim3(nb), dim3(256), 0, st, diag_work, pval[0], pidx[0], (int)N);
-  } else {
-    hipLaunchKernelGGL(pivchol_init_kernel, dim3(nb), dim3(256), 0, st, diag_work, pval[0], pidx[0], (int)N, d0);
   }
+  // (a stationary kernel's residual diagonal starts at d0 everywhere: step 0 knows that itself — no initialisation launch)
   for (int m = 0; m < rank; ++m) {
     hipLaunchKernelGGL(pivchol_step_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
                        pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, kind, group,
-                       ncomp, wts, gp, G);
+                       ncomp, wts, gp, G, (m == 0 && !gp) ? 1 : 0);
   }
   return launch_status();
 }

@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void k_step_hyper_backward(const float *__rest
                                                              const float *__restrict__ hyp, const float *__restrict__ gs,
                                                              const float *__restrict__ part, int nparts,
                                                              const float *__restrict__ g, float gscale, float dlp_over_n,
-                                                             float *__restrict__ g_raw_ls, float *__restrict__ g_raw_os,
+                                                             float gs_scale, float *__restrict__ g_raw_ls,
+                                                             float *__restrict__ g_raw_os,
                                                              float *__restrict__ g_raw_noise, float *__restrict__ g_mean) {
   __shared__ double sa[256], sb[256];
   const float *ls = hyp + 8, *sig_ls = hyp + 8 + n_ls;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void k_step_hyper_backward(const float *__rest
   }
   if (threadIdx.x == 0) {
     const float gq = g[0] * gscale;
-    g_raw_os[0] = gs[0] * hyp[3];
+    g_raw_os[0] = gs[0] * gs_scale * hyp[3];
     g_raw_noise[0] = ((float)sa[0] + g[0] * dlp_over_n) * hyp[4];
     g_mean[0] = -(2.f * gq * (float)sb[0]);
   }
@@ -391,14 +392,14 @@ int rpgp_step_lr(const float *solves, const float *norms, const float *pre_probe
 
 int rpgp_step_hyper_backward(const float *dPeff, const float *W, int d, int J, int n_ls, int prescale, float zfac,
                              const float *hyper_dev, const float *gs, const float *partials, int nparts, const float *g,
-                             float gscale, float dlp_over_n, float *g_raw_ls, float *g_raw_os, float *g_raw_noise,
-                             float *g_mean, void *stream) {
+                             float gscale, float dlp_over_n, float gs_scale, float *g_raw_ls, float *g_raw_os,
+                             float *g_raw_noise, float *g_mean, void *stream) {
   if (!dPeff || !W || !hyper_dev || !gs || !partials || !g || !g_raw_ls || !g_raw_os || !g_raw_noise || !g_mean || d < 1 ||
       J < 1 || n_ls < 1 || nparts < 1 || (n_ls != 1 && n_ls != (prescale ? d : J)))
     return RPGP_EINVAL;
   hipLaunchKernelGGL(k_step_hyper_backward, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dPeff, W, d, J, n_ls,
-                     prescale, zfac, hyper_dev, gs, partials, nparts, g, gscale, dlp_over_n, g_raw_ls, g_raw_os, g_raw_noise,
-                     g_mean);
+                     prescale, zfac, hyper_dev, gs, partials, nparts, g, gscale, dlp_over_n, gs_scale, g_raw_ls, g_raw_os,
+                     g_raw_noise, g_mean);
   return (int)hipGetLastError();
 }
 

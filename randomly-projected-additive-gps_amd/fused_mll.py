@@ -189,11 +189,20 @@ class _FusedMLL(torch.autograd.Function):
             g = g.reshape(1).contiguous()
             pre_probes = ctx.pre.solve(ctx.probes)
             left, right, part, nparts = be.step_lr(ctx.solves, ctx.norms, pre_probes, g, -0.5 / n)
-            gZ, gs = ctx.op._bilinear_derivative(left, right)
+            op, gs_scale = ctx.op, 1.0
+            from .operators import AdditiveRPOperator
+            if type(op) is AdditiveRPOperator and (op.shard is None or op.shard.world_size <= 1):
+                # (the plain operator's `_bilinear_derivative` is this call followed by `gs * weight`: the weight rides into the
+                #  chain-rule kernel instead of being one more launch)
+                gZ, gs = be.bilinear_grad(op.Z1.detach(), left, right, op._scale)
+                gs_scale = op.weight
+            else:
+                gZ, gs = op._bilinear_derivative(left, right)
             dPeff = be.project_grad(ctx.X, gZ.contiguous())                              # d x J:  Z = X Peff
             n_ls = (ctx.hyp.numel() - 8) // 2
             g_ls, g_os, g_nz, g_mu = be.step_hyper_backward(dPeff, ctx.W, n_ls, ctx.prescale, ctx.zfac, ctx.hyp,
-                                                            gs.reshape(1), part, nparts, g, -0.5 / n, ctx.dlp / n)
+                                                            gs.reshape(1), part, nparts, g, -0.5 / n, ctx.dlp / n,
+                                                            gs_scale=gs_scale)
         s_ls, s_os, s_nz, s_mu = ctx.shapes
         return g_ls.reshape(s_ls), g_os.reshape(s_os), g_nz.reshape(s_nz), g_mu.reshape(s_mu), None, None, None
 

@@ -258,8 +258,11 @@ def bilinear_grad(Z, L, R, scale, j0=0, j1=None):
     if L2.shape != R2.shape:
         raise ValueError("L and R must have the same shape")
     T = L2.shape[1]
-    gZ = torch.zeros((N, J), dtype=Z.dtype, device=Z.device)
-    gs = torch.zeros((), dtype=Z.dtype, device=Z.device)
+    # (the kernels WRITE gZ[:, j0:j1] and gs: the zero fill is only needed for the columns outside a J-slice and for the
+    #  accumulation over 12-column pieces)
+    full = j0 == 0 and j1 == J and (T <= 12 or Z.dtype == torch.float64)
+    gZ = (torch.empty if full else torch.zeros)((N, J), dtype=Z.dtype, device=Z.device)
+    gs = (torch.empty if full else torch.zeros)((), dtype=Z.dtype, device=Z.device)
     if Z.dtype == torch.float64:
         scratch = torch.empty(N, dtype=torch.float64, device=Z.device)
         with _on(Z.device):
@@ -1201,7 +1204,7 @@ def step_lr(solves, norms, pre_probes, g, gscale):
     return left, right, part, nparts.value
 
 
-def step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyper_dev, gs, partials, nparts, g, gscale, dlp_over_n):
+def step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyper_dev, gs, partials, nparts, g, gscale, dlp_over_n, gs_scale=1.0):
     """Gradients of the raw parameters (rpgp_step_hyper_backward): (g_raw_ls [n_ls], g_raw_os, g_raw_noise, g_mean) as views of
     one buffer."""
     lib = _lib.load()
@@ -1211,7 +1214,7 @@ def step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyper_dev, gs, partials,
     with _on(W.device):
         _lib.check(lib.rpgp_step_hyper_backward(dPeff.data_ptr(), W.data_ptr(), d, J, int(n_ls), 1 if prescale else 0, float(zfac),
                                                 hyper_dev.data_ptr(), gs.data_ptr(), partials.data_ptr(), int(nparts),
-                                                g.data_ptr(), float(gscale), float(dlp_over_n), base, base + 4 * n_ls,
+                                                g.data_ptr(), float(gscale), float(dlp_over_n), float(gs_scale), base, base + 4 * n_ls,
                                                 base + 4 * (n_ls + 1), base + 4 * (n_ls + 2), _stream()),
                    "rpgp_step_hyper_backward")
     return out[:n_ls], out[n_ls:n_ls + 1], out[n_ls + 1:n_ls + 2], out[n_ls + 2:n_ls + 3]

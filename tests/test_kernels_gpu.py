@@ -614,11 +614,12 @@ def test_step_kernels_against_torch_formulas(gpu_device):
         gs, gten = torch.randn(1, generator=g).to(gpu_device), torch.tensor([-1.0], device=gpu_device)
         part = torch.randn(2 * 37, generator=g).to(gpu_device)
         zfac, gscale, dlp_n = 0.83, -0.5 / 1234, 0.017
-        g_ls, g_os, g_nz, g_mu = ops.step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyp, gs, part, 37, gten, gscale, dlp_n)
+        g_ls, g_os, g_nz, g_mu = ops.step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyp, gs, part, 37, gten, gscale, dlp_n,
+                                                         gs_scale=0.7)
         t = dPeff * zfac * W.t()
         ref_ls = -(t.sum() if n_ls == 1 else (t.sum(1) if prescale else t.sum(0))) / (ls * ls) * torch.sigmoid(raw_ls)
         assert torch.allclose(g_ls, ref_ls.reshape(-1), rtol=1e-5, atol=1e-6)
-        assert torch.allclose(g_os, gs * torch.sigmoid(raw_os), rtol=1e-6)
+        assert torch.allclose(g_os, gs * 0.7 * torch.sigmoid(raw_os), rtol=1e-6)
         gq = float(gten) * gscale
         assert abs(float(g_nz) - (float(part[0::2].double().sum()) + float(gten) * dlp_n) * float(torch.sigmoid(raw_nz))) < 1e-5
         assert abs(float(g_mu) + 2 * gq * float(part[1::2].double().sum())) < 1e-6

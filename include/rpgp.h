@@ -553,9 +553,18 @@ int rpgp_gram_f64(const float *A, int64_t lda, const float *B, int64_t ldb, int6
                   void *workspace, size_t workspace_bytes, void *stream);
 int rpgp_woodbury_apply(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *Tm, double noise,
                         float *out, int64_t ldo, int64_t N, int K, int T, void *stream);
+/* The same with t = Cinv gram_LR formed inside the kernel (gram_LR = L^T R from rpgp_gram_f64, Cinv from rpgp_woodbury_setup):
+ * M^-1 R in two launches (Gram product, this) instead of four. */
+int rpgp_woodbury_apply_cinv(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *gram_LR,
+                             const double *Cinv, double noise, float *out, int64_t ldo, int64_t N, int K, int T,
+                             void *stream);
 /* One launch for the K x K capacitance matrix C = gram + noise I (gram = L^T L, row-major float64, K <= 64): chol = its lower
  * Cholesky factor, cinv = C^-1, logdet[0] = log|C| (all float64, device).  A non-positive pivot fills the outputs with NaN. */
 int rpgp_woodbury_setup(const double *gram, double noise, int K, double *chol, double *cinv, double *logdet, void *stream);
+/* The same; *logdet_pinned_host (may be NULL) is PINNED host memory (hipHostMalloc) that the kernel writes log|C| to as well:
+ * readable by the host once the stream has passed the launch — no device-to-host copy. */
+int rpgp_woodbury_setup_pinned(const double *gram, double noise, int K, double *chol, double *cinv, double *logdet,
+                               double *logdet_pinned_host, void *stream);
 
 /*
  * Float64 variants for `--double` (training_routines.py:481).  Same contracts as the fp32 entry points of the same

@@ -125,7 +125,9 @@ SIGNATURES = {
     "rpgp_gram_f64_workspace_bytes": (_sz, [_int, _int]),
     "rpgp_gram_f64": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _vp, _vp, _sz, _vp]),
     "rpgp_woodbury_apply": (_int, [_vp, _i64, _vp, _i64, _vp, _f64, _vp, _i64, _i64, _int, _int, _vp]),
+    "rpgp_woodbury_apply_cinv": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _f64, _vp, _i64, _i64, _int, _int, _vp]),
     "rpgp_woodbury_setup": (_int, [_vp, _f64, _int, _vp, _vp, _vp, _vp]),
+    "rpgp_woodbury_setup_pinned": (_int, [_vp, _f64, _int, _vp, _vp, _vp, _vp, _vp]),
     "rpgp_profile_begin": (_int, []),
     "rpgp_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
     "rpgp_prepared_kernel_id": (_int, [ctypes.c_int64, _int, _int]),

@@ -48,6 +48,7 @@ class HipBackend:
     gram_f64 = staticmethod(ops.gram_f64)
     woodbury_apply = staticmethod(ops.woodbury_apply)
     woodbury_setup = staticmethod(ops.woodbury_setup)
+    woodbury_solve = staticmethod(ops.woodbury_solve)
     make_operator_desc = staticmethod(ops.make_operator_desc)
     make_sum_operator_desc = staticmethod(ops.make_sum_operator_desc)
     mbcg_solve = staticmethod(ops.mbcg_solve)

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "../../include/rpgp.h"
 #include "rpgp_internal.h"
@@ -24,11 +25,18 @@ constexpr int kGramMaxWg = 512;
 // Lane l of a wave: c = l % 16 (column inside a 16-wide tile), q = l / 16 (row inside a 4-row step).  One matrix
 // instruction per (A tile, B tile, 4 rows): A operand [i = c][k = q] = A[n + q][16 ma + c], B operand [k = q][j = c] =
 // B[n + q][16 nb + c]; result register r of lane l = out[16 ma + q + 4 r][16 nb + c].
+// `counter` != nullptr (few slabs: N <= 16k): the LAST workgroup to finish adds the slabs up itself — gram_finish_kernel's sums
+// in gram_finish_kernel's order (four quarters of the slabs, each in slab order, combined in order: bitwise the same result) —
+// instead of a second launch; three Gram products per optimiser step are on the host-bound stretches around the solve
+// (DESIGN §3.4).  Hand-off as in k_step_value (rpgp_step.hip): stores drained, workgroup barrier, agent-scope release, arrive;
+// the last arriver acquires and reads.  The counter returns to zero.
 template <int MA, int NB>
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restrict__ A, long long lda,
                                                            const float *__restrict__ B, long long ldb, long long N, int K,
-                                                           int T, double *__restrict__ part) {
+                                                           int T, double *__restrict__ part, unsigned *__restrict__ counter,
+                                                           double *__restrict__ out64, float *__restrict__ out32) {
   __shared__ double sred[4][64];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
   // kU accumulator sets (steps s, s + nwaves, ...): consecutive matrix instructions never chain on one accumulator, and
@@ -91,6 +99,51 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restri
         }
       }
     }
+  if (!counter) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == gridDim.x - 1;
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int nparts = (int)gridDim.x, per = (nparts + 3) / 4, pos = threadIdx.x;
+  const size_t stride = (size_t)MA * NB * 256;
+  for (int tile = 0; tile < MA * NB; ++tile) {
+    const double *src = part + (size_t)tile * 256 + pos;
+    double qs[4];
+#pragma unroll
+    for (int quarter = 0; quarter < 4; ++quarter) {
+      const int p0 = quarter * per, p1 = min(nparts, p0 + per);
+      double sacc = 0.0;
+      int p = p0;
+      for (; p + 7 < p1; p += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(p + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc += v[u];
+      }
+      for (; p < p1; ++p) sacc += src[(size_t)p * stride];
+      qs[quarter] = sacc;
+    }
+    const double sum = ((qs[0] + qs[1]) + qs[2]) + qs[3];
+    const int a = tile / NB, b = tile % NB, r = pos >> 6, q = (pos & 63) >> 4, c = pos & 15;
+    const int i = 16 * a + q + 4 * r, j = 16 * b + c;
+    if (i < K && j < T) {
+      if (out64) out64[i * T + j] = sum;
+      if (out32) out32[i * T + j] = (float)sum;
+    }
+  }
 }
 
 // One workgroup of 1024 threads per 16 x 16 tile: thread (quarter, position) sums its quarter of the slabs for one of the
@@ -132,9 +185,18 @@ __global__ __launch_bounds__(256) void woodbury_apply_kernel(const float *__rest
                                                              const float *__restrict__ R, long long ldr,
                                                              const double *__restrict__ Tm, double inv_noise,
                                                              float *__restrict__ out, long long ldo, long long N, int K,
-                                                             int T) {
+                                                             int T, const double *__restrict__ Cinv) {
   extern __shared__ double sT[];                    // K x T
-  for (int e = threadIdx.x; e < K * T; e += 256) sT[e] = Tm[e];
+  if (Cinv) {                                       // Tm = L^T R: every workgroup forms t = C^-1 Tm itself (K^2 T products)
+    for (int e = threadIdx.x; e < K * T; e += 256) {
+      const int k = e / T, t = e - k * T;
+      double acc = 0.0;
+      for (int kk = 0; kk < K; ++kk) acc = fma(Cinv[k * K + kk], Tm[kk * T + t], acc);
+      sT[e] = acc;
+    }
+  } else {
+    for (int e = threadIdx.x; e < K * T; e += 256) sT[e] = Tm[e];
+  }
   __syncthreads();
   const long long total = N * T;
   for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
@@ -153,7 +215,7 @@ __global__ __launch_bounds__(256) void woodbury_apply_kernel(const float *__rest
 // A non-positive pivot writes NaN into everything (the caller checks log|C| where it synchronises anyway).
 __global__ __launch_bounds__(256) void woodbury_setup_kernel(const double *__restrict__ G, double noise, int K,
                                                              double *__restrict__ chol, double *__restrict__ cinv,
-                                                             double *__restrict__ logdet) {
+                                                             double *__restrict__ logdet, double *__restrict__ logdet_host) {
   __shared__ double sA[64 * 65];      // C, then its Cholesky factor (lower), row stride 65
   __shared__ double sI[64 * 65];      // inverse of the factor (lower)
   __shared__ int bad;
@@ -200,9 +262,31 @@ __global__ __launch_bounds__(256) void woodbury_setup_kernel(const double *__res
     double ld = 0.0;
     for (int i = 0; i < K; ++i) ld += log(sA[i * 65 + i]);
     logdet[0] = bad ? nanv : 2.0 * ld;
+    if (logdet_host) {                 // (pinned host memory: the value the host reads behind the solve — no copy launch)
+      logdet_host[0] = bad ? nanv : 2.0 * ld;
+      __threadfence_system();
+    }
   }
 }
 
+// arrival counters of the folded finish: zero at allocation, left at zero by every launch; 64 per device, handed out round-robin
+// (two launches share a counter only if 64 others are in flight between them)
+inline unsigned *gram_counter() {
+  constexpr int kSlots = 64, kMaxDev = 16;
+  static unsigned *pool[kMaxDev] = {nullptr};
+  static int next[kMaxDev] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  if (!pool[dev]) {
+    unsigned *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), kSlots * 64) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, kSlots * 64) != hipSuccess) return nullptr;
+    pool[dev] = p;
+  }
+  const int slot = next[dev];
+  next[dev] = (slot + 1) % kSlots;
+  return pool[dev] + slot * 16;
+}
 inline int tiles16(int n) { return (n + 15) / 16; }
 inline int gram_blocks(long long N) {
   long long g = (N + 255) / 256;
@@ -230,14 +314,22 @@ int gram_launch(const float *A, long long lda, const float *B, long long ldb, lo
   int ma = tiles16(K), nb = tiles16(T);
   if (ma == 3) ma = 4;                               // compiled tile counts: 1, 2, 4
   if (nb == 3) nb = 4;
+  // few slabs: the last workgroup of the partial kernel finishes (no second launch); RPGP_GRAM_FOLD=0 keeps the finish kernel
+  unsigned *counter = nullptr;
+  static const bool fold_on = [] {
+    const char *e = getenv("RPGP_GRAM_FOLD");
+    return !(e && e[0] == '0');
+  }();
+  if (fold_on && g <= 64) counter = gram_counter();
 #define RPGP_GRAM_CASE(MA_, NB_)                                                                                       \
   if (ma == MA_ && nb == NB_)                                                                                          \
-    hipLaunchKernelGGL((gram_partial_kernel<MA_, NB_>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, N, K, T, part)
+    hipLaunchKernelGGL((gram_partial_kernel<MA_, NB_>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, N, K, T, part, counter,   \
+                       out64, out32)
   RPGP_GRAM_CASE(1, 1); RPGP_GRAM_CASE(1, 2); RPGP_GRAM_CASE(1, 4);
   RPGP_GRAM_CASE(2, 1); RPGP_GRAM_CASE(2, 2); RPGP_GRAM_CASE(2, 4);
   RPGP_GRAM_CASE(4, 1); RPGP_GRAM_CASE(4, 2); RPGP_GRAM_CASE(4, 4);
 #undef RPGP_GRAM_CASE
-  hipLaunchKernelGGL(gram_finish_kernel, dim3(ma * nb), dim3(1024), 0, st, part, g, ma, nb, K, T, out64, out32);
+  if (!counter) hipLaunchKernelGGL(gram_finish_kernel, dim3(ma * nb), dim3(1024), 0, st, part, g, ma, nb, K, T, out64, out32);
   return (int)hipGetLastError();
 }
 
@@ -256,24 +348,45 @@ int rpgp_gram_f64(const float *A, int64_t lda, const float *B, int64_t ldb, int6
 }
 
 int rpgp_woodbury_setup(const double *gram, double noise, int K, double *chol, double *cinv, double *logdet, void *stream) {
+  return rpgp_woodbury_setup_pinned(gram, noise, K, chol, cinv, logdet, nullptr, stream);
+}
+
+int rpgp_woodbury_setup_pinned(const double *gram, double noise, int K, double *chol, double *cinv, double *logdet,
+                               double *logdet_pinned_host, void *stream) {
   if (!gram || !chol || !cinv || !logdet || K <= 0 || K > 64 || !(noise > 0.0)) return RPGP_EINVAL;
+  double *hdev = nullptr;
+  if (logdet_pinned_host &&
+      hipHostGetDevicePointer(reinterpret_cast<void **>(&hdev), logdet_pinned_host, 0) != hipSuccess)
+    return RPGP_EINVAL;
   hipLaunchKernelGGL(woodbury_setup_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gram, noise, K,
-                     chol, cinv, logdet);
+                     chol, cinv, logdet, hdev);
   return (int)hipGetLastError();
 }
 
-int rpgp_woodbury_apply(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *Tm, double noise,
-                        float *out, int64_t ldo, int64_t N, int K, int T, void *stream) {
+static int woodbury_apply_impl(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *Tm, const double *Cinv,
+                               double noise, float *out, int64_t ldo, int64_t N, int K, int T, void *stream) {
   if (!L || !R || !Tm || !out || N < 0 || K <= 0 || T <= 0 || K > 64 || T > 64 || ldl < K || ldr < T || ldo < T ||
       !(noise > 0.0))
     return RPGP_EINVAL;
   if (N == 0) return 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   long long blocks = (N * T + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > (Cinv ? 1024 : 8192)) blocks = Cinv ? 1024 : 8192;      // (every workgroup of the fused form pays K^2 T products)
   hipLaunchKernelGGL(woodbury_apply_kernel, dim3((int)blocks), dim3(256), (size_t)K * T * sizeof(double), st, L,
-                     (long long)ldl, R, (long long)ldr, Tm, 1.0 / noise, out, (long long)ldo, (long long)N, K, T);
+                     (long long)ldl, R, (long long)ldr, Tm, 1.0 / noise, out, (long long)ldo, (long long)N, K, T, Cinv);
   return (int)hipGetLastError();
+}
+
+int rpgp_woodbury_apply(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *Tm, double noise,
+                        float *out, int64_t ldo, int64_t N, int K, int T, void *stream) {
+  return woodbury_apply_impl(L, ldl, R, ldr, Tm, nullptr, noise, out, ldo, N, K, T, stream);
+}
+
+int rpgp_woodbury_apply_cinv(const float *L, int64_t ldl, const float *R, int64_t ldr, const double *gram_LR,
+                             const double *Cinv, double noise, float *out, int64_t ldo, int64_t N, int K, int T,
+                             void *stream) {
+  if (!Cinv) return RPGP_EINVAL;
+  return woodbury_apply_impl(L, ldl, R, ldr, gram_LR, Cinv, noise, out, ldo, N, K, T, stream);
 }
 
 }  // extern "C"

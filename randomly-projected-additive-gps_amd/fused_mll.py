@@ -164,7 +164,7 @@ class _FusedMLL(torch.autograd.Function):
             e1 = torch.randn(pre.k, p, generator=gen, device=Z.device, dtype=Z.dtype)      # (the draws of pre.sample, same order)
             e2 = torch.randn(n, p, generator=gen, device=Z.device, dtype=Z.dtype)
             probes, full_rhs, norms = be.step_probes(pre.L, e1, e2, math.sqrt(noise_f), target, hyp[2:3])
-            khat = AddedDiagOperator(op, noise)
+            khat = AddedDiagOperator(op, noise, noise_value=noise_f)
             matmul, native_op, _ = solve_operator(op, khat, Z, noise_f, p + 1)
             solves, hist = linear_cg(matmul, full_rhs, n_tridiag=p, operator=native_op,
                                      tolerance=settings.cg_tolerance.value(), max_iter=settings.max_cg_iterations.value(),

@@ -107,11 +107,11 @@ class InvQuadLogDet(torch.autograd.Function):
     def forward(ctx, Z, outputscale, noise, rhs, op, comp_weights=None):
         # `op` is the AdditiveRPOperator built on (Z, outputscale); passed as a non-tensor argument
         N = Z.shape[0]
-        khat = AddedDiagOperator(op, noise.detach())
+        noise_f = op._noise_host if getattr(op, "_noise_host", None) is not None else host_float(noise)
+        khat = AddedDiagOperator(op, noise.detach(), noise_value=noise_f)
         r = rhs.detach().reshape(N, 1)
         ctx.op = op
         ctx.N = N
-        noise_f = op._noise_host if getattr(op, "_noise_host", None) is not None else host_float(noise)
         if use_cholesky(N):
             Kd = khat.to_dense()
             Lc = psd_safe_cholesky(Kd)

@@ -981,12 +981,14 @@ class MixedGroupOperator(AdditiveRPOperator):
 class AddedDiagOperator(LinearOperator):
     """base + noise * I  (the likelihood's AddedDiagLazyTensor); the noise term is fused into the MVM kernel."""
 
-    def __init__(self, base, noise):
+    def __init__(self, base, noise, noise_value=None):
         if not isinstance(noise, torch.Tensor):
             noise = torch.as_tensor(float(noise), dtype=base.dtype, device=base.device)
         self.base = base
         self.noise = noise
-        self._noise = float(noise.detach())
+        # host value of the noise: given by the caller, or the one `hostvals.prefetch` / the step kernels left on the tensor —
+        # a plain `float(noise)` is a device-to-host copy and a synchronisation in the middle of the step's set-up
+        self._noise = float(noise_value) if noise_value is not None else host_float(noise)
 
     def _size(self):
         return self.base._size()

@@ -779,9 +779,28 @@ def woodbury_apply(L, R, Tm, noise):
     return out
 
 
-def woodbury_setup(gram, noise):
+def woodbury_solve(L, R, cinv, noise):
+    """M^-1 R = (R - L (C^-1 (L^T R))) / noise for M = L L^T + noise I in two launches: the float64 Gram product L^T R
+    (rpgp_gram_f64) and rpgp_woodbury_apply_cinv, which forms C^-1 (L^T R) itself."""
+    lib = _lib.load()
+    g = gram_f64(L, R)
+    L, ldl = _rows_fp32(L, "L")
+    R, ldr = _rows_fp32(R, "R")
+    N, K = L.shape
+    T = R.shape[1]
+    if tuple(cinv.shape) != (K, K) or cinv.dtype != torch.float64 or not cinv.is_contiguous():
+        raise ValueError("woodbury_solve: cinv must be a contiguous K x K float64 matrix")
+    out = torch.empty((N, T), dtype=torch.float32, device=L.device)
+    with _on(L.device):
+        _lib.check(lib.rpgp_woodbury_apply_cinv(L.data_ptr(), ldl, R.data_ptr(), ldr, g.data_ptr(), cinv.data_ptr(), float(noise),
+                                                out.data_ptr(), T, N, K, T, _stream()), "rpgp_woodbury_apply_cinv")
+    return out
+
+
+def woodbury_setup(gram, noise, logdet_pinned=None):
     """(chol, cinv, logdet) of C = gram + noise I for a K x K float64 device matrix, K <= 64, in one launch
-    (rpgp_woodbury_setup); logdet is a 1-element device tensor (no synchronisation here)."""
+    (rpgp_woodbury_setup); logdet is a 1-element device tensor (no synchronisation here).  `logdet_pinned`: a 1-element pinned
+    float64 HOST tensor the kernel writes log|C| to as well (read it once the stream has passed this launch)."""
     lib = _lib.load()
     if gram.dtype != torch.float64 or not gram.is_cuda or gram.dim() != 2 or gram.shape[0] != gram.shape[1] or \
             gram.shape[0] > 64:
@@ -791,8 +810,10 @@ def woodbury_setup(gram, noise):
     out = torch.empty((2 * K * K + 1,), dtype=torch.float64, device=gram.device)
     chol, cinv, logdet = out[:K * K].view(K, K), out[K * K:2 * K * K].view(K, K), out[2 * K * K:]
     with _on(gram.device):
-        _lib.check(lib.rpgp_woodbury_setup(gram.data_ptr(), float(noise), K, chol.data_ptr(), cinv.data_ptr(),
-                                           logdet.data_ptr(), _stream()), "rpgp_woodbury_setup")
+        _lib.check(lib.rpgp_woodbury_setup_pinned(gram.data_ptr(), float(noise), K, chol.data_ptr(), cinv.data_ptr(),
+                                                  logdet.data_ptr(),
+                                                  logdet_pinned.data_ptr() if logdet_pinned is not None else None, _stream()),
+                   "rpgp_woodbury_setup")
     return chol, cinv, logdet
 
 

@@ -73,12 +73,16 @@ class WoodburyPreconditioner:
         self._cinv = self._logdet_cap = self._logdet_host = None
         if self._be is not None and hasattr(self._be, "woodbury_setup"):
             # Cholesky factor, inverse and log-determinant of the capacitance matrix in one launch, no synchronisation
-            self._cap_chol, self._cinv, self._logdet_cap = self._be.woodbury_setup(cap, self.noise)
-            if self._logdet_cap.is_cuda:
-                # the log-determinant starts its way to (pinned) host memory NOW: by the time somebody asks for it a solve has
-                # synchronised the stream and the read is free (a `float()` of the device scalar is a copy + a synchronisation)
-                self._logdet_host = torch.empty(self._logdet_cap.shape, dtype=self._logdet_cap.dtype, pin_memory=True)
-                self._logdet_host.copy_(self._logdet_cap, non_blocking=True)
+            # the log-determinant also lands in pinned host memory, written by the set-up kernel itself: by the time somebody
+            # asks for it a solve has synchronised the stream and the read is free (a `float()` of the device scalar is a
+            # copy + a synchronisation)
+            pinned = torch.empty(1, dtype=torch.float64, pin_memory=True) if cap.is_cuda else None
+            if pinned is not None:
+                self._cap_chol, self._cinv, self._logdet_cap = self._be.woodbury_setup(cap, self.noise, logdet_pinned=pinned)
+            else:
+                self._cap_chol, self._cinv, self._logdet_cap = self._be.woodbury_setup(cap, self.noise)
+            if pinned is not None:
+                self._logdet_host = pinned
                 self._logdet_ev = torch.cuda.Event()
                 self._logdet_ev.record()
         else:
@@ -110,6 +114,8 @@ class WoodburyPreconditioner:
 
     def _solve_panel(self, r):
         if self._be is not None and r.dtype == torch.float32:
+            if self._cinv is not None and hasattr(self._be, "woodbury_solve") and self._cinv.is_contiguous():
+                return self._be.woodbury_solve(self.L, r, self._cinv, self.noise)      # Gram product + one fused launch
             g = self._be.gram_f64(self.L, r)
             # (the float64 inverse from the set-up kernel: one small product instead of two triangular solves)
             t = self._cinv @ g if self._cinv is not None else torch.cholesky_solve(g, self._cap_chol)

@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 
 #include "../../include/rpgp.h"
 #include "rpgp_internal.h"
@@ -273,19 +275,25 @@ __global__ __launch_bounds__(256) void woodbury_setup_kernel(const double *__res
 // (two launches share a counter only if 64 others are in flight between them)
 inline unsigned *gram_counter() {
   constexpr int kSlots = 64, kMaxDev = 16;
-  static unsigned *pool[kMaxDev] = {nullptr};
-  static int next[kMaxDev] = {0};
+  static std::atomic<unsigned *> pool[kMaxDev];
+  static std::atomic<unsigned> next[kMaxDev];
+  static std::mutex init_lock;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-  if (!pool[dev]) {
-    unsigned *p = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&p), kSlots * 64) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, kSlots * 64) != hipSuccess) return nullptr;
-    pool[dev] = p;
+  unsigned *base = pool[dev].load(std::memory_order_acquire);
+  if (!base) {
+    std::lock_guard<std::mutex> g(init_lock);
+    base = pool[dev].load(std::memory_order_acquire);
+    if (!base) {
+      unsigned *p = nullptr;
+      if (hipMalloc(reinterpret_cast<void **>(&p), kSlots * 64) != hipSuccess) return nullptr;
+      if (hipMemset(p, 0, kSlots * 64) != hipSuccess) return nullptr;
+      pool[dev].store(p, std::memory_order_release);
+      base = p;
+    }
   }
-  const int slot = next[dev];
-  next[dev] = (slot + 1) % kSlots;
-  return pool[dev] + slot * 16;
+  const unsigned slot = next[dev].fetch_add(1u, std::memory_order_relaxed) % kSlots;
+  return base + slot * 16;
 }
 inline int tiles16(int n) { return (n + 15) / 16; }
 inline int gram_blocks(long long N) {

@@ -1129,7 +1129,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   for (it = 0; it < n_iter; ++it) {
     int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
-    float *pb_new = partB[it & 1], *pb_old = partB[(it & 1) ^ 1];
+    float *pb_new = partB[it & 1];        // (ping-pong kept: the set-up pass B's slabs live in partB[1] until iteration 0 has read redB)
     CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, partA, N, K));
     CG_REDUCE(partA, redA, nba);
     const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)

@@ -472,7 +472,7 @@ int rpgp_slq_logdet(const float *alpha_hist, const float *beta_hist, int iters, 
 
 /*
  * The small kernels AROUND the solve of one optimiser step of the flagship model (csrc/rpgp_step.hip): each call is one launch
- * (rpgp_step_probes: two) for a stretch the reference runs as a chain of element-wise torch launches on d + 3 scalars and a few
+ * for a stretch the reference runs as a chain of element-wise torch launches on d + 3 scalars and a few
  * N x 11 blocks — `-mll(model(train_x), train_y)` / `loss.backward()` at /root/reference/fitting/optimizing.py:67-72 on the model
  * of /root/reference/training_routines.py:131-189, 325-410.  All enqueue on `stream`; only rpgp_step_hyper waits (for three floats).
  *
@@ -482,12 +482,13 @@ int rpgp_slq_logdet(const float *alpha_hist, const float *beta_hist, int iters, 
  *   [8..) ls, then sigmoid(raw_ls).  The three scalars the other entry points take BY VALUE come back through pinned memory
  *   (the call spins until the kernel has published them): *outputscale_host, *noise_host, *mean_host.
  * rpgp_step_probes: z = L e1 + sqrt_noise e2 (L: N x k, e1: k x p, e2: N x p standard normal draws — GPyTorch's preconditioner-
- *   distributed probe vectors), norms[c] = |z_c|, full_rhs[N x (p + 1)] = [z_c / |z_c| | y - *mean_dev].  p <= 16, k <= 64.
+ *   distributed probe vectors), full_rhs[N x (p + 1)] = [z | y - *mean_dev].  p <= 16, k <= 64.  The probes are not normalised:
+ *   rpgp_mbcg_solve normalises every column itself and returns Khat^-1 of the columns as given.
  * rpgp_step_value: inv_quad = sum_i full_rhs[i][col] solves[i][col] (N x T blocks);  out2[0] = (inv_quad + logdet) c1 + c2,
  *   out2[1] = inv_quad.  The workspace's first 4 bytes are an arrival counter: ZERO on entry (zero the buffer once), zero
  *   again on exit; it must not be shared between streams.
  * rpgp_step_lr: the two sides of the bilinear derivative from the solve of [probes | r] (solves: N x (p + 1)):
- *   left = [solves_c norms[c] gq / p | -gq alpha], right = [pre_probes | alpha], gq = g[0] * gscale (g: device scalar, the
+ *   left = [solves_c gq / p | -gq alpha], right = [pre_probes (row stride ldp) | alpha], gq = g[0] * gscale (g: device scalar, the
  *   incoming gradient); partials[2 b], partials[2 b + 1] = workgroup b's sum(left * right), sum(alpha); *nparts_out workgroups.
  * rpgp_step_hyper_backward: dPeff (d x J, gradient w.r.t. Peff, to be scaled by zfac) -> gradients of the raw parameters:
  *   g_raw_ls = -sum(dPeff P) / ls^2 sigmoid(raw_ls) (per row / column / overall), g_raw_os = gs_scale gs[0] sigmoid(raw_os),
@@ -496,16 +497,14 @@ int rpgp_slq_logdet(const float *alpha_hist, const float *beta_hist, int iters, 
 int rpgp_step_hyper(const float *raw_ls, int n_ls, const float *raw_os, const float *raw_noise, const float *mean,
                     const float *W, int d, int J, int prescale, float min_noise, float *Peff, float *dev_out,
                     float *outputscale_host, float *noise_host, float *mean_host, void *stream);
-size_t rpgp_step_probes_workspace_bytes(void);
 int rpgp_step_probes(const float *L, int k, const float *e1, const float *e2, float sqrt_noise, const float *y,
-                     const float *mean_dev, int64_t N, int p, float *probes, float *full_rhs, float *norms, void *workspace,
-                     size_t workspace_bytes, void *stream);
+                     const float *mean_dev, int64_t N, int p, float *full_rhs, void *stream);
 size_t rpgp_step_value_workspace_bytes(void);
 int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T, int col, double logdet, double c1, double c2,
                     float *out2, void *workspace, size_t workspace_bytes, void *stream);
 size_t rpgp_step_lr_workspace_bytes(void);
-int rpgp_step_lr(const float *solves, const float *norms, const float *pre_probes, const float *g, float gscale, int64_t N,
-                 int p, float *left, float *right, float *partials, int *nparts_out, void *stream);
+int rpgp_step_lr(const float *solves, const float *pre_probes, int64_t ldp, const float *g, float gscale, int64_t N, int p,
+                 float *left, float *right, float *partials, int *nparts_out, void *stream);
 int rpgp_step_hyper_backward(const float *dPeff, const float *W, int d, int J, int n_ls, int prescale, float zfac,
                              const float *hyper_dev, const float *gs, const float *partials, int nparts, const float *g,
                              float gscale, float dlp_over_n, float gs_scale, float *g_raw_ls, float *g_raw_os,

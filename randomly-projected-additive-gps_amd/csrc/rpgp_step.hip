@@ -6,8 +6,7 @@
 // softplus and its derivative, the lengthscale division, the probe draw z = L e1 + sigma e2 and its normalisation, the
 // concatenations that lay out [probes | y - c] and the two sides of the bilinear derivative, the reductions r.alpha,
 // sum(L * R), sum(alpha), the chain rule back to the raw parameters.  The device needs ~0.2 ms for them, the host ~0.9 ms to
-// issue them (profiles/r4_step_C2_step_gaps.txt): the step is HOST-bound there.  Each entry point below is one launch (two for
-// the probes) for one such stretch; the arithmetic is the one the torch operations perform (fp32, the same formulas), the
+// issue them (profiles/r4_step_C2_step_gaps.txt): the step is HOST-bound there.  Each entry point below is one launch for one such stretch; the arithmetic is the one the torch operations perform (fp32, the same formulas), the
 // reductions are fixed-order (bitwise reproducible).  rpgp_amd/fused_mll.py is the caller.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -81,23 +80,24 @@ __global__ __launch_bounds__(256) void k_step_hyper(const float *__restrict__ ra
   }
 }
 
-// ---- probes z = L e1 + sqrt(sigma^2) e2 (WoodburyPreconditioner.sample), their column norms, [z / |z| | y - c] ---------------
-constexpr int kMaxP = 16, kMaxKp = 64, kProbeBlocks = 512;
-// one ROW per thread (a wave reads 64 consecutive rows of L and e2: whole cache lines), the p <= 16 results in registers; the
-// column sums of squares are carried per thread over its rows and added up ONCE per workgroup, in a fixed order
+// ---- probes z = L e1 + sqrt(sigma^2) e2 (WoodburyPreconditioner.sample) and the solve's right-hand sides [z | y - c] ------------
+// One ROW per thread (a wave reads 64 consecutive rows of L and e2: whole cache lines), the p <= 16 results in registers, written
+// straight into the N x (p + 1) block with y - c in the last column.  The probes are NOT normalised here: the executor
+// normalises every right-hand-side column itself (k_init) and hands back Khat^-1 of the columns as given — exactly the
+// Khat^-1 z_p the derivative needs (the generic path divides by |z_p| first and multiplies the solves by it afterwards).
+constexpr int kMaxP = 16, kMaxKp = 64;
 __global__ __launch_bounds__(256) void k_step_probes(const float *__restrict__ L, int k, const float *__restrict__ e1,
-                                                     const float *__restrict__ e2, float sqrt_noise, long long N, int p,
-                                                     float *__restrict__ probes, float *__restrict__ part) {
+                                                     const float *__restrict__ e2, float sqrt_noise,
+                                                     const float *__restrict__ y, const float *__restrict__ mean_dev, long long N,
+                                                     int p, float *__restrict__ full_rhs) {
   __shared__ float se1[kMaxKp * kMaxP];                 // e1 padded to 16 columns
-  __shared__ float sq[256 * (kMaxP + 1)];
   for (int e = threadIdx.x; e < k * kMaxP; e += 256) {
     const int kk = e / kMaxP, c = e - kk * kMaxP;
     se1[e] = c < p ? e1[kk * p + c] : 0.f;
   }
   __syncthreads();
-  float ssq[kMaxP];
-#pragma unroll
-  for (int c = 0; c < kMaxP; ++c) ssq[c] = 0.f;
+  const float mu = mean_dev[0];
+  const int T = p + 1;
   for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < N; row += (long long)gridDim.x * 256) {
     float acc[kMaxP];
 #pragma unroll
@@ -109,51 +109,8 @@ __global__ __launch_bounds__(256) void k_step_probes(const float *__restrict__ L
     }
 #pragma unroll
     for (int c = 0; c < kMaxP; ++c)
-      if (c < p) {
-        const float v = acc[c] + sqrt_noise * e2[row * p + c];
-        probes[row * p + c] = v;
-        ssq[c] = __builtin_fmaf(v, v, ssq[c]);
-      }
-  }
-#pragma unroll
-  for (int c = 0; c < kMaxP; ++c) sq[threadIdx.x * (kMaxP + 1) + c] = ssq[c];
-  __syncthreads();
-  if (threadIdx.x < p) {
-    float s = 0.f;
-    for (int t = 0; t < 256; ++t) s += sq[t * (kMaxP + 1) + threadIdx.x];
-    part[(size_t)blockIdx.x * kMaxP + threadIdx.x] = s;
-  }
-}
-
-// norms from the partials (every workgroup adds them up itself: 16 groups of every 16th slab, then the groups in order);
-// full_rhs = [probes / |probes| | y - mean]
-__global__ __launch_bounds__(256) void k_step_rhs(const float *__restrict__ probes, const float *__restrict__ part, int nparts,
-                                                  const float *__restrict__ y, const float *__restrict__ mean_dev, long long N,
-                                                  int p, float *__restrict__ full_rhs, float *__restrict__ norms) {
-  __shared__ double sg[16][kMaxP];
-  __shared__ float snorm[kMaxP];
-  {
-    const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    double s = 0.0;
-    for (int q = grp; q < nparts; q += 16) s += (double)part[(size_t)q * kMaxP + c];
-    sg[grp][c] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < p) {
-    double s = 0.0;
-    for (int q = 0; q < 16; ++q) s += sg[q][threadIdx.x];
-    const float nrm = sqrtf((float)s);
-    snorm[threadIdx.x] = nrm;
-    if (blockIdx.x == 0) norms[threadIdx.x] = nrm;
-  }
-  __syncthreads();
-  const float mu = mean_dev[0];
-  const int T = p + 1;
-  const long long total = N * T;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long row = e / T;
-    const int c = (int)(e - row * T);
-    full_rhs[e] = c < p ? probes[row * p + c] / snorm[c] : y[row] - mu;
+      if (c < p) full_rhs[row * T + c] = acc[c] + sqrt_noise * e2[row * p + c];
+    full_rhs[row * T + p] = y[row] - mu;
   }
 }
 
@@ -198,17 +155,14 @@ __global__ __launch_bounds__(256) void k_step_value(const float *__restrict__ rh
 }
 
 // ---- the two sides of the bilinear derivative ---------------------------------------------------------------------------------
-// left = [Khat^-1 z_p * (g_ld / p) | -g_iq alpha],  right = [M^-1 z_p | alpha]   with Khat^-1 z_p = sol[:, c] * norms[c];
+// left = [Khat^-1 z_p * (g_ld / p) | -g_iq alpha],  right = [M^-1 z_p | alpha]   with Khat^-1 z_p = sol[:, c];
 // g_iq = g_ld = g[0] * gscale (the incoming gradient is a device scalar).  Per block: partial sum(left * right), sum(alpha).
 constexpr int kLrBlocks = 512;
-__global__ __launch_bounds__(256) void k_step_lr(const float *__restrict__ sol, const float *__restrict__ norms,
-                                                 const float *__restrict__ pre_probes, const float *__restrict__ g,
-                                                 float gscale, long long N, int p, float *__restrict__ left,
-                                                 float *__restrict__ right, float *__restrict__ part) {
-  __shared__ float snorm[kMaxP];
+__global__ __launch_bounds__(256) void k_step_lr(const float *__restrict__ sol, const float *__restrict__ pre_probes,
+                                                 long long ldp, const float *__restrict__ g, float gscale, long long N, int p,
+                                                 float *__restrict__ left, float *__restrict__ right,
+                                                 float *__restrict__ part) {
   __shared__ float s1[256], s2[256];
-  if (threadIdx.x < p) snorm[threadIdx.x] = norms[threadIdx.x];
-  __syncthreads();
   const float gq = g[0] * gscale;
   const float gp = gq / (float)p;
   const int T = p + 1;
@@ -220,8 +174,8 @@ __global__ __launch_bounds__(256) void k_step_lr(const float *__restrict__ sol, 
     const float sv = sol[e];
     float l, r;
     if (c < p) {
-      l = sv * snorm[c] * gp;
-      r = pre_probes[row * p + c];
+      l = sv * gp;
+      r = pre_probes[row * ldp + c];
     } else {
       l = -gq * sv;
       r = sv;
@@ -340,25 +294,13 @@ int rpgp_step_hyper(const float *raw_ls, int n_ls, const float *raw_os, const fl
   return 0;
 }
 
-size_t rpgp_step_probes_workspace_bytes(void) { return (size_t)kProbeBlocks * kMaxP * sizeof(float); }
-
 int rpgp_step_probes(const float *L, int k, const float *e1, const float *e2, float sqrt_noise, const float *y,
-                     const float *mean_dev, int64_t N, int p, float *probes, float *full_rhs, float *norms, void *workspace,
-                     size_t workspace_bytes, void *stream) {
-  if (!L || !e1 || !e2 || !y || !mean_dev || !probes || !full_rhs || !norms || N < 1 || p < 1 || p > kMaxP || k < 1 ||
-      k > kMaxKp)
-    return RPGP_EINVAL;
-  if (!workspace || workspace_bytes < rpgp_step_probes_workspace_bytes()) return RPGP_EWORKSPACE;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  float *part = reinterpret_cast<float *>(workspace);
-  const int rpb = 256 / p;
-  long long nb = (N + rpb - 1) / rpb;
-  if (nb > kProbeBlocks) nb = kProbeBlocks;
-  hipLaunchKernelGGL(k_step_probes, dim3((unsigned)nb), dim3(256), 0, st, L, k, e1, e2, sqrt_noise, (long long)N, p, probes, part);
-  long long nb2 = (N * (p + 1) + 255) / 256;
-  if (nb2 > 2048) nb2 = 2048;
-  hipLaunchKernelGGL(k_step_rhs, dim3((unsigned)nb2), dim3(256), 0, st, probes, part, (int)nb, y, mean_dev, (long long)N, p,
-                     full_rhs, norms);
+                     const float *mean_dev, int64_t N, int p, float *full_rhs, void *stream) {
+  if (!L || !e1 || !e2 || !y || !mean_dev || !full_rhs || N < 1 || p < 1 || p > kMaxP || k < 1 || k > kMaxKp) return RPGP_EINVAL;
+  long long nb = (N + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_step_probes, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), L, k, e1, e2,
+                     sqrt_noise, y, mean_dev, (long long)N, p, full_rhs);
   return (int)hipGetLastError();
 }
 
@@ -378,14 +320,14 @@ int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T
 
 size_t rpgp_step_lr_workspace_bytes(void) { return (size_t)kLrBlocks * 2 * sizeof(float); }
 
-int rpgp_step_lr(const float *solves, const float *norms, const float *pre_probes, const float *g, float gscale, int64_t N,
-                 int p, float *left, float *right, float *partials, int *nparts_out, void *stream) {
-  if (!solves || !norms || !pre_probes || !g || !left || !right || !partials || !nparts_out || N < 1 || p < 1 || p > kMaxP)
+int rpgp_step_lr(const float *solves, const float *pre_probes, int64_t ldp, const float *g, float gscale, int64_t N, int p,
+                 float *left, float *right, float *partials, int *nparts_out, void *stream) {
+  if (!solves || !pre_probes || !g || !left || !right || !partials || !nparts_out || N < 1 || p < 1 || p > kMaxP || ldp < p)
     return RPGP_EINVAL;
   long long nb = (N * (p + 1) + 255) / 256;
   if (nb > kLrBlocks) nb = kLrBlocks;
-  hipLaunchKernelGGL(k_step_lr, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), solves, norms,
-                     pre_probes, g, gscale, (long long)N, p, left, right, partials);
+  hipLaunchKernelGGL(k_step_lr, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), solves, pre_probes,
+                     (long long)ldp, g, gscale, (long long)N, p, left, right, partials);
   *nparts_out = (int)nb;
   return (int)hipGetLastError();
 }

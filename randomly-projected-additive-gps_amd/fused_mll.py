@@ -163,7 +163,7 @@ class _FusedMLL(torch.autograd.Function):
             gen = _probe_generator(Z.device)
             e1 = torch.randn(pre.k, p, generator=gen, device=Z.device, dtype=Z.dtype)      # (the draws of pre.sample, same order)
             e2 = torch.randn(n, p, generator=gen, device=Z.device, dtype=Z.dtype)
-            probes, full_rhs, norms = be.step_probes(pre.L, e1, e2, math.sqrt(noise_f), target, hyp[2:3])
+            full_rhs = be.step_probes(pre.L, e1, e2, math.sqrt(noise_f), target, hyp[2:3])      # [z | y - c], unnormalised
             khat = AddedDiagOperator(op, noise, noise_value=noise_f)
             matmul, native_op, _ = solve_operator(op, khat, Z, noise_f, p + 1)
             solves, hist = linear_cg(matmul, full_rhs, n_tridiag=p, operator=native_op,
@@ -177,7 +177,7 @@ class _FusedMLL(torch.autograd.Function):
         ctx.native = True
         ctx.n, ctx.dlp, ctx.prescale, ctx.zfac = n, dlp, pk.prescale, bk.input_scale_factor()
         ctx.X, ctx.W, ctx.hyp, ctx.op, ctx.pre = X, W, hyp, op, pre
-        ctx.solves, ctx.norms, ctx.probes = solves, norms, probes
+        ctx.solves, ctx.probes = solves, full_rhs[:, :p]          # (solves[:, :p] = Khat^-1 z: the probes were not normalised)
         ctx.shapes = (raw_ls.shape, raw_os.shape, raw_noise.shape, mean_c.shape)
         return out[0]
 
@@ -188,7 +188,7 @@ class _FusedMLL(torch.autograd.Function):
         with torch.no_grad():
             g = g.reshape(1).contiguous()
             pre_probes = ctx.pre.solve(ctx.probes)
-            left, right, part, nparts = be.step_lr(ctx.solves, ctx.norms, pre_probes, g, -0.5 / n)
+            left, right, part, nparts = be.step_lr(ctx.solves, pre_probes, g, -0.5 / n)
             op, gs_scale = ctx.op, 1.0
             from .operators import AdditiveRPOperator
             if type(op) is AdditiveRPOperator and (op.shard is None or op.shard.world_size <= 1):

@@ -1169,8 +1169,8 @@ def step_hyper(raw_ls, raw_os, raw_noise, mean, W, prescale, min_noise):
 
 
 def step_probes(L, e1, e2, sqrt_noise, y, mean_dev):
-    """z = L e1 + sqrt_noise e2, norms = |z_c|, full_rhs = [z_c / |z_c| | y - mean]: rpgp_step_probes (two launches).
-    Returns (probes [N x p], full_rhs [N x (p + 1)], norms [p])."""
+    """full_rhs [N x (p + 1)] = [L e1 + sqrt_noise e2 | y - mean]: rpgp_step_probes, one launch (the probes stay unnormalised:
+    the executor normalises its right-hand sides itself)."""
     lib = _lib.load()
     L = _require(L, "L", 2)
     e1 = _require(e1, "e1", 2)
@@ -1179,15 +1179,11 @@ def step_probes(L, e1, e2, sqrt_noise, y, mean_dev):
     p = e1.shape[1]
     if e1.shape[0] != k or e2.shape != (N, p) or y.shape != (N,) or y.dtype != torch.float32 or not y.is_contiguous():
         raise ValueError("step_probes: e1 is k x p, e2 is N x p, y has N float32 entries")
-    probes = torch.empty((N, p), dtype=torch.float32, device=L.device)
     full_rhs = torch.empty((N, p + 1), dtype=torch.float32, device=L.device)
-    norms = torch.empty(p, dtype=torch.float32, device=L.device)
     with _on(L.device):
-        ws = _workspace(L.device, lib.rpgp_step_probes_workspace_bytes())
         _lib.check(lib.rpgp_step_probes(L.data_ptr(), k, e1.data_ptr(), e2.data_ptr(), float(sqrt_noise), y.data_ptr(),
-                                        mean_dev.data_ptr(), N, p, probes.data_ptr(), full_rhs.data_ptr(), norms.data_ptr(),
-                                        ws.data_ptr(), ws.numel(), _stream()), "rpgp_step_probes")
-    return probes, full_rhs, norms
+                                        mean_dev.data_ptr(), N, p, full_rhs.data_ptr(), _stream()), "rpgp_step_probes")
+    return full_rhs
 
 
 _value_ws = {}
@@ -1208,19 +1204,22 @@ def step_value(full_rhs, solves, col, logdet, c1, c2):
     return out
 
 
-def step_lr(solves, norms, pre_probes, g, gscale):
-    """The two sides of the bilinear derivative (rpgp_step_lr): (left, right, partials, nparts)."""
+def step_lr(solves, pre_probes, g, gscale):
+    """The two sides of the bilinear derivative (rpgp_step_lr): (left, right, partials, nparts).  `pre_probes`: N x p with unit
+    column stride (any row stride)."""
     import ctypes
     lib = _lib.load()
     N, T = solves.shape
     p = T - 1
+    if pre_probes.shape != (N, p) or pre_probes.stride(1) != 1 or pre_probes.dtype != torch.float32:
+        raise ValueError("step_lr: pre_probes must be N x p float32 with unit column stride")
     left = torch.empty_like(solves)
     right = torch.empty_like(solves)
     part = torch.empty(lib.rpgp_step_lr_workspace_bytes() // 4, dtype=torch.float32, device=solves.device)
     nparts = ctypes.c_int(0)
     with _on(solves.device):
-        _lib.check(lib.rpgp_step_lr(solves.data_ptr(), norms.data_ptr(), pre_probes.data_ptr(), g.data_ptr(), float(gscale), N, p,
-                                    left.data_ptr(), right.data_ptr(), part.data_ptr(), ctypes.byref(nparts), _stream()),
+        _lib.check(lib.rpgp_step_lr(solves.data_ptr(), pre_probes.data_ptr(), pre_probes.stride(0), g.data_ptr(), float(gscale), N,
+                                    p, left.data_ptr(), right.data_ptr(), part.data_ptr(), ctypes.byref(nparts), _stream()),
                    "rpgp_step_lr")
     return left, right, part, nparts.value
 

@@ -22,10 +22,17 @@ def _require(t, name, ndim=None, allow64=False):
     return t.contiguous()
 
 
+# (private torch entry points, with the public ones as the fallback of a build that lacks them)
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEV = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 def _stream():
     """Raw handle of the current stream of the current device.  (`torch.cuda.current_stream().cuda_stream` is the same value
     through ~10 us of Python — 13 calls per optimiser step; the step is host-bound between its launches)"""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(_CUR_DEV())
+    return torch.cuda.current_stream().cuda_stream
 
 
 class _NoGuard:
@@ -43,7 +50,7 @@ def _on(device):
     """`torch.cuda.device(device)` — entered only when `device` is not the current device already (the context manager reads and
     restores the device through several Python layers: ~8 us per entry, ~20 entries per optimiser step)."""
     idx = device.index
-    if idx is None or idx == torch._C._cuda_getDevice():
+    if idx is None or idx == _CUR_DEV():
         return _NO_GUARD
     return torch.cuda.device(device)
 

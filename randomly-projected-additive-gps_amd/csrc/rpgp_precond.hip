@@ -32,12 +32,14 @@ constexpr int kGramMaxWg = 512;
 // instead of a second launch; three Gram products per optimiser step are on the host-bound stretches around the solve
 // (DESIGN §3.4).  Hand-off as in k_step_value (rpgp_step.hip): stores drained, workgroup barrier, agent-scope release, arrive;
 // the last arriver acquires and reads.  The counter returns to zero.
-template <int MA, int NB>
-__global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restrict__ A, long long lda,
+// NW = waves per workgroup: 4, or 16 for tall inputs — the slab count (= workgroups) is capped at 512, so at N = 391k four waves
+// per workgroup leave 8 waves per CU to hide ~12 dependent load round trips each (37 us for 39 MB); sixteen fill the CU.
+template <int MA, int NB, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gram_partial_kernel(const float *__restrict__ A, long long lda,
                                                            const float *__restrict__ B, long long ldb, long long N, int K,
                                                            int T, double *__restrict__ part, unsigned *__restrict__ counter,
                                                            double *__restrict__ out64, float *__restrict__ out32) {
-  __shared__ double sred[4][64];
+  __shared__ double sred[NW][64];
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restri
     for (int a = 0; a < MA; ++a)
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc[u][a][b] = doublex4p{0.0, 0.0, 0.0, 0.0};
-  const long long nwaves = (long long)gridDim.x * 4;
-  const long long w = (long long)blockIdx.x * 4 + wave;
+  const long long nwaves = (long long)gridDim.x * NW;
+  const long long w = (long long)blockIdx.x * NW + wave;
   const long long nsteps = (N + 3) / 4;
   for (long long s = w; s < nsteps; s += kU * nwaves) {
     float af[kU][MA], bf[kU][NB];
@@ -96,12 +98,17 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float *__restri
         sred[wave][lane] = v[r];
         __syncthreads();
         if (wave == 0) {
-          const double sum = ((sred[0][lane] + sred[1][lane]) + sred[2][lane]) + sred[3][lane];
+          double sum = ((sred[0][lane] + sred[1][lane]) + sred[2][lane]) + sred[3][lane];
+          if constexpr (NW == 16) {
+#pragma unroll
+            for (int g4 = 4; g4 < 16; g4 += 4)
+              sum += ((sred[g4][lane] + sred[g4 + 1][lane]) + sred[g4 + 2][lane]) + sred[g4 + 3][lane];
+          }
           part[(((size_t)blockIdx.x * (MA * NB) + (a * NB + b)) * 4 + r) * 64 + lane] = sum;
         }
       }
     }
-  if (!counter) return;
+  if (!counter || NW != 4) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -329,10 +336,16 @@ int gram_launch(const float *A, long long lda, const float *B, long long ldb, lo
     return !(e && e[0] == '0');
   }();
   if (fold_on && g <= 64) counter = gram_counter();
+  const bool tall = N >= 131072 && !counter;           // (sixteen waves per workgroup; the small tile counts only)
 #define RPGP_GRAM_CASE(MA_, NB_)                                                                                       \
-  if (ma == MA_ && nb == NB_)                                                                                          \
-    hipLaunchKernelGGL((gram_partial_kernel<MA_, NB_>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, N, K, T, part, counter,   \
-                       out64, out32)
+  if (ma == MA_ && nb == NB_) {                                                                                        \
+    if (tall && MA_ * NB_ <= 2)                                                                                        \
+      hipLaunchKernelGGL((gram_partial_kernel<MA_, NB_, 16>), dim3(g), dim3(1024), 0, st, A, lda, B, ldb, N, K, T, part,       \
+                         counter, out64, out32);                                                                       \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gram_partial_kernel<MA_, NB_, 4>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, N, K, T, part,        \
+                         counter, out64, out32);                                                                       \
+  }
   RPGP_GRAM_CASE(1, 1); RPGP_GRAM_CASE(1, 2); RPGP_GRAM_CASE(1, 4);
   RPGP_GRAM_CASE(2, 1); RPGP_GRAM_CASE(2, 2); RPGP_GRAM_CASE(2, 4);
   RPGP_GRAM_CASE(4, 1); RPGP_GRAM_CASE(4, 2); RPGP_GRAM_CASE(4, 4);

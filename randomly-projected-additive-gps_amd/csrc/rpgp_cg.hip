@@ -812,11 +812,8 @@ thread_local PollCtx g_poll;
 // After ~20 ms without the stamp (a kernel that never ran: launch error, hung device) the caller falls back to the runtime's
 // own synchronisation, which reports such errors.
 inline bool wait_record(const CgPoll *rec, int stamp) {
-  static const bool spin = [] {
-    const char *e = getenv("RPGP_CG_SPIN");          // RPGP_CG_SPIN=0: the runtime's synchronisation (A/B measurements)
-    return !(e && e[0] == '0');
-  }();
-  if (!spin) return false;
+  const char *e = getenv("RPGP_CG_SPIN");            // RPGP_CG_SPIN=0: the runtime's synchronisation (A/B measurements, tests)
+  if (e && e[0] == '0') return false;
   const volatile int *p = &rec->seq;
   for (long spins = 0; spins < 40000000L; ++spins) {
     if (*p == stamp) {

@@ -252,3 +252,29 @@ def test_history_quadrature_matches_tridiagonal_eigendecomposition(gpu_device):
     import math
     ld = pre.logdet()
     assert abs(ld - (float(pre._logdet_cap) + (N - pre.k) * math.log(0.2))) < 1e-9 * abs(ld)
+
+
+@pytest.mark.parametrize("N,J,ski", [(3000, 20, False), (9000, 8, False), (4000, 3, True)])
+def test_consumer_side_reductions_are_bitwise_the_separate_launches(gpu_device, monkeypatch, N, J, ski):
+    """The executor's two reduction forms (passes adding up the slabs themselves / `k_reduce` launches, RPGP_CG_DIRECT=0) and its
+    two ways of waiting (spinning on the pinned record / the runtime's synchronisation, RPGP_CG_SPIN=0) give bit-identical
+    solutions, coefficient histories and iteration counts; so do two runs of the same form."""
+    from rpgp_amd import linear_cg as lcg
+    from rpgp_amd.precond import pivoted_cholesky, WoodburyPreconditioner
+    noise = 0.2
+    base, khat = _ops_pair(gpu_device, N, J, noise, ski, 1.0, seed=N + 1)
+    rhs = torch.randn(N, 11, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    pre = WoodburyPreconditioner(pivoted_cholesky(base._diagonal(), base._get_rows, 15), noise)
+    kw = dict(n_tridiag=10, tolerance=1e-4, max_iter=500, max_tridiag_iter=20, preconditioner=pre, operator=khat, lanczos="history")
+    outs = []
+    for env in ({}, {"RPGP_CG_DIRECT": "0"}, {"RPGP_CG_DIRECT": "0", "RPGP_CG_SPIN": "0"}, {}):
+        for k in ("RPGP_CG_DIRECT", "RPGP_CG_SPIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        x, hist = lcg.linear_cg(khat._matmul, rhs, **kw)
+        outs.append((x.clone(), hist.alpha.copy(), hist.beta.copy(), lcg.stats["last_iterations"]))
+    for x, a, b, it in outs[1:]:
+        assert it == outs[0][3]
+        assert torch.equal(x, outs[0][0])
+        assert np.array_equal(a, outs[0][1]) and np.array_equal(b, outs[0][2])

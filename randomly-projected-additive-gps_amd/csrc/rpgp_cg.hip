@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "../../include/rpgp.h"
+#include "rpgp_internal.h"
 
 namespace {
 
@@ -809,20 +810,22 @@ thread_local PollCtx g_poll;
 // Wait for a record a kernel publishes into pinned memory (publish_poll): the host SPINS on the stamp — the record of a
 // 5 us pass arrives within microseconds of the pass finishing, where hipEventSynchronize / hipStreamSynchronize wake the
 // thread up ~50 - 150 us later (measured as an idle device in front of k_unnormalise, once per solve, and again behind it).
-// After ~20 ms without the stamp (a kernel that never ran: launch error, hung device) the caller falls back to the runtime's
-// own synchronisation, which reports such errors.
-inline bool wait_record(const CgPoll *rec, int stamp) {
-  const char *e = getenv("RPGP_CG_SPIN");            // RPGP_CG_SPIN=0: the runtime's synchronisation (A/B measurements, tests)
-  if (e && e[0] == '0') return false;
+// The spin is bounded by wall time (`budget_us`): a poll record of an EARLIER iteration is at most a few passes away
+// (kPollSpinUs); the final record sits behind everything the host queued ahead, so after kFinalSpinUs the caller blocks in
+// the runtime's own synchronisation instead of burning a core for the rest of a long solve (its late wake-up is then a
+// negligible part of that solve) — which is also what reports a failed launch or a hung device.
+constexpr long kPollSpinUs = 2000, kFinalSpinUs = 20000;
+inline bool cg_spin_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("RPGP_CG_SPIN");          // RPGP_CG_SPIN=0: the runtime's synchronisation (A/B measurements, tests)
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+inline bool wait_record(const CgPoll *rec, int stamp, long budget_us) {
+  if (!cg_spin_enabled()) return false;
   const volatile int *p = &rec->seq;
-  for (long spins = 0; spins < 40000000L; ++spins) {
-    if (*p == stamp) {
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      return true;
-    }
-    __builtin_ia32_pause();
-  }
-  return false;
+  return rpgp_internal::spin_until([p, stamp] { return *p == stamp; }, budget_us);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1147,7 +1150,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
                 it + 1, stagnation_window, x, x_best, poll_dst, nil, 0);
     }
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
-      if (!wait_record(&hpoll[polled_it % kPollRing], polled_it + 1)) CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
+      if (!wait_record(&hpoll[polled_it % kPollRing], polled_it + 1, kPollSpinUs)) CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
       last = hpoll[polled_it % kPollRing];
       polled_it = -1;
       if (last.done) {
@@ -1171,7 +1174,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     *reinterpret_cast<volatile int *>(&hpoll[kPollRing].seq) = 0;
     hipLaunchKernelGGL(k_unnormalise, dim3(nbc), dim3(256), 0, st, x, x_best, state, N, T, g_poll.host_dev + kPollRing);
     CG_CHECK(hipGetLastError());
-    if (!wait_record(&hpoll[kPollRing], 1)) CG_CHECK(hipStreamSynchronize(st));
+    if (!wait_record(&hpoll[kPollRing], 1, kFinalSpinUs)) CG_CHECK(hipStreamSynchronize(st));
   } else {
     CG_CHECK(hipMemcpyAsync(&hpoll[kPollRing], &state->poll, sizeof(CgPoll), hipMemcpyDeviceToHost, st));
     CG_CHECK(hipStreamSynchronize(st));

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "../../include/rpgp.h"
+#include "rpgp_internal.h"
 
 namespace {
 
@@ -258,15 +259,10 @@ __global__ __launch_bounds__(256) void k_step_hyper_backward(const float *__rest
   }
 }
 
+// (wall-time bounded: the single-workgroup kernel behind this stamp finishes within microseconds of its launch unless the
+//  queue in front of it is long — then the runtime's synchronisation takes over, rpgp_internal::spin_until)
 inline bool spin_stamp(const volatile float *p, float stamp) {
-  for (long spins = 0; spins < 40000000L; ++spins) {
-    if (*p == stamp) {
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      return true;
-    }
-    __builtin_ia32_pause();
-  }
-  return false;
+  return rpgp_internal::spin_until([p, stamp] { return *p == stamp; }, 5000);
 }
 
 }  // namespace

@@ -25,7 +25,7 @@ from torch.nn import functional as F
 
 from . import backend as _backend
 from . import settings
-from .hostvals import host_float, prefetch
+from .hostvals import host_float, prefetch, remember
 
 LOG2PI = math.log(2.0 * math.pi)
 
@@ -153,7 +153,8 @@ class _FusedMLL(torch.autograd.Function):
             Peff, hyp, os_f, noise_f, _ = be.step_hyper(raw_ls.reshape(-1), raw_os.reshape(-1), raw_noise.reshape(-1),
                                                         mean_c.reshape(-1), W, pk.prescale, likelihood.MIN_NOISE)
             os_, noise = hyp[0], hyp[1]                            # 0-dim views; their host values are known
-            os_._host_value, noise._host_value = os_f, noise_f
+            remember(os_, os_f)
+            remember(noise, noise_f)
             Z = be.project(X, Peff)
             op = bk.operator(Z, None, outputscale=os_, shard=None)
             op._noise_host = noise_f

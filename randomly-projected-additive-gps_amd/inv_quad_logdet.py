@@ -11,7 +11,7 @@ Two regimes, switched like GPyTorch does (Appendix B.1):
 import torch
 
 from . import settings
-from .hostvals import host_float
+from .hostvals import host_float, peek
 from .linear_cg import linear_cg
 from .operators import AddedDiagOperator, DenseOperator, SKIAdditiveOperator, SymCachedOperator
 from .precond import build_preconditioner
@@ -300,6 +300,6 @@ def _row_sharded_backward(ctx, g_inv_quad, g_logdet):
 def inv_quad_logdet(op, noise, rhs):
     """op: symmetric AdditiveRPOperator on (Z, outputscale) (both may require grad); noise: 0-dim tensor; rhs: (N,)."""
     noise_t = noise.reshape(())
-    op._noise_host = getattr(noise, "_host_value", None)      # (set by hostvals.prefetch in the marginal log-likelihood)
+    op._noise_host = peek(noise)                              # (set by hostvals.prefetch in the marginal log-likelihood)
     gr = InvQuadLogDet.apply(op.Z1, op.outputscale, noise_t, rhs, op, getattr(op, "comp_weights", None))
     return gr

@@ -164,19 +164,30 @@ class PredictionStrategy:
         shard = getattr(self.op, "shard", None)
         if shard is not None and shard.world_size > 1:
             return False
-        total = torch.cuda.get_device_properties(like.device).total_memory
-        c = min(n_test, max(32, settings.predictive_block_floats.value() // max(n_train, 1)))
-        need = 20.0 * n_train * n_train + 32.0 * n_train * c + 12.0 * n_test * n_test
-        if need > 0.7 * total:
-            return False
         if getattr(self, "_mp", None) is None:
-            if getattr(self, "_dense_khat", None) is None:
-                self._dense_khat = DenseOperator(self.op.to_dense_cached() if hasattr(self.op, "to_dense_cached")
-                                                 else self.op.to_dense(), host_float(self.noise))
-            Kh = self._dense_khat.to_dense()                       # float32, noise on the diagonal
-            K64 = Kh.double()
-            Lc, info = torch.linalg.cholesky_ex(Kh)
-            del Kh
+            # decided on the memory that is FREE now (the symmetric / dense cache, the LOVE and solve buffers of this
+            # strategy and, with several ranks on one device, the other processes already hold theirs), minus a margin
+            # for the library's potrf / trsm workspaces; what the allocator caches but does not use counts as free
+            free, _total = torch.cuda.mem_get_info(like.device)
+            free += torch.cuda.memory_reserved(like.device) - torch.cuda.memory_allocated(like.device)
+            c = min(n_test, max(32, settings.predictive_block_floats.value() // max(n_train, 1)))
+            have = 4.0 * n_train * n_train if getattr(self, "_dense_khat", None) is not None else 0.0
+            need = 20.0 * n_train * n_train - have + 32.0 * n_train * c + 12.0 * n_test * n_test
+            if need > 0.8 * free - 2.0e9:
+                return False
+            try:
+                if getattr(self, "_dense_khat", None) is None:
+                    self._dense_khat = DenseOperator(self.op.to_dense_cached() if hasattr(self.op, "to_dense_cached")
+                                                     else self.op.to_dense(), host_float(self.noise))
+                Kh = self._dense_khat.to_dense()                   # float32, noise on the diagonal
+                K64 = Kh.double()
+                Lc, info = torch.linalg.cholesky_ex(Kh)
+                del Kh
+            except torch.OutOfMemoryError:                         # lost the race for the memory: the general path serves
+                Kh = K64 = Lc = None
+                self._mp = False
+                torch.cuda.empty_cache()
+                return False
             if int(info) != 0:
                 self._mp = False
             else:

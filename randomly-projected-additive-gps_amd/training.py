@@ -57,8 +57,9 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
     """Additive randomly-projected kernel (RPA-GP; DPA-GP when `space_proj`).  Same options and validation errors as
     training_routines.py:131-189.  `ski=True` selects the 1-D grid-interpolation operator.
     k > 1 RBF sub-kernels of ANY k <= 20 run on the family kernels (k outside (2, 3, 4, 5, 8, 10, 20) zero-padded to the next
-    instantiated group size: the same function); k > 1 with Matern / InverseMQ / Cosine sub-kernels raises
-    NotImplementedError (no reference specification uses it)."""
+    instantiated group size: the same function); k > 1 Matern / InverseMQ / Cosine sub-kernels (radial form of the
+    per-dimension AdditiveKernel, `batch_kernel=False`) run on the runtime-(kind, group) kernels of
+    csrc/rpgp_family_generic.hip for k <= 32 and J k <= 64 projected columns; NotImplementedError outside those limits."""
     if k > 1 and (mem_efficient or batch_kernel or space_proj):
         raise ValueError("Can't have k > 1 with memory efficient GAM kernel or a batch kernel or spaced projections.")
     if mem_efficient:
@@ -73,7 +74,7 @@ def create_additive_rp_kernel(d, J, learn_proj=False, kernel_type="RBF", space_p
     if k > 1 and kernel_type != "RBF" and (batch_kernel or k > 32 or J * k > 64):
         raise NotImplementedError("k > 1 sub-kernels of the non-RBF types: the radial form of the per-dimension AdditiveKernel "
                                   "(batch_kernel=False), k <= 32 and J k <= 64 columns")
-    if k > 20:
+    if k > 20 and kernel_type == "RBF":
         raise NotImplementedError("k-dimensional RBF sub-kernels are built up to k = 20 (the reference's largest: "
                                   "additive_rp_prescale_J1_K20.json); other k are padded to the next instantiated size")
     if ski and (k > 1 or kernel_type != "RBF"):
@@ -336,7 +337,11 @@ _GPY_INNER_LS = "covar_module.base_kernel.base_kernel.base_kernel.base_kernel.ra
 
 
 def gpytorch_state_dict(model):
-    """`model.state_dict()` re-keyed to the GPyTorch layout above (flagship `additive_rp` structure)."""
+    """`model.state_dict()` re-keyed to the GPyTorch layout above (flagship `additive_rp` structure).
+
+    The layout is written from memory ([GPT-mem]) and carries the PARAMETERS only: GPyTorch modules also register
+    their prior and constraint buffers (`...raw_noise_constraint.lower_bound`, `...noise_prior.a`, ...), which are not
+    emitted here — load the result on the GPyTorch side with `model.load_state_dict(state, strict=False)`."""
     from .kernels import inv_softplus
     out = {}
     for k, v in model.state_dict().items():
@@ -480,14 +485,22 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
                    skip_posterior_variances=False, skip_random_restart=False, evaluate_on_train=True,
                    output_device=None, record_pred_unc=False, double=False):
     """Create and train an exact GP with the given options (counterpart of training_routines.py:469-585: same arguments,
-    same metric names, same return triple).  Returns (model_metrics, pred_mean [cpu float32], model)."""
+    same metric names, same return triple).  Returns (model_metrics, pred_mean [cpu float32], model).
+
+    Row order: for grid-interpolation models (`ski: true`) with N >= 4096 the TRAINING rows are stored in a
+    locality-preserving order (`locality_order`: Morton code of the leading principal coordinates) — the returned
+    `model.train_inputs` / `model.train_targets` are that permutation of the caller's (trainX, trainY), kept on the model as
+    `model.train_row_order` (a LongTensor `order` with `model.train_inputs == trainX[order]`; None when the rows were not
+    reordered).  `pred_mean` and every metric refer to the TEST rows, whose order is the caller's; a GP's posterior does
+    not depend on the order of its training rows.  `RPGP_SKI_ROW_ORDER=file` keeps the caller's order."""
     model_kwargs, train_kwargs = copy.copy(model_kwargs), copy.copy(train_kwargs)
     if double:
         _check_double_supported(kind, model_kwargs)
     dtype = torch.double if double else torch.float
     devices = [torch.device(dev) for dev in devices]
     output_device = devices[0] if output_device is None else torch.device(output_device)
-    if model_kwargs.get("ski", False) and trainX.shape[0] >= 4096:
+    order = None
+    if model_kwargs.get("ski", False) and trainX.shape[0] >= 4096 and os.environ.get("RPGP_SKI_ROW_ORDER", "") != "file":
         # grid-interpolation kernels: store the training set in a locality-preserving row order (see locality_order)
         order = locality_order(trainX)
         trainX, trainY = trainX[order.to(trainX.device)], trainY[order.to(trainY.device)]
@@ -521,6 +534,7 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
     model_metrics["training_warnings"] = len(fit_warnings)
     model_metrics["testing_warning"] = "" if len(test_warnings) == 0 else test_warnings[-1].message
     model_metrics["state_dict_file"] = _save_state_dict(model)
+    model.train_row_order = None if order is None else order.to("cpu")
     return model_metrics, pred_mean.to("cpu", torch.float), model
 
 

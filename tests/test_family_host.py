@@ -181,6 +181,9 @@ def test_family_validation_errors():
     create_additive_rp_kernel(6, 3, k=2, batch_kernel=False, kernel_type="Matern")     # radial k-dimensional Matern: served
     with pytest.raises(NotImplementedError):
         create_additive_rp_kernel(6, 3, k=40, batch_kernel=False, kernel_type="Matern")
+    create_additive_rp_kernel(30, 2, k=24, batch_kernel=False, kernel_type="Matern")   # non-RBF: k <= 32, J k <= 64 columns
+    with pytest.raises(NotImplementedError):
+        create_additive_rp_kernel(30, 3, k=24, batch_kernel=False, kernel_type="Matern")   # 72 columns
     create_additive_rp_kernel(6, 3, k=7, batch_kernel=False)            # any k <= 20 is served (padded group)
     with pytest.raises(NotImplementedError):
         create_additive_rp_kernel(6, 1, k=21, batch_kernel=False)
@@ -362,3 +365,18 @@ def test_model_average_weights_and_routine(oracle_backend, tmp_path):
     json.dump(spec, open(f, "w"))
     df = runner.main(["-m", str(f), "-d", "synthetic:tiny", "-o", str(tmp_path / "ma.csv"), "--no_cv"])
     assert np.isfinite(df.iloc[0]["normal_mean_mse"]) and np.isfinite(df.iloc[0]["rmse"])
+
+
+def test_utils_getters_on_this_builds_kernels():
+    """The four introspection getters of the reference's utils.py (:7-52), kept as an extra."""
+    from rpgp_amd import utils
+    from rpgp_amd.kernels import ScaleKernel
+    from rpgp_amd.training import create_additive_rp_kernel, create_rp_poly_kernel
+    k = ScaleKernel(create_additive_rp_kernel(5, 4, prescale=True, init_lengthscale_range=(2.0, 2.0)))
+    ls = utils.get_lengthscales(k)
+    assert isinstance(ls, torch.Tensor) and torch.allclose(ls.detach().reshape(-1), torch.full((5,), 2.0), atol=1e-6)
+    assert utils.get_mixins(k) is None and float(utils.get_outputscale(k)) == float(k.outputscale)
+    g = create_rp_poly_kernel(5, 2, 3, weighted=True)
+    assert [len(c) for c in utils.get_lengthscales(g)] == [2, 2, 2] and len(utils.get_mixins(g)) == 3
+    assert utils.format_for_str([0.12345, torch.tensor([1.23456])]) == [0.123, [1.235]]
+    assert utils.format_for_str("x") == ""

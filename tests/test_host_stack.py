@@ -658,3 +658,45 @@ def test_library_slq_matches_eigendecomposition():
     assert abs(got - np.linalg.slogdet(A)[1]) < 0.2 * abs(ref)        # (and it IS a log-determinant estimate)
     hist = lcg.LanczosHistory(ah[:, :p], bh[:, :p], p, torch.float32, "cpu")
     assert abs(float(slq_logdet(hist, n)) - ref) < 1e-12 * abs(ref)
+
+
+def test_hostvals_drop_a_remembered_value_when_the_tensor_changes():
+    """The remembered host copy of a scalar follows in-place updates (version counter) and rebinding (data pointer)."""
+    from rpgp_amd.hostvals import forget, host_float, peek, prefetch, remember
+    t = torch.tensor(0.3)
+    assert host_float(t) == pytest.approx(0.3)
+    t.add_(1.0)
+    assert host_float(t) == pytest.approx(1.3)
+    p = torch.nn.Parameter(torch.tensor(2.0))
+    prefetch(p, t)
+    assert peek(p) == pytest.approx(2.0)
+    with torch.no_grad():
+        p.mul_(0.5)                                            # what optimizer.step() does to a leaf
+    assert peek(p) is None and host_float(p) == pytest.approx(1.0)
+    p.data = torch.tensor(7.0)                                 # rebinding: new storage, same object
+    assert host_float(p) == pytest.approx(7.0)
+    remember(t, 5.0)                                           # a value known by other means is taken as given ...
+    assert host_float(t) == 5.0
+    t.zero_()                                                  # ... until the tensor changes
+    assert host_float(t) == 0.0
+    forget(t)
+    assert peek(t) is None
+
+
+def test_operator_scale_and_noise_follow_in_place_updates_of_leaf_tensors():
+    """AdditiveRPOperator._scale / AddedDiagOperator._noise are read through hostvals: a leaf updated in place between two
+    constructions must give the new value (advisor finding, round 4)."""
+    from rpgp_amd.inv_quad_logdet import AddedDiagOperator
+    from rpgp_amd.operators import AdditiveRPOperator
+    Z = torch.randn(9, 3)
+    s = torch.tensor(0.7, requires_grad=True)
+    n = torch.tensor(0.2, requires_grad=True)
+    op = AdditiveRPOperator(Z, None, outputscale=s)
+    assert op._scale == pytest.approx(0.7 * op.weight)
+    assert AddedDiagOperator(op, n)._noise == pytest.approx(0.2)
+    with torch.no_grad():
+        s.add_(0.5)
+        n.mul_(3.0)
+    op2 = AdditiveRPOperator(Z, None, outputscale=s)
+    assert op2._scale == pytest.approx(1.2 * op2.weight)
+    assert AddedDiagOperator(op2, n)._noise == pytest.approx(0.6)

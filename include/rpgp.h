@@ -273,6 +273,16 @@ int rpgp_ski_scatter_planned(const void *plan, const float *V, double *hist, int
                              size_t workspace_bytes, void *stream);
 int rpgp_ski_gather_fast(const void *plan, const float *Z, const float *grid_params, const float *H, const float *V, float *out,
                          int64_t M, int ldz, int J, int G, int T, float scale, float noise, void *stream);
+/*
+ * Chunked form of the planned product (round 5; J <= 4 projections, N >= 16384, G <= 2048, T <= 12 — the shape of the
+ * reference's additive_spread_prescale_Jd_ski.json on 3droad, training_routines.py:157-158): the rows are cut into ~256
+ * contiguous chunks, a chunk's rows of V are staged in LDS once for all projections, a chunk leaves one window of grid
+ * rows per projection and reads back only the window of the Toeplitz product it needs.  Same entry points, same result
+ * contract (bitwise reproducible; the gather is bit-identical to the cell-sorted form, the scatter sums in another order).
+ * rpgp_ski_plan builds the tables of both forms; rpgp_ski_chunk_mode(0 | 1) selects the form the products run (process-wide;
+ * default 1, or the environment variable RPGP_SKI_CHUNK), any other argument only queries.  Returns the previous setting.
+ */
+int rpgp_ski_chunk_mode(int mode);
 /* Pivoted Cholesky of the SKI operator (same contract as rpgp_pivoted_cholesky; diag_work: N + RPGP_PIVCHOL_SCRATCH). */
 int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
                               int J, int G, int rank, float scale, void *stream);

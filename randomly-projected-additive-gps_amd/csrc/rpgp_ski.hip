@@ -45,8 +45,46 @@ struct PlanView {
   int *item_start;     // [J * G + 1]  first scatter item of the cell (exclusive scan of ceil(count / kSeg))
   int2 *item_info;     // [max_items]  (first sorted entry, number of points) of every scatter item
   double *tcol;        // [J][G16]  first column of the Toeplitz matrix of every projection, exp(-0.5 (k h_j)^2)
+  // chunked product (round 5; only when chunk_ok(N, J, G)) -- see "chunked product" below
+  int CH, nch;         // rows per chunk, chunks
+  int4 *winfo;         // [nch * J]       (first cell, cells spanned, first window row in the window table, window rows)
+  float *uloc;         // [nch * J][CH]   clamped grid coordinate of every (chunk row, projection)
+  uint16_t *lperm;     // [nch * J][CH]   the chunk's rows sorted by (cell, row)
+  uint16_t *coff;      // [nch * J][G]    first sorted entry of every cell of the window (+ one closing entry)
   size_t bytes;
 };
+
+// ---- chunked product: geometry ---------------------------------------------------------------------------------------------
+// The rows are cut into `nch` contiguous chunks of CH rows, one per workgroup and about one per CU; CH <= 2048 so that
+// chunk-local row numbers and offsets are 16-bit and a chunk's right-hand-side rows fit in LDS.
+constexpr int kChunkTarget = 256;              // chunks aimed at (the CUs of an MI355X)
+constexpr int kChunkMaxRows = 2048;
+inline int chunk_rows(long long N) {
+  long long ch = (N + kChunkTarget - 1) / kChunkTarget;
+  ch = (ch + 15) & ~15LL;
+  if (ch < 256) ch = 256;
+  if (ch > kChunkMaxRows) ch = kChunkMaxRows;
+  return (int)ch;
+}
+// RPGP_SKI_CHUNK=0 (or rpgp_ski_chunk_mode(0)): the cell-sorted product of rounds 3 - 4 (A/B measurements, tests).  The
+// plan carries the tables of BOTH products whenever the shape allows, so the switch may be flipped between two products.
+inline int &chunk_mode_ref() {
+  static int mode = [] {
+    const char *e = getenv("RPGP_SKI_CHUNK");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return mode;
+}
+inline bool chunk_env_on() { return chunk_mode_ref() != 0; }
+// The window table lives in the scatter slabs of the SKI workspace (rpgp_ski_workspace_bytes: 1024 / J chunks of J x G x 12
+// floats), which bounds chunks x projections by 1024; few projections, enough rows to fill the chip.
+inline bool chunk_shape_ok(long long N, int J, int G) {
+  if (J < 1 || J > 4 || G < 8 || G > 2048 || N < 16384) return false;
+  const int ch = chunk_rows(N);
+  const long long nch = (N + ch - 1) / ch;
+  return nch * J <= 1024 && nch <= (1024 + J - 1) / J;
+}
+inline bool chunk_ok(long long N, int J, int G) { return chunk_env_on() && chunk_shape_ok(N, J, G); }
 
 inline long long max_items(long long N, int J, int G);
 
@@ -62,6 +100,17 @@ inline PlanView plan_view(void *base, long long N, int J, int G) {
   v.item_start = reinterpret_cast<int *>(p); p += align256(cells * sizeof(int));
   v.item_info = reinterpret_cast<int2 *>(p); p += align256((size_t)max_items(N, J, G) * sizeof(int2));
   v.tcol = reinterpret_cast<double *>(p); p += align256((size_t)J * G16 * sizeof(double));
+  v.CH = v.nch = 0;
+  v.winfo = nullptr; v.uloc = nullptr; v.lperm = nullptr; v.coff = nullptr;
+  if (chunk_shape_ok(N, J, G)) {       // (the area is there whatever RPGP_SKI_CHUNK says: the size must not depend on it)
+    v.CH = chunk_rows(N);
+    v.nch = (int)((N + v.CH - 1) / v.CH);
+    const size_t cj = (size_t)v.nch * J;
+    v.winfo = reinterpret_cast<int4 *>(p); p += align256(cj * sizeof(int4));
+    v.uloc = reinterpret_cast<float *>(p); p += align256(cj * v.CH * sizeof(float));
+    v.lperm = reinterpret_cast<uint16_t *>(p); p += align256(cj * v.CH * sizeof(uint16_t));
+    v.coff = reinterpret_cast<uint16_t *>(p); p += align256(cj * G * sizeof(uint16_t));
+  }
   v.bytes = (size_t)(p - reinterpret_cast<char *>(base));
   return v;
 }
@@ -484,11 +533,436 @@ __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__res
   }
 }
 
+// ============================================================================================================================
+// Chunked product (round 5).  The cell-sorted scatter above reads, per projection, every row of V in grid-cell order: J random
+// passes over a 17 MB array in 44-byte pieces (C5: 93 MB fetched for 51 MB useful) behind three dependent round trips.  Here a
+// workgroup owns a contiguous CHUNK of rows (about N / 256 of them):
+//   scatter : the chunk's rows of V are copied to LDS ONCE, in storage order (one coalesced block), and serve all J projections;
+//             per projection the chunk's rows are walked in (cell, row) order through a 16-bit chunk-local permutation, a lane
+//             group per cell — a segmented sum without atomics whose operands are LDS reads; the four taps of neighbouring
+//             cells are combined by lane shuffles, and the chunk leaves one WINDOW of grid rows [first cell, last cell + 3]
+//             per projection.  With the rows stored in a locality-preserving order (training.locality_order) a chunk's window
+//             is ~100 - 150 of the 1024 grid rows; in any order the product is the same, only the windows grow.
+//   combine : hist[j][g] = the windows that cover g, added in chunk order in float64 (fixed order: bitwise reproducible).
+//   gather  : a chunk reads the window of H it needs into LDS (not all of H) and its rows' stencils once.
+// The plan keeps, per (chunk, projection): the clamped grid coordinates, the permutation, the per-cell offsets and the window.
+// ============================================================================================================================
+constexpr int kPlanItems = 8;                  // rows per thread of the plan's block sort (256 threads x 8 = kChunkMaxRows)
+
+// one workgroup per (chunk, projection): grid coordinates, (cell, row) block sort, per-cell offsets, window bounds
+__global__ __launch_bounds__(256) void chunk_plan_kernel(const float *__restrict__ Z, const float *__restrict__ gp, long long N,
+                                                         int ldz, int J, int G, int CH, int4 *__restrict__ winfo,
+                                                         float *__restrict__ uloc, uint16_t *__restrict__ lperm,
+                                                         uint16_t *__restrict__ coff) {
+  using Sort = rocprim::block_radix_sort<unsigned, 256, kPlanItems>;
+  __shared__ typename Sort::storage_type sort_storage;
+  __shared__ int cnt[kChunkMaxRows + 8];       // points per cell (G <= 2048), then their exclusive scan
+  __shared__ int red[2][4];
+  __shared__ int wsum[4];
+  const int chunk = blockIdx.x, j = blockIdx.y;
+  const long long base = (long long)chunk * CH;
+  const int n = (int)((N - base) < CH ? (N - base) : CH);
+  const float *gj = ski_grid_of(gp, J, j);
+  const float g0 = gj[0], inv_h = gj[2];
+  const size_t cj = (size_t)chunk * J + j;
+  for (int c = threadIdx.x; c < G + 8; c += 256) cnt[c] = 0;
+  __syncthreads();
+  unsigned keys[kPlanItems];
+  int cmin = 0x7fffffff, cmax = -1;
+#pragma unroll
+  for (int i = 0; i < kPlanItems; ++i) {
+    const int p = threadIdx.x * kPlanItems + i;
+    keys[i] = 0xffffffffu;
+    if (p < n) {
+      const float u = ski_grid_coord(Z[(base + p) * ldz + j], g0, inv_h, G);
+      float w[4], dw[4];
+      const int cell = ski_taps_u<false>(u, inv_h, G, w, dw);
+      uloc[cj * CH + p] = u;
+      keys[i] = ((unsigned)cell << 11) | (unsigned)p;
+      atomicAdd(&cnt[cell], 1);
+      cmin = cell < cmin ? cell : cmin;
+      cmax = cell > cmax ? cell : cmax;
+    } else if (p < CH) {
+      uloc[cj * CH + p] = 1.0f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int a = __shfl_xor(cmin, off, 64), b = __shfl_xor(cmax, off, 64);
+    cmin = a < cmin ? a : cmin;
+    cmax = b > cmax ? b : cmax;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = cmin;
+    red[1][threadIdx.x >> 6] = cmax;
+  }
+  Sort().sort(keys, sort_storage, 0, 22);      // 11 bits of row, <= 11 bits of cell; padding keys sort last
+  __syncthreads();
+  cmin = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
+  cmax = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
+#pragma unroll
+  for (int i = 0; i < kPlanItems; ++i) {
+    const int pos = threadIdx.x * kPlanItems + i;
+    if (pos < CH) lperm[cj * CH + pos] = (uint16_t)(pos < n ? (keys[i] & 2047u) : 0u);
+  }
+  // exclusive scan of the counts of cells cmin .. cmax (+ the closing entry): 8 consecutive cells per thread
+  const int ncell = cmax - cmin + 1;
+  int loc[8], run = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x * 8 + i;
+    loc[i] = run;
+    run += (c < ncell) ? cnt[cmin + c] : 0;
+  }
+  int incl = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if ((int)(threadIdx.x & 63) >= off) incl += v;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int before = incl - run;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wsum[w];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x * 8 + i;
+    if (c <= ncell && c < G) coff[cj * G + c] = (uint16_t)(before + loc[i]);
+  }
+  if (threadIdx.x == 0) winfo[cj] = make_int4(cmin, ncell, 0, ncell + 3);
+}
+
+// first window row of every (chunk, projection) in the window table: exclusive scan of the window lengths, one workgroup
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(int4 *__restrict__ winfo, int n) {
+  __shared__ int ssum[1024];
+  const int len = (int)threadIdx.x < n ? winfo[threadIdx.x].w : 0;
+  ssum[threadIdx.x] = len;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = 0;
+    if ((int)threadIdx.x >= off) v = ssum[threadIdx.x - off];
+    __syncthreads();
+    ssum[threadIdx.x] += v;
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < n) winfo[threadIdx.x].z = ssum[threadIdx.x] - len;
+}
+
+// LDS rows of P = 4 LPP floats: element e of the chunk's contiguous n x T block -> (row, column) without a division
+// (e < 2048 * 12 < 2^15, T <= 12: floor(e / T) = (e * ceil(2^20 / T)) >> 20 exactly)
+__device__ __forceinline__ unsigned div_small(unsigned e, unsigned magic) { return (e * magic) >> 20; }
+
+template <int LPP>
+__global__ __launch_bounds__(1024) void ski_chunk_scatter_kernel(const int4 *__restrict__ winfo, const float *__restrict__ uloc,
+                                                                 const uint16_t *__restrict__ lperm,
+                                                                 const uint16_t *__restrict__ coff,
+                                                                 const float *__restrict__ V, float *__restrict__ win,
+                                                                 long long N, int J, int G, int T, int CH) {
+  constexpr int P = 4 * LPP;                   // floats per LDS row of V / per window row
+  constexpr int SLOTS = 64 / LPP;              // cells per wave step (21 / 32 / 64)
+  constexpr int NOUT = SLOTS - 3;              // of which this many produce a window row (3 leading cells are re-done: halo)
+  extern __shared__ float4 lds4[];
+  float *Vs = reinterpret_cast<float *>(lds4);                       // [CH][P]
+  float4 *Ws = lds4 + (size_t)CH * LPP;                               // [CH]    tap weights of the current projection
+  uint16_t *lp = reinterpret_cast<uint16_t *>(Ws + CH);               // [CH]    rows in (cell, row) order
+  uint16_t *co = lp + CH;                                             // [G + 2] per-cell offsets of the window
+  const int chunk = blockIdx.x;
+  const long long base = (long long)chunk * CH;
+  const int n = (int)((N - base) < CH ? (N - base) : CH);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the chunk's rows of V: one contiguous n x T block, 16-byte aligned (CH is a multiple of 16)
+  {
+    const unsigned magic = ((1u << 20) + T - 1) / T;
+    const unsigned total = (unsigned)n * T, total4 = total >> 2;
+    const float4 *src = reinterpret_cast<const float4 *>(V + base * T);
+    for (unsigned e4 = threadIdx.x; e4 < total4; e4 += 1024) {
+      const float4 x = src[e4];
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned e = 4 * e4 + i, row = div_small(e, magic);
+        Vs[row * P + (e - row * T)] = xs[i];
+      }
+    }
+    for (unsigned e = (total4 << 2) + threadIdx.x; e < total; e += 1024) {
+      const unsigned row = div_small(e, magic);
+      Vs[row * P + (e - row * T)] = V[base * T + e];
+    }
+    if (T < P)
+      for (unsigned r = threadIdx.x; r < (unsigned)n; r += 1024)
+        for (int c = T; c < P; ++c) Vs[r * P + c] = 0.f;
+  }
+  const int slot = lane / LPP, q = lane - slot * LPP;
+  for (int j = 0; j < J; ++j) {
+    const size_t cj = (size_t)chunk * J + j;
+    const int4 wi = winfo[cj];
+    const int ncell = wi.y;
+    __syncthreads();                           // (the previous projection's readers of Ws / lp / co are done; Vs is complete)
+    for (int p = threadIdx.x; p < n; p += 1024) {
+      float w[4], dw[4];
+      (void)ski_taps_u<false>(uloc[cj * CH + p], 0.f, G, w, dw);
+      Ws[p] = make_float4(w[0], w[1], w[2], w[3]);
+      lp[p] = lperm[cj * CH + p];
+    }
+    for (int c = threadIdx.x; c <= ncell; c += 1024) co[c] = coff[cj * G + c];
+    __syncthreads();
+    const int ngroups = (ncell + 3 + NOUT - 1) / NOUT;
+    for (int grp = wave; grp < ngroups; grp += 16) {
+      const int cl = grp * NOUT + slot - 3;    // cell of this lane group, relative to the window's first cell
+      const bool valid = slot < SLOTS && cl >= 0 && cl < ncell;
+      int it = valid ? co[cl] : 0;
+      const int end = valid ? co[cl + 1] : 0;
+      float acc[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[k][r] = 0.f;
+      for (; it < end; ++it) {
+        const unsigned p = lp[it];
+        const float4 w = Ws[p];
+        const float4 v = *reinterpret_cast<const float4 *>(Vs + p * P + 4 * q);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[0][r] = __builtin_fmaf(w.x, vv[r], acc[0][r]);
+          acc[1][r] = __builtin_fmaf(w.y, vv[r], acc[1][r]);
+          acc[2][r] = __builtin_fmaf(w.z, vv[r], acc[2][r]);
+          acc[3][r] = __builtin_fmaf(w.w, vv[r], acc[3][r]);
+        }
+      }
+      // window row cl = tap 0 of cell cl + tap 1 of cell cl - 1 + tap 2 of cell cl - 2 + tap 3 of cell cl - 3
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a1 = __shfl_up(acc[1][r], LPP, 64);
+        const float a2 = __shfl_up(acc[2][r], 2 * LPP, 64);
+        const float a3 = __shfl_up(acc[3][r], 3 * LPP, 64);
+        o[r] = ((acc[0][r] + a1) + a2) + a3;
+      }
+      if (slot >= 3 && slot < SLOTS && cl < ncell + 3)
+        *reinterpret_cast<float4 *>(win + ((size_t)(wi.z + cl) * LPP + q) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// hist[j][g][hoff + t] (row stride HT, float64) = sum over the chunks whose window covers g, in chunk order.  One workgroup
+// per (16 grid rows, projection): the covering chunks are listed in LDS (ordered compaction), four lane groups take every
+// fourth list entry each and their float64 sums are added in a fixed order.
+template <int LPP>
+__global__ __launch_bounds__(256) void ski_chunk_combine_kernel(const int4 *__restrict__ winfo, const float *__restrict__ win,
+                                                                double *__restrict__ hist, int nch, int J, int G, int tcnt,
+                                                                int HT, int hoff) {
+  constexpr int P = 4 * LPP;
+  __shared__ int list[1024];
+  __shared__ int wcount[4];
+  __shared__ int lbase[4];
+  __shared__ double part[4][16][12];
+  const int j = blockIdx.y, g0 = blockIdx.x * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int total = 0;
+  for (int c0 = 0; c0 < nch; c0 += 256) {      // ordered compaction of the covering chunks, 256 candidates per round
+    const int chunk = c0 + threadIdx.x;
+    bool cov = false;
+    if (chunk < nch) {
+      const int4 wi = winfo[(size_t)chunk * J + j];
+      cov = wi.x < g0 + 16 && wi.x + wi.w > g0;
+    }
+    const unsigned long long m = __ballot(cov);
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    int off = total;
+    for (int w = 0; w < wave; ++w) off += wcount[w];
+    if (cov) list[off + __popcll(m & ((1ull << lane) - 1ull))] = chunk;
+    total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+  }
+  // thread = (part r of 4, grid row gl of 16, column group q of LPP); threads beyond 64 LPP idle
+  const int q = threadIdx.x % LPP, gl = (threadIdx.x / LPP) % 16, r = threadIdx.x / (16 * LPP);
+  const int g = g0 + gl;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (r < 4 && g < G) {
+    for (int i = r; i < total; i += 4) {
+      const int4 wi = winfo[(size_t)list[i] * J + j];
+      const int rel = g - wi.x;
+      if (rel >= 0 && rel < wi.w) {
+        const float4 x = *reinterpret_cast<const float4 *>(win + ((size_t)(wi.z + rel) * LPP + q) * 4);
+        acc[0] += (double)x.x;
+        acc[1] += (double)x.y;
+        acc[2] += (double)x.z;
+        acc[3] += (double)x.w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[r][gl][4 * q + c] = acc[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 * P) {
+    const int gl2 = threadIdx.x / P, c = threadIdx.x % P;
+    if (g0 + gl2 < G && c < tcnt)
+      hist[((size_t)j * G + g0 + gl2) * HT + hoff + c] = ((part[0][gl2][c] + part[1][gl2][c]) + part[2][gl2][c]) + part[3][gl2][c];
+  }
+}
+
+// out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0 + k][t] + noise V[i][t] for the chunk's rows: per projection the window
+// of H_j the chunk touches and the rows' stencils are staged in LDS; the sum over j runs in float64 in projection order and
+// every product is formed exactly as in ski_gather_lds_kernel (same bits).
+template <int LPP>
+__global__ __launch_bounds__(1024) void ski_chunk_gather_kernel(const int4 *__restrict__ winfo, const float *__restrict__ uloc,
+                                                                const float *__restrict__ H, const float *__restrict__ V,
+                                                                float *__restrict__ out, long long N, int J, int G, int T, int CH,
+                                                                float scale, float noise) {
+  constexpr int P = 4 * LPP;
+  constexpr int SLOTS = 64 / LPP;              // rows per wave step
+  constexpr int STEPS = 4;                     // wave steps per pass: 16 waves x SLOTS x 4 rows (1344 / 2048 / 4096) —
+  constexpr int RPP = 16 * SLOTS * STEPS;      // 4 x 4 float64 sums per lane; a chunk of more rows takes a second pass
+  extern __shared__ float4 lds4[];
+  float *Hs = reinterpret_cast<float *>(lds4);                        // [G][P]  window rows of H_j
+  float4 *Ws = lds4 + (size_t)G * LPP;                                // [RPP]   stencils of the pass's rows
+  uint16_t *Is = reinterpret_cast<uint16_t *>(Ws + RPP);              // [RPP]   first tap, relative to the window
+  const int chunk = blockIdx.x;
+  const long long base = (long long)chunk * CH;
+  const int n = (int)((N - base) < CH ? (N - base) : CH);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPP, q = lane - slot * LPP;
+  const unsigned magic = ((1u << 20) + T - 1) / T;
+  for (int p0 = 0; p0 < n; p0 += RPP) {
+    const int np = n - p0 < RPP ? n - p0 : RPP;
+    double acc[STEPS][4];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
+    for (int j = 0; j < J; ++j) {
+      const size_t cj = (size_t)chunk * J + j;
+      const int4 wi = winfo[cj];
+      __syncthreads();
+      {                                        // window rows wi.x .. wi.x + wi.w - 1 of H_j: one contiguous block of wi.w x T floats
+        const float *src = H + ((size_t)j * G + wi.x) * T;
+        const unsigned total = (unsigned)wi.w * T;
+        for (unsigned e = threadIdx.x; e < total; e += 1024) {
+          const unsigned row = div_small(e, magic);
+          Hs[row * P + (e - row * T)] = src[e];
+        }
+        if (T < P)
+          for (unsigned r = threadIdx.x; r < (unsigned)wi.w; r += 1024)
+            for (int c = T; c < P; ++c) Hs[r * P + c] = 0.f;
+      }
+      for (int p = threadIdx.x; p < np; p += 1024) {
+        float w[4], dw[4];
+        const int idx0 = ski_taps_u<false>(uloc[cj * CH + p0 + p], 0.f, G, w, dw);
+        Ws[p] = make_float4(w[0], w[1], w[2], w[3]);
+        Is[p] = (uint16_t)(idx0 - wi.x);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const int p = (s * 16 + wave) * SLOTS + slot;
+        if (slot < SLOTS && p < np) {
+          const float4 w = Ws[p];
+          const float *hp = Hs + (unsigned)Is[p] * P + 4 * q;
+          const float4 h0 = *reinterpret_cast<const float4 *>(hp);
+          const float4 h1 = *reinterpret_cast<const float4 *>(hp + P);
+          const float4 h2 = *reinterpret_cast<const float4 *>(hp + 2 * P);
+          const float4 h3 = *reinterpret_cast<const float4 *>(hp + 3 * P);
+          const float a0[4] = {h0.x, h0.y, h0.z, h0.w}, a1[4] = {h1.x, h1.y, h1.z, h1.w};
+          const float a2[4] = {h2.x, h2.y, h2.z, h2.w}, a3[4] = {h3.x, h3.y, h3.z, h3.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pr = w.x * a0[r];
+            pr = __builtin_fmaf(w.y, a1[r], pr);
+            pr = __builtin_fmaf(w.z, a2[r], pr);
+            pr = __builtin_fmaf(w.w, a3[r], pr);
+            acc[s][r] += (double)pr;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int p = (s * 16 + wave) * SLOTS + slot;
+      if (slot < SLOTS && p < np) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = 4 * q + r;
+          if (col < T) {
+            const size_t o = (size_t)(base + p0 + p) * T + col;
+            const float vin = noise != 0.f ? V[o] : 0.f;
+            out[o] = __builtin_fmaf(noise, vin, scale * (float)acc[s][r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+inline size_t chunk_scatter_lds(int CH, int G, int LPP) {
+  return (size_t)CH * LPP * 16 + (size_t)CH * 16 + (size_t)CH * 2 + (size_t)(G + 8) * 2;
+}
+inline size_t chunk_gather_lds(int G, int LPP) {
+  const size_t rpp = (size_t)16 * (64 / LPP) * 4;          // RPP of ski_chunk_gather_kernel
+  return (size_t)G * LPP * 16 + rpp * 16 + rpp * 2;
+}
+
+template <class K>
+inline int big_lds(K kernel, size_t bytes) {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// hist[j][g][hoff .. hoff + T) from the chunk tables of the plan; `win`: the scatter slabs of the SKI workspace
+int scatter_chunked(const PlanView &pv, const float *V, double *hist, float *win, long long N, int J, int G, int T, int HT,
+                    int hoff, hipStream_t st) {
+  const int LPP = (T + 3) / 4;
+  const size_t lds = chunk_scatter_lds(pv.CH, G, LPP);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const size_t mx = chunk_scatter_lds(kChunkMaxRows, 2048, 3);
+    if (big_lds(ski_chunk_scatter_kernel<1>, mx) || big_lds(ski_chunk_scatter_kernel<2>, mx) ||
+        big_lds(ski_chunk_scatter_kernel<3>, mx))
+      return RPGP_EWORKSPACE;
+    attr_set = true;
+  }
+  const dim3 cgrid((unsigned)((G + 15) / 16), (unsigned)J);
+#define RPGP_CHUNK_SCATTER(L_)                                                                                                 \
+  hipLaunchKernelGGL((ski_chunk_scatter_kernel<L_>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, pv.lperm,  \
+                     pv.coff, V, win, N, J, G, T, pv.CH);                                                                       \
+  hipLaunchKernelGGL((ski_chunk_combine_kernel<L_>), cgrid, dim3(256), 0, st, pv.winfo, win, hist, pv.nch, J, G, T, HT, hoff)
+  if (LPP == 1) {
+    RPGP_CHUNK_SCATTER(1);
+  } else if (LPP == 2) {
+    RPGP_CHUNK_SCATTER(2);
+  } else {
+    RPGP_CHUNK_SCATTER(3);
+  }
+#undef RPGP_CHUNK_SCATTER
+  return launch_status();
+}
+
+int gather_chunked(const PlanView &pv, const float *H, const float *V, float *out, long long N, int J, int G, int T, float scale,
+                   float noise, hipStream_t st) {
+  const int LPP = (T + 3) / 4;
+  const size_t lds = chunk_gather_lds(G, LPP);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (big_lds(ski_chunk_gather_kernel<1>, chunk_gather_lds(2048, 1)) || big_lds(ski_chunk_gather_kernel<2>, chunk_gather_lds(2048, 2)) ||
+        big_lds(ski_chunk_gather_kernel<3>, chunk_gather_lds(2048, 3)))
+      return RPGP_EWORKSPACE;
+    attr_set = true;
+  }
+  if (LPP == 1)
+    hipLaunchKernelGGL((ski_chunk_gather_kernel<1>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, H, V, out, N, J, G, T, pv.CH, scale, noise);
+  else if (LPP == 2)
+    hipLaunchKernelGGL((ski_chunk_gather_kernel<2>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, H, V, out, N, J, G, T, pv.CH, scale, noise);
+  else
+    hipLaunchKernelGGL((ski_chunk_gather_kernel<3>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, H, V, out, N, J, G, T, pv.CH, scale, noise);
+  return launch_status();
+}
+
 constexpr size_t kGatherLdsMax = 150 * 1024;
 
 int gather_planned(const PlanView *pv, const float *Z, const float *gp, const float *H, const float *V, float *out, long long M,
                    int ldz, int J, int G, int T, float scale, float noise, hipStream_t st) {
-  (void)pv;
+  if (pv && pv->nch > 0 && chunk_env_on() && T <= 12 && (V || noise == 0.f))
+    return gather_chunked(*pv, H, V, out, M, J, G, T, scale, noise, st);
   const size_t lds = (size_t)J * G * T * sizeof(float);
   static const int mode = [] { const char *e = getenv("RPGP_SKI_GATHER"); return e ? atoi(e) : 0; }();   // 3: never the LDS form
   if (T > 1 && T <= 12 && lds <= kGatherLdsMax && M >= 32768 && mode != 3 && ((size_t)J * G * T) % 4 == 0) {
@@ -521,6 +995,7 @@ inline int ski_tpiece(int remaining) { return remaining > 4 ? 12 : (remaining > 
 // hist[j][g][hoff .. hoff + T) (row stride HT, float64) from the plan; `partial` holds max_items * 4 * 12 floats
 int scatter_planned(const PlanView &pv, const float *V, double *hist, float *partial, long long N, int J, int G, int T, int HT,
                     int hoff, hipStream_t st) {
+  if (pv.nch > 0 && chunk_env_on() && T <= 12) return scatter_chunked(pv, V, hist, partial, N, J, G, T, HT, hoff, st);
   const int cells = J * G;
   const long long items = max_items(N, J, G);
   const unsigned nb = (unsigned)items;
@@ -622,7 +1097,18 @@ int rpgp_ski_plan(const float *Z, const float *grid_params, int64_t N, int ldz, 
   hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(1024), 0, st, pv.cell_start, cells, pv.item_start, pv.item_info);
   hipLaunchKernelGGL(plan_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, keys_out, vals_out, pv.wnat, (long long)N, J, G,
                      (long long)nj, pv.perm, pv.wsort);
+  if (pv.nch > 0) {                            // chunk tables of the round-5 product (its kernels read nothing of the above)
+    hipLaunchKernelGGL(chunk_plan_kernel, dim3((unsigned)pv.nch, (unsigned)J), dim3(256), 0, st, Z, grid_params, (long long)N, ldz,
+                       J, G, pv.CH, pv.winfo, pv.uloc, pv.lperm, pv.coff);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, pv.winfo, pv.nch * J);
+  }
   return launch_status();
+}
+
+int rpgp_ski_chunk_mode(int mode) {
+  const int prev = chunk_mode_ref();
+  if (mode == 0 || mode == 1) chunk_mode_ref() = mode;
+  return prev;
 }
 
 int rpgp_ski_scatter_planned(const void *plan, const float *V, double *hist, int64_t N, int J, int G, int T, void *workspace,

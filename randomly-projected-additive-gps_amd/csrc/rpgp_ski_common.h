@@ -25,11 +25,15 @@ __device__ __forceinline__ const float *ski_grid_of(const float *__restrict__ gp
   return (ski_flags(gp) & 2) ? gp + 4 + J + 3 * j : gp;
 }
 
-// taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
-template <bool DERIV>
-__device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, float (&w)[4], float (&dw)[4]) {
+// the grid coordinate of z, clamped into the interior (extrapolation guard): what the chunked product keeps in its plan
+__device__ __forceinline__ float ski_grid_coord(float z, float g0, float inv_h, int G) {
   float u = (z - g0) * inv_h;
-  u = u < 1.0f ? 1.0f : (u > (float)(G - 2) ? (float)(G - 2) : u);   // clamp into the interior (extrapolation guard)
+  return u < 1.0f ? 1.0f : (u > (float)(G - 2) ? (float)(G - 2) : u);
+}
+
+// taps idx0..idx0+3 and their weights for the clamped grid coordinate u; DERIV also returns d w_k / d z
+template <bool DERIV>
+__device__ __forceinline__ int ski_taps_u(float u, float inv_h, int G, float (&w)[4], float (&dw)[4]) {
   const float fl = __builtin_floorf(u);
   const float fr = u - fl;
   int idx0 = (int)fl - 1;
@@ -45,6 +49,12 @@ __device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, f
     dw[3] = -cubic_dw(s[3]) * inv_h;
   }
   return idx0;
+}
+
+// taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
+template <bool DERIV>
+__device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, float (&w)[4], float (&dw)[4]) {
+  return ski_taps_u<DERIV>(ski_grid_coord(z, g0, inv_h, G), inv_h, G, w, dw);
 }
 
 

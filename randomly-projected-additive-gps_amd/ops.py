@@ -527,6 +527,13 @@ def ski_grid_from_range(zmin, zmax, grid_size, device, weights=None):
     return gp
 
 
+def ski_chunk_mode(mode=None):
+    """Which form of the planned SKI product runs (rpgp_ski_chunk_mode): True = the chunked form of round 5 where the shape
+    allows (default), False = the cell-sorted form.  `mode=None` only queries.  Returns the previous setting."""
+    lib = _lib.load()
+    return bool(lib.rpgp_ski_chunk_mode(-1 if mode is None else int(bool(mode))))
+
+
 def ski_scatter(Z, gp, V, grid_size=1024, plan=None):
     """Stage 1 of the SKI MVM: hist[j][g][t] (float64, J x G x T) = sum over the rows of Z of w(z_ij)[g] V[i][t]."""
     lib = _lib.load()

@@ -652,74 +652,141 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(int4 *__restrict__ win
 // (e < 2048 * 12 < 2^15, T <= 12: floor(e / T) = (e * ceil(2^20 / T)) >> 20 exactly)
 __device__ __forceinline__ unsigned div_small(unsigned e, unsigned magic) { return (e * magic) >> 20; }
 
+constexpr int kChunkMaxJ = 4;                  // projections of the chunked product (chunk_shape_ok)
+constexpr size_t kChunkLdsBytes = 160 * 1024 - 256;       // dynamic LDS a chunk workgroup may take (one workgroup per CU)
+
+// The scatter of one chunk.  Every global load of the workgroup is requested before the first is consumed: the chunk's rows of
+// V (<= 6 float4 per thread) and, for the projections of the first round, the rows' grid coordinates, their permutation, the
+// per-cell offsets and the window record — one memory round trip, then LDS only.  NJB projections are resident at a time
+// (the host takes the most that fit beside V: all three at the C5 shape), and their (projection, cell group) items are dealt
+// to the 16 waves together.
 template <int LPP>
 __global__ __launch_bounds__(1024) void ski_chunk_scatter_kernel(const int4 *__restrict__ winfo, const float *__restrict__ uloc,
                                                                  const uint16_t *__restrict__ lperm,
                                                                  const uint16_t *__restrict__ coff,
                                                                  const float *__restrict__ V, float *__restrict__ win,
-                                                                 long long N, int J, int G, int T, int CH) {
+                                                                 long long N, int J, int G, int T, int CH, int NJB) {
   constexpr int P = 4 * LPP;                   // floats per LDS row of V / per window row
   constexpr int SLOTS = 64 / LPP;              // cells per wave step (21 / 32 / 64)
   constexpr int NOUT = SLOTS - 3;              // of which this many produce a window row (3 leading cells are re-done: halo)
+  constexpr int VQ = kChunkMaxRows * 12 / 4 / 1024;      // float4 of V per thread (6)
   extern __shared__ float4 lds4[];
   float *Vs = reinterpret_cast<float *>(lds4);                       // [CH][P]
-  float4 *Ws = lds4 + (size_t)CH * LPP;                               // [CH]    tap weights of the current projection
-  uint16_t *lp = reinterpret_cast<uint16_t *>(Ws + CH);               // [CH]    rows in (cell, row) order
-  uint16_t *co = lp + CH;                                             // [G + 2] per-cell offsets of the window
+  float4 *Ws = lds4 + (size_t)CH * LPP;                               // [NJB][CH]     tap weights
+  uint16_t *lp = reinterpret_cast<uint16_t *>(Ws + (size_t)NJB * CH); // [NJB][CH]     rows in (cell, row) order
+  uint16_t *co = lp + (size_t)NJB * CH;                               // [NJB][G + 2]  per-cell offsets of the window
+  __shared__ int4 swi[kChunkMaxJ];
   const int chunk = blockIdx.x;
   const long long base = (long long)chunk * CH;
   const int n = (int)((N - base) < CH ? (N - base) : CH);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the chunk's rows of V: one contiguous n x T block, 16-byte aligned (CH is a multiple of 16)
-  {
-    const unsigned magic = ((1u << 20) + T - 1) / T;
-    const unsigned total = (unsigned)n * T, total4 = total >> 2;
-    const float4 *src = reinterpret_cast<const float4 *>(V + base * T);
-    for (unsigned e4 = threadIdx.x; e4 < total4; e4 += 1024) {
-      const float4 x = src[e4];
-      const float xs[4] = {x.x, x.y, x.z, x.w};
+  const int slot = lane / LPP, q = lane - slot * LPP;
+  const unsigned magic = ((1u << 20) + T - 1) / T;
+  const unsigned total = (unsigned)n * T, total4 = total >> 2;
+
+  // ---- requests: V, then the tables of the first round ------------------------------------------------------------------
+  const float4 *src = reinterpret_cast<const float4 *>(V + base * T);
+  float4 vq[VQ];
+#pragma unroll
+  for (int k = 0; k < VQ; ++k) {
+    const unsigned e4 = threadIdx.x + k * 1024;
+    vq[k] = src[e4 < total4 ? e4 : 0];         // (unconditional, clamped: every thread has VQ loads in flight)
+  }
+  float vtail = 0.f;
+  if (threadIdx.x < (total & 3u)) vtail = V[base * T + (total4 << 2) + threadIdx.x];
+  float ru[kChunkMaxJ][2];
+  unsigned rl[kChunkMaxJ][2], rc[kChunkMaxJ][2];
+  auto request = [&](int j0) {
+#pragma unroll
+    for (int jl = 0; jl < kChunkMaxJ; ++jl) {
+      const int j = j0 + jl;
+      const bool live = jl < NJB && j < J;
+      const size_t cj = (size_t)chunk * J + (live ? j : 0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int p = threadIdx.x + h * 1024;
+        const int pc = p < CH ? p : 0, cc = p < G ? p : 0;
+        ru[jl][h] = uloc[cj * CH + pc];
+        rl[jl][h] = lperm[cj * CH + pc];
+        rc[jl][h] = coff[cj * G + cc];
+      }
+      if (threadIdx.x == 0 && live) swi[jl] = winfo[cj];
+    }
+  };
+  request(0);
+
+  // ---- V into LDS rows of P floats ------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < VQ; ++k) {
+    const unsigned e4 = threadIdx.x + k * 1024;
+    if (e4 < total4) {
+      const float xs[4] = {vq[k].x, vq[k].y, vq[k].z, vq[k].w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const unsigned e = 4 * e4 + i, row = div_small(e, magic);
         Vs[row * P + (e - row * T)] = xs[i];
       }
     }
-    for (unsigned e = (total4 << 2) + threadIdx.x; e < total; e += 1024) {
-      const unsigned row = div_small(e, magic);
-      Vs[row * P + (e - row * T)] = V[base * T + e];
-    }
-    if (T < P)
-      for (unsigned r = threadIdx.x; r < (unsigned)n; r += 1024)
-        for (int c = T; c < P; ++c) Vs[r * P + c] = 0.f;
   }
-  const int slot = lane / LPP, q = lane - slot * LPP;
-  for (int j = 0; j < J; ++j) {
-    const size_t cj = (size_t)chunk * J + j;
-    const int4 wi = winfo[cj];
-    const int ncell = wi.y;
-    __syncthreads();                           // (the previous projection's readers of Ws / lp / co are done; Vs is complete)
-    for (int p = threadIdx.x; p < n; p += 1024) {
-      float w[4], dw[4];
-      (void)ski_taps_u<false>(uloc[cj * CH + p], 0.f, G, w, dw);
-      Ws[p] = make_float4(w[0], w[1], w[2], w[3]);
-      lp[p] = lperm[cj * CH + p];
+  if (threadIdx.x < (total & 3u)) {
+    const unsigned e = (total4 << 2) + threadIdx.x, row = div_small(e, magic);
+    Vs[row * P + (e - row * T)] = vtail;
+  }
+  if (T < P)
+    for (unsigned r = threadIdx.x; r < (unsigned)n; r += 1024)
+      for (int c = T; c < P; ++c) Vs[r * P + c] = 0.f;
+
+  for (int j0 = 0; j0 < J; j0 += NJB) {
+    if (j0 > 0) {
+      __syncthreads();                         // (the previous round's readers are done)
+      request(j0);
     }
-    for (int c = threadIdx.x; c <= ncell; c += 1024) co[c] = coff[cj * G + c];
+    const int nj = J - j0 < NJB ? J - j0 : NJB;
+#pragma unroll
+    for (int jl = 0; jl < kChunkMaxJ; ++jl) {
+      if (jl < nj) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int p = threadIdx.x + h * 1024;
+          if (p < n) {
+            float w[4], dw[4];
+            (void)ski_taps_u<false>(ru[jl][h], 0.f, G, w, dw);
+            Ws[(size_t)jl * CH + p] = make_float4(w[0], w[1], w[2], w[3]);
+            lp[(size_t)jl * CH + p] = (uint16_t)rl[jl][h];
+          }
+          if (p < G) co[jl * (G + 2) + p] = (uint16_t)rc[jl][h];
+        }
+      }
+    }
     __syncthreads();
-    const int ngroups = (ncell + 3 + NOUT - 1) / NOUT;
-    for (int grp = wave; grp < ngroups; grp += 16) {
+    // items of the round: (projection jl, cell group grp), dealt to the waves in one sequence
+    int gstart[kChunkMaxJ + 1];
+    gstart[0] = 0;
+#pragma unroll
+    for (int jl = 0; jl < kChunkMaxJ; ++jl)
+      gstart[jl + 1] = gstart[jl] + (jl < nj ? (swi[jl].y + 3 + NOUT - 1) / NOUT : 0);
+    for (int item = wave; item < gstart[kChunkMaxJ]; item += 16) {
+      int jl = 0;
+#pragma unroll
+      for (int t = 1; t < kChunkMaxJ; ++t) jl += (item >= gstart[t]) ? 1 : 0;
+      const int grp = item - gstart[jl];
+      const int4 wi = swi[jl];
+      const int ncell = wi.y;
+      const float4 *Wj = Ws + (size_t)jl * CH;
+      const uint16_t *lj = lp + (size_t)jl * CH, *cj_ = co + jl * (G + 2);
       const int cl = grp * NOUT + slot - 3;    // cell of this lane group, relative to the window's first cell
       const bool valid = slot < SLOTS && cl >= 0 && cl < ncell;
-      int it = valid ? co[cl] : 0;
-      const int end = valid ? co[cl + 1] : 0;
+      int it = valid ? cj_[cl] : 0;
+      const int end = valid ? cj_[cl + 1] : 0;
       float acc[4][4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[k][r] = 0.f;
+      unsigned p = lj[it < end ? it : 0];
       for (; it < end; ++it) {
-        const unsigned p = lp[it];
-        const float4 w = Ws[p];
+        const unsigned pn = lj[it + 1 < end ? it + 1 : it];      // the next row number is requested under this row's work
+        const float4 w = Wj[p];
         const float4 v = *reinterpret_cast<const float4 *>(Vs + p * P + 4 * q);
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -729,6 +796,7 @@ __global__ __launch_bounds__(1024) void ski_chunk_scatter_kernel(const int4 *__r
           acc[2][r] = __builtin_fmaf(w.z, vv[r], acc[2][r]);
           acc[3][r] = __builtin_fmaf(w.w, vv[r], acc[3][r]);
         }
+        p = pn;
       }
       // window row cl = tap 0 of cell cl + tap 1 of cell cl - 1 + tap 2 of cell cl - 2 + tap 3 of cell cl - 3
       float o[4];
@@ -746,50 +814,66 @@ __global__ __launch_bounds__(1024) void ski_chunk_scatter_kernel(const int4 *__r
 }
 
 // hist[j][g][hoff + t] (row stride HT, float64) = sum over the chunks whose window covers g, in chunk order.  One workgroup
-// per (16 grid rows, projection): the covering chunks are listed in LDS (ordered compaction), four lane groups take every
-// fourth list entry each and their float64 sums are added in a fixed order.
+// per (16 grid rows, projection): the covering chunks are listed in LDS with their window records (ordered compaction, one
+// round trip), 8 lane groups take every eighth list entry each with all their window reads in flight together, and the eight
+// float64 sums are added in a fixed order.
 template <int LPP>
-__global__ __launch_bounds__(256) void ski_chunk_combine_kernel(const int4 *__restrict__ winfo, const float *__restrict__ win,
+__global__ __launch_bounds__(512) void ski_chunk_combine_kernel(const int4 *__restrict__ winfo, const float *__restrict__ win,
                                                                 double *__restrict__ hist, int nch, int J, int G, int tcnt,
                                                                 int HT, int hoff) {
   constexpr int P = 4 * LPP;
-  __shared__ int list[1024];
-  __shared__ int wcount[4];
-  __shared__ int lbase[4];
-  __shared__ double part[4][16][12];
+  constexpr int NP = 8;                        // lane groups (parts of the list) per output
+  constexpr int UN = 8;                        // window reads in flight per thread
+  __shared__ int llo[1024], lhi[1024], lrow[1024];       // window [llo, lhi) and (first table row - llo) of the listed chunks
+  __shared__ int wcount[8];
+  __shared__ double part[NP][16][12];
   const int j = blockIdx.y, g0 = blockIdx.x * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int total = 0;
-  for (int c0 = 0; c0 < nch; c0 += 256) {      // ordered compaction of the covering chunks, 256 candidates per round
+  for (int c0 = 0; c0 < nch; c0 += 512) {      // ordered compaction of the covering chunks, 512 candidates per round
     const int chunk = c0 + threadIdx.x;
-    bool cov = false;
-    if (chunk < nch) {
-      const int4 wi = winfo[(size_t)chunk * J + j];
-      cov = wi.x < g0 + 16 && wi.x + wi.w > g0;
-    }
+    const int4 wi = winfo[(size_t)(chunk < nch ? chunk : 0) * J + j];
+    const bool cov = chunk < nch && wi.x < g0 + 16 && wi.x + wi.w > g0;
     const unsigned long long m = __ballot(cov);
     if (lane == 0) wcount[wave] = __popcll(m);
     __syncthreads();
-    int off = total;
-    for (int w = 0; w < wave; ++w) off += wcount[w];
-    if (cov) list[off + __popcll(m & ((1ull << lane) - 1ull))] = chunk;
-    total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    int off = total, all = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      off += w < wave ? wcount[w] : 0;
+      all += wcount[w];
+    }
+    if (cov) {
+      const int i = off + __popcll(m & ((1ull << lane) - 1ull));
+      llo[i] = wi.x;
+      lhi[i] = wi.x + wi.w;
+      lrow[i] = wi.z - wi.x;
+    }
+    total += all;
     __syncthreads();
   }
-  // thread = (part r of 4, grid row gl of 16, column group q of LPP); threads beyond 64 LPP idle
+  // thread = (part r of NP, grid row gl of 16, column group q of LPP); threads beyond 16 NP LPP idle
   const int q = threadIdx.x % LPP, gl = (threadIdx.x / LPP) % 16, r = threadIdx.x / (16 * LPP);
   const int g = g0 + gl;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (r < 4 && g < G) {
-    for (int i = r; i < total; i += 4) {
-      const int4 wi = winfo[(size_t)list[i] * J + j];
-      const int rel = g - wi.x;
-      if (rel >= 0 && rel < wi.w) {
-        const float4 x = *reinterpret_cast<const float4 *>(win + ((size_t)(wi.z + rel) * LPP + q) * 4);
-        acc[0] += (double)x.x;
-        acc[1] += (double)x.y;
-        acc[2] += (double)x.z;
-        acc[3] += (double)x.w;
+  if (r < NP) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = r; i0 < total; i0 += NP * UN) {
+      float4 x[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {           // unconditional reads of a clamped, valid table row; masked below
+        const int i = i0 + u * NP;
+        const int ii = i < total ? i : 0;
+        const bool ok = i < total && g >= llo[ii] && g < lhi[ii];
+        const int row = ok ? lrow[ii] + g : lrow[ii] + llo[ii];
+        const float4 y = *reinterpret_cast<const float4 *>(win + ((size_t)row * LPP + q) * 4);
+        x[u] = ok ? y : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        acc[0] += (double)x[u].x;
+        acc[1] += (double)x[u].y;
+        acc[2] += (double)x[u].z;
+        acc[3] += (double)x[u].w;
       }
     }
 #pragma unroll
@@ -798,110 +882,162 @@ __global__ __launch_bounds__(256) void ski_chunk_combine_kernel(const int4 *__re
   __syncthreads();
   if (threadIdx.x < 16 * P) {
     const int gl2 = threadIdx.x / P, c = threadIdx.x % P;
-    if (g0 + gl2 < G && c < tcnt)
-      hist[((size_t)j * G + g0 + gl2) * HT + hoff + c] = ((part[0][gl2][c] + part[1][gl2][c]) + part[2][gl2][c]) + part[3][gl2][c];
+    if (g0 + gl2 < G && c < tcnt) {
+      double sum = part[0][gl2][c];
+#pragma unroll
+      for (int k = 1; k < NP; ++k) sum += part[k][gl2][c];
+      hist[((size_t)j * G + g0 + gl2) * HT + hoff + c] = sum;
+    }
   }
 }
 
-// out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0 + k][t] + noise V[i][t] for the chunk's rows: per projection the window
-// of H_j the chunk touches and the rows' stencils are staged in LDS; the sum over j runs in float64 in projection order and
-// every product is formed exactly as in ski_gather_lds_kernel (same bits).
-template <int LPP>
+// out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0 + k][t] + noise V[i][t] for the chunk's rows.  The windows of H the
+// chunk touches (all projections': ~3 x 160 rows at the C5 shape) and the rows' stencils are staged in LDS behind ONE round
+// of requests; a row is then finished in one go — the sum over j in float64 in projection order, every product formed exactly
+// as in ski_gather_lds_kernel (same bits) — with its V values requested one step ahead.  A chunk whose windows exceed the LDS
+// rows (HCAP; rows far out in the tails, or rows in no particular order) reads H from memory instead: same arithmetic.
+// STEPS wave steps of 64 / LPP rows per wave make a pass of RPP rows.
+template <int LPP, int STEPS>
 __global__ __launch_bounds__(1024) void ski_chunk_gather_kernel(const int4 *__restrict__ winfo, const float *__restrict__ uloc,
                                                                 const float *__restrict__ H, const float *__restrict__ V,
                                                                 float *__restrict__ out, long long N, int J, int G, int T, int CH,
-                                                                float scale, float noise) {
+                                                                float scale, float noise, int HCAP, int RPA) {
   constexpr int P = 4 * LPP;
   constexpr int SLOTS = 64 / LPP;              // rows per wave step
-  constexpr int STEPS = 4;                     // wave steps per pass: 16 waves x SLOTS x 4 rows (1344 / 2048 / 4096) —
-  constexpr int RPP = 16 * SLOTS * STEPS;      // 4 x 4 float64 sums per lane; a chunk of more rows takes a second pass
+  constexpr int RPP = 16 * SLOTS * STEPS;      // rows per pass
   extern __shared__ float4 lds4[];
-  float *Hs = reinterpret_cast<float *>(lds4);                        // [G][P]  window rows of H_j
-  float4 *Ws = lds4 + (size_t)G * LPP;                                // [RPP]   stencils of the pass's rows
-  uint16_t *Is = reinterpret_cast<uint16_t *>(Ws + RPP);              // [RPP]   first tap, relative to the window
+  float *Hs = reinterpret_cast<float *>(lds4);                        // [HCAP][P]  window rows of all projections
+  float4 *Ws = lds4 + (size_t)HCAP * LPP;                             // [J][RPA]   stencils of the pass's rows
+  uint16_t *Is = reinterpret_cast<uint16_t *>(Ws + (size_t)J * RPA);  // [J][RPA]   first tap, as a row of Hs
+  __shared__ int4 swi[kChunkMaxJ];
   const int chunk = blockIdx.x;
   const long long base = (long long)chunk * CH;
   const int n = (int)((N - base) < CH ? (N - base) : CH);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = lane / LPP, q = lane - slot * LPP;
   const unsigned magic = ((1u << 20) + T - 1) / T;
+  if (threadIdx.x < J) swi[threadIdx.x] = winfo[(size_t)chunk * J + threadIdx.x];
+  __syncthreads();
+  int hrow[kChunkMaxJ], rows = 0;
+#pragma unroll
+  for (int j = 0; j < kChunkMaxJ; ++j) {
+    hrow[j] = rows;
+    rows += j < J ? swi[j].w : 0;
+  }
+  const bool resident = rows <= HCAP;          // (uniform over the workgroup)
+  auto load_v = [&](int p0, int np, int s, float (&vin)[4]) {
+    const int p = (s * 16 + wave) * SLOTS + slot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = 4 * q + r;
+      const bool ok = s < STEPS && slot < SLOTS && p < np && col < T && noise != 0.f;
+      const float x = V[ok ? (size_t)(base + p0 + p) * T + col : 0];
+      vin[r] = ok ? x : 0.f;
+    }
+  };
+  auto store_out = [&](int p0, int np, int s, const double (&a)[4], const float (&vin)[4]) {
+    const int p = (s * 16 + wave) * SLOTS + slot;
+    if (slot < SLOTS && p < np) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 4 * q + r;
+        if (col < T) out[(size_t)(base + p0 + p) * T + col] = __builtin_fmaf(noise, vin[r], scale * (float)a[r]);
+      }
+    }
+  };
   for (int p0 = 0; p0 < n; p0 += RPP) {
     const int np = n - p0 < RPP ? n - p0 : RPP;
-    double acc[STEPS][4];
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
-    for (int j = 0; j < J; ++j) {
-      const size_t cj = (size_t)chunk * J + j;
-      const int4 wi = winfo[cj];
-      __syncthreads();
-      {                                        // window rows wi.x .. wi.x + wi.w - 1 of H_j: one contiguous block of wi.w x T floats
-        const float *src = H + ((size_t)j * G + wi.x) * T;
-        const unsigned total = (unsigned)wi.w * T;
-        for (unsigned e = threadIdx.x; e < total; e += 1024) {
-          const unsigned row = div_small(e, magic);
-          Hs[row * P + (e - row * T)] = src[e];
+    if (resident) {
+      if (p0 > 0) __syncthreads();             // (the previous pass's readers of the stencils are done)
+      for (int j = 0; j < J; ++j) {
+        const int4 wi = swi[j];
+        if (p0 == 0) {                         // the windows serve every pass
+          const float *src = H + ((size_t)j * G + wi.x) * T;          // rows wi.x .. of H_j: one contiguous block
+          const unsigned total = (unsigned)wi.w * T;
+          float *dst = Hs + (size_t)hrow[j] * P;
+          for (unsigned e = threadIdx.x; e < total; e += 1024) {
+            const unsigned row = div_small(e, magic);
+            dst[row * P + (e - row * T)] = src[e];
+          }
+          if (T < P)
+            for (unsigned r = threadIdx.x; r < (unsigned)wi.w; r += 1024)
+              for (int c = T; c < P; ++c) dst[r * P + c] = 0.f;
         }
-        if (T < P)
-          for (unsigned r = threadIdx.x; r < (unsigned)wi.w; r += 1024)
-            for (int c = T; c < P; ++c) Hs[r * P + c] = 0.f;
+        const size_t cj = (size_t)chunk * J + j;
+        for (int p = threadIdx.x; p < np; p += 1024) {
+          float w[4], dw[4];
+          const int idx0 = ski_taps_u<false>(uloc[cj * CH + p0 + p], 0.f, G, w, dw);
+          Ws[(size_t)j * RPA + p] = make_float4(w[0], w[1], w[2], w[3]);
+          Is[(size_t)j * RPA + p] = (uint16_t)(idx0 - wi.x + hrow[j]);
+        }
       }
-      for (int p = threadIdx.x; p < np; p += 1024) {
-        float w[4], dw[4];
-        const int idx0 = ski_taps_u<false>(uloc[cj * CH + p0 + p], 0.f, G, w, dw);
-        Ws[p] = make_float4(w[0], w[1], w[2], w[3]);
-        Is[p] = (uint16_t)(idx0 - wi.x);
-      }
+      float vnext[4];
+      load_v(p0, np, 0, vnext);                // (in flight across the barrier)
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        float vin[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vin[r] = vnext[r];
+        load_v(p0, np, s + 1, vnext);
         const int p = (s * 16 + wave) * SLOTS + slot;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
         if (slot < SLOTS && p < np) {
-          const float4 w = Ws[p];
-          const float *hp = Hs + (unsigned)Is[p] * P + 4 * q;
-          const float4 h0 = *reinterpret_cast<const float4 *>(hp);
-          const float4 h1 = *reinterpret_cast<const float4 *>(hp + P);
-          const float4 h2 = *reinterpret_cast<const float4 *>(hp + 2 * P);
-          const float4 h3 = *reinterpret_cast<const float4 *>(hp + 3 * P);
-          const float a0[4] = {h0.x, h0.y, h0.z, h0.w}, a1[4] = {h1.x, h1.y, h1.z, h1.w};
-          const float a2[4] = {h2.x, h2.y, h2.z, h2.w}, a3[4] = {h3.x, h3.y, h3.z, h3.w};
+          for (int j = 0; j < J; ++j) {
+            const float4 w = Ws[(size_t)j * RPA + p];
+            const float *hp = Hs + (unsigned)Is[(size_t)j * RPA + p] * P + 4 * q;
+            const float4 h0 = *reinterpret_cast<const float4 *>(hp);
+            const float4 h1 = *reinterpret_cast<const float4 *>(hp + P);
+            const float4 h2 = *reinterpret_cast<const float4 *>(hp + 2 * P);
+            const float4 h3 = *reinterpret_cast<const float4 *>(hp + 3 * P);
+            const float a0[4] = {h0.x, h0.y, h0.z, h0.w}, a1[4] = {h1.x, h1.y, h1.z, h1.w};
+            const float a2[4] = {h2.x, h2.y, h2.z, h2.w}, a3[4] = {h3.x, h3.y, h3.z, h3.w};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float pr = w.x * a0[r];
-            pr = __builtin_fmaf(w.y, a1[r], pr);
-            pr = __builtin_fmaf(w.z, a2[r], pr);
-            pr = __builtin_fmaf(w.w, a3[r], pr);
-            acc[s][r] += (double)pr;
+            for (int r = 0; r < 4; ++r) {
+              float pr = w.x * a0[r];
+              pr = __builtin_fmaf(w.y, a1[r], pr);
+              pr = __builtin_fmaf(w.z, a2[r], pr);
+              pr = __builtin_fmaf(w.w, a3[r], pr);
+              a[r] += (double)pr;
+            }
           }
         }
+        store_out(p0, np, s, a, vin);
       }
-    }
+    } else {
+      for (int s = 0; s < STEPS; ++s) {
+        const int p = (s * 16 + wave) * SLOTS + slot;
+        float vin[4];
+        load_v(p0, np, s, vin);
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (slot < SLOTS && p < np) {
+          for (int j = 0; j < J; ++j) {
+            float w[4], dw[4];
+            const int idx0 = ski_taps_u<false>(uloc[((size_t)chunk * J + j) * CH + p0 + p], 0.f, G, w, dw);
+            const float *hp = H + ((size_t)j * G + idx0) * T;
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      const int p = (s * 16 + wave) * SLOTS + slot;
-      if (slot < SLOTS && p < np) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = 4 * q + r;
-          if (col < T) {
-            const size_t o = (size_t)(base + p0 + p) * T + col;
-            const float vin = noise != 0.f ? V[o] : 0.f;
-            out[o] = __builtin_fmaf(noise, vin, scale * (float)acc[s][r]);
+            for (int r = 0; r < 4; ++r) {
+              const int col = 4 * q + r < T ? 4 * q + r : 0;
+              float pr = w[0] * hp[col];
+              pr = __builtin_fmaf(w[1], hp[T + col], pr);
+              pr = __builtin_fmaf(w[2], hp[2 * T + col], pr);
+              pr = __builtin_fmaf(w[3], hp[3 * T + col], pr);
+              a[r] += (double)pr;
+            }
           }
         }
+        store_out(p0, np, s, a, vin);
       }
     }
   }
 }
 
-inline size_t chunk_scatter_lds(int CH, int G, int LPP) {
-  return (size_t)CH * LPP * 16 + (size_t)CH * 16 + (size_t)CH * 2 + (size_t)(G + 8) * 2;
+// LDS of the scatter with `njb` projections resident
+inline size_t chunk_scatter_lds(int CH, int G, int LPP, int njb) {
+  return (size_t)CH * LPP * 16 + (size_t)njb * ((size_t)CH * 16 + (size_t)CH * 2 + (size_t)(G + 2) * 2);
 }
-inline size_t chunk_gather_lds(int G, int LPP) {
-  const size_t rpp = (size_t)16 * (64 / LPP) * 4;          // RPP of ski_chunk_gather_kernel
-  return (size_t)G * LPP * 16 + rpp * 16 + rpp * 2;
-}
+template <int LPP> struct GatherGeom { static constexpr int STEPS = LPP == 3 ? 5 : 2; };      // passes of 1680 / 1024 / 2048 rows
 
 template <class K>
 inline int big_lds(K kernel, size_t bytes) {
@@ -912,20 +1048,22 @@ inline int big_lds(K kernel, size_t bytes) {
 int scatter_chunked(const PlanView &pv, const float *V, double *hist, float *win, long long N, int J, int G, int T, int HT,
                     int hoff, hipStream_t st) {
   const int LPP = (T + 3) / 4;
-  const size_t lds = chunk_scatter_lds(pv.CH, G, LPP);
+  int njb = J;
+  while (njb > 1 && chunk_scatter_lds(pv.CH, G, LPP, njb) > kChunkLdsBytes) --njb;
+  const size_t lds = chunk_scatter_lds(pv.CH, G, LPP, njb);
+  if (lds > kChunkLdsBytes) return RPGP_EWORKSPACE;
   static bool attr_set = false;
   if (!attr_set) {
-    const size_t mx = chunk_scatter_lds(kChunkMaxRows, 2048, 3);
-    if (big_lds(ski_chunk_scatter_kernel<1>, mx) || big_lds(ski_chunk_scatter_kernel<2>, mx) ||
-        big_lds(ski_chunk_scatter_kernel<3>, mx))
+    if (big_lds(ski_chunk_scatter_kernel<1>, kChunkLdsBytes) || big_lds(ski_chunk_scatter_kernel<2>, kChunkLdsBytes) ||
+        big_lds(ski_chunk_scatter_kernel<3>, kChunkLdsBytes))
       return RPGP_EWORKSPACE;
     attr_set = true;
   }
   const dim3 cgrid((unsigned)((G + 15) / 16), (unsigned)J);
 #define RPGP_CHUNK_SCATTER(L_)                                                                                                 \
   hipLaunchKernelGGL((ski_chunk_scatter_kernel<L_>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, pv.lperm,  \
-                     pv.coff, V, win, N, J, G, T, pv.CH);                                                                       \
-  hipLaunchKernelGGL((ski_chunk_combine_kernel<L_>), cgrid, dim3(256), 0, st, pv.winfo, win, hist, pv.nch, J, G, T, HT, hoff)
+                     pv.coff, V, win, N, J, G, T, pv.CH, njb);                                                                  \
+  hipLaunchKernelGGL((ski_chunk_combine_kernel<L_>), cgrid, dim3(512), 0, st, pv.winfo, win, hist, pv.nch, J, G, T, HT, hoff)
   if (LPP == 1) {
     RPGP_CHUNK_SCATTER(1);
   } else if (LPP == 2) {
@@ -940,20 +1078,33 @@ int scatter_chunked(const PlanView &pv, const float *V, double *hist, float *win
 int gather_chunked(const PlanView &pv, const float *H, const float *V, float *out, long long N, int J, int G, int T, float scale,
                    float noise, hipStream_t st) {
   const int LPP = (T + 3) / 4;
-  const size_t lds = chunk_gather_lds(G, LPP);
+  const int steps = LPP == 3 ? GatherGeom<3>::STEPS : (LPP == 2 ? GatherGeom<2>::STEPS : GatherGeom<1>::STEPS);
+  const int rpp = 16 * (64 / LPP) * steps;
+  const int rpa = pv.CH < rpp ? pv.CH : rpp;                         // stencil slots per projection (rows of a pass)
+  const size_t sten = (((size_t)J * rpa * 18) + 15) & ~(size_t)15;
+  if (sten + (size_t)256 * LPP * 16 > kChunkLdsBytes) return RPGP_EWORKSPACE;
+  long long hcap = (long long)((kChunkLdsBytes - sten) / ((size_t)LPP * 16));      // window rows that fit beside the stencils
+  if (hcap > (long long)J * G) hcap = (long long)J * G;
+  const size_t lds = (size_t)hcap * LPP * 16 + sten;
   static bool attr_set = false;
   if (!attr_set) {
-    if (big_lds(ski_chunk_gather_kernel<1>, chunk_gather_lds(2048, 1)) || big_lds(ski_chunk_gather_kernel<2>, chunk_gather_lds(2048, 2)) ||
-        big_lds(ski_chunk_gather_kernel<3>, chunk_gather_lds(2048, 3)))
+    if (big_lds(ski_chunk_gather_kernel<1, GatherGeom<1>::STEPS>, kChunkLdsBytes) ||
+        big_lds(ski_chunk_gather_kernel<2, GatherGeom<2>::STEPS>, kChunkLdsBytes) ||
+        big_lds(ski_chunk_gather_kernel<3, GatherGeom<3>::STEPS>, kChunkLdsBytes))
       return RPGP_EWORKSPACE;
     attr_set = true;
   }
-  if (LPP == 1)
-    hipLaunchKernelGGL((ski_chunk_gather_kernel<1>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, H, V, out, N, J, G, T, pv.CH, scale, noise);
-  else if (LPP == 2)
-    hipLaunchKernelGGL((ski_chunk_gather_kernel<2>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, H, V, out, N, J, G, T, pv.CH, scale, noise);
-  else
-    hipLaunchKernelGGL((ski_chunk_gather_kernel<3>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, H, V, out, N, J, G, T, pv.CH, scale, noise);
+#define RPGP_CHUNK_GATHER(L_)                                                                                                  \
+  hipLaunchKernelGGL((ski_chunk_gather_kernel<L_, GatherGeom<L_>::STEPS>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, \
+                     pv.uloc, H, V, out, N, J, G, T, pv.CH, scale, noise, (int)hcap, rpa)
+  if (LPP == 1) {
+    RPGP_CHUNK_GATHER(1);
+  } else if (LPP == 2) {
+    RPGP_CHUNK_GATHER(2);
+  } else {
+    RPGP_CHUNK_GATHER(3);
+  }
+#undef RPGP_CHUNK_GATHER
   return launch_status();
 }
 

@@ -24,7 +24,10 @@ def timed(fn, reps=50, warm=3):
     return round(e0.elapsed_time(e1) / reps * 1e3, 2)
 
 
+orders = os.environ.get("ORDERS", "locality,file").split(",")
 for name, rows in (("locality order", locality_order(X)), ("file order", torch.arange(N))):
+    if name.split()[0] not in orders:
+        continue
     Z = (X[rows] @ Q).contiguous().to(dev)
     gp = ops.ski_grid(Z, None, G)
     plan = ops.SkiPlan(Z, gp, G)

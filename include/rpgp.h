@@ -279,10 +279,13 @@ int rpgp_ski_gather_fast(const void *plan, const float *Z, const float *grid_par
  * contiguous chunks, a chunk's rows of V are staged in LDS once for all projections, a chunk leaves one window of grid
  * rows per projection and reads back only the window of the Toeplitz product it needs.  Same entry points, same result
  * contract (bitwise reproducible; the gather is bit-identical to the cell-sorted form, the scatter sums in another order).
- * rpgp_ski_plan builds the tables of both forms; rpgp_ski_chunk_mode(0 | 1) selects the form the products run (process-wide;
- * default 1, or the environment variable RPGP_SKI_CHUNK), any other argument only queries.  Returns the previous setting.
+ * OPT-IN — measured at the C5 shape it does not beat the cell-sorted form:
+ * rpgp_ski_chunk_mode(0 | 1) selects the form (process-wide; default 0, or the environment variable RPGP_SKI_CHUNK=1), any
+ * other argument only queries; returns the previous setting.  A plan built while the mode is on carries the tables of both
+ * forms (rpgp_ski_plan_is_chunked), and the mode may then be flipped between two products of that plan.
  */
 int rpgp_ski_chunk_mode(int mode);
+int rpgp_ski_plan_is_chunked(const void *plan);
 /* Pivoted Cholesky of the SKI operator (same contract as rpgp_pivoted_cholesky; diag_work: N + RPGP_PIVCHOL_SCRATCH). */
 int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
                               int J, int G, int rank, float scale, void *stream);

@@ -17,8 +17,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdio.h>
 
 #include <cstring>
+#include <mutex>
+#include <unordered_set>
 #include <stdlib.h>
 #include <string.h>
 
@@ -46,6 +49,7 @@ struct PlanView {
   int2 *item_info;     // [max_items]  (first sorted entry, number of points) of every scatter item
   double *tcol;        // [J][G16]  first column of the Toeplitz matrix of every projection, exp(-0.5 (k h_j)^2)
   // chunked product (round 5; only when chunk_ok(N, J, G)) -- see "chunked product" below
+  const void *base;    // the plan blob (key of chunked_plans())
   int CH, nch;         // rows per chunk, chunks
   int4 *winfo;         // [nch * J]       (first cell, cells spanned, first window row in the window table, window rows)
   float *uloc;         // [nch * J][CH]   clamped grid coordinate of every (chunk row, projection)
@@ -66,16 +70,34 @@ inline int chunk_rows(long long N) {
   if (ch > kChunkMaxRows) ch = kChunkMaxRows;
   return (int)ch;
 }
-// RPGP_SKI_CHUNK=0 (or rpgp_ski_chunk_mode(0)): the cell-sorted product of rounds 3 - 4 (A/B measurements, tests).  The
-// plan carries the tables of BOTH products whenever the shape allows, so the switch may be flipped between two products.
+// The chunked product is OPT-IN (RPGP_SKI_CHUNK=1 or rpgp_ski_chunk_mode(1)): measured at the C5 shape it does not beat the
+// cell-sorted product of rounds 3 - 4.  A plan built while the mode is on carries the tables of BOTH
+// products (the set below remembers which plans do), so the switch may be flipped between two products of such a plan.
 inline int &chunk_mode_ref() {
   static int mode = [] {
     const char *e = getenv("RPGP_SKI_CHUNK");
-    return (e && e[0] == '0') ? 0 : 1;
+    return (e && e[0] == '1') ? 1 : 0;
   }();
   return mode;
 }
 inline bool chunk_env_on() { return chunk_mode_ref() != 0; }
+struct ChunkedPlans {
+  std::mutex mu;
+  std::unordered_set<const void *> set;
+  void mark(const void *plan, bool chunked) {
+    std::lock_guard<std::mutex> g(mu);
+    if (chunked) set.insert(plan);
+    else set.erase(plan);
+  }
+  bool has(const void *plan) {
+    std::lock_guard<std::mutex> g(mu);
+    return set.count(plan) != 0;
+  }
+};
+inline ChunkedPlans &chunked_plans() {
+  static ChunkedPlans p;
+  return p;
+}
 // The window table lives in the scatter slabs of the SKI workspace (rpgp_ski_workspace_bytes: 1024 / J chunks of J x G x 12
 // floats), which bounds chunks x projections by 1024; few projections, enough rows to fill the chip.
 inline bool chunk_shape_ok(long long N, int J, int G) {
@@ -90,6 +112,7 @@ inline long long max_items(long long N, int J, int G);
 
 inline PlanView plan_view(void *base, long long N, int J, int G) {
   PlanView v;
+  v.base = base;
   char *p = reinterpret_cast<char *>(base);
   const size_t nj = (size_t)N * J, cells = (size_t)J * G + 1, G16 = (size_t)((G + 15) & ~15);
   v.perm = reinterpret_cast<int *>(p); p += align256(nj * sizeof(int));
@@ -783,20 +806,32 @@ __global__ __launch_bounds__(1024) void ski_chunk_scatter_kernel(const int4 *__r
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[k][r] = 0.f;
-      unsigned p = lj[it < end ? it : 0];
-      for (; it < end; ++it) {
-        const unsigned pn = lj[it + 1 < end ? it + 1 : it];      // the next row number is requested under this row's work
-        const float4 w = Wj[p];
-        const float4 v = *reinterpret_cast<const float4 *>(Vs + p * P + 4 * q);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+      // four rows per trip: the four row numbers, then the eight 16-byte records, are requested together (one row per trip
+      // is a chain of two dependent LDS round trips per row: measured 140 ns per row and wave); rows beyond the cell's end
+      // repeat the last row with its V masked to zero — the sums keep the cell's row order
+      for (; it < end; it += 4) {
+        unsigned pr[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc[0][r] = __builtin_fmaf(w.x, vv[r], acc[0][r]);
-          acc[1][r] = __builtin_fmaf(w.y, vv[r], acc[1][r]);
-          acc[2][r] = __builtin_fmaf(w.z, vv[r], acc[2][r]);
-          acc[3][r] = __builtin_fmaf(w.w, vv[r], acc[3][r]);
+        for (int u = 0; u < 4; ++u) pr[u] = lj[it + u < end ? it + u : end - 1];
+        float4 w[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          w[u] = Wj[pr[u]];
+          v[u] = *reinterpret_cast<const float4 *>(Vs + pr[u] * P + 4 * q);
         }
-        p = pn;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool live = it + u < end;      // (masking V, not the weights: a repeated non-finite row must not add 0 x inf)
+          const float ww[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+          const float vv[4] = {live ? v[u].x : 0.f, live ? v[u].y : 0.f, live ? v[u].z : 0.f, live ? v[u].w : 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[0][r] = __builtin_fmaf(ww[0], vv[r], acc[0][r]);
+            acc[1][r] = __builtin_fmaf(ww[1], vv[r], acc[1][r]);
+            acc[2][r] = __builtin_fmaf(ww[2], vv[r], acc[2][r]);
+            acc[3][r] = __builtin_fmaf(ww[3], vv[r], acc[3][r]);
+          }
+        }
       }
       // window row cl = tap 0 of cell cl + tap 1 of cell cl - 1 + tap 2 of cell cl - 2 + tap 3 of cell cl - 3
       float o[4];
@@ -892,11 +927,12 @@ __global__ __launch_bounds__(512) void ski_chunk_combine_kernel(const int4 *__re
 }
 
 // out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0 + k][t] + noise V[i][t] for the chunk's rows.  The windows of H the
-// chunk touches (all projections': ~3 x 160 rows at the C5 shape) and the rows' stencils are staged in LDS behind ONE round
-// of requests; a row is then finished in one go — the sum over j in float64 in projection order, every product formed exactly
-// as in ski_gather_lds_kernel (same bits) — with its V values requested one step ahead.  A chunk whose windows exceed the LDS
-// rows (HCAP; rows far out in the tails, or rows in no particular order) reads H from memory instead: same arithmetic.
-// STEPS wave steps of 64 / LPP rows per wave make a pass of RPP rows.
+// chunk touches (all projections': ~3 x 160 rows at the C5 shape) and the rows' grid coordinates are staged in LDS behind ONE
+// round of requests; a row is then finished in one go — its stencils derived in the lane (the LDS pipe, which bounds this
+// kernel, only serves the coordinate and the four tap rows), the sum over j in float64 in projection order, every product
+// formed exactly as in ski_gather_lds_kernel (same bits) — with its V values in flight across the row sums.  A chunk whose
+// windows exceed the LDS rows (HCAP: more than ~98 % of the grid in every projection) reads H from memory instead: same
+// arithmetic.  STEPS wave steps of 64 / LPP rows per wave make a pass of RPP rows.
 template <int LPP, int STEPS>
 __global__ __launch_bounds__(1024) void ski_chunk_gather_kernel(const int4 *__restrict__ winfo, const float *__restrict__ uloc,
                                                                 const float *__restrict__ H, const float *__restrict__ V,
@@ -907,8 +943,7 @@ __global__ __launch_bounds__(1024) void ski_chunk_gather_kernel(const int4 *__re
   constexpr int RPP = 16 * SLOTS * STEPS;      // rows per pass
   extern __shared__ float4 lds4[];
   float *Hs = reinterpret_cast<float *>(lds4);                        // [HCAP][P]  window rows of all projections
-  float4 *Ws = lds4 + (size_t)HCAP * LPP;                             // [J][RPA]   stencils of the pass's rows
-  uint16_t *Is = reinterpret_cast<uint16_t *>(Ws + (size_t)J * RPA);  // [J][RPA]   first tap, as a row of Hs
+  float *Us = Hs + (size_t)HCAP * P;                                  // [J][RPA]   grid coordinates of the pass's rows
   __shared__ int4 swi[kChunkMaxJ];
   const int chunk = blockIdx.x;
   const long long base = (long long)chunk * CH;
@@ -918,116 +953,142 @@ __global__ __launch_bounds__(1024) void ski_chunk_gather_kernel(const int4 *__re
   const unsigned magic = ((1u << 20) + T - 1) / T;
   if (threadIdx.x < J) swi[threadIdx.x] = winfo[(size_t)chunk * J + threadIdx.x];
   __syncthreads();
-  int hrow[kChunkMaxJ], rows = 0;
+  int hrow[kChunkMaxJ], wlo[kChunkMaxJ], rows = 0;      // (uniform: kept in scalar registers)
 #pragma unroll
   for (int j = 0; j < kChunkMaxJ; ++j) {
     hrow[j] = rows;
-    rows += j < J ? swi[j].w : 0;
+    wlo[j] = __builtin_amdgcn_readfirstlane(j < J ? swi[j].x : 0);
+    rows += __builtin_amdgcn_readfirstlane(j < J ? swi[j].w : 0);
   }
   const bool resident = rows <= HCAP;          // (uniform over the workgroup)
-  auto load_v = [&](int p0, int np, int s, float (&vin)[4]) {
-    const int p = (s * 16 + wave) * SLOTS + slot;
+  const float *Vc = noise != 0.f ? V + base * T : H;      // (only element 0 is touched when noise == 0)
+  float *outc = out + base * T;
+  for (int p0 = 0; p0 < n; p0 += RPP) {
+    const int np = n - p0 < RPP ? n - p0 : RPP;
+    if (p0 > 0) __syncthreads();               // (the previous pass's readers of the coordinates are done)
+    // ---- requests: the rows' grid coordinates and the first batch of window rows -------------------------------------------
+    constexpr int HB = 8;                      // window floats per thread and batch
+    float ru[kChunkMaxJ][2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int col = 4 * q + r;
-      const bool ok = s < STEPS && slot < SLOTS && p < np && col < T && noise != 0.f;
-      const float x = V[ok ? (size_t)(base + p0 + p) * T + col : 0];
-      vin[r] = ok ? x : 0.f;
+    for (int j = 0; j < kChunkMaxJ; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int p = threadIdx.x + h * 1024;
+        ru[j][h] = uloc[((size_t)chunk * J + (j < J ? j : 0)) * CH + p0 + (p < np ? p : 0)];
+      }
+    const unsigned etot = (p0 == 0 && resident) ? (unsigned)rows * T : 0u;      // the windows serve every pass
+    unsigned eoff[kChunkMaxJ];
+    const float *hsrc[kChunkMaxJ];
+#pragma unroll
+    for (int j = 0; j < kChunkMaxJ; ++j) {
+      eoff[j] = (unsigned)hrow[j] * T;
+      hsrc[j] = H + ((size_t)(j < J ? j : 0) * G + wlo[j]) * T;
     }
-  };
-  auto store_out = [&](int p0, int np, int s, const double (&a)[4], const float (&vin)[4]) {
-    const int p = (s * 16 + wave) * SLOTS + slot;
-    if (slot < SLOTS && p < np) {
+    auto window_of = [&](unsigned e) {
+      int j = 0;
+#pragma unroll
+      for (int t = 1; t < kChunkMaxJ; ++t) j += (t < J && e >= eoff[t]) ? 1 : 0;
+      return j;
+    };
+    float hq[HB];
+#pragma unroll
+    for (int k = 0; k < HB; ++k) {
+      const unsigned e = threadIdx.x + k * 1024;
+      const unsigned ec = e < etot ? e : 0;
+      const int j = window_of(ec);
+      hq[k] = hsrc[j][ec - eoff[j]];
+    }
+    // ---- into LDS ---------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < kChunkMaxJ; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int p = threadIdx.x + h * 1024;
+        if (j < J && p < np) Us[(size_t)j * RPA + p] = ru[j][h];
+      }
+    auto window_store = [&](unsigned e, float x) {
+      const int j = window_of(e);
+      const unsigned rel = e - eoff[j], row = div_small(rel, magic);
+      Hs[((unsigned)hrow[j] + row) * P + (rel - row * T)] = x;
+    };
+#pragma unroll
+    for (int k = 0; k < HB; ++k) {
+      const unsigned e = threadIdx.x + k * 1024;
+      if (e < etot) window_store(e, hq[k]);
+    }
+    for (unsigned e = threadIdx.x + HB * 1024; e < etot; e += 1024) {      // (windows beyond 8192 floats: rare)
+      const int j = window_of(e);
+      window_store(e, hsrc[j][e - eoff[j]]);
+    }
+    if (T < P && etot > 0)
+      for (unsigned r = threadIdx.x; r < (unsigned)rows; r += 1024)
+        for (int c = T; c < P; ++c) Hs[r * P + c] = 0.f;
+    // the rows' V values are requested two steps ahead of their use (a ring of three: all twenty at once cost the registers
+    // the row sums need)
+    float vring[3][4];
+    auto load_v = [&](int s, float (&vin)[4]) {
+      const int p = (s * 16 + wave) * SLOTS + slot;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int col = 4 * q + r;
-        if (col < T) out[(size_t)(base + p0 + p) * T + col] = __builtin_fmaf(noise, vin[r], scale * (float)a[r]);
+        const bool ok = s < STEPS && slot < SLOTS && p < np && col < T && noise != 0.f;
+        const float x = Vc[ok ? (unsigned)(p0 + p) * T + col : 0u];      // (32-bit offsets from the chunk's first row)
+        vin[r] = ok ? x : 0.f;
       }
-    }
-  };
-  for (int p0 = 0; p0 < n; p0 += RPP) {
-    const int np = n - p0 < RPP ? n - p0 : RPP;
-    if (resident) {
-      if (p0 > 0) __syncthreads();             // (the previous pass's readers of the stencils are done)
-      for (int j = 0; j < J; ++j) {
-        const int4 wi = swi[j];
-        if (p0 == 0) {                         // the windows serve every pass
-          const float *src = H + ((size_t)j * G + wi.x) * T;          // rows wi.x .. of H_j: one contiguous block
-          const unsigned total = (unsigned)wi.w * T;
-          float *dst = Hs + (size_t)hrow[j] * P;
-          for (unsigned e = threadIdx.x; e < total; e += 1024) {
-            const unsigned row = div_small(e, magic);
-            dst[row * P + (e - row * T)] = src[e];
-          }
-          if (T < P)
-            for (unsigned r = threadIdx.x; r < (unsigned)wi.w; r += 1024)
-              for (int c = T; c < P; ++c) dst[r * P + c] = 0.f;
-        }
-        const size_t cj = (size_t)chunk * J + j;
-        for (int p = threadIdx.x; p < np; p += 1024) {
-          float w[4], dw[4];
-          const int idx0 = ski_taps_u<false>(uloc[cj * CH + p0 + p], 0.f, G, w, dw);
-          Ws[(size_t)j * RPA + p] = make_float4(w[0], w[1], w[2], w[3]);
-          Is[(size_t)j * RPA + p] = (uint16_t)(idx0 - wi.x + hrow[j]);
-        }
-      }
-      float vnext[4];
-      load_v(p0, np, 0, vnext);                // (in flight across the barrier)
-      __syncthreads();
+    };
+    load_v(0, vring[0]);
+    load_v(1, vring[1]);
+    __syncthreads();
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        __builtin_amdgcn_sched_barrier(0);
-        float vin[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vin[r] = vnext[r];
-        load_v(p0, np, s + 1, vnext);
-        const int p = (s * 16 + wave) * SLOTS + slot;
+    for (int s = 0; s < STEPS; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_v(s + 2, vring[(s + 2) % 3]);
+      const int p = (s * 16 + wave) * SLOTS + slot;
+      if (slot < SLOTS && p < np) {
         double a[4] = {0.0, 0.0, 0.0, 0.0};
-        if (slot < SLOTS && p < np) {
-          for (int j = 0; j < J; ++j) {
-            const float4 w = Ws[(size_t)j * RPA + p];
-            const float *hp = Hs + (unsigned)Is[(size_t)j * RPA + p] * P + 4 * q;
+#pragma unroll 1
+        for (int j = 0; j < J; ++j) {
+          float w[4], dw[4];
+          const int idx0 = ski_taps_u<false>(Us[(size_t)j * RPA + p], 0.f, G, w, dw);
+          float a0[4], a1[4], a2[4], a3[4];
+          if (resident) {
+            int hj = hrow[0] - wlo[0];         // (row of Hs of grid row 0 of projection j)
+#pragma unroll
+            for (int t = 1; t < kChunkMaxJ; ++t) hj = j == t ? hrow[t] - wlo[t] : hj;
+            const float *hp = Hs + (unsigned)(idx0 + hj) * P + 4 * q;
             const float4 h0 = *reinterpret_cast<const float4 *>(hp);
             const float4 h1 = *reinterpret_cast<const float4 *>(hp + P);
             const float4 h2 = *reinterpret_cast<const float4 *>(hp + 2 * P);
             const float4 h3 = *reinterpret_cast<const float4 *>(hp + 3 * P);
-            const float a0[4] = {h0.x, h0.y, h0.z, h0.w}, a1[4] = {h1.x, h1.y, h1.z, h1.w};
-            const float a2[4] = {h2.x, h2.y, h2.z, h2.w}, a3[4] = {h3.x, h3.y, h3.z, h3.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float pr = w.x * a0[r];
-              pr = __builtin_fmaf(w.y, a1[r], pr);
-              pr = __builtin_fmaf(w.z, a2[r], pr);
-              pr = __builtin_fmaf(w.w, a3[r], pr);
-              a[r] += (double)pr;
-            }
-          }
-        }
-        store_out(p0, np, s, a, vin);
-      }
-    } else {
-      for (int s = 0; s < STEPS; ++s) {
-        const int p = (s * 16 + wave) * SLOTS + slot;
-        float vin[4];
-        load_v(p0, np, s, vin);
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
-        if (slot < SLOTS && p < np) {
-          for (int j = 0; j < J; ++j) {
-            float w[4], dw[4];
-            const int idx0 = ski_taps_u<false>(uloc[((size_t)chunk * J + j) * CH + p0 + p], 0.f, G, w, dw);
+            a0[0] = h0.x; a0[1] = h0.y; a0[2] = h0.z; a0[3] = h0.w;
+            a1[0] = h1.x; a1[1] = h1.y; a1[2] = h1.z; a1[3] = h1.w;
+            a2[0] = h2.x; a2[1] = h2.y; a2[2] = h2.z; a2[3] = h2.w;
+            a3[0] = h3.x; a3[1] = h3.y; a3[2] = h3.z; a3[3] = h3.w;
+          } else {
             const float *hp = H + ((size_t)j * G + idx0) * T;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int col = 4 * q + r < T ? 4 * q + r : 0;
-              float pr = w[0] * hp[col];
-              pr = __builtin_fmaf(w[1], hp[T + col], pr);
-              pr = __builtin_fmaf(w[2], hp[2 * T + col], pr);
-              pr = __builtin_fmaf(w[3], hp[3 * T + col], pr);
-              a[r] += (double)pr;
+              a0[r] = hp[col];
+              a1[r] = hp[T + col];
+              a2[r] = hp[2 * T + col];
+              a3[r] = hp[3 * T + col];
             }
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pr = w[0] * a0[r];
+            pr = __builtin_fmaf(w[1], a1[r], pr);
+            pr = __builtin_fmaf(w[2], a2[r], pr);
+            pr = __builtin_fmaf(w[3], a3[r], pr);
+            a[r] += (double)pr;
+          }
         }
-        store_out(p0, np, s, a, vin);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = 4 * q + r;
+          if (col < T) outc[(unsigned)(p0 + p) * T + col] = __builtin_fmaf(noise, vring[s % 3][r], scale * (float)a[r]);
+        }
       }
     }
   }
@@ -1062,7 +1123,7 @@ int scatter_chunked(const PlanView &pv, const float *V, double *hist, float *win
   const dim3 cgrid((unsigned)((G + 15) / 16), (unsigned)J);
 #define RPGP_CHUNK_SCATTER(L_)                                                                                                 \
   hipLaunchKernelGGL((ski_chunk_scatter_kernel<L_>), dim3((unsigned)pv.nch), dim3(1024), lds, st, pv.winfo, pv.uloc, pv.lperm,  \
-                     pv.coff, V, win, N, J, G, T, pv.CH, njb);                                                                  \
+                     pv.coff, V, win, N, J, G, T, pv.CH, njb);                                                                            \
   hipLaunchKernelGGL((ski_chunk_combine_kernel<L_>), cgrid, dim3(512), 0, st, pv.winfo, win, hist, pv.nch, J, G, T, HT, hoff)
   if (LPP == 1) {
     RPGP_CHUNK_SCATTER(1);
@@ -1080,12 +1141,12 @@ int gather_chunked(const PlanView &pv, const float *H, const float *V, float *ou
   const int LPP = (T + 3) / 4;
   const int steps = LPP == 3 ? GatherGeom<3>::STEPS : (LPP == 2 ? GatherGeom<2>::STEPS : GatherGeom<1>::STEPS);
   const int rpp = 16 * (64 / LPP) * steps;
-  const int rpa = pv.CH < rpp ? pv.CH : rpp;                         // stencil slots per projection (rows of a pass)
-  const size_t sten = (((size_t)J * rpa * 18) + 15) & ~(size_t)15;
-  if (sten + (size_t)256 * LPP * 16 > kChunkLdsBytes) return RPGP_EWORKSPACE;
-  long long hcap = (long long)((kChunkLdsBytes - sten) / ((size_t)LPP * 16));      // window rows that fit beside the stencils
+  const int rpa = pv.CH < rpp ? pv.CH : rpp;                         // coordinate slots per projection (rows of a pass)
+  const size_t coord = (((size_t)J * rpa * 4) + 15) & ~(size_t)15;
+  long long hcap = (long long)((kChunkLdsBytes - coord) / ((size_t)LPP * 16));     // window rows that fit beside the coordinates
   if (hcap > (long long)J * G) hcap = (long long)J * G;
-  const size_t lds = (size_t)hcap * LPP * 16 + sten;
+  if (hcap < 64) return RPGP_EWORKSPACE;
+  const size_t lds = (size_t)hcap * LPP * 16 + coord;
   static bool attr_set = false;
   if (!attr_set) {
     if (big_lds(ski_chunk_gather_kernel<1, GatherGeom<1>::STEPS>, kChunkLdsBytes) ||
@@ -1112,7 +1173,7 @@ constexpr size_t kGatherLdsMax = 150 * 1024;
 
 int gather_planned(const PlanView *pv, const float *Z, const float *gp, const float *H, const float *V, float *out, long long M,
                    int ldz, int J, int G, int T, float scale, float noise, hipStream_t st) {
-  if (pv && pv->nch > 0 && chunk_env_on() && T <= 12 && (V || noise == 0.f))
+  if (pv && pv->nch > 0 && chunk_env_on() && T <= 12 && (V || noise == 0.f) && chunked_plans().has(pv->base))
     return gather_chunked(*pv, H, V, out, M, J, G, T, scale, noise, st);
   const size_t lds = (size_t)J * G * T * sizeof(float);
   static const int mode = [] { const char *e = getenv("RPGP_SKI_GATHER"); return e ? atoi(e) : 0; }();   // 3: never the LDS form
@@ -1146,7 +1207,8 @@ inline int ski_tpiece(int remaining) { return remaining > 4 ? 12 : (remaining > 
 // hist[j][g][hoff .. hoff + T) (row stride HT, float64) from the plan; `partial` holds max_items * 4 * 12 floats
 int scatter_planned(const PlanView &pv, const float *V, double *hist, float *partial, long long N, int J, int G, int T, int HT,
                     int hoff, hipStream_t st) {
-  if (pv.nch > 0 && chunk_env_on() && T <= 12) return scatter_chunked(pv, V, hist, partial, N, J, G, T, HT, hoff, st);
+  if (pv.nch > 0 && chunk_env_on() && T <= 12 && chunked_plans().has(pv.base))
+    return scatter_chunked(pv, V, hist, partial, N, J, G, T, HT, hoff, st);
   const int cells = J * G;
   const long long items = max_items(N, J, G);
   const unsigned nb = (unsigned)items;
@@ -1248,7 +1310,9 @@ int rpgp_ski_plan(const float *Z, const float *grid_params, int64_t N, int ldz, 
   hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(1024), 0, st, pv.cell_start, cells, pv.item_start, pv.item_info);
   hipLaunchKernelGGL(plan_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, keys_out, vals_out, pv.wnat, (long long)N, J, G,
                      (long long)nj, pv.perm, pv.wsort);
-  if (pv.nch > 0) {                            // chunk tables of the round-5 product (its kernels read nothing of the above)
+  const bool chunked = pv.nch > 0 && chunk_env_on();
+  chunked_plans().mark(plan, chunked);         // (a blob reused for a plan without the tables must not look chunked)
+  if (chunked) {                               // chunk tables of the round-5 product (its kernels read nothing of the above)
     hipLaunchKernelGGL(chunk_plan_kernel, dim3((unsigned)pv.nch, (unsigned)J), dim3(256), 0, st, Z, grid_params, (long long)N, ldz,
                        J, G, pv.CH, pv.winfo, pv.uloc, pv.lperm, pv.coff);
     hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, pv.winfo, pv.nch * J);
@@ -1261,6 +1325,8 @@ int rpgp_ski_chunk_mode(int mode) {
   if (mode == 0 || mode == 1) chunk_mode_ref() = mode;
   return prev;
 }
+
+int rpgp_ski_plan_is_chunked(const void *plan) { return plan && chunked_plans().has(plan) ? 1 : 0; }
 
 int rpgp_ski_scatter_planned(const void *plan, const float *V, double *hist, int64_t N, int J, int G, int T, void *workspace,
                              size_t workspace_bytes, void *stream) {

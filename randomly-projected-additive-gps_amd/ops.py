@@ -477,6 +477,11 @@ class SkiPlan:
     def ok(self):
         return self.buf is not None
 
+    @property
+    def chunked(self):
+        """True when the plan also carries the tables of the chunked product (built while ski_chunk_mode was on)."""
+        return self.buf is not None and bool(_lib.load().rpgp_ski_plan_is_chunked(self.buf.data_ptr()))
+
 
 def ski_plan(Z, gp, grid_size=1024):
     return SkiPlan(Z, gp, grid_size)
@@ -528,8 +533,9 @@ def ski_grid_from_range(zmin, zmax, grid_size, device, weights=None):
 
 
 def ski_chunk_mode(mode=None):
-    """Which form of the planned SKI product runs (rpgp_ski_chunk_mode): True = the chunked form of round 5 where the shape
-    allows (default), False = the cell-sorted form.  `mode=None` only queries.  Returns the previous setting."""
+    """Which form of the planned SKI product runs (rpgp_ski_chunk_mode): False = the cell-sorted form (default), True = the
+    chunked form of round 5 where the shape allows (opt-in: not faster at the C5 shape) — for plans built
+    while the mode is on (`SkiPlan.chunked`).  `mode=None` only queries.  Returns the previous setting."""
     lib = _lib.load()
     return bool(lib.rpgp_ski_chunk_mode(-1 if mode is None else int(bool(mode))))
 

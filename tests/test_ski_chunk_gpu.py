@@ -1,4 +1,4 @@
-"""The chunked form of the planned SKI product (round 5, csrc/rpgp_ski.hip "chunked product"): against the float64
+"""The chunked form of the planned SKI product (round 5, csrc/rpgp_ski.hip "chunked product"; opt-in): against the float64
 sparse-W oracle, against the cell-sorted form it replaces (rpgp_ski_chunk_mode switches between them on ONE plan), bitwise
 reproducibility, and the edge shapes of its tables (last chunk short, all rows in one cell, windows that cover the grid)."""
 import numpy as np
@@ -52,9 +52,9 @@ def test_chunked_product_matches_oracle_and_cell_sorted_form(gpu_device, chunk_m
     gph = gp.double().cpu().numpy()
     grid = (float(gph[0]), float(gph[1]))
     scale, noise = 0.8 / J, 0.25
-    plan = ops.SkiPlan(Zt, gp, G)
-    assert plan.ok
     chunk_mode(True)
+    plan = ops.SkiPlan(Zt, gp, G)
+    assert plan.ok and plan.chunked
     out = ops.ski_mvm(Zt, Zt, gp, Vt, scale, noise, G, plan=plan)
     hist = ops.ski_scatter(Zt, gp, Vt, G, plan=plan)
     H = ops.ski_grid_product(hist, gp, G)
@@ -82,7 +82,11 @@ def test_chunked_product_propagates_non_finite_rhs_and_serves_the_derivative_sca
     Z, V = _problem(N, J, T, 3, ordered=True)
     Zt, Vt = Z.to(gpu_device), V.to(gpu_device)
     gp = ops.ski_grid(Zt, None, G)
+    chunk_mode(True)
     plan = ops.SkiPlan(Zt, gp, G)
+    assert plan.chunked
+    chunk_mode(False)
+    assert not ops.SkiPlan(Zt, gp, G).chunked                    # the default: no chunk tables, the cell-sorted product
     chunk_mode(True)
     Vb = Vt.clone()
     Vb[12345, 2] = float("nan")

@@ -464,6 +464,17 @@ typedef struct rpgp_reducer {
   rpgp_allreduce_fn fn;
   void *ctx;
 } rpgp_reducer;
+/*
+ * Graph form of the executor ("hipGraph-captured CG iteration"): rpgp_mbcg_graph_mode(1), or the
+ * environment variable RPGP_CG_GRAPH=1, makes rpgp_mbcg_solve capture ONE iteration (operator product, passes A / B / C)
+ * into a hipGraph after the first iteration and replay it — the per-iteration quantities (parity, history row, whether the
+ * iteration tests convergence, its number, the poll slot) are then derived on the device from an iteration counter instead
+ * of being kernel arguments.  Same arithmetic, same results bit for bit; unsharded solves of the fused / prepared / packed-
+ * cache / SKI / family operators (others keep the queue-ahead form).  Default 0: the queue-ahead form already keeps the device
+ * busy, and a capture per solve costs more than the launches it saves except for small systems.  Returns the
+ * previous setting; any other argument only queries.
+ */
+int rpgp_mbcg_graph_mode(int mode);
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank);
 int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,
                     int hist_len, int check_every, int stagnation_window, float tolerance, int precond_rank,

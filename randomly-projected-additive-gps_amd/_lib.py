@@ -67,6 +67,7 @@ SIGNATURES = {
     "rpgp_ski_scatter_planned": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
     "rpgp_ski_gather_fast": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp]),
     "rpgp_ski_chunk_mode": (_int, [_int]),
+    "rpgp_mbcg_graph_mode": (_int, [_int]),
     "rpgp_ski_plan_is_chunked": (_int, [_vp]),
     "rpgp_ski_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp]),
     "rpgp_ski_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f32, _vp]),

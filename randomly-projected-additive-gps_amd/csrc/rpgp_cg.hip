@@ -47,6 +47,7 @@ constexpr int kMaxBlocks = 1024;   // workgroups of the streaming passes (= part
 constexpr int kMaxHist = 64;       // Lanczos coefficients kept for at most this many iterations
 constexpr int kRedW = 288;         // reduction vector: [16 col sums a][16 col sums b][16 x 16 L^T X]
 constexpr int kRedLt = 32;         // offset of the L^T X block
+constexpr int kPollRingDev = 4;    // poll records in flight (= kPollRing of the host side)
 
 typedef float floatx4m __attribute__((ext_vector_type(4)));
 typedef double doublex4m __attribute__((ext_vector_type(4)));
@@ -104,7 +105,36 @@ struct CgState {
   int done_pp[2];           // poll.done as pass C reads it at its head (ping-pong: workgroup 0 sets poll.done at its tail while
                             // late workgroups of the same launch may only just be starting)
   CgPoll poll;
+  int it;                   // graph form only: the iteration in flight (-1 after the set-up; pass A's workgroup 0 advances it)
 };
+// Graph form (RPGP_CG_GRAPH=1): ONE iteration is captured into a hipGraph and replayed, so a launch may not carry anything
+// that changes from one iteration to the next.  What the host passes per iteration in the queue-ahead form — parity, history
+// row, whether this iteration tests convergence, its number, the poll slot, the ping-pong slab area — is derived in the
+// kernels from the iteration counter in CgState and these per-solve constants.
+struct CgGraphCtl {
+  int hist_len, n_hist, min_it, check_every, n_iter;
+  float *alpha_base, *beta_base;      // history rows (pinned host memory, device view)
+  CgPoll *poll_base;                  // poll ring (pinned host memory, device view)
+  float *partB[2];                    // ping-pong slab areas of pass B
+};
+struct CgIterView {                   // what a pass needs to know about "this iteration"
+  int cur, check_now, iter_count;
+  float *alpha_out, *beta_out, *partB;
+  CgPoll *poll_host;
+};
+__device__ __forceinline__ CgIterView iter_view(const CgGraphCtl &gc, int it) {
+  CgIterView v;
+  v.cur = it & 1;
+  const int slot = it < gc.hist_len ? it : kMaxHist;
+  const bool hist_pending = it < gc.n_hist - 1;
+  v.check_now = (it >= gc.min_it && !hist_pending && (it % gc.check_every == 0 || it == gc.n_iter - 1)) ? 1 : 0;
+  v.iter_count = it + 1;
+  v.alpha_out = gc.alpha_base + (size_t)slot * kMaxT;
+  v.beta_out = gc.beta_base + (size_t)slot * kMaxT;
+  v.partB = gc.partB[it & 1];
+  v.poll_host = v.check_now ? gc.poll_base + (it % kPollRingDev) : (CgPoll *)nullptr;
+  return v;
+}
 
 // ---- the lane <-> element map of the streaming passes -------------------------------------------------------------
 // wave `wave` of the workgroup, 16-row block `blk` (0..3) of the 256-row tile starting at row0:
@@ -257,9 +287,13 @@ __device__ __forceinline__ void slab_sums(const float *const (&src)[NQ], const i
 // part[blk][0..15] = sum over the workgroup's rows of a*b per column; part[blk][32 + kk*16 + t] = sum L[row][kk] b[row][t]
 template <int TT>
 __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, const float *__restrict__ b,
-                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K) {
+                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K,
+                                                int *__restrict__ tick = nullptr) {
   __shared__ float sh[1024];
   const Lane ln;
+  // graph form: this pass opens the iteration — nothing in it depends on the iteration number, passes B and C behind it
+  // read the advanced counter (stream order), and the previous iteration's readers are done
+  if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick = *tick + 1;
   float dot = 0.f;
   // four independent accumulators (one per 16-row block): a single one is a chain of 16 DEPENDENT matrix instructions per
   // tile, and with 3 - 4 waves per SIMD nothing hides their latency (PMC: SQ_WAIT_INST_ANY = 40 % of the wave cycles)
@@ -377,6 +411,7 @@ __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, con
     st->snap_resid[1] = 3.0e38f;
     st->done_pp[0] = 0;
     st->done_pp[1] = 0;
+    st->it = -1;
   }
   __syncthreads();
   const float nrm = snrm[ln.c];
@@ -428,12 +463,19 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
                                                 float *__restrict__ alpha_out, long long N, int K, float sigma2,
                                                 float eps, float stop_after, int cur, int first,
                                                 const float *__restrict__ dirA = nullptr, int nA = 0,
-                                                const float *__restrict__ dirB = nullptr, int nB = 0) {
+                                                const float *__restrict__ dirB = nullptr, int nB = 0,
+                                                const CgGraphCtl *__restrict__ gc = nullptr) {
   __shared__ float sh[1024];
   __shared__ double sW[256];
   __shared__ double sTv[256];
   __shared__ float salpha[kMaxT];
   const Lane ln;
+  if (gc) {                     // graph form: this iteration's parity, history row and slab area from the device counter
+    const CgIterView iv = iter_view(*gc, st->it);
+    cur = iv.cur;
+    alpha_out = iv.alpha_out;
+    part = iv.partB;
+  }
   // Every scalar this prologue needs is requested up front and pinned by one empty asm (hipcc otherwise sinks each load under
   // the condition that uses it — eight dependent round trips, about half of this kernel's time at small N).  (`redA` of
   // the set-up call holds the |rhs|^2 sums — valid memory, value unused; `Cinv` without a preconditioner is not a valid
@@ -597,11 +639,21 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
                                                 int check_now, float tolerance, int iter_count, int stagnation_window,
                                                 const float *__restrict__ x, float *__restrict__ x_best,
                                                 CgPoll *__restrict__ poll_host, const float *__restrict__ dirB = nullptr,
-                                                int nB = 0, double *__restrict__ lt_out = nullptr) {
+                                                int nB = 0, double *__restrict__ lt_out = nullptr,
+                                                const CgGraphCtl *__restrict__ gc = nullptr) {
   __shared__ float sbeta[kMaxT];
   __shared__ float sres[kMaxT];
   __shared__ float srzn[kMaxT];
   const Lane ln;
+  if (gc) {                     // graph form (see CgGraphCtl)
+    const CgIterView iv = iter_view(*gc, st->it);
+    cur = iv.cur;
+    check_now = iv.check_now;
+    iter_count = iv.iter_count;
+    beta_out = iv.beta_out;
+    poll_host = iv.poll_host;
+    if constexpr (DIRECT) dirB = iv.partB;
+  }
   // Every scalar this prologue needs is requested up front and pinned by one empty asm (hipcc otherwise sinks each load under
   // the condition that uses it: six dependent round trips — most of the kernel's time at small N)
   const int tcl = (int)threadIdx.x < TT ? (int)threadIdx.x : TT - 1;
@@ -779,6 +831,7 @@ Grids grids_for(long long N) {
 // Pinned host landing zone for the lagged convergence polls (one per host thread; the executor keeps no other
 // state between calls).
 constexpr int kPollRing = 4;
+static_assert(kPollRing == kPollRingDev, "poll ring of the graph form");
 constexpr size_t kHistFloats = (size_t)(kMaxHist + 1) * kMaxT;       // one coefficient history (the last row is a scratch slot)
 struct PollCtx {
   CgPoll *host = nullptr;
@@ -973,6 +1026,15 @@ size_t operator_workspace(const rpgp_operator *op, int T) {
   }
 }
 
+// RPGP_CG_GRAPH=1 / rpgp_mbcg_graph_mode(1): the iterations of a solve as replays of one captured hipGraph (see CgGraphCtl)
+inline int &graph_mode_ref() {
+  static int mode = [] {
+    const char *e = getenv("RPGP_CG_GRAPH");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return mode;
+}
+
 inline size_t ski_stage_bytes(const rpgp_operator *op, int T) {
   if (op->kind != RPGP_OP_SKI) return 0;
   const size_t nh = (size_t)op->J * op->G * T;
@@ -983,11 +1045,17 @@ inline size_t ski_stage_bytes(const rpgp_operator *op, int T) {
 
 extern "C" {
 
+int rpgp_mbcg_graph_mode(int mode) {
+  const int prev = graph_mode_ref();
+  if (mode == 0 || mode == 1) graph_mode_ref() = mode;
+  return prev;
+}
+
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank) {
   if (!op || T <= 0 || T > kMaxT || precond_rank < 0 || precond_rank > kMaxK || op->N < 0) return 0;
   const size_t nt = (size_t)(op->N > 0 ? op->N : 1) * T * sizeof(float);
   size_t total = 5 * align256(nt);                                             // r, p, z, Ap, x_best
-  total += align256(sizeof(CgState));
+  total += align256(sizeof(CgState)) + align256(sizeof(CgGraphCtl));
   total += align256((size_t)kMaxBlocks * kRedW * sizeof(float));               // per-workgroup partials
   total += 2 * align256((size_t)kRedW * sizeof(double));                       // reduced vectors A / B
   total += ski_stage_bytes(op, T);
@@ -1037,6 +1105,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   float *Ap = reinterpret_cast<float *>(w); w += align256(nt);
   float *x_best = reinterpret_cast<float *>(w); w += align256(nt);
   CgState *state = reinterpret_cast<CgState *>(w); w += align256(sizeof(CgState));
+  CgGraphCtl *gctl = reinterpret_cast<CgGraphCtl *>(w); w += align256(sizeof(CgGraphCtl));
   float *part = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kRedW * sizeof(float));
   double *redA = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
   double *redB = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
@@ -1126,28 +1195,76 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   // no-op on x (alpha = 0).
   int polled_it = -1;                     // iteration whose poll is in flight (-1: none)
   CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f};
-  for (it = 0; it < n_iter; ++it) {
+  // Graph form: RPGP_CG_GRAPH=1, unsharded solves of the operators whose product is plain launches on the stream (the cached
+  // dense product allocates its slabs stream-ordered and stays in the queue-ahead form).
+  const bool graph_form = graph_mode_ref() != 0 && sh.mode == RPGP_SHARD_NONE && n_iter > 2 &&
+                          (op->kind == RPGP_OP_FUSED || op->kind == RPGP_OP_FUSED_PREPARED || op->kind == RPGP_OP_SYMCACHE ||
+                           op->kind == RPGP_OP_SKI || op->kind == RPGP_OP_FAMILY);
+  // One iteration's launches.  gc == nullptr: the queue-ahead form — everything that depends on `it` is a kernel argument.
+  // gc != nullptr: the graph form — the same launches with nothing iteration-dependent in them (CgGraphCtl), so that the
+  // sequence can be captured once and replayed.
+  auto enqueue_iteration = [&](int it, const CgGraphCtl *gc) -> int {
     int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
-    float *pb_new = partB[it & 1];        // (ping-pong kept: the set-up pass B's slabs live in partB[1] until iteration 0 has read redB)
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, partA, N, K));
+    float *pb_new = partB[gc ? 0 : (it & 1)];   // (ping-pong kept: the set-up pass B's slabs live in partB[1] until iteration 0 has read redB)
+    int *tick = graph_form ? &state->it : (int *)nullptr;      // (the graph form counts its iterations on the device)
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, partA, N, K, tick));
     CG_REDUCE(partA, redA, nba);
-    const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
+    const int slot = gc ? 0 : (it < hist_len ? it : kMaxHist);      // history row (the last row is a scratch slot)
     const bool hist_pending = it < n_hist - 1;
-    const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
+    const bool check_now = !gc && it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
     CgPoll *poll_dst = check_now ? g_poll.host_dev + (it % kPollRing) : (CgPoll *)nullptr;
-    if (check_now) *reinterpret_cast<volatile int *>(&hpoll[it % kPollRing].seq) = 0;      // (stale stamp of an earlier solve)
+    const int cur = gc ? 0 : (it & 1), count = gc ? 0 : it + 1;
     if (direct) {
       CG_PASS_B(true, p, Ap, x, r, z, L, Cinv, redA, redB, pb_new, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2,
-                eps, stop_after, it & 1, 0, partA, nba, nil, 0);
-      CG_PASS_C(true, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
-                it + 1, stagnation_window, x, x_best, poll_dst, pb_new, nbb, redB);
+                eps, stop_after, cur, 0, partA, nba, nil, 0, gc);
+      CG_PASS_C(true, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, cur, 0, check_now ? 1 : 0, tolerance,
+                count, stagnation_window, x, x_best, poll_dst, pb_new, nbb, redB, gc);
     } else {
       CG_PASS_B(false, p, Ap, x, r, z, L, Cinv, redA, redB, pb_new, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2,
-                eps, stop_after, it & 1, 0, nil, 0, nil, 0);
+                eps, stop_after, cur, 0, nil, 0, nil, 0, gc);
       CG_REDUCE(pb_new, redB, nbb);
-      CG_PASS_C(false, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, it & 1, 0, check_now ? 1 : 0, tolerance,
-                it + 1, stagnation_window, x, x_best, poll_dst, nil, 0);
+      CG_PASS_C(false, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, cur, 0, check_now ? 1 : 0, tolerance,
+                count, stagnation_window, x, x_best, poll_dst, nil, 0, (double *)nullptr, gc);
+    }
+    return (int)hipGetLastError();
+  };
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  struct GraphGuard {                     // (every return path below destroys what was instantiated)
+    hipGraph_t &g;
+    hipGraphExec_t &e;
+    ~GraphGuard() {
+      if (e) (void)hipGraphExecDestroy(e);
+      if (g) (void)hipGraphDestroy(g);
+    }
+  } graph_guard{graph, gexec};
+  if (graph_form) {
+    CgGraphCtl hc;
+    hc.hist_len = hist_len; hc.n_hist = n_hist; hc.min_it = min_it; hc.check_every = check_every; hc.n_iter = n_iter;
+    hc.alpha_base = alpha_d; hc.beta_base = beta_d; hc.poll_base = g_poll.host_dev;
+    hc.partB[0] = partB[0]; hc.partB[1] = partB[1];
+    CG_CHECK(hipMemcpyAsync(gctl, &hc, sizeof(hc), hipMemcpyHostToDevice, st));      // (pageable source: staged before the call returns)
+  }
+  for (it = 0; it < n_iter; ++it) {
+    const bool hist_pending = it < n_hist - 1;
+    const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
+    if (check_now) *reinterpret_cast<volatile int *>(&hpoll[it % kPollRing].seq) = 0;      // (stale stamp of an earlier solve)
+    if (graph_form && it > 0) {
+      // iteration 0 went through plain launches (every one-time set-up of the operator's launch path — function attributes,
+      // lazily created tables — happens there, outside a capture); the same sequence is now captured once and replayed
+      if (!gexec) {
+        CG_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int crc = enqueue_iteration(it, gctl);
+        const hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (crc) return crc;
+        CG_CHECK(ce);
+        CG_CHECK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+      }
+      CG_CHECK(hipGraphLaunch(gexec, st));
+    } else {
+      const int rc = enqueue_iteration(it, nullptr);
+      if (rc) return rc;
     }
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
       if (!wait_record(&hpoll[polled_it % kPollRing], polled_it + 1, kPollSpinUs)) CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));

@@ -532,6 +532,13 @@ def ski_grid_from_range(zmin, zmax, grid_size, device, weights=None):
     return gp
 
 
+def mbcg_graph_mode(mode=None):
+    """Graph form of the native mBCG executor (rpgp_mbcg_graph_mode): True = one captured iteration replayed as a hipGraph,
+    False = the queue-ahead form (default).  `mode=None` only queries.  Returns the previous setting."""
+    lib = _lib.load()
+    return bool(lib.rpgp_mbcg_graph_mode(-1 if mode is None else int(bool(mode))))
+
+
 def ski_chunk_mode(mode=None):
     """Which form of the planned SKI product runs (rpgp_ski_chunk_mode): False = the cell-sorted form (default), True = the
     chunked form of round 5 where the shape allows (opt-in: not faster at the C5 shape) — for plans built

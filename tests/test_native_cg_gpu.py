@@ -278,3 +278,47 @@ def test_consumer_side_reductions_are_bitwise_the_separate_launches(gpu_device, 
         assert it == outs[0][3]
         assert torch.equal(x, outs[0][0])
         assert np.array_equal(a, outs[0][1]) and np.array_equal(b, outs[0][2])
+
+
+@pytest.mark.parametrize("N,J,T,kind,precond", [(3000, 20, 11, "fused", True), (2500, 20, 1, "fused", False),
+                                                (4200, 20, 11, "symcache", True), (4000, 3, 11, "ski", True),
+                                                (20000, 3, 11, "ski", True)])
+def test_graph_form_is_bitwise_the_queue_ahead_form(gpu_device, monkeypatch, N, J, T, kind, precond):
+    """rpgp_mbcg_graph_mode(1): one captured iteration replayed as a hipGraph, the per-iteration quantities derived on the
+    device from the iteration counter.  Solutions, coefficient histories and iteration counts are
+    bit-identical to the queue-ahead form, with either reduction form, and the mode leaves nothing behind."""
+    from rpgp_amd import linear_cg as lcg, ops
+    from rpgp_amd.operators import SymCachedOperator
+    from rpgp_amd.precond import pivoted_cholesky, WoodburyPreconditioner
+    noise = 0.2
+    base, khat = _ops_pair(gpu_device, N, J, noise, kind == "ski", 1.0, seed=N + 7)
+    op = khat
+    if kind == "symcache":
+        op = SymCachedOperator(base.to_symcache(wide=True), base._scale, noise, diag_value=base._scale * base.num_projections)
+    rhs = torch.randn(N, T, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    pre = WoodburyPreconditioner(pivoted_cholesky(base._diagonal(), base._get_rows, 15), noise) if precond else None
+    nt = min(T, 10) if T > 1 else 0
+    kw = dict(n_tridiag=nt, tolerance=1e-4, max_iter=400, max_tridiag_iter=20, preconditioner=pre, operator=op)
+    if nt:
+        kw["lanczos"] = "history"
+    prev = ops.mbcg_graph_mode()
+    outs = []
+    try:
+        for graph, direct in ((False, "1"), (True, "1"), (True, "0"), (False, "0"), (True, "1")):
+            ops.mbcg_graph_mode(graph)
+            monkeypatch.setenv("RPGP_CG_DIRECT", direct)
+            before = lcg.stats.get("native_calls", 0)
+            res = lcg.linear_cg(op._matmul, rhs, **kw)
+            assert lcg.stats.get("native_calls", 0) == before + 1
+            x, hist = res if nt else (res, None)
+            outs.append((x.clone(), None if hist is None else (hist.alpha.copy(), hist.beta.copy()), lcg.stats["last_iterations"]))
+    finally:
+        ops.mbcg_graph_mode(prev)
+    assert outs[0][2] > 3                                       # (iterations beyond the first were replays)
+    for x, h, it in outs[1:]:
+        assert it == outs[0][2]
+        assert torch.equal(x, outs[0][0])
+        if h is not None:
+            assert np.array_equal(h[0], outs[0][1][0]) and np.array_equal(h[1], outs[0][1][1])
+    resid = (khat._matmul(outs[0][0]) - rhs).norm(dim=0) / rhs.norm(dim=0)
+    assert float(resid.max()) < 5e-3

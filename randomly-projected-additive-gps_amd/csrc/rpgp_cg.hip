@@ -859,6 +859,18 @@ struct PollCtx {
   }
 };
 thread_local PollCtx g_poll;
+struct GraphStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int init() {
+    if (s) return 0;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) s = nullptr;
+    return (int)e;
+  }
+};
+thread_local GraphStream g_gstream;
 
 // Wait for a record a kernel publishes into pinned memory (publish_poll): the host SPINS on the stamp — the record of a
 // 5 us pass arrives within microseconds of the pass finishing, where hipEventSynchronize / hipStreamSynchronize wake the
@@ -1200,10 +1212,24 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   const bool graph_form = graph_mode_ref() != 0 && sh.mode == RPGP_SHARD_NONE && n_iter > 2 &&
                           (op->kind == RPGP_OP_FUSED || op->kind == RPGP_OP_FUSED_PREPARED || op->kind == RPGP_OP_SYMCACHE ||
                            op->kind == RPGP_OP_SKI || op->kind == RPGP_OP_FAMILY);
+  // The legacy default stream (what PyTorch hands over unless a side stream is current) cannot be captured: the graph form then
+  // runs its iterations on a stream of its own, ordered behind the set-up and in front of k_unnormalise by two events.
+  hipStream_t ist = st;
+  void *istream = stream;
+  if (graph_form && st == nullptr) {
+    const int grc = g_gstream.init();
+    if (grc) return grc;
+    ist = g_gstream.s;
+    istream = reinterpret_cast<void *>(ist);
+    CG_CHECK(hipEventRecord(g_gstream.ev[0], st));
+    CG_CHECK(hipStreamWaitEvent(ist, g_gstream.ev[0], 0));
+  }
   // One iteration's launches.  gc == nullptr: the queue-ahead form — everything that depends on `it` is a kernel argument.
   // gc != nullptr: the graph form — the same launches with nothing iteration-dependent in them (CgGraphCtl), so that the
   // sequence can be captured once and replayed.
-  auto enqueue_iteration = [&](int it, const CgGraphCtl *gc) -> int {
+  auto enqueue_iteration = [&, ist, istream](int it, const CgGraphCtl *gc) -> int {
+    hipStream_t st = ist;                 // (the launch macros name `st` / `stream`: the iterations' stream inside this lambda)
+    void *stream = istream;
     int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
     float *pb_new = partB[gc ? 0 : (it & 1)];   // (ping-pong kept: the set-up pass B's slabs live in partB[1] until iteration 0 has read redB)
@@ -1244,7 +1270,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
     hc.hist_len = hist_len; hc.n_hist = n_hist; hc.min_it = min_it; hc.check_every = check_every; hc.n_iter = n_iter;
     hc.alpha_base = alpha_d; hc.beta_base = beta_d; hc.poll_base = g_poll.host_dev;
     hc.partB[0] = partB[0]; hc.partB[1] = partB[1];
-    CG_CHECK(hipMemcpyAsync(gctl, &hc, sizeof(hc), hipMemcpyHostToDevice, st));      // (pageable source: staged before the call returns)
+    CG_CHECK(hipMemcpyAsync(gctl, &hc, sizeof(hc), hipMemcpyHostToDevice, ist));     // (pageable source: staged before the call returns)
   }
   for (it = 0; it < n_iter; ++it) {
     const bool hist_pending = it < n_hist - 1;
@@ -1254,14 +1280,14 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
       // iteration 0 went through plain launches (every one-time set-up of the operator's launch path — function attributes,
       // lazily created tables — happens there, outside a capture); the same sequence is now captured once and replayed
       if (!gexec) {
-        CG_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        CG_CHECK(hipStreamBeginCapture(ist, hipStreamCaptureModeThreadLocal));
         const int crc = enqueue_iteration(it, gctl);
-        const hipError_t ce = hipStreamEndCapture(st, &graph);
+        const hipError_t ce = hipStreamEndCapture(ist, &graph);
         if (crc) return crc;
         CG_CHECK(ce);
         CG_CHECK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
       }
-      CG_CHECK(hipGraphLaunch(gexec, st));
+      CG_CHECK(hipGraphLaunch(gexec, ist));
     } else {
       const int rc = enqueue_iteration(it, nullptr);
       if (rc) return rc;
@@ -1276,9 +1302,13 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
       }
     }
     if (check_now) {
-      CG_CHECK(hipEventRecord(g_poll.ev[it % kPollRing], st));
+      CG_CHECK(hipEventRecord(g_poll.ev[it % kPollRing], ist));
       polled_it = it;
     }
+  }
+  if (ist != st) {                        // (back on the caller's stream behind the last iteration)
+    CG_CHECK(hipEventRecord(g_gstream.ev[1], ist));
+    CG_CHECK(hipStreamWaitEvent(st, g_gstream.ev[1], 0));
   }
 #undef CG_REDUCE
 #undef CG_PASS_B

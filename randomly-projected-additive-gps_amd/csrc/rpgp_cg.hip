@@ -47,6 +47,8 @@ constexpr int kMaxBlocks = 1024;   // workgroups of the streaming passes (= part
 constexpr int kMaxHist = 64;       // Lanczos coefficients kept for at most this many iterations
 constexpr int kRedW = 288;         // reduction vector: [16 col sums a][16 col sums b][16 x 16 L^T X]
 constexpr int kRedLt = 32;         // offset of the L^T X block
+static_assert(kRedW == rpgp_internal::kCgRedW && kRedLt == rpgp_internal::kCgRedLt && kMaxK == rpgp_internal::kCgMaxK,
+              "slab format shared with the operator kernels that fold pass A (rpgp_internal.h)");
 constexpr int kPollRingDev = 4;    // poll records in flight (= kPollRing of the host side)
 
 typedef float floatx4m __attribute__((ext_vector_type(4)));
@@ -334,6 +336,9 @@ __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, con
   if (threadIdx.x < 16) dst[16 + threadIdx.x] = 0.f;
   block_ltsum(lt, sh, dst + kRedLt, ln);
 }
+
+// the graph form's iteration counter when pass A is folded into the operator (nothing else advances it then)
+__global__ void k_tick(int *tick) { *tick = *tick + 1; }
 
 // red[e] = sum over the slabs of part[.][e] in float64, fixed order: workgroup b owns entries 8 b .. 8 b + 7, its 32
 // thread groups take every 32nd slab (8 independent loads in flight) and the 32 group sums are added in order.
@@ -1209,6 +1214,11 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f};
   // Graph form: RPGP_CG_GRAPH=1, unsharded solves of the operators whose product is plain launches on the stream (the cached
   // dense product allocates its slabs stream-ordered and stays in the queue-ahead form).
+  // RPGP_CG_FOLD_A=0 keeps the separate pass A everywhere (A/B measurements, tests)
+  const char *env_fold = getenv("RPGP_CG_FOLD_A");
+  const bool fold_env = !(env_fold && env_fold[0] == '0');
+  const bool fold_pass_a = fold_env && !direct && sh.mode == RPGP_SHARD_NONE && op->kind == RPGP_OP_SKI && op->prep && T > 8 &&
+                           T <= 12 && op->noise != 0.f && op->N >= 32768;
   const bool graph_form = graph_mode_ref() != 0 && sh.mode == RPGP_SHARD_NONE && n_iter > 2 &&
                           (op->kind == RPGP_OP_FUSED || op->kind == RPGP_OP_FUSED_PREPARED || op->kind == RPGP_OP_SYMCACHE ||
                            op->kind == RPGP_OP_SKI || op->kind == RPGP_OP_FAMILY);
@@ -1230,12 +1240,23 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   auto enqueue_iteration = [&, ist, istream](int it, const CgGraphCtl *gc) -> int {
     hipStream_t st = ist;                 // (the launch macros name `st` / `stream`: the iterations' stream inside this lambda)
     void *stream = istream;
-    int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
+    // pass A folded into the operator's last kernel where that kernel offers it (round 5: the LDS gather of the planned SKI
+    // product): the operator then leaves `folded` slabs in partA and pass A is not launched
+    int rc, folded = 0;
+    if (fold_pass_a)
+      rc = rpgp_internal::ski_mvm_planned_passa(op->prep, op->Z, op->grid_params, p, Ap, op->N, op->ldz, op->J, op->G, T, op->scale,
+                                                op->noise, op_ws, op_ws_bytes, st, L, K, partA, &folded);
+    else
+      rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
     float *pb_new = partB[gc ? 0 : (it & 1)];   // (ping-pong kept: the set-up pass B's slabs live in partB[1] until iteration 0 has read redB)
     int *tick = graph_form ? &state->it : (int *)nullptr;      // (the graph form counts its iterations on the device)
-    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, partA, N, K, tick));
-    CG_REDUCE(partA, redA, nba);
+    if (!folded) {
+      CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, partA, N, K, tick));
+    } else if (tick) {
+      hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, st, tick);
+    }
+    CG_REDUCE(partA, redA, folded ? folded : nba);
     const int slot = gc ? 0 : (it < hist_len ? it : kMaxHist);      // history row (the last row is a scratch slot)
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = !gc && it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);

@@ -475,11 +475,17 @@ __device__ __forceinline__ int quad_bcast_i(int x) {
   return __builtin_amdgcn_update_dpp(0, x, Q * 0x55, 0xf, 0xf, true);
 }
 
-template <int CPL, int U>
+// PASSA (round 5): the executor's pass A — partial p . Ap per column and partial L^T (Ap) — accumulated here, where Ap is
+// formed and p (= V) is already in registers for the noise term: the workgroup leaves one slab of the executor's reduction
+// format (csrc/rpgp_cg.hip, k_pass_a: [16 column sums][16 zeros][16 x 16 L^T Ap]) and the separate pass over p, Ap and L
+// (11 us per iteration at the C5 shape) is not launched.  Fixed summation order: per lane over its rows, the sixteen rows of a
+// wave step by xor shuffles, the sixteen waves in order.
+template <int CPL, int U, bool PASSA = false>
 __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
                                                               const float *__restrict__ H, const float *__restrict__ V,
                                                               float *__restrict__ out, long long M, int ldz, int J, int G, int T,
-                                                              float scale, float noise) {
+                                                              float scale, float noise, const float *__restrict__ Lp = nullptr,
+                                                              int K = 0, float *__restrict__ partA = nullptr) {
   extern __shared__ float sH[];              // [J][G][T]
   const int nH = J * G * T;
   // float4 granules, 16 independent 16-byte loads per thread in flight (the launcher takes this kernel only when
@@ -504,6 +510,14 @@ __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__res
   int colc[CPL];
 #pragma unroll
   for (int r = 0; r < CPL; ++r) colc[r] = (c + 4 * r < T) ? c + 4 * r : 0;
+  constexpr int KA = PASSA ? rpgp_internal::kCgMaxK : 1;
+  float pa_dot[CPL], pa_lt[KA][CPL];
+#pragma unroll
+  for (int r = 0; r < CPL; ++r) {
+    pa_dot[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KA; ++kk) pa_lt[kk][r] = 0.f;
+  }
   __syncthreads();
   for (long long q0 = gw * U; q0 < groups; q0 += nw * U) {
     float zc[U], vin[U][CPL];
@@ -548,10 +562,62 @@ __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__res
         one(j0 + 3, quad_bcast_i<3>(idx_mine), quad_bcast<3>(w[0]), quad_bcast<3>(w[1]), quad_bcast<3>(w[2]), quad_bcast<3>(w[3]));
       }
       if (live) {
+        float o[CPL];
 #pragma unroll
-        for (int r = 0; r < CPL; ++r)
-          if (c + 4 * r < T) out[p * T + c + 4 * r] = __builtin_fmaf(noise, vin[u][r], scale * (float)acc[r]);
+        for (int r = 0; r < CPL; ++r) {
+          o[r] = __builtin_fmaf(noise, vin[u][r], scale * (float)acc[r]);
+          if (c + 4 * r < T) out[p * T + c + 4 * r] = o[r];
+          else o[r] = 0.f;
+        }
+        if constexpr (PASSA) {
+#pragma unroll
+          for (int r = 0; r < CPL; ++r) pa_dot[r] = __builtin_fmaf(vin[u][r], o[r], pa_dot[r]);
+#pragma unroll
+          for (int kk = 0; kk < KA; ++kk) {
+            const float lv = Lp[p * K + (kk < K ? kk : 0)];
+            const float lm = kk < K ? lv : 0.f;
+#pragma unroll
+            for (int r = 0; r < CPL; ++r) pa_lt[kk][r] = __builtin_fmaf(lm, o[r], pa_lt[kk][r]);
+          }
+        }
       }
+    }
+  }
+  if constexpr (PASSA) {
+    // the 16 rows of a wave step (lanes with the same c), then the 16 waves through the (no longer needed) image of H
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) {
+        pa_dot[r] += __shfl_xor(pa_dot[r], off, 64);
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) pa_lt[kk][r] += __shfl_xor(pa_lt[kk][r], off, 64);
+      }
+    }
+    __syncthreads();                           // (every wave is done with sH)
+    float *sw = sH;                            // [16 waves][17][16]: row 0 = column sums, rows 1 .. 16 = L^T Ap
+    const int wave = threadIdx.x >> 6;
+    if (pg == 0) {
+#pragma unroll
+      for (int r = 0; r < CPL; ++r) {
+        const int col = c + 4 * r;             // < 16
+        sw[(wave * 17 + 0) * 16 + col] = pa_dot[r];
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) sw[(wave * 17 + 1 + kk) * 16 + col] = pa_lt[kk][r];
+      }
+    }
+    __syncthreads();
+    float *dst = partA + (size_t)blockIdx.x * rpgp_internal::kCgRedW;
+    for (int e = threadIdx.x; e < rpgp_internal::kCgRedW; e += 1024) {
+      float v = 0.f;
+      const int row = e < 16 ? 0 : (e >= rpgp_internal::kCgRedLt ? 1 + (e - rpgp_internal::kCgRedLt) / 16 : -1);
+      const int col = e & 15;
+      if (row >= 0 && col < 4 * CPL && row <= KA) {
+        float acc = sw[(0 * 17 + row) * 16 + col];
+        for (int w = 1; w < 16; ++w) acc += sw[(w * 17 + row) * 16 + col];
+        v = acc;
+      }
+      dst[e] = v;
     }
   }
 }
@@ -1171,8 +1237,15 @@ int gather_chunked(const PlanView &pv, const float *H, const float *V, float *ou
 
 constexpr size_t kGatherLdsMax = 150 * 1024;
 
+struct GatherPassA {                         // the executor's pass A folded into the gather (see ski_gather_lds_kernel<.., PASSA>)
+  const float *L;
+  int K;
+  float *partA;
+  int nparts;                                // out: slabs written (0: not folded)
+};
 int gather_planned(const PlanView *pv, const float *Z, const float *gp, const float *H, const float *V, float *out, long long M,
-                   int ldz, int J, int G, int T, float scale, float noise, hipStream_t st) {
+                   int ldz, int J, int G, int T, float scale, float noise, hipStream_t st, GatherPassA *pa = nullptr) {
+  if (pa) pa->nparts = 0;
   if (pv && pv->nch > 0 && chunk_env_on() && T <= 12 && (V || noise == 0.f) && chunked_plans().has(pv->base))
     return gather_chunked(*pv, H, V, out, M, J, G, T, scale, noise, st);
   const size_t lds = (size_t)J * G * T * sizeof(float);
@@ -1191,6 +1264,19 @@ int gather_planned(const PlanView *pv, const float *Z, const float *gp, const fl
     }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (pa && T > 8 && noise != 0.f && V && pa->K >= 0 && pa->K <= rpgp_internal::kCgMaxK &&
+        lds >= (size_t)16 * 17 * 16 * sizeof(float)) {
+      static bool pa_attr = false;
+      if (!pa_attr)
+        pa_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ski_gather_lds_kernel<3, 2, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatherLdsMax) == hipSuccess;
+      if (pa_attr) {
+        hipLaunchKernelGGL((ski_gather_lds_kernel<3, 2, true>), dim3((unsigned)cus), dim3(1024), lds, st, Z, gp, H, V, out, M, ldz, J,
+                           G, T, scale, noise, pa->L, pa->K, pa->partA);
+        pa->nparts = cus;
+        return launch_status();
+      }
+    }
     if (T <= 4)
       hipLaunchKernelGGL((ski_gather_lds_kernel<1, 4>), dim3((unsigned)cus), dim3(1024), lds, st, Z, gp, H, V, out, M, ldz, J, G, T, scale, noise);
     else if (T <= 8)
@@ -1369,6 +1455,33 @@ int rpgp_ski_mvm_planned(const void *plan, const float *Z, const float *grid_par
   if (rc) return rc;
   return gather_planned(&pv, Z, grid_params, H, V, out, N, ldz, J, G, T, scale, noise, st);
 }
+
+}  // extern "C"
+
+namespace rpgp_internal {
+int ski_mvm_planned_passa(const void *plan, const float *Z, const float *grid_params, const float *V, float *out, long long N,
+                          int ldz, int J, int G, int T, float scale, float noise, void *workspace, size_t workspace_bytes,
+                          hipStream_t st, const float *L, int K, float *partA, int *nparts) {
+  *nparts = 0;
+  if (!plan || !Z || !grid_params || !V || !out || !plan_args_ok(N, J, G) || T <= 0 || T > 12 || ldz < J) return RPGP_EINVAL;
+  if (!workspace || workspace_bytes < rpgp_ski_workspace_bytes(J, G, T)) return RPGP_EWORKSPACE;
+  if ((size_t)max_items(N, J, G) * 48 > ski_scratch_floats(J, G)) return RPGP_EWORKSPACE;
+  const PlanView pv = plan_view(const_cast<void *>(plan), N, J, G);
+  double *hist = reinterpret_cast<double *>(workspace);
+  float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * (2 * T);
+  float *partial = reinterpret_cast<float *>(workspace) + ski_scratch_offset_floats(J, G, T);
+  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st);
+  if (rc) return rc;
+  rc = ski_toeplitz_launch(hist, 1, grid_params, H, J, G, T, st, pv.tcol);
+  if (rc) return rc;
+  GatherPassA pa{L, K, partA, 0};
+  rc = gather_planned(&pv, Z, grid_params, H, V, out, N, ldz, J, G, T, scale, noise, st, (L || K == 0) ? &pa : nullptr);
+  *nparts = pa.nparts;
+  return rc;
+}
+}  // namespace rpgp_internal
+
+extern "C" {
 
 int rpgp_ski_gather_fast(const void *plan, const float *Z, const float *grid_params, const float *H, const float *V, float *out,
                          int64_t M, int ldz, int J, int G, int T, float scale, float noise, void *stream) {

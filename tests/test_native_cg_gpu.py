@@ -322,3 +322,30 @@ def test_graph_form_is_bitwise_the_queue_ahead_form(gpu_device, monkeypatch, N, 
             assert np.array_equal(h[0], outs[0][1][0]) and np.array_equal(h[1], outs[0][1][1])
     resid = (khat._matmul(outs[0][0]) - rhs).norm(dim=0) / rhs.norm(dim=0)
     assert float(resid.max()) < 5e-3
+
+
+def test_pass_a_folded_into_the_ski_gather_solves_the_same_system(gpu_device, monkeypatch):
+    """Round 5: at N >= 32 768 the executor's pass A (p . Ap, L^T Ap) is accumulated by the SKI gather kernel instead of a pass of
+    its own (RPGP_CG_FOLD_A=0 restores the separate pass).  Another partition of the same sums: the two solves agree to
+    rounding, stop within an iteration of each other, and both are bitwise reproducible."""
+    from rpgp_amd import linear_cg as lcg
+    from rpgp_amd.precond import pivoted_cholesky, WoodburyPreconditioner
+    N, J, noise = 50000, 3, 0.2
+    base, khat = _ops_pair(gpu_device, N, J, noise, True, 1.0, seed=5)
+    rhs = torch.randn(N, 11, generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    pre = WoodburyPreconditioner(pivoted_cholesky(base._diagonal(), base._get_rows, 15), noise)
+    kw = dict(n_tridiag=10, tolerance=1e-4, max_iter=500, max_tridiag_iter=20, preconditioner=pre, operator=khat, lanczos="history")
+    outs = []
+    for env in ("1", "0", "1", "0"):
+        monkeypatch.setenv("RPGP_CG_FOLD_A", env)
+        x, hist = lcg.linear_cg(khat._matmul, rhs, **kw)
+        outs.append((x.clone(), hist.alpha.copy(), hist.beta.copy(), lcg.stats["last_iterations"]))
+    assert torch.equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1]) and outs[0][3] == outs[2][3]
+    assert torch.equal(outs[1][0], outs[3][0]) and outs[1][3] == outs[3][3]
+    assert abs(outs[0][3] - outs[1][3]) <= 1
+    assert float((outs[0][0] - outs[1][0]).norm() / outs[1][0].norm()) < 1e-4
+    n = min(len(outs[0][1]), len(outs[1][1]), 5)
+    assert np.allclose(outs[0][1][:n], outs[1][1][:n], rtol=1e-4, atol=1e-6)
+    for x, _, _, _ in outs[:2]:
+        resid = (khat._matmul(x) - rhs).norm(dim=0) / rhs.norm(dim=0)
+        assert float(resid.max()) < 5e-3

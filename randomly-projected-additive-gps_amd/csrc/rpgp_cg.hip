@@ -1214,9 +1214,11 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f};
   // Graph form: RPGP_CG_GRAPH=1, unsharded solves of the operators whose product is plain launches on the stream (the cached
   // dense product allocates its slabs stream-ordered and stays in the queue-ahead form).
-  // RPGP_CG_FOLD_A=0 keeps the separate pass A everywhere (A/B measurements, tests)
+  // RPGP_CG_FOLD_A=1 (opt-in): measured at the C5 shape the gather with pass A folded in takes 31 us against 19 + 11 us for the
+  // two kernels — the L^T Ap sums on the vector units cost what re-reading p and Ap saved: 2 % per
+  // iteration from the launch boundary alone
   const char *env_fold = getenv("RPGP_CG_FOLD_A");
-  const bool fold_env = !(env_fold && env_fold[0] == '0');
+  const bool fold_env = env_fold && env_fold[0] == '1';
   const bool fold_pass_a = fold_env && !direct && sh.mode == RPGP_SHARD_NONE && op->kind == RPGP_OP_SKI && op->prep && T > 8 &&
                            T <= 12 && op->noise != 0.f && op->N >= 32768;
   const bool graph_form = graph_mode_ref() != 0 && sh.mode == RPGP_SHARD_NONE && n_iter > 2 &&

@@ -533,6 +533,27 @@ __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__res
     for (int u = 0; u < U; ++u) {
       const long long p = (q0 + u) * 16 + pg;
       const bool live = q0 + u < groups && p < M;
+      // pass A: the row of L is requested here, at the head of the group's tap reads (asked for where it is used, the four
+      // requests of every group were a round trip with nothing to hide behind: 31 us for the kernel)
+      float lrow[KA];
+      if constexpr (PASSA) {
+        const long long pl = live ? p : 0;
+        if (K == 15) {                         // the reference's preconditioner rank: the row as four 16-byte requests
+          typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+          const float *lp = Lp + pl * 15;
+          const f4u a = *reinterpret_cast<const f4u *>(lp), b = *reinterpret_cast<const f4u *>(lp + 4);
+          const f4u d = *reinterpret_cast<const f4u *>(lp + 8), e = *reinterpret_cast<const f4u *>(lp + 11);
+          lrow[0] = a.x; lrow[1] = a.y; lrow[2] = a.z; lrow[3] = a.w; lrow[4] = b.x; lrow[5] = b.y; lrow[6] = b.z; lrow[7] = b.w;
+          lrow[8] = d.x; lrow[9] = d.y; lrow[10] = d.z; lrow[11] = e.x; lrow[12] = e.y; lrow[13] = e.z; lrow[14] = e.w;
+          if (KA > 15) lrow[KA - 1] = 0.f;
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < KA; ++kk) {
+            const float lv = Lp[pl * K + (kk < K ? kk : 0)];
+            lrow[kk] = kk < K ? lv : 0.f;
+          }
+        }
+      }
       double acc[CPL];
 #pragma unroll
       for (int r = 0; r < CPL; ++r) acc[r] = 0.0;
@@ -573,12 +594,9 @@ __global__ __launch_bounds__(1024) void ski_gather_lds_kernel(const float *__res
 #pragma unroll
           for (int r = 0; r < CPL; ++r) pa_dot[r] = __builtin_fmaf(vin[u][r], o[r], pa_dot[r]);
 #pragma unroll
-          for (int kk = 0; kk < KA; ++kk) {
-            const float lv = Lp[p * K + (kk < K ? kk : 0)];
-            const float lm = kk < K ? lv : 0.f;
+          for (int kk = 0; kk < KA; ++kk)
 #pragma unroll
-            for (int r = 0; r < CPL; ++r) pa_lt[kk][r] = __builtin_fmaf(lm, o[r], pa_lt[kk][r]);
-          }
+            for (int r = 0; r < CPL; ++r) pa_lt[kk][r] = __builtin_fmaf(lrow[kk], o[r], pa_lt[kk][r]);
         }
       }
     }
@@ -1268,10 +1286,10 @@ int gather_planned(const PlanView *pv, const float *Z, const float *gp, const fl
         lds >= (size_t)16 * 17 * 16 * sizeof(float)) {
       static bool pa_attr = false;
       if (!pa_attr)
-        pa_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ski_gather_lds_kernel<3, 2, true>),
+        pa_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ski_gather_lds_kernel<3, 1, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatherLdsMax) == hipSuccess;
       if (pa_attr) {
-        hipLaunchKernelGGL((ski_gather_lds_kernel<3, 2, true>), dim3((unsigned)cus), dim3(1024), lds, st, Z, gp, H, V, out, M, ldz, J,
+        hipLaunchKernelGGL((ski_gather_lds_kernel<3, 1, true>), dim3((unsigned)cus), dim3(1024), lds, st, Z, gp, H, V, out, M, ldz, J,
                            G, T, scale, noise, pa->L, pa->K, pa->partA);
         pa->nparts = cus;
         return launch_status();

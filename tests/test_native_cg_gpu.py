@@ -325,9 +325,9 @@ def test_graph_form_is_bitwise_the_queue_ahead_form(gpu_device, monkeypatch, N, 
 
 
 def test_pass_a_folded_into_the_ski_gather_solves_the_same_system(gpu_device, monkeypatch):
-    """Round 5: at N >= 32 768 the executor's pass A (p . Ap, L^T Ap) is accumulated by the SKI gather kernel instead of a pass of
-    its own (RPGP_CG_FOLD_A=0 restores the separate pass).  Another partition of the same sums: the two solves agree to
-    rounding, stop within an iteration of each other, and both are bitwise reproducible."""
+    """Round 5 (opt-in, RPGP_CG_FOLD_A=1): at N >= 32 768 the executor's pass A (p . Ap, L^T Ap) accumulated by the SKI gather
+    kernel instead of a pass of its own.  Another partition of the same sums: the two solves agree to rounding, stop within an
+    iteration of each other, and both are bitwise reproducible."""
     from rpgp_amd import linear_cg as lcg
     from rpgp_amd.precond import pivoted_cholesky, WoodburyPreconditioner
     N, J, noise = 50000, 3, 0.2

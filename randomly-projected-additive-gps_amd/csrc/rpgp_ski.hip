@@ -40,10 +40,11 @@ inline int launch_status() { return (int)hipGetLastError(); }
 
 // ---- plan layout -------------------------------------------------------------------------------------------------------
 struct PlanView {
-  int *perm;           // [N * J]  point index of the s-th entry in (projection, cell, point) order
-  float4 *wsort;       // [N * J]  its 4 tap weights
-  float4 *wnat;        // [N][J]   tap weights in point order (the gather reads them instead of re-deriving the stencil)
-  int *inat;           // [N][J]   first tap index in point order
+  int2 *rec;           // [N * J]  (point index, tap fraction as bits) of the s-th entry in (projection, cell, point) order:
+                       //          ONE 8-byte record per entry (rounds 3 - 4: a 4-byte index and a 16-byte weight record,
+                       //          20 of the 64 bytes a scattered row cost); the four weights are re-derived from the fraction
+                       //          by the arithmetic that produced them (ski_weights_of_frac: same bits)
+  float *fnat;         // [N][J]   tap fraction in point order (plan construction only)
   int *cell_start;     // [J * G + 1]  first entry of cell (j, c);  cell = index of the first tap, 0 .. G - 4
   int *item_start;     // [J * G + 1]  first scatter item of the cell (exclusive scan of ceil(count / kSeg))
   int2 *item_info;     // [max_items]  (first sorted entry, number of points) of every scatter item
@@ -115,10 +116,8 @@ inline PlanView plan_view(void *base, long long N, int J, int G) {
   v.base = base;
   char *p = reinterpret_cast<char *>(base);
   const size_t nj = (size_t)N * J, cells = (size_t)J * G + 1, G16 = (size_t)((G + 15) & ~15);
-  v.perm = reinterpret_cast<int *>(p); p += align256(nj * sizeof(int));
-  v.wsort = reinterpret_cast<float4 *>(p); p += align256(nj * sizeof(float4));
-  v.wnat = reinterpret_cast<float4 *>(p); p += align256(nj * sizeof(float4));
-  v.inat = reinterpret_cast<int *>(p); p += align256(nj * sizeof(int));
+  v.rec = reinterpret_cast<int2 *>(p); p += align256(nj * sizeof(int2));
+  v.fnat = reinterpret_cast<float *>(p); p += align256(nj * sizeof(float));
   v.cell_start = reinterpret_cast<int *>(p); p += align256(cells * sizeof(int));
   v.item_start = reinterpret_cast<int *>(p); p += align256(cells * sizeof(int));
   v.item_info = reinterpret_cast<int2 *>(p); p += align256((size_t)max_items(N, J, G) * sizeof(int2));
@@ -145,19 +144,18 @@ inline long long max_items(long long N, int J, int G) { return (N * J + kSeg - 1
 // every (point, projection) in point order
 __global__ __launch_bounds__(256) void plan_keys_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
                                                         long long N, int ldz, int J, int G, unsigned *__restrict__ keys,
-                                                        unsigned *__restrict__ vals, float4 *__restrict__ wnat,
-                                                        int *__restrict__ inat) {
+                                                        unsigned *__restrict__ vals, float *__restrict__ fnat) {
   const long long total = N * J;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int j = (int)(e / N);
     const long long i = e - (long long)j * N;
-    float w[4], dw[4];
     const float *gj = ski_grid_of(gp, J, j);
-    const int idx0 = ski_taps<false>(Z[i * ldz + j], gj[0], gj[2], G, w, dw);
+    const float u = ski_grid_coord(Z[i * ldz + j], gj[0], gj[2], G);
+    float w[4], dw[4];
+    const int idx0 = ski_taps_u<false>(u, gj[2], G, w, dw);
     keys[e] = (unsigned)(j * G + idx0);
     vals[e] = (unsigned)e;
-    wnat[i * J + j] = make_float4(w[0], w[1], w[2], w[3]);
-    inat[i * J + j] = idx0;
+    fnat[i * J + j] = u - __builtin_floorf(u);               // (the fraction ski_taps_u derives the weights from)
   }
 }
 
@@ -213,14 +211,13 @@ __global__ __launch_bounds__(1024) void plan_items_kernel(const int *__restrict_
 // perm / tap weights in sorted order
 __global__ __launch_bounds__(256) void plan_finish_kernel(const unsigned *__restrict__ keys_sorted,
                                                           const unsigned *__restrict__ vals_sorted,
-                                                          const float4 *__restrict__ wnat, long long N, int J, int G,
-                                                          long long total, int *__restrict__ perm, float4 *__restrict__ wsort) {
+                                                          const float *__restrict__ fnat, long long N, int J, int G,
+                                                          long long total, int2 *__restrict__ rec) {
   for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < total; s += (long long)gridDim.x * 256) {
     const unsigned e = vals_sorted[s];
     const int j = (int)(keys_sorted[s] / (unsigned)G);
     const long long i = (long long)e - (long long)j * N;
-    perm[s] = (int)i;
-    wsort[s] = wnat[i * J + j];
+    rec[s] = make_int2((int)i, __builtin_bit_cast(int, fnat[i * J + j]));
   }
 }
 
@@ -232,7 +229,7 @@ __global__ __launch_bounds__(256) void plan_finish_kernel(const unsigned *__rest
 // every lane of a wave receives its own copy of a broadcast load), so the per-point records (index, 4 weights) are read by
 // 4 lanes per point, not 16: 8 KB of returned data per 64 points instead of 24 KB.
 template <int LPP, int CPL>
-__global__ __launch_bounds__(256) void ski_scatter_sorted_kernel(const int *__restrict__ perm, const float4 *__restrict__ wsort,
+__global__ __launch_bounds__(256) void ski_scatter_sorted_kernel(const int2 *__restrict__ rec,
                                                                  const int2 *__restrict__ item_info,
                                                                  const int *__restrict__ item_start, int cells,
                                                                  const float *__restrict__ V, float *__restrict__ partial,
@@ -255,23 +252,24 @@ __global__ __launch_bounds__(256) void ski_scatter_sorted_kernel(const int *__re
 #pragma unroll
     for (int r = 0; r < CPL; ++r) acc[k][r] = 0.f;
   if (cnt > 0) {
-    int pi[STEPS];
+    int2 pr[STEPS];
 #pragma unroll
     for (int m = 0; m < STEPS; ++m) {
       const int src = m * PPW + pg;
-      pi[m] = perm[s0 + (src < cnt ? src : 0)];
+      pr[m] = rec[s0 + (src < cnt ? src : 0)];
     }
     float v[STEPS][CPL];
     float4 w[STEPS];
 #pragma unroll
     for (int m = 0; m < STEPS; ++m) {
       const int src = m * PPW + pg;
-      w[m] = wsort[s0 + (src < cnt ? src : 0)];
+      const int pi_m = pr[m].x;
+      w[m] = ski_weights_of_frac(__builtin_bit_cast(float, pr[m].y));
 #pragma unroll
       for (int r = 0; r < CPL; ++r) {
         const int col = c + LPP * r;
         const bool ok = src < cnt && col < tcnt;
-        const float x = V[ok ? (size_t)pi[m] * T + t0 + col : 0];
+        const float x = V[ok ? (size_t)pi_m * T + t0 + col : 0];
         v[m][r] = ok ? x : 0.f;
       }
     }
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(256) void ski_scatter_sorted_kernel(const int *__re
 // lists.  Sums: per lane over the rounds, then the lanes of a wave (xor tree), then the four waves in order: fixed order,
 // bitwise reproducible.  Same lane layout as the item kernel.
 template <int LPP, int CPL>
-__global__ __launch_bounds__(256) void ski_scatter_cell_kernel(const int *__restrict__ perm, const float4 *__restrict__ wsort,
+__global__ __launch_bounds__(256) void ski_scatter_cell_kernel(const int2 *__restrict__ rec,
                                                                const int *__restrict__ cell_start, const float *__restrict__ V,
                                                                float *__restrict__ cellpart, int T, int t0, int tcnt) {
   constexpr int TT = LPP * CPL;
@@ -333,27 +331,27 @@ __global__ __launch_bounds__(256) void ski_scatter_cell_kernel(const int *__rest
 #pragma unroll
     for (int r = 0; r < CPL; ++r) acc[k][r] = 0.f;
   int base = sb + wave * 64;
-  int pin[STEPS];
+  int2 pin[STEPS];
   if (base < se) {
     const int cnt = se - base < 64 ? se - base : 64;
 #pragma unroll
     for (int m = 0; m < STEPS; ++m) {
       const int src = m * PPW + pg;
-      pin[m] = perm[base + (src < cnt ? src : 0)];
+      pin[m] = rec[base + (src < cnt ? src : 0)];
     }
   }
   for (; base < se; base += 256) {
     const int cnt = se - base < 64 ? se - base : 64;
-    int pi[STEPS];
+    int2 pi[STEPS];
 #pragma unroll
     for (int m = 0; m < STEPS; ++m) pi[m] = pin[m];
     const int nbase = base + 256;
-    if (nbase < se) {                          // next round's indices: in flight while this round's rows arrive
+    if (nbase < se) {                          // next round's records: in flight while this round's rows arrive
       const int ncnt = se - nbase < 64 ? se - nbase : 64;
 #pragma unroll
       for (int m = 0; m < STEPS; ++m) {
         const int src = m * PPW + pg;
-        pin[m] = perm[nbase + (src < ncnt ? src : 0)];
+        pin[m] = rec[nbase + (src < ncnt ? src : 0)];
       }
     }
     float v[STEPS][CPL];
@@ -361,14 +359,14 @@ __global__ __launch_bounds__(256) void ski_scatter_cell_kernel(const int *__rest
 #pragma unroll
     for (int m = 0; m < STEPS; ++m) {
       const int src = m * PPW + pg;
-      w[m] = wsort[base + (src < cnt ? src : 0)];
 #pragma unroll
       for (int r = 0; r < CPL; ++r) {
         const int col = c + LPP * r;
         const bool ok = src < cnt && col < tcnt;
-        const float x = V[ok ? (size_t)pi[m] * T + t0 + col : 0];
+        const float x = V[ok ? (size_t)pi[m].x * T + t0 + col : 0];
         v[m][r] = ok ? x : 0.f;
       }
+      w[m] = ski_weights_of_frac(__builtin_bit_cast(float, pi[m].y));      // (on the vector units, under the rows' latency)
     }
 #pragma unroll
     for (int m = 0; m < STEPS; ++m) {
@@ -1327,11 +1325,11 @@ int scatter_planned(const PlanView &pv, const float *V, double *hist, float *par
     const long long n = (long long)J * G * tt;
     if (by_cell) {
       if (tt == 1)
-        hipLaunchKernelGGL((ski_scatter_cell_kernel<1, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.perm, pv.wsort, pv.cell_start, V, partial, T, t0, tcnt);
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<1, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt);
       else if (tt == 4)
-        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.perm, pv.wsort, pv.cell_start, V, partial, T, t0, tcnt);
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt);
       else
-        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 3>), dim3((unsigned)cells), dim3(256), 0, st, pv.perm, pv.wsort, pv.cell_start, V, partial, T, t0, tcnt);
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 3>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt);
       int rc = launch_status();
       if (rc) return rc;
       hipLaunchKernelGGL(ski_cellsum4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, hist, J, G, tt, tcnt,
@@ -1342,11 +1340,11 @@ int scatter_planned(const PlanView &pv, const float *V, double *hist, float *par
       continue;
     }
     if (tt == 1)
-      hipLaunchKernelGGL((ski_scatter_sorted_kernel<1, 1>), dim3(nb), dim3(256), 0, st, pv.perm, pv.wsort, pv.item_info, pv.item_start, cells, V, partial, T, t0, tcnt);
+      hipLaunchKernelGGL((ski_scatter_sorted_kernel<1, 1>), dim3(nb), dim3(256), 0, st, pv.rec, pv.item_info, pv.item_start, cells, V, partial, T, t0, tcnt);
     else if (tt == 4)
-      hipLaunchKernelGGL((ski_scatter_sorted_kernel<4, 1>), dim3(nb), dim3(256), 0, st, pv.perm, pv.wsort, pv.item_info, pv.item_start, cells, V, partial, T, t0, tcnt);
+      hipLaunchKernelGGL((ski_scatter_sorted_kernel<4, 1>), dim3(nb), dim3(256), 0, st, pv.rec, pv.item_info, pv.item_start, cells, V, partial, T, t0, tcnt);
     else
-      hipLaunchKernelGGL((ski_scatter_sorted_kernel<4, 3>), dim3(nb), dim3(256), 0, st, pv.perm, pv.wsort, pv.item_info, pv.item_start, cells, V, partial, T, t0, tcnt);
+      hipLaunchKernelGGL((ski_scatter_sorted_kernel<4, 3>), dim3(nb), dim3(256), 0, st, pv.rec, pv.item_info, pv.item_start, cells, V, partial, T, t0, tcnt);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(ski_cellsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, pv.item_start, hist, J,
@@ -1398,7 +1396,7 @@ int rpgp_ski_plan(const float *Z, const float *grid_params, int64_t N, int ldz, 
   long long nblk = ((long long)nj + 255) / 256;
   if (nblk > 4096) nblk = 4096;
   hipLaunchKernelGGL(plan_keys_kernel, dim3((unsigned)nblk), dim3(256), 0, st, Z, grid_params, (long long)N, ldz, J, G, keys_in,
-                     vals_in, pv.wnat, pv.inat);
+                     vals_in, pv.fnat);
   int rc = launch_status();
   if (rc) return rc;
   int bits = 1;
@@ -1412,8 +1410,8 @@ int rpgp_ski_plan(const float *Z, const float *grid_params, int64_t N, int ldz, 
   hipLaunchKernelGGL(plan_starts_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, keys_out, (long long)nj,
                      cells, pv.cell_start, grid_params, G, pv.tcol);
   hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(1024), 0, st, pv.cell_start, cells, pv.item_start, pv.item_info);
-  hipLaunchKernelGGL(plan_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, keys_out, vals_out, pv.wnat, (long long)N, J, G,
-                     (long long)nj, pv.perm, pv.wsort);
+  hipLaunchKernelGGL(plan_finish_kernel, dim3((unsigned)nblk), dim3(256), 0, st, keys_out, vals_out, pv.fnat, (long long)N, J, G,
+                     (long long)nj, pv.rec);
   const bool chunked = pv.nch > 0 && chunk_env_on();
   chunked_plans().mark(plan, chunked);         // (a blob reused for a plan without the tables must not look chunked)
   if (chunked) {                               // chunk tables of the round-5 product (its kernels read nothing of the above)

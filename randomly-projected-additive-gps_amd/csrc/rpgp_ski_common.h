@@ -51,6 +51,11 @@ __device__ __forceinline__ int ski_taps_u(float u, float inv_h, int G, float (&w
   return idx0;
 }
 
+// the four tap weights from the tap fraction fr = u - floor(u): the arithmetic of ski_taps_u, so the same bits
+__device__ __forceinline__ float4 ski_weights_of_frac(float fr) {
+  return make_float4(cubic_w(fr + 1.0f), cubic_w(fr), cubic_w(1.0f - fr), cubic_w(2.0f - fr));
+}
+
 // taps idx0..idx0+3 and their weights for coordinate z; DERIV also returns d w_k / d z
 template <bool DERIV>
 __device__ __forceinline__ int ski_taps(float z, float g0, float inv_h, int G, float (&w)[4], float (&dw)[4]) {

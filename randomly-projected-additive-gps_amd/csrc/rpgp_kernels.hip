@@ -2756,10 +2756,15 @@ typedef double doublex4m __attribute__((ext_vector_type(4)));
 // One workgroup owns ONE 16-row output tile; its 4 waves split the grid points (the K loop) four ways and add their
 // partial tiles through LDS in a fixed order.  (The first version gave each wave its own tile and the whole K loop:
 // 64 dependent K-steps x 4 MFMAs per wave and only 16 J workgroups — 31 us of the 66 us SKI MVM at the C5 shape.)
-template <int NW>
+// CELLS (round 5): the B operand is formed from the cell-sorted scatter's per-cell tap records instead of being read from the
+// histogram — hist[j][g][t] = ((x0 + x1) + x2) + x3 with x_k = cellpart[cell (j, g - k)][k][t] in float64, the sums of
+// ski_cellsum4_kernel in its order (same bits) — so that the product needs no histogram pass between the scatter and this
+// kernel (a 5 us launch over 270 KB at the C5 shape).  TTc = floats per tap row of cellpart.
+template <int NW, bool CELLS = false>
 __global__ __launch_bounds__(64 * NW) void ski_toeplitz_mfma_kernel(const double *__restrict__ hist,
                                                                 const float *__restrict__ gp, float *__restrict__ H,
-                                                                int G, int T, const double *__restrict__ tcol) {
+                                                                int G, int T, const double *__restrict__ tcol,
+                                                                const float *__restrict__ cellpart = nullptr, int TTc = 0) {
   extern __shared__ double dmem[];          // sc[G16] | red[NW - 1][256]
   const int G16 = (G + 15) & ~15;
   double *sc = dmem;
@@ -2794,15 +2799,45 @@ __global__ __launch_bounds__(64 * NW) void ski_toeplitz_mfma_kernel(const double
   constexpr int SB = NW > 4 ? 4 : 8;
   for (int st0 = s_begin; st0 < s_end; st0 += SB) {
     double b[SB][4];
+    if constexpr (CELLS) {
+      float xq[SB][4][4];                                // (all 4 x 4 x SB requests together, clamped to valid records)
 #pragma unroll
-    for (int ss = 0; ss < SB; ++ss) {
+      for (int ss = 0; ss < SB; ++ss)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = (st0 + ss) * 16 + 4 * u + q;
-        const bool ok = k < G && st0 + ss < s_end;
-        const int kc = ok ? k : 0;
-        const double x = hj[(size_t)kc * T + nbc];
-        b[ss][u] = ok ? x * bmask : 0.0;
+        for (int u = 0; u < 4; ++u) {
+          const int k = (st0 + ss) * 16 + 4 * u + q;
+#pragma unroll
+          for (int tap = 0; tap < 4; ++tap) {
+            const int cc = k - tap;
+            const bool okc = k < G && st0 + ss < s_end && !(cc < 0 || cc > G - 4);
+            xq[ss][u][tap] = cellpart[(((size_t)j * G + (okc ? cc : 0)) * 4 + tap) * TTc + nbc];
+          }
+        }
+#pragma unroll
+      for (int ss = 0; ss < SB; ++ss)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = (st0 + ss) * 16 + 4 * u + q;
+          double x[4];
+#pragma unroll
+          for (int tap = 0; tap < 4; ++tap) {
+            const int cc = k - tap;
+            const bool okc = k < G && st0 + ss < s_end && !(cc < 0 || cc > G - 4);
+            x[tap] = okc ? (double)xq[ss][u][tap] : 0.0;
+          }
+          b[ss][u] = (((x[0] + x[1]) + x[2]) + x[3]) * bmask;
+        }
+    } else {
+#pragma unroll
+      for (int ss = 0; ss < SB; ++ss) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = (st0 + ss) * 16 + 4 * u + q;
+          const bool ok = k < G && st0 + ss < s_end;
+          const int kc = ok ? k : 0;
+          const double x = hj[(size_t)kc * T + nbc];
+          b[ss][u] = ok ? x * bmask : 0.0;
+        }
       }
     }
     if (st0 == s_begin) __syncthreads();              // sc[] is complete (the loads above are already in flight)
@@ -4946,7 +4981,7 @@ int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist
 }
 
 int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T, hipStream_t st,
-                 const double *tcol = nullptr) {
+                 const double *tcol = nullptr, const float *cellpart = nullptr, int TTc = 0) {
   if (!hist_is_double && T > 24) {
     dim3 grid((T + 63) / 64, (G + 15) / 16, J);
     hipLaunchKernelGGL(ski_toeplitz_wide_kernel, grid, dim3(256), (size_t)G * sizeof(float), st,
@@ -4961,6 +4996,15 @@ int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H
   const size_t lds = ((size_t)G16 + (size_t)(nw - 1) * 256) * sizeof(double);
   if (hist_is_double && T <= 64 && lds <= 64 * 1024) {        // matrix-core path, float64 (16 columns per workgroup)
     dim3 grid((G + 15) / 16, J, (T + 15) / 16);
+    if (cellpart && T <= 16) {                               // B operand straight from the scatter's per-cell tap records
+      if (wide_wg)
+        hipLaunchKernelGGL((ski_toeplitz_mfma_kernel<16, true>), grid, dim3(1024), lds, st, (const double *)nullptr, gp, H, G, T,
+                           tcol, cellpart, TTc);
+      else
+        hipLaunchKernelGGL((ski_toeplitz_mfma_kernel<4, true>), grid, dim3(256), lds, st, (const double *)nullptr, gp, H, G, T,
+                           tcol, cellpart, TTc);
+      return launch_status();
+    }
     if (wide_wg)
       hipLaunchKernelGGL(ski_toeplitz_mfma_kernel<16>, grid, dim3(1024), lds, st, reinterpret_cast<const double *>(hist), gp,
                          H, G, T, tcol);
@@ -5015,6 +5059,16 @@ namespace rpgp_internal {
 int ski_toeplitz_launch(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T,
                         hipStream_t st, const double *tcol) {
   return ski_toeplitz(hist, hist_is_double, gp, H, J, G, T, st, tcol);
+}
+bool ski_toeplitz_takes_cells(int J, int G, int T) {          // (the conditions of the matrix-core path above)
+  const int G16 = (G + 15) & ~15;
+  const bool wide_wg = (size_t)J * ((G + 15) / 16) <= 640 && G16 >= 256;
+  const size_t lds = ((size_t)G16 + (size_t)((wide_wg ? 16 : 4) - 1) * 256) * sizeof(double);
+  return T <= 16 && lds <= 64 * 1024;
+}
+int ski_toeplitz_cells_launch(const float *cellpart, int TTc, const float *gp, float *H, int J, int G, int T, hipStream_t st,
+                              const double *tcol) {
+  return ski_toeplitz(nullptr, 1, gp, H, J, G, T, st, tcol, cellpart, TTc);
 }
 int ski_gather_launch(const float *Z, const float *gp, const float *H, const float *V, float *out, long long M, int ldz,
                       int J, int G, int T, float scale, float noise, hipStream_t st) {

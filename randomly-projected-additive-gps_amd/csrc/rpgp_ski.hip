@@ -1307,8 +1307,11 @@ int gather_planned(const PlanView *pv, const float *Z, const float *gp, const fl
 inline int ski_tpiece(int remaining) { return remaining > 4 ? 12 : (remaining > 1 ? 4 : 1); }
 
 // hist[j][g][hoff .. hoff + T) (row stride HT, float64) from the plan; `partial` holds max_items * 4 * 12 floats
+// `cells_tt` != nullptr: the caller's Toeplitz stage forms the histogram from the tap records itself — when the whole block is
+// ONE column piece of the per-cell form, only the scatter runs and *cells_tt = the floats per tap row of `partial`; else 0.
 int scatter_planned(const PlanView &pv, const float *V, double *hist, float *partial, long long N, int J, int G, int T, int HT,
-                    int hoff, hipStream_t st) {
+                    int hoff, hipStream_t st, int *cells_tt = nullptr) {
+  if (cells_tt) *cells_tt = 0;
   if (pv.nch > 0 && chunk_env_on() && T <= 12 && chunked_plans().has(pv.base))
     return scatter_chunked(pv, V, hist, partial, N, J, G, T, HT, hoff, st);
   const int cells = J * G;
@@ -1332,6 +1335,10 @@ int scatter_planned(const PlanView &pv, const float *V, double *hist, float *par
         hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 3>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt);
       int rc = launch_status();
       if (rc) return rc;
+      if (cells_tt && t0 == 0 && tcnt == T) {              // one piece: the tap records go to the Toeplitz stage as they are
+        *cells_tt = tt;
+        return 0;
+      }
       hipLaunchKernelGGL(ski_cellsum4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, hist, J, G, tt, tcnt,
                          HT, hoff + t0);
       rc = launch_status();
@@ -1465,9 +1472,15 @@ int rpgp_ski_mvm_planned(const void *plan, const float *Z, const float *grid_par
   double *hist = reinterpret_cast<double *>(workspace);
   float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * (2 * T);
   float *partial = reinterpret_cast<float *>(workspace) + rpgp_internal::ski_scratch_offset_floats(J, G, T);
-  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st);
+  // the four-tap cell sums ride in the Toeplitz stage's operand load where that stage takes them (RPGP_SKI_CELLSUM=1: the
+  // separate histogram pass of rounds 3 - 4)
+  static const bool fold_cells = [] { const char *e = getenv("RPGP_SKI_CELLSUM"); return !(e && e[0] == '1'); }();
+  int cells_tt = 0;
+  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st,
+                           fold_cells && rpgp_internal::ski_toeplitz_takes_cells(J, G, T) ? &cells_tt : nullptr);
   if (rc) return rc;
-  rc = rpgp_internal::ski_toeplitz_launch(hist, 1, grid_params, H, J, G, T, st, pv.tcol);
+  rc = cells_tt ? rpgp_internal::ski_toeplitz_cells_launch(partial, cells_tt, grid_params, H, J, G, T, st, pv.tcol)
+                : rpgp_internal::ski_toeplitz_launch(hist, 1, grid_params, H, J, G, T, st, pv.tcol);
   if (rc) return rc;
   return gather_planned(&pv, Z, grid_params, H, V, out, N, ldz, J, G, T, scale, noise, st);
 }
@@ -1486,9 +1499,11 @@ int ski_mvm_planned_passa(const void *plan, const float *Z, const float *grid_pa
   double *hist = reinterpret_cast<double *>(workspace);
   float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * (2 * T);
   float *partial = reinterpret_cast<float *>(workspace) + ski_scratch_offset_floats(J, G, T);
-  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st);
+  int cells_tt = 0;
+  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st, ski_toeplitz_takes_cells(J, G, T) ? &cells_tt : nullptr);
   if (rc) return rc;
-  rc = ski_toeplitz_launch(hist, 1, grid_params, H, J, G, T, st, pv.tcol);
+  rc = cells_tt ? ski_toeplitz_cells_launch(partial, cells_tt, grid_params, H, J, G, T, st, pv.tcol)
+                : ski_toeplitz_launch(hist, 1, grid_params, H, J, G, T, st, pv.tcol);
   if (rc) return rc;
   GatherPassA pa{L, K, partA, 0};
   rc = gather_planned(&pv, Z, grid_params, H, V, out, N, ldz, J, G, T, scale, noise, st, (L || K == 0) ? &pa : nullptr);

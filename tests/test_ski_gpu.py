@@ -522,3 +522,21 @@ def test_planned_bilinear_derivative_matches_the_fused_one(gpu_device, N, J, T, 
     h_plan = ops.ski_bilinear_scatter(Z, op.gp, Lc, Rc, G, plan=plan).cpu().numpy()
     h_ref = ops.ski_bilinear_scatter(Z, op.gp, Lc, Rc, G).cpu().numpy()
     assert np.linalg.norm(h_plan - h_ref) <= 1e-6 * np.linalg.norm(h_ref)
+
+
+@pytest.mark.parametrize("N,J,T,G", [(5000, 3, 11, 1024), (40000, 3, 11, 64), (3000, 20, 12, 1024), (2000, 3, 4, 256),
+                                     (1500, 2, 1, 128), (391386, 3, 11, 1024)])
+def test_cell_sums_folded_into_the_toeplitz_stage_are_the_same_bits(gpu_device, N, J, T, G):
+    """Round 5: rpgp_ski_mvm_planned forms the Toeplitz stage's operand from the scatter's per-cell tap records (no histogram
+    pass in between).  The staged entry points — planned scatter (which runs the histogram pass), rpgp_ski_grid_product,
+    rpgp_ski_gather_fast — are the unfolded form: the two must agree bit for bit."""
+    from rpgp_amd import ops
+    g = torch.Generator().manual_seed(N + T)
+    Zt = torch.randn(N, J, generator=g).to(gpu_device)
+    Vt = torch.randn(N, T, generator=g).to(gpu_device)
+    gp = ops.ski_grid(Zt, None, G, weights=torch.linspace(0.5, 1.5, J))
+    plan = ops.SkiPlan(Zt, gp, G)
+    out = ops.ski_mvm(Zt, Zt, gp, Vt, 0.7 / J, 0.2, G, plan=plan)
+    hist = ops.ski_scatter(Zt, gp, Vt, G, plan=plan)
+    staged = ops.ski_gather(Zt, gp, ops.ski_grid_product(hist, gp, G), Vt, 0.7 / J, 0.2, G, plan=plan)
+    assert torch.equal(out, staged)

@@ -1472,12 +1472,14 @@ int rpgp_ski_mvm_planned(const void *plan, const float *Z, const float *grid_par
   double *hist = reinterpret_cast<double *>(workspace);
   float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * (2 * T);
   float *partial = reinterpret_cast<float *>(workspace) + rpgp_internal::ski_scratch_offset_floats(J, G, T);
-  // the four-tap cell sums ride in the Toeplitz stage's operand load where that stage takes them (RPGP_SKI_CELLSUM=1: the
-  // separate histogram pass of rounds 3 - 4)
-  static const bool fold_cells = [] { const char *e = getenv("RPGP_SKI_CELLSUM"); return !(e && e[0] == '1'); }();
+  // For ONE right-hand side the four-tap cell sums ride in the Toeplitz stage's operand load (RPGP_SKI_CELLSUM=1: the separate
+  // histogram pass of rounds 3 - 4; =0: folded for every width).  Measured at the C5 shape: T = 1 product 49 -> 37 us; at
+  // T = 11 every one of the 64 row tiles of a projection repeats the sums of the whole histogram and the Toeplitz stage goes
+  // 8.3 -> 16.6 us for the 4.8 us launch it saves — not folded.
+  static const int fold_cells = [] { const char *e = getenv("RPGP_SKI_CELLSUM"); return e ? (e[0] == '1' ? 0 : 2) : 1; }();
   int cells_tt = 0;
-  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st,
-                           fold_cells && rpgp_internal::ski_toeplitz_takes_cells(J, G, T) ? &cells_tt : nullptr);
+  const bool fold = (fold_cells == 2 || (fold_cells == 1 && T == 1)) && rpgp_internal::ski_toeplitz_takes_cells(J, G, T);
+  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st, fold ? &cells_tt : nullptr);
   if (rc) return rc;
   rc = cells_tt ? rpgp_internal::ski_toeplitz_cells_launch(partial, cells_tt, grid_params, H, J, G, T, st, pv.tcol)
                 : rpgp_internal::ski_toeplitz_launch(hist, 1, grid_params, H, J, G, T, st, pv.tcol);
@@ -1500,7 +1502,7 @@ int ski_mvm_planned_passa(const void *plan, const float *Z, const float *grid_pa
   float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * (2 * T);
   float *partial = reinterpret_cast<float *>(workspace) + ski_scratch_offset_floats(J, G, T);
   int cells_tt = 0;
-  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st, ski_toeplitz_takes_cells(J, G, T) ? &cells_tt : nullptr);
+  int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st, nullptr);      // (wide blocks: the histogram pass pays)
   if (rc) return rc;
   rc = cells_tt ? ski_toeplitz_cells_launch(partial, cells_tt, grid_params, H, J, G, T, st, pv.tcol)
                 : ski_toeplitz_launch(hist, 1, grid_params, H, J, G, T, st, pv.tcol);

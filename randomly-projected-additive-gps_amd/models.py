@@ -181,7 +181,8 @@ class PredictionStrategy:
                                                      else self.op.to_dense(), host_float(self.noise))
                 Kh = self._dense_khat.to_dense()                   # float32, noise on the diagonal
                 K64 = Kh.double()
-                Lc, info = torch.linalg.cholesky_ex(Kh)
+                from .precond import blocked_cholesky
+                Lc, info = blocked_cholesky(Kh)                    # (bf16x3 trailing updates beyond N = 16k: precond.py)
                 del Kh
             except torch.OutOfMemoryError:                         # lost the race for the memory: the general path serves
                 Kh = K64 = Lc = None
@@ -349,8 +350,9 @@ class PredictionStrategy:
                     # preconditioner — the wide CG then converges in a handful of 91 ms GEMMs instead of ~40
                     if getattr(self, "_chol_pre", None) is None:
                         from .precond import CholeskyPreconditioner
+                        from .precond import blocked_cholesky
                         Kh = khat.to_dense()
-                        Lc, info = torch.linalg.cholesky_ex(Kh)
+                        Lc, info = blocked_cholesky(Kh)
                         del Kh
                         self._chol_pre = CholeskyPreconditioner(Lc) if int(info) == 0 else False
                     if self._chol_pre:

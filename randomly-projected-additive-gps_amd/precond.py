@@ -170,6 +170,48 @@ def build_preconditioner(operator, noise, settings):
     return WoodburyPreconditioner(L, noise)
 
 
+def blocked_cholesky(K, block=2048, min_size=16384):
+    """(L, info) like `torch.linalg.cholesky_ex` for a LARGE float32 SPD matrix on a HIP device: a blocked right-looking
+    factorisation written for MI355X (round 5, tools/r5_chol_lab.py).  Per panel of `block` columns: the library factors the
+    diagonal block, the panel below it is `A21 D^-T` as ONE float32 GEMM against the explicitly inverted diagonal factor, and
+    the trailing update — where the flops are — runs on the LOWER block triangle only as **bf16x3** products: the panel is
+    split into hi = bf16(P) and lo = bf16(P - hi), and `P P^T ~ hi hi^T + hi lo^T + lo hi^T` is three bf16 matrix products
+    accumulated into the float32 block (`addmm(..., out_dtype=float32)`): ~350 TFLOP/s float32-equivalent against 140 for
+    the float32 matrix instruction, at a relative error of 3e-6 per product instead of 1e-6.  N = 50 000: 0.40 s against
+    0.69 - 0.96 s for the library routine; backward error of the factor 4e-6 (library 6e-7) — it is only ever used as the
+    approximate solver of a float64 iterative refinement (`_mp_solve`) or as a CG preconditioner, both of which remove that
+    error in their first round.  Only the lower triangle of the result is meaningful (what `cholesky_solve` reads).
+    Falls back to the library below `min_size`, off the GPU, or for other dtypes."""
+    n = K.shape[0]
+    if (not K.is_cuda) or K.dtype != torch.float32 or n < min_size or K.dim() != 2:
+        return torch.linalg.cholesky_ex(K)
+    L = K.clone()
+    eye = torch.eye(block, device=K.device, dtype=K.dtype)
+    bad = torch.zeros((), dtype=torch.int32, device=K.device)
+    for j0 in range(0, n, block):
+        j1 = min(j0 + block, n)
+        D, info = torch.linalg.cholesky_ex(L[j0:j1, j0:j1])
+        bad = torch.where((bad == 0) & (info != 0), info.to(torch.int32) + j0, bad)     # (no host synchronisation per panel)
+        L[j0:j1, j0:j1] = D
+        if j1 >= n:
+            break
+        Dinv = torch.linalg.solve_triangular(D, eye[: j1 - j0, : j1 - j0], upper=False)
+        P = L[j1:, j0:j1] @ Dinv.t()
+        L[j1:, j0:j1] = P
+        hi = P.bfloat16()
+        lo = (P - hi.float()).bfloat16()
+        for c0 in range(j1, n, block):
+            c1 = min(c0 + block, n)
+            blk = L[c0:, c0:c1]
+            ah, al = hi[c0 - j1:], lo[c0 - j1:]
+            bh, bl = hi[c0 - j1:c1 - j1].t(), lo[c0 - j1:c1 - j1].t()
+            t1 = torch.mm(ah, bh, out_dtype=torch.float32)
+            t1 = torch.addmm(t1, ah, bl, out_dtype=torch.float32)
+            t1 = torch.addmm(t1, al, bh, out_dtype=torch.float32)
+            blk.sub_(t1)
+    return L, bad
+
+
 class CholeskyPreconditioner:
     """M = the fp32 Cholesky factor of Khat itself: M^-1 r is two triangular solves.  Used for the N_test-wide covariance
     solve when the dense matrix is in HBM anyway and N is beyond the float64 direct solve: CG on the fp32 operator then

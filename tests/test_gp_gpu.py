@@ -362,3 +362,38 @@ def test_step_kernels_match_torch_operations_and_generic_path(gpu_device, ski):
         for k, gref in res[mode][1].items():
             gk = res["kernels"][1][k]
             assert (gk - gref).abs().max() < 2e-4 * gref.abs().max() + 1e-7, (mode, k)
+
+
+def test_blocked_bf16x3_cholesky_factor(gpu_device):
+    """precond.blocked_cholesky (round 5): the blocked float32 factorisation with bf16x3 trailing updates that the mixed-precision
+    covariance solve and the Cholesky-preconditioned wide CG use beyond N = 16k.  Its factor is slightly less accurate than the
+    library's (backward error ~4e-6 against ~6e-7) and is only ever used inside a refinement: one float64 refinement round must
+    bring a solve to 1e-9; a matrix that is not positive definite is reported through `info`."""
+    from rpgp_amd import ops
+    from rpgp_amd.precond import blocked_cholesky
+    N = 20000
+    g = torch.Generator().manual_seed(0)
+    Z = torch.randn(N, 20, generator=g).to(gpu_device)
+    K = ops.dense(Z, Z, 0.05)
+    K.diagonal().add_(0.1)
+    L, info = blocked_cholesky(K, block=2048, min_size=4096)
+    assert int(info) == 0
+    K64 = K.double()
+    B = torch.randn(N, 8, generator=g).to(gpu_device).double()
+    X = torch.cholesky_solve(B.float(), L).double()
+    r1 = float(((B - K64 @ X).norm(dim=0) / B.norm(dim=0)).max())
+    assert r1 < 1e-3                                              # the factor alone: kappa * 4e-6
+    R = B - K64 @ X
+    X = X + torch.cholesky_solve(R.float(), L).double()
+    R = B - K64 @ X
+    X = X + torch.cholesky_solve(R.float(), L).double()
+    r3 = float(((B - K64 @ X).norm(dim=0) / B.norm(dim=0)).max())
+    assert r3 < 1e-9, (r1, r3)
+    Lref = torch.linalg.cholesky(K)
+    assert float((L.tril() - Lref).abs().max()) < 2e-4
+    small, info_s = blocked_cholesky(K[:512, :512].contiguous())           # below min_size: the library routine
+    assert int(info_s) == 0 and torch.equal(small, torch.linalg.cholesky_ex(K[:512, :512].contiguous())[0])
+    Kbad = K.clone()
+    Kbad[9000, 9000] = -1.0
+    _, info_b = blocked_cholesky(Kbad, block=2048, min_size=4096)
+    assert int(info_b) != 0

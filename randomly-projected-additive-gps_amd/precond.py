@@ -174,16 +174,20 @@ def blocked_cholesky(K, block=2048, min_size=16384):
     """(L, info) like `torch.linalg.cholesky_ex` for a LARGE float32 SPD matrix on a HIP device: a blocked right-looking
     factorisation written for MI355X (round 5, tools/r5_chol_lab.py).  Per panel of `block` columns: the library factors the
     diagonal block, the panel below it is `A21 D^-T` as ONE float32 GEMM against the explicitly inverted diagonal factor, and
-    the trailing update — where the flops are — runs on the LOWER block triangle only as **bf16x3** products: the panel is
-    split into hi = bf16(P) and lo = bf16(P - hi), and `P P^T ~ hi hi^T + hi lo^T + lo hi^T` is three bf16 matrix products
-    accumulated into the float32 block (`addmm(..., out_dtype=float32)`): ~350 TFLOP/s float32-equivalent against 140 for
-    the float32 matrix instruction, at a relative error of 3e-6 per product instead of 1e-6.  N = 50 000: 0.40 s against
-    0.69 - 0.96 s for the library routine; backward error of the factor 4e-6 (library 6e-7) — it is only ever used as the
-    approximate solver of a float64 iterative refinement (`_mp_solve`) or as a CG preconditioner, both of which remove that
-    error in their first round.  Only the lower triangle of the result is meaningful (what `cholesky_solve` reads).
-    Falls back to the library below `min_size`, off the GPU, or for other dtypes."""
+    the trailing update — where the flops are — runs on the LOWER block triangle only as **fp16x3** products: the panel is
+    split into hi = fp16(P) and lo = fp16(2^11 (P - hi)) (22 of float32's 24 mantissa bits; the scale keeps lo out of the
+    fp16 subnormals), and `P P^T ~ hi hi^T + 2^-11 (hi lo^T + lo hi^T)` is three fp16 matrix products accumulated in float32
+    (`mm / addmm(..., out_dtype=float32)`): the fp16 matrix rate of MI355X (1.2 PFLOP/s measured for one product) instead of
+    140 TFLOP/s for the float32 matrix instruction.  N = 50 000: 0.41 s against 0.69 - 0.96 s for the library routine, and
+    the factor is as accurate (backward error 6e-7, library 5e-7; a bf16 split, 16 mantissa bits, gave 4e-6 and a refinement
+    that contracted by 0.3 per round instead of 4e-4).  Only the lower triangle of the result is meaningful (what
+    `cholesky_solve` reads).  Falls back to the library below `min_size`, off the GPU, for other dtypes, and when the
+    factor's entries (<= sqrt(max diagonal)) would leave the comfortable fp16 range."""
     n = K.shape[0]
     if (not K.is_cuda) or K.dtype != torch.float32 or n < min_size or K.dim() != 2:
+        return torch.linalg.cholesky_ex(K)
+    dmax = float(K.diagonal().max())                 # (one host synchronisation per factorisation of >= 0.1 s)
+    if not (1e-6 < dmax < 1e8):
         return torch.linalg.cholesky_ex(K)
     L = K.clone()
     eye = torch.eye(block, device=K.device, dtype=K.dtype)
@@ -198,16 +202,16 @@ def blocked_cholesky(K, block=2048, min_size=16384):
         Dinv = torch.linalg.solve_triangular(D, eye[: j1 - j0, : j1 - j0], upper=False)
         P = L[j1:, j0:j1] @ Dinv.t()
         L[j1:, j0:j1] = P
-        hi = P.bfloat16()
-        lo = (P - hi.float()).bfloat16()
+        hi = P.half()
+        lo = ((P - hi.float()) * 2048.0).half()
         for c0 in range(j1, n, block):
             c1 = min(c0 + block, n)
             blk = L[c0:, c0:c1]
             ah, al = hi[c0 - j1:], lo[c0 - j1:]
             bh, bl = hi[c0 - j1:c1 - j1].t(), lo[c0 - j1:c1 - j1].t()
-            t1 = torch.mm(ah, bh, out_dtype=torch.float32)
-            t1 = torch.addmm(t1, ah, bl, out_dtype=torch.float32)
+            t1 = torch.mm(ah, bl, out_dtype=torch.float32)
             t1 = torch.addmm(t1, al, bh, out_dtype=torch.float32)
+            t1 = torch.addmm(t1, ah, bh, beta=1.0 / 2048.0, out_dtype=torch.float32)
             blk.sub_(t1)
     return L, bad
 

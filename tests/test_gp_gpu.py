@@ -364,11 +364,11 @@ def test_step_kernels_match_torch_operations_and_generic_path(gpu_device, ski):
             assert (gk - gref).abs().max() < 2e-4 * gref.abs().max() + 1e-7, (mode, k)
 
 
-def test_blocked_bf16x3_cholesky_factor(gpu_device):
-    """precond.blocked_cholesky (round 5): the blocked float32 factorisation with bf16x3 trailing updates that the mixed-precision
-    covariance solve and the Cholesky-preconditioned wide CG use beyond N = 16k.  Its factor is slightly less accurate than the
-    library's (backward error ~4e-6 against ~6e-7) and is only ever used inside a refinement: one float64 refinement round must
-    bring a solve to 1e-9; a matrix that is not positive definite is reported through `info`."""
+def test_blocked_fp16x3_cholesky_factor(gpu_device):
+    """precond.blocked_cholesky (round 5): the blocked float32 factorisation with fp16x3 trailing updates that the mixed-precision
+    covariance solve and the Cholesky-preconditioned wide CG use beyond N = 16k.  Its factor is as accurate as the library's
+    (backward error ~6e-7): a solve with it is at the float32 level and two float64 refinement rounds bring it to 1e-9; a
+    matrix that is not positive definite is reported through `info`."""
     from rpgp_amd import ops
     from rpgp_amd.precond import blocked_cholesky
     N = 20000
@@ -382,15 +382,17 @@ def test_blocked_bf16x3_cholesky_factor(gpu_device):
     B = torch.randn(N, 8, generator=g).to(gpu_device).double()
     X = torch.cholesky_solve(B.float(), L).double()
     r1 = float(((B - K64 @ X).norm(dim=0) / B.norm(dim=0)).max())
-    assert r1 < 1e-3                                              # the factor alone: kappa * 4e-6
+    Lref = torch.linalg.cholesky(K)
+    Xl = torch.cholesky_solve(B.float(), Lref).double()
+    rl = float(((B - K64 @ Xl).norm(dim=0) / B.norm(dim=0)).max())
+    assert r1 < 3.0 * rl + 1e-6, (r1, rl)                          # the factor alone: as good as the library's
     R = B - K64 @ X
     X = X + torch.cholesky_solve(R.float(), L).double()
     R = B - K64 @ X
     X = X + torch.cholesky_solve(R.float(), L).double()
     r3 = float(((B - K64 @ X).norm(dim=0) / B.norm(dim=0)).max())
     assert r3 < 1e-9, (r1, r3)
-    Lref = torch.linalg.cholesky(K)
-    assert float((L.tril() - Lref).abs().max()) < 2e-4
+    assert float((L.tril() - Lref).abs().max()) < 1e-4
     small, info_s = blocked_cholesky(K[:512, :512].contiguous())           # below min_size: the library routine
     assert int(info_s) == 0 and torch.equal(small, torch.linalg.cholesky_ex(K[:512, :512].contiguous())[0])
     Kbad = K.clone()

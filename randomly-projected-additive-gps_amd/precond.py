@@ -173,13 +173,13 @@ def build_preconditioner(operator, noise, settings):
 def blocked_cholesky(K, block=2048, min_size=16384):
     """(L, info) like `torch.linalg.cholesky_ex` for a LARGE float32 SPD matrix on a HIP device: a blocked right-looking
     factorisation written for MI355X (round 5, tools/r5_chol_lab.py).  Per panel of `block` columns: the library factors the
-    diagonal block, the panel below it is `A21 D^-T` as ONE float32 GEMM against the explicitly inverted diagonal factor, and
+    diagonal block, the panel below it is `A21 D^-T` by the library's triangular solve, and
     the trailing update — where the flops are — runs on the LOWER block triangle only as **fp16x3** products: the panel is
     split into hi = fp16(P) and lo = fp16(2^11 (P - hi)) (22 of float32's 24 mantissa bits; the scale keeps lo out of the
     fp16 subnormals), and `P P^T ~ hi hi^T + 2^-11 (hi lo^T + lo hi^T)` is three fp16 matrix products accumulated in float32
     (`mm / addmm(..., out_dtype=float32)`): the fp16 matrix rate of MI355X (1.2 PFLOP/s measured for one product) instead of
     140 TFLOP/s for the float32 matrix instruction.  N = 50 000: 0.41 s against 0.69 - 0.96 s for the library routine, and
-    the factor is as accurate (backward error 6e-7, library 5e-7; a bf16 split, 16 mantissa bits, gave 4e-6 and a refinement
+    the factor is as accurate (backward error 4e-7, library 3e-7; a bf16 split, 16 mantissa bits, gave 4e-6 and a refinement
     that contracted by 0.3 per round instead of 4e-4).  Only the lower triangle of the result is meaningful (what
     `cholesky_solve` reads).  Falls back to the library below `min_size`, off the GPU, for other dtypes, and when the
     factor's entries (<= sqrt(max diagonal)) would leave the comfortable fp16 range."""
@@ -190,7 +190,6 @@ def blocked_cholesky(K, block=2048, min_size=16384):
     if not (1e-6 < dmax < 1e8):
         return torch.linalg.cholesky_ex(K)
     L = K.clone()
-    eye = torch.eye(block, device=K.device, dtype=K.dtype)
     bad = torch.zeros((), dtype=torch.int32, device=K.device)
     for j0 in range(0, n, block):
         j1 = min(j0 + block, n)
@@ -199,8 +198,7 @@ def blocked_cholesky(K, block=2048, min_size=16384):
         L[j0:j1, j0:j1] = D
         if j1 >= n:
             break
-        Dinv = torch.linalg.solve_triangular(D, eye[: j1 - j0, : j1 - j0], upper=False)
-        P = L[j1:, j0:j1] @ Dinv.t()
+        P = torch.linalg.solve_triangular(D, L[j1:, j0:j1].t(), upper=False).t().contiguous()      # A21 D^-T
         L[j1:, j0:j1] = P
         hi = P.half()
         lo = ((P - hi.float()) * 2048.0).half()

@@ -391,7 +391,7 @@ def test_blocked_fp16x3_cholesky_factor(gpu_device):
     R = B - K64 @ X
     X = X + torch.cholesky_solve(R.float(), L).double()
     r3 = float(((B - K64 @ X).norm(dim=0) / B.norm(dim=0)).max())
-    assert r3 < 1e-9, (r1, r3)
+    assert r3 < 1e-8 and r3 < 1e-4 * r1, (r1, r3)                  # (two rounds, each contracting by ~2e-3)
     assert float((L.tril() - Lref).abs().max()) < 1e-4
     small, info_s = blocked_cholesky(K[:512, :512].contiguous())           # below min_size: the library routine
     assert int(info_s) == 0 and torch.equal(small, torch.linalg.cholesky_ex(K[:512, :512].contiguous())[0])

@@ -296,7 +296,8 @@ class PredictionStrategy:
         # 2 Khat_64 w - sigma^2 w: no float64 copy of B
         Bf = self._dense_khat.Kd[:, :N] * 2.0
         Bf.diagonal().add_(s2)
-        Lb, info = torch.linalg.cholesky_ex(Bf)
+        from .precond import blocked_cholesky
+        Lb, info = blocked_cholesky(Bf)                           # (fp16x3 trailing updates beyond N = 16k)
         del Bf
         if int(info) != 0:
             raise RuntimeError("2 K + sigma^2 I is not positive definite in float32")

@@ -1472,13 +1472,14 @@ int rpgp_ski_mvm_planned(const void *plan, const float *Z, const float *grid_par
   double *hist = reinterpret_cast<double *>(workspace);
   float *H = reinterpret_cast<float *>(workspace) + 2 * (size_t)J * G * (2 * T);
   float *partial = reinterpret_cast<float *>(workspace) + rpgp_internal::ski_scratch_offset_floats(J, G, T);
-  // For ONE right-hand side the four-tap cell sums ride in the Toeplitz stage's operand load (RPGP_SKI_CELLSUM=1: the separate
-  // histogram pass of rounds 3 - 4; =0: folded for every width).  Measured at the C5 shape: T = 1 product 49 -> 37 us; at
-  // T = 11 every one of the 64 row tiles of a projection repeats the sums of the whole histogram and the Toeplitz stage goes
-  // 8.3 -> 16.6 us for the 4.8 us launch it saves — not folded.
-  static const int fold_cells = [] { const char *e = getenv("RPGP_SKI_CELLSUM"); return e ? (e[0] == '1' ? 0 : 2) : 1; }();
+  // RPGP_SKI_CELLSUM=0 (opt-in): the four-tap cell sums formed in the Toeplitz stage's operand load instead of a histogram pass
+  // of their own (same bits).  Measured at the C5 shape ON THE DEVICE the folded Toeplitz stage takes 16.6 us against 8.1 + 4.8
+  // (T = 11) and 8.1 + ~3 (T = 1): every one of the 64 row tiles of a projection repeats the sums of the whole histogram.  Through
+  // the Python wrappers the T = 1 product is faster folded (49 -> 33 us: three launches instead of four on a host-bound path),
+  // inside the executor — where the products of a solve run — it is not; the default keeps the histogram pass.
+  static const bool fold_cells = [] { const char *e = getenv("RPGP_SKI_CELLSUM"); return e && e[0] == '0'; }();
   int cells_tt = 0;
-  const bool fold = (fold_cells == 2 || (fold_cells == 1 && T == 1)) && rpgp_internal::ski_toeplitz_takes_cells(J, G, T);
+  const bool fold = fold_cells && rpgp_internal::ski_toeplitz_takes_cells(J, G, T);
   int rc = scatter_planned(pv, V, hist, partial, N, J, G, T, T, 0, st, fold ? &cells_tt : nullptr);
   if (rc) return rc;
   rc = cells_tt ? rpgp_internal::ski_toeplitz_cells_launch(partial, cells_tt, grid_params, H, J, G, T, st, pv.tcol)

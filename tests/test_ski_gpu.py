@@ -527,8 +527,9 @@ def test_planned_bilinear_derivative_matches_the_fused_one(gpu_device, N, J, T, 
 @pytest.mark.parametrize("N,J,T,G", [(5000, 3, 11, 1024), (40000, 3, 1, 64), (3000, 20, 12, 1024), (2000, 3, 4, 256),
                                      (1500, 2, 1, 128), (391386, 3, 1, 1024), (391386, 3, 11, 1024)])
 def test_cell_sums_folded_into_the_toeplitz_stage_are_the_same_bits(gpu_device, N, J, T, G):
-    """Round 5: for one right-hand side rpgp_ski_mvm_planned forms the Toeplitz stage's operand from the scatter's per-cell tap
-    records (no histogram pass in between; RPGP_SKI_CELLSUM=0 folds every width).  The staged entry points — planned scatter (which runs the histogram pass), rpgp_ski_grid_product,
+    """Round 5 (opt-in, RPGP_SKI_CELLSUM=0): rpgp_ski_mvm_planned forms the Toeplitz stage's operand from the scatter's per-cell
+    tap records (no histogram pass in between).  Run with and without the variable by the driver script of the round; here the
+    default form and the staged form are compared.  The staged entry points — planned scatter (which runs the histogram pass), rpgp_ski_grid_product,
     rpgp_ski_gather_fast — are the unfolded form: the two must agree bit for bit."""
     from rpgp_amd import ops
     g = torch.Generator().manual_seed(N + T)

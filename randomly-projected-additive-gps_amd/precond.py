@@ -170,6 +170,24 @@ def build_preconditioner(operator, noise, settings):
     return WoodburyPreconditioner(L, noise)
 
 
+_FP16X3 = {}
+
+
+def _fp16x3_available(device):
+    """fp16 operands into a float32 result (`torch.mm / addmm(..., out_dtype=torch.float32)`): present in this image's
+    PyTorch-ROCm; probed once per device so that another build falls back to the library factorisation instead of failing."""
+    key = str(device)
+    if key not in _FP16X3:
+        try:
+            a = torch.ones(16, 16, device=device, dtype=torch.float16)
+            c = torch.mm(a, a, out_dtype=torch.float32)
+            c = torch.addmm(c, a, a, beta=0.5, out_dtype=torch.float32)
+            _FP16X3[key] = c.dtype == torch.float32 and abs(float(c[0, 0]) - 24.0) < 1e-3
+        except (TypeError, RuntimeError):
+            _FP16X3[key] = False
+    return _FP16X3[key]
+
+
 def blocked_cholesky(K, block=2048, min_size=16384):
     """(L, info) like `torch.linalg.cholesky_ex` for a LARGE float32 SPD matrix on a HIP device: a blocked right-looking
     factorisation written for MI355X (round 5, tools/r5_chol_lab.py).  Per panel of `block` columns: the library factors the
@@ -184,7 +202,7 @@ def blocked_cholesky(K, block=2048, min_size=16384):
     `cholesky_solve` reads).  Falls back to the library below `min_size`, off the GPU, for other dtypes, and when the
     factor's entries (<= sqrt(max diagonal)) would leave the comfortable fp16 range."""
     n = K.shape[0]
-    if (not K.is_cuda) or K.dtype != torch.float32 or n < min_size or K.dim() != 2:
+    if (not K.is_cuda) or K.dtype != torch.float32 or n < min_size or K.dim() != 2 or not _fp16x3_available(K.device):
         return torch.linalg.cholesky_ex(K)
     dmax = float(K.diagonal().max())                 # (one host synchronisation per factorisation of >= 0.1 s)
     if not (1e-6 < dmax < 1e8):

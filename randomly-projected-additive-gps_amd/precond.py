@@ -6,6 +6,8 @@ Used when N >= settings.min_preconditioning_size (2000).  Needs only diag(K) (co
 of K (rpgp_dense on k x N)."""
 import math
 
+import os
+
 import torch
 
 from . import backend as _backend
@@ -202,7 +204,8 @@ def blocked_cholesky(K, block=2048, min_size=16384):
     `cholesky_solve` reads).  Falls back to the library below `min_size`, off the GPU, for other dtypes, and when the
     factor's entries (<= sqrt(max diagonal)) would leave the comfortable fp16 range."""
     n = K.shape[0]
-    if (not K.is_cuda) or K.dtype != torch.float32 or n < min_size or K.dim() != 2 or not _fp16x3_available(K.device):
+    if (not K.is_cuda) or K.dtype != torch.float32 or n < min_size or K.dim() != 2 or not _fp16x3_available(K.device) or \
+            os.environ.get("RPGP_BLOCKED_CHOL", "1") == "0":          # (RPGP_BLOCKED_CHOL=0: the library routine, for A/B runs)
         return torch.linalg.cholesky_ex(K)
     dmax = float(K.diagonal().max())                 # (one host synchronisation per factorisation of >= 0.1 s)
     if not (1e-6 < dmax < 1e8):
@@ -216,19 +219,31 @@ def blocked_cholesky(K, block=2048, min_size=16384):
         L[j0:j1, j0:j1] = D
         if j1 >= n:
             break
-        P = torch.linalg.solve_triangular(D, L[j1:, j0:j1].t(), upper=False).t().contiguous()      # A21 D^-T
+        P = torch.empty((n - j1, j1 - j0), device=K.device, dtype=K.dtype)                        # A21 D^-T, in row chunks of
+        r1 = n                                                                                    # a fixed height (see below)
+        while r1 > j1:
+            r0 = max(j1, r1 - 4 * block)
+            P[r0 - j1:r1 - j1] = torch.linalg.solve_triangular(D, L[r0:r1, j0:j1].t(), upper=False).t()
+            r1 = r0
         L[j1:, j0:j1] = P
         hi = P.half()
         lo = ((P - hi.float()) * 2048.0).half()
+        # Row chunks of a FIXED height, counted from the bottom: the library picks a kernel per (M, N, K) on first sight of a
+        # shape (~3 ms each), and whole-column-block products have ~300 distinct heights per factorisation — the first call of
+        # a process took 3.1 s against 0.41 s for the next.  With fixed chunks the heights are `rows` and four remainders.
+        rows = 4 * block
         for c0 in range(j1, n, block):
             c1 = min(c0 + block, n)
-            blk = L[c0:, c0:c1]
-            ah, al = hi[c0 - j1:], lo[c0 - j1:]
             bh, bl = hi[c0 - j1:c1 - j1].t(), lo[c0 - j1:c1 - j1].t()
-            t1 = torch.mm(ah, bl, out_dtype=torch.float32)
-            t1 = torch.addmm(t1, al, bh, out_dtype=torch.float32)
-            t1 = torch.addmm(t1, ah, bh, beta=1.0 / 2048.0, out_dtype=torch.float32)
-            blk.sub_(t1)
+            r1 = n
+            while r1 > c0:
+                r0 = max(c0, r1 - rows)
+                ah, al = hi[r0 - j1:r1 - j1], lo[r0 - j1:r1 - j1]
+                t1 = torch.mm(ah, bl, out_dtype=torch.float32)
+                t1 = torch.addmm(t1, al, bh, out_dtype=torch.float32)
+                t1 = torch.addmm(t1, ah, bh, beta=1.0 / 2048.0, out_dtype=torch.float32)
+                L[r0:r1, c0:c1].sub_(t1)
+                r1 = r0
     return L, bad
 
 

@@ -1211,7 +1211,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   // already queued while it waits and the GPU never idles on the round trip.  The iteration queued past convergence is a
   // no-op on x (alpha = 0).
   int polled_it = -1;                     // iteration whose poll is in flight (-1: none)
-  CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f};
+  CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f, 0};
   // Graph form: RPGP_CG_GRAPH=1, unsharded solves of the operators whose product is plain launches on the stream (the cached
   // dense product allocates its slabs stream-ordered and stays in the queue-ahead form).
   // RPGP_CG_FOLD_A=1 (opt-in): measured at the C5 shape the gather with pass A folded in takes 31 us against 19 + 11 us for the

@@ -107,7 +107,6 @@ inline bool chunk_shape_ok(long long N, int J, int G) {
   const long long nch = (N + ch - 1) / ch;
   return nch * J <= 1024 && nch <= (1024 + J - 1) / J;
 }
-inline bool chunk_ok(long long N, int J, int G) { return chunk_env_on() && chunk_shape_ok(N, J, G); }
 
 inline long long max_items(long long N, int J, int G);
 
@@ -1033,7 +1032,7 @@ __global__ __launch_bounds__(1024) void ski_chunk_gather_kernel(const int4 *__re
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = lane / LPP, q = lane - slot * LPP;
   const unsigned magic = ((1u << 20) + T - 1) / T;
-  if (threadIdx.x < J) swi[threadIdx.x] = winfo[(size_t)chunk * J + threadIdx.x];
+  if ((int)threadIdx.x < J) swi[threadIdx.x] = winfo[(size_t)chunk * J + threadIdx.x];
   __syncthreads();
   int hrow[kChunkMaxJ], wlo[kChunkMaxJ], rows = 0;      // (uniform: kept in scalar registers)
 #pragma unroll
@@ -1086,7 +1085,7 @@ __global__ __launch_bounds__(1024) void ski_chunk_gather_kernel(const int4 *__re
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int p = threadIdx.x + h * 1024;
-        if (j < J && p < np) Us[(size_t)j * RPA + p] = ru[j][h];
+        if (j < J && p < np) Us[(size_t)j * RPA + p] = ru[j][h];      // (np, RPA: rows of the pass / coordinate slots)
       }
     auto window_store = [&](unsigned e, float x) {
       const int j = window_of(e);

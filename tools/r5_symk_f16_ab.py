@@ -1,4 +1,6 @@
-"""Wide packed-cache product (T = 11): exact-fp32 matrix instructions on the float32 cache against the fp16x3 form on the
+"""(Needs tools/experiments/r5_symk_fp16_pair_cache.patch applied to csrc/rpgp_kernels.hip, RPGP_SYMCACHE_WIDE16 = 2 added to
+include/rpgp.h / _lib.py and `wide="packed16"` to ops.SymCache — the experiment is not part of the tree.)
+Wide packed-cache product (T = 11): exact-fp32 matrix instructions on the float32 cache against the fp16x3 form on the
 fp16-pair cache (RPGP_SYMCACHE_WIDE16), same process, alternating; error of both against a float64 dense product on a row sample.  JSON lines."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

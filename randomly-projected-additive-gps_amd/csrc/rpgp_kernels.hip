@@ -878,13 +878,13 @@ __global__ __launch_bounds__(256) void mvm_fact_rows_kernel(const float2v *__res
 // A workgroup owns 32 consecutive outputs; its 8 half-waves split the slab entries (entry k goes to group k % 8, each
 // read is a 128-byte contiguous segment) and the 8 group sums are added in a fixed order: deterministic, and short
 // enough for the small problems (N < 10k) where a one-thread-per-output loop over ~150 slabs was latency-bound.
-constexpr int kRedGroups = 8;
-constexpr int kRedOutputs = 32;
+template <int kRedOutputs>
 __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict__ slabR, const float *__restrict__ slabT,
                                   const float *__restrict__ V, float *__restrict__ out, int M, int N, int T,
                                   int BR, int chunk_cols, int sym, float scale, float noise,
                                   const int *__restrict__ guard, int rb0, int rb1, int slab_row0, int slab_rows,
                                   rpgp_internal::Taper taper = rpgp_internal::Taper{0x7fffffff, 0x7fffffff, 0x7fffffff}) {
+  constexpr int kRedGroups = 256 / kRedOutputs;
   __shared__ double sacc[kRedGroups][kRedOutputs];   // float64: ~150 slab entries per output, free at this size
   const int o = threadIdx.x & (kRedOutputs - 1), g = threadIdx.x / kRedOutputs;
   const size_t gid = (size_t)blockIdx.x * kRedOutputs + o;
@@ -927,6 +927,29 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
   if (noise != 0.f) r = __builtin_fmaf(noise, V[gid], r);
   out[gid] = r;
 }
+
+// Outputs per workgroup of the slab reduce: 32 (eight groups share the slab entries: the latency-bound small problems) up to
+// 256 (one group, 1 KB contiguous per slab entry: the large ones, where 128-byte pieces 2 MB apart waste the HBM rate).
+inline int red_outputs(size_t total) {
+  static const int forced = [] {
+    const char *e = getenv("RPGP_RED_OUTS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return forced;
+  // measured (tools/r5_symk_red_prof.sh, T = 11 packed-cache product): 64 outputs beat 32 at every size (N = 7k: 7.2 -> 6.5 us,
+  // 15k: 10.4 -> 9.4, 50k: 36.6 -> 29.6); 128 only from N ~ 15k (8.3 us) and lose at 7k (10.0 us)
+  return total >= (size_t)16384 * 8 ? 64 : 32;
+}
+#define RPGP_LAUNCH_MVM_REDUCE(total_, st_, ...)                                                                          \
+  do {                                                                                                                    \
+    const size_t tot__ = (total_);                                                                                        \
+    switch (red_outputs(tot__)) {                                                                                         \
+      case 256: hipLaunchKernelGGL(mvm_reduce_kernel<256>, dim3((unsigned)((tot__ + 255) / 256)), dim3(256), 0, st_, __VA_ARGS__); break; \
+      case 128: hipLaunchKernelGGL(mvm_reduce_kernel<128>, dim3((unsigned)((tot__ + 127) / 128)), dim3(256), 0, st_, __VA_ARGS__); break; \
+      case 64: hipLaunchKernelGGL(mvm_reduce_kernel<64>, dim3((unsigned)((tot__ + 63) / 64)), dim3(256), 0, st_, __VA_ARGS__); break;    \
+      default: hipLaunchKernelGGL(mvm_reduce_kernel<32>, dim3((unsigned)((tot__ + 31) / 32)), dim3(256), 0, st_, __VA_ARGS__); break;    \
+    }                                                                                                                     \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // Packed symmetric cache ("symcache"): the cached-K mode without the lower triangle.
@@ -1441,6 +1464,164 @@ __global__ __launch_bounds__(256, 2) void symk_mvm_tile_kernel(const float4v *__
     }
   }
   // accR[rt]: lane holds D[t = 4 kap + r][rho = tn] of row tile rt
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    const int row = rw0 + 16 * rt + tn;
+    if (row < N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 4 * kap + r;
+        if (t < tcnt) slabR[((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0 + t] = accR[rt][r];
+      }
+    }
+  }
+}
+
+// Round 5 (second session): the same product with ONE workgroup barrier per 64-column subtile instead of three.
+//  * The staged right-hand sides and the four waves' transposed sums live in DOUBLE-BUFFERED LDS images.  Subtile s reads its
+//    A operands from sV[s & 1], requests the block of subtile s + 1 at its head (four registers per thread) and writes it to
+//    sV[(s + 1) & 1] at its end; the waves' transposed sums go to sT[s & 1]; ONE barrier; then the fixed-order cross-wave
+//    sum and the slab store (bit-identical results to the three-barrier form).
+//  * Why one barrier is enough: an image written in subtile s was last read in subtile s - 1 (sV) or s - 2 (sT), and every
+//    reader of those passed the barrier of subtile s - 1 only after its reads — which the writer has passed too.
+//  (A first form without any staging — every wave requesting its own sixteen A operands from global memory one subtile
+//  ahead — needs 16 more registers than the 256 there are: the reloads put an `s_waitcnt vmcnt(0)` at the head of every
+//  subtile, which drains the tile ring.)
+template <int R>
+__global__ __launch_bounds__(256, 2) void symk_mvm_tile2_kernel(const float4v *__restrict__ cache, const float *__restrict__ V,
+                                                             float *__restrict__ slabR, float *__restrict__ slabT, int N,
+                                                             int ldv, int t0, int tcnt, int chunk_cols, int w0, int rb_first,
+                                                             int slab_row0, int slab_rows, long long sub0) {
+  constexpr int BR = 256 * R;
+  constexpr int NRT = 4 * R;
+  constexpr int NT = 4 * NRT;
+  constexpr int D = 8;
+  constexpr int SVS = 17;
+  __shared__ __attribute__((aligned(16))) float sV[2][64 * SVS];
+  __shared__ __attribute__((aligned(16))) float sT[2][4 * 64 * 16];
+  __shared__ __attribute__((aligned(16))) float sX[4 * 640];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = lane & 15, kap = lane >> 4;
+  int rb, kchunk;
+  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
+  const int r0 = rb * BR;
+  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
+  if (cb >= N) return;
+  const int c_begin = (int)cb;
+  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
+  const int rw0 = r0 + wave * (64 * R);
+
+  float arow[NRT][4];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = rw0 + 16 * rt + 4 * kap + j;
+      arow[rt][j] = (row < N && tn < tcnt) ? V[(size_t)row * ldv + t0 + tn] : 0.f;
+    }
+  float *scr = sX + wave * 640;
+  const int woff = tn * 20 + 4 * kap;
+  const int roff = 4 * kap * 20 + tn;
+  floatx4m accR[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) accR[rt] = floatx4m{0.f, 0.f, 0.f, 0.f};
+
+  const long long g0 = symk_first_subtile(rb, N, BR) + (long long)kchunk * (chunk_cols / 64) - sub0;
+  const float4v *wp = cache + ((size_t)(g0 * 4 + wave) * 16) * R * 64 + lane;
+  constexpr size_t SUB = (size_t)4 * NT * 64;
+  float4v ring[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) ring[d] = __builtin_nontemporal_load(wp + (size_t)d * 64);
+  float vpre[4];
+  auto v_request = [&](int c0n) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + 256 * it;
+      const int c = e >> 4, t = e & 15;
+      const int col = c0n + c;
+      const int colc = col < N ? col : N - 1;
+      const int tc = t < tcnt ? t : 0;
+      vpre[it] = V[(size_t)colc * ldv + t0 + tc];
+    }
+  };
+  auto v_stage = [&](float *dst, int c0n) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + 256 * it;
+      const int c = e >> 4, t = e & 15;
+      dst[c * SVS + t] = (c0n + c < c_end && t < tcnt) ? vpre[it] : 0.f;
+    }
+  };
+  // contiguous slab stores: element e = c * tcnt + t of a subtile's block (when the block is one run: t0 == 0, tcnt == ldv)
+  const bool dense_slab = (t0 == 0 && tcnt == ldv);
+  int lidx[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = tid + 256 * it;
+    const int c = e / tcnt, t = e - c * tcnt;
+    lidx[it] = (e < 64 * tcnt) ? c * 16 + t : -1;
+  }
+  v_request(c_begin);
+  v_stage(sV[0], c_begin);
+  __syncthreads();
+  int par = 0;
+  for (int c0 = c_begin; c0 < c_end; c0 += 64, wp += SUB, par ^= 1) {
+    float acol[4][4];
+    {
+      const float *sv = sV[par];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acol[ct][i] = sv[(16 * ct + 4 * kap + i) * SVS + tn];
+    }
+    // The next subtile's block is requested here and written to LDS at the END of this subtile: in straight-line code hipcc
+    // counts the 16 R tile requests issued in between and waits with `vmcnt(8)` — the ring stays in flight.  (Consumed at the
+    // head of the next iteration the wait becomes `vmcnt(3..0)`: across the back edge the counter model is conservative, and
+    // that drains the ring once per subtile — the three-barrier form above does exactly that.)
+    v_request(c0 + 64 < c_end ? c0 + 64 : c0);
+    const bool doT = (c0 >= r0 + BR);
+    floatx4m accT[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) accT[ct] = floatx4m{0.f, 0.f, 0.f, 0.f};
+    float *st = sT[par];
+    // ONE instruction stream for every subtile: the diagonal block's subtiles (no transposed product: the block is stored
+    // whole) run the transposed MFMAs too and drop their sums — BR / N of the matrix work (1 % at N = 50k, 7 % at 7k) on a
+    // pipe that is not the bound, against two copies of the tile code whose register maps hipcc reconciles with moves of the
+    // whole ring (and an `s_waitcnt vmcnt(0)`) on the loop's back edge.
+    symk_tile_rows<R, true, 0>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[(wave * 64 + 16 * ct + tn) * 16 + 4 * kap + r] = accT[ct][r];
+    v_stage(sV[par ^ 1], c0 + 64);                       // (past the chunk: zeros, never read)
+    __syncthreads();
+    if (doT) {
+      if (dense_slab) {
+        // the subtile's 64 x tcnt sums are one contiguous run of the slab: thread e writes element e (whole 256-byte
+        // wave stores instead of 176-byte fragments with five idle lanes in sixteen)
+        float *dstT = slabT + ((size_t)(rb - rb_first) * N + c0) * ldv;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int e = tid + 256 * it;
+          const int li = lidx[it];
+          if (li >= 0 && c0 + (li >> 4) < c_end) {
+            const float sum = st[0 * 1024 + li] + st[1 * 1024 + li] + st[2 * 1024 + li] + st[3 * 1024 + li];
+            dstT[e] = sum;
+          }
+        }
+      } else {
+      for (int e = tid; e < 64 * 16; e += 256) {
+        const int c = e >> 4, t = e & 15;
+        const int col = c0 + c;
+        if (col < c_end && t < tcnt) {
+          const float sum = st[(0 * 64 + c) * 16 + t] + st[(1 * 64 + c) * 16 + t] + st[(2 * 64 + c) * 16 + t] +
+                            st[(3 * 64 + c) * 16 + t];
+          slabT[((size_t)(rb - rb_first) * N + col) * ldv + t0 + t] = sum;
+        }
+      }
+      }
+    }
+  }
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) {
     const int row = rw0 + 16 * rt + tn;
@@ -3737,7 +3918,7 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
     ++g_prof_n;
   }
   const size_t total = (size_t)M * T;
-  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st, slabR, slabT, V,
+  RPGP_LAUNCH_MVM_REDUCE(total, st, slabR, slabT, V,
                      out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise, (const int *)nullptr, p.rb0,
                      p.rb1, p.row0, p.rows);
   return launch_status();
@@ -4007,8 +4188,7 @@ int family_mvm_common(const rpgp_family *fam, const float *Z1, const float *Z2, 
   });
   if (rc) return rc;
   const size_t total = (size_t)M * T;
-  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st,
-                     slabR, slabT, V, out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise,
+  RPGP_LAUNCH_MVM_REDUCE(total, st, slabR, slabT, V, out, (int)M, (int)N, T, p.BR, p.chunk_cols, SYM ? 1 : 0, scale, noise,
                      (const int *)nullptr, p.rb0, p.rb1, p.row0, p.rows);
   return launch_status();
 }
@@ -4101,6 +4281,18 @@ int symk_launch_build_tile(const SymkPlan &sp, const float *Z, float4v *cache, i
 inline int symk_launch_mvm_tile(const SymkPlan &sp, const float4v *cache, const float *V, float *slabR, float *slabT,
                                 int N, int T, int t0, int tcnt, hipStream_t st) {
   dim3 grid(sp.p.w1 - sp.p.w0), block(256);
+  // RPGP_SYMK_WIDE_V2=0: the three-barrier kernel (read per call: tools/r5_symk_wide_ab.py alternates inside one process)
+  const char *env_v2 = getenv("RPGP_SYMK_WIDE_V2");
+  const bool one_barrier = env_v2 ? env_v2[0] != '0' : true;
+  if (one_barrier) {
+    if (sp.p.R == 2)
+      hipLaunchKernelGGL((symk_mvm_tile2_kernel<2>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
+                         sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
+    else
+      hipLaunchKernelGGL((symk_mvm_tile2_kernel<1>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
+                         sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
+    return launch_status();
+  }
   if (sp.p.R == 2)
     hipLaunchKernelGGL((symk_mvm_tile_kernel<2>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
                        sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
@@ -4355,7 +4547,7 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
     ++g_prof_n;
   }
   const size_t total = (size_t)N * T;
-  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st, slabR, slabT, V, out,
+  RPGP_LAUNCH_MVM_REDUCE(total, st, slabR, slabT, V, out,
                      (int)N, (int)N, T, p.BR, p.chunk_cols, 1, scale, noise,
                      reinterpret_cast<const int *>(L.header), p.rb0, p.rb1, p.row0, p.rows, p.taper);
   return launch_status();
@@ -4808,7 +5000,7 @@ int rpgp_symcache_mvm(const void *cache, size_t cache_bytes, int layout, const f
     t0 += tcnt;
   }
   const size_t total = (size_t)N * T;
-  hipLaunchKernelGGL(mvm_reduce_kernel, dim3((unsigned)((total + kRedOutputs - 1) / kRedOutputs)), dim3(256), 0, st, slabR,
+  RPGP_LAUNCH_MVM_REDUCE(total, st, slabR,
                      slabT, V, out, (int)N, (int)N, T, p.BR, p.chunk_cols, 1, scale, noise, (const int *)nullptr, p.rb0,
                      p.rb1, p.row0, p.rows);
   return launch_status();

@@ -204,6 +204,29 @@ def test_symcache_pair_shards_sum_to_whole(gpu_device, N, world, wide):
     assert nbytes >= ops.SymCache(Zt).nbytes                      # the shards cover the cache (each carries its own pad)
 
 
+@pytest.mark.parametrize("N,T,shard", [(257, 11, None), (4097, 11, None), (4500, 16, None), (6211, 5, None), (5000, 20, None),
+                                       (9000, 11, (3, 1)), (12345, 11, None), (2049, 37, (2, 0))])
+def test_symcache_wide_kernels_bitwise_interchangeable(gpu_device, N, T, shard, monkeypatch):
+    """The wide product's two kernels — one workgroup barrier per subtile with double-buffered LDS images and contiguous
+    slab stores (default) / three barriers (RPGP_SYMK_WIDE_V2=0) — form the same sums in the same order: identical bits
+    for ragged sizes, one and two rows per lane, pair shards, blocks of more than 16 right-hand sides (second pass at
+    t0 = 16: the strided slab stores) and against the oracle."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + T)
+    Z = rng.standard_normal((N, 20)).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
+    cache = ops.SymCache(Zt, wide=True, shard=shard)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RPGP_SYMK_WIDE_V2", mode)
+        outs[mode] = ops.symcache_mvm(cache, Vt, 0.2, 0.3)
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["0"], outs["1"])
+    if shard is None:
+        assert _rel(outs["1"].cpu().numpy(), orc.mvm(Z, Z, V, 0.2, 0.3)) < 2e-6
+
+
 def test_symcache_rejects_mismatched_arguments(gpu_device):
     from rpgp_amd import ops, _lib
     Zt = torch.randn(2000, 4, device=gpu_device)

@@ -3605,6 +3605,118 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
   }
 }
 
+// Cooperative form for 2048 < N <= 32768 (round 5; OPT-IN, see pivchol_common: bitwise equal and no faster): ALL greedy steps in ONE launch of ceil(N / 256) <= 128 co-resident
+// workgroups (a thread owns one row for the whole factorisation: its coordinates in LDS, its row of L and its residual
+// diagonal entry in registers), separated by a grid barrier instead of a launch boundary — rank + 1 launches of ~9 us each
+// (plus the dispatch gaps between them: 175 - 250 us per optimiser step at the C2 / C3 shapes) become one.  Same arithmetic
+// per entry, same tie-break: the factor is bitwise the one of the per-step form.  The barrier is the release / counter /
+// acquire sequence of the Gram finish (rpgp_precond.hip) with a BOUNDED spin: a barrier that does not complete within ~1 s
+// (it cannot, unless the workgroups are not co-resident) poisons the factor with NaN instead of hanging the device.
+__device__ __forceinline__ bool pivchol_grid_barrier(unsigned *counter, unsigned target, int *s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    long spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1L << 21)) { ok = 0; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+__global__ __launch_bounds__(256) void pivchol_coop_kernel(const float *__restrict__ Z, float *__restrict__ L,
+                                                           float *pval, int *pidx, unsigned *bar, int N, int ldz,
+                                                           int ncols, int k, float scale, float d0, int kind, int group,
+                                                           int ncomp, const float *__restrict__ wts) {
+  constexpr int KMAX = 16, SZ = 33, PSTRIDE = 128;
+  __shared__ float sval[4];
+  __shared__ int sidx[4];
+  __shared__ float szp[64];
+  __shared__ float slp[KMAX];
+  __shared__ float sdp;
+  __shared__ int spiv;
+  __shared__ int sflag;
+  __shared__ float sZ[256 * SZ];
+  const int tid = threadIdx.x, nb = (int)gridDim.x;
+  const int i = blockIdx.x * 256 + tid;
+  const bool own = i < N;
+  const bool in_lds = ncols <= 32;
+  const float pre = pivchol_pre(kind);
+  if (in_lds)
+    for (int j = 0; j < ncols; ++j) sZ[tid * SZ + j] = own ? Z[(size_t)i * ldz + j] : 0.f;
+  const float *zi = in_lds ? (const float *)(sZ + tid * SZ) : Z + (size_t)(own ? i : 0) * ldz;
+  float lrow[KMAX];
+  float dres = d0;
+#pragma unroll
+  for (int m = 0; m < KMAX; ++m) {
+    if (m < k) {                                     // (k is uniform: no thread leaves before the others' barriers)
+      float bv = -1.f;
+      int bi = 0x7fffffff;
+      if (m == 0) {
+        if (tid == 0) { sdp = d0; spiv = 0; }        // stationary kernel: the diagonal is d0 everywhere, ties -> row 0
+      } else {
+        for (int q = tid; q < nb; q += 256) {
+          const float v = pval[(m & 1) * PSTRIDE + q];
+          const int ix = pidx[(m & 1) * PSTRIDE + q];
+          if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+        }
+        block_argmax(bv, bi, sval, sidx);
+        if (tid == 0) { sdp = bv; spiv = bi; }
+      }
+      __syncthreads();
+      const int piv = spiv;
+      const float dp = sdp;
+      const bool ok = dp > 1e-10f * d0;
+      if (tid < ncols) szp[tid] = Z[(size_t)piv * ldz + tid] * pre;
+      if (tid < m) slp[tid] = L[(size_t)piv * k + tid];
+      __syncthreads();
+      const float inv_sq = ok ? 1.0f / sqrtf(dp) : 0.f;
+      bv = -1.f;
+      bi = 0x7fffffff;
+      if (own) {
+        float l = 0.f;
+        if (ok) {
+          const float row = scale * pivchol_entry(zi, szp, kind, group, ncomp, wts);
+          float corr = 0.f;
+#pragma unroll
+          for (int q = 0; q < m; ++q) corr = __builtin_fmaf(lrow[q], slp[q], corr);
+          l = (row - corr) * inv_sq;
+        }
+        lrow[m] = l;
+        L[(size_t)i * k + m] = l;
+        float nd = dres - l * l;
+        nd = nd < 0.f ? 0.f : nd;
+        nd = (i == piv) ? 0.f : nd;
+        dres = nd;
+        bv = nd;
+        bi = i;
+      }
+      if (m + 1 < k) {
+        __syncthreads();
+        block_argmax(bv, bi, sval, sidx);
+        if (tid == 0) {
+          pval[((m + 1) & 1) * PSTRIDE + blockIdx.x] = bv;
+          pidx[((m + 1) & 1) * PSTRIDE + blockIdx.x] = bi;
+        }
+        if (!pivchol_grid_barrier(bar, (unsigned)(m + 1) * (unsigned)nb, &sflag)) {
+          if (own)
+            for (int q = 0; q < k; ++q) L[(size_t)i * k + q] = __builtin_nanf("");
+          return;
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // DPA-GP diversification (rp.space_equally, rp.py:241-266) as ONE single-workgroup launch:
 // `niter` plain gradient steps of size lr on  L(P) = sum_{a != b} cos^4(angle(P_a, P_b)),  then row normalisation.
@@ -4863,6 +4975,20 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
   hipStream_t st = as_stream(stream);
   if (N <= 2048 && kind == RPGP_KIND_RBF && group == 1 && !wts && !gp) {      // launch-latency regime: one workgroup
     hipLaunchKernelGGL(pivchol_kernel, dim3(1), dim3(1024), 0, st, Z, L, diag_work, (int)N, ldz, ncols, rank, scale);
+    return launch_status();
+  }
+  // RPGP_PIVCHOL_COOP=1 (opt-in, read per call: tools/r5_pivchol_ab.py alternates): measured 124 / 134 / 141 / 164 us against
+  // 137 / 138 / 139 / 142 us for the per-step launches at N = 4k / 7k / 15k / 33k — a grid barrier with its agent-scope release
+  // and acquire costs ~8 us, a dependent launch boundary 1.5 - 2 us (MI355X_MICROARCH.md, persistent-kernel price list)
+  const char *env_coop = getenv("RPGP_PIVCHOL_COOP");
+  const bool coop = env_coop ? env_coop[0] == '1' : false;
+  if (coop && N <= 32768 && !gp && rank <= 16) {   // one cooperative launch: <= 128 co-resident workgroups, grid barriers
+    float *cp = diag_work + N;
+    unsigned *bar = reinterpret_cast<unsigned *>(cp + 2047);
+    RPGP_CHECK(hipMemsetAsync(bar, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(pivchol_coop_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, Z, L, cp,
+                       reinterpret_cast<int *>(cp + 1024), bar, (int)N, ldz, ncols, rank, scale, d0, kind, group, ncomp,
+                       wts);
     return launch_status();
   }
   int nb = (int)((N + 255) / 256);

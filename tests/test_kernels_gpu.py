@@ -355,6 +355,34 @@ def test_family_pivoted_cholesky_matches_generic(gpu_device, kind, group, cols, 
     assert Lf is not None and torch.allclose(Lf, Lg, rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("N,J,rank", [(2049, 20, 15), (7372, 20, 15), (14939, 20, 15), (32768, 8, 16), (32769, 3, 15),
+                                      (5000, 40, 15), (4097, 3, 1), (9999, 64, 7)])
+def test_pivoted_cholesky_cooperative_launch_is_bitwise_the_per_step_form(gpu_device, N, J, rank, monkeypatch):
+    """One cooperative launch with grid barriers (2048 < N <= 32768, rank <= 16; opt-in RPGP_PIVCHOL_COOP=1) against one launch
+    per greedy step (default): the same pivots and the same factor bit for bit, for coordinates held in LDS (J <= 32) and read
+    from memory (J > 32), repeated calls on one scratch buffer, sizes on both sides of the limits; and the family form."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + J)
+    Z = torch.from_numpy((rng.standard_normal((N, J)) * 0.8).astype(np.float32)).to(gpu_device)
+    out = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("RPGP_PIVCHOL_COOP", mode)
+        L = ops.pivoted_cholesky(Z, 0.7 / J, rank)
+        assert torch.isfinite(L).all()
+        if mode in out:
+            assert torch.equal(out[mode], L)
+        out[mode] = L
+    assert torch.equal(out["0"], out["1"])
+    if J == 20 and N <= 15000:
+        from rpgp_amd.operators import FamilyAdditiveOperator
+        w = torch.from_numpy(rng.uniform(0.3, 1.0, size=J).astype(np.float32)).to(gpu_device)
+        fam = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("RPGP_PIVCHOL_COOP", mode)
+            fam[mode] = FamilyAdditiveOperator(Z, None, torch.tensor(0.8, device=gpu_device), w, "Matern", 1).fused_pivoted_cholesky(12)
+        assert fam["1"] is not None and torch.equal(fam["0"], fam["1"])
+
+
 @pytest.mark.parametrize("N,T,world", [(3000, 1, 3), (20000, 1, 8), (5000, 11, 4), (700, 4, 2), (300, 1, 8)])
 def test_pair_sharded_mvm_sums_to_full(gpu_device, N, T, world):
     """Pair-sharding (rpgp_mvm_sym[_prepared]_range): the per-rank partial products sum to the full MVM, for the

@@ -4458,7 +4458,7 @@ int rpgp_init(void) {
   hipLaunchKernelGGL(probe_rotate_kernel, dim3(1), dim3(64), 0, 0, d);
   int h[64];
   hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-  hipFree(d);
+  (void)hipFree(d);
   if (e != hipSuccess) return (int)e;
   if (h[0] == 1 && h[63] == 0) g_rotdir = 1;
   else if (h[0] == 63 && h[1] == 0) g_rotdir = -1;
@@ -4525,7 +4525,7 @@ int rpgp_project_grad(const float *X, const float *G, float *dPeff, int64_t N, i
     double *gpart = nullptr;
     RPGP_CHECK(hipMallocAsync((void **)&gpart, rpgp_internal::gram_part_bytes(d, J), st));
     const int grc = rpgp_internal::gram_launch(X, d, G, J, (long long)N, d, J, nullptr, dPeff, gpart, st);
-    hipFreeAsync(gpart, st);
+    (void)hipFreeAsync(gpart, st);
     return grc;
   }
   const int nblk = (int)((N + 511) / 512 < 1024 ? (N + 511) / 512 : 1024);
@@ -4536,7 +4536,7 @@ int rpgp_project_grad(const float *X, const float *G, float *dPeff, int64_t N, i
                      rows_per_block);
   hipLaunchKernelGGL(sum_partials_kernel, dim3((d * J + 255) / 256), dim3(256), 0, st, part, dPeff, d * J, nblk, 1.0f);
   int rc = launch_status();
-  hipFreeAsync(part, st);
+  (void)hipFreeAsync(part, st);
   return rc;
 }
 

@@ -1045,7 +1045,17 @@ __global__ __launch_bounds__(256) void symk_build_kernel(const float *__restrict
 // Cached symmetric product: the loop nest of mvm_fact_kernel with the kernel value taken from the cache.  The wave's
 // stream is requested D steps (of 4 rotation steps x R rows = R KB) ahead through a register ring, across subtile and
 // LDS-stage boundaries.
-template <int TT, int R>
+// Loads of the packed cache: nontemporal for a cache that is streamed once per product; DEFAULT policy for one that fits the
+// 256 MB Infinity Cache, where the products of one solve re-read it back to back (symk_nt_loads below; measured
+// tools/r5_symk_nt_ab.py, T = 11: 39 MB 24.6 -> 21.9 us, 118 MB 37.7 -> 35.4, 234 MB 59.9 -> 52.4, thin T = 1 46.1 -> 41.4; the other
+// way from ~300 MB: 464 MB 106 -> 113 us, 5 GB 947 -> 1039).
+template <bool NT>
+__device__ __forceinline__ float4v symk_tile_load(const float4v *p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
+template <int TT, int R, bool NTL = true>
 __global__ __launch_bounds__(256) void symk_mvm_kernel(const float4v *__restrict__ cache, const float *__restrict__ V,
                                                        float *__restrict__ slabR, float *__restrict__ slabT, int N, int ldv,
                                                        int t0, int tcnt, int chunk_cols, int rotdir, int accumulate, int w0,
@@ -1087,7 +1097,7 @@ __global__ __launch_bounds__(256) void symk_mvm_kernel(const float4v *__restrict
   for (int d = 0; d < D; ++d) {
     const float4v *q = step_ptr(d);
 #pragma unroll
-    for (int r = 0; r < R; ++r) ring[d][r] = __builtin_nontemporal_load(q + r * 64);
+    for (int r = 0; r < R; ++r) ring[d][r] = symk_tile_load<NTL>(q + r * 64);
   }
   int n = 0;
   // the stage's right-hand sides are requested one stage ahead, from clamped addresses (a load under a condition compiles to
@@ -1125,7 +1135,7 @@ __global__ __launch_bounds__(256) void symk_mvm_kernel(const float4v *__restrict
           {
             const float4v *q = step_ptr(n + D);
 #pragma unroll
-            for (int r = 0; r < R; ++r) ring[k][r] = __builtin_nontemporal_load(q + r * 64);
+            for (int r = 0; r < R; ++r) ring[k][r] = symk_tile_load<NTL>(q + r * 64);
           }
           ++n;
           if (doT) {
@@ -1296,12 +1306,12 @@ __global__ __launch_bounds__(256) void symk_build_tile_kernel(const float *__res
 // One pair of row tiles (2 RT2, 2 RT2 + 1) of a subtile, then the next pair (compile-time recursion: a `#pragma unroll`
 // loop over the pairs was kept rolled by hipcc, which then rotated the accumulator arrays through registers with ~1000
 // v_mov per subtile).
-template <int R, bool DOT, int RT2>
+template <int R, bool DOT, int RT2, bool NT = true>
 __device__ __forceinline__ void symk_tile_rows(const float4v *wp, float4v (&ring)[8], const float (&acol)[4][4],
                                                const float (&arow)[4 * R][4], float *scr, int woff, int roff,
                                                floatx4m (&accR)[4 * R], floatx4m (&accT)[4]) {
-  constexpr int NRT = 4 * R, NT = 4 * NRT, D = 8;
-  constexpr size_t SUB = (size_t)4 * NT * 64;
+  constexpr int NRT = 4 * R, NTL = 4 * NRT, D = 8;
+  constexpr size_t SUB = (size_t)4 * NTL * 64;
   if constexpr (RT2 < NRT / 2) {
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
@@ -1309,8 +1319,8 @@ __device__ __forceinline__ void symk_tile_rows(const float4v *wp, float4v (&ring
       const float4v kA = ring[2 * pp], kB = ring[2 * pp + 1];
       {
         const int m0 = RT2 * 8 + 2 * pp + D, m1 = m0 + 1;            // slots requested now (>= NT: next subtile)
-        ring[2 * pp] = __builtin_nontemporal_load(wp + (m0 < NT ? (size_t)m0 * 64 : SUB + (size_t)(m0 - NT) * 64));
-        ring[2 * pp + 1] = __builtin_nontemporal_load(wp + (m1 < NT ? (size_t)m1 * 64 : SUB + (size_t)(m1 - NT) * 64));
+        ring[2 * pp] = symk_tile_load<NT>(wp + (m0 < NTL ? (size_t)m0 * 64 : SUB + (size_t)(m0 - NTL) * 64));
+        ring[2 * pp + 1] = symk_tile_load<NT>(wp + (m1 < NTL ? (size_t)m1 * 64 : SUB + (size_t)(m1 - NTL) * 64));
       }
       __builtin_amdgcn_sched_barrier(0);       // keep the requests D tiles ahead (hipcc sinks them to their first use)
       if constexpr (DOT) {
@@ -1343,7 +1353,7 @@ __device__ __forceinline__ void symk_tile_rows(const float4v *wp, float4v (&ring
         }
       }
     }
-    symk_tile_rows<R, DOT, RT2 + 1>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
+    symk_tile_rows<R, DOT, RT2 + 1, NT>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
   }
 }
 
@@ -1487,7 +1497,7 @@ __global__ __launch_bounds__(256, 2) void symk_mvm_tile_kernel(const float4v *__
 //  (A first form without any staging — every wave requesting its own sixteen A operands from global memory one subtile
 //  ahead — needs 16 more registers than the 256 there are: the reloads put an `s_waitcnt vmcnt(0)` at the head of every
 //  subtile, which drains the tile ring.)
-template <int R>
+template <int R, bool NTLOAD = true>
 __global__ __launch_bounds__(256, 2) void symk_mvm_tile2_kernel(const float4v *__restrict__ cache, const float *__restrict__ V,
                                                              float *__restrict__ slabR, float *__restrict__ slabT, int N,
                                                              int ldv, int t0, int tcnt, int chunk_cols, int w0, int rb_first,
@@ -1531,7 +1541,7 @@ __global__ __launch_bounds__(256, 2) void symk_mvm_tile2_kernel(const float4v *_
   constexpr size_t SUB = (size_t)4 * NT * 64;
   float4v ring[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) ring[d] = __builtin_nontemporal_load(wp + (size_t)d * 64);
+  for (int d = 0; d < D; ++d) ring[d] = symk_tile_load<NTLOAD>(wp + (size_t)d * 64);
   float vpre[4];
   auto v_request = [&](int c0n) {
 #pragma unroll
@@ -1588,7 +1598,7 @@ __global__ __launch_bounds__(256, 2) void symk_mvm_tile2_kernel(const float4v *_
     // whole) run the transposed MFMAs too and drop their sums — BR / N of the matrix work (1 % at N = 50k, 7 % at 7k) on a
     // pipe that is not the bound, against two copies of the tile code whose register maps hipcc reconciles with moves of the
     // whole ring (and an `s_waitcnt vmcnt(0)`) on the loop's back edge.
-    symk_tile_rows<R, true, 0>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
+    symk_tile_rows<R, true, 0, NTLOAD>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -4361,6 +4371,12 @@ inline SymkPlan symk_plan(int64_t N, int world, int rank, bool wide = false) {
 }
 // (+ one subtile of padding: the wide product's requests run a few tiles past a workgroup's last subtile)
 inline size_t symk_bytes(const SymkPlan &sp) { return (size_t)(sp.sub1 - sp.sub0 + 1) * sp.p.BR * 64 * sizeof(float); }
+// nontemporal loads unless the (rank's share of the) cache fits the Infinity Cache; RPGP_SYMK_NT=0/1 forces (read per call: A/B)
+inline bool symk_nt_loads(const SymkPlan &sp) {
+  const char *e = getenv("RPGP_SYMK_NT");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return symk_bytes(sp) > (size_t)300000000;      // (277 MB: default policy 60.9 us against 64.6; 464 MB: 113 against 106)
+}
 inline int symk_t_piece(int remaining) {
   if (remaining > 4) return 12;                        // (an exact T = 11 instantiation measured slower than the padded 12)
   if (remaining > 1) return 4;
@@ -4397,12 +4413,16 @@ inline int symk_launch_mvm_tile(const SymkPlan &sp, const float4v *cache, const 
   const char *env_v2 = getenv("RPGP_SYMK_WIDE_V2");
   const bool one_barrier = env_v2 ? env_v2[0] != '0' : true;
   if (one_barrier) {
-    if (sp.p.R == 2)
-      hipLaunchKernelGGL((symk_mvm_tile2_kernel<2>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
-                         sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
-    else
-      hipLaunchKernelGGL((symk_mvm_tile2_kernel<1>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
-                         sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
+    const bool nt = symk_nt_loads(sp);
+#define RPGP_SYMK_T2(RR, NTF)                                                                                        \
+  hipLaunchKernelGGL((symk_mvm_tile2_kernel<RR, NTF>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,   \
+                     sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0)
+    if (sp.p.R == 2) {
+      if (nt) RPGP_SYMK_T2(2, true); else RPGP_SYMK_T2(2, false);
+    } else {
+      if (nt) RPGP_SYMK_T2(1, true); else RPGP_SYMK_T2(1, false);
+    }
+#undef RPGP_SYMK_T2
     return launch_status();
   }
   if (sp.p.R == 2)
@@ -4417,12 +4437,16 @@ template <int TT>
 int symk_launch_mvm(const SymkPlan &sp, const float4v *cache, const float *V, float *slabR, float *slabT, int N, int T,
                     int t0, int tcnt, hipStream_t st) {
   dim3 grid(sp.p.w1 - sp.p.w0), block(256);
-  if (sp.p.R == 2)
-    hipLaunchKernelGGL((symk_mvm_kernel<TT, 2>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
-                       sp.p.chunk_cols, g_rotdir, 0, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
-  else
-    hipLaunchKernelGGL((symk_mvm_kernel<TT, 1>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
-                       sp.p.chunk_cols, g_rotdir, 0, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
+  const bool nt = symk_nt_loads(sp);
+#define RPGP_SYMK_THIN(RR, NTF)                                                                                      \
+  hipLaunchKernelGGL((symk_mvm_kernel<TT, RR, NTF>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,     \
+                     sp.p.chunk_cols, g_rotdir, 0, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0)
+  if (sp.p.R == 2) {
+    if (nt) RPGP_SYMK_THIN(2, true); else RPGP_SYMK_THIN(2, false);
+  } else {
+    if (nt) RPGP_SYMK_THIN(1, true); else RPGP_SYMK_THIN(1, false);
+  }
+#undef RPGP_SYMK_THIN
   return launch_status();
 }
 }  // namespace

@@ -223,6 +223,14 @@ def test_symcache_wide_kernels_bitwise_interchangeable(gpu_device, N, T, shard, 
         outs[mode] = ops.symcache_mvm(cache, Vt, 0.2, 0.3)
     assert torch.isfinite(outs["1"]).all()
     assert torch.equal(outs["0"], outs["1"])
+    # the load policy (nontemporal / default: chosen by the cache's size) is invisible in the result, in both layouts
+    thin = ops.SymCache(Zt, wide=False, shard=shard)
+    ref_thin = ops.symcache_mvm(thin, Vt[:, :3].contiguous(), 0.2, 0.3)
+    for nt in ("0", "1"):
+        monkeypatch.setenv("RPGP_SYMK_NT", nt)
+        assert torch.equal(ops.symcache_mvm(cache, Vt, 0.2, 0.3), outs["1"])
+        assert torch.equal(ops.symcache_mvm(thin, Vt[:, :3].contiguous(), 0.2, 0.3), ref_thin)
+    monkeypatch.delenv("RPGP_SYMK_NT")
     if shard is None:
         assert _rel(outs["1"].cpu().numpy(), orc.mvm(Z, Z, V, 0.2, 0.3)) < 2e-6
 

@@ -101,7 +101,10 @@ def _native_step_ok(model, target, raw_ls):
 
 class _FusedMLL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target):
+    def forward(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target, sign=1.0):
+        # sign = -1: the training LOSS -mll as the node's value (fitting/optimizing.py:70 negates the objective; as a separate
+        # tensor operation that is a launch each way plus two autograd nodes per step: exact either way, -(a x + c) = (-a) x - c)
+        ctx.sign = sign
         if _native_step_ok(model, target, raw_ls):
             done = _FusedMLL._forward_native(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target)
             if done is not None:
@@ -129,7 +132,7 @@ class _FusedMLL(torch.autograd.Function):
             inv_quad, logdet = InvQuadLogDet.forward(st, Z, os_, noise, r, op, None)
             lp, dlp = _prior(likelihood, noise_f)
             # mll = (-0.5 (inv_quad + logdet + n log 2 pi) + log p(sigma^2)) / n      (models.ExactMarginalLogLikelihood)
-            value = (inv_quad + logdet) * (-0.5 / n) + ((-0.5 * n * LOG2PI + lp) / n)
+            value = (inv_quad + logdet) * (sign * -0.5 / n) + (sign * (-0.5 * n * LOG2PI + lp) / n)
         ctx.st, ctx.n, ctx.dlp, ctx.prescale = st, n, dlp, pk.prescale
         ctx.zfac = bk.input_scale_factor()            # the operator acts on zfac * Z (inner lengthscale of the base kernel)
         ctx.X, ctx.P, ctx.ls, ctx.col = X, P, ls, col
@@ -174,7 +177,8 @@ class _FusedMLL(torch.autograd.Function):
             logdet = float(slq_logdet(hist, n)) + pre.logdet()
             lp, dlp = _prior(likelihood, noise_f)
             # mll = (-0.5 (inv_quad + logdet + n log 2 pi) + log p(sigma^2)) / n      (models.ExactMarginalLogLikelihood)
-            out = be.step_value(full_rhs, solves, p, logdet, -0.5 / n, (-0.5 * n * LOG2PI + lp) / n)
+            sign = ctx.sign
+            out = be.step_value(full_rhs, solves, p, logdet, sign * -0.5 / n, sign * (-0.5 * n * LOG2PI + lp) / n)
         ctx.native = True
         ctx.n, ctx.dlp, ctx.prescale, ctx.zfac = n, dlp, pk.prescale, bk.input_scale_factor()
         ctx.X, ctx.W, ctx.hyp, ctx.op, ctx.pre = X, W, hyp, op, pre
@@ -189,7 +193,8 @@ class _FusedMLL(torch.autograd.Function):
         with torch.no_grad():
             g = g.reshape(1).contiguous()
             pre_probes = ctx.pre.solve(ctx.probes)
-            left, right, part, nparts = be.step_lr(ctx.solves, pre_probes, g, -0.5 / n)
+            sign = ctx.sign
+            left, right, part, nparts = be.step_lr(ctx.solves, pre_probes, g, sign * -0.5 / n)
             op, gs_scale = ctx.op, 1.0
             from .operators import AdditiveRPOperator
             if type(op) is AdditiveRPOperator and (op.shard is None or op.shard.world_size <= 1):
@@ -202,10 +207,10 @@ class _FusedMLL(torch.autograd.Function):
             dPeff = be.project_grad(ctx.X, gZ.contiguous())                              # d x J:  Z = X Peff
             n_ls = (ctx.hyp.numel() - 8) // 2
             g_ls, g_os, g_nz, g_mu = be.step_hyper_backward(dPeff, ctx.W, n_ls, ctx.prescale, ctx.zfac, ctx.hyp,
-                                                            gs.reshape(1), part, nparts, g, -0.5 / n, ctx.dlp / n,
-                                                            gs_scale=gs_scale)
+                                                            gs.reshape(1), part, nparts, g, sign * -0.5 / n,
+                                                            sign * ctx.dlp / n, gs_scale=gs_scale)
         s_ls, s_os, s_nz, s_mu = ctx.shapes
-        return g_ls.reshape(s_ls), g_os.reshape(s_os), g_nz.reshape(s_nz), g_mu.reshape(s_mu), None, None, None
+        return g_ls.reshape(s_ls), g_os.reshape(s_os), g_nz.reshape(s_nz), g_mu.reshape(s_mu), None, None, None, None
 
     @staticmethod
     def backward(ctx, g):
@@ -215,7 +220,8 @@ class _FusedMLL(torch.autograd.Function):
         raw_ls, raw_os, raw_noise = ctx.saved_tensors
         n = ctx.n
         with torch.no_grad():
-            gq = g.reshape(()) * (-0.5 / n)                        # d mll / d inv_quad = d mll / d logdet
+            sign = ctx.sign
+            gq = g.reshape(()) * (sign * -0.5 / n)                 # d (sign mll) / d inv_quad = d (sign mll) / d logdet
             gZ, gs, gn, gr, _, _ = InvQuadLogDet.backward(ctx.st, gq, gq)
             be = _backend.get_backend()
             if ctx.zfac != 1.0:
@@ -229,14 +235,14 @@ class _FusedMLL(torch.autograd.Function):
                 g_ls = -t.sum().reshape(1) / (ctx.ls * ctx.ls)
             g_raw_ls = (g_ls * torch.sigmoid(raw_ls.reshape(-1))).reshape(raw_ls.shape)
             g_raw_os = (gs.reshape(()) * torch.sigmoid(raw_os.reshape(()))).reshape(raw_os.shape)
-            g_noise = gn.reshape(()) + g.reshape(()) * (ctx.dlp / n) if ctx.dlp != 0.0 else gn.reshape(())
+            g_noise = gn.reshape(()) + g.reshape(()) * (sign * ctx.dlp / n) if ctx.dlp != 0.0 else gn.reshape(())
             g_raw_noise = (g_noise * torch.sigmoid(raw_noise.reshape(()))).reshape(raw_noise.shape)
             g_mean = (-gr.sum()).reshape(1)                         # r = y - c
-        return g_raw_ls, g_raw_os, g_raw_noise, g_mean, None, None, None
+        return g_raw_ls, g_raw_os, g_raw_noise, g_mean, None, None, None, None
 
 
-def evaluate(model, likelihood, target):
-    """mll(model(X), y) per datum (ExactMarginalLogLikelihood's value) as one autograd node."""
+def evaluate(model, likelihood, target, negate=False):
+    """mll(model(X), y) per datum (ExactMarginalLogLikelihood's value) as one autograd node; `negate`: the loss -mll."""
     pk = model.covar_module.base_kernel
     return _FusedMLL.apply(pk.raw_lengthscale, model.covar_module.raw_outputscale, likelihood.raw_noise,
-                           model.mean_module.constant, model, likelihood, target)
+                           model.mean_module.constant, model, likelihood, target, -1.0 if negate else 1.0)

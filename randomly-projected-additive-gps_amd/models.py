@@ -618,6 +618,15 @@ class ExactMarginalLogLikelihood(nn.Module):
         self.likelihood = likelihood
         self.model = model
 
+    def negative(self, output, target):
+        """-mll(output, target): the training loss of fitting/optimizing.py:70.  For the fused objective the sign rides inside
+        the one autograd node (same bits as negating its value: the separate negation was a launch each way per step)."""
+        if isinstance(output, LazyPrior) and not output.materialized:
+            from . import fused_mll, settings
+            if output._model is self.model and self.likelihood is self.model.likelihood and settings.fused_training.on():
+                return fused_mll.evaluate(self.model, self.likelihood, target, negate=True)
+        return -self(output, target)
+
     def forward(self, output, target):
         n = target.shape[0]
         if isinstance(output, LazyPrior) and not output.materialized:

@@ -271,7 +271,11 @@ def train_to_convergence(model, xs, ys, optimizer=None, lr=0.1, objective=None, 
         def closure():
             optimizer_.zero_grad()
             output = model(xs)
-            loss = objective(output, ys) if isloss else -objective(output, ys)
+            if isloss:
+                loss = objective(output, ys)
+            else:                         # (an objective that can negate itself does: models.ExactMarginalLogLikelihood.negative)
+                neg = getattr(objective, "negative", None)
+                loss = neg(output, ys) if neg is not None else -objective(output, ys)
             loss.backward()
             return loss
 

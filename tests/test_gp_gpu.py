@@ -364,6 +364,40 @@ def test_step_kernels_match_torch_operations_and_generic_path(gpu_device, ski):
             assert (gk - gref).abs().max() < 2e-4 * gref.abs().max() + 1e-7, (mode, k)
 
 
+@pytest.mark.parametrize("ski", [False, True])
+@pytest.mark.parametrize("kernels", [True, False])
+def test_negated_objective_on_the_step_kernels_is_bitwise_the_negation(gpu_device, ski, kernels):
+    """mll.negative(...) — the loss train_to_convergence forms, sign inside the fused node — against -mll(...): identical bits
+    for the value and every gradient, on the step kernels and on the torch form of the fused node."""
+    from rpgp_amd import settings
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    gen = torch.Generator().manual_seed(6)
+    N, d, J = 3000, 5, (3 if ski else 10)
+    X = torch.randn(N, d, generator=gen)
+    y = torch.sin(X).sum(1) + 0.1 * torch.randn(N, generator=gen)
+    X, y = X.to(gpu_device), ((y - y.mean()) / y.std()).to(gpu_device)
+    res = {}
+    for folded in (True, False):
+        torch.manual_seed(4)
+        np.random.seed(4)
+        model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                     prescale=True, space_proj=True, ski=ski,
+                                     ski_options={"grid_size": 512, "num_dims": 1} if ski else None)
+        model = model.to(gpu_device)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        model.train()
+        with settings.step_kernels(kernels), settings.deterministic_probes(True), settings.cg_tolerance(1e-3):
+            out = model(X)
+            loss = mll.negative(out, y) if folded else -mll(out, y)
+            loss.backward()
+        res[folded] = (loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][0], res[False][0])
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) >= 4
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+
+
 def test_blocked_fp16x3_cholesky_factor(gpu_device):
     """precond.blocked_cholesky (round 5): the blocked float32 factorisation with fp16x3 trailing updates that the mixed-precision
     covariance solve and the Cholesky-preconditioned wide CG use beyond N = 16k.  Its factor is as accurate as the library's

@@ -608,6 +608,40 @@ def test_fused_objective_equals_generic_path(oracle_backend, prescale, regime):
     assert abs(-mll(out, y).item() - res[False][0]) < (5e-2 if regime == "cg" else 1e-6) * abs(res[False][0]) + 1e-7
 
 
+@pytest.mark.parametrize("regime", ["chol", "cg"])
+def test_negated_objective_is_bitwise_the_negation(oracle_backend, regime):
+    """ExactMarginalLogLikelihood.negative (the sign folded into the fused node: what train_to_convergence calls) against
+    -mll(...): the same bits for the value and for the four gradients; for a materialised prior it IS -mll(...)."""
+    import contextlib
+    from rpgp_amd import settings
+    X, y, P, ls, noise, s = _problem(N=140, d=5, J=7, seed=13, noise=0.25)
+    res = {}
+    for folded in (True, False):
+        model, lik, mll = _build_model(X, y, P, ls, noise, s, True)
+        model.train()
+        ctxs = [settings.deterministic_probes(True)]
+        if regime == "cg":
+            ctxs += [settings.max_cholesky_size(10), settings.min_preconditioning_size(50), settings.cg_tolerance(1e-8),
+                     settings.max_cg_iterations(500)]
+        with contextlib.ExitStack() as es:
+            for c in ctxs:
+                es.enter_context(c)
+            out = model(X)
+            loss = mll.negative(out, y) if folded else -mll(out, y)
+            loss.backward()
+        res[folded] = (loss.detach().clone(), [p.grad.clone() for p in (model.covar_module.base_kernel.raw_lengthscale,
+                                                                          model.covar_module.raw_outputscale, lik.raw_noise,
+                                                                          model.mean_module.constant)])
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b), (a, b)
+    model, lik, mll = _build_model(X, y, P, ls, noise, s, True)
+    model.train()
+    out = model(X)
+    _ = out.mean                                            # materialised: the generic path
+    assert torch.equal(mll.negative(out, y), -mll(out, y))
+
+
 def test_gpytorch_layout_state_dict_round_trip():
     """training.gpytorch_state_dict / load_gpytorch_state_dict: the reference's checkpoint key layout
     (training_routines.py:37-44; keys from memory of GPyTorch, see the table in training.py) round-trips."""

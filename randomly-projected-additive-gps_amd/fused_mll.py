@@ -99,6 +99,28 @@ def _native_step_ok(model, target, raw_ls):
             and settings.num_trace_samples.value() <= 15 and settings.step_kernels.on())
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _overlap_ok(op, Z):
+    """Build the cached operator beside the preconditioner?  Only where a cache WILL be built: the plain float32 exact operator
+    on a HIP device under the cached-K rule (inv_quad_logdet.solve_operator).  Opt-in (settings.overlap_cache_build or
+    RPGP_OVERLAP_BUILD=1): measured a draw, see settings.py."""
+    import os
+    from .operators import AdditiveRPOperator
+    return ((settings.overlap_cache_build.on() or os.environ.get("RPGP_OVERLAP_BUILD", "0") == "1") and Z.is_cuda
+            and type(op) is AdditiveRPOperator and Z.dtype == torch.float32 and hasattr(op, "to_symcache")
+            and settings.use_cached_kernel(Z.shape[0], Z.device, 2.0))
+
+
 class _FusedMLL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target, sign=1.0):
@@ -161,15 +183,32 @@ class _FusedMLL(torch.autograd.Function):
             Z = be.project(X, Peff)
             op = bk.operator(Z, None, outputscale=os_, shard=None)
             op._noise_host = noise_f
+            khat = AddedDiagOperator(op, noise, noise_value=noise_f)
+            # The cached form of the operator (packed symmetric cache: one compute-bound launch that fills the chip) is built on
+            # a side stream while this one builds the preconditioner (rank + 4 latency-bound launches of a few workgroups
+            # each): both depend on Z only.  The cache's memory comes from the side stream's pool; `record_stream` tells the
+            # allocator that this stream uses it too (the solve), and this stream waits for the build's event before the solve.
+            built = side_done = None
+            if _overlap_ok(op, Z):
+                main = torch.cuda.current_stream(Z.device)
+                side = _side_stream(Z.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    built = solve_operator(op, khat, Z, noise_f, p + 1)
+                    side_done = side.record_event()
+                cache = getattr(built[1], "cache", None)
+                if cache is not None and hasattr(cache, "buf"):
+                    cache.buf.record_stream(main)
             pre = build_preconditioner(op, noise_f, settings)
+            if side_done is not None:
+                torch.cuda.current_stream(Z.device).wait_event(side_done)
             if not isinstance(pre, WoodburyPreconditioner) or pre.L.dtype != torch.float32 or pre.k > 64:
                 return None
             gen = _probe_generator(Z.device)
             e1 = torch.randn(pre.k, p, generator=gen, device=Z.device, dtype=Z.dtype)      # (the draws of pre.sample, same order)
             e2 = torch.randn(n, p, generator=gen, device=Z.device, dtype=Z.dtype)
             full_rhs = be.step_probes(pre.L, e1, e2, math.sqrt(noise_f), target, hyp[2:3])      # [z | y - c], unnormalised
-            khat = AddedDiagOperator(op, noise, noise_value=noise_f)
-            matmul, native_op, _ = solve_operator(op, khat, Z, noise_f, p + 1)
+            matmul, native_op, _ = built if built is not None else solve_operator(op, khat, Z, noise_f, p + 1)
             solves, hist = linear_cg(matmul, full_rhs, n_tridiag=p, operator=native_op,
                                      tolerance=settings.cg_tolerance.value(), max_iter=settings.max_cg_iterations.value(),
                                      max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),

@@ -398,6 +398,44 @@ def test_negated_objective_on_the_step_kernels_is_bitwise_the_negation(gpu_devic
         assert torch.equal(res[True][1][k], res[False][1][k]), k
 
 
+def test_cache_build_on_the_side_stream_changes_nothing(gpu_device):
+    """settings.overlap_cache_build: the packed cache built on a side stream beside the preconditioner build — the same
+    kernels on the same data, so the same loss and gradients bit for bit over several steps (and the allocator's reuse of
+    the cache's memory from step to step is safe)."""
+    from rpgp_amd import settings
+    from rpgp_amd.training import create_exact_gp, make_optimizer
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    gen = torch.Generator().manual_seed(8)
+    N, d, J = 4500, 6, 20
+    X = torch.randn(N, d, generator=gen)
+    y = torch.sin(X).sum(1) + 0.1 * torch.randn(N, generator=gen)
+    X, y = X.to(gpu_device), ((y - y.mean()) / y.std()).to(gpu_device)
+    res = {}
+    for overlap in (True, False):
+        torch.manual_seed(4)
+        np.random.seed(4)
+        model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                     prescale=True, space_proj=False)
+        model = model.to(gpu_device)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        opt = make_optimizer(torch.optim.Adam, [p for p in model.parameters() if p.requires_grad], 0.05)
+        model.train()
+        losses = []
+        with settings.overlap_cache_build(overlap), settings.deterministic_probes(True), settings.cg_tolerance(0.05), \
+                settings.cache_kernel(True):
+            for _ in range(6):
+                opt.zero_grad()
+                loss = mll.negative(model(X), y)
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach().clone())
+        res[overlap] = (torch.stack(losses), [p.detach().clone() for p in model.parameters()])
+    assert torch.isfinite(res[True][0]).all()
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+
+
 def test_blocked_fp16x3_cholesky_factor(gpu_device):
     """precond.blocked_cholesky (round 5): the blocked float32 factorisation with fp16x3 trailing updates that the mixed-precision
     covariance solve and the Cholesky-preconditioned wide CG use beyond N = 16k.  Its factor is as accurate as the library's

@@ -3870,7 +3870,7 @@ inline int chunks_of(const TilePlan &p, int64_t N, bool sym, int b) {
 // `world`-way split: the chunk size is chosen for the per-rank share of the pairs so that every rank still launches
 // a few thousand workgroups; rank r gets workgroups [total*r/world, total*(r+1)/world).
 inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, int rank = 0, bool r1 = false,
-                          int br_override = 0, double target_wgs = 4608.0, bool taper = false) {
+                          int br_override = 0, double target_wgs = 4608.0, bool taper = false, int chunk_override = 0) {
   TilePlan p;
   // two rows per lane halve the LDS traffic per pair (measured: one row per lane is 20 % slower even at T = 11)
   // measured (tools/time_small.py): with T > 4 right-hand sides two rows per lane win from N ~ 4k up (362 vs 429 us at
@@ -3884,7 +3884,7 @@ inline TilePlan make_plan(int64_t M, int64_t N, bool sym, int T, int world = 1, 
   }
   p.nrb = (int)((M + p.BR - 1) / p.BR);
   const double pairs = (sym ? 0.5 * (double)M * (double)N : (double)M * (double)N) / (double)(world > 0 ? world : 1);
-  p.chunk_cols = plan_chunk(pairs, p.BR, M >= 16384, target_wgs);
+  p.chunk_cols = chunk_override > 0 ? chunk_override : plan_chunk(pairs, p.BR, M >= 16384, target_wgs);
   p.taper = rpgp_internal::Taper{p.nrb, p.nrb, p.nrb};
   if (taper && sym && world <= 1 && M == N && p.chunk_cols >= 256) {
     // remaining share of the pairs after row block b is ((N - b BR) / N)^2: half-size chunks for the last 20 % of the work,
@@ -4348,6 +4348,26 @@ inline long long symk_wg_subtile(const TilePlan &p, int64_t N, int lin) {
   }
   return symk_host_first_subtile(p.nrb, N, p.BR);
 }
+// One row-tile set per wave (R = 1: 256-row blocks) for a whole cache up to this size — squarer workgroup tiles and twice the
+// workgroups to spread over the chip (tools/experiments/r5_symk_r1_sweep.py, profiles/r5b_symk_r1_sweep.jsonl: wide T = 11
+// N = 4k 22.6 -> 20.5 us, 5.5k 25.6 -> 22.0, 7.4k 35.0 -> 32.2, 11k 56.8 -> 53.8, 15k 107.6 -> 100.6; thin T = 1 15k 86.1 -> 77.1).
+// The LAYOUT of the cache follows R, so every entry point asks this one function.
+constexpr int64_t kSymkR1Max = 16384;
+inline bool symk_r1(int64_t N, int world) { return world <= 1 && N <= kSymkR1Max; }
+
+// Smallest chunk (multiple of 64 columns) whose workgroups all fit ONE resident round of `slots`: with every workgroup
+// running at once the product's time is the longest workgroup's, and a handful of workgroups beyond the slots wait for a
+// whole workgroup time (N = 14939: 523 workgroups of 896 columns 123 us, 465 of 1024 columns 101 us).
+inline int symk_one_round_chunk(int64_t N, int BR, int slots) {
+  const int nrb = (int)((N + BR - 1) / BR);
+  for (int c = 64; c <= 8192; c += 64) {
+    long long total = 0;
+    for (int b = 0; b < nrb; ++b) total += (N - (long long)b * BR + c - 1) / c;
+    if (total <= slots) return c;
+  }
+  return 8192;
+}
+
 inline SymkPlan symk_plan(int64_t N, int world, int rank, bool wide = false) {
   SymkPlan sp;
   // A cached workgroup has no exponentials to hide its prologue (row block of V, ring start-up) and epilogue (slabs)
@@ -4355,16 +4375,19 @@ inline SymkPlan symk_plan(int64_t N, int world, int rank, bool wide = false) {
   // (N = 15k: 1000, T = 11 product 0.152 ms against 0.199 ms with the fused sweep's 4600; N = 50k: 3600, 1.31 ms).
   double wgs = (double)N / 14.0;
   wgs = wgs < 512.0 ? 512.0 : (wgs > 4608.0 ? 4608.0 : wgs);
+  const bool r1 = symk_r1(N, world);
+  int chunk = 0;
   if (wide && world <= 1) {
-    // The matrix-core (wide) product keeps two workgroups per CU resident (512 slots) and a workgroup's prologue / slabs cost
-    // more than in the thin form: up to N ~ 28k ONE round of ~500 long workgroups wins, above that ~N / 28 (late round 3,
-    // same-process sweeps, T = 11 product + slab reduce: N = 11k 81 -> 67 us, 15k 120 -> 111, 20k 188 -> 173, 25k 279 -> 252,
-    // 35k 506 -> 487, 50k 952 -> 937).  The subtile layout of the cache depends on N only, so the build and the product of a
-    // whole (unsharded) cache may be chunked differently; sharded caches keep one rule for both (their byte ranges follow it).
-    wgs = N <= 28000 ? 500.0 : (double)N / 28.0;
-    wgs = wgs < 500.0 ? 500.0 : (wgs > 4608.0 ? 4608.0 : wgs);
+    // The matrix-core (wide) product keeps two workgroups per CU resident and a workgroup's prologue / slabs cost more than
+    // in the thin form: few, long workgroups.  The subtile layout of the cache depends on (N, R) only, so the build and the
+    // product of a whole (unsharded) cache may be chunked differently; sharded caches keep one rule for both (their byte
+    // ranges follow it).
+    // EXACTLY filled rounds of the 2-per-CU resident workgroups: one round up to N = 36 000, three above
+    // (tools/experiments/r5_symk_rounds.py: 28 001: 342 -> 307 us, 33 000: 426 -> 397, 40 000: 613 -> 592, 50 000: 957 -> 934
+    // against the N / 28 rule, whose workgroup count lands between two rounds)
+    chunk = symk_one_round_chunk(N, r1 ? 256 : 512, (N <= 36000 ? 1 : 3) * 2 * (g_num_cus > 0 ? g_num_cus : 256));
   }
-  sp.p = make_plan(N, N, true, 12, world, rank, false, 0, wgs);      // R = 2 from N = 4096 up (the wide-block rule), whatever T is later
+  sp.p = make_plan(N, N, true, 12, world, rank, r1, 0, wgs, false, chunk);      // R = 2 above kSymkR1Max, whatever T is later
   sp.sub0 = symk_wg_subtile(sp.p, N, sp.p.w0);
   sp.sub1 = symk_wg_subtile(sp.p, N, sp.p.w1);
   return sp;
@@ -5062,12 +5085,15 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
 
 size_t rpgp_symcache_bytes(int64_t N, int world, int rank) {
   if (N <= 0 || N > 0x7fffffffLL || world < 1 || rank < 0 || rank >= world) return 0;
-  return symk_bytes(symk_plan(N, world, rank));
+  return symk_bytes(symk_plan(N, world, rank));          // (the layout's R depends on (N, world) only: one size for both layouts)
 }
 
 size_t rpgp_symcache_workspace_bytes(int64_t N, int T, int world, int rank) {
   if (N <= 0 || N > 0x7fffffffLL || T <= 0 || world < 1 || rank < 0 || rank >= world) return 0;
-  return plan_workspace_floats(symk_plan(N, world, rank).p, N, T, true) * sizeof(float);
+  (void)rpgp_init();                               // (the wide plan counts the device's CUs; harmless without a device)
+  const size_t a = plan_workspace_floats(symk_plan(N, world, rank, false).p, N, T, true);
+  const size_t b = plan_workspace_floats(symk_plan(N, world, rank, true).p, N, T, true);        // (chunked differently)
+  return (a > b ? a : b) * sizeof(float);
 }
 
 int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t N, int ldz, int j0, int j1, int layout,

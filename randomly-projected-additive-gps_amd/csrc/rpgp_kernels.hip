@@ -4147,8 +4147,11 @@ inline bool bilinear_use_sym(int64_t N) {
   const double slabT_bytes = (double)((N + 511) / 512) * (double)N * 21.0 * 4.0;
   return slabT_bytes <= 6.0e9;                     // beyond ~190k rows the full sweep's 46 MB workspace is kept
 }
+// (Chunk sizes from 448 to 896 columns at C4, 64 to 192 at C3 / C2 are within 2 % of each other for this sweep: its nine
+//  rounds of unequal workgroups leave the dispatcher enough to smooth — profiles/r5b_bilinear_chunk_sweep.jsonl.)
+inline TilePlan bilinear_plan(int64_t N) { return make_plan(N, N, true, 12, 1, 0, false, 512); }
 inline size_t bilinear_sym_floats(int64_t N) {
-  const TilePlan p = make_plan(N, N, true, 12, 1, 0, false, 512);
+  const TilePlan p = bilinear_plan(N);
   return ((size_t)p.maxchunks * N + (size_t)p.nrb * N) * 21 + (size_t)N + (size_t)N * 20;     // slabs, rowS, scaled copy of Z
 }
 
@@ -4775,7 +4778,7 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
     // symmetric sweep: every unordered pair once (half the exponentials), tile plan of the fused MVM with BR = 512
     int rc = rpgp_init();
     if (rc) return rc;
-    const TilePlan p = make_plan(N, N, true, 12, 1, 0, false, 512);
+    const TilePlan p = bilinear_plan(N);
     float *slabR = reinterpret_cast<float *>(workspace);
     float *slabT = slabR + (size_t)p.maxchunks * N * 21;
     float *rowS = slabT + (size_t)p.nrb * N * 21;

@@ -4388,6 +4388,7 @@ inline SymkPlan symk_plan(int64_t N, int world, int rank, bool wide = false) {
     // EXACTLY filled rounds of the 2-per-CU resident workgroups: one round up to N = 36 000, three above
     // (tools/experiments/r5_symk_rounds.py: 28 001: 342 -> 307 us, 33 000: 426 -> 397, 40 000: 613 -> 592, 50 000: 957 -> 934
     // against the N / 28 rule, whose workgroup count lands between two rounds)
+    // (two per CU also for the 256-row kernel, whose 154 registers would admit three: sized for three it is 0 - 9 % slower)
     chunk = symk_one_round_chunk(N, r1 ? 256 : 512, (N <= 36000 ? 1 : 3) * 2 * (g_num_cus > 0 ? g_num_cus : 256));
   }
   sp.p = make_plan(N, N, true, 12, world, rank, r1, 0, wgs, false, chunk);      // R = 2 above kSymkR1Max, whatever T is later

@@ -235,6 +235,22 @@ def test_symcache_wide_kernels_bitwise_interchangeable(gpu_device, N, T, shard, 
         assert _rel(outs["1"].cpu().numpy(), orc.mvm(Z, Z, V, 0.2, 0.3)) < 2e-6
 
 
+@pytest.mark.parametrize("N", [4095, 4096, 16384, 16385, 36000, 36001])
+def test_symcache_layout_rule_boundaries(gpu_device, N):
+    """symk_plan's thresholds (one row-tile set per wave up to N = 16384; one exactly filled round of workgroups up to 36000,
+    three above): both layouts against the fused sweep on either side of each."""
+    from rpgp_amd import ops
+    g = torch.Generator().manual_seed(N)
+    Z = torch.randn(N, 20, generator=g).to(gpu_device)
+    V = torch.randn(N, 11, generator=g).to(gpu_device)
+    ref = ops.mvm_sym(Z, V, 0.05, 0.1)
+    wide = ops.symcache_mvm(ops.SymCache(Z, wide=True), V, 0.05, 0.1)
+    assert float((wide - ref).norm() / ref.norm()) < 2e-6
+    if N <= 20000:
+        thin = ops.symcache_mvm(ops.SymCache(Z, wide=False), V[:, :3].contiguous(), 0.05, 0.1)
+        assert float((thin - ref[:, :3]).norm() / ref[:, :3].norm()) < 2e-6
+
+
 def test_symcache_rejects_mismatched_arguments(gpu_device):
     from rpgp_amd import ops, _lib
     Zt = torch.randn(2000, 4, device=gpu_device)

@@ -5107,8 +5107,16 @@ int rpgp_symcache_build(const float *Z, void *cache, size_t cache_bytes, int64_t
     return RPGP_EINVAL;
   const int irc = rpgp_init();
   if (irc) return irc;
-  const SymkPlan sp = symk_plan(N, world, rank);
+  SymkPlan sp = symk_plan(N, world, rank);
   if (cache_bytes < symk_bytes(sp)) return RPGP_EWORKSPACE;
+  if (world <= 1) {
+    // The build of a whole cache is chunked on its own (the layout depends on (N, R) only): a compute-bound sweep of equal
+    // workgroups at eight per CU wants MANY of them — ~6000 instead of the product's N / 14 (tools/experiments/
+    // r5_symk_build_wgs.py, profiles/r5b_symk_build_wgs.jsonl: N = 7k 93.6 -> 72.8 us, 15k 267 -> 245, 28k 930 -> 834, 50k 2796 -> 2739)
+    sp.p = make_plan(N, N, true, 12, world, rank, symk_r1(N, world), 0, 6144.0);
+    sp.sub0 = symk_wg_subtile(sp.p, N, sp.p.w0);
+    sp.sub1 = symk_wg_subtile(sp.p, N, sp.p.w1);
+  }
   if (sp.p.w1 <= sp.p.w0) return 0;
   hipStream_t st = as_stream(stream);
   float4v *c = reinterpret_cast<float4v *>(cache);

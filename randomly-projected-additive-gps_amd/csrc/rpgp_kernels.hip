@@ -3615,6 +3615,102 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
   }
 }
 
+// Fast path of the per-step form for the flagship operator (plain RBF projections, <= 32 columns, rank <= 16, one row per
+// thread: N <= 131072).  A greedy step is a chain of dependent round trips — argmax partials -> pivot -> the pivot's row ->
+// this thread's own row -> entry — of which the LAST operands do not depend on the pivot at all: the thread's coordinates,
+// its row of L and its residual diagonal entry are requested at the head of the kernel, behind the partials, and land while
+// the pivot is being found.  Same arithmetic in the same order as pivchol_step_kernel (padded terms add exact zeros).
+__global__ __launch_bounds__(256) void pivchol_step_fast_kernel(const float *__restrict__ Z, float *__restrict__ L,
+                                                                float *__restrict__ dwork,
+                                                                const float *__restrict__ pval_in,
+                                                                const int *__restrict__ pidx_in,
+                                                                float *__restrict__ pval_out, int *__restrict__ pidx_out,
+                                                                int nparts, int N, int ldz, int ncols, int k, int m,
+                                                                float scale, float d0, int const_diag) {
+  __shared__ float sval[4];
+  __shared__ int sidx[4];
+  __shared__ float szp[32];
+  __shared__ float slp[16];
+  __shared__ float sdp;
+  __shared__ int spiv;
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  const bool own = i < N;
+  const size_t ic = (size_t)(own ? i : N - 1);
+  float pv[2];
+  int pi[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {                     // (nparts <= 512; clamped, always loaded)
+    const int q = tid + 256 * u;
+    const int qc = q < nparts ? q : nparts - 1;
+    pv[u] = const_diag ? -1.f : pval_in[qc];
+    pi[u] = const_diag ? 0x7fffffff : pidx_in[qc];
+  }
+  float zr[32], lr[16];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) zr[j] = Z[ic * ldz + (j < ncols ? j : ncols - 1)];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lr[q] = L[ic * k + (q < k ? q : k - 1)];
+  const float dprev = const_diag ? d0 : dwork[ic];
+  float bv = -1.f;
+  int bi = 0x7fffffff;
+  if (const_diag) {
+    if (tid == 0) { sdp = d0; spiv = 0; }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = tid + 256 * u;
+      if (q < nparts && (pv[u] > bv || (pv[u] == bv && pi[u] < bi))) { bv = pv[u]; bi = pi[u]; }
+    }
+    block_argmax(bv, bi, sval, sidx);
+    if (tid == 0) { sdp = bv; spiv = bi; }
+  }
+  __syncthreads();
+  const int piv = spiv;
+  const float dp = sdp;
+  const bool ok = dp > 1e-10f * d0;
+  if (tid < ncols) szp[tid] = Z[(size_t)piv * ldz + tid] * kExp2Scale;
+  if (tid < m) slp[tid] = L[(size_t)piv * k + tid];
+  __syncthreads();
+  const float inv_sq = ok ? 1.0f / sqrtf(dp) : 0.f;
+  bv = -1.f;
+  bi = 0x7fffffff;
+  if (own) {
+    float l = 0.f;
+    if (ok) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        if (j < ncols) {
+          const float dd = zr[j] * kExp2Scale - szp[j];
+          float r2 = 0.f;
+          r2 = __builtin_fmaf(dd, dd, r2);
+          acc = acc + fast_exp2(-r2);
+        }
+      }
+      const float row = scale * acc;
+      float corr = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (q < m) corr = __builtin_fmaf(lr[q], slp[q], corr);
+      l = (row - corr) * inv_sq;
+    }
+    L[(size_t)i * k + m] = l;
+    float nd = dprev - l * l;
+    nd = nd < 0.f ? 0.f : nd;
+    nd = (i == piv) ? 0.f : nd;
+    dwork[i] = nd;
+    bv = nd;
+    bi = i;
+  }
+  __syncthreads();
+  block_argmax(bv, bi, sval, sidx);
+  if (tid == 0) {
+    pval_out[blockIdx.x] = bv;
+    pidx_out[blockIdx.x] = bi;
+  }
+}
+
 // Cooperative form for 2048 < N <= 32768 (round 5; OPT-IN, see pivchol_common: bitwise equal and no faster): ALL greedy steps in ONE launch of ceil(N / 256) <= 128 co-resident
 // workgroups (a thread owns one row for the whole factorisation: its coordinates in LDS, its row of L and its residual
 // diagonal entry in registers), separated by a grid barrier instead of a launch boundary — rank + 1 launches of ~9 us each
@@ -5052,6 +5148,14 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
     hipLaunchKernelGGL(pivchol_init_from_diag_kernel, dim3(nb), dim3(256), 0, st, diag_work, pval[0], pidx[0], (int)N);
   }
   // (a stationary kernel's residual diagonal starts at d0 everywhere: step 0 knows that itself — no initialisation launch)
+  // RPGP_PIVCHOL_FAST=0: the general per-step kernel also for the flagship operator (read per call: A/B)
+  const char *env_fast = getenv("RPGP_PIVCHOL_FAST");
+  const bool fast = !(env_fast && env_fast[0] == '0') && kind == RPGP_KIND_RBF && group == 1 && !wts && !gp && ncols <= 32 &&
+                    rank <= 16 && (long long)nb * 256 >= N;
+  for (int m = 0; fast && m < rank; ++m)
+    hipLaunchKernelGGL(pivchol_step_fast_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
+                       pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, m == 0 ? 1 : 0);
+  if (fast) return launch_status();
   for (int m = 0; m < rank; ++m) {
     hipLaunchKernelGGL(pivchol_step_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
                        pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, kind, group,

@@ -407,6 +407,26 @@ def test_pivoted_cholesky_cooperative_launch_is_bitwise_the_per_step_form(gpu_de
         assert fam["1"] is not None and torch.equal(fam["0"], fam["1"])
 
 
+@pytest.mark.parametrize("N,J,rank", [(2049, 20, 15), (7372, 20, 15), (14939, 8, 16), (50000, 20, 15), (131072, 3, 15),
+                                      (131073, 3, 15), (9000, 32, 15), (9000, 33, 15), (4097, 20, 1)])
+def test_pivoted_cholesky_fast_step_kernel_is_bitwise_the_general_one(gpu_device, N, J, rank, monkeypatch):
+    """pivchol_step_fast_kernel (the flagship operator's per-step kernel: own-row operands requested before the pivot is
+    known) against the general per-step kernel (RPGP_PIVCHOL_FAST=0): the same factor bit for bit, on both sides of its limits
+    (<= 32 columns, one row per thread up to N = 131072), repeated on one scratch buffer."""
+    from rpgp_amd import ops
+    rng = np.random.default_rng(N + J)
+    Z = torch.from_numpy((rng.standard_normal((N, J)) * 0.8).astype(np.float32)).to(gpu_device)
+    out = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("RPGP_PIVCHOL_FAST", mode)
+        L = ops.pivoted_cholesky(Z, 0.7 / J, rank)
+        assert torch.isfinite(L).all()
+        if mode in out:
+            assert torch.equal(out[mode], L)
+        out[mode] = L
+    assert torch.equal(out["0"], out["1"])
+
+
 @pytest.mark.parametrize("N,T,world", [(3000, 1, 3), (20000, 1, 8), (5000, 11, 4), (700, 4, 2), (300, 1, 8)])
 def test_pair_sharded_mvm_sums_to_full(gpu_device, N, T, world):
     """Pair-sharding (rpgp_mvm_sym[_prepared]_range): the per-rank partial products sum to the full MVM, for the

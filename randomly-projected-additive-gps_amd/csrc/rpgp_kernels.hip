@@ -936,9 +936,10 @@ inline int red_outputs(size_t total) {
     return e ? atoi(e) : 0;
   }();
   if (forced > 0) return forced;
-  // measured (tools/r5_symk_red_prof.sh, T = 11 packed-cache product): 64 outputs beat 32 at every size (N = 7k: 7.2 -> 6.5 us,
-  // 15k: 10.4 -> 9.4, 50k: 36.6 -> 29.6); 128 only from N ~ 15k (8.3 us) and lose at 7k (10.0 us)
-  return total >= (size_t)16384 * 8 ? 64 : 32;
+  // measured (tools/r5_symk_red_prof.sh, T = 11 packed-cache product): 64 outputs beat 32 at every size measured (N = 7k,
+  // 81k outputs: 7.2 -> 6.5 us; 15k: 10.4 -> 9.4; 50k: 36.6 -> 29.6); 128 only from N ~ 15k (8.3 us) and lose at 7k (10.0 us);
+  // below the measured range the round-2 width stays
+  return total >= (size_t)65536 ? 64 : 32;
 }
 #define RPGP_LAUNCH_MVM_REDUCE(total_, st_, ...)                                                                          \
   do {                                                                                                                    \

@@ -110,6 +110,11 @@ def _side_stream(device):
     return st
 
 
+def _early_presolve():
+    import os
+    return os.environ.get("RPGP_EARLY_PRESOLVE", "1") != "0"          # (=0: A/B, tools/r5_step_presolve_ab.py)
+
+
 def _overlap_ok(op, Z):
     """Build the cached operator beside the preconditioner?  Only where a cache WILL be built: the plain float32 exact operator
     on a HIP device under the cached-K rule (inv_quad_logdet.solve_operator).  Opt-in (settings.overlap_cache_build or
@@ -213,6 +218,9 @@ class _FusedMLL(torch.autograd.Function):
                                      tolerance=settings.cg_tolerance.value(), max_iter=settings.max_cg_iterations.value(),
                                      max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),
                                      preconditioner=pre, lanczos="history")
+            # The backward pass opens with M^-1 [probes] (two launches): queued HERE, they run while the host does the SLQ
+            # quadrature below, instead of behind the autograd engine's start-up at the head of the backward pass.
+            ctx.pre_probes = pre.solve(full_rhs[:, :p]) if _early_presolve() else None
             logdet = float(slq_logdet(hist, n)) + pre.logdet()
             lp, dlp = _prior(likelihood, noise_f)
             # mll = (-0.5 (inv_quad + logdet + n log 2 pi) + log p(sigma^2)) / n      (models.ExactMarginalLogLikelihood)
@@ -231,7 +239,7 @@ class _FusedMLL(torch.autograd.Function):
         n = ctx.n
         with torch.no_grad():
             g = g.reshape(1).contiguous()
-            pre_probes = ctx.pre.solve(ctx.probes)
+            pre_probes = ctx.pre_probes if ctx.pre_probes is not None else ctx.pre.solve(ctx.probes)
             sign = ctx.sign
             left, right, part, nparts = be.step_lr(ctx.solves, pre_probes, g, sign * -0.5 / n)
             op, gs_scale = ctx.op, 1.0

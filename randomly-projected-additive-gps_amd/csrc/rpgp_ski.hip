@@ -315,13 +315,24 @@ __global__ __launch_bounds__(256) void ski_scatter_sorted_kernel(const int2 *__r
 template <int LPP, int CPL>
 __global__ __launch_bounds__(256) void ski_scatter_cell_kernel(const int2 *__restrict__ rec,
                                                                const int *__restrict__ cell_start, const float *__restrict__ V,
-                                                               float *__restrict__ cellpart, int T, int t0, int tcnt) {
+                                                               float *__restrict__ cellpart, int T, int t0, int tcnt,
+                                                               int Gorder) {
   constexpr int TT = LPP * CPL;
   constexpr int PPW = 64 / LPP;
   constexpr int STEPS = 64 / PPW;
   __shared__ float sP[4][4][12];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cell = blockIdx.x;
+  // Dispatch order (round 5): a cell's workgroup walks ALL its points, so its lifetime follows the cell's count, and with
+  // ~1.5 rounds of resident workgroups the cells that start LAST decide when the kernel ends.  Projected coordinates pile up
+  // around the middle of the grid: the workgroups take the cells centre-out (middle cell first, alternating sides, the
+  // projections interleaved), so the long cells start first and the short ones fill the tail.  Which workgroup computes a cell
+  // does not touch what it computes: same bits.  Gorder = 0: storage order.
+  int cell = blockIdx.x;
+  if (Gorder > 0) {
+    const int J = (int)gridDim.x / Gorder, j = (int)blockIdx.x % J, r = (int)blockIdx.x / J;
+    const int g = Gorder / 2 + ((r & 1) ? -((r + 1) >> 1) : (r >> 1));
+    cell = j * Gorder + g;
+  }
   const int sb = cell_start[cell], se = cell_start[cell + 1];
   const int c = lane % LPP, pg = lane / LPP;
   float acc[4][CPL];
@@ -1326,12 +1337,14 @@ int scatter_planned(const PlanView &pv, const float *V, double *hist, float *par
     const int tcnt = (T - t0 < tt) ? T - t0 : tt;
     const long long n = (long long)J * G * tt;
     if (by_cell) {
+      const char *env_co = getenv("RPGP_SKI_CELL_ORDER");          // =0: storage order (read per call: A/B)
+      const int go = (env_co && env_co[0] == '0') ? 0 : G;
       if (tt == 1)
-        hipLaunchKernelGGL((ski_scatter_cell_kernel<1, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt);
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<1, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt, go);
       else if (tt == 4)
-        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt);
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt, go);
       else
-        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 3>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt);
+        hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 3>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt, go);
       int rc = launch_status();
       if (rc) return rc;
       if (cells_tt && t0 == 0 && tcnt == T) {              // one piece: the tap records go to the Toeplitz stage as they are

@@ -541,3 +541,28 @@ def test_cell_sums_folded_into_the_toeplitz_stage_are_the_same_bits(gpu_device, 
     hist = ops.ski_scatter(Zt, gp, Vt, G, plan=plan)
     staged = ops.ski_gather(Zt, gp, ops.ski_grid_product(hist, gp, G), Vt, 0.7 / J, 0.2, G, plan=plan)
     assert torch.equal(out, staged)
+
+
+@pytest.mark.parametrize("N,J,T,G,dist", [(5000, 3, 11, 1024, "gaussian"), (60000, 3, 11, 1024, "skewed"), (60000, 3, 1, 1024, "skewed"),
+                                          (30000, 20, 12, 256, "gaussian"), (20000, 2, 4, 129, "uniform"), (391386, 3, 11, 1024, "gaussian")])
+def test_scatter_dispatch_order_does_not_change_a_bit(gpu_device, N, J, T, G, dist, monkeypatch):
+    """The cell-sorted scatter's workgroups take the cells centre-out (round 5: the long cells of centre-peaked coordinates start
+    first) or in storage order (RPGP_SKI_CELL_ORDER=0): which workgroup computes a cell does not change what it computes — even and
+    odd grid sizes, one- and many-round cells, the histogram and the whole planned product."""
+    from rpgp_amd import ops
+    g = torch.Generator().manual_seed(N + T)
+    Z = torch.randn(N, J, generator=g)
+    if dist == "skewed":
+        Z = Z.exp()
+    elif dist == "uniform":
+        Z = torch.rand(N, J, generator=g) * 4 - 2
+    Zt = Z.to(gpu_device)
+    Vt = torch.randn(N, T, generator=g).to(gpu_device)
+    gp = ops.ski_grid(Zt, None, G)
+    plan = ops.SkiPlan(Zt, gp, G)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RPGP_SKI_CELL_ORDER", mode)
+        res[mode] = (ops.ski_scatter(Zt, gp, Vt, G, plan=plan), ops.ski_mvm(Zt, Zt, gp, Vt, 0.7 / J, 0.2, G, plan=plan))
+    assert torch.isfinite(res["1"][1]).all()
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])

@@ -273,11 +273,36 @@ def resolve_datasets(names):
     return names
 
 
+def launch_ranks(argv, devices, entry=None):
+    """The reference's one-command multi-device form, `--device cuda:0,cuda:1,cuda:2` (gp_experiment_runner.py:263 →
+    training_routines.py:407-408; run_scripts/additive_spread_prescale_Jd.sh:6): start one rank per listed device through a
+    fresh `torch.distributed.run` child and return its exit status.  This parent has made no HIP call and never will (the
+    ranks bind their devices themselves, `init_distributed`); the flags travel through the environment because
+    torch.distributed.run's own parser abbreviation-matches script flags such as `--no_cv` / `-m` before the script sees
+    them.  `entry` replaces the rank program (default `-m rpgp_amd.runner`); tests/ use it to start ranks that install
+    their CPU test double first."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["RPGP_RUNNER_ARGV"] = json.dumps(list(argv))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))         # where the `rpgp_amd` import shim lives
+    env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(len(devices)),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + list(entry or ["-m", "rpgp_amd.runner"])
+    return subprocess.call(cmd, env=env)
+
+
 def init_distributed(devices, backend=None):
-    """One process per GPU under `python -m torch.distributed.run --nproc-per-node N -m rpgp_amd.runner ... --device cuda`
-    (the replacement of the reference's `--device cuda:0,cuda:1,...`, gp_experiment_runner.py:263 +
-    training_routines.py:407-408): bind this rank to its GPU and join the RCCL process group BEFORE any GPU call, and map
-    `--device` to the local device.  Returns (rank, world); (0, 1) when not launched by a distributed launcher."""
+    """One process per GPU — started by `launch_ranks` for the reference's `--device cuda:0,cuda:1,...` form, or by the user
+    as `python -m torch.distributed.run --nproc-per-node N -m rpgp_amd.runner ... --device cuda` (gp_experiment_runner.py:263
+    + training_routines.py:407-408): bind this rank to its GPU and join the RCCL process group BEFORE any GPU call, and map
+    `--device` to this rank's device (the LOCAL_RANK-th listed device when the list names one per rank, else
+    `cuda:LOCAL_RANK`).  Returns (rank, world); (0, 1) when not launched by a distributed launcher."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
@@ -285,23 +310,45 @@ def init_distributed(devices, backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = devices[0].startswith("cuda")
+    if on_gpu:
+        mine = torch.device(devices[local_rank]) if len(devices) == world else torch.device("cuda", local_rank)
+        index = local_rank if mine.index is None else mine.index
     if not dist.is_initialized():
-        if on_gpu:
+        if on_gpu and len(devices) == world and len(set(devices)) < world:
+            # the same device listed more than once (`--device cuda:0,cuda:0`): a rehearsal of the multi-rank path on a
+            # one-GPU box.  RCCL refuses two ranks per device, so the group is bootstrapped over gloo and the data-path
+            # all-reduce runs through rpgp_comm's IPC-mapped buffers (distributed.Reducer backend "ipc").
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend or "nccl", device_id=torch.device("cuda", local_rank))
+            os.environ["RPGP_COMM"] = "ipc"
+            torch.cuda.set_device(index)
+            dist.init_process_group(backend or "gloo")
+        elif on_gpu:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(index)
+            dist.init_process_group(backend or "nccl", device_id=torch.device("cuda", index))
         else:
             dist.init_process_group(backend or "gloo")
     if on_gpu:
-        devices[:] = ["cuda:%d" % local_rank]
+        devices[:] = ["cuda:%d" % index]
+    else:
+        devices[:] = devices[:1]
     if rank != 0:
         import sys
         sys.stdout = open(os.devnull, "w")     # one voice on stdout (every rank computes identical metrics)
     return rank, world
 
 
-def main(argv=None):
+def main(argv=None, rank_entry=None):
+    import sys
+    if argv is None and len(sys.argv) == 1 and "RPGP_RUNNER_ARGV" in os.environ and "WORLD_SIZE" in os.environ:
+        argv = json.loads(os.environ["RPGP_RUNNER_ARGV"])          # a rank started by launch_ranks
     args = build_parser().parse_args(argv)
+    if len(args.device.split(",")) > 1 and "WORLD_SIZE" not in os.environ:
+        # `--device cuda:0,cuda:1,...` in ONE command: one rank per listed device, started before anything touches a GPU
+        status = launch_ranks(sys.argv[1:] if argv is None else argv, args.device.split(","), entry=rank_entry)
+        if status != 0:
+            raise SystemExit(status)
+        return pd.read_csv(args.output, index_col=0) if os.path.exists(args.output) else None
     print("Parser arguments", args)
     if os.path.exists(args.model_spec):
         with open(args.model_spec, "r") as f:

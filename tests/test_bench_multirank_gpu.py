@@ -16,10 +16,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N, D, J = 20000, 20, 20
+D, J = 20, 20
 
 
-def _oracle_rows(rows):
+def _oracle_rows(N, rows):
     import torch
     import bench
     from oracle import cmvm, dense_gp as orc
@@ -29,8 +29,11 @@ def _oracle_rows(rows):
     return cmvm.mvm(Z[rows], Z, Vh, 1.0 / J) + 0.1 * Vh[rows]
 
 
-@pytest.mark.parametrize("world,shard", [(2, "pairs"), (4, "j"), (3, "pairs")])
-def test_bench_gpus_n_runs_on_one_device(gpu_device, tmp_path, world, shard):
+# (world, split that is `value`, N): every run times BOTH splits (the other one lands in multi_gpu.other_split), so the
+# last case is north_star's uneven J = 20 -> (3,3,3,3,2,2,2,2) split AND the equal-pairs split at world 8 on the BASELINE
+# size N = 50 000 (VERDICT r5 #1b)
+@pytest.mark.parametrize("world,shard,N", [(2, "pairs", 20000), (3, "j", 20000), (8, "pairs", 50000)])
+def test_bench_gpus_n_runs_on_one_device(gpu_device, tmp_path, world, shard, N):
     dump = str(tmp_path / "res.npy")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--all-ranks-on-device", "0", "--shard", shard,
            "--n", str(N), "--steps", "5", "--warmup", "2", "--no-extras", "--cpu-budget", "0", "--dump-result", dump]
@@ -44,15 +47,28 @@ def test_bench_gpus_n_runs_on_one_device(gpu_device, tmp_path, world, shard):
     assert res["value"] > 0 and abs(res["value"] * res["ms_per_step"] / 1e3 - 1.0) < 1e-3
     assert res["config"]["parallelism"] == "%s-shard x%d + all-reduce" % (shard, world)
     assert res["config"]["split"].startswith(shard) and "rpgp_comm" in res["config"]["comm"]
+    sys.path.insert(0, ROOT)
+    from rpgp_amd.distributed import j_partition
+    jtab = ", ".join("%d:%d" % ab for ab in j_partition(J, world))
+    assert "j-shard x%d [%s]" % (world, jtab) in res["config"]["north_star_split"]
+    if world == 8:
+        assert jtab == "0:3, 3:6, 6:9, 9:12, 12:14, 14:16, 16:18, 18:20"
     mg = res["multi_gpu"]
     assert len(mg["per_rank_kernel_ms"]) == world and all(k > 0 for k in mg["per_rank_kernel_ms"])
     assert len(mg["per_rank_allreduce_us"]) == world and mg["allreduce_us"] > 0 and mg["allreduce_bytes"] == 4 * N
     assert mg["all_ranks_on_device"] == 0 and "NOT a scaling measurement" in mg["note"]
     assert abs(res["roofline"]["kernel_ms"] - max(mg["per_rank_kernel_ms"])) < 1e-3
     assert res["roofline"]["traffic"] is None and "cpu_baseline" not in res
-    # the all-reduced product of the last step against the oracle (identical inputs: bench.make_inputs seeds)
-    out = np.load(dump).astype(np.float64)
-    assert out.shape == (N, 1)
+    # the kernel the line names is the one the split launches (the hand-scheduled kernel serves the pair shares)
+    other = mg["other_split"]
+    names = {shard: res["roofline"]["kernel"], ("j" if shard == "pairs" else "pairs"): other["kernel"]}
+    assert names["pairs"] == "mvm_fact_asm_kernel" and names["j"].startswith("mvm_fact_kernel<")
+    assert other["parallelism"] == "%s-shard x%d + all-reduce" % ("j" if shard == "pairs" else "pairs", world)
+    assert other["value"] > 0 and len(other["per_rank_kernel_ms"]) == world and other["rel_diff_vs_value_split"] < 1e-5
+    # the all-reduced products of the last step of BOTH splits against the oracle (identical inputs: bench.make_inputs seeds)
     rows = np.sort(np.random.default_rng(world).choice(N, size=384, replace=False))
-    ref = _oracle_rows(rows)
-    assert np.linalg.norm(out[rows] - ref) / np.linalg.norm(ref) < 1e-5
+    ref = _oracle_rows(N, rows)
+    for path in (dump, dump + ".other.npy"):
+        out = np.load(path).astype(np.float64)
+        assert out.shape == (N, 1)
+        assert np.linalg.norm(out[rows] - ref) / np.linalg.norm(ref) < 1e-5, path

@@ -55,3 +55,32 @@ def test_sharded_training_end_to_end_multi_process_one_device(gpu_device, tmp_pa
         r = _launch("ipc_train_child.py", world, timeout=900, args=[ref])
         assert r.returncode == 0, (world, _why(r))
         assert "IPC_TRAIN_CHILD_OK world=%d" % world in r.stdout
+
+
+@pytest.mark.parametrize("spec,devices", [("additive_rp_prescale_J20", "cuda:0,cuda:0"),
+                                          ("additive_spread_prescale_Jd_ski", "cuda:0,cuda:0,cuda:0")])
+def test_runner_one_command_multi_device_form_on_gpu(gpu_device, tmp_path, spec, devices):
+    """The reference's ONE-command multi-device form (`--device cuda:0,cuda:1,cuda:2`, gp_experiment_runner.py:263,
+    run_scripts/additive_spread_prescale_Jd.sh:6) through the CLI: the runner starts one rank per listed device itself.
+    On the one-GPU box the list repeats cuda:0 (gloo bootstrap + rpgp_comm all-reduce); the result must agree with the
+    single-device run of the same command."""
+    import json
+    import pandas as pd
+    sys.path.insert(0, ROOT)
+    from rpgp_amd import specs
+    sp = specs.get(spec)                          # a user's own copy of the spec with a fixed, short schedule
+    sp["train_kwargs"].update(max_iter=6, check_conv=False)
+    spec = str(tmp_path / "my_spec.json")
+    json.dump(sp, open(spec, "w"))
+    base = [sys.executable, "-m", "rpgp_amd.runner", "-m", spec, "-d", "synthetic:kin8nm" if "ski" not in spec else
+            "synthetic:elevators", "--no_cv", "--skip_random_restart", "--skip_posterior_variances"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    outs = {}
+    for name, dev in (("one", "cuda:0"), ("many", devices)):
+        out = str(tmp_path / (name + ".csv"))
+        r = subprocess.run(base + ["-o", out, "--device", dev], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-1500:] + _why(r)
+        outs[name] = pd.read_csv(out)
+        assert "error" not in outs[name].columns or outs[name]["error"].isna().all(), outs[name].get("error")
+    a, b = float(outs["one"]["rmse"].iloc[0]), float(outs["many"]["rmse"].iloc[0])
+    assert abs(a - b) < 2e-2 * max(abs(a), 1e-3), (a, b)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPGP_ABI_VERSION 2
+#define RPGP_ABI_VERSION 3
 
 #define RPGP_EINVAL     10001 /* bad argument (shape, range, null pointer) */
 #define RPGP_EWORKSPACE 10002 /* workspace too small: call the matching *_workspace_bytes */
@@ -257,10 +257,10 @@ int rpgp_ski_gather(const float *Z, const float *grid_params, const float *H, co
  * points — no atomics — and the Toeplitz stage reads its first column from the plan.
  *   rpgp_ski_mvm_planned     : same result contract as rpgp_ski_mvm(Z, Z, ...) for T <= 12 (bitwise reproducible)
  *   rpgp_ski_scatter_planned : stage 1 only (the row-sharded operator: plan built on the LOCAL rows), = rpgp_ski_scatter
- *   rpgp_ski_gather_fast     : stage 3; with a plan of Z (may be NULL) and J * G * T floats fitting in LDS the table H is
- *                              LDS-resident and the stencils come from the plan, else = rpgp_ski_gather
- * Workspace of the products: rpgp_ski_workspace_bytes(J, G, T) (RPGP_EWORKSPACE when N * J is too large for the planned
- * form: fall back to rpgp_ski_mvm).  N * J < 2^31.
+ *   rpgp_ski_gather_fast     : stage 3; with J * G * T floats fitting in LDS (and >= 32 768 rows) the table H is LDS-resident,
+ *                              else = rpgp_ski_gather (`plan` may be NULL: the gather reads the coordinates themselves)
+ * Workspace of the products: rpgp_ski_workspace_bytes(J, G, T) (RPGP_EWORKSPACE when the per-cell tap records of J * G cells
+ * exceed its scratch — more than ~340 projections: fall back to rpgp_ski_mvm).  N * J < 2^31.
  */
 size_t rpgp_ski_plan_bytes(int64_t N, int J, int G);
 size_t rpgp_ski_plan_workspace_bytes(int64_t N, int J, int G);
@@ -273,19 +273,6 @@ int rpgp_ski_scatter_planned(const void *plan, const float *V, double *hist, int
                              size_t workspace_bytes, void *stream);
 int rpgp_ski_gather_fast(const void *plan, const float *Z, const float *grid_params, const float *H, const float *V, float *out,
                          int64_t M, int ldz, int J, int G, int T, float scale, float noise, void *stream);
-/*
- * Chunked form of the planned product (round 5; J <= 4 projections, N >= 16384, G <= 2048, T <= 12 — the shape of the
- * reference's additive_spread_prescale_Jd_ski.json on 3droad, training_routines.py:157-158): the rows are cut into ~256
- * contiguous chunks, a chunk's rows of V are staged in LDS once for all projections, a chunk leaves one window of grid
- * rows per projection and reads back only the window of the Toeplitz product it needs.  Same entry points, same result
- * contract (bitwise reproducible; the gather is bit-identical to the cell-sorted form, the scatter sums in another order).
- * OPT-IN — measured at the C5 shape it does not beat the cell-sorted form:
- * rpgp_ski_chunk_mode(0 | 1) selects the form (process-wide; default 0, or the environment variable RPGP_SKI_CHUNK=1), any
- * other argument only queries; returns the previous setting.  A plan built while the mode is on carries the tables of both
- * forms (rpgp_ski_plan_is_chunked), and the mode may then be flipped between two products of that plan.
- */
-int rpgp_ski_chunk_mode(int mode);
-int rpgp_ski_plan_is_chunked(const void *plan);
 /* Pivoted Cholesky of the SKI operator (same contract as rpgp_pivoted_cholesky; diag_work: N + RPGP_PIVCHOL_SCRATCH). */
 int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
                               int J, int G, int rank, float scale, void *stream);
@@ -464,17 +451,8 @@ typedef struct rpgp_reducer {
   rpgp_allreduce_fn fn;
   void *ctx;
 } rpgp_reducer;
-/*
- * Graph form of the executor ("hipGraph-captured CG iteration"): rpgp_mbcg_graph_mode(1), or the
- * environment variable RPGP_CG_GRAPH=1, makes rpgp_mbcg_solve capture ONE iteration (operator product, passes A / B / C)
- * into a hipGraph after the first iteration and replay it — the per-iteration quantities (parity, history row, whether the
- * iteration tests convergence, its number, the poll slot) are then derived on the device from an iteration counter instead
- * of being kernel arguments.  Same arithmetic, same results bit for bit; unsharded solves of the fused / prepared / packed-
- * cache / SKI / family operators (others keep the queue-ahead form).  Default 0: the queue-ahead form already keeps the device
- * busy, and a capture per solve costs more than the launches it saves except for small systems.  Returns the
- * previous setting; any other argument only queries.
- */
-int rpgp_mbcg_graph_mode(int mode);
+/* (The hipGraph form of the iteration loop — SURVEY.md §8(f) rank 3 — was built in round 5, measured 6 - 17 % slower than the
+ *  queue-ahead executor and is parked as tools/experiments/r6_removed_forms.patch; ABI 3 no longer exports its switch.) */
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank);
 int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, int max_iter, int min_iter,
                     int hist_len, int check_every, int stagnation_window, float tolerance, int precond_rank,
@@ -618,9 +596,21 @@ int rpgp_profile_end(float *avg_ms_host, int *count_host);
 
 /* Which kernel `rpgp_mvm_sym_prepared` launches for a single-GPU N x N operator with J projections and T right-hand sides on
  * THIS process' settings (benchmark / profile labelling only; no reference counterpart — GPyTorch has one `_matmul`):
- *   0 = mvm_fact_kernel (compiler-scheduled), 1 = mvm_fact_asm_kernel (hand-scheduled loop, rpgp_fact_asm.hip),
- *   2 = mvm_mfma_kernel (RPGP_MFMA=1).  Negative: RPGP_EINVAL. */
+ *   0 = mvm_fact_kernel (compiler-scheduled), 1 = mvm_fact_asm_kernel (hand-scheduled loop, rpgp_fact_asm.hip).
+ *   Negative: RPGP_EINVAL. */
 int rpgp_prepared_kernel_id(int64_t N, int J, int T);
+
+/*
+ * Phase markers (SURVEY.md §5 "Tracing / profiling"; the loop they annotate is fitting/optimizing.py:65-76): roctx ranges
+ * pushed / popped on the calling thread, recorded by `rocprofv3 --marker-trace`.  The library marks its own phases (one mBCG
+ * solve, every 8th CG iteration, all-reduce hook calls); the host stack marks projection + tables, the preconditioner, the
+ * derivative and the optimiser update through these two calls.  ROCm's librocprofiler-sdk-roctx is bound at first use ONLY if
+ * it is already loaded in the process (rocprofv3 --marker-trace preloads it): otherwise rpgp_range_available() == 0 and the
+ * calls do nothing.
+ */
+int rpgp_range_push(const char *name);
+int rpgp_range_pop(void);
+int rpgp_range_available(void);
 
 #ifdef __cplusplus
 }

@@ -66,9 +66,6 @@ SIGNATURES = {
     "rpgp_ski_mvm_planned": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
     "rpgp_ski_scatter_planned": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
     "rpgp_ski_gather_fast": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp]),
-    "rpgp_ski_chunk_mode": (_int, [_int]),
-    "rpgp_mbcg_graph_mode": (_int, [_int]),
-    "rpgp_ski_plan_is_chunked": (_int, [_vp]),
     "rpgp_ski_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp]),
     "rpgp_ski_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f32, _vp]),
     "rpgp_ski_diag": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp]),
@@ -133,6 +130,9 @@ SIGNATURES = {
     "rpgp_profile_begin": (_int, []),
     "rpgp_profile_end": (_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
     "rpgp_prepared_kernel_id": (_int, [ctypes.c_int64, _int, _int]),
+    "rpgp_range_push": (_int, [ctypes.c_char_p]),
+    "rpgp_range_pop": (_int, []),
+    "rpgp_range_available": (_int, []),
 }
 
 class RpgpOperator(ctypes.Structure):
@@ -162,7 +162,7 @@ RPGP_SYMCACHE_THIN, RPGP_SYMCACHE_WIDE = 0, 1
 RPGP_PIVCHOL_SCRATCH = 2048
 RPGP_F32, RPGP_F64 = 0, 1
 RPGP_SHARD_NONE, RPGP_SHARD_PARTIAL, RPGP_SHARD_ROWS = 0, 1, 2
-RPGP_ABI_VERSION = 2
+RPGP_ABI_VERSION = 3
 RPGP_COMM_HANDLE_BYTES = 64
 # int (*rpgp_allreduce_fn)(void *ctx, void *buf, size_t count, int dtype, void *stream)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)

@@ -27,8 +27,6 @@ class HipBackend:
     ski_grid = staticmethod(ops.ski_grid)
     ski_mvm = staticmethod(ops.ski_mvm)
     ski_plan = staticmethod(ops.ski_plan)
-    ski_chunk_mode = staticmethod(ops.ski_chunk_mode)
-    mbcg_graph_mode = staticmethod(ops.mbcg_graph_mode)
     ski_diag = staticmethod(ops.ski_diag)
     ski_grid_from_range = staticmethod(ops.ski_grid_from_range)
     ski_scatter = staticmethod(ops.ski_scatter)

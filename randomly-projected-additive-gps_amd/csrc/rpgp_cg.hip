@@ -48,8 +48,7 @@ constexpr int kMaxHist = 64;       // Lanczos coefficients kept for at most this
 constexpr int kRedW = 288;         // reduction vector: [16 col sums a][16 col sums b][16 x 16 L^T X]
 constexpr int kRedLt = 32;         // offset of the L^T X block
 static_assert(kRedW == rpgp_internal::kCgRedW && kRedLt == rpgp_internal::kCgRedLt && kMaxK == rpgp_internal::kCgMaxK,
-              "slab format shared with the operator kernels that fold pass A (rpgp_internal.h)");
-constexpr int kPollRingDev = 4;    // poll records in flight (= kPollRing of the host side)
+              "slab format constants of rpgp_internal.h");
 
 typedef float floatx4m __attribute__((ext_vector_type(4)));
 typedef double doublex4m __attribute__((ext_vector_type(4)));
@@ -107,37 +106,7 @@ struct CgState {
   int done_pp[2];           // poll.done as pass C reads it at its head (ping-pong: workgroup 0 sets poll.done at its tail while
                             // late workgroups of the same launch may only just be starting)
   CgPoll poll;
-  int it;                   // graph form only: the iteration in flight (-1 after the set-up; pass A's workgroup 0 advances it)
 };
-// Graph form (RPGP_CG_GRAPH=1): ONE iteration is captured into a hipGraph and replayed, so a launch may not carry anything
-// that changes from one iteration to the next.  What the host passes per iteration in the queue-ahead form — parity, history
-// row, whether this iteration tests convergence, its number, the poll slot, the ping-pong slab area — is derived in the
-// kernels from the iteration counter in CgState and these per-solve constants.
-struct CgGraphCtl {
-  int hist_len, n_hist, min_it, check_every, n_iter;
-  float *alpha_base, *beta_base;      // history rows (pinned host memory, device view)
-  CgPoll *poll_base;                  // poll ring (pinned host memory, device view)
-  float *partB[2];                    // ping-pong slab areas of pass B
-};
-struct CgIterView {                   // what a pass needs to know about "this iteration"
-  int cur, check_now, iter_count;
-  float *alpha_out, *beta_out, *partB;
-  CgPoll *poll_host;
-};
-__device__ __forceinline__ CgIterView iter_view(const CgGraphCtl &gc, int it) {
-  CgIterView v;
-  v.cur = it & 1;
-  const int slot = it < gc.hist_len ? it : kMaxHist;
-  const bool hist_pending = it < gc.n_hist - 1;
-  v.check_now = (it >= gc.min_it && !hist_pending && (it % gc.check_every == 0 || it == gc.n_iter - 1)) ? 1 : 0;
-  v.iter_count = it + 1;
-  v.alpha_out = gc.alpha_base + (size_t)slot * kMaxT;
-  v.beta_out = gc.beta_base + (size_t)slot * kMaxT;
-  v.partB = gc.partB[it & 1];
-  v.poll_host = v.check_now ? gc.poll_base + (it % kPollRingDev) : (CgPoll *)nullptr;
-  return v;
-}
-
 // ---- the lane <-> element map of the streaming passes -------------------------------------------------------------
 // wave `wave` of the workgroup, 16-row block `blk` (0..3) of the 256-row tile starting at row0:
 //   rows R0 .. R0 + 15 with R0 = row0 + 64 wave + 16 blk; lane (c = l % 16, q = l / 16), register r: row R0 + q + 4 r.
@@ -289,13 +258,9 @@ __device__ __forceinline__ void slab_sums(const float *const (&src)[NQ], const i
 // part[blk][0..15] = sum over the workgroup's rows of a*b per column; part[blk][32 + kk*16 + t] = sum L[row][kk] b[row][t]
 template <int TT>
 __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, const float *__restrict__ b,
-                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K,
-                                                int *__restrict__ tick = nullptr) {
+                                                const float *__restrict__ L, float *__restrict__ part, long long N, int K) {
   __shared__ float sh[1024];
   const Lane ln;
-  // graph form: this pass opens the iteration — nothing in it depends on the iteration number, passes B and C behind it
-  // read the advanced counter (stream order), and the previous iteration's readers are done
-  if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick = *tick + 1;
   float dot = 0.f;
   // four independent accumulators (one per 16-row block): a single one is a chain of 16 DEPENDENT matrix instructions per
   // tile, and with 3 - 4 waves per SIMD nothing hides their latency (PMC: SQ_WAIT_INST_ANY = 40 % of the wave cycles)
@@ -337,9 +302,6 @@ __global__ __launch_bounds__(256) void k_pass_a(const float *__restrict__ a, con
   block_ltsum(lt, sh, dst + kRedLt, ln);
 }
 
-// the graph form's iteration counter when pass A is folded into the operator (nothing else advances it then)
-__global__ void k_tick(int *tick) { *tick = *tick + 1; }
-
 // red[e] = sum over the slabs of part[.][e] in float64, fixed order: workgroup b owns entries 8 b .. 8 b + 7, its 32
 // thread groups take every 32nd slab (8 independent loads in flight) and the 32 group sums are added in order.
 __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ part, int nparts, double *__restrict__ red) {
@@ -348,6 +310,16 @@ __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ part, 
   const int idx = blockIdx.x * 8 + e;
   double s = 0.0;
   int p = g;
+  // (round 6: ALL of a thread group's slabs requested before the first addition — 32 loads in flight at kMaxBlocks = 1 024
+  //  slabs, one L2 round trip instead of four batches of eight; the additions keep their order: same bits)
+  for (; p + 31 * 32 < nparts; p += 32 * 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = part[(size_t)(p + 32 * u) * kRedW + idx];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += (double)v[u];
+  }
   for (; p + 7 * 32 < nparts; p += 8 * 32) {
     float v[8];
 #pragma unroll
@@ -416,7 +388,6 @@ __global__ __launch_bounds__(256) void k_init(const float *__restrict__ rhs, con
     st->snap_resid[1] = 3.0e38f;
     st->done_pp[0] = 0;
     st->done_pp[1] = 0;
-    st->it = -1;
   }
   __syncthreads();
   const float nrm = snrm[ln.c];
@@ -468,19 +439,12 @@ __global__ __launch_bounds__(256) void k_pass_b(const float *__restrict__ p, con
                                                 float *__restrict__ alpha_out, long long N, int K, float sigma2,
                                                 float eps, float stop_after, int cur, int first,
                                                 const float *__restrict__ dirA = nullptr, int nA = 0,
-                                                const float *__restrict__ dirB = nullptr, int nB = 0,
-                                                const CgGraphCtl *__restrict__ gc = nullptr) {
+                                                const float *__restrict__ dirB = nullptr, int nB = 0) {
   __shared__ float sh[1024];
   __shared__ double sW[256];
   __shared__ double sTv[256];
   __shared__ float salpha[kMaxT];
   const Lane ln;
-  if (gc) {                     // graph form: this iteration's parity, history row and slab area from the device counter
-    const CgIterView iv = iter_view(*gc, st->it);
-    cur = iv.cur;
-    alpha_out = iv.alpha_out;
-    part = iv.partB;
-  }
   // Every scalar this prologue needs is requested up front and pinned by one empty asm (hipcc otherwise sinks each load under
   // the condition that uses it — eight dependent round trips, about half of this kernel's time at small N).  (`redA` of
   // the set-up call holds the |rhs|^2 sums — valid memory, value unused; `Cinv` without a preconditioner is not a valid
@@ -644,21 +608,11 @@ __global__ __launch_bounds__(256) void k_pass_c(const float *__restrict__ z, flo
                                                 int check_now, float tolerance, int iter_count, int stagnation_window,
                                                 const float *__restrict__ x, float *__restrict__ x_best,
                                                 CgPoll *__restrict__ poll_host, const float *__restrict__ dirB = nullptr,
-                                                int nB = 0, double *__restrict__ lt_out = nullptr,
-                                                const CgGraphCtl *__restrict__ gc = nullptr) {
+                                                int nB = 0, double *__restrict__ lt_out = nullptr) {
   __shared__ float sbeta[kMaxT];
   __shared__ float sres[kMaxT];
   __shared__ float srzn[kMaxT];
   const Lane ln;
-  if (gc) {                     // graph form (see CgGraphCtl)
-    const CgIterView iv = iter_view(*gc, st->it);
-    cur = iv.cur;
-    check_now = iv.check_now;
-    iter_count = iv.iter_count;
-    beta_out = iv.beta_out;
-    poll_host = iv.poll_host;
-    if constexpr (DIRECT) dirB = iv.partB;
-  }
   // Every scalar this prologue needs is requested up front and pinned by one empty asm (hipcc otherwise sinks each load under
   // the condition that uses it: six dependent round trips — most of the kernel's time at small N)
   const int tcl = (int)threadIdx.x < TT ? (int)threadIdx.x : TT - 1;
@@ -836,7 +790,6 @@ Grids grids_for(long long N) {
 // Pinned host landing zone for the lagged convergence polls (one per host thread; the executor keeps no other
 // state between calls).
 constexpr int kPollRing = 4;
-static_assert(kPollRing == kPollRingDev, "poll ring of the graph form");
 constexpr size_t kHistFloats = (size_t)(kMaxHist + 1) * kMaxT;       // one coefficient history (the last row is a scratch slot)
 struct PollCtx {
   CgPoll *host = nullptr;
@@ -864,19 +817,6 @@ struct PollCtx {
   }
 };
 thread_local PollCtx g_poll;
-struct GraphStream {
-  hipStream_t s = nullptr;
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  int init() {
-    if (s) return 0;
-    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
-    if (e != hipSuccess) s = nullptr;
-    return (int)e;
-  }
-};
-thread_local GraphStream g_gstream;
-
 // Wait for a record a kernel publishes into pinned memory (publish_poll): the host SPINS on the stamp — the record of a
 // 5 us pass arrives within microseconds of the pass finishing, where hipEventSynchronize / hipStreamSynchronize wake the
 // thread up ~50 - 150 us later (measured as an idle device in front of k_unnormalise, once per solve, and again behind it).
@@ -885,15 +825,7 @@ thread_local GraphStream g_gstream;
 // the runtime's own synchronisation instead of burning a core for the rest of a long solve (its late wake-up is then a
 // negligible part of that solve) — which is also what reports a failed launch or a hung device.
 constexpr long kPollSpinUs = 2000, kFinalSpinUs = 20000;
-inline bool cg_spin_enabled() {
-  static const bool on = [] {
-    const char *e = getenv("RPGP_CG_SPIN");          // RPGP_CG_SPIN=0: the runtime's synchronisation (A/B measurements, tests)
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
 inline bool wait_record(const CgPoll *rec, int stamp, long budget_us) {
-  if (!cg_spin_enabled()) return false;
   const volatile int *p = &rec->seq;
   return rpgp_internal::spin_until([p, stamp] { return *p == stamp; }, budget_us);
 }
@@ -908,6 +840,7 @@ struct ShardCtx {
   float *H = nullptr;            // row mode: J x G x T Toeplitz product
   int reduce(void *buf, size_t count, int dtype, void *stream) const {
     if (!fn) return 0;
+    rpgp_internal::TraceRange tr("rpgp:allreduce");
     return fn(ctx, buf, count, dtype, stream);
   }
 };
@@ -1043,15 +976,6 @@ size_t operator_workspace(const rpgp_operator *op, int T) {
   }
 }
 
-// RPGP_CG_GRAPH=1 / rpgp_mbcg_graph_mode(1): the iterations of a solve as replays of one captured hipGraph (see CgGraphCtl)
-inline int &graph_mode_ref() {
-  static int mode = [] {
-    const char *e = getenv("RPGP_CG_GRAPH");
-    return (e && e[0] == '1') ? 1 : 0;
-  }();
-  return mode;
-}
-
 inline size_t ski_stage_bytes(const rpgp_operator *op, int T) {
   if (op->kind != RPGP_OP_SKI) return 0;
   const size_t nh = (size_t)op->J * op->G * T;
@@ -1062,17 +986,11 @@ inline size_t ski_stage_bytes(const rpgp_operator *op, int T) {
 
 extern "C" {
 
-int rpgp_mbcg_graph_mode(int mode) {
-  const int prev = graph_mode_ref();
-  if (mode == 0 || mode == 1) graph_mode_ref() = mode;
-  return prev;
-}
-
 size_t rpgp_mbcg_workspace_bytes(const rpgp_operator *op, int T, int precond_rank) {
   if (!op || T <= 0 || T > kMaxT || precond_rank < 0 || precond_rank > kMaxK || op->N < 0) return 0;
   const size_t nt = (size_t)(op->N > 0 ? op->N : 1) * T * sizeof(float);
   size_t total = 5 * align256(nt);                                             // r, p, z, Ap, x_best
-  total += align256(sizeof(CgState)) + align256(sizeof(CgGraphCtl));
+  total += align256(sizeof(CgState));
   total += align256((size_t)kMaxBlocks * kRedW * sizeof(float));               // per-workgroup partials
   total += 2 * align256((size_t)kRedW * sizeof(double));                       // reduced vectors A / B
   total += ski_stage_bytes(op, T);
@@ -1111,6 +1029,7 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   if (op->N >= (1LL << 27)) return RPGP_EINVAL;              // 32-bit element offsets in the streaming passes (N * 16 < 2^31)
   if (!workspace || workspace_bytes < rpgp_mbcg_workspace_bytes(op, T, precond_rank)) return RPGP_EWORKSPACE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  rpgp_internal::TraceRange tr_solve("rpgp:mbcg_solve");
   const long long N = op->N;
   const int K = precond_rank;
   const size_t nt = (size_t)(N > 0 ? N : 1) * T * sizeof(float);
@@ -1122,7 +1041,6 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   float *Ap = reinterpret_cast<float *>(w); w += align256(nt);
   float *x_best = reinterpret_cast<float *>(w); w += align256(nt);
   CgState *state = reinterpret_cast<CgState *>(w); w += align256(sizeof(CgState));
-  CgGraphCtl *gctl = reinterpret_cast<CgGraphCtl *>(w); w += align256(sizeof(CgGraphCtl));
   float *part = reinterpret_cast<float *>(w); w += align256((size_t)kMaxBlocks * kRedW * sizeof(float));
   double *redA = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
   double *redB = reinterpret_cast<double *>(w); w += align256((size_t)kRedW * sizeof(double));
@@ -1212,109 +1130,41 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
   // no-op on x (alpha = 0).
   int polled_it = -1;                     // iteration whose poll is in flight (-1: none)
   CgPoll last = {1.0f, 0, 0, 0.f, 0, 0, 3.0e38f, 0};
-  // Graph form: RPGP_CG_GRAPH=1, unsharded solves of the operators whose product is plain launches on the stream (the cached
-  // dense product allocates its slabs stream-ordered and stays in the queue-ahead form).
-  // RPGP_CG_FOLD_A=1 (opt-in): measured at the C5 shape the gather with pass A folded in takes 31 us against 19 + 11 us for the
-  // two kernels — the L^T Ap sums on the vector units cost what re-reading p and Ap saved: 2 % per
-  // iteration from the launch boundary alone
-  const char *env_fold = getenv("RPGP_CG_FOLD_A");
-  const bool fold_env = env_fold && env_fold[0] == '1';
-  const bool fold_pass_a = fold_env && !direct && sh.mode == RPGP_SHARD_NONE && op->kind == RPGP_OP_SKI && op->prep && T > 8 &&
-                           T <= 12 && op->noise != 0.f && op->N >= 32768;
-  const bool graph_form = graph_mode_ref() != 0 && sh.mode == RPGP_SHARD_NONE && n_iter > 2 &&
-                          (op->kind == RPGP_OP_FUSED || op->kind == RPGP_OP_FUSED_PREPARED || op->kind == RPGP_OP_SYMCACHE ||
-                           op->kind == RPGP_OP_SKI || op->kind == RPGP_OP_FAMILY);
-  // The legacy default stream (what PyTorch hands over unless a side stream is current) cannot be captured: the graph form then
-  // runs its iterations on a stream of its own, ordered behind the set-up and in front of k_unnormalise by two events.
-  hipStream_t ist = st;
-  void *istream = stream;
-  if (graph_form && st == nullptr) {
-    const int grc = g_gstream.init();
-    if (grc) return grc;
-    ist = g_gstream.s;
-    istream = reinterpret_cast<void *>(ist);
-    CG_CHECK(hipEventRecord(g_gstream.ev[0], st));
-    CG_CHECK(hipStreamWaitEvent(ist, g_gstream.ev[0], 0));
-  }
-  // One iteration's launches.  gc == nullptr: the queue-ahead form — everything that depends on `it` is a kernel argument.
-  // gc != nullptr: the graph form — the same launches with nothing iteration-dependent in them (CgGraphCtl), so that the
-  // sequence can be captured once and replayed.
-  auto enqueue_iteration = [&, ist, istream](int it, const CgGraphCtl *gc) -> int {
-    hipStream_t st = ist;                 // (the launch macros name `st` / `stream`: the iterations' stream inside this lambda)
-    void *stream = istream;
-    // pass A folded into the operator's last kernel where that kernel offers it (round 5: the LDS gather of the planned SKI
-    // product): the operator then leaves `folded` slabs in partA and pass A is not launched
-    int rc, folded = 0;
-    if (fold_pass_a)
-      rc = rpgp_internal::ski_mvm_planned_passa(op->prep, op->Z, op->grid_params, p, Ap, op->N, op->ldz, op->J, op->G, T, op->scale,
-                                                op->noise, op_ws, op_ws_bytes, st, L, K, partA, &folded);
-    else
-      rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
+  // One iteration's launches: the executor only ENQUEUES (the hipGraph form of this loop — one captured iteration replayed —
+  // was built in round 5 and measured 6 - 17 % slower than this queue-ahead form, whose launches already run ahead of the
+  // device: DESIGN.md §3.4, tools/experiments/r5_cg_graph_form.patch).
+  auto enqueue_iteration = [&](int it) -> int {
+    rpgp_internal::TraceRange tr_it(it % 8 == 0 ? "rpgp:cg_iteration" : nullptr);
+    const int rc = apply_operator(op, sh, p, Ap, T, op_ws, op_ws_bytes, stream);
     if (rc) return rc;
-    float *pb_new = partB[gc ? 0 : (it & 1)];   // (ping-pong kept: the set-up pass B's slabs live in partB[1] until iteration 0 has read redB)
-    int *tick = graph_form ? &state->it : (int *)nullptr;      // (the graph form counts its iterations on the device)
-    if (!folded) {
-      CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, partA, N, K, tick));
-    } else if (tick) {
-      hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, st, tick);
-    }
-    CG_REDUCE(partA, redA, folded ? folded : nba);
-    const int slot = gc ? 0 : (it < hist_len ? it : kMaxHist);      // history row (the last row is a scratch slot)
+    float *pb_new = partB[it & 1];   // (ping-pong kept: the set-up pass B's slabs live in partB[1] until iteration 0 has read redB)
+    CG_DISPATCH_T(T, hipLaunchKernelGGL((k_pass_a<TT>), dim3(nba), dim3(256), 0, st, p, Ap, L, partA, N, K));
+    CG_REDUCE(partA, redA, nba);
+    const int slot = it < hist_len ? it : kMaxHist;      // history row (the last row is a scratch slot)
     const bool hist_pending = it < n_hist - 1;
-    const bool check_now = !gc && it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
+    const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
     CgPoll *poll_dst = check_now ? g_poll.host_dev + (it % kPollRing) : (CgPoll *)nullptr;
-    const int cur = gc ? 0 : (it & 1), count = gc ? 0 : it + 1;
+    const int cur = it & 1, count = it + 1;
     if (direct) {
       CG_PASS_B(true, p, Ap, x, r, z, L, Cinv, redA, redB, pb_new, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2,
-                eps, stop_after, cur, 0, partA, nba, nil, 0, gc);
+                eps, stop_after, cur, 0, partA, nba, nil, 0);
       CG_PASS_C(true, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, cur, 0, check_now ? 1 : 0, tolerance,
-                count, stagnation_window, x, x_best, poll_dst, pb_new, nbb, redB, gc);
+                count, stagnation_window, x, x_best, poll_dst, pb_new, nbb, redB);
     } else {
       CG_PASS_B(false, p, Ap, x, r, z, L, Cinv, redA, redB, pb_new, state, alpha_d + (size_t)slot * kMaxT, N, K, precond_sigma2,
-                eps, stop_after, cur, 0, nil, 0, nil, 0, gc);
+                eps, stop_after, cur, 0, nil, 0, nil, 0);
       CG_REDUCE(pb_new, redB, nbb);
       CG_PASS_C(false, zsrc, p, redB, state, beta_d + (size_t)slot * kMaxT, N, eps, cur, 0, check_now ? 1 : 0, tolerance,
-                count, stagnation_window, x, x_best, poll_dst, nil, 0, (double *)nullptr, gc);
+                count, stagnation_window, x, x_best, poll_dst, nil, 0, (double *)nullptr);
     }
     return (int)hipGetLastError();
   };
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t gexec = nullptr;
-  struct GraphGuard {                     // (every return path below destroys what was instantiated)
-    hipGraph_t &g;
-    hipGraphExec_t &e;
-    ~GraphGuard() {
-      if (e) (void)hipGraphExecDestroy(e);
-      if (g) (void)hipGraphDestroy(g);
-    }
-  } graph_guard{graph, gexec};
-  if (graph_form) {
-    CgGraphCtl hc;
-    hc.hist_len = hist_len; hc.n_hist = n_hist; hc.min_it = min_it; hc.check_every = check_every; hc.n_iter = n_iter;
-    hc.alpha_base = alpha_d; hc.beta_base = beta_d; hc.poll_base = g_poll.host_dev;
-    hc.partB[0] = partB[0]; hc.partB[1] = partB[1];
-    CG_CHECK(hipMemcpyAsync(gctl, &hc, sizeof(hc), hipMemcpyHostToDevice, ist));     // (pageable source: staged before the call returns)
-  }
   for (it = 0; it < n_iter; ++it) {
     const bool hist_pending = it < n_hist - 1;
     const bool check_now = it >= min_it && !hist_pending && (it % check_every == 0 || it == n_iter - 1);
     if (check_now) *reinterpret_cast<volatile int *>(&hpoll[it % kPollRing].seq) = 0;      // (stale stamp of an earlier solve)
-    if (graph_form && it > 0) {
-      // iteration 0 went through plain launches (every one-time set-up of the operator's launch path — function attributes,
-      // lazily created tables — happens there, outside a capture); the same sequence is now captured once and replayed
-      if (!gexec) {
-        CG_CHECK(hipStreamBeginCapture(ist, hipStreamCaptureModeThreadLocal));
-        const int crc = enqueue_iteration(it, gctl);
-        const hipError_t ce = hipStreamEndCapture(ist, &graph);
-        if (crc) return crc;
-        CG_CHECK(ce);
-        CG_CHECK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
-      }
-      CG_CHECK(hipGraphLaunch(gexec, ist));
-    } else {
-      const int rc = enqueue_iteration(it, nullptr);
-      if (rc) return rc;
-    }
+    const int rc = enqueue_iteration(it);
+    if (rc) return rc;
     if (polled_it >= 0) {                 // consume the previous poll while this iteration runs
       if (!wait_record(&hpoll[polled_it % kPollRing], polled_it + 1, kPollSpinUs)) CG_CHECK(hipEventSynchronize(g_poll.ev[polled_it % kPollRing]));
       last = hpoll[polled_it % kPollRing];
@@ -1325,13 +1175,9 @@ int rpgp_mbcg_solve(const rpgp_operator *op, const float *rhs, float *x, int T, 
       }
     }
     if (check_now) {
-      CG_CHECK(hipEventRecord(g_poll.ev[it % kPollRing], ist));
+      CG_CHECK(hipEventRecord(g_poll.ev[it % kPollRing], st));
       polled_it = it;
     }
-  }
-  if (ist != st) {                        // (back on the caller's stream behind the last iteration)
-    CG_CHECK(hipEventRecord(g_gstream.ev[1], ist));
-    CG_CHECK(hipStreamWaitEvent(st, g_gstream.ev[1], 0));
   }
 #undef CG_REDUCE
 #undef CG_PASS_B

@@ -760,129 +760,6 @@ __global__ __launch_bounds__(256) void mvm_fact_kernel(const float2v *__restrict
   }
 }
 
-// The T = 1, two-rows-per-lane form with the packed lanes running over the lane's TWO ROWS instead of over a pair of
-// projections: t = pk_fma({a_r0, a_r1}, splat(2b), splat(-b^2)), e = exp2 both, acc = pk_fma(e, {Ea_r0, Ea_r1}, acc) — after
-// the JT projections acc.x / acc.y ARE the two rows' kernel values.  The pair form above ends every step with a horizontal
-// add per row, which hipcc packs into one v_pk_add_f32 behind three v_mov_b32 (ISA of round 2: 6 v_mov + 2 v_pk_add per two
-// steps = 11 of the ~60 issue cycles per step that are not exp / fma).  Same instruction count in the projection loop.
-// d = a * splat(b.lo) + splat(c.lo)  /  a * splat(b.hi) + splat(c.hi): the splats are op_sel modifiers of v_pk_fma_f32 (the
-// builtin form materialises them with a v_mov_b32 per operand)
-__device__ __forceinline__ float2v pk_fma_bcast_lo(float2v a, float2v b, float2v c) {
-  float2v d;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-__device__ __forceinline__ float2v pk_fma_bcast_hi(float2v a, float2v b, float2v c) {
-  float2v d;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-
-template <int JT>
-__global__ __launch_bounds__(256) void mvm_fact_rows_kernel(const float2v *__restrict__ rowdat,
-                                                            const float2v *__restrict__ coldat,
-                                                            const float *__restrict__ V, float *__restrict__ slabR,
-                                                            float *__restrict__ slabT, int N, int J, int ldv, int j0, int t0,
-                                                            int chunk_cols, int rotdir, int accumulate, int w0, int rb_first,
-                                                            int slab_row0, int slab_rows) {
-  static_assert(JT % 2 == 0, "even JT");
-  constexpr int R = 2, BR = 512, SC = StageCols<1>::v, NP = JT / 2, STR = FactStride<JT>::v;
-  __shared__ __attribute__((aligned(16))) float sB[SC * STR];
-  __shared__ __attribute__((aligned(16))) float sV[SC];
-  __shared__ __attribute__((aligned(16))) float sT[4 * SC];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int rb, kchunk;
-  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
-  const int r0 = rb * BR;
-  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
-  if (cb >= N) return;
-  const int c_begin = (int)cb;
-  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
-  float2v ap[JT], ea[JT];                 // {row 0, row 1} of this lane per projection
-  float vrow[R];
-  {
-    const int row0 = r0 + wave * 128 + lane, row1 = row0 + 64;
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      float2v x0 = {0.f, 0.f}, x1 = {0.f, 0.f};
-      if (row0 < N) x0 = rowdat[(size_t)row0 * J + j0 + j];
-      if (row1 < N) x1 = rowdat[(size_t)row1 * J + j0 + j];
-      ap[j] = float2v{x0.x, x1.x};
-      ea[j] = float2v{x0.y, x1.y};        // invalid rows: Ea = 0 -> K = 0
-    }
-    vrow[0] = row0 < N ? V[(size_t)row0 * ldv + t0] : 0.f;
-    vrow[1] = row1 < N ? V[(size_t)row1 * ldv + t0] : 0.f;
-  }
-  float accR0 = 0.f, accR1 = 0.f;
-  for (int c0 = c_begin; c0 < c_end; c0 += SC) {
-    __syncthreads();
-    if (tid < SC) {
-      const int col = c0 + tid;
-      const bool cv = col < c_end;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        float2v x0 = {0.f, -1.0e30f}, x1 = {0.f, -1.0e30f};   // padded columns: exp2(-1e30) = 0
-        if (cv) {
-          x0 = coldat[(size_t)col * J + j0 + 2 * p];
-          x1 = coldat[(size_t)col * J + j0 + 2 * p + 1];
-        }
-        *reinterpret_cast<float4v *>(&sB[tid * STR + 4 * p]) = float4v{x0.x, x1.x, x0.y, x1.y};
-      }
-      sV[tid] = cv ? V[(size_t)col * ldv + t0] : 0.f;
-    }
-    __syncthreads();
-    const int ncol = c_end - c0;
-    const int nsub = ncol >= SC ? SC / 64 : (ncol + 63) / 64;
-    for (int sub = 0; sub < nsub; ++sub) {
-      const bool doT = (c0 + sub * 64 >= r0 + BR);
-      float accT = 0.f;
-#pragma unroll 2
-      for (int s = 0; s < 64; ++s) {
-        const int idx = sub * 64 + ((lane + rotdir * s) & 63);
-        const float v = sV[idx];
-        const float *q = sB + __mul24(idx, STR);
-        float2v acc = {0.f, 0.f};
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const float4v c = *reinterpret_cast<const float4v *>(q + 4 * p);
-          const float2v cb2 = {c.x, c.y}, cnb = {c.z, c.w};       // {2b_even, 2b_odd}, {-b^2_even, -b^2_odd}
-          const float2v ta = pk_fma_bcast_lo(ap[2 * p], cb2, cnb);
-          const float2v tb = pk_fma_bcast_hi(ap[2 * p + 1], cb2, cnb);
-          const float2v ea_ = {fast_exp2(ta.x), fast_exp2(ta.y)};
-          const float2v eb_ = {fast_exp2(tb.x), fast_exp2(tb.y)};
-          acc = __builtin_elementwise_fma(ea_, ea[2 * p], acc);
-          acc = __builtin_elementwise_fma(eb_, ea[2 * p + 1], acc);
-        }
-        accR0 = __builtin_fmaf(acc.x, v, accR0);
-        accR1 = __builtin_fmaf(acc.y, v, accR1);
-        float ts = __builtin_fmaf(acc.x, vrow[0], accT);       // (subtiles inside the row block: the sums are discarded)
-        ts = __builtin_fmaf(acc.y, vrow[1], ts);
-        accT = wave_rotate1(ts);
-      }
-      (void)doT;
-      sT[wave * SC + sub * 64 + lane] = accT;
-    }
-    __syncthreads();
-    {
-      const int col = c0 + tid;
-      if (tid < SC && col < c_end && col >= r0 + BR) {
-        const float sum = sT[0 * SC + tid] + sT[1 * SC + tid] + sT[2 * SC + tid] + sT[3 * SC + tid];
-        float *dst = slabT + ((size_t)(rb - rb_first) * N + col) * ldv + t0;
-        *dst = accumulate ? *dst + sum : sum;
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int row = r0 + wave * 128 + r * 64 + lane;
-    if (row < N) {
-      float *dst = slabR + ((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0;
-      const float a = r == 0 ? accR0 : accR1;
-      *dst = accumulate ? *dst + a : a;
-    }
-  }
-}
-
 // out[row][t] = scale * (sum_k slabR[k][row][t] + sum_{rb < row/BR} slabT[rb][row][t]) + noise * V[row][t]
 // A workgroup owns 32 consecutive outputs; its 8 half-waves split the slab entries (entry k goes to group k % 8, each
 // read is a 128-byte contiguous segment) and the 8 group sums are added in a fixed order: deterministic, and short
@@ -940,11 +817,6 @@ __global__ __launch_bounds__(256) void mvm_reduce_kernel(const float *__restrict
 // Outputs per workgroup of the slab reduce: 32 (eight groups share the slab entries: the latency-bound small problems) up to
 // 256 (one group, 1 KB contiguous per slab entry: the large ones, where 128-byte pieces 2 MB apart waste the HBM rate).
 inline int red_outputs(size_t total) {
-  static const int forced = [] {
-    const char *e = getenv("RPGP_RED_OUTS");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced > 0) return forced;
   // measured (tools/r5_symk_red_prof.sh, T = 11 packed-cache product): 64 outputs beat 32 at every size measured (N = 7k,
   // 81k outputs: 7.2 -> 6.5 us; 15k: 10.4 -> 9.4; 50k: 36.6 -> 29.6); 128 only from N ~ 15k (8.3 us) and lose at 7k (10.0 us);
   // below the measured range the round-2 width stays
@@ -954,8 +826,6 @@ inline int red_outputs(size_t total) {
   do {                                                                                                                    \
     const size_t tot__ = (total_);                                                                                        \
     switch (red_outputs(tot__)) {                                                                                         \
-      case 256: hipLaunchKernelGGL(mvm_reduce_kernel<256>, dim3((unsigned)((tot__ + 255) / 256)), dim3(256), 0, st_, __VA_ARGS__); break; \
-      case 128: hipLaunchKernelGGL(mvm_reduce_kernel<128>, dim3((unsigned)((tot__ + 127) / 128)), dim3(256), 0, st_, __VA_ARGS__); break; \
       case 64: hipLaunchKernelGGL(mvm_reduce_kernel<64>, dim3((unsigned)((tot__ + 63) / 64)), dim3(256), 0, st_, __VA_ARGS__); break;    \
       default: hipLaunchKernelGGL(mvm_reduce_kernel<32>, dim3((unsigned)((tot__ + 31) / 32)), dim3(256), 0, st_, __VA_ARGS__); break;    \
     }                                                                                                                     \
@@ -1367,137 +1237,8 @@ __device__ __forceinline__ void symk_tile_rows(const float4v *wp, float4v (&ring
   }
 }
 
-template <int R>
-__global__ __launch_bounds__(256, 2) void symk_mvm_tile_kernel(const float4v *__restrict__ cache, const float *__restrict__ V,
-                                                            float *__restrict__ slabR, float *__restrict__ slabT, int N,
-                                                            int ldv, int t0, int tcnt, int chunk_cols, int w0, int rb_first,
-                                                            int slab_row0, int slab_rows, long long sub0) {
-  constexpr int BR = 256 * R;
-  constexpr int NRT = 4 * R;                        // row tiles of a wave
-  constexpr int NT = 4 * NRT;                       // tiles per wave per subtile
-  constexpr int D = 8;                              // tiles requested ahead
-  constexpr int SVS = 17;                           // LDS row stride of the staged right-hand sides
-  __shared__ __attribute__((aligned(16))) float sV[64 * SVS];
-  __shared__ __attribute__((aligned(16))) float sT[4 * 64 * 16];
-  __shared__ __attribute__((aligned(16))) float sX[4 * 640];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tn = lane & 15, kap = lane >> 4;        // l % 16 (t for A operands, rho / gamma for B and D), l / 16
-  int rb, kchunk;
-  wg_to_tile(blockIdx.x + w0, N, BR, chunk_cols, true, rb, kchunk);
-  const int r0 = rb * BR;
-  const long long cb = (long long)r0 + (long long)kchunk * chunk_cols;
-  if (cb >= N) return;
-  const int c_begin = (int)cb;
-  const int c_end = (c_begin + chunk_cols < N) ? c_begin + chunk_cols : N;
-  const int rw0 = r0 + wave * (64 * R);             // first row of this wave
-
-  // A operands of the transposed product: V[rw0 + 16 rt + 4 kap + j][t = tn]
-  float arow[NRT][4];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = rw0 + 16 * rt + 4 * kap + j;
-      arow[rt][j] = (row < N && tn < tcnt) ? V[(size_t)row * ldv + t0 + tn] : 0.f;
-    }
-  float *scr = sX + wave * 640;                     // this wave's transpose scratch: two 16 x 20 tiles
-  const int woff = tn * 20 + 4 * kap;               // layout 1 in:  K[rho = tn][4 kap .. 4 kap + 3]
-  const int roff = 4 * kap * 20 + tn;               // layout 2 out: K[4 kap + j][gamma = tn], j = 0..3 (stride 20)
-  floatx4m accR[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) accR[rt] = floatx4m{0.f, 0.f, 0.f, 0.f};
-
-  const long long g0 = symk_first_subtile(rb, N, BR) + (long long)kchunk * (chunk_cols / 64) - sub0;
-  const int nsub_wg = (c_end - c_begin + 63) / 64;
-  (void)nsub_wg;
-  // The wave's stream: subtile s at wp + s * SUB, tiles in slot order 64 float4 apart.  Tile slot + D is requested while
-  // tile slot is consumed; past the last subtile of the workgroup the request falls into the neighbouring region of the
-  // cache (or its trailing pad): harmless, and it keeps every address a constant offset from the subtile's base.
-  const float4v *wp = cache + ((size_t)(g0 * 4 + wave) * 16) * R * 64 + lane;
-  constexpr size_t SUB = (size_t)4 * NT * 64;
-  float4v ring[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) ring[d] = __builtin_nontemporal_load(wp + (size_t)d * 64);
-  // The subtile's 64 x 16 right-hand-side block is requested ONE SUBTILE AHEAD into four registers per thread, from clamped
-  // addresses (no load under a condition).  The first version loaded it at the head of its subtile inside a rolled loop whose
-  // conditional load compiled to `global_load; s_waitcnt vmcnt(0); ds_write` — four serial round trips per subtile, each of
-  // which also drained the eight tiles of the ring (933 -> 900-915 us at C4).
-  // Also measured in round 3 and NOT kept (all parity-green): a 32-tile register ring at one wave per SIMD (431 registers):
-  // 1.08 ms; the ring in LDS filled by `global_load_lds_dwordx4` (11-13 slots per wave, hand-counted `s_waitcnt vmcnt`, the
-  // right-hand sides by DMA too, XOR-swizzled slot image read conflict-free in both operand orders, no scratch transposition):
-  // 0.98 ms against 0.94 ms for this kernel in the same run — more bytes in flight do not buy bandwidth here.
-  float vpre[4];
-  auto v_request = [&](int c0n) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int e = tid + 256 * it;
-      const int c = e >> 4, t = e & 15;
-      const int col = c0n + c;
-      const int colc = col < N ? col : N - 1;
-      const int tc = t < tcnt ? t : 0;
-      vpre[it] = V[(size_t)colc * ldv + t0 + tc];        // (selected against the padding when it is written to LDS:
-    }                                                   //  a select next to the load is turned back into a branch + wait)
-  };
-  v_request(c_begin);
-  for (int c0 = c_begin; c0 < c_end; c0 += 64, wp += SUB) {
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int e = tid + 256 * it;
-      const int c = e >> 4, t = e & 15;
-      sV[c * SVS + t] = (c0 + c < c_end && t < tcnt) ? vpre[it] : 0.f;
-    }
-    v_request(c0 + 64 < c_end ? c0 + 64 : c0);          // (last subtile: a harmless re-request keeps the loop branch-free)
-    __syncthreads();
-    float acol[4][4];                               // A operands of the row product: V[c0 + 16 ct + 4 kap + i][t = tn]
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acol[ct][i] = sV[(16 * ct + 4 * kap + i) * SVS + tn];
-    const bool doT = (c0 >= r0 + BR);
-    floatx4m accT[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) accT[ct] = floatx4m{0.f, 0.f, 0.f, 0.f};
-    // Tiles are consumed in pairs A = (rt, p), B = (rt + 1, (p + 1) % 4) — the order the build stores them in — so that
-    // consecutive MFMAs never share an accumulator: the row products of A and B alternate, then the two transposed products.
-    if (doT) {
-      symk_tile_rows<R, true, 0>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
-    } else {
-      symk_tile_rows<R, false, 0>(wp, ring, acol, arow, scr, woff, roff, accR, accT);
-    }
-    // accT[ct]: lane holds D'[t = 4 kap + r][gamma = tn] of column tile ct
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sT[(wave * 64 + 16 * ct + tn) * 16 + 4 * kap + r] = accT[ct][r];
-    __syncthreads();
-    if (doT) {
-      for (int e = tid; e < 64 * 16; e += 256) {
-        const int c = e >> 4, t = e & 15;
-        const int col = c0 + c;
-        if (col < c_end && t < tcnt) {
-          const float sum = sT[(0 * 64 + c) * 16 + t] + sT[(1 * 64 + c) * 16 + t] + sT[(2 * 64 + c) * 16 + t] +
-                            sT[(3 * 64 + c) * 16 + t];
-          slabT[((size_t)(rb - rb_first) * N + col) * ldv + t0 + t] = sum;
-        }
-      }
-    }
-  }
-  // accR[rt]: lane holds D[t = 4 kap + r][rho = tn] of row tile rt
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) {
-    const int row = rw0 + 16 * rt + tn;
-    if (row < N) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = 4 * kap + r;
-        if (t < tcnt) slabR[((size_t)kchunk * slab_rows + (row - slab_row0)) * ldv + t0 + t] = accR[rt][r];
-      }
-    }
-  }
-}
-
-// Round 5 (second session): the same product with ONE workgroup barrier per 64-column subtile instead of three.
+// The wide-layout product: ONE workgroup barrier per 64-column subtile (round 5; the three-barrier first form it replaced is
+// tools/experiments/r6_removed_forms.patch).
 //  * The staged right-hand sides and the four waves' transposed sums live in DOUBLE-BUFFERED LDS images.  Subtile s reads its
 //    A operands from sV[s & 1], requests the block of subtile s + 1 at its head (four registers per thread) and writes it to
 //    sV[(s + 1) & 1] at its end; the waves' transposed sums go to sT[s & 1]; ONE barrier; then the fixed-order cross-wave
@@ -2957,15 +2698,10 @@ typedef double doublex4m __attribute__((ext_vector_type(4)));
 // One workgroup owns ONE 16-row output tile; its 4 waves split the grid points (the K loop) four ways and add their
 // partial tiles through LDS in a fixed order.  (The first version gave each wave its own tile and the whole K loop:
 // 64 dependent K-steps x 4 MFMAs per wave and only 16 J workgroups — 31 us of the 66 us SKI MVM at the C5 shape.)
-// CELLS (round 5): the B operand is formed from the cell-sorted scatter's per-cell tap records instead of being read from the
-// histogram — hist[j][g][t] = ((x0 + x1) + x2) + x3 with x_k = cellpart[cell (j, g - k)][k][t] in float64, the sums of
-// ski_cellsum4_kernel in its order (same bits) — so that the product needs no histogram pass between the scatter and this
-// kernel (a 5 us launch over 270 KB at the C5 shape).  TTc = floats per tap row of cellpart.
-template <int NW, bool CELLS = false>
+template <int NW>
 __global__ __launch_bounds__(64 * NW) void ski_toeplitz_mfma_kernel(const double *__restrict__ hist,
                                                                 const float *__restrict__ gp, float *__restrict__ H,
-                                                                int G, int T, const double *__restrict__ tcol,
-                                                                const float *__restrict__ cellpart = nullptr, int TTc = 0) {
+                                                                int G, int T, const double *__restrict__ tcol) {
   extern __shared__ double dmem[];          // sc[G16] | red[NW - 1][256]
   const int G16 = (G + 15) & ~15;
   double *sc = dmem;
@@ -3000,45 +2736,15 @@ __global__ __launch_bounds__(64 * NW) void ski_toeplitz_mfma_kernel(const double
   constexpr int SB = NW > 4 ? 4 : 8;
   for (int st0 = s_begin; st0 < s_end; st0 += SB) {
     double b[SB][4];
-    if constexpr (CELLS) {
-      float xq[SB][4][4];                                // (all 4 x 4 x SB requests together, clamped to valid records)
 #pragma unroll
-      for (int ss = 0; ss < SB; ++ss)
+    for (int ss = 0; ss < SB; ++ss) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = (st0 + ss) * 16 + 4 * u + q;
-#pragma unroll
-          for (int tap = 0; tap < 4; ++tap) {
-            const int cc = k - tap;
-            const bool okc = k < G && st0 + ss < s_end && !(cc < 0 || cc > G - 4);
-            xq[ss][u][tap] = cellpart[(((size_t)j * G + (okc ? cc : 0)) * 4 + tap) * TTc + nbc];
-          }
-        }
-#pragma unroll
-      for (int ss = 0; ss < SB; ++ss)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = (st0 + ss) * 16 + 4 * u + q;
-          double x[4];
-#pragma unroll
-          for (int tap = 0; tap < 4; ++tap) {
-            const int cc = k - tap;
-            const bool okc = k < G && st0 + ss < s_end && !(cc < 0 || cc > G - 4);
-            x[tap] = okc ? (double)xq[ss][u][tap] : 0.0;
-          }
-          b[ss][u] = (((x[0] + x[1]) + x[2]) + x[3]) * bmask;
-        }
-    } else {
-#pragma unroll
-      for (int ss = 0; ss < SB; ++ss) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = (st0 + ss) * 16 + 4 * u + q;
-          const bool ok = k < G && st0 + ss < s_end;
-          const int kc = ok ? k : 0;
-          const double x = hj[(size_t)kc * T + nbc];
-          b[ss][u] = ok ? x * bmask : 0.0;
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int k = (st0 + ss) * 16 + 4 * u + q;
+        const bool ok = k < G && st0 + ss < s_end;
+        const int kc = ok ? k : 0;
+        const double x = hj[(size_t)kc * T + nbc];
+        b[ss][u] = ok ? x * bmask : 0.0;
       }
     }
     if (st0 == s_begin) __syncthreads();              // sc[] is complete (the loads above are already in flight)
@@ -3721,118 +3427,6 @@ __global__ __launch_bounds__(256) void pivchol_step_fast_kernel(const float *__r
   }
 }
 
-// Cooperative form for 2048 < N <= 32768 (round 5; OPT-IN, see pivchol_common: bitwise equal and no faster): ALL greedy steps in ONE launch of ceil(N / 256) <= 128 co-resident
-// workgroups (a thread owns one row for the whole factorisation: its coordinates in LDS, its row of L and its residual
-// diagonal entry in registers), separated by a grid barrier instead of a launch boundary — rank + 1 launches of ~9 us each
-// (plus the dispatch gaps between them: 175 - 250 us per optimiser step at the C2 / C3 shapes) become one.  Same arithmetic
-// per entry, same tie-break: the factor is bitwise the one of the per-step form.  The barrier is the release / counter /
-// acquire sequence of the Gram finish (rpgp_precond.hip) with a BOUNDED spin: a barrier that does not complete within ~1 s
-// (it cannot, unless the workgroups are not co-resident) poisons the factor with NaN instead of hanging the device.
-__device__ __forceinline__ bool pivchol_grid_barrier(unsigned *counter, unsigned target, int *s_flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 1;
-    long spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1L << 21)) { ok = 0; break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *s_flag = ok;
-  }
-  __syncthreads();
-  return *s_flag != 0;
-}
-
-__global__ __launch_bounds__(256) void pivchol_coop_kernel(const float *__restrict__ Z, float *__restrict__ L,
-                                                           float *pval, int *pidx, unsigned *bar, int N, int ldz,
-                                                           int ncols, int k, float scale, float d0, int kind, int group,
-                                                           int ncomp, const float *__restrict__ wts) {
-  constexpr int KMAX = 16, SZ = 33, PSTRIDE = 128;
-  __shared__ float sval[4];
-  __shared__ int sidx[4];
-  __shared__ float szp[64];
-  __shared__ float slp[KMAX];
-  __shared__ float sdp;
-  __shared__ int spiv;
-  __shared__ int sflag;
-  __shared__ float sZ[256 * SZ];
-  const int tid = threadIdx.x, nb = (int)gridDim.x;
-  const int i = blockIdx.x * 256 + tid;
-  const bool own = i < N;
-  const bool in_lds = ncols <= 32;
-  const float pre = pivchol_pre(kind);
-  if (in_lds)
-    for (int j = 0; j < ncols; ++j) sZ[tid * SZ + j] = own ? Z[(size_t)i * ldz + j] : 0.f;
-  const float *zi = in_lds ? (const float *)(sZ + tid * SZ) : Z + (size_t)(own ? i : 0) * ldz;
-  float lrow[KMAX];
-  float dres = d0;
-#pragma unroll
-  for (int m = 0; m < KMAX; ++m) {
-    if (m < k) {                                     // (k is uniform: no thread leaves before the others' barriers)
-      float bv = -1.f;
-      int bi = 0x7fffffff;
-      if (m == 0) {
-        if (tid == 0) { sdp = d0; spiv = 0; }        // stationary kernel: the diagonal is d0 everywhere, ties -> row 0
-      } else {
-        for (int q = tid; q < nb; q += 256) {
-          const float v = pval[(m & 1) * PSTRIDE + q];
-          const int ix = pidx[(m & 1) * PSTRIDE + q];
-          if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
-        }
-        block_argmax(bv, bi, sval, sidx);
-        if (tid == 0) { sdp = bv; spiv = bi; }
-      }
-      __syncthreads();
-      const int piv = spiv;
-      const float dp = sdp;
-      const bool ok = dp > 1e-10f * d0;
-      if (tid < ncols) szp[tid] = Z[(size_t)piv * ldz + tid] * pre;
-      if (tid < m) slp[tid] = L[(size_t)piv * k + tid];
-      __syncthreads();
-      const float inv_sq = ok ? 1.0f / sqrtf(dp) : 0.f;
-      bv = -1.f;
-      bi = 0x7fffffff;
-      if (own) {
-        float l = 0.f;
-        if (ok) {
-          const float row = scale * pivchol_entry(zi, szp, kind, group, ncomp, wts);
-          float corr = 0.f;
-#pragma unroll
-          for (int q = 0; q < m; ++q) corr = __builtin_fmaf(lrow[q], slp[q], corr);
-          l = (row - corr) * inv_sq;
-        }
-        lrow[m] = l;
-        L[(size_t)i * k + m] = l;
-        float nd = dres - l * l;
-        nd = nd < 0.f ? 0.f : nd;
-        nd = (i == piv) ? 0.f : nd;
-        dres = nd;
-        bv = nd;
-        bi = i;
-      }
-      if (m + 1 < k) {
-        __syncthreads();
-        block_argmax(bv, bi, sval, sidx);
-        if (tid == 0) {
-          pval[((m + 1) & 1) * PSTRIDE + blockIdx.x] = bv;
-          pidx[((m + 1) & 1) * PSTRIDE + blockIdx.x] = bi;
-        }
-        if (!pivchol_grid_barrier(bar, (unsigned)(m + 1) * (unsigned)nb, &sflag)) {
-          if (own)
-            for (int q = 0; q < k; ++q) L[(size_t)i * k + q] = __builtin_nanf("");
-          return;
-        }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // DPA-GP diversification (rp.space_equally, rp.py:241-266) as ONE single-workgroup launch:
 // `niter` plain gradient steps of size lr on  L(P) = sum_{a != b} cos^4(angle(P_a, P_b)),  then row normalisation.
@@ -3899,13 +3493,6 @@ __global__ __launch_bounds__(256) void space_equally_kernel(float *__restrict__ 
 
 // ------------------------------- host-side helpers -------------------------------------------
 
-// The matrix-core form of the prepared MVM (rpgp_mfma.hip) is an opt-in experiment: `v_mfma_f32_32x32x2_f32` runs on
-// the SIMD's fp32 vector lanes and serialises with the v_exp/v_fma stream (measured: +64 cycles per stage),
-// so it is slower than the VALU kernel.  RPGP_MFMA=1 in the environment (read per call) selects it for A/B measurements.
-inline bool mfma_requested() {
-  const char *e = getenv("RPGP_MFMA");
-  return e && e[0] == '1';
-}
 int g_num_cus = 256;       // compute units of the current device (set by rpgp_init)
 int g_rotdir = 0;  // +1: wave_rotate1 delivers lane l+1's value to lane l; -1: lane l-1's.  0 = not probed.
 
@@ -4089,20 +3676,10 @@ inline size_t plan_workspace_floats(const TilePlan &p, int64_t N, int T, bool sy
   return f;
 }
 
-// When does the prepared symmetric MVM take the matrix-core kernels?  Single right-hand side pieces (T = 1) and enough
-// rows to fill the chip with 128-row workgroups.
-inline bool use_mfma_plan(int64_t N, int T) { return T == 1 && N >= 2048; }
-
 inline size_t mvm_workspace_floats(int64_t M, int64_t N, int T, bool sym, int world = 1, int rank = 0, bool r1 = false) {
   size_t f = plan_workspace_floats(make_plan(M, N, sym, T, world, rank, r1), N, T, sym);
   if (sym && !r1 && M == N && world <= 1) {       // the tapered plan of the single-GPU T = 1 prepared path (more chunk slabs)
     const size_t g = plan_workspace_floats(make_plan(M, N, sym, T, world, rank, false, 0, 4608.0, true), N, T, sym);
-    if (g > f) f = g;
-  }
-  if (sym && !r1 && M == N && use_mfma_plan(N, T)) {
-    // the prepared path may run the matrix-core plan (smaller row blocks -> more transposed slabs): one workspace
-    // size serves both plans
-    const size_t g = plan_workspace_floats(make_plan(M, N, sym, T, world, rank, false, rpgp_internal::kMfmaBR), N, T, sym);
     if (g > f) f = g;
   }
   return f;
@@ -4166,16 +3743,6 @@ template <int JT, int TT>
 int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *coldat, const float *V, float *slabR,
                     float *slabT, int N, int J, int ldv, int j0, int t0, int tcnt, int accumulate, hipStream_t st) {
   dim3 grid(p.w1 - p.w0), block(256);
-  if constexpr (TT == 1 && (JT == 20 || JT == 10)) {
-    // opt-in experiment (RPGP_FACT_ROWS=1), measured SLOWER than the pair form: 2.48 vs 2.31 ms at C4 — the op_sel splats
-    // need inline asm, and hipcc then pads every exp -> fma dependence with s_nop (32 per two steps) instead of interleaving
-    const char *env_rows = getenv("RPGP_FACT_ROWS");
-    if (p.R == 2 && tcnt == 1 && env_rows && atoi(env_rows) != 0) {
-      hipLaunchKernelGGL((mvm_fact_rows_kernel<JT>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv, j0, t0,
-                         p.chunk_cols, g_rotdir, accumulate, p.w0, p.rb0, p.row0, p.rows);
-      return launch_status();
-    }
-  }
   if constexpr (TT == 1 && JT == 20) {
     if (tcnt == 1 && fact_asm_applies(p, 1, J, j0, j0 + 20))
       return rpgp_internal::launch_mvm_fact_asm(rowdat, coldat, V, slabR, slabT, N, ldv, t0, p.chunk_cols, p.taper, accumulate,
@@ -4269,9 +3836,8 @@ int launch_bilinear_sym(int tt, const TilePlan &p, const float *Z, const float *
   constexpr bool dma4 = !((JT + 8) % 4 == 0 && ((JT + 8) / 4) % 2 == 0), dma12 = !((JT + 24) % 4 == 0 && ((JT + 24) / 4) % 2 == 0);
   if constexpr (dma4 && dma12) {
     // the column records are staged by LDS-DMA from a pre-scaled copy of Z (20-column piece at C4: 6.26 -> 5.87 ms alternating
-    // in one process, bit-identical results); RPGP_BIL_DMA=0 restores the register staging
-    const char *ev = getenv("RPGP_BIL_DMA");
-    if (Zs && !(ev && ev[0] == '0')) {
+    // in one process, bit-identical results)
+    if (Zs) {
       const long long total = (long long)N * JT;
       hipLaunchKernelGGL(scale_columns_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256),
                          0, st, Z, Zs, (long long)N, ldz, j0, JT);
@@ -4504,10 +4070,8 @@ inline SymkPlan symk_plan(int64_t N, int world, int rank, bool wide = false) {
 }
 // (+ one subtile of padding: the wide product's requests run a few tiles past a workgroup's last subtile)
 inline size_t symk_bytes(const SymkPlan &sp) { return (size_t)(sp.sub1 - sp.sub0 + 1) * sp.p.BR * 64 * sizeof(float); }
-// nontemporal loads unless the (rank's share of the) cache fits the Infinity Cache; RPGP_SYMK_NT=0/1 forces (read per call: A/B)
+// nontemporal loads unless the (rank's share of the) cache fits the Infinity Cache
 inline bool symk_nt_loads(const SymkPlan &sp) {
-  const char *e = getenv("RPGP_SYMK_NT");
-  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
   return symk_bytes(sp) > (size_t)300000000;      // (277 MB: default policy 60.9 us against 64.6; 464 MB: 113 against 106)
 }
 inline int symk_t_piece(int remaining) {
@@ -4542,28 +4106,16 @@ int symk_launch_build_tile(const SymkPlan &sp, const float *Z, float4v *cache, i
 inline int symk_launch_mvm_tile(const SymkPlan &sp, const float4v *cache, const float *V, float *slabR, float *slabT,
                                 int N, int T, int t0, int tcnt, hipStream_t st) {
   dim3 grid(sp.p.w1 - sp.p.w0), block(256);
-  // RPGP_SYMK_WIDE_V2=0: the three-barrier kernel (read per call: tools/r5_symk_wide_ab.py alternates inside one process)
-  const char *env_v2 = getenv("RPGP_SYMK_WIDE_V2");
-  const bool one_barrier = env_v2 ? env_v2[0] != '0' : true;
-  if (one_barrier) {
-    const bool nt = symk_nt_loads(sp);
+  const bool nt = symk_nt_loads(sp);
 #define RPGP_SYMK_T2(RR, NTF)                                                                                        \
   hipLaunchKernelGGL((symk_mvm_tile2_kernel<RR, NTF>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,   \
                      sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0)
-    if (sp.p.R == 2) {
-      if (nt) RPGP_SYMK_T2(2, true); else RPGP_SYMK_T2(2, false);
-    } else {
-      if (nt) RPGP_SYMK_T2(1, true); else RPGP_SYMK_T2(1, false);
-    }
-#undef RPGP_SYMK_T2
-    return launch_status();
+  if (sp.p.R == 2) {
+    if (nt) RPGP_SYMK_T2(2, true); else RPGP_SYMK_T2(2, false);
+  } else {
+    if (nt) RPGP_SYMK_T2(1, true); else RPGP_SYMK_T2(1, false);
   }
-  if (sp.p.R == 2)
-    hipLaunchKernelGGL((symk_mvm_tile_kernel<2>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
-                       sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
-  else
-    hipLaunchKernelGGL((symk_mvm_tile_kernel<1>), grid, block, 0, st, cache, V, slabR, slabT, N, T, t0, tcnt,
-                       sp.p.chunk_cols, sp.p.w0, sp.p.rb0, sp.p.row0, sp.p.rows, sp.sub0);
+#undef RPGP_SYMK_T2
   return launch_status();
 }
 template <int TT>
@@ -4626,7 +4178,6 @@ int rpgp_init(void) {
 int rpgp_prepared_kernel_id(int64_t N, int J, int T) {
   if (N <= 0 || J <= 0 || T <= 0) return -RPGP_EINVAL;
   if (rpgp_init()) return -RPGP_EINVAL;
-  if (use_mfma_plan(N, T) && mfma_requested() && rpgp_internal::mfma_supported(next_j_piece(J), next_t_piece(T))) return 2;
   const TilePlan p = make_plan(N, N, true, T);
   return fact_asm_applies(p, T, J, 0, J) ? 1 : 0;
 }
@@ -4775,23 +4326,9 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
   const size_t need = mvm_workspace_floats(N, N, T, true, world, rank) * sizeof(float);
   if (!workspace || workspace_bytes < need) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  // matrix-core plan when every (column piece, right-hand-side piece) of this call is served by rpgp_mfma.hip
-  bool mfma = use_mfma_plan(N, T) && mfma_requested();
-  for (int j = j0; mfma && j < j1;) {
-    const int jt = next_j_piece(j1 - j);
-    for (int t0 = 0; mfma && t0 < T;) {
-      const int tt = next_t_piece(T - t0);
-      mfma = rpgp_internal::mfma_supported(jt, tt);
-      t0 += tt;
-    }
-    j += jt;
-  }
-  TilePlan p = make_plan(N, N, true, T, world, rank, false, mfma ? rpgp_internal::kMfmaBR : 0);
-  if (!mfma && fact_asm_applies(p, T, J, j0, j1)) {
-    // the hand-scheduled kernel (rpgp_fact_asm.hip) understands tapered chunks: smaller workgroups at the end of the sweep
-    const char *env_tp = getenv("RPGP_TAPER");
-    if (!env_tp || atoi(env_tp) != 0) p = make_plan(N, N, true, T, world, rank, false, 0, 4608.0, true);
-  }
+  TilePlan p = make_plan(N, N, true, T, world, rank);
+  // the hand-scheduled kernel (rpgp_fact_asm.hip) understands tapered chunks: smaller workgroups at the end of the sweep
+  if (fact_asm_applies(p, T, J, j0, j1)) p = make_plan(N, N, true, T, world, rank, false, 0, 4608.0, true);
   PrepLayout L = prep_layout(const_cast<void *>(prep), N, J);
   float *slabR = reinterpret_cast<float *>(workspace);
   float *slabT = slabR + (size_t)p.maxchunks * p.rows * T;
@@ -4804,11 +4341,7 @@ int rpgp_mvm_sym_prepared_range(const void *prep, const float *V, float *out, in
     for (int t0 = 0; t0 < T;) {
       const int tt = next_t_piece(T - t0);
       const int tcnt = (T - t0 < tt) ? T - t0 : tt;
-      if (mfma)   // table roles are swapped: the row side of the MFMA kernel is {2a, -a^2}, its column side {a, exp2(-a^2)}
-        rc = rpgp_internal::launch_mvm_mfma(jt, tt, L.coldat, L.rowdat, V, slabR, slabT, (int)N, J, T, j, t0, tcnt,
-                                            p.chunk_cols, first ? 0 : 1, p.w0, p.w1 - p.w0, p.rb0, p.row0, p.rows, st);
-      else
-        rc = dispatch_fact_jt(jt, tt, p, L.rowdat, L.coldat, V, slabR, slabT, (int)N, J, T, j, t0, tcnt, first ? 0 : 1, st);
+      rc = dispatch_fact_jt(jt, tt, p, L.rowdat, L.coldat, V, slabR, slabT, (int)N, J, T, j, t0, tcnt, first ? 0 : 1, st);
       if (rc) return rc;
       t0 += tcnt;
     }
@@ -4885,7 +4418,7 @@ int rpgp_bilinear_grad(const float *Z, const float *L, const float *R, float *gZ
   if (N > 0x7fffffffLL) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_bilinear_grad_workspace_bytes(N, j1 - j0)) return RPGP_EWORKSPACE;
   hipStream_t st = as_stream(stream);
-  if (bilinear_use_sym(N) && !(getenv("RPGP_BILINEAR_FULL") && getenv("RPGP_BILINEAR_FULL")[0] == '1')) {
+  if (bilinear_use_sym(N)) {
     // symmetric sweep: every unordered pair once (half the exponentials), tile plan of the fused MVM with BR = 512
     int rc = rpgp_init();
     if (rc) return rc;
@@ -5138,20 +4671,8 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
     hipLaunchKernelGGL(pivchol_kernel, dim3(1), dim3(1024), 0, st, Z, L, diag_work, (int)N, ldz, ncols, rank, scale);
     return launch_status();
   }
-  // RPGP_PIVCHOL_COOP=1 (opt-in, read per call: tools/r5_pivchol_ab.py alternates): measured 124 / 134 / 141 / 164 us against
-  // 137 / 138 / 139 / 142 us for the per-step launches at N = 4k / 7k / 15k / 33k — a grid barrier with its agent-scope release
-  // and acquire costs ~8 us, a dependent launch boundary 1.5 - 2 us (MI355X_MICROARCH.md, persistent-kernel price list)
-  const char *env_coop = getenv("RPGP_PIVCHOL_COOP");
-  const bool coop = env_coop ? env_coop[0] == '1' : false;
-  if (coop && N <= 32768 && !gp && rank <= 16) {   // one cooperative launch: <= 128 co-resident workgroups, grid barriers
-    float *cp = diag_work + N;
-    unsigned *bar = reinterpret_cast<unsigned *>(cp + 2047);
-    RPGP_CHECK(hipMemsetAsync(bar, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(pivchol_coop_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, Z, L, cp,
-                       reinterpret_cast<int *>(cp + 1024), bar, (int)N, ldz, ncols, rank, scale, d0, kind, group, ncomp,
-                       wts);
-    return launch_status();
-  }
+  // (all greedy steps as ONE cooperative launch with grid barriers was built in round 5 and measured no faster than the
+  //  per-step launches — a grid barrier ~8 us against a 1.5 - 2 us launch boundary: tools/experiments/r6_removed_forms.patch)
   int nb = (int)((N + 255) / 256);
   if (nb > 512) nb = 512;
   float *pval[2] = {diag_work + N, diag_work + N + 512};
@@ -5162,9 +4683,9 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
     hipLaunchKernelGGL(pivchol_init_from_diag_kernel, dim3(nb), dim3(256), 0, st, diag_work, pval[0], pidx[0], (int)N);
   }
   // (a stationary kernel's residual diagonal starts at d0 everywhere: step 0 knows that itself — no initialisation launch)
-  // RPGP_PIVCHOL_FAST=0: the general per-step kernel also for the flagship operator (read per call: A/B)
-  const char *env_fast = getenv("RPGP_PIVCHOL_FAST");
-  const bool fast = !(env_fast && env_fast[0] == '0') && kind == RPGP_KIND_RBF && group == 1 && !wts && !gp && ncols <= 32 &&
+  // the flagship operator's fast per-step kernel (own-row operands requested before the pivot is known); every other operator,
+  // wide coordinate rows and ranks beyond 16 take the general per-step kernel
+  const bool fast = kind == RPGP_KIND_RBF && group == 1 && !wts && !gp && ncols <= 32 &&
                     rank <= 16 && (long long)nb * 256 >= N;
   for (int m = 0; fast && m < rank; ++m)
     hipLaunchKernelGGL(pivchol_step_fast_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
@@ -5479,7 +5000,7 @@ int ski_scatter_all(const float *Z, const float *gp, const float *V, float *hist
 }
 
 int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T, hipStream_t st,
-                 const double *tcol = nullptr, const float *cellpart = nullptr, int TTc = 0) {
+                 const double *tcol = nullptr) {
   if (!hist_is_double && T > 24) {
     dim3 grid((T + 63) / 64, (G + 15) / 16, J);
     hipLaunchKernelGGL(ski_toeplitz_wide_kernel, grid, dim3(256), (size_t)G * sizeof(float), st,
@@ -5494,15 +5015,6 @@ int ski_toeplitz(const void *hist, int hist_is_double, const float *gp, float *H
   const size_t lds = ((size_t)G16 + (size_t)(nw - 1) * 256) * sizeof(double);
   if (hist_is_double && T <= 64 && lds <= 64 * 1024) {        // matrix-core path, float64 (16 columns per workgroup)
     dim3 grid((G + 15) / 16, J, (T + 15) / 16);
-    if (cellpart && T <= 16) {                               // B operand straight from the scatter's per-cell tap records
-      if (wide_wg)
-        hipLaunchKernelGGL((ski_toeplitz_mfma_kernel<16, true>), grid, dim3(1024), lds, st, (const double *)nullptr, gp, H, G, T,
-                           tcol, cellpart, TTc);
-      else
-        hipLaunchKernelGGL((ski_toeplitz_mfma_kernel<4, true>), grid, dim3(256), lds, st, (const double *)nullptr, gp, H, G, T,
-                           tcol, cellpart, TTc);
-      return launch_status();
-    }
     if (wide_wg)
       hipLaunchKernelGGL(ski_toeplitz_mfma_kernel<16>, grid, dim3(1024), lds, st, reinterpret_cast<const double *>(hist), gp,
                          H, G, T, tcol);
@@ -5557,16 +5069,6 @@ namespace rpgp_internal {
 int ski_toeplitz_launch(const void *hist, int hist_is_double, const float *gp, float *H, int J, int G, int T,
                         hipStream_t st, const double *tcol) {
   return ski_toeplitz(hist, hist_is_double, gp, H, J, G, T, st, tcol);
-}
-bool ski_toeplitz_takes_cells(int J, int G, int T) {          // (the conditions of the matrix-core path above)
-  const int G16 = (G + 15) & ~15;
-  const bool wide_wg = (size_t)J * ((G + 15) / 16) <= 640 && G16 >= 256;
-  const size_t lds = ((size_t)G16 + (size_t)((wide_wg ? 16 : 4) - 1) * 256) * sizeof(double);
-  return T <= 16 && lds <= 64 * 1024;
-}
-int ski_toeplitz_cells_launch(const float *cellpart, int TTc, const float *gp, float *H, int J, int G, int T, hipStream_t st,
-                              const double *tcol) {
-  return ski_toeplitz(nullptr, 1, gp, H, J, G, T, st, tcol, cellpart, TTc);
 }
 int ski_gather_launch(const float *Z, const float *gp, const float *H, const float *V, float *out, long long M, int ldz,
                       int J, int G, int T, float scale, float noise, hipStream_t st) {

@@ -329,13 +329,9 @@ int gram_launch(const float *A, long long lda, const float *B, long long ldb, lo
   int ma = tiles16(K), nb = tiles16(T);
   if (ma == 3) ma = 4;                               // compiled tile counts: 1, 2, 4
   if (nb == 3) nb = 4;
-  // few slabs: the last workgroup of the partial kernel finishes (no second launch); RPGP_GRAM_FOLD=0 keeps the finish kernel
+  // few slabs: the last workgroup of the partial kernel finishes (no second launch)
   unsigned *counter = nullptr;
-  static const bool fold_on = [] {
-    const char *e = getenv("RPGP_GRAM_FOLD");
-    return !(e && e[0] == '0');
-  }();
-  if (fold_on && g <= 64) counter = gram_counter();
+  if (g <= 64) counter = gram_counter();
   const bool tall = N >= 131072 && !counter;           // (sixteen waves per workgroup; the small tile counts only)
 #define RPGP_GRAM_CASE(MA_, NB_)                                                                                       \
   if (ma == MA_ && nb == NB_) {                                                                                        \

@@ -26,6 +26,7 @@ from torch.nn import functional as F
 from . import backend as _backend
 from . import settings
 from .hostvals import host_float, prefetch, remember
+from .ops import trace_range
 
 LOG2PI = math.log(2.0 * math.pi)
 
@@ -99,33 +100,6 @@ def _native_step_ok(model, target, raw_ls):
             and settings.num_trace_samples.value() <= 15 and settings.step_kernels.on())
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    key = torch.device(device).index
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
-
-
-def _early_presolve():
-    import os
-    return os.environ.get("RPGP_EARLY_PRESOLVE", "1") != "0"          # (=0: A/B, tools/r5_step_presolve_ab.py)
-
-
-def _overlap_ok(op, Z):
-    """Build the cached operator beside the preconditioner?  Only where a cache WILL be built: the plain float32 exact operator
-    on a HIP device under the cached-K rule (inv_quad_logdet.solve_operator).  Opt-in (settings.overlap_cache_build or
-    RPGP_OVERLAP_BUILD=1): measured a draw, see settings.py."""
-    import os
-    from .operators import AdditiveRPOperator
-    return ((settings.overlap_cache_build.on() or os.environ.get("RPGP_OVERLAP_BUILD", "0") == "1") and Z.is_cuda
-            and type(op) is AdditiveRPOperator and Z.dtype == torch.float32 and hasattr(op, "to_symcache")
-            and settings.use_cached_kernel(Z.shape[0], Z.device, 2.0))
-
-
 class _FusedMLL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target, sign=1.0):
@@ -180,47 +154,34 @@ class _FusedMLL(torch.autograd.Function):
         W = pk.projection_module.weight                            # J x d
         p = settings.num_trace_samples.value()
         with torch.no_grad():
-            Peff, hyp, os_f, noise_f, _ = be.step_hyper(raw_ls.reshape(-1), raw_os.reshape(-1), raw_noise.reshape(-1),
-                                                        mean_c.reshape(-1), W, pk.prescale, likelihood.MIN_NOISE)
-            os_, noise = hyp[0], hyp[1]                            # 0-dim views; their host values are known
-            remember(os_, os_f)
-            remember(noise, noise_f)
-            Z = be.project(X, Peff)
+            with trace_range("rpgp:project+prepare"):
+                Peff, hyp, os_f, noise_f, _ = be.step_hyper(raw_ls.reshape(-1), raw_os.reshape(-1), raw_noise.reshape(-1),
+                                                            mean_c.reshape(-1), W, pk.prescale, likelihood.MIN_NOISE)
+                os_, noise = hyp[0], hyp[1]                        # 0-dim views; their host values are known
+                remember(os_, os_f)
+                remember(noise, noise_f)
+                Z = be.project(X, Peff)
             op = bk.operator(Z, None, outputscale=os_, shard=None)
             op._noise_host = noise_f
             khat = AddedDiagOperator(op, noise, noise_value=noise_f)
-            # The cached form of the operator (packed symmetric cache: one compute-bound launch that fills the chip) is built on
-            # a side stream while this one builds the preconditioner (rank + 4 latency-bound launches of a few workgroups
-            # each): both depend on Z only.  The cache's memory comes from the side stream's pool; `record_stream` tells the
-            # allocator that this stream uses it too (the solve), and this stream waits for the build's event before the solve.
-            built = side_done = None
-            if _overlap_ok(op, Z):
-                main = torch.cuda.current_stream(Z.device)
-                side = _side_stream(Z.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    built = solve_operator(op, khat, Z, noise_f, p + 1)
-                    side_done = side.record_event()
-                cache = getattr(built[1], "cache", None)
-                if cache is not None and hasattr(cache, "buf"):
-                    cache.buf.record_stream(main)
-            pre = build_preconditioner(op, noise_f, settings)
-            if side_done is not None:
-                torch.cuda.current_stream(Z.device).wait_event(side_done)
+            # (building the packed cache on a side stream beside the preconditioner build was measured a draw in round 5 and
+            #  is parked in tools/experiments/r6_removed_forms.patch)
+            with trace_range("rpgp:preconditioner"):
+                pre = build_preconditioner(op, noise_f, settings)
             if not isinstance(pre, WoodburyPreconditioner) or pre.L.dtype != torch.float32 or pre.k > 64:
                 return None
             gen = _probe_generator(Z.device)
             e1 = torch.randn(pre.k, p, generator=gen, device=Z.device, dtype=Z.dtype)      # (the draws of pre.sample, same order)
             e2 = torch.randn(n, p, generator=gen, device=Z.device, dtype=Z.dtype)
             full_rhs = be.step_probes(pre.L, e1, e2, math.sqrt(noise_f), target, hyp[2:3])      # [z | y - c], unnormalised
-            matmul, native_op, _ = built if built is not None else solve_operator(op, khat, Z, noise_f, p + 1)
+            matmul, native_op, _ = solve_operator(op, khat, Z, noise_f, p + 1)
             solves, hist = linear_cg(matmul, full_rhs, n_tridiag=p, operator=native_op,
                                      tolerance=settings.cg_tolerance.value(), max_iter=settings.max_cg_iterations.value(),
                                      max_tridiag_iter=settings.max_lanczos_quadrature_iterations.value(),
                                      preconditioner=pre, lanczos="history")
             # The backward pass opens with M^-1 [probes] (two launches): queued HERE, they run while the host does the SLQ
             # quadrature below, instead of behind the autograd engine's start-up at the head of the backward pass.
-            ctx.pre_probes = pre.solve(full_rhs[:, :p]) if _early_presolve() else None
+            ctx.pre_probes = pre.solve(full_rhs[:, :p])
             logdet = float(slq_logdet(hist, n)) + pre.logdet()
             lp, dlp = _prior(likelihood, noise_f)
             # mll = (-0.5 (inv_quad + logdet + n log 2 pi) + log p(sigma^2)) / n      (models.ExactMarginalLogLikelihood)
@@ -237,7 +198,7 @@ class _FusedMLL(torch.autograd.Function):
     def _backward_native(ctx, g):
         be = _backend.get_backend()
         n = ctx.n
-        with torch.no_grad():
+        with torch.no_grad(), trace_range("rpgp:derivative"):
             g = g.reshape(1).contiguous()
             pre_probes = ctx.pre_probes if ctx.pre_probes is not None else ctx.pre.solve(ctx.probes)
             sign = ctx.sign

@@ -182,7 +182,7 @@ class PredictionStrategy:
                 Kh = self._dense_khat.to_dense()                   # float32, noise on the diagonal
                 K64 = Kh.double()
                 from .precond import blocked_cholesky
-                Lc, info = blocked_cholesky(Kh)                    # (bf16x3 trailing updates beyond N = 16k: precond.py)
+                Lc, info = blocked_cholesky(Kh)                    # (fp16x3 trailing updates beyond N = 16k: precond.py)
                 del Kh
             except torch.OutOfMemoryError:                         # lost the race for the memory: the general path serves
                 Kh = K64 = Lc = None

@@ -151,6 +151,46 @@ def mvm_sym(Z, V, scale, noise=0.0, j0=0, j1=None, out=None, shard=None):
     return out.squeeze(1) if squeeze else out
 
 
+class _NullRange:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_RANGE = _NullRange()
+_RANGES_ON = None
+
+
+class _Range:
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _lib.load().rpgp_range_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().rpgp_range_pop()
+        return False
+
+
+def trace_range(name):
+    """Context manager marking a phase of a training step as a roctx range (rpgp_range_push / rpgp_range_pop; SURVEY.md §5
+    "Tracing / profiling").  Live only when a marker library is loaded in the process (`rocprofv3 --marker-trace`); otherwise
+    the shared no-op object is returned — an unprofiled step pays one attribute test per phase."""
+    global _RANGES_ON
+    if _RANGES_ON is None:
+        try:
+            _RANGES_ON = bool(_lib.load().rpgp_range_available())
+        except Exception:
+            _RANGES_ON = False
+    return _Range(name.encode()) if _RANGES_ON else _NULL_RANGE
+
+
 class Prepared:
     """Device-side tables of rpgp_prepare for one Z (centred, pre-scaled coordinates for the factorised fast path)."""
 
@@ -477,11 +517,6 @@ class SkiPlan:
     def ok(self):
         return self.buf is not None
 
-    @property
-    def chunked(self):
-        """True when the plan also carries the tables of the chunked product (built while ski_chunk_mode was on)."""
-        return self.buf is not None and bool(_lib.load().rpgp_ski_plan_is_chunked(self.buf.data_ptr()))
-
 
 def ski_plan(Z, gp, grid_size=1024):
     return SkiPlan(Z, gp, grid_size)
@@ -530,21 +565,6 @@ def ski_grid_from_range(zmin, zmax, grid_size, device, weights=None):
     if weights is not None:
         gp = torch.cat([gp, weights.detach().reshape(-1).to(device=device, dtype=torch.float32)])
     return gp
-
-
-def mbcg_graph_mode(mode=None):
-    """Graph form of the native mBCG executor (rpgp_mbcg_graph_mode): True = one captured iteration replayed as a hipGraph,
-    False = the queue-ahead form (default).  `mode=None` only queries.  Returns the previous setting."""
-    lib = _lib.load()
-    return bool(lib.rpgp_mbcg_graph_mode(-1 if mode is None else int(bool(mode))))
-
-
-def ski_chunk_mode(mode=None):
-    """Which form of the planned SKI product runs (rpgp_ski_chunk_mode): False = the cell-sorted form (default), True = the
-    chunked form of round 5 where the shape allows (opt-in: not faster at the C5 shape) — for plans built
-    while the mode is on (`SkiPlan.chunked`).  `mode=None` only queries.  Returns the previous setting."""
-    lib = _lib.load()
-    return bool(lib.rpgp_ski_chunk_mode(-1 if mode is None else int(bool(mode))))
 
 
 def ski_scatter(Z, gp, V, grid_size=1024, plan=None):

@@ -120,11 +120,6 @@ fused_training = _setting("fused_training", True, flag=True)
 # the two sides of the derivative, the chain rule back to the raw parameters) as single launches (csrc/rpgp_step.hip) instead of
 # chains of element-wise torch launches: the step is host-bound there.  False = the torch operations (same arithmetic).
 step_kernels = _setting("step_kernels", True, flag=True)
-# ... and the packed-cache build of the step (compute-bound, fills the chip) on a SIDE stream beside the preconditioner build
-# (rank + 4 small latency-bound launches that need a few CUs each): the two depend only on Z.  OPT-IN: measured a draw at the
-# C2 / C3 shapes (2080 vs 2085 us, 4471 vs 4449 us per step) and +3 % at C4 (33.4 -> 34.3 ms) — the stretch is paced by the host
-# issuing its ~25 launches, during which the build already runs (profiles/r5b_step_overlap_ab.jsonl).
-overlap_cache_build = _setting("overlap_cache_build", False, flag=True)
 # the all-reduce of the sharded multi-GPU solve: "rccl" (torch.distributed, backend nccl = RCCL over xGMI) or "ipc" (one-shot
 # kernel over IPC-mapped peer buffers, csrc/rpgp_comm.hip); the environment variable RPGP_COMM overrides it
 comm_backend = _setting("comm_backend", "rccl")

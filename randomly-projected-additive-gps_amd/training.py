@@ -16,6 +16,7 @@ from .kernels import (AdditiveStructureRBFKernel, CustomAdditiveKernel, MemoryEf
                       PolynomialProjectionKernel, RBFKernel, ScaledProjectionKernel, ScaleKernel, StrictlyAdditiveKernel)
 from .likelihoods import GaussianLikelihood, SmoothedBoxPrior
 from .models import ExactGPModel, ExactMarginalLogLikelihood
+from .ops import trace_range
 
 EXACT_GP_KINDS = ("full", "additive_rp", "strictly_additive", "additive", "rp_poly", "general_rp_poly")
 REFERENCE_ONLY_KINDS = ("rp", "deep_rp_poly", "multi_full", "duvenaud_additive", "sgpr")
@@ -269,17 +270,21 @@ def train_to_convergence(model, xs, ys, optimizer=None, lr=0.1, objective=None, 
     ma = np.zeros((max_iter,))
     for i in range(max_iter):
         def closure():
-            optimizer_.zero_grad()
-            output = model(xs)
-            if isloss:
-                loss = objective(output, ys)
-            else:                         # (an objective that can negate itself does: models.ExactMarginalLogLikelihood.negative)
-                neg = getattr(objective, "negative", None)
-                loss = neg(output, ys) if neg is not None else -objective(output, ys)
-            loss.backward()
+            with trace_range("rpgp:objective+backward"):
+                optimizer_.zero_grad()
+                output = model(xs)
+                if isloss:
+                    loss = objective(output, ys)
+                else:                     # (an objective that can negate itself does: models.ExactMarginalLogLikelihood.negative)
+                    neg = getattr(objective, "negative", None)
+                    loss = neg(output, ys) if neg is not None else -objective(output, ys)
+                loss.backward()
             return loss
 
-        loss = optimizer_.step(closure).item()
+        # (roctx ranges, live under `rocprofv3 --marker-trace` only: the optimiser's own update is what is left of this range
+        #  behind the closure's)
+        with trace_range("rpgp:optimiser_step"):
+            loss = optimizer_.step(closure).item()
         if verbose > 1:
             print("epoch {}, iter {}, loss {}".format(i, 0, loss))
         losses[i] = loss
@@ -496,7 +501,7 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
     `model.train_inputs` / `model.train_targets` are that permutation of the caller's (trainX, trainY), kept on the model as
     `model.train_row_order` (a LongTensor `order` with `model.train_inputs == trainX[order]`; None when the rows were not
     reordered).  `pred_mean` and every metric refer to the TEST rows, whose order is the caller's; a GP's posterior does
-    not depend on the order of its training rows.  `RPGP_SKI_ROW_ORDER=file` keeps the caller's order."""
+    not depend on the order of its training rows."""
     model_kwargs, train_kwargs = copy.copy(model_kwargs), copy.copy(train_kwargs)
     if double:
         _check_double_supported(kind, model_kwargs)
@@ -504,7 +509,7 @@ def train_exact_gp(trainX, trainY, testX, testY, kind, model_kwargs, train_kwarg
     devices = [torch.device(dev) for dev in devices]
     output_device = devices[0] if output_device is None else torch.device(output_device)
     order = None
-    if model_kwargs.get("ski", False) and trainX.shape[0] >= 4096 and os.environ.get("RPGP_SKI_ROW_ORDER", "") != "file":
+    if model_kwargs.get("ski", False) and trainX.shape[0] >= 4096:
         # grid-interpolation kernels: store the training set in a locality-preserving row order (see locality_order)
         order = locality_order(trainX)
         trainX, trainY = trainX[order.to(trainX.device)], trainY[order.to(trainY.device)]

@@ -194,7 +194,7 @@ def test_cg_regime_inv_quad_and_solution_f32(case):
 def test_cg_regime_mll_with_slq_logdet_f32(case):
     """The same objective WITH the stochastic log-det (what training differentiates): SLQ carries probe noise, so this
     gate is SURVEY §7.3-2's (reported with its spread, not 1e-4): 40 probes x 50 Lanczos steps landed 3.5e-3 (C2) and 8e-4
-    (C3) from the exact value; gated at 1e-2."""
+    (C3) from the exact value; gated at 1e-2 (C2) and 3e-3 (C3)."""
     from rpgp_amd import settings
     model, lik, mll = case.model(torch.float32)
     ref = case.oracle_for(model, lik)
@@ -202,8 +202,9 @@ def test_cg_regime_mll_with_slq_logdet_f32(case):
     with settings.cg_tolerance(1e-5), settings.num_trace_samples(40), settings.max_lanczos_quadrature_iterations(50), \
             settings.deterministic_probes(True), settings.max_cg_iterations(4000), torch.no_grad():
         v = mll(model(model.train_inputs), model.train_targets)
+    # (gates ~3x the measured values, profiles/r4_parity_at_baseline_sizes.jsonl: a regression of the estimator shows)
     _gate(case.c["name"] + " f32 CG-regime MLL with SLQ log-det (40 probes) rel err",
-          abs(v.item() - ref.mll()) / abs(ref.mll()), 1e-2)
+          abs(v.item() - ref.mll()) / abs(ref.mll()), 1e-2 if case.c["name"].startswith("C2") else 3e-3)
 
 
 def _predict(case, dtype, tol):
@@ -222,8 +223,8 @@ def _predict(case, dtype, tol):
 def test_predictive_mean_and_variance_f32(case):
     """training_routines.py:551-575 in float32 (the default dtype): mean cache by preconditioned CG at 1e-7, the N_test-wide
     covariance through the float64 factor of the stored fp32 matrix.  Gates: north_star's 1e-4 for the mean and the
-    variance; Khat^-1 (y - c) itself is gated at 2e-3 — its error sits in the eigen-directions below sigma^2 where
-    fp32 entries of K (relative 6e-8 on O(1) values against sigma^2 = 0.1 ... kappa ~ 1e5) leave O(kappa eps)."""
+    variance; Khat^-1 (y - c) itself is gated at 2e-5 (measured 7e-8 with the float64-residual refinement of the mean cache;
+    2e-3 before it — its unrefined error sits in the eigen-directions below sigma^2, O(kappa eps))."""
     model, lik, mean, var, alpha, nll = _predict(case, torch.float32, 1e-7)
     ref = case.oracle_for(model, lik)
     mean_ref, cov_ref = ref.predict(case.c["Xs"].numpy(), full_cov=True)
@@ -232,7 +233,7 @@ def test_predictive_mean_and_variance_f32(case):
     _gate(nm + " f32 predictive variance rel err", _rel(var, np.diag(cov_ref)), 1e-4)
     _gate(nm + " f32 predictive variance max rel err per point",
           float(np.max(np.abs(var - np.diag(cov_ref)) / np.diag(cov_ref))), 5e-4)
-    _gate(nm + " f32 Khat^-1 (y - c) rel err", _rel(alpha, ref.solve(ref.y - ref.c)), 2e-3)
+    _gate(nm + " f32 Khat^-1 (y - c) rel err", _rel(alpha, ref.solve(ref.y - ref.c)), 2e-5)
     nll_ref = ref.test_nll(case.c["Xs"].numpy(), case.c["ys"].numpy())
     _gate(nm + " f32 test_nll rel err", abs(nll - nll_ref) / abs(nll_ref), 1e-4)
 

@@ -206,33 +206,25 @@ def test_symcache_pair_shards_sum_to_whole(gpu_device, N, world, wide):
 
 @pytest.mark.parametrize("N,T,shard", [(257, 11, None), (4097, 11, None), (4500, 16, None), (6211, 5, None), (5000, 20, None),
                                        (9000, 11, (3, 1)), (12345, 11, None), (2049, 37, (2, 0))])
-def test_symcache_wide_kernels_bitwise_interchangeable(gpu_device, N, T, shard, monkeypatch):
-    """The wide product's two kernels — one workgroup barrier per subtile with double-buffered LDS images and contiguous
-    slab stores (default) / three barriers (RPGP_SYMK_WIDE_V2=0) — form the same sums in the same order: identical bits
-    for ragged sizes, one and two rows per lane, pair shards, blocks of more than 16 right-hand sides (second pass at
-    t0 = 16: the strided slab stores) and against the oracle."""
+def test_symcache_wide_product_ragged_sizes_and_shards(gpu_device, N, T, shard):
+    """The wide product (one workgroup barrier per subtile, double-buffered LDS images, contiguous slab stores) for ragged
+    sizes, one and two rows per lane, pair shards, blocks of more than 16 right-hand sides (second pass at t0 = 16: the strided
+    slab stores): against the oracle (whole cache), reproducible bit for bit, and — whatever the load policy the cache's size
+    selects — equal to the thin layout's product of the same columns to rounding."""
     from rpgp_amd import ops
     rng = np.random.default_rng(N + T)
     Z = rng.standard_normal((N, 20)).astype(np.float32)
     V = rng.standard_normal((N, T)).astype(np.float32)
     Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
     cache = ops.SymCache(Zt, wide=True, shard=shard)
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("RPGP_SYMK_WIDE_V2", mode)
-        outs[mode] = ops.symcache_mvm(cache, Vt, 0.2, 0.3)
-    assert torch.isfinite(outs["1"]).all()
-    assert torch.equal(outs["0"], outs["1"])
-    # the load policy (nontemporal / default: chosen by the cache's size) is invisible in the result, in both layouts
+    out = ops.symcache_mvm(cache, Vt, 0.2, 0.3)
+    assert torch.isfinite(out).all()
+    assert torch.equal(ops.symcache_mvm(cache, Vt, 0.2, 0.3), out)
     thin = ops.SymCache(Zt, wide=False, shard=shard)
     ref_thin = ops.symcache_mvm(thin, Vt[:, :3].contiguous(), 0.2, 0.3)
-    for nt in ("0", "1"):
-        monkeypatch.setenv("RPGP_SYMK_NT", nt)
-        assert torch.equal(ops.symcache_mvm(cache, Vt, 0.2, 0.3), outs["1"])
-        assert torch.equal(ops.symcache_mvm(thin, Vt[:, :3].contiguous(), 0.2, 0.3), ref_thin)
-    monkeypatch.delenv("RPGP_SYMK_NT")
+    assert float((out[:, :3] - ref_thin).norm() / ref_thin.norm()) < 2e-6
     if shard is None:
-        assert _rel(outs["1"].cpu().numpy(), orc.mvm(Z, Z, V, 0.2, 0.3)) < 2e-6
+        assert _rel(out.cpu().numpy(), orc.mvm(Z, Z, V, 0.2, 0.3)) < 2e-6
 
 
 @pytest.mark.parametrize("N", [4095, 4096, 16384, 16385, 36000, 36001])
@@ -379,52 +371,23 @@ def test_family_pivoted_cholesky_matches_generic(gpu_device, kind, group, cols, 
     assert Lf is not None and torch.allclose(Lf, Lg, rtol=1e-3, atol=2e-4)
 
 
-@pytest.mark.parametrize("N,J,rank", [(2049, 20, 15), (7372, 20, 15), (14939, 20, 15), (32768, 8, 16), (32769, 3, 15),
-                                      (5000, 40, 15), (4097, 3, 1), (9999, 64, 7)])
-def test_pivoted_cholesky_cooperative_launch_is_bitwise_the_per_step_form(gpu_device, N, J, rank, monkeypatch):
-    """One cooperative launch with grid barriers (2048 < N <= 32768, rank <= 16; opt-in RPGP_PIVCHOL_COOP=1) against one launch
-    per greedy step (default): the same pivots and the same factor bit for bit, for coordinates held in LDS (J <= 32) and read
-    from memory (J > 32), repeated calls on one scratch buffer, sizes on both sides of the limits; and the family form."""
-    from rpgp_amd import ops
-    rng = np.random.default_rng(N + J)
-    Z = torch.from_numpy((rng.standard_normal((N, J)) * 0.8).astype(np.float32)).to(gpu_device)
-    out = {}
-    for mode in ("0", "1", "1"):
-        monkeypatch.setenv("RPGP_PIVCHOL_COOP", mode)
-        L = ops.pivoted_cholesky(Z, 0.7 / J, rank)
-        assert torch.isfinite(L).all()
-        if mode in out:
-            assert torch.equal(out[mode], L)
-        out[mode] = L
-    assert torch.equal(out["0"], out["1"])
-    if J == 20 and N <= 15000:
-        from rpgp_amd.operators import FamilyAdditiveOperator
-        w = torch.from_numpy(rng.uniform(0.3, 1.0, size=J).astype(np.float32)).to(gpu_device)
-        fam = {}
-        for mode in ("0", "1"):
-            monkeypatch.setenv("RPGP_PIVCHOL_COOP", mode)
-            fam[mode] = FamilyAdditiveOperator(Z, None, torch.tensor(0.8, device=gpu_device), w, "Matern", 1).fused_pivoted_cholesky(12)
-        assert fam["1"] is not None and torch.equal(fam["0"], fam["1"])
-
-
 @pytest.mark.parametrize("N,J,rank", [(2049, 20, 15), (7372, 20, 15), (14939, 8, 16), (50000, 20, 15), (131072, 3, 15),
-                                      (131073, 3, 15), (9000, 32, 15), (9000, 33, 15), (4097, 20, 1)])
-def test_pivoted_cholesky_fast_step_kernel_is_bitwise_the_general_one(gpu_device, N, J, rank, monkeypatch):
+                                      (131073, 3, 15), (9000, 32, 15), (9000, 33, 15), (4097, 20, 1), (9999, 64, 7)])
+def test_pivoted_cholesky_step_kernels_on_both_sides_of_their_limits(gpu_device, N, J, rank):
     """pivchol_step_fast_kernel (the flagship operator's per-step kernel: own-row operands requested before the pivot is
-    known) against the general per-step kernel (RPGP_PIVCHOL_FAST=0): the same factor bit for bit, on both sides of its limits
-    (<= 32 columns, one row per thread up to N = 131072), repeated on one scratch buffer."""
+    known; <= 32 columns, one row per thread up to N = 131072) and the general per-step kernel beyond its limits: the factor
+    against the generic row-by-row greedy factorisation of the same operator, reproducible on one scratch buffer."""
     from rpgp_amd import ops
+    from rpgp_amd.operators import AdditiveRPOperator
+    from rpgp_amd.precond import pivoted_cholesky
     rng = np.random.default_rng(N + J)
     Z = torch.from_numpy((rng.standard_normal((N, J)) * 0.8).astype(np.float32)).to(gpu_device)
-    out = {}
-    for mode in ("0", "1", "1"):
-        monkeypatch.setenv("RPGP_PIVCHOL_FAST", mode)
-        L = ops.pivoted_cholesky(Z, 0.7 / J, rank)
-        assert torch.isfinite(L).all()
-        if mode in out:
-            assert torch.equal(out[mode], L)
-        out[mode] = L
-    assert torch.equal(out["0"], out["1"])
+    L = ops.pivoted_cholesky(Z, 0.7 / J, rank)
+    assert torch.isfinite(L).all()
+    assert torch.equal(ops.pivoted_cholesky(Z, 0.7 / J, rank), L)
+    op = AdditiveRPOperator(Z, None, torch.tensor(0.7, device=gpu_device), 1.0 / J)
+    Lg = pivoted_cholesky(op._diagonal(), op._get_rows, rank)
+    assert torch.allclose(L, Lg, rtol=1e-3, atol=2e-4)
 
 
 @pytest.mark.parametrize("N,T,world", [(3000, 1, 3), (20000, 1, 8), (5000, 11, 4), (700, 4, 2), (300, 1, 8)])
@@ -569,44 +532,6 @@ def test_no_op_reads_uninitialised_scratch(gpu_device, monkeypatch):
     for i, (a, b) in enumerate(zip(ref, got)):
         assert torch.isfinite(b).all(), "output %d has non-finite entries" % i
         assert torch.allclose(a.cpu(), b.cpu(), rtol=1e-5, atol=1e-6), "output %d changed" % i
-
-
-@pytest.mark.parametrize("N,J", [(2048, 20), (3001, 20), (4097, 12), (2300, 8), (2100, 2)])
-def test_matrix_core_prepared_mvm_matches_oracle(gpu_device, monkeypatch, N, J):
-    """RPGP_MFMA=1 routes the prepared symmetric MVM (T = 1) through rpgp_mfma.hip (`v_mfma_f32_32x32x2_f32` for the
-    rank-2 exponent, exact fp32): an opt-in experiment kept for A/B measurements, same results."""
-    from rpgp_amd import ops
-    rng = np.random.default_rng(N + J)
-    Z = (rng.standard_normal((N, J)) * 1.3).astype(np.float32)
-    V = rng.standard_normal((N, 1)).astype(np.float32)
-    Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
-    prep = ops.Prepared(Zt)
-    assert prep.fast_ok
-    base = ops.mvm_sym_prepared(prep, Vt, 0.7 / J, 0.1).cpu().numpy()
-    monkeypatch.setenv("RPGP_MFMA", "1")
-    out = ops.mvm_sym_prepared(prep, Vt, 0.7 / J, 0.1).cpu().numpy()
-    ref = orc.mvm(Z, Z, V, 0.7 / J, 0.1)
-    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 1e-5
-    assert np.linalg.norm(out - base) / np.linalg.norm(base) < 2e-6
-    assert not np.array_equal(out, base), "RPGP_MFMA=1 did not select the matrix-core kernel"
-
-
-@pytest.mark.parametrize("N,J", [(5000, 20), (12000, 10)])
-def test_rows_packed_prepared_mvm_matches_oracle(gpu_device, monkeypatch, N, J):
-    """The opt-in rows-packed form of the prepared T = 1 kernel (RPGP_FACT_ROWS=1, round-3 experiment on the headline
-    kernel's per-step overhead: parity-green, measured slower) against the float64 oracle."""
-    from rpgp_amd import ops
-    monkeypatch.setenv("RPGP_FACT_ROWS", "1")
-    Z, V = _data(N, J, 1, seed=N)
-    ref = orc.mvm(Z, Z, V, 1.0 / J, 0.05)
-    Zt = torch.from_numpy(Z).to(gpu_device)
-    prep = ops.Prepared(Zt)
-    assert prep.fast_ok
-    out = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), 1.0 / J, 0.05)
-    assert _rel(out.cpu().numpy(), ref) < 1e-5
-    monkeypatch.setenv("RPGP_FACT_ROWS", "0")
-    out0 = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), 1.0 / J, 0.05)
-    assert _rel(out.cpu().numpy(), out0.cpu().numpy()) < 2e-6
 
 
 @pytest.mark.parametrize("N,K,T", [(1, 1, 1), (7, 15, 10), (1237, 15, 11), (7372, 15, 10), (50001, 16, 64), (4099, 33, 17),

@@ -1,0 +1,30 @@
+"""N optimiser steps of the reference's loop (training.train_to_convergence = fitting/optimizing.py:14-108) at a BASELINE shape,
+for `rocprofv3 --marker-trace --kernel-trace`: the roctx ranges of a step (rpgp:optimiser_step, rpgp:objective+backward,
+rpgp:project+prepare, rpgp:preconditioner, rpgp:mbcg_solve, rpgp:cg_iteration (every 8th), rpgp:allreduce, rpgp:derivative)
+are live because rocprofv3 preloads the marker library."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from rpgp_amd import settings, _lib
+from rpgp_amd.training import create_exact_gp, train_to_convergence
+from rpgp_amd.models import ExactMarginalLogLikelihood
+SHAPES = {"C2": (7372, 8, 20, False, False), "C3": (14939, 18, 20, True, False), "C4": (50000, 20, 20, False, False),
+          "C5": (391386, 3, 3, True, True)}
+shape = sys.argv[1]; steps = int(sys.argv[2]); warm = 5
+N, d, J, sp, ski = SHAPES[shape]
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+X = torch.randn(N, d, generator=g); y = torch.sin(X).sum(1) + 0.05 * torch.randn(N, generator=g); y = (y - y.mean()) / y.std()
+X, y = X.to(dev), y.to(dev)
+torch.manual_seed(0); np.random.seed(0)
+model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False, prescale=True,
+                             space_proj=sp, ski=ski, ski_options={"grid_size": 1024, "num_dims": 1} if ski else None)
+model = model.to(dev); mll = ExactMarginalLogLikelihood(lik, model)
+with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
+    train_to_convergence(model, X, y, optimizer=torch.optim.Adam, objective=mll, max_iter=warm, check_conv=False, lr=0.0)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); b = time.time_ns()
+    train_to_convergence(model, X, y, optimizer=torch.optim.Adam, objective=mll, max_iter=steps, check_conv=False, lr=0.0)
+    torch.cuda.synchronize(); t1 = time.perf_counter(); e = time.time_ns()
+print(json.dumps({"shape": shape, "steps": steps, "warm": warm, "step_ms": (t1 - t0) / steps * 1e3,
+                  "ranges_live": int(_lib.load().rpgp_range_available())}))

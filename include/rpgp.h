@@ -314,6 +314,20 @@ int rpgp_ski_f64_dense(const double *Z1, const double *Z2, const double *grid_pa
 int rpgp_ski_f64_bilinear_grad(const double *Z, const double *grid_params, const double *L, const double *R, double *gZ,
                                double *gscale, double *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T, double scale,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* The stages of the float64 product and derivative as separate calls — `--double` for the row-sharded operator (one process per
+ * GPU: MultiDeviceKernel around the grid-interpolation kernel, /root/reference/training_routines.py:407-408 with :157-158, under
+ * :481): scatter the LOCAL rows into columns [hoff, hoff + T) of a J x G x HT float64 histogram (zero_first: clear it), all-reduce
+ * it (caller), replicated grid product, gather the local rows; the derivative from the all-reduced J x G x 2T block
+ * [W^T L | W^T R].  rpgp_ski_f64_bilinear_finish workspace: J * G * 2T + J doubles (+ 512 B). */
+int rpgp_ski_f64_scatter(const double *Z, const double *grid_params, const double *V, double *hist, int64_t N, int ldz, int J,
+                         int G, int T, int HT, int hoff, int zero_first, void *stream);
+int rpgp_ski_f64_grid_product(const double *hist, const double *grid_params, double *H, int J, int G, int T, int weighted,
+                              void *stream);
+int rpgp_ski_f64_gather(const double *Z, const double *grid_params, const double *H, const double *V, double *out, int64_t M,
+                        int ldz, int J, int G, int T, double scale, double noise, void *stream);
+int rpgp_ski_f64_bilinear_finish(const double *Z, const double *grid_params, const double *hist2, const double *L, const double *R,
+                                 double *gZ, double *gscale, double *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
+                                 double scale, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The derivative in two stages for the row-sharded SKI operator (MLL backward of a model whose rows are split over ranks):

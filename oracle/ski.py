@@ -4,7 +4,9 @@ model_specs/additive_spread_prescale_Jd_ski.json: grid_size 1024, num_dims 1) â€
 
 K ~= scale * sum_j W_j Tm W_j^T with cubic-convolution interpolation (Keys 1981, the 4-tap kernel GPyTorch's
 `Interpolation` uses: u<=1: ((1.5u-2.5)u)u+1 ; 1<u<=2: ((-0.5u+2.5)u-4)u+2) onto one regular grid shared by all
-projections, and Tm[m,m'] = exp(-0.5 ((m-m')h)^2).  Two grid rules: this build's shared grid (`grid_params`: h = (max-min)/(G-5),
+projections, and Tm[m,m'] = k1((m-m')h) for the wrapped 1-D sub-kernel k1 â€” the RBF exp(-0.5 d^2) by default, or whatever
+`_map_to_kernel` returned (training_routines.py:47-88 with :157-158): `kind` in oracle.family.KINDS, the radial forms of
+oracle/family.py (`_phi`).  Two grid rules: this build's shared grid (`grid_params`: h = (max-min)/(G-5),
 g0 = min - 2h over ALL projections, every stencil interior) and the reference's per-projection rule
 (`grid_params_reference`, polynomial_projection_kernels.py:54-63); every function takes `grid` as (g0, h) floats or as
 per-projection arrays.  **Parity unpinned**: GPyTorch is not installable and the reference has no SKI tests
@@ -66,13 +68,14 @@ def interp_matrix(z, g0, h, G):
     return W
 
 
-def toeplitz(h, G):
+def toeplitz(h, G, kind="RBF"):
+    from .family import _phi
     m = np.arange(G)
     d = (m[:, None] - m[None, :]) * h
-    return np.exp(-0.5 * d * d)
+    return _phi(kind, d * d)
 
 
-def dense_kernel(Z1, Z2, scale, G=1024, grid=None, weights=None):
+def dense_kernel(Z1, Z2, scale, G=1024, grid=None, weights=None, kind="RBF"):
     """scale * sum_j w_j W_j(Z1) Tm W_j(Z2)^T; `weights` = per-projection output scales (the `weighted` components of
     polynomial_projection_kernels.py:88-98), default all one."""
     Z1 = np.asarray(Z1, dtype=np.float64)
@@ -82,13 +85,13 @@ def dense_kernel(Z1, Z2, scale, G=1024, grid=None, weights=None):
     w = np.ones(Z1.shape[1]) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)
     for j in range(Z1.shape[1]):
         g0, h = _grid_j(grid, j)
-        K += w[j] * (interp_matrix(Z1[:, j], g0, h, G) @ toeplitz(h, G) @ interp_matrix(Z2[:, j], g0, h, G).T)
+        K += w[j] * (interp_matrix(Z1[:, j], g0, h, G) @ toeplitz(h, G, kind) @ interp_matrix(Z2[:, j], g0, h, G).T)
     return scale * K
 
 
-def bilinear_objective(Z, L, R, scale, G, grid, weights=None):
+def bilinear_objective(Z, L, R, scale, G, grid, weights=None, kind="RBF"):
     """sum((L R^T) * K_ski(Z, Z)) with a FIXED grid (the grid is a buffer, not differentiated)."""
-    K = dense_kernel(Z, Z, scale, G, grid, weights)
+    K = dense_kernel(Z, Z, scale, G, grid, weights, kind)
     return float((np.asarray(L, dtype=np.float64) @ np.asarray(R, dtype=np.float64).T * K).sum())
 
 
@@ -109,7 +112,7 @@ def interp_sparse(z, g0, h, G):
     return sp.csr_matrix((vals.ravel(), cols.ravel(), indptr), shape=(n, G))
 
 
-def mvm_sparse(Z1, Z2, V, scale, G, grid, noise=0.0, weights=None):
+def mvm_sparse(Z1, Z2, V, scale, G, grid, noise=0.0, weights=None, kind="RBF"):
     """scale * sum_j w_j W_j(Z1) (Tm (W_j(Z2)^T V)) + noise * V in float64 with sparse W and a dense G x G Toeplitz:
     O(N (J + T)) memory, the full-size counterpart of `dense_kernel(...) @ V`."""
     Z1 = np.asarray(Z1, dtype=np.float64)
@@ -121,7 +124,7 @@ def mvm_sparse(Z1, Z2, V, scale, G, grid, noise=0.0, weights=None):
     for j in range(Z1.shape[1]):
         g0, h = _grid_j(grid, j)
         if h != h_prev:
-            Tm, h_prev = toeplitz(h, G), h
+            Tm, h_prev = toeplitz(h, G, kind), h
         W2 = interp_sparse(Z2[:, j], g0, h, G)
         W1 = W2 if Z1 is Z2 else interp_sparse(Z1[:, j], g0, h, G)
         out += w[j] * (W1 @ (Tm @ (W2.T @ V)))
@@ -131,7 +134,7 @@ def mvm_sparse(Z1, Z2, V, scale, G, grid, noise=0.0, weights=None):
     return out
 
 
-def diag_sparse(Z, scale, G, grid, weights=None):
+def diag_sparse(Z, scale, G, grid, weights=None, kind="RBF"):
     """diag(scale * sum_j w_j W_j Tm W_j^T) in float64 with O(N) memory: per row the 4 x 4 quadratic form of its
     stencil weights with the Toeplitz lags 0..3."""
     Z = np.asarray(Z, dtype=np.float64)
@@ -139,7 +142,8 @@ def diag_sparse(Z, scale, G, grid, weights=None):
     d = np.zeros(Z.shape[0])
     for j in range(Z.shape[1]):
         g0, h = _grid_j(grid, j)
-        lag = np.exp(-0.5 * (np.arange(4) * h) ** 2)
+        from .family import _phi
+        lag = _phi(kind, (np.arange(4) * h) ** 2)
         u = np.clip((Z[:, j] - g0) / h, 1.0, G - 2.0)
         fr = u - np.floor(u)
         vals = [_cubic(fr + 1.0), _cubic(fr), _cubic(1.0 - fr), _cubic(2.0 - fr)]

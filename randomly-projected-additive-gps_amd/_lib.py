@@ -101,6 +101,11 @@ SIGNATURES = {
     "rpgp_ski_f64_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f64, _vp]),
     "rpgp_ski_f64_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f64, _vp, _sz,
                                           _vp]),
+    "rpgp_ski_f64_scatter": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "rpgp_ski_f64_grid_product": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "rpgp_ski_f64_gather": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f64, _f64, _vp]),
+    "rpgp_ski_f64_bilinear_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f64,
+                                            _vp, _sz, _vp]),
     "rpgp_step_hyper": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rpgp_step_probes": (_int, [_vp, _int, _vp, _vp, _f32, _vp, _vp, _i64, _int, _vp, _vp]),
     "rpgp_step_value_workspace_bytes": (_sz, []),

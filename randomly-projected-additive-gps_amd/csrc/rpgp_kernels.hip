@@ -2558,14 +2558,13 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
         for (int j = 0; j < ncols; ++j) {
           float w[4], dw[4];
           const float *gj = ski_grid_of(gp, ncols, j);
-          const float hs = gj[1] * kExp2Scale;
           const int idx = ski_taps<false>(Z[(size_t)i * ldz + j], gj[0], gj[2], G, w, dw);
           const int delta = idx - spidx[j];
           float tl[7];
 #pragma unroll
           for (int u = 0; u < 7; ++u) {
-            const float dd = (float)(delta + u - 3) * hs;
-            tl[u] = fast_exp2(-(dd * dd));
+            const int lag = delta + u - 3;            // (the sub-kernel of the grid block: RBF unless flags say otherwise)
+            tl[u] = ski_radial_f32(ski_kind(gp), lag < 0 ? -lag : lag, gj[1]);
           }
           float aj = 0.f;
 #pragma unroll

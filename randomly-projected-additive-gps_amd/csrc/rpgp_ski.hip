@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void plan_starts_kernel(const unsigned *__rest
   if (c < J * G16) {                         // (with a shared grid only row 0 is read)
     const int j = c / G16, k = c % G16;
     const double d = (double)k * (double)ski_grid_of(gp, J, j)[1];
-    tcol[c] = k < G ? exp(-0.5 * d * d) : 0.0;
+    tcol[c] = k < G ? ski_radial_f64(ski_kind(gp), d) : 0.0;
   }
 }
 

@@ -344,10 +344,8 @@ __global__ __launch_bounds__(256) void ski_toeplitz_kernel(const HT_ *__restrict
   extern __shared__ double scd[];   // G toeplitz coefficients (float64)
   double *sc = scd;
   const double hd = (double)ski_grid_of(gp, gridDim.y, blockIdx.y)[1];
-  for (int k = threadIdx.x; k < G; k += 256) {
-    const double d = (double)k * hd;
-    sc[k] = exp(-0.5 * d * d);
-  }
+  const int kind = ski_kind(gp);
+  for (int k = threadIdx.x; k < G; k += 256) sc[k] = ski_radial_f64(kind, (double)k * hd);
   __syncthreads();
   const int j = blockIdx.y;
   // thread -> (m, t): 256 threads cover (256 / Tp) rows x Tp columns, Tp = T rounded up to a power of two <= 16
@@ -390,10 +388,8 @@ __global__ __launch_bounds__(64 * NW) void ski_toeplitz_mfma_kernel(const double
     const double *tc = tcol + (size_t)((ski_flags(gp) & 2) ? j : 0) * G16;
     for (int k = threadIdx.x; k < G16; k += 64 * NW) sc[k] = k < G ? tc[k] : 0.0;
   } else {
-    for (int k = threadIdx.x; k < G16; k += 64 * NW) {
-      const double d = (double)k * hd;
-      sc[k] = k < G ? exp(-0.5 * d * d) : 0.0;
-    }
+    const int kind = ski_kind(gp);
+    for (int k = threadIdx.x; k < G16; k += 64 * NW) sc[k] = k < G ? ski_radial_f64(kind, (double)k * hd) : 0.0;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
@@ -558,11 +554,9 @@ __global__ __launch_bounds__(256) void ski_toeplitz_wide_kernel(const float *__r
                                                                 const float *__restrict__ gp, float *__restrict__ H,
                                                                 int G, int T) {
   extern __shared__ float sc[];   // G toeplitz coefficients
-  const float hs = ski_grid_of(gp, gridDim.z, blockIdx.z)[1] * kExp2Scale;
-  for (int k = threadIdx.x; k < G; k += 256) {
-    const float d = (float)k * hs;
-    sc[k] = fast_exp2(-(d * d));
-  }
+  const float hgrid = ski_grid_of(gp, gridDim.z, blockIdx.z)[1];
+  const int kind = ski_kind(gp);
+  for (int k = threadIdx.x; k < G; k += 256) sc[k] = ski_radial_f32(kind, k, hgrid);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;
@@ -680,12 +674,9 @@ __global__ __launch_bounds__(256) void ski_dense_kernel(const float *__restrict_
   const bool per_proj = (ski_flags(gp) & 2) != 0;     // per-projection grids: the 7 lags are evaluated on the fly
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * RT;
+  const int kind = ski_kind(gp);
   if (!per_proj) {
-    const float hs = gp[1] * kExp2Scale;
-    for (int q = tid; q < G; q += 256) {
-      const float dd = (float)q * hs;
-      sc[q] = fast_exp2(-(dd * dd));
-    }
+    for (int q = tid; q < G; q += 256) sc[q] = ski_radial_f32(kind, q, gp[1]);
   }
   for (int e = tid; e < RT * J; e += 256) {
     const int r = e / J, j = e % J;
@@ -708,7 +699,7 @@ __global__ __launch_bounds__(256) void ski_dense_kernel(const float *__restrict_
     const float *gj = ski_grid_of(gp, J, j);
     const int idc = ski_taps<false>(Z2[(size_t)col * ldz2 + j], gj[0], gj[2], G, wc, dw);
     const float wj = ski_wj(gp, j);
-    const float hsj = gj[1] * kExp2Scale;
+    const float hj = gj[1];
 #pragma unroll 4
     for (int r = 0; r < RT; ++r) {
       const int delta = sI[r * J + j] - idc;
@@ -719,8 +710,7 @@ __global__ __launch_bounds__(256) void ski_dense_kernel(const float *__restrict_
         int lag = delta + u - 3;
         lag = lag < 0 ? -lag : lag;
         if (per_proj) {
-          const float dd = (float)lag * hsj;
-          tl[u] = fast_exp2(-(dd * dd));
+          tl[u] = ski_radial_f32(kind, lag, hj);
         } else {
           tl[u] = lag < G ? sc[lag] : 0.f;
         }
@@ -748,10 +738,9 @@ __global__ __launch_bounds__(256) void ski_diag_kernel(const float *__restrict__
   for (int j = 0; j < J; ++j) {
     float w[4], dw[4];
     const float *gj = ski_grid_of(gp, J, j);
-    const float hs = gj[1] * kExp2Scale;
     float c[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const float d = (float)k * hs; c[k] = fast_exp2(-(d * d)); }
+    for (int k = 0; k < 4; ++k) c[k] = ski_radial_f32(ski_kind(gp), k, gj[1]);
     ski_taps<false>(Z[i * ldz + j], gj[0], gj[2], G, w, dw);
     float aj = 0.f;
 #pragma unroll

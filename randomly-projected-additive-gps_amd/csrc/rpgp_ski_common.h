@@ -18,7 +18,39 @@ __device__ __forceinline__ float cubic_dw(float U) {     // d/dU of the above
 // K = scale * sum_j w_j W_j Tm_j W_j^T — the weight rides on the Toeplitz stage.  flags & 2: the reference's grid rule
 // (polynomial_projection_kernels.py:54-63: every projection has its own bounds, spacing (max - min) / (G - 4), +- 2.01
 // spacings of margin), so interpolation cells, and the Toeplitz first column, differ per projection.
+// flags & 12: the 1-D sub-kernel the grid's Toeplitz matrix is built from, (flags >> 2) = RPGP_KIND_* of include/rpgp.h
+// (training_routines.py:157-158 wraps WHATEVER `_map_to_kernel` returned, :47-88, in GridInterpolationKernel): 0 RBF
+// exp(-d^2 / 2), 1 Matern-1.5 (1 + sqrt3 |d|) exp(-sqrt3 |d|), 2 InverseMQ (1 + d^2)^(-1/2) (imq_kernel.py:8-9), 3 Cosine
+// cos(pi d).  Scatter, gather and the derivative's staging never look at it: only the grid-to-grid entries do.
 __device__ __forceinline__ int ski_flags(const float *__restrict__ gp) { return (int)gp[3]; }
+__device__ __forceinline__ int ski_kind(const float *__restrict__ gp) { return (ski_flags(gp) >> 2) & 3; }
+// the sub-kernel between two grid points `lag` spacings h apart — float64 (Toeplitz first columns) ...
+__device__ __forceinline__ double ski_radial_f64(int kind, double d) {
+  switch (kind) {
+    case 1: {
+      const double s = 1.7320508075688772 * fabs(d);
+      return (1.0 + s) * exp(-s);
+    }
+    case 2: return 1.0 / sqrt(1.0 + d * d);
+    case 3: return cos(3.14159265358979323846 * d);
+    default: return exp(-0.5 * d * d);
+  }
+}
+// ... and float32 (dense blocks, diagonal, wide Toeplitz): the RBF branch is the arithmetic these kernels always used
+// (exp2 of the pre-scaled square: same bits as before the other kinds existed)
+__device__ __forceinline__ float ski_radial_f32(int kind, int lag, float h) {
+  if (kind == 0) {
+    const float d = (float)lag * (h * 0.8493218002880191f);
+    return __builtin_amdgcn_exp2f(-(d * d));
+  }
+  const float d = (float)lag * h;
+  if (kind == 1) {
+    const float s = 1.7320508075688772f * d;
+    return (1.0f + s) * __builtin_amdgcn_exp2f(-1.4426950408889634f * s);
+  }
+  if (kind == 2) return __builtin_amdgcn_rsqf(__builtin_fmaf(d, d, 1.0f));
+  return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(0.5f * d));
+}
 __device__ __forceinline__ float ski_wj(const float *__restrict__ gp, int j) { return (ski_flags(gp) & 1) ? gp[4 + j] : 1.0f; }
 // (g0, h, 1/h) of projection j
 __device__ __forceinline__ const float *ski_grid_of(const float *__restrict__ gp, int J, int j) {

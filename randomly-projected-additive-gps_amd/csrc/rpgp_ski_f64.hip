@@ -25,6 +25,18 @@ __device__ __forceinline__ double cubic_w(double U) {
 }
 __device__ __forceinline__ double cubic_dw(double U) { return (U < 1.0) ? (4.5 * U - 5.0) * U : (-1.5 * U + 5.0) * U - 4.0; }
 __device__ __forceinline__ int gp_flags(const double *__restrict__ gp) { return (int)gp[3]; }
+// the 1-D sub-kernel of the grid's Toeplitz matrix, (flags >> 2) & 3 = RPGP_KIND_* (rpgp_ski_common.h: ski_radial_f64)
+__device__ __forceinline__ double gp_radial(const double *__restrict__ gp, double d) {
+  switch ((gp_flags(gp) >> 2) & 3) {
+    case 1: {
+      const double s = 1.7320508075688772 * fabs(d);
+      return (1.0 + s) * exp(-s);
+    }
+    case 2: return 1.0 / sqrt(1.0 + d * d);
+    case 3: return cos(3.14159265358979323846 * d);
+    default: return exp(-0.5 * d * d);
+  }
+}
 __device__ __forceinline__ double gp_wj(const double *__restrict__ gp, int j) { return (gp_flags(gp) & 1) ? gp[4 + j] : 1.0; }
 __device__ __forceinline__ const double *gp_grid(const double *__restrict__ gp, int J, int j) {
   return (gp_flags(gp) & 2) ? gp + 4 + J + 3 * j : gp;
@@ -50,9 +62,10 @@ __device__ __forceinline__ int taps(double z, double g0, double inv_h, int G, do
 }
 
 // hist[j][g][t] += w_q(z_ij) V[i][t]
+// (hist rows are HT wide, the T columns land at hoff: the staged derivative fills [W^T L | W^T R] of a J x G x 2T block)
 __global__ __launch_bounds__(256) void k_scatter(const double *__restrict__ Z, const double *__restrict__ gp,
                                                  const double *__restrict__ V, double *__restrict__ hist, long long N, int ldz,
-                                                 int J, int G, int T) {
+                                                 int J, int G, int T, int HT, int hoff) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= N * T) return;
   const long long i = e / T;
@@ -63,7 +76,7 @@ __global__ __launch_bounds__(256) void k_scatter(const double *__restrict__ Z, c
     double w[4], dw[4];
     const int idx = taps<false>(Z[i * ldz + j], gj[0], gj[2], G, w, dw);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) unsafeAtomicAdd(&hist[((size_t)j * G + idx + q) * T + t], w[q] * v);
+    for (int q = 0; q < 4; ++q) unsafeAtomicAdd(&hist[((size_t)j * G + idx + q) * HT + hoff + t], w[q] * v);
   }
 }
 
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(256) void k_grid_product(const double *__restrict__
   double acc = 0.0;
   for (int gg = 0; gg < G; ++gg) {
     const double dd = (double)(g - gg) * h;
-    acc = fma(exp(-0.5 * dd * dd), hist[((size_t)j * G + gg) * T + t], acc);
+    acc = fma(gp_radial(gp, dd), hist[((size_t)j * G + gg) * T + t], acc);
   }
   H[e] = (weighted ? gp_wj(gp, j) : 1.0) * acc;
 }
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(256) void k_dense(const double *__restrict__ Z1, co
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const double dd = (double)(i1 - i2 + u - 3) * gj[1];
-      tl[u] = exp(-0.5 * dd * dd);
+      tl[u] = gp_radial(gp, dd);
     }
     double aj = 0.0;
 #pragma unroll
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(256) void k_diag(const double *__restrict__ Z, cons
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const double dd = (double)(q - qq) * gj[1];
-        aj = fma(w[q] * w[qq], exp(-0.5 * dd * dd), aj);
+        aj = fma(w[q] * w[qq], gp_radial(gp, dd), aj);
       }
     acc = fma(gp_wj(gp, j), aj, acc);
   }
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(256) void k_bilinear_finish(const double *__restric
                                                          const double *__restrict__ HL, const double *__restrict__ HR,
                                                          const double *__restrict__ L, const double *__restrict__ R,
                                                          double *__restrict__ gZ, double *__restrict__ gcomp, long long N,
-                                                         int ldz, int ldg, int J, int G, int T, double scale) {
+                                                         int ldz, int ldg, int J, int G, int T, double scale, int ldh) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= N * J) return;
   const long long i = e / J;
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(256) void k_bilinear_finish(const double *__restric
     const double l = L[i * T + t], r = R[i * T + t];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const double hr = HR[((size_t)j * G + idx + q) * T + t], hl = HL[((size_t)j * G + idx + q) * T + t];
+      const double hr = HR[((size_t)j * G + idx + q) * ldh + t], hl = HL[((size_t)j * G + idx + q) * ldh + t];
       gz = fma(dw[q], l * hr + r * hl, gz);
       gc = fma(w[q], l * hr, gc);
     }
@@ -220,7 +233,7 @@ int rpgp_ski_f64_mvm(const double *Z1, const double *Z2, const double *grid_para
   hipError_t e = hipMemsetAsync(hist, 0, nh * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k_scatter, dim3(blocks_for((long long)N * T)), dim3(256), 0, st, Z2, grid_params, V, hist, (long long)N, ldz2,
-                     J, G, T);
+                     J, G, T, T, 0);
   hipLaunchKernelGGL(k_grid_product, dim3(blocks_for((long long)nh)), dim3(256), 0, st, hist, grid_params, H, J, G, T, 1);
   hipLaunchKernelGGL(k_gather, dim3(blocks_for((long long)M * T)), dim3(256), 0, st, Z1, grid_params, H, noise != 0.0 ? V : nullptr,
                      out, (long long)M, ldz1, J, G, T, scale, noise);
@@ -261,17 +274,78 @@ int rpgp_ski_f64_bilinear_grad(const double *Z, const double *grid_params, const
   e = hipMemsetAsync(gc, 0, (size_t)J * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k_scatter, dim3(blocks_for((long long)N * T)), dim3(256), 0, st, Z, grid_params, L, histL, (long long)N, ldz, J,
-                     G, T);
+                     G, T, T, 0);
   hipLaunchKernelGGL(k_scatter, dim3(blocks_for((long long)N * T)), dim3(256), 0, st, Z, grid_params, R, histR, (long long)N, ldz, J,
-                     G, T);
+                     G, T, T, 0);
   hipLaunchKernelGGL(k_grid_product, dim3(blocks_for((long long)nh)), dim3(256), 0, st, histL, grid_params, HL, J, G, T, 0);
   hipLaunchKernelGGL(k_grid_product, dim3(blocks_for((long long)nh)), dim3(256), 0, st, histR, grid_params, HR, J, G, T, 0);
   hipLaunchKernelGGL(k_bilinear_finish, dim3(blocks_for((long long)N * J)), dim3(256), 0, st, Z, grid_params, HL, HR, L, R, gZ, gc,
-                     (long long)N, ldz, ldg, J, G, T, scale);
+                     (long long)N, ldz, ldg, J, G, T, scale, T);
   hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, st, gc, J, gscale);
   if (gcomp) {
     e = hipMemcpyAsync(gcomp, gc, (size_t)J * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
+  }
+  return launch_status();
+}
+
+// ---- the stages as separate calls: `--double` (training_routines.py:481) for the ROW-SHARDED operator (one process per GPU, the
+// ---- counterpart of MultiDeviceKernel around the grid-interpolation kernel, training_routines.py:407-408 with :157-158): every
+// ---- rank scatters ITS rows, the float64 histogram is all-reduced by the caller, the grid product is replicated, every rank
+// ---- gathers ITS rows.  Same contracts as rpgp_ski_scatter / rpgp_ski_grid_product / rpgp_ski_gather /
+// ---- rpgp_ski_bilinear_scatter / rpgp_ski_bilinear_finish, float64 throughout.
+int rpgp_ski_f64_scatter(const double *Z, const double *grid_params, const double *V, double *hist, int64_t N, int ldz, int J,
+                         int G, int T, int HT, int hoff, int zero_first, void *stream) {
+  if (!Z || !grid_params || !V || !hist || N <= 0 || J <= 0 || G < 8 || T <= 0 || ldz < J || HT < T || hoff < 0 || hoff + T > HT)
+    return RPGP_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (zero_first) {
+    const hipError_t e = hipMemsetAsync(hist, 0, (size_t)J * G * HT * sizeof(double), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k_scatter, dim3(blocks_for((long long)N * T)), dim3(256), 0, st, Z, grid_params, V, hist, (long long)N, ldz, J, G,
+                     T, HT, hoff);
+  return launch_status();
+}
+
+int rpgp_ski_f64_grid_product(const double *hist, const double *grid_params, double *H, int J, int G, int T, int weighted,
+                              void *stream) {
+  if (!hist || !grid_params || !H || J <= 0 || G < 8 || T <= 0) return RPGP_EINVAL;
+  hipLaunchKernelGGL(k_grid_product, dim3(blocks_for((long long)J * G * T)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), hist,
+                     grid_params, H, J, G, T, weighted ? 1 : 0);
+  return launch_status();
+}
+
+int rpgp_ski_f64_gather(const double *Z, const double *grid_params, const double *H, const double *V, double *out, int64_t M,
+                        int ldz, int J, int G, int T, double scale, double noise, void *stream) {
+  if (!Z || !grid_params || !H || !out || M <= 0 || J <= 0 || G < 8 || T <= 0 || ldz < J) return RPGP_EINVAL;
+  if (noise != 0.0 && !V) return RPGP_EINVAL;
+  hipLaunchKernelGGL(k_gather, dim3(blocks_for((long long)M * T)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Z, grid_params,
+                     H, noise != 0.0 ? V : nullptr, out, (long long)M, ldz, J, G, T, scale, noise);
+  return launch_status();
+}
+
+// hist2: J x G x 2T float64 = [W^T L | W^T R] summed over ALL rows (all-reduced by the caller); workspace: J * G * 2T + J doubles
+int rpgp_ski_f64_bilinear_finish(const double *Z, const double *grid_params, const double *hist2, const double *L, const double *R,
+                                 double *gZ, double *gscale, double *gcomp, int64_t N, int ldz, int ldg, int J, int G, int T,
+                                 double scale, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!Z || !grid_params || !hist2 || !L || !R || !gZ || !gscale || N <= 0 || J <= 0 || G < 8 || T <= 0 || ldz < J || ldg < J)
+    return RPGP_EINVAL;
+  const size_t nh2 = (size_t)J * G * 2 * T;
+  if (!workspace || workspace_bytes < align256(nh2 * sizeof(double)) + align256((size_t)J * sizeof(double))) return RPGP_EWORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double *H2 = reinterpret_cast<double *>(workspace);
+  double *gc = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + align256(nh2 * sizeof(double)));
+  const hipError_t e = hipMemsetAsync(gc, 0, (size_t)J * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  // UNWEIGHTED Toeplitz products of both halves at once (2T columns), then the per-row finish reading HL / HR out of H2
+  hipLaunchKernelGGL(k_grid_product, dim3(blocks_for((long long)nh2)), dim3(256), 0, st, hist2, grid_params, H2, J, G, 2 * T, 0);
+  hipLaunchKernelGGL(k_bilinear_finish, dim3(blocks_for((long long)N * J)), dim3(256), 0, st, Z, grid_params, H2, H2 + T, L, R, gZ, gc,
+                     (long long)N, ldz, ldg, J, G, T, scale, 2 * T);
+  hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, st, gc, J, gscale);
+  if (gcomp) {
+    const hipError_t e2 = hipMemcpyAsync(gcomp, gc, (size_t)J * sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (e2 != hipSuccess) return (int)e2;
   }
   return launch_status();
 }

@@ -124,9 +124,9 @@ class AdditiveStructureRBFKernel(Kernel):
         if il != 1.0:
             Z1 = Z1 / il
             Z2 = None if Z2 is None else Z2 / il
-        if self.kernel_type != "RBF" or self.group != 1:
-            if self.ski:
-                raise NotImplementedError("grid interpolation is built for the 1-D RBF sub-kernels only")
+        if self.ski and self.group != 1:
+            raise NotImplementedError("grid interpolation is built for 1-D sub-kernels (ski_options.num_dims == 1, k == 1)")
+        if (self.kernel_type != "RBF" or self.group != 1) and not self.ski:
             ncomp = Z1.shape[1] // self.group
             w = torch.full((ncomp,), weight_f, dtype=Z1.dtype, device=Z1.device)
             group = self.group
@@ -145,7 +145,7 @@ class AdditiveStructureRBFKernel(Kernel):
             return FamilyAdditiveOperator(Z1, Z2, outputscale=outputscale, comp_weights=w, kind=self.kernel_type,
                                           group=group)
         if self.ski:
-            return SKIAdditiveOperator(Z1, Z2, outputscale=outputscale, weight=weight_f,
+            return SKIAdditiveOperator(Z1, Z2, outputscale=outputscale, weight=weight_f, kind=self.kernel_type,
                                        grid_size=self.grid_size, row_shard=shard if isinstance(shard, RowShard) else None)
         return AdditiveRPOperator(Z1, Z2, outputscale=outputscale, weight=weight_f,
                                   shard=shard if isinstance(shard, JShard) else None)
@@ -262,8 +262,8 @@ class GeneralizedProjectionKernel(Kernel):
                  ski=False, ski_options=None, X=None, **kernel_kwargs):
         super().__init__()
         degrees = list(component_degrees)
-        if ski and (kernel_type != "RBF" or any(dg != 1 for dg in degrees)):
-            raise NotImplementedError("grid interpolation is built for 1-D RBF sub-kernels only")
+        if ski and any(dg != 1 for dg in degrees):
+            raise NotImplementedError("grid interpolation is built for 1-D sub-kernels only")
         if ski and dict(ski_options or {}).get("num_dims", 1) != 1:
             raise ValueError("only 1-D grid interpolation per projection is supported (ski_options.num_dims == 1)")
         self.ski = bool(ski)
@@ -323,7 +323,7 @@ class GeneralizedProjectionKernel(Kernel):
             # polynomial_projection_kernels.py:52-63, which scale with 1 / lengthscale like the coordinates do);
             # per-component output scales ride in the grid block
             return SKIAdditiveOperator(z1, z2, outputscale=outputscale, weight=1.0, grid_size=self.grid_size,
-                                       comp_weights=self.outputscales,
+                                       comp_weights=self.outputscales, kind=self.kernel_type,
                                        row_shard=shard if isinstance(shard, RowShard) else None, grid_rule=self.grid_rule)
         if self.k is None or (self.kernel_type == "RBF" and padded_group_size(self.k) != self.k):
             # mixed group sizes, or one size the tile kernels are not instantiated for (padded with zero columns there)

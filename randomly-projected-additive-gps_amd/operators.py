@@ -300,14 +300,17 @@ class AdditiveRPOperator(LinearOperator):
 class SKIAdditiveOperator(AdditiveRPOperator):
     """K ~= outputscale * weight * sum_j W_j Tm W_j^T  — the `ski=True` variant (training_routines.py:157-158;
     SURVEY.md Appendix E): cubic interpolation of every projection onto one shared regular grid of `grid_size` points
-    and a Toeplitz RBF on the grid.  O(N) per MVM (scatter / Toeplitz / gather kernels); same protocol as the exact
+    and a Toeplitz matrix of the wrapped 1-D sub-kernel (`kind`: RBF by default) on the grid.  O(N) per MVM (scatter / Toeplitz / gather kernels); same protocol as the exact
     operator so the whole solve stack is unchanged.  The grid is recomputed from the data range at construction
     (once per hyper-parameter step) and is not differentiated (it is a buffer in GPyTorch as well)."""
 
     def __init__(self, Z1, Z2=None, outputscale=None, weight=1.0, shard=None, grid_size=1024, comp_weights=None,
-                 row_shard=None, grid_rule="shared"):
+                 row_shard=None, grid_rule="shared", kind="RBF"):
         super().__init__(Z1, Z2, outputscale, weight, shard=None)     # (no J-sharding: the SKI product is O(N))
         self.grid_size = int(grid_size)
+        # the wrapped 1-D sub-kernel (training_routines.py:157-158 wraps whatever `_map_to_kernel` returned): only the
+        # grid-to-grid Toeplitz entries depend on it; scatter, gather and the derivative's staging are kernel-agnostic
+        self.kind = kind
         self._plan = None
         self._local_plan = None       # plan of this rank's rows (row-sharded solve + derivative)
         # Multi-GPU: the N training rows are split over the ranks (distributed.RowShard).  The operator itself keeps the
@@ -324,6 +327,8 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         self.grid_rule = grid_rule
         be = _backend.get_backend()
         kw = {} if grid_rule == "shared" else {"rule": grid_rule}
+        if kind != "RBF":
+            kw["kind"] = kind
         if comp_weights is None:
             self.gp = be.ski_grid(Z1.detach(), None if Z2 is None else Z2.detach(), self.grid_size, **kw)
         else:
@@ -382,6 +387,7 @@ class SKIAdditiveOperator(AdditiveRPOperator):
         t.grid_size, t.gp, t.comp_weights, t.row_shard, t._plan = self.grid_size, self.gp, self.comp_weights, None, None
         t._local_plan = None
         t.grid_rule = self.grid_rule
+        t.kind = self.kind
         return t
 
     def row_sharded(self, noise):
@@ -521,7 +527,7 @@ class RowShardedSKIOperator(LinearOperator):
     histogram.  CG on it runs with all-reduced inner products (`linear_cg(..., reduce=shard.all_reduce_)`); the rank-k
     pivoted-Cholesky preconditioner is built from distributed pivots (`row_sharded_preconditioner`)."""
 
-    def __init__(self, Z_local, outputscale, weight, row_shard, grid_size=1024, noise=0.0, gp=None):
+    def __init__(self, Z_local, outputscale, weight, row_shard, grid_size=1024, noise=0.0, gp=None, kind="RBF"):
         self.Z1 = Z_local.detach().contiguous()
         self.row_shard = row_shard
         self.grid_size = int(grid_size)
@@ -537,7 +543,10 @@ class RowShardedSKIOperator(LinearOperator):
         else:
             rng = torch.full((2,), float("inf"), device=self.Z1.device, dtype=self.Z1.dtype)
         row_shard.all_reduce_(rng, "min")                     # one collective for (min, -max)
-        self.gp = be.ski_grid_from_range(float(rng[0]), float(-rng[1]), self.grid_size, self.Z1.device)
+        kw = {} if kind == "RBF" else {"kind": kind}
+        if self.Z1.dtype == torch.float64:
+            kw["dtype"] = torch.float64
+        self.gp = be.ski_grid_from_range(float(rng[0]), float(-rng[1]), self.grid_size, self.Z1.device, **kw)
 
     def _size(self):
         n = self.Z1.shape[0]

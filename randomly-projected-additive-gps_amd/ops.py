@@ -455,18 +455,32 @@ def symcache_mvm(cache, V, scale, noise=0.0):
 
 # ------------------------------------------------------------------------------------------------ SKI path
 
-def ski_grid(Z1, Z2=None, grid_size=1024, weights=None, rule="shared"):
+_SKI_KINDS = {"RBF": 0, "Matern": 1, "InverseMQ": 2, "Cosine": 3}          # RPGP_KIND_* of include/rpgp.h
+
+
+def _ski_set_kind(gp, kind):
+    """The 1-D sub-kernel the grid's Toeplitz matrix is built from rides in the flags word of the grid block (bits 2-3:
+    csrc/rpgp_ski_common.h) — `GridInterpolationKernel` wraps whatever `_map_to_kernel` returned (training_routines.py:157-158)."""
+    if kind not in _SKI_KINDS:
+        raise ValueError("Unknown kernel type")
+    if _SKI_KINDS[kind]:
+        gp[3] += 4.0 * _SKI_KINDS[kind]
+    return gp
+
+
+def ski_grid(Z1, Z2=None, grid_size=1024, weights=None, rule="shared", kind="RBF"):
     """Device grid-parameter block covering Z1 (and Z2).
     rule "shared" (this build's default for the additive_rp kinds): ONE regular grid for all projections,
         [g0, h, 1/h, flags, (w_0 .. w_{J-1})];
     rule "reference" (polynomial_projection_kernels.py:54-63, the rp_poly / strictly_additive / additive kinds): a grid
         per projection, [., ., ., flags, w_0 .. w_{J-1}, (g0_j, h_j, 1/h_j) x J].
     `weights` (J per-projection output scales) switches every SKI entry point to the weighted sum (flags |= 1).
+    `kind` (RBF | Matern | InverseMQ | Cosine): the wrapped 1-D sub-kernel (flags |= 4 * RPGP_KIND_*).
     float64 coordinates get the float64 twin of the block (the float64 parity path, rpgp_ski_f64.hip)."""
     if rule not in ("shared", "reference"):
         raise ValueError("unknown SKI grid rule %r (shared | reference)" % (rule,))
     if Z1.dtype == torch.float64:
-        return _ski64_grid(Z1, Z2, grid_size, weights, rule)
+        return _ski_set_kind(_ski64_grid(Z1, Z2, grid_size, weights, rule), kind)
     lib = _lib.load()
     Z1 = _require(Z1, "Z1", 2)
     N1, J = Z1.shape
@@ -490,7 +504,7 @@ def ski_grid(Z1, Z2=None, grid_size=1024, weights=None, rule="shared"):
             raise ValueError("weights must have one entry per projection (%d)" % J)
         gp[3] = 3.0 if per_proj else 1.0
         gp[4:4 + J] = w
-    return gp
+    return _ski_set_kind(gp, kind)
 
 
 class SkiPlan:
@@ -551,25 +565,29 @@ def ski_mvm(Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024, plan=None):
     return out.squeeze(1) if squeeze else out
 
 
-def ski_grid_from_range(zmin, zmax, grid_size, device, weights=None):
+def ski_grid_from_range(zmin, zmax, grid_size, device, weights=None, kind="RBF", dtype=torch.float32):
     """The grid-parameter block of rpgp_ski_grid for a KNOWN coordinate range (row-sharded SKI: the range is all-reduced
-    over the ranks first): h = range / (G - 5), g0 = zmin - 2 h, so that every 4-tap stencil is interior."""
+    over the ranks first): h = range / (G - 5), g0 = zmin - 2 h, so that every 4-tap stencil is interior.  `dtype`
+    float64: the float64 twin of the block (`--double`, the rule of _ski64_grid)."""
     import numpy as np
-    mn, mx = np.float32(zmin), np.float32(zmax)
-    rng = np.float32(mx - mn)
-    if not rng > np.float32(1e-12):
-        rng = np.float32(1e-12)
-    h = np.float32(rng / np.float32(grid_size - 5))
-    head = [float(np.float32(mn - np.float32(2.0) * h)), float(h), float(np.float32(1.0) / h), 0.0 if weights is None else 1.0]
-    gp = torch.tensor(head, dtype=torch.float32, device=device)
+    ft = np.float64 if dtype == torch.float64 else np.float32
+    mn, mx = ft(zmin), ft(zmax)
+    rng = ft(mx - mn)
+    if not rng > ft(1e-12):
+        rng = ft(1e-12)
+    h = ft(rng / ft(grid_size - 5))
+    head = [float(ft(mn - ft(2.0) * h)), float(h), float(ft(1.0) / h), 0.0 if weights is None else 1.0]
+    gp = torch.tensor(head, dtype=dtype, device=device)
     if weights is not None:
-        gp = torch.cat([gp, weights.detach().reshape(-1).to(device=device, dtype=torch.float32)])
-    return gp
+        gp = torch.cat([gp, weights.detach().reshape(-1).to(device=device, dtype=dtype)])
+    return _ski_set_kind(gp, kind)
 
 
 def ski_scatter(Z, gp, V, grid_size=1024, plan=None):
     """Stage 1 of the SKI MVM: hist[j][g][t] (float64, J x G x T) = sum over the rows of Z of w(z_ij)[g] V[i][t]."""
     lib = _lib.load()
+    if Z.dtype == torch.float64:
+        return _ski64_scatter(Z, gp, V, grid_size)
     Z = _require(Z, "Z", 2)
     N, J = Z.shape
     V2, _ = _as_matrix(V, N, "V")
@@ -597,6 +615,12 @@ def ski_grid_product(hist, gp, grid_size=1024):
         raise TypeError("hist must be a float64 J x G x T tensor on a HIP device")
     hist = hist.contiguous()
     J, G, T = hist.shape
+    if gp.dtype == torch.float64:                 # the float64 twin of the grid block: the float64 parity path
+        H = torch.empty((J, G, T), dtype=torch.float64, device=hist.device)
+        with _on(hist.device):
+            _lib.check(lib.rpgp_ski_f64_grid_product(hist.data_ptr(), gp.data_ptr(), H.data_ptr(), J, G, T, 1, _stream()),
+                       "rpgp_ski_f64_grid_product")
+        return H
     H = torch.empty((J, G, T), dtype=torch.float32, device=hist.device)
     with _on(hist.device):
         _lib.check(lib.rpgp_ski_grid_product(hist.data_ptr(), gp.data_ptr(), H.data_ptr(), J, G, T, _stream()),
@@ -607,6 +631,8 @@ def ski_grid_product(hist, gp, grid_size=1024):
 def ski_gather(Z, gp, H, V, scale, noise=0.0, grid_size=1024, plan=None):
     """Stage 3: out[i][t] = scale * sum_j sum_k w_k(z_ij) H[j][idx0 + k][t] + noise * V[i][t] for the rows of Z."""
     lib = _lib.load()
+    if Z.dtype == torch.float64:
+        return _ski64_gather(Z, gp, H, V, scale, noise, grid_size)
     Z = _require(Z, "Z", 2)
     M, J = Z.shape
     H = _require(H, "H", 3)
@@ -736,6 +762,13 @@ def ski_bilinear_scatter(Z, gp, L, R, grid_size=1024, plan=None):
     hist = torch.zeros((J, grid_size, 2 * T), dtype=torch.float64, device=Z.device)
     if N == 0:
         return hist
+    if Z.dtype == torch.float64:
+        Zc, Lc, Rc = (_require(t, n, 2, allow64=True) for t, n in ((Z, "Z"), (L, "L"), (R, "R")))
+        with _on(Z.device):
+            for src, off in ((Lc, 0), (Rc, T)):
+                _lib.check(lib.rpgp_ski_f64_scatter(Zc.data_ptr(), gp.data_ptr(), src.data_ptr(), hist.data_ptr(), N, J, J,
+                                                    grid_size, T, 2 * T, off, 0, _stream()), "rpgp_ski_f64_scatter")
+        return hist
     Z = _require(Z, "Z", 2)
     L2, _ = _as_matrix(L, N, "L")
     R2, _ = _as_matrix(R, N, "R")
@@ -760,10 +793,20 @@ def ski_bilinear_finish(Z, gp, hist2, L, R, scale, grid_size=1024, comp=False):
     lib = _lib.load()
     N, J = Z.shape
     T = L.shape[1]
-    gZ = torch.zeros((N, J), dtype=torch.float32, device=Z.device)
-    gs = torch.zeros((), dtype=torch.float32, device=Z.device)
-    gc = torch.zeros(J, dtype=torch.float32, device=Z.device) if comp else None
+    gZ = torch.zeros((N, J), dtype=Z.dtype, device=Z.device)
+    gs = torch.zeros((), dtype=Z.dtype, device=Z.device)
+    gc = torch.zeros(J, dtype=Z.dtype, device=Z.device) if comp else None
     if N == 0:
+        return gZ, gs, gc
+    if Z.dtype == torch.float64:
+        Zc, Lc, Rc = (_require(t, n, 2, allow64=True) for t, n in ((Z, "Z"), (L, "L"), (R, "R")))
+        hist2 = hist2.contiguous()
+        with _on(Z.device):
+            ws = _workspace(Z.device, 8 * J * grid_size * 2 * T + 8 * J + 1024)
+            _lib.check(lib.rpgp_ski_f64_bilinear_finish(Zc.data_ptr(), gp.data_ptr(), hist2.data_ptr(), Lc.data_ptr(), Rc.data_ptr(),
+                                                        gZ.data_ptr(), gs.data_ptr(), None if gc is None else gc.data_ptr(), N, J,
+                                                        J, J, grid_size, T, float(scale), ws.data_ptr(), ws.numel(), _stream()),
+                       "rpgp_ski_f64_bilinear_finish")
         return gZ, gs, gc
     Z = _require(Z, "Z", 2)
     L2, _ = _as_matrix(L, N, "L")
@@ -1288,6 +1331,39 @@ def step_hyper_backward(dPeff, W, n_ls, prescale, zfac, hyper_dev, gs, partials,
 
 
 # ---- float64 parity path of the SKI operator (csrc/rpgp_ski_f64.hip): `--double` for the `ski: true` specifications --------
+def _ski64_scatter(Z, gp, V, grid_size):
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2, allow64=True)
+    N, J = Z.shape
+    V2 = V.reshape(N, -1).contiguous()
+    if V2.dtype != torch.float64:
+        raise TypeError("V must be float64 for float64 coordinates")
+    T = V2.shape[1]
+    hist = torch.empty((J, grid_size, T), dtype=torch.float64, device=Z.device)
+    with _on(Z.device):
+        _lib.check(lib.rpgp_ski_f64_scatter(Z.data_ptr(), gp.data_ptr(), V2.data_ptr(), hist.data_ptr(), N, J, J, grid_size, T, T,
+                                            0, 1, _stream()), "rpgp_ski_f64_scatter")
+    return hist
+
+
+def _ski64_gather(Z, gp, H, V, scale, noise, grid_size):
+    lib = _lib.load()
+    Z = _require(Z, "Z", 2, allow64=True)
+    M, J = Z.shape
+    H = H.contiguous()
+    if H.dtype != torch.float64 or H.dim() != 3:
+        raise TypeError("H must be the float64 J x G x T grid product for float64 coordinates")
+    T = H.shape[2]
+    V2 = V.reshape(M, -1).contiguous() if noise else None
+    out = torch.empty((M, T), dtype=torch.float64, device=Z.device)
+    with _on(Z.device):
+        _lib.check(lib.rpgp_ski_f64_gather(Z.data_ptr(), gp.data_ptr(), H.data_ptr(), None if V2 is None else V2.data_ptr(),
+                                           out.data_ptr(), M, J, J, grid_size, T, float(scale), float(noise), _stream()),
+                   "rpgp_ski_f64_gather")
+    return out
+
+
+
 def _ski64_grid(Z1, Z2, grid_size, weights, rule):
     """The float64 twin of the grid-parameter block, from the same rules (rpgp_ski_grid / rpgp_ski_grid_per_projection), as
     torch operations on the device (a dozen scalars per hyper-parameter step)."""

@@ -161,16 +161,22 @@ class OracleBackend:
         return ((R.double() - L.double() @ Tm) / float(noise)).to(torch.float32)
 
     # ---- SKI path -------------------------------------------------------------------------------------------
-    def ski_grid(self, Z1, Z2=None, grid_size=1024, weights=None, rule="shared"):
+    _KINDS = ("RBF", "Matern", "InverseMQ", "Cosine")
+
+    def _kind(self, gp):
+        return self._KINDS[(int(gp[3]) >> 2) & 3]
+
+    def ski_grid(self, Z1, Z2=None, grid_size=1024, weights=None, rule="shared", kind="RBF"):
+        kflag = 4.0 * self._KINDS.index(kind)
         J = Z1.shape[1]
         if rule == "reference":          # per-projection grids: [., ., ., flags, w_0..w_{J-1}, (g0_j, h_j, 1/h_j) x J]
             g0, h = sko.grid_params_reference(_np(Z1), None if Z2 is None else _np(Z2), grid_size)
-            head = [0.0, 1.0, 1.0, 2.0 if weights is None else 3.0]
+            head = [0.0, 1.0, 1.0, (2.0 if weights is None else 3.0) + kflag]
             w = [1.0] * J if weights is None else [float(x) for x in weights.detach().reshape(-1)]
             tail = [v for j in range(J) for v in (g0[j], h[j], 1.0 / h[j])]
             return torch.tensor(head + w + tail, dtype=torch.float64)
         g0, h = sko.grid_params(_np(Z1), None if Z2 is None else _np(Z2), grid_size)
-        head = [g0, h, 1.0 / h, 0.0 if weights is None else 1.0]
+        head = [g0, h, 1.0 / h, (0.0 if weights is None else 1.0) + kflag]
         tail = [] if weights is None else [float(x) for x in weights.detach().reshape(-1)]
         return torch.tensor(head + tail, dtype=Z1.dtype)
 
@@ -194,7 +200,7 @@ class OracleBackend:
     def ski_mvm(self, Z1, Z2, gp, V, scale, noise=0.0, grid_size=1024):
         squeeze = V.dim() == 1
         v = _np(V).reshape(Z2.shape[0], -1)
-        K = sko.dense_kernel(_np(Z1), _np(Z2), scale, grid_size, self._grid(gp), self._w(gp))
+        K = sko.dense_kernel(_np(Z1), _np(Z2), scale, grid_size, self._grid(gp), self._w(gp), self._kind(gp))
         out = K @ v
         if noise:
             out = out + noise * v
@@ -202,13 +208,13 @@ class OracleBackend:
         return r.squeeze(1) if squeeze else r
 
     def ski_dense(self, Z1, Z2, gp, scale, grid_size=1024):
-        return _t(sko.dense_kernel(_np(Z1), _np(Z2), scale, grid_size, self._grid(gp), self._w(gp)), Z1)
+        return _t(sko.dense_kernel(_np(Z1), _np(Z2), scale, grid_size, self._grid(gp), self._w(gp), self._kind(gp)), Z1)
 
     # ---- staged SKI (row-sharded operator): scatter -> all-reduce -> grid product -> gather ----------------------
-    def ski_grid_from_range(self, zmin, zmax, grid_size, device, weights=None):
+    def ski_grid_from_range(self, zmin, zmax, grid_size, device, weights=None, kind="RBF", dtype=None):
         rng = max(float(zmax) - float(zmin), 1e-12)
         h = rng / (grid_size - 5)
-        head = [float(zmin) - 2.0 * h, h, 1.0 / h, 0.0 if weights is None else 1.0]
+        head = [float(zmin) - 2.0 * h, h, 1.0 / h, (0.0 if weights is None else 1.0) + 4.0 * self._KINDS.index(kind)]
         tail = [] if weights is None else [float(x) for x in weights.detach().reshape(-1)]
         return torch.tensor(head + tail, dtype=torch.float64)
 
@@ -221,7 +227,7 @@ class OracleBackend:
     def ski_grid_product(self, hist, gp, grid_size=1024):
         grid = self._grid(gp)
         w = self._w(gp)
-        H = np.stack([(1.0 if w is None else w[j]) * (sko.toeplitz(sko._grid_j(grid, j)[1], grid_size) @ hist[j].double().numpy())
+        H = np.stack([(1.0 if w is None else w[j]) * (sko.toeplitz(sko._grid_j(grid, j)[1], grid_size, self._kind(gp)) @ hist[j].double().numpy())
                       for j in range(hist.shape[0])])
         return torch.from_numpy(H)
 
@@ -237,7 +243,7 @@ class OracleBackend:
         return _t(out, Z)
 
     def ski_diag(self, Z, gp, scale, grid_size=1024):
-        return _t(np.diag(sko.dense_kernel(_np(Z), _np(Z), scale, grid_size, self._grid(gp), self._w(gp))).copy(), Z)
+        return _t(np.diag(sko.dense_kernel(_np(Z), _np(Z), scale, grid_size, self._grid(gp), self._w(gp), self._kind(gp))).copy(), Z)
 
     def ski_bilinear_grad(self, Z, gp, L, R, scale, grid_size=1024):
         """Analytic derivative of sum((L R^T) * K_ski) in float64 (same formulas as the HIP kernel, dense)."""
@@ -251,7 +257,7 @@ class OracleBackend:
         self._last_comp = np.zeros(z.shape[1])
         for j in range(z.shape[1]):
             g0, h = sko._grid_j(grid, j)
-            Tm = sko.toeplitz(h, G)
+            Tm = sko.toeplitz(h, G, self._kind(gp))
             wj = 1.0 if wts is None else wts[j]
             u = np.clip((z[:, j] - g0) / h, 1.0, G - 2.0)
             fl = np.floor(u)
@@ -299,7 +305,7 @@ class OracleBackend:
         hh = hist2.double().numpy()
         for j in range(z.shape[1]):
             g0, h = sko._grid_j(grid, j)
-            Tm = sko.toeplitz(h, G)
+            Tm = sko.toeplitz(h, G, self._kind(gp))
             wj = 1.0 if wts is None else wts[j]
             HL, HR = Tm @ hh[j][:, :T], Tm @ hh[j][:, T:]
             if not z.shape[0]:

@@ -187,8 +187,11 @@ def test_family_validation_errors():
     create_additive_rp_kernel(6, 3, k=7, batch_kernel=False)            # any k <= 20 is served (padded group)
     with pytest.raises(NotImplementedError):
         create_additive_rp_kernel(6, 1, k=21, batch_kernel=False)
-    with pytest.raises(NotImplementedError):
-        create_additive_rp_kernel(6, 3, kernel_type="Matern", ski=True, ski_options={"grid_size": 64})
+    # grid interpolation wraps whatever 1-D sub-kernel `_map_to_kernel` returned (training_routines.py:157-158): served for every
+    # kernel type since round 6; only k > 1 (a k-dimensional grid per projection group) is not built
+    create_additive_rp_kernel(6, 3, kernel_type="Matern", ski=True, ski_options={"grid_size": 64})
+    with pytest.raises((NotImplementedError, ValueError)):
+        create_additive_rp_kernel(6, 3, k=2, batch_kernel=False, ski=True, ski_options={"grid_size": 64})
     with pytest.raises(ValueError):
         create_rp_poly_kernel(6, 1, 3, kernel_type="bogus")
     with pytest.raises(ValueError):
@@ -230,6 +233,9 @@ def test_family_predictions_match_dense(oracle_backend):
 @pytest.mark.parametrize("kind,model_kwargs", [
     ("rp_poly", dict(J=5, k=1, weighted=True, kernel_type="RBF")),
     ("strictly_additive", dict(weighted=False, kernel_type="RBF")),
+    # round 6: the wrapped sub-kernel may be any of the reference's types (training_routines.py:47-88 with :157-158)
+    ("rp_poly", dict(J=5, k=1, weighted=True, kernel_type="InverseMQ")),
+    ("rp_poly", dict(J=4, k=1, weighted=False, kernel_type="Matern")),
 ])
 def test_weighted_ski_kinds_track_the_exact_kernel(oracle_backend, kind, model_kwargs):
     """`ski: true` on the weighted kinds (additive_rp_J20_K1_ski.json, additive_deterministic_spec_unweighted_ski.json):
@@ -258,11 +264,13 @@ def test_weighted_ski_kinds_track_the_exact_kernel(oracle_backend, kind, model_k
                       None if base.raw_outputscales.grad is None else base.raw_outputscales.grad.clone(),
                       model.covar_module.raw_outputscale.grad.clone())
     (v0, gl0, gw0, gs0), (v1, gl1, gw1, gs1) = grads[False], grads[True]
-    assert abs(v0 - v1) < 2e-4 * max(1.0, abs(v0))
-    assert torch.allclose(gl0, gl1, rtol=3e-2, atol=2e-4)
-    assert torch.allclose(gs0, gs1, rtol=3e-2, atol=2e-4)
+    # (the Matern-1.5 kernel has a kink at zero distance: cubic interpolation of it converges with h^2, not h^4)
+    loose = 10.0 if model_kwargs["kernel_type"] == "Matern" else 1.0
+    assert abs(v0 - v1) < 2e-4 * loose * max(1.0, abs(v0))
+    assert torch.allclose(gl0, gl1, rtol=3e-2 * loose, atol=2e-4 * loose)
+    assert torch.allclose(gs0, gs1, rtol=3e-2 * loose, atol=2e-4 * loose)
     if model_kwargs["weighted"]:
-        assert torch.allclose(gw0, gw1, rtol=3e-2, atol=2e-4)
+        assert torch.allclose(gw0, gw1, rtol=3e-2 * loose, atol=2e-4 * loose)
     else:
         assert gw0 is None and gw1 is None
 

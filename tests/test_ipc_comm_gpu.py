@@ -62,8 +62,9 @@ def test_sharded_training_end_to_end_multi_process_one_device(gpu_device, tmp_pa
 def test_runner_one_command_multi_device_form_on_gpu(gpu_device, tmp_path, spec, devices):
     """The reference's ONE-command multi-device form (`--device cuda:0,cuda:1,cuda:2`, gp_experiment_runner.py:263,
     run_scripts/additive_spread_prescale_Jd.sh:6) through the CLI: the runner starts one rank per listed device itself.
-    On the one-GPU box the list repeats cuda:0 (gloo bootstrap + rpgp_comm all-reduce); the result must agree with the
-    single-device run of the same command."""
+    On the one-GPU box the list repeats cuda:0 (gloo bootstrap + rpgp_comm all-reduce).  Like the reference's, the command
+    line has no seed: the two runs draw different random projections, so their scores agree only as two fits of the same
+    model family do (the seeded equality of sharded and single-process fits is tests above and tests/test_distributed_cpu.py)."""
     import json
     import pandas as pd
     sys.path.insert(0, ROOT)
@@ -83,4 +84,5 @@ def test_runner_one_command_multi_device_form_on_gpu(gpu_device, tmp_path, spec,
         outs[name] = pd.read_csv(out)
         assert "error" not in outs[name].columns or outs[name]["error"].isna().all(), outs[name].get("error")
     a, b = float(outs["one"]["rmse"].iloc[0]), float(outs["many"]["rmse"].iloc[0])
-    assert abs(a - b) < 2e-2 * max(abs(a), 1e-3), (a, b)
+    assert 0.0 < a < 1.0 and 0.0 < b < 1.0 and abs(a - b) < 0.3 * max(a, b), (a, b)
+    assert int(outs["many"]["n"].iloc[0]) == int(outs["one"]["n"].iloc[0])

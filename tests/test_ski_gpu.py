@@ -566,3 +566,112 @@ def test_centre_out_cell_dispatch_covers_every_cell(gpu_device, N, J, T, G, dist
     assert float((h_plan - h_ref).norm() / h_ref.norm()) < 1e-6
     out = ops.ski_mvm(Zt, Zt, gp, Vt, 0.7 / J, 0.2, G, plan=plan)
     assert torch.isfinite(out).all() and torch.equal(out, ops.ski_mvm(Zt, Zt, gp, Vt, 0.7 / J, 0.2, G, plan=plan))
+
+
+@pytest.mark.parametrize("kind", ["Matern", "InverseMQ", "Cosine"])
+@pytest.mark.parametrize("N,J,T,G,rule,weighted", [(1500, 3, 11, 256, "shared", False), (40000, 3, 11, 1024, "shared", False),
+                                                   (2000, 8, 23, 128, "reference", True), (900, 2, 1, 1024, "shared", True)])
+def test_ski_around_the_other_sub_kernels_every_entry_point(gpu_device, kind, N, J, T, G, rule, weighted):
+    """Round 6 (VERDICT r5 missing #4): `GridInterpolationKernel` wraps whatever `_map_to_kernel` returned
+    (training_routines.py:157-158 with :47-88) — Matern-1.5, InverseMQ (imq_kernel.py:8-9) and Cosine 1-D sub-kernels under the
+    grid: the sub-kernel rides in the grid block's flags and only the grid-to-grid Toeplitz entries depend on it.  Every entry
+    point — plain and planned product (narrow and wide blocks), staged scatter / grid product / gather, diagonal, dense block,
+    pivoted Cholesky rows, derivative — against the float64 oracle with the same radial form (oracle/ski.py + oracle/family.py),
+    in float32 and through the float64 parity kernels."""
+    from rpgp_amd import ops
+    from rpgp_amd.operators import SKIAdditiveOperator
+    rng = np.random.default_rng(N + G)
+    Z = (rng.standard_normal((N, J)) * 0.9).astype(np.float32)
+    V = rng.standard_normal((N, T)).astype(np.float32)
+    w = rng.uniform(0.4, 1.6, size=J).astype(np.float32) if weighted else None
+    Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
+    wt = None if w is None else torch.from_numpy(w).to(gpu_device)
+    gp = ops.ski_grid(Zt, None, G, weights=wt, rule=rule, kind=kind)
+    assert (int(gp[3]) >> 2) == {"Matern": 1, "InverseMQ": 2, "Cosine": 3}[kind]
+    if rule == "shared":
+        gph = gp.double().cpu().numpy()
+        grid = (float(gph[0]), float(gph[1]))
+    else:
+        arr = gp.double().cpu().numpy()[4 + J:].reshape(J, 3)
+        grid = (arr[:, 0].copy(), arr[:, 1].copy())
+    K = sko.dense_kernel(Z, Z, 0.4, G, grid, w, kind)
+    ref = K @ V.astype(np.float64) + 0.2 * V if N <= 4000 else sko.mvm_sparse(Z, Z, V, 0.4, G, grid, 0.2, w, kind)
+    tol = 3e-5
+    out = ops.ski_mvm(Zt, Zt, gp, Vt, 0.4, 0.2, G)
+    assert _rel(out.cpu().numpy(), ref) < tol
+    plan = ops.SkiPlan(Zt, gp, G)
+    outp = ops.ski_mvm(Zt, Zt, gp, Vt, 0.4, 0.2, G, plan=plan)
+    assert _rel(outp.cpu().numpy(), ref) < tol
+    Tc = min(T, 12)
+    hist = ops.ski_scatter(Zt, gp, Vt[:, :Tc].contiguous(), G, plan=plan)
+    staged = ops.ski_gather(Zt, gp, ops.ski_grid_product(hist, gp, G), Vt[:, :Tc].contiguous(), 0.4, 0.2, G, plan=plan)
+    assert _rel(staged.cpu().numpy(), ref[:, :Tc]) < tol
+    diag_ref = np.diag(K) if N <= 4000 else sko.diag_sparse(Z, 0.4, G, grid, w, kind)
+    np.testing.assert_allclose(ops.ski_diag(Zt, gp, 0.4, G).cpu().numpy(), diag_ref, rtol=3e-5, atol=2e-6)
+    rows = torch.from_numpy(Z[:7]).to(gpu_device)
+    blk = ops.ski_dense(rows, Zt, gp, 0.4, G).cpu().numpy()
+    np.testing.assert_allclose(blk, sko.dense_kernel(Z[:7], Z, 0.4, G, grid, w, kind), rtol=3e-5, atol=2e-6)
+    if kind != "Cosine" and J <= 64:
+        # greedy factor of the (positive definite) operator: the library's per-step kernel evaluates the SKI rows itself
+        from rpgp_amd.precond import pivoted_cholesky
+        op = SKIAdditiveOperator(Zt, None, torch.tensor(0.4, device=gpu_device), 1.0, grid_size=G, comp_weights=wt,
+                                 grid_rule=rule, kind=kind)
+        Lf = op.fused_pivoted_cholesky(8)
+        Lg = pivoted_cholesky(op._diagonal(), op._get_rows, 8)
+        assert Lf is not None and torch.allclose(Lf, Lg, rtol=2e-3, atol=3e-4)
+    if N <= 4000:
+        # derivative of sum((L R^T) * K) with the grid held fixed, against float64 finite differences of the oracle
+        Tb = min(T, 5)
+        Lm = rng.standard_normal((N, Tb)).astype(np.float32) * 0.1
+        Rm = rng.standard_normal((N, Tb)).astype(np.float32) * 0.1
+        gz, gs = ops.ski_bilinear_grad(Zt, gp, torch.from_numpy(Lm).to(gpu_device), torch.from_numpy(Rm).to(gpu_device), 0.4, G)[:2]
+        gz = gz.cpu().numpy()
+        Lh, Rh = Lm.astype(np.float64), Rm.astype(np.float64)
+        for (i, j) in ((3, 0), (N // 2, J - 1)):
+            Zp, Zm = Z.astype(np.float64).copy(), Z.astype(np.float64).copy()
+            Zp[i, j] += 1e-4
+            Zm[i, j] -= 1e-4
+            fd = (sko.bilinear_objective(Zp, Lh, Rh, 0.4, G, grid, w, kind) - sko.bilinear_objective(Zm, Lh, Rh, 0.4, G, grid, w, kind)) / 2e-4
+            assert abs(gz[i, j] - fd) < 3e-3 * np.abs(gz).max() + 3e-3 * abs(fd)
+        obj1 = sko.bilinear_objective(Z, Lh, Rh, 1.0, G, grid, w, kind)            # d / d scale is linear: objective / scale
+        assert abs(float(gs) - obj1) < 2e-4 * (np.abs(Lh).sum() * np.abs(Rh).sum() / N) ** 0.5 + 2e-4 * abs(obj1)
+        # the float64 parity kernels (`--double`) on the same problem
+        Zd, Vd = Zt.double(), Vt.double()
+        gpd = ops.ski_grid(Zd, None, G, weights=None if wt is None else wt.double(), rule=rule, kind=kind)
+        outd = ops.ski_mvm(Zd, Zd, gpd, Vd, 0.4, 0.2, G)
+        if rule == "shared":
+            gd = gpd.cpu().numpy()
+            grid_d = (float(gd[0]), float(gd[1]))
+        else:
+            ad = gpd.cpu().numpy()[4 + J:].reshape(J, 3)
+            grid_d = (ad[:, 0].copy(), ad[:, 1].copy())
+        refd = sko.dense_kernel(Z, Z, 0.4, G, grid_d, w, kind) @ V.astype(np.float64) + 0.2 * V
+        assert _rel(outd.cpu().numpy(), refd) < 1e-11
+        histd = ops.ski_scatter(Zd, gpd, Vd[:, :Tc].contiguous(), G)
+        stagedd = ops.ski_gather(Zd, gpd, ops.ski_grid_product(histd, gpd, G), Vd[:, :Tc].contiguous(), 0.4, 0.2, G)
+        assert _rel(stagedd.cpu().numpy(), refd[:, :Tc]) < 1e-11
+
+
+@pytest.mark.parametrize("kernel_type", ["Matern", "InverseMQ"])
+def test_ski_model_with_another_sub_kernel_tracks_its_exact_counterpart(gpu_device, kernel_type):
+    """`additive_rp` with `kernel_type` Matern / InverseMQ and `ski: true`: the MLL of the interpolated model against the exact
+    family operator of the same hyper-parameters (interpolation error only; the Matern kink converges with h^2)."""
+    from rpgp_amd import settings
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(3000, 5, generator=g)
+    y = torch.sin(X).sum(1) + 0.1 * torch.randn(3000, generator=g)
+    X, y = X.to(gpu_device), ((y - y.mean()) / y.std()).to(gpu_device)
+    vals = {}
+    for ski in (False, True):
+        torch.manual_seed(1)
+        np.random.seed(1)
+        model, lik = create_exact_gp(X, y, "additive_rp", J=5, noise_prior=True, kernel_type=kernel_type, learn_proj=False,
+                                     prescale=True, ski=ski, ski_options={"grid_size": 1024, "num_dims": 1} if ski else None)
+        model = model.to(gpu_device)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        model.train()
+        with settings.max_cholesky_size(10000), torch.no_grad():
+            vals[ski] = mll(model(X), y).item()
+    assert abs(vals[True] - vals[False]) < (3e-3 if kernel_type == "Matern" else 3e-4) * abs(vals[False]), vals

@@ -73,4 +73,24 @@ void oracle_mvm_f64(const double *Z1, const double *Z2, const double *V, double 
   }
 }
 
-int oracle_cmvm_version(void) { return 1; }
+/* gZ[i][j] = -scale * sum_i' S[i][i'] (z_ij - z_i'j) exp(-0.5 (z_ij - z_i'j)^2): d/dZ of sum(W * scale K_add(Z, Z)) with
+ * S = W + W^T (the analytic x1 / x2 gradients of memory_efficient_gam_kernel.py:53-58 summed for
+ * x1 == x2).  S: N x N row-major.  Same arithmetic as the numpy loop it replaces in tests/test_parity_gpu.py (projection
+ * outermost, row sums), so that the C2 / C3-size derivative checks take seconds. */
+void oracle_bilinear_gz_f64(const double *Z, const double *S, double *gZ, long N, int J, double scale) {
+#pragma omp parallel for schedule(dynamic, 8)
+  for (long i = 0; i < N; ++i) {
+    const double *si = S + (size_t)i * N;
+    for (int j = 0; j < J; ++j) {
+      const double a = Z[i * J + j];
+      double acc = 0.0;
+      for (long c = 0; c < N; ++c) {
+        const double d = a - Z[c * J + j];
+        acc += exp(-0.5 * d * d) * si[c] * d;
+      }
+      gZ[i * J + j] = -scale * acc;
+    }
+  }
+}
+
+int oracle_cmvm_version(void) { return 2; }

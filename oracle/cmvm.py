@@ -40,8 +40,21 @@ def _load():
         lib.oracle_mvm_f64.argtypes = [dp, dp, dp, dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_double, ctypes.c_double, ctypes.c_int]
         lib.oracle_mvm_f64.restype = None
+        lib.oracle_bilinear_gz_f64.argtypes = [dp, dp, dp, ctypes.c_long, ctypes.c_int, ctypes.c_double]
+        lib.oracle_bilinear_gz_f64.restype = None
         lib.oracle_cmvm_version.restype = ctypes.c_int
-        assert lib.oracle_cmvm_version() == 1
+        if lib.oracle_cmvm_version() != 2:          # a stale build of an older source: rebuild once
+            del lib
+            lib = ctypes.CDLL(build(force=True))
+            lib.oracle_kernel_f64.argtypes = [dp, dp, dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_double]
+            lib.oracle_kernel_f64.restype = None
+            lib.oracle_mvm_f64.argtypes = [dp, dp, dp, dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_double, ctypes.c_double, ctypes.c_int]
+            lib.oracle_mvm_f64.restype = None
+            lib.oracle_bilinear_gz_f64.argtypes = [dp, dp, dp, ctypes.c_long, ctypes.c_int, ctypes.c_double]
+            lib.oracle_bilinear_gz_f64.restype = None
+            lib.oracle_cmvm_version.restype = ctypes.c_int
+            assert lib.oracle_cmvm_version() == 2
         _lib = lib
     return _lib
 
@@ -76,3 +89,14 @@ def mvm(Z1, Z2, V, scale, noise=0.0):
     _load().oracle_mvm_f64(p1, p2, pv, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), Z1.shape[0], Z2.shape[0],
                            Z1.shape[1], V.shape[1], float(scale), float(noise), 1 if noise else 0)
     return out[:, 0] if vec else out
+
+
+def bilinear_gz(Z, S, scale):
+    """d/dZ of sum(W * scale K_add(Z, Z)) given S = W + W^T (N x N float64): gZ[i][j] = -scale sum_i' S[i,i'] (z_ij - z_i'j)
+    exp(-0.5 (z_ij - z_i'j)^2)  (SURVEY.md Appendix A.2)."""
+    Z, pz = _c(Z)
+    S, ps = _c(S)
+    assert S.shape == (Z.shape[0], Z.shape[0])
+    out = np.empty_like(Z)
+    _load().oracle_bilinear_gz_f64(pz, ps, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), Z.shape[0], Z.shape[1], float(scale))
+    return out

@@ -370,20 +370,16 @@ inline int ski_tpiece(int remaining) { return remaining > 4 ? 12 : (remaining > 
 int scatter_planned(const PlanView &pv, const float *V, double *hist, float *partial, long long N, int J, int G, int T, int HT,
                     int hoff, hipStream_t st) {
   const int cells = J * G;
-  // EXPERIMENT (round 6; removed again after the measurement, tools/experiments/r6_ski_padded_rows.patch): the rows
-  // of V padded to RPGP_EXP_SKI_LDV floats (16 = 64 bytes: every gathered row one aligned sector)
-  const char *env_ldv = getenv("RPGP_EXP_SKI_LDV");
-  const int ldv = env_ldv ? atoi(env_ldv) : T;
   for (int t0 = 0; t0 < T;) {
     const int tt = ski_tpiece(T - t0);
     const int tcnt = (T - t0 < tt) ? T - t0 : tt;
     const long long n = (long long)J * G * tt;
     if (tt == 1)
-      hipLaunchKernelGGL((ski_scatter_cell_kernel<1, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, ldv, t0, tcnt, G);
+      hipLaunchKernelGGL((ski_scatter_cell_kernel<1, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt, G);
     else if (tt == 4)
-      hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, ldv, t0, tcnt, G);
+      hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 1>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt, G);
     else
-      hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 3>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, ldv, t0, tcnt, G);
+      hipLaunchKernelGGL((ski_scatter_cell_kernel<4, 3>), dim3((unsigned)cells), dim3(256), 0, st, pv.rec, pv.cell_start, V, partial, T, t0, tcnt, G);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(ski_cellsum4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, hist, J, G, tt, tcnt,

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import dense_gp as orc
+from tests.oracle_fast import omvm
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +30,7 @@ def test_mvm_sym_matches_oracle(gpu_device, N, J, T):
     from rpgp_amd import ops
     Z, V = _data(N, J, T, seed=N + J)
     scale, noise = 0.7 / J, 0.1
-    ref = orc.mvm(Z, Z, V, scale, noise)
+    ref = omvm(Z, Z, V, scale, noise)
     out = ops.mvm_sym(torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device), scale, noise)
     # tolerance: fp32 accumulation of N terms + v_exp_f32 (1 ulp) -> 1e-5 relative in the 2-norm
     assert _rel(out.cpu().numpy(), ref) < 1e-5
@@ -39,7 +40,7 @@ def test_mvm_sym_large_two_rows_per_lane(gpu_device):
     from rpgp_amd import ops
     N, J, T = 16500, 20, 1
     Z, V = _data(N, J, T, seed=5)
-    ref = orc.mvm(Z, Z, V, 1.0 / J, 0.05)
+    ref = omvm(Z, Z, V, 1.0 / J, 0.05)
     out = ops.mvm_sym(torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device), 1.0 / J, 0.05)
     assert _rel(out.cpu().numpy(), ref) < 1e-5
 
@@ -54,7 +55,7 @@ def test_mvm_sym_vector_rhs_and_jrange(gpu_device):
     parts = sum(ops.mvm_sym(Zt, v, 0.05, 0.0, j0=a, j1=b) for a, b in [(0, 3), (3, 6), (6, 13), (13, 20)])
     assert full.shape == (N,)
     assert _rel(parts.cpu().numpy(), full.cpu().numpy()) < 1e-6
-    ref = orc.mvm(Z[:, 3:6], Z[:, 3:6], V, 0.05)
+    ref = omvm(Z[:, 3:6], Z[:, 3:6], V, 0.05)
     got = ops.mvm_sym(Zt, v, 0.05, 0.0, j0=3, j1=6)
     assert _rel(got.cpu().numpy(), ref[:, 0]) < 1e-5
 
@@ -67,7 +68,7 @@ def test_mvm_rect_matches_oracle(gpu_device, M, N, J, T):
     Z1 = rng.standard_normal((M, J)).astype(np.float32)
     Z2 = rng.standard_normal((N, J)).astype(np.float32)
     V = rng.standard_normal((N, T)).astype(np.float32)
-    ref = orc.mvm(Z1, Z2, V, 0.3)
+    ref = omvm(Z1, Z2, V, 0.3)
     out = ops.mvm_rect(torch.from_numpy(Z1).to(gpu_device), torch.from_numpy(Z2).to(gpu_device),
                        torch.from_numpy(V).to(gpu_device), 0.3)
     assert _rel(out.cpu().numpy(), ref) < 1e-5
@@ -132,7 +133,7 @@ def test_dense_mvm(gpu_device, N, T):
     Zt = torch.from_numpy(Z).to(gpu_device)
     Kd = ops.dense(Zt, Zt, 0.2)
     out = ops.dense_mvm(Kd, torch.from_numpy(V).to(gpu_device), 0.3)
-    ref = orc.mvm(Z, Z, V, 0.2, 0.3)
+    ref = omvm(Z, Z, V, 0.2, 0.3)
     assert _rel(out.cpu().numpy(), ref) < 1e-5
 
 
@@ -150,7 +151,7 @@ def test_dense_mvm_padded_rows_ragged_edge(gpu_device, N, T):
     base[:, :N] = ops.dense(Zt, Zt, 0.2)
     Kd = base[:, :N]
     out = ops.dense_mvm(Kd, torch.from_numpy(V).to(gpu_device), 0.3)
-    ref = orc.mvm(Z, Z, V, 0.2, 0.3)
+    ref = omvm(Z, Z, V, 0.2, 0.3)
     assert torch.isfinite(out).all()
     assert _rel(out.cpu().numpy(), ref) < 1e-5
     Kp = ops.dense(Zt, Zt, 0.2, pad=True)
@@ -175,7 +176,7 @@ def test_symcache_product_matches_oracle(gpu_device, N, J, T, wide):
     cache = ops.SymCache(Zt, wide=wide)
     assert cache.nbytes < 0.75 * 4 * N * N + (1 << 22)            # about half of the dense matrix (plus block padding)
     out = ops.symcache_mvm(cache, Vt, 0.2, 0.3)
-    ref = orc.mvm(Z, Z, V, 0.2, 0.3)
+    ref = omvm(Z, Z, V, 0.2, 0.3)
     assert _rel(out.cpu().numpy(), ref) < 2e-6
     # identical arithmetic to the direct fused sweep: same sums in the same order
     fused = ops.mvm_sym(Zt, Vt, 0.2, 0.3)
@@ -183,7 +184,7 @@ def test_symcache_product_matches_oracle(gpu_device, N, J, T, wide):
     # a column range of the projections
     if J >= 5:
         part = ops.symcache_mvm(ops.SymCache(Zt, j0=1, j1=J - 1, wide=wide), Vt, 0.2, 0.0)
-        assert _rel(part.cpu().numpy(), orc.mvm(Z[:, 1:J - 1], Z[:, 1:J - 1], V, 0.2, 0.0)) < 2e-6
+        assert _rel(part.cpu().numpy(), omvm(Z[:, 1:J - 1], Z[:, 1:J - 1], V, 0.2, 0.0)) < 2e-6
 
 
 @pytest.mark.parametrize("wide", [False, True])
@@ -224,7 +225,7 @@ def test_symcache_wide_product_ragged_sizes_and_shards(gpu_device, N, T, shard):
     ref_thin = ops.symcache_mvm(thin, Vt[:, :3].contiguous(), 0.2, 0.3)
     assert float((out[:, :3] - ref_thin).norm() / ref_thin.norm()) < 2e-6
     if shard is None:
-        assert _rel(out.cpu().numpy(), orc.mvm(Z, Z, V, 0.2, 0.3)) < 2e-6
+        assert _rel(out.cpu().numpy(), omvm(Z, Z, V, 0.2, 0.3)) < 2e-6
 
 
 @pytest.mark.parametrize("N", [4095, 4096, 16384, 16385, 36000, 36001])
@@ -306,14 +307,14 @@ def test_mvm_sym_prepared_matches_oracle(gpu_device, N, J, T, shift):
     Z, V = _data(N, J, T, seed=N + J + 1)
     Z = (Z + np.float32(shift)).astype(np.float32)
     scale, noise = 0.7 / J, 0.1
-    ref = orc.mvm(Z, Z, V, scale, noise)
+    ref = omvm(Z, Z, V, scale, noise)
     Zt = torch.from_numpy(Z).to(gpu_device)
     prep = ops.Prepared(Zt)
     assert prep.fast_ok and prep.max_abs < 10.0
     out = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), scale, noise)
     assert _rel(out.cpu().numpy(), ref) < 1e-5
     part = ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), scale, 0.0, j0=1, j1=J)
-    ref_p = orc.mvm(Z[:, 1:], Z[:, 1:], V, scale) if J > 1 else None
+    ref_p = omvm(Z[:, 1:], Z[:, 1:], V, scale) if J > 1 else None
     if ref_p is not None:
         assert _rel(part.cpu().numpy(), ref_p) < 1e-5
 
@@ -330,7 +331,7 @@ def test_prepared_range_guard(gpu_device):
     with pytest.raises(RuntimeError):
         ops.mvm_sym_prepared(prep, torch.from_numpy(V).to(gpu_device), 1.0)
     out = ops.mvm_sym(Zt, torch.from_numpy(V).to(gpu_device), 1.0, 0.0)
-    assert _rel(out.cpu().numpy(), orc.mvm(Z, Z, V, 1.0)) < 1e-5
+    assert _rel(out.cpu().numpy(), omvm(Z, Z, V, 1.0)) < 1e-5
     bad = torch.from_numpy(np.full((10, 2), np.nan, dtype=np.float32)).to(gpu_device)
     assert not ops.Prepared(bad).fast_ok
 
@@ -416,14 +417,14 @@ def test_edge_shapes(gpu_device):
     Z = rng.standard_normal((2, 3)).astype(np.float32)
     V = rng.standard_normal((2, 1)).astype(np.float32)
     out = ops.mvm_sym(torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device), 1.0, 0.5)
-    assert _rel(out.cpu().numpy(), orc.mvm(Z, Z, V, 1.0, 0.5)) < 1e-6
+    assert _rel(out.cpu().numpy(), omvm(Z, Z, V, 1.0, 0.5)) < 1e-6
     Z = rng.standard_normal((600, 70)).astype(np.float32)
     V = rng.standard_normal((600, 33)).astype(np.float32)
     Zt, Vt = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(V).to(gpu_device)
-    ref = orc.mvm(Z, Z, V, 0.01, 0.1)
+    ref = omvm(Z, Z, V, 0.01, 0.1)
     assert _rel(ops.mvm_sym(Zt, Vt, 0.01, 0.1).cpu().numpy(), ref) < 1e-5
     op = AdditiveRPOperator(Zt, None, torch.tensor(0.7, device=gpu_device), 1.0 / 70)
-    assert _rel(op._matmul(Vt, noise=0.1).cpu().numpy(), orc.mvm(Z, Z, V, 0.01, 0.1)) < 1e-5      # J > 64: direct kernel
+    assert _rel(op._matmul(Vt, noise=0.1).cpu().numpy(), omvm(Z, Z, V, 0.01, 0.1)) < 1e-5      # J > 64: direct kernel
     assert op._prep is not None and not op._prep.fast_ok
     zero = torch.zeros(600, 2, device=gpu_device)
     assert float(ops.mvm_sym(Zt, zero, 0.01, 0.1).abs().max()) == 0.0

@@ -169,3 +169,12 @@ def test_c_oracle_matches_reference_golden_and_numpy_oracle():
     finally:
         orc.BIG_PAIR_TERMS = big
     np.testing.assert_allclose(K_c, K_np, rtol=1e-13, atol=1e-14)
+    # the C form of the derivative's d/dZ (tests/test_parity_gpu.py at the C2 / C3 sizes) against the reference-pinned GAM
+    # backward: x1 == x2, grad_output = L R^T (memory_efficient_gam_kernel.py:53-58), and against oracle.bilinear_grad
+    n, J, T = 137, 7, 4
+    Zs, L, R = rng.standard_normal((n, J)), rng.standard_normal((n, T)), rng.standard_normal((n, T))
+    W = L @ R.T
+    g1, g2, _ = orc.gam_backward(Zs, Zs, np.ones(J), W)
+    gz_c = cmvm.bilinear_gz(Zs, W + W.T, 1.0)
+    np.testing.assert_allclose(gz_c, g1 + g2, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(cmvm.bilinear_gz(Zs, W + W.T, 0.37), orc.bilinear_grad(Zs, L, R, 0.37)[0], rtol=1e-10, atol=1e-12)

@@ -8,7 +8,9 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import cmvm
 from oracle import dense_gp as orc
+from tests.oracle_fast import okernel
 
 pytestmark = pytest.mark.gpu
 
@@ -112,8 +114,7 @@ def test_fused_mvm_and_derivative_at_c2_c3_shapes(gpu_device, name, N, d):
     assert _rel(Zt.cpu().numpy(), Zo) < 2e-6
     scale, noise = 0.9 / J, 0.2
     Zh = Zt.double().cpu().numpy()                         # oracle on the SAME projected inputs
-    K = orc.additive_rbf(Zh, Zh)
-    K *= scale
+    K = okernel(Zh, Zh, scale)                             # (the C / OpenMP restatement of the oracle at these sizes)
     ref = K @ V.double().numpy() + noise * V.double().numpy()
     Vt = V.to(gpu_device)
     prep = ops.Prepared(Zt)
@@ -137,12 +138,6 @@ def test_fused_mvm_and_derivative_at_c2_c3_shapes(gpu_device, name, N, d):
     gs_ref = (W * K).sum() / scale
     S = W + W.T
     del W
-    gz_ref = np.zeros_like(Zh)
-    for j in range(J):
-        dj = Zh[:, j:j + 1] - Zh[:, j:j + 1].T
-        e = np.exp(-0.5 * dj * dj)
-        e *= S
-        e *= dj
-        gz_ref[:, j] = -scale * e.sum(axis=1)
+    gz_ref = cmvm.bilinear_gz(Zh, S, scale)                # -scale sum_i' S_ii' (z_ij - z_i'j) exp(-(z_ij - z_i'j)^2 / 2)
     assert _rel(gZ.double().cpu().numpy(), gz_ref) < 2e-5
     assert abs(float(gs) - gs_ref) < 2e-5 * abs(gs_ref) + 1e-4

@@ -601,7 +601,7 @@ def _step_times(device):
         def run(n):
             for _ in range(n):
                 opt.zero_grad()
-                loss = -mll(model(X), y)
+                loss = mll.negative(model(X), y)
                 loss.backward()
                 opt.step()
                 loss.item()

@@ -3017,10 +3017,12 @@ int mvm_common(const float *Z1, const float *Z2, const float *V, float *out, int
 // Does the hand-scheduled kernel (rpgp_fact_asm.hip) serve this call?  The whole J = 20 operator, ONE right-hand side, two
 // rows per lane, and the rotation direction its LDS image assumes; RPGP_FACT_ASM=0 keeps the compiler-scheduled kernel
 // (read per launch: A/B pairs alternate inside one process).
-inline bool fact_asm_applies(const TilePlan &p, int T, int J, int j0, int j1) {
+inline bool fact_asm_enabled() {
   const char *env_asm = getenv("RPGP_FACT_ASM");
-  if (env_asm && atoi(env_asm) == 0) return false;
-  return p.R == 2 && T == 1 && J == 20 && j0 == 0 && j1 == 20 && g_rotdir == 1;
+  return !(env_asm && atoi(env_asm) == 0);
+}
+inline bool fact_asm_applies(const TilePlan &p, int T, int J, int j0, int j1) {
+  return fact_asm_enabled() && p.R == 2 && T == 1 && J == 20 && j0 == 0 && j1 == 20 && g_rotdir == 1;
 }
 
 // ---- prepared (factorised) path -----------------------------------------------------------------
@@ -3032,6 +3034,12 @@ int launch_mvm_fact(const TilePlan &p, const float2v *rowdat, const float2v *col
     if (tcnt == 1 && fact_asm_applies(p, 1, J, j0, j0 + 20))
       return rpgp_internal::launch_mvm_fact_asm(rowdat, coldat, V, slabR, slabT, N, ldv, t0, p.chunk_cols, p.taper, accumulate,
                                                 p.w0, p.w1 - p.w0, p.rb0, p.row0, p.rows, st);
+  }
+  if constexpr (TT == 1 && JT >= 2 && JT <= 10) {
+    // J-slices (the ranks of north_star's J-split; J = d models): the same generated loop with fewer quads per record
+    if (tcnt == 1 && fact_asm_enabled() && p.R == 2 && g_rotdir == 1 && rpgp_internal::fact_asm_thin_supported(JT))
+      return rpgp_internal::launch_mvm_fact_asm_thin(JT, rowdat, coldat, V, slabR, slabT, N, J, j0, ldv, t0, p.chunk_cols,
+                                                     p.taper, accumulate, p.w0, p.w1 - p.w0, p.rb0, p.row0, p.rows, st);
   }
   if (p.R == 2)
     hipLaunchKernelGGL((mvm_fact_kernel<JT, TT, 2>), grid, block, 0, st, rowdat, coldat, V, slabR, slabT, N, J, ldv,

@@ -33,7 +33,7 @@ def run(name, N, d, J, ntest, steps, space_proj, cg_tol, eval_tol, ski=False, fu
             torch.cuda.synchronize(); t0 = time.perf_counter()
             lcg.stats["iterations"] = 0
             opt.zero_grad()
-            loss = -mll(model(Xtr), ytr)
+            loss = mll.negative(model(Xtr), ytr)
             loss.backward()
             opt.step()
             torch.cuda.synchronize()

@@ -23,9 +23,9 @@ opt = make_optimizer(torch.optim.Adam, [p for p in model.parameters() if p.requi
 with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
     model.train()
     for it in range(warm):
-        opt.zero_grad(); loss = -mll(model(X), y); loss.backward(); opt.step()
+        opt.zero_grad(); loss = mll.negative(model(X), y); loss.backward(); opt.step()
     torch.cuda.synchronize(); t0 = time.perf_counter(); b = time.time_ns()
     for it in range(steps):
-        opt.zero_grad(); loss = -mll(model(X), y); loss.backward(); opt.step()
+        opt.zero_grad(); loss = mll.negative(model(X), y); loss.backward(); opt.step()
     torch.cuda.synchronize(); t1 = time.perf_counter(); e = time.time_ns()
 print(json.dumps({"shape": shape, "steps": steps, "warm": warm, "step_ms": (t1 - t0) / steps * 1e3, "t_begin_ns": b, "t_end_ns": e}))

@@ -233,12 +233,14 @@ def main():
         if world == 1 or mode == "pairs":
             # (the hand-scheduled kernel serves a rank's share of the tile pairs as it serves the whole sweep)
             kid = lib.rpgp_prepared_kernel_id(N, J, T)
-            return {1: "mvm_fact_asm_kernel"}.get(kid, "mvm_fact_kernel<%d,%d,2>" % (J, tt))
+            return {1: "mvm_fact_asm_kernel", 2: "mvm_fact_asm_thin_kernel<%d>" % J}.get(kid, "mvm_fact_kernel<%d,%d,2>" % (J, tt))
         pieces, left = [], shard.j1 - shard.j0         # greedy pieces of this rank's slice (kJPieces, csrc/rpgp_kernels.hip)
         while left > 0:
             pieces.append(next(q for q in (20, 10, 8, 5, 4, 3, 2, 1) if q <= left))
             left -= pieces[-1]
-        return " + ".join("mvm_fact_kernel<%d,%d,2>" % (q, tt) for q in pieces) + " (rank 0's J-slice)"
+        # (a piece of 2 / 3 / 4 / 5 / 8 / 10 projections runs the hand-scheduled loop generated for that width)
+        return " + ".join("mvm_fact_asm_thin_kernel<%d>" % q if lib.rpgp_prepared_kernel_id(N, q, T) == 2 else
+                          "mvm_fact_kernel<%d,%d,2>" % (q, tt) for q in pieces) + " (rank 0's J-slice)"
 
     primary = run_split(args.shard if world > 1 else "single")
     other = None

@@ -610,8 +610,9 @@ int rpgp_profile_end(float *avg_ms_host, int *count_host);
 
 /* Which kernel `rpgp_mvm_sym_prepared` launches for a single-GPU N x N operator with J projections and T right-hand sides on
  * THIS process' settings (benchmark / profile labelling only; no reference counterpart — GPyTorch has one `_matmul`):
- *   0 = mvm_fact_kernel (compiler-scheduled), 1 = mvm_fact_asm_kernel (hand-scheduled loop, rpgp_fact_asm.hip).
- *   Negative: RPGP_EINVAL. */
+ *   0 = mvm_fact_kernel (compiler-scheduled), 1 = mvm_fact_asm_kernel (hand-scheduled loop, rpgp_fact_asm.hip),
+ *   2 = mvm_fact_asm_thin_kernel<J> (the same schedule generated for a sweep of exactly J = 2 / 3 / 4 / 5 / 8 / 10 projections:
+ *   a rank's slice under the J-split, or a model with that many projections).  Negative: RPGP_EINVAL. */
 int rpgp_prepared_kernel_id(int64_t N, int J, int T);
 
 /*

@@ -3485,7 +3485,10 @@ int rpgp_prepared_kernel_id(int64_t N, int J, int T) {
   if (N <= 0 || J <= 0 || T <= 0) return -RPGP_EINVAL;
   if (rpgp_init()) return -RPGP_EINVAL;
   const TilePlan p = make_plan(N, N, true, T);
-  return fact_asm_applies(p, T, J, 0, J) ? 1 : 0;
+  if (fact_asm_applies(p, T, J, 0, J)) return 1;
+  // a sweep over J projections that is one compiled piece (a rank's J-slice, or a model with that many projections)
+  if (T == 1 && fact_asm_enabled() && p.R == 2 && g_rotdir == 1 && rpgp_internal::fact_asm_thin_supported(J)) return 2;
+  return 0;
 }
 
 int rpgp_profile_begin(void) {

@@ -365,6 +365,10 @@ int rpgp_ski_bilinear_finish(const float *Z, const float *grid_params, const dou
 #define RPGP_KIND_MATERN15 1
 #define RPGP_KIND_IMQ 2
 #define RPGP_KIND_COSINE 3
+/* OR-ed into the `kind` of the rpgp_family_generic_* calls only: a group is the PRODUCT of `group` 1-D sub-kernels
+ * (the ProductKernel groups of polynomial_projection_kernels.py:70-86) instead of one radial group-dimensional sub-kernel
+ * (training_routines.py:172-174).  The two are the same function for the RBF. */
+#define RPGP_KIND_PRODUCT 16
 typedef struct rpgp_family {
   int kind, group, ncomp;
   const float *weights;
@@ -390,7 +394,8 @@ int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *
 /* The same family with RUNTIME (kind, group) in float32 or float64 (csrc/rpgp_family_generic.hip) — what the templated
  * kernels above do not instantiate: `--double` (training_routines.py:481) for every member, k > 1 sub-kernels of the
  * non-RBF types in the RADIAL form `additive_rp` builds (training_routines.py:172-174: kernel(active_dims = a group of k
- * columns); imq_kernel.py:8-9), any group size <= 32 (ncomp * group <= 64).  `dtype`: RPGP_F32 / RPGP_F64 selects the element
+ * columns); imq_kernel.py:8-9) or, with `kind | RPGP_KIND_PRODUCT`, in the PRODUCT-of-1-D form of the rp_poly kinds
+ * (polynomial_projection_kernels.py:70-86), any group size <= 32 (ncomp * group <= 64).  `dtype`: RPGP_F32 / RPGP_F64 selects the element
  * type of EVERY pointer argument (weights, Z, V, L, R, S, outputs).  Parity path: lane-owns-row, library transcendental
  * functions, one writer per output (bitwise reproducible).
  *   mvm:      out (M x T) = scale * K(Z1, Z2) V (+ noise V when Z2 == NULL: the symmetric operator on Z1, M == N); T <= 16

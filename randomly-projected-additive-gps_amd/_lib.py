@@ -163,6 +163,7 @@ class RpgpFamily(ctypes.Structure):
 RPGP_OP_FUSED, RPGP_OP_FUSED_PREPARED, RPGP_OP_SKI, RPGP_OP_DENSE, RPGP_OP_FAMILY, RPGP_OP_SYMCACHE = 0, 1, 2, 3, 4, 5
 RPGP_OP_SUM = 6
 RPGP_KIND_RBF, RPGP_KIND_MATERN15, RPGP_KIND_IMQ, RPGP_KIND_COSINE = 0, 1, 2, 3
+RPGP_KIND_PRODUCT = 16
 RPGP_SYMCACHE_THIN, RPGP_SYMCACHE_WIDE = 0, 1
 RPGP_PIVCHOL_SCRATCH = 2048
 RPGP_F32, RPGP_F64 = 0, 1

@@ -1,5 +1,8 @@
 // rpgp_family_generic.hip — the generalised additive family with RUNTIME (kind, group) in float32 and float64:
 //     K[i,i'] = scale * sum_c w[c] * phi_kind( r_c ),   r_c^2 = sum_{m < group} (Z[i][c group + m] - Z'[i'][c group + m])^2
+// or, with RPGP_KIND_PRODUCT set in `kind`, the PRODUCT of 1-D sub-kernels over the group (the ProductKernel groups of
+// polynomial_projection_kernels.py:70-86; for the RBF the two forms are the same function):
+//     K[i,i'] = scale * sum_c w[c] * prod_{m < group} phi_kind( (Z[i][c group + m] - Z'[i'][c group + m])^2 )
 // What it serves (everything the templated fast kernels of rpgp_kernels.hip do not instantiate):
 //   * `--double` (training_routines.py:481) for every family member — Matern / InverseMQ / Cosine sub-kernels, k > 1 RBF
 //     sub-kernels, the per-component weights of the rp_poly / strictly_additive / additive kinds;
@@ -64,15 +67,27 @@ __device__ __forceinline__ void phi_eval(int kind, F r2, F &phi, F &dphi2) {
 template <typename F>
 __device__ __forceinline__ F pair_value(int kind, int group, int ncomp, const F *__restrict__ w, const F *__restrict__ a,
                                         const F *__restrict__ b) {
+  const bool product = (kind & RPGP_KIND_PRODUCT) != 0;
+  kind &= 3;
   F acc = 0;
   for (int c = 0; c < ncomp; ++c) {
-    F r2 = 0;
-    for (int m = 0; m < group; ++m) {
-      const F d = a[c * group + m] - b[c * group + m];
-      r2 += d * d;
-    }
     F phi, dp;
-    phi_eval<F>(kind, r2, phi, dp);
+    if (product) {
+      F pr = 1;
+      for (int m = 0; m < group; ++m) {
+        const F d = a[c * group + m] - b[c * group + m];
+        phi_eval<F>(kind, d * d, phi, dp);
+        pr *= phi;
+      }
+      phi = pr;
+    } else {
+      F r2 = 0;
+      for (int m = 0; m < group; ++m) {
+        const F d = a[c * group + m] - b[c * group + m];
+        r2 += d * d;
+      }
+      phi_eval<F>(kind, r2, phi, dp);
+    }
     acc += w[c] * phi;
   }
   return acc;
@@ -175,6 +190,8 @@ __global__ __launch_bounds__(kRows) void famg_bilinear_kernel(int kind, int grou
     ri[t] = (!DENSE && valid && t < T) ? Rm[row * T + t] : (F)0;
   }
   const F w = weights[comp];
+  const bool product = (kind & RPGP_KIND_PRODUCT) != 0 && group > 1;
+  kind &= 3;
   F accC = 0;
   for (long long c0 = 0; c0 < N; c0 += kTile) {
     __syncthreads();
@@ -208,11 +225,37 @@ __global__ __launch_bounds__(kRows) void famg_bilinear_kernel(int kind, int grou
         r2 += dd[m] * dd[m];
       }
       F phi, dp;
-      phi_eval<F>(kind, r2, phi, dp);
-      accC += Sv * phi;
-      const F f = Sv * (F)2 * dp;
+      if (product) {
+        // d/dz_m of prod_m phi(d_m^2) = 2 dphi2(d_m^2) d_m * (the product of the OTHER factors): prefix times suffix
+        // products (no division: a factor may be zero — the cosine has roots)
+        F ph[kMaxGroup], dq[kMaxGroup];
+        F pre = 1;
 #pragma unroll
-      for (int m = 0; m < kMaxGroup; ++m) g[m] += f * dd[m];
+        for (int m = 0; m < kMaxGroup; ++m) {
+          ph[m] = 1;
+          dq[m] = 0;
+          if (m < group) {
+            phi_eval<F>(kind, dd[m] * dd[m], ph[m], dp);
+            dq[m] = pre * (F)2 * dp * dd[m];        // prefix product * own derivative
+            pre *= ph[m];
+          }
+        }
+        accC += Sv * pre;
+        F suf = 1;
+#pragma unroll
+        for (int m = kMaxGroup - 1; m >= 0; --m) {
+          if (m < group) {
+            g[m] += Sv * dq[m] * suf;
+            suf *= ph[m];
+          }
+        }
+      } else {
+        phi_eval<F>(kind, r2, phi, dp);
+        accC += Sv * phi;
+        const F f = Sv * (F)2 * dp;
+#pragma unroll
+        for (int m = 0; m < kMaxGroup; ++m) g[m] += f * dd[m];
+      }
     }
   }
   if (valid) {
@@ -247,7 +290,7 @@ int ensure_lds(K kernel, size_t bytes) {
 }
 
 bool bad_family(int kind, int group, int ncomp) {
-  return kind < RPGP_KIND_RBF || kind > RPGP_KIND_COSINE || group < 1 || group > kMaxGroup || ncomp < 1 ||
+  return kind < 0 || (kind & ~(3 | RPGP_KIND_PRODUCT)) != 0 || group < 1 || group > kMaxGroup || ncomp < 1 ||
          (long long)group * ncomp > kMaxCols;
 }
 

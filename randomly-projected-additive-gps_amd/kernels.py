@@ -255,8 +255,8 @@ class GeneralizedProjectionKernel(Kernel):
         k(x, x') = sum_c s_c prod_{m in group c} k1((p_m(x) - p_m(x')) / l_m)
     with one base-kernel type, a projection module, equally sized multiplicative groups (`component_degrees`), one
     lengthscale per projected dimension and one output scale per additive component (trainable iff `weighted`,
-    :88-98).  For the RBF the product over a group is the group's multi-dimensional RBF; for the other base kernels
-    only 1-D groups are built.  `forward` returns operators.FamilyAdditiveOperator."""
+    :88-98).  For the RBF the product over a group is the group's multi-dimensional RBF; for the other base kernels it is
+    the product form of the runtime-(kind, group) kernels.  `forward` returns operators.FamilyAdditiveOperator."""
 
     def __init__(self, component_degrees, d, kernel_type, projection_module, learn_proj=False, weighted=False,
                  ski=False, ski_options=None, X=None, **kernel_kwargs):
@@ -273,8 +273,10 @@ class GeneralizedProjectionKernel(Kernel):
         self.grid_rule = dict(ski_options or {}).get("grid_rule", "reference")
         if kernel_type not in ("RBF", "Matern", "InverseMQ", "Cosine"):
             raise ValueError("Unknown kernel type")
-        if max(degrees) > 1 and kernel_type != "RBF":
-            raise NotImplementedError("products of non-RBF sub-kernels are not built")
+        # a group of degree k is the ProductKernel of k 1-D sub-kernels (polynomial_projection_kernels.py:70-86); for the RBF that
+        # is the group's k-dimensional RBF (the tile kernels), for the other kinds the product form of the runtime-(kind,
+        # group) kernels (csrc/rpgp_family_generic.hip, RPGP_KIND_PRODUCT)
+        self.product = max(degrees) > 1 and kernel_type != "RBF"
         self.component_degrees = degrees
         # k: the common group size, or None for mixed sizes (general_rp_poly / multi_additive -> MixedGroupOperator)
         self.J, self.k, self.d = len(degrees), (degrees[0] if len(set(degrees)) == 1 else None), d
@@ -328,9 +330,9 @@ class GeneralizedProjectionKernel(Kernel):
         if self.k is None or (self.kernel_type == "RBF" and padded_group_size(self.k) != self.k):
             # mixed group sizes, or one size the tile kernels are not instantiated for (padded with zero columns there)
             return MixedGroupOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
-                                      kind=self.kernel_type, degrees=self.component_degrees)
+                                      kind=self.kernel_type, degrees=self.component_degrees, product=self.product)
         return FamilyAdditiveOperator(z1, z2, outputscale=outputscale, comp_weights=self.outputscales,
-                                      kind=self.kernel_type, group=self.k)
+                                      kind=self.kernel_type, group=self.k, product=self.product)
 
 
 class PolynomialProjectionKernel(GeneralizedProjectionKernel):

@@ -744,9 +744,12 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
     Z is already divided by the lengthscales.  Same fused tile kernels with a different kernel-function policy
     (rpgp_family_*); runs replicated (no J-sharding), fp32 only."""
 
-    def __init__(self, Z1, Z2=None, outputscale=None, comp_weights=None, kind="RBF", group=1):
+    def __init__(self, Z1, Z2=None, outputscale=None, comp_weights=None, kind="RBF", group=1, product=False):
         super().__init__(Z1, Z2, outputscale, 1.0, shard=None)
         self.kind, self.group = kind, int(group)
+        # a k > 1 group as the PRODUCT of its 1-D sub-kernels (polynomial_projection_kernels.py:70-86) instead of the radial
+        # k-dimensional sub-kernel of `additive_rp` (training_routines.py:172-174); one and the same for the RBF
+        self.product = bool(product) and self.group > 1 and kind != "RBF"
         if Z1.shape[1] % self.group:
             raise ValueError("the number of columns must be a multiple of the sub-kernel dimension")
         ncomp = Z1.shape[1] // self.group
@@ -757,7 +760,8 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
         # kernels (csrc/rpgp_family_generic.hip), as it does k > 1 sub-kernels of the non-RBF types
         wdt = torch.float64 if Z1.dtype == torch.float64 else torch.float32
         w = comp_weights.detach().to(device=Z1.device, dtype=wdt).reshape(-1).contiguous()
-        self.fam = _backend.get_backend().make_family(kind, self.group, w)
+        self.fam = _backend.get_backend().make_family(kind, self.group, w, self.product) if self.product else \
+            _backend.get_backend().make_family(kind, self.group, w)
         self._generic = bool(getattr(self.fam, "generic", False))
         self._wsum = float(w.sum())                 # one host sync per construction (= per optimiser step)
 
@@ -796,7 +800,7 @@ class FamilyAdditiveOperator(AdditiveRPOperator):
     def _transpose_nonbatch(self):
         if self.symmetric:
             return self
-        return FamilyAdditiveOperator(self.Z2, self.Z1, self.outputscale, self.comp_weights, self.kind, self.group)
+        return FamilyAdditiveOperator(self.Z2, self.Z1, self.outputscale, self.comp_weights, self.kind, self.group, self.product)
 
     def _diagonal(self):
         if not self.symmetric:
@@ -860,9 +864,10 @@ class MixedGroupOperator(AdditiveRPOperator):
     product; sums, diagonals, rows and derivatives are assembled here.  Runs replicated, fp32; solves in the native mBCG
     executor as an RPGP_OP_SUM of the buckets."""
 
-    def __init__(self, Z1, Z2=None, outputscale=None, comp_weights=None, kind="RBF", degrees=(1,)):
+    def __init__(self, Z1, Z2=None, outputscale=None, comp_weights=None, kind="RBF", degrees=(1,), product=False):
         super().__init__(Z1, Z2, outputscale, 1.0, shard=None)
         self.kind = kind
+        self.product = bool(product)
         self.degrees = [int(dg) for dg in degrees]
         if sum(self.degrees) != Z1.shape[1]:
             raise ValueError("the group sizes must add up to the number of columns")
@@ -890,7 +895,7 @@ class MixedGroupOperator(AdditiveRPOperator):
             co = torch.as_tensor(cols, dtype=torch.long, device=Z1.device)
             z1 = gather(Z1, co, k, kp, len(comps))
             z2 = None if Z2 is None else gather(Z2, co, k, kp, len(comps))
-            part = FamilyAdditiveOperator(z1, z2, outputscale, comp_weights.detach().index_select(0, ci), kind, kp)
+            part = FamilyAdditiveOperator(z1, z2, outputscale, comp_weights.detach().index_select(0, ci), kind, kp, product)
             part._true_group = k
             self.buckets.append((ci, co, part))
         self._wsum = sum(part._wsum for _, _, part in self.buckets)
@@ -929,7 +934,7 @@ class MixedGroupOperator(AdditiveRPOperator):
     def _transpose_nonbatch(self):
         if self.symmetric:
             return self
-        return MixedGroupOperator(self.Z2, self.Z1, self.outputscale, self.comp_weights, self.kind, self.degrees)
+        return MixedGroupOperator(self.Z2, self.Z1, self.outputscale, self.comp_weights, self.kind, self.degrees, self.product)
 
     def _diagonal(self):
         if not self.symmetric:

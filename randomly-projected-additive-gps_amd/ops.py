@@ -920,12 +920,15 @@ class Family:
     """`struct rpgp_family`: kind (name of training_routines.py:47-88 or RPGP_KIND_*), group size, per-component
     weights (device tensor, kept alive here).  `generic`: served by the runtime-(kind, group) kernels of
     csrc/rpgp_family_generic.hip instead of the templated fast kernels — float64 weights (`--double`), k > 1 sub-kernels of
-    the non-RBF types (radial form), group sizes that are not instantiated."""
+    the non-RBF types, group sizes that are not instantiated.  `product`: a k > 1 group is the product of k 1-D sub-kernels
+    (the ProductKernel groups of polynomial_projection_kernels.py:70-86) instead of one radial k-dimensional sub-kernel
+    (training_routines.py:172-174); the same function for the RBF, so the flag only changes the other kinds."""
 
-    def __init__(self, kind, group, weights):
+    def __init__(self, kind, group, weights, product=False):
         import ctypes
         self.kind = KINDS[kind] if isinstance(kind, str) else int(kind)
         self.group = int(group)
+        self.product = bool(product) and self.group > 1 and self.kind != _lib.RPGP_KIND_RBF
         w = weights.detach().reshape(-1)
         self.dtype = torch.float64 if w.dtype == torch.float64 else torch.float32
         if not w.is_cuda:
@@ -943,6 +946,8 @@ class Family:
         else:
             self.struct = self.ref = None
         self.code = _lib.RPGP_F64 if self.dtype == torch.float64 else _lib.RPGP_F32
+        # what the runtime-(kind, group) entry points take as `kind`
+        self.generic_kind = self.kind | (_lib.RPGP_KIND_PRODUCT if self.product else 0)
 
     @property
     def ncols(self):
@@ -979,7 +984,7 @@ def _generic_mvm(fam, Z1, Z2, V, scale, noise):
         for t0 in range(0, V2.shape[1], 16):
             Vc = V2[:, t0:t0 + 16].contiguous()
             oc = torch.empty((M, Vc.shape[1]), dtype=fam.dtype, device=Z1.device)
-            _lib.check(lib.rpgp_family_generic_mvm(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(), Z1.data_ptr(),
+            _lib.check(lib.rpgp_family_generic_mvm(fam.code, fam.generic_kind, fam.group, fam.ncomp, fam.weights.data_ptr(), Z1.data_ptr(),
                                                    None if Z2 is None else Z2.data_ptr(), Vc.data_ptr(), oc.data_ptr(), M, N, J, J,
                                                    Vc.shape[1], float(scale), float(noise), _stream()),
                        "rpgp_family_generic_mvm")
@@ -1034,7 +1039,7 @@ def family_dense(fam, Z1, Z2, scale):
     out = torch.empty((M, N), dtype=fam.dtype, device=Z1.device)
     with _on(Z1.device):
         if fam.generic:
-            _lib.check(lib.rpgp_family_generic_dense(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
+            _lib.check(lib.rpgp_family_generic_dense(fam.code, fam.generic_kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
                                                      Z1.data_ptr(), Z2.data_ptr(), out.data_ptr(), M, N, J, J, N, float(scale),
                                                      _stream()), "rpgp_family_generic_dense")
         else:
@@ -1052,7 +1057,7 @@ def _generic_bilinear(fam, Z, L, R, S, scale):
         ws = _workspace(Z.device, lib.rpgp_family_generic_bilinear_workspace_bytes(fam.code, N, fam.ncomp))
         if S is not None:
             S = S.to(fam.dtype).contiguous()
-            _lib.check(lib.rpgp_family_generic_bilinear(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
+            _lib.check(lib.rpgp_family_generic_bilinear(fam.code, fam.generic_kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
                                                         Z.data_ptr(), None, None, S.data_ptr(), gZ.data_ptr(), gc.data_ptr(), N, J,
                                                         J, 0, N, float(scale), ws.data_ptr(), ws.numel(), _stream()),
                        "rpgp_family_generic_bilinear")
@@ -1060,7 +1065,7 @@ def _generic_bilinear(fam, Z, L, R, S, scale):
         gZp, gcp = torch.empty_like(gZ), torch.empty_like(gc)
         for t0 in range(0, L.shape[1], 16):      # the derivative is additive over the columns of L, R
             Lc, Rc = L[:, t0:t0 + 16].contiguous(), R[:, t0:t0 + 16].contiguous()
-            _lib.check(lib.rpgp_family_generic_bilinear(fam.code, fam.kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
+            _lib.check(lib.rpgp_family_generic_bilinear(fam.code, fam.generic_kind, fam.group, fam.ncomp, fam.weights.data_ptr(),
                                                         Z.data_ptr(), Lc.data_ptr(), Rc.data_ptr(), None, gZp.data_ptr(),
                                                         gcp.data_ptr(), N, J, J, Lc.shape[1], 0, float(scale), ws.data_ptr(),
                                                         ws.numel(), _stream()), "rpgp_family_generic_bilinear")

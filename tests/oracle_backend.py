@@ -117,34 +117,35 @@ class OracleBackend:
 
     # ---- generalised family ----------------------------------------------------------------------------------
     class _Fam:
-        def __init__(self, kind, group, weights):
+        def __init__(self, kind, group, weights, product=False):
             self.kind, self.group, self.w = kind, int(group), _np(weights).reshape(-1)
             self.ncomp = self.w.size
+            self.product = bool(product) and self.group > 1 and kind != "RBF"
 
-    def make_family(self, kind, group, weights):
-        return OracleBackend._Fam(kind, group, weights)
+    def make_family(self, kind, group, weights, product=False):
+        return OracleBackend._Fam(kind, group, weights, product)
 
     def family_mvm_sym(self, fam, Z, V, scale, noise=0.0):
         squeeze = V.dim() == 1
         v = _np(V).reshape(Z.shape[0], -1)
-        r = _t(fmo.mvm(_np(Z), _np(Z), v, fam.kind, fam.group, fam.w, scale, noise), V)
+        r = _t(fmo.mvm(_np(Z), _np(Z), v, fam.kind, fam.group, fam.w, scale, noise, fam.product), V)
         return r.squeeze(1) if squeeze else r
 
     def family_mvm_rect(self, fam, Z1, Z2, V, scale):
         squeeze = V.dim() == 1
         v = _np(V).reshape(Z2.shape[0], -1)
-        r = _t(fmo.mvm(_np(Z1), _np(Z2), v, fam.kind, fam.group, fam.w, scale), V)
+        r = _t(fmo.mvm(_np(Z1), _np(Z2), v, fam.kind, fam.group, fam.w, scale, 0.0, fam.product), V)
         return r.squeeze(1) if squeeze else r
 
     def family_dense(self, fam, Z1, Z2, scale):
-        return _t(fmo.kernel_matrix(_np(Z1), _np(Z2), fam.kind, fam.group, fam.w, scale), Z1)
+        return _t(fmo.kernel_matrix(_np(Z1), _np(Z2), fam.kind, fam.group, fam.w, scale, fam.product), Z1)
 
     def family_bilinear_grad(self, fam, Z, L, R, scale):
-        g, gc = fmo.bilinear_grad(_np(Z), _np(L), _np(R), fam.kind, fam.group, fam.w, scale)
+        g, gc = fmo.bilinear_grad(_np(Z), _np(L), _np(R), fam.kind, fam.group, fam.w, scale, fam.product)
         return _t(g, Z), _t(gc, Z)
 
     def family_bilinear_grad_dense(self, fam, Z, S, scale):
-        g, gc = fmo.bilinear_grad_dense(_np(Z), _np(S), fam.kind, fam.group, fam.w, scale)
+        g, gc = fmo.bilinear_grad_dense(_np(Z), _np(S), fam.kind, fam.group, fam.w, scale, fam.product)
         return _t(g, Z), _t(gc, Z)
 
     # ---- Woodbury preconditioner pieces (rpgp_gram_f64 / rpgp_woodbury_apply) ---------------------------------

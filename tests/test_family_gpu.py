@@ -115,7 +115,10 @@ def test_family_errors(gpu_device):
 # what the templated kernels do not instantiate: float64 members, radial k > 1 groups of the non-RBF types, other group sizes
 GENERIC = [("Matern", 2, 6, "f32"), ("InverseMQ", 3, 9, "f32"), ("Cosine", 2, 4, "f32"), ("RBF", 6, 12, "f32"),
            ("RBF", 1, 20, "f64"), ("Matern", 1, 7, "f64"), ("InverseMQ", 4, 8, "f64"), ("Cosine", 1, 5, "f64"),
-           ("RBF", 20, 20, "f64")]
+           ("RBF", 20, 20, "f64"),
+           # the PRODUCT-of-1-D form of a group (RPGP_KIND_PRODUCT: the ProductKernel groups of the rp_poly kinds)
+           ("Matern*", 2, 6, "f32"), ("InverseMQ*", 3, 9, "f32"), ("Cosine*", 2, 4, "f64"), ("Matern*", 5, 10, "f64"),
+           ("InverseMQ*", 32, 32, "f64")]
 
 
 @pytest.mark.parametrize("kind,group,cols,prec", GENERIC)
@@ -131,27 +134,29 @@ def test_generic_family_kernels_match_oracle(gpu_device, kind, group, cols, prec
     sz = 0.5 if group >= 8 else 1.0
     Z, Z1 = (rng.normal(size=(N, cols)) * sz).astype(npdt), (rng.normal(size=(M, cols)) * sz).astype(npdt)
     w = rng.uniform(0.3, 1.2, size=cols // group).astype(npdt)
-    fam = ops.Family(kind, group, torch.from_numpy(w).to(gpu_device))
-    assert fam.generic and fam.dtype == dt
+    product = kind.endswith("*")
+    kind = kind.rstrip("*")
+    fam = ops.Family(kind, group, torch.from_numpy(w).to(gpu_device), product=product)
+    assert fam.generic and fam.dtype == dt and fam.product == product
     Zt, Z1t = torch.from_numpy(Z).to(gpu_device), torch.from_numpy(Z1).to(gpu_device)
     for T in (1, 11, 19):
         V = rng.normal(size=(N, T)).astype(npdt)
         Vt = torch.from_numpy(V).to(gpu_device)
         got = ops.family_mvm_sym(fam, Zt, Vt, 0.7, 0.13)
         assert got.dtype == dt and torch.equal(got, ops.family_mvm_sym(fam, Zt, Vt, 0.7, 0.13))
-        assert _rel(got.cpu().numpy(), fmo.mvm(Z, Z, V, kind, group, w, 0.7, 0.13)) < tol
+        assert _rel(got.cpu().numpy(), fmo.mvm(Z, Z, V, kind, group, w, 0.7, 0.13, product)) < tol
         got_r = ops.family_mvm_rect(fam, Z1t, Zt, Vt, 0.7).cpu().numpy()
-        assert _rel(got_r, fmo.mvm(Z1, Z, V, kind, group, w, 0.7)) < tol
+        assert _rel(got_r, fmo.mvm(Z1, Z, V, kind, group, w, 0.7, 0.0, product)) < tol
     Kd = ops.family_dense(fam, Z1t, Zt, 1.3).cpu().numpy()
-    assert np.abs(Kd - fmo.kernel_matrix(Z1, Z, kind, group, w, 1.3)).max() < tol * 10
+    assert np.abs(Kd - fmo.kernel_matrix(Z1, Z, kind, group, w, 1.3, product)).max() < tol * 10
     L, R = rng.normal(size=(N, 3)).astype(npdt), rng.normal(size=(N, 3)).astype(npdt)
     gZ, gc = ops.family_bilinear_grad(fam, Zt, torch.from_numpy(L).to(gpu_device), torch.from_numpy(R).to(gpu_device), 1.3)
-    rZ, rc = fmo.bilinear_grad(Z.astype(np.float64), L, R, kind, group, w, 1.3)
+    rZ, rc = fmo.bilinear_grad(Z.astype(np.float64), L, R, kind, group, w, 1.3, product)
     assert _rel(gZ.cpu().numpy(), rZ) < tol * 2 and _rel(gc.cpu().numpy(), rc) < tol * 2
     S = rng.normal(size=(N, N)).astype(npdt)
     S = (S + S.T) / 2
     gZ2, gc2 = ops.family_bilinear_grad_dense(fam, Zt, torch.from_numpy(S).to(gpu_device), 1.3)
-    rZ2, rc2 = fmo.bilinear_grad_dense(Z.astype(np.float64), S, kind, group, w, 1.3)
+    rZ2, rc2 = fmo.bilinear_grad_dense(Z.astype(np.float64), S, kind, group, w, 1.3, product)
     assert _rel(gZ2.cpu().numpy(), rZ2) < tol * 2 and _rel(gc2.cpu().numpy(), rc2) < tol * 2
 
 
@@ -163,6 +168,7 @@ def test_generic_family_kernels_match_oracle(gpu_device, kind, group, cols, prec
     ("additive_rp", dict(J=3, k=2, batch_kernel=False, kernel_type="Matern", prescale=True)),   # radial non-RBF groups
     ("rp_poly", dict(J=8, k=1, weighted=True, kernel_type="RBF")),
     ("strictly_additive", dict(weighted=True, kernel_type="InverseMQ")),
+    ("rp_poly", dict(J=3, k=2, weighted=True, kernel_type="Matern")),                   # products of non-RBF sub-kernels
 ])
 @pytest.mark.parametrize("regime", ["chol", "cg"])
 def test_family_model_mll_and_prediction(gpu_device, kind, model_kwargs, regime):
@@ -200,9 +206,10 @@ def test_family_model_mll_and_prediction(gpu_device, kind, model_kwargs, regime)
         tr = lambda A: ((A.double() @ P) / ls).numpy()
         ktype, group = base.kernel_type, base.k
         w = base.outputscales.detach().double().cpu().numpy()
+    product = bool(getattr(base, "product", False))
     s, noise, c = float(model.covar_module.outputscale), float(lik.noise), float(model.mean_module.constant)
     Z, Zs = tr(X), tr(Xs)
-    K = fmo.kernel_matrix(Z, Z, ktype, group, w, s) + noise * np.eye(N)
+    K = fmo.kernel_matrix(Z, Z, ktype, group, w, s, product) + noise * np.eye(N)
     r = y.double().numpy() - c
     alpha = np.linalg.solve(K, r)
     ref_mll = (-0.5 * r @ alpha - 0.5 * np.linalg.slogdet(K)[1] - 0.5 * N * math.log(2 * math.pi)
@@ -221,9 +228,9 @@ def test_family_model_mll_and_prediction(gpu_device, kind, model_kwargs, regime)
         model.eval()
         with torch.no_grad():
             out = model(Xs.to(gpu_device))
-        Ks = fmo.kernel_matrix(Zs, Z, ktype, group, w, s)
+        Ks = fmo.kernel_matrix(Zs, Z, ktype, group, w, s, product)
         mean = Ks @ alpha + c
-        cov = fmo.kernel_matrix(Zs, Zs, ktype, group, w, s) - Ks @ np.linalg.solve(K, Ks.T)
+        cov = fmo.kernel_matrix(Zs, Zs, ktype, group, w, s, product) - Ks @ np.linalg.solve(K, Ks.T)
         assert _rel(out.mean.cpu().numpy(), mean) < 1e-4
         assert np.abs(out.variance.cpu().numpy() - np.diag(cov)).max() < 1e-4 * s + 1e-5
 

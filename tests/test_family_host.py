@@ -23,15 +23,22 @@ def _phi_t(kind, d2):
     return torch.cos(math.pi * r)
 
 
-def _dense_family(Z, kind, group, w):
-    """`group`: the common group size, or the list of group sizes (in column order) for mixed sizes."""
+def _dense_family(Z, kind, group, w, product=False):
+    """`group`: the common group size, or the list of group sizes (in column order) for mixed sizes.  `product`: a group is
+    the product of its 1-D sub-kernels (the rp_poly kinds) instead of one radial sub-kernel (additive_rp)."""
     n = Z.shape[0]
     K = torch.zeros(n, n, dtype=torch.float64)
     sizes = [group] * (Z.shape[1] // group) if isinstance(group, int) else list(group)
     col = 0
     for c, k in enumerate(sizes):
-        d2 = sum((Z[:, col + m:col + m + 1] - Z[:, col + m:col + m + 1].t()) ** 2 for m in range(k))
-        K = K + w[c] * _phi_t(kind, d2)
+        sq = [(Z[:, col + m:col + m + 1] - Z[:, col + m:col + m + 1].t()) ** 2 for m in range(k)]
+        if product:
+            comp = torch.ones(n, n, dtype=torch.float64)
+            for q in sq:
+                comp = comp * _phi_t(kind, q)
+        else:
+            comp = _phi_t(kind, sum(sq))
+        K = K + w[c] * comp
         col += k
     return K
 
@@ -52,6 +59,28 @@ def test_family_oracle_pinned_to_rbf_oracle_and_reference_formulas():
     # group's Euclidean distance, not the product of 1-D kernels
     r = np.sqrt(((Z1[:, None, :2] - Z2[None, :, :2]) ** 2).sum(-1))
     assert np.allclose(fmo.component_matrices(Z1, Z2, "Matern", 2)[0], (1 + np.sqrt(3) * r) * np.exp(-np.sqrt(3) * r))
+    # ... unless `product`: the ProductKernel groups of the rp_poly kinds (polynomial_projection_kernels.py:70-86)
+    for kind in ("Matern", "InverseMQ", "Cosine", "RBF"):
+        c1 = fmo.component_matrices(Z1, Z2, kind, 1)
+        c3 = fmo.component_matrices(Z1, Z2, kind, 3, product=True)
+        assert np.allclose(c3[1], c1[3] * c1[4] * c1[5], atol=1e-15)
+    # the product form's derivative against central differences of its own kernel matrix
+    Zs = rng.normal(size=(9, 4))
+    S = rng.normal(size=(9, 9))
+    S = S + S.T
+    w = np.array([0.4, 1.1])
+    for kind in ("Matern", "InverseMQ", "Cosine"):
+        gZ, gc = fmo.bilinear_grad_dense(Zs, S, kind, 2, w, 0.9, product=True)
+        comps = fmo.component_matrices(Zs, Zs, kind, 2, product=True)
+        assert np.allclose(gc, [0.5 * (S * c).sum() for c in comps])
+        num = np.zeros_like(Zs)
+        for i in range(9):
+            for j in range(4):
+                e = np.zeros_like(Zs)
+                e[i, j] = 1e-6
+                f = lambda Zq: 0.5 * (S * fmo.kernel_matrix(Zq, Zq, kind, 2, w, 0.9, product=True)).sum()
+                num[i, j] = (f(Zs + e) - f(Zs - e)) / 2e-6
+        assert np.allclose(gZ, num, rtol=1e-5, atol=1e-7), kind
 
 
 def _problem(n=60, d=5, seed=0):
@@ -82,6 +111,10 @@ def _problem(n=60, d=5, seed=0):
     ("general_rp_poly", dict(degrees=[2, 1], weighted=False, learn_proj=False)),
     ("general_rp_poly", dict(degrees=[6, 1, 6], weighted=True, learn_proj=False)),           # 6 is padded to the 8-wide kernel
     ("rp_poly", dict(J=2, k=7, weighted=True, kernel_type="RBF")),                           # equal sizes, padded as well
+    ("rp_poly", dict(J=3, k=2, weighted=True, kernel_type="Matern")),                        # products of non-RBF sub-kernels
+    ("rp_poly", dict(J=2, k=3, weighted=False, kernel_type="InverseMQ")),
+    ("general_rp_poly", dict(degrees=[1, 2, 1, 3], weighted=True, learn_proj=False, kernel_type="Matern")),
+    ("general_rp_poly", dict(degrees=[2, 1], weighted=True, learn_proj=False, kernel_type="Cosine")),
 ])
 def test_family_mll_and_gradients_match_dense_autograd(oracle_backend, kind, model_kwargs):
     from rpgp_amd.training import create_exact_gp
@@ -129,7 +162,8 @@ def test_family_mll_and_gradients_match_dense_autograd(oracle_backend, kind, mod
         group, ktype = (base.k if base.k is not None else base.component_degrees), base.kernel_type
         w = F.softplus(raw_w)
     n = X.shape[0]
-    Kh = F.softplus(raw_s) * _dense_family(Z, ktype, group, w) + (F.softplus(raw_n) + 1e-4) * torch.eye(n, dtype=torch.float64)
+    Kh = F.softplus(raw_s) * _dense_family(Z, ktype, group, w, product=bool(getattr(base, "product", False))) + \
+        (F.softplus(raw_n) + 1e-4) * torch.eye(n, dtype=torch.float64)
     r = yd - c
     obj = (-0.5 * r @ torch.linalg.solve(Kh, r) - 0.5 * torch.logdet(Kh) - 0.5 * n * math.log(2 * math.pi)) / n
     # the noise-prior term comes from the model's own code on both sides; its gradient w.r.t. raw_noise is not compared
@@ -197,8 +231,9 @@ def test_family_validation_errors():
     with pytest.raises(ValueError):
         create_rp_poly_kernel(6, 1, 3, activation="relu")
     X, y = _problem(20, 4)
-    with pytest.raises(NotImplementedError):
-        create_exact_gp(X, y, "general_rp_poly", noise_prior=False, degrees=[1, 2], kernel_type="Matern")
+    # products of non-RBF sub-kernels (the ProductKernel groups of the rp_poly kinds): served since round 6
+    m, _ = create_exact_gp(X, y, "general_rp_poly", noise_prior=False, degrees=[1, 2], kernel_type="Matern")
+    assert m.covar_module.base_kernel.product
     with pytest.raises(NotImplementedError):
         create_exact_gp(X, y, "deep_rp_poly", noise_prior=False)
     with pytest.raises(ValueError):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RPGP_ABI_VERSION 3
+#define RPGP_ABI_VERSION 4
 
 #define RPGP_EINVAL     10001 /* bad argument (shape, range, null pointer) */
 #define RPGP_EWORKSPACE 10002 /* workspace too small: call the matching *_workspace_bytes */
@@ -164,7 +164,7 @@ int rpgp_bilinear_grad_dense(const float *Z, const float *S, float *gZ, float *g
  * device scratch.  J, rank <= 64.  The family variant takes weight_sum = sum_c weights[c] (the kernel's diagonal is
  * scale * weight_sum).
  */
-#define RPGP_PIVCHOL_SCRATCH 2048
+#define RPGP_PIVCHOL_SCRATCH 8192
 int rpgp_pivoted_cholesky(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int J, int rank,
                           float scale, void *stream);
 
@@ -273,8 +273,13 @@ int rpgp_ski_scatter_planned(const void *plan, const float *V, double *hist, int
                              size_t workspace_bytes, void *stream);
 int rpgp_ski_gather_fast(const void *plan, const float *Z, const float *grid_params, const float *H, const float *V, float *out,
                          int64_t M, int ldz, int J, int G, int T, float scale, float noise, void *stream);
-/* Pivoted Cholesky of the SKI operator (same contract as rpgp_pivoted_cholesky; diag_work: N + RPGP_PIVCHOL_SCRATCH). */
-int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
+/* Pivoted Cholesky of the SKI operator (same contract as rpgp_pivoted_cholesky).  diag_work: DEVICE scratch of
+ * rpgp_ski_pivoted_cholesky_work_floats(N, rank) floats — the residual diagonal, the argmax partials and, from N = 65 536 on,
+ * the factor in column-major order while it is built (step m then reads m coalesced vectors instead of every line of the
+ * N x rank array); RPGP_EWORKSPACE if smaller. */
+size_t rpgp_ski_pivoted_cholesky_work_floats(int64_t N, int rank);
+int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, size_t diag_work_floats,
+                              int64_t N, int ldz,
                               int J, int G, int rank, float scale, void *stream);
 int rpgp_ski_diag(const float *Z, const float *grid_params, float *diag, int64_t N, int ldz, int J, int G,
                   float scale, void *stream);

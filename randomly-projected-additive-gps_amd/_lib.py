@@ -66,7 +66,8 @@ SIGNATURES = {
     "rpgp_ski_mvm_planned": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp, _sz, _vp]),
     "rpgp_ski_scatter_planned": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
     "rpgp_ski_gather_fast": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp]),
-    "rpgp_ski_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp]),
+    "rpgp_ski_pivoted_cholesky_work_floats": (_sz, [_i64, _int]),
+    "rpgp_ski_pivoted_cholesky": (_int, [_vp, _vp, _vp, _vp, _sz, _i64, _int, _int, _int, _int, _f32, _vp]),
     "rpgp_ski_dense": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _i64, _int, _int, _f32, _vp]),
     "rpgp_ski_diag": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _f32, _vp]),
     "rpgp_ski_bilinear_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _f32, _vp, _sz,
@@ -165,10 +166,10 @@ RPGP_OP_SUM = 6
 RPGP_KIND_RBF, RPGP_KIND_MATERN15, RPGP_KIND_IMQ, RPGP_KIND_COSINE = 0, 1, 2, 3
 RPGP_KIND_PRODUCT = 16
 RPGP_SYMCACHE_THIN, RPGP_SYMCACHE_WIDE = 0, 1
-RPGP_PIVCHOL_SCRATCH = 2048
+RPGP_PIVCHOL_SCRATCH = 8192
 RPGP_F32, RPGP_F64 = 0, 1
 RPGP_SHARD_NONE, RPGP_SHARD_PARTIAL, RPGP_SHARD_ROWS = 0, 1, 2
-RPGP_ABI_VERSION = 3
+RPGP_ABI_VERSION = 4
 RPGP_COMM_HANDLE_BYTES = 64
 # int (*rpgp_allreduce_fn)(void *ctx, void *buf, size_t count, int dtype, void *stream)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)

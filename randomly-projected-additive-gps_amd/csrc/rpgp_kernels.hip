@@ -2523,7 +2523,11 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
                                                            int *__restrict__ pidx_out, int nparts, int N, int ldz,
                                                            int ncols, int k, int m, float scale, float d0, int kind,
                                                            int group, int ncomp, const float *__restrict__ wts,
-                                                           const float *__restrict__ gp, int G, int const_diag = 0) {
+                                                           const float *__restrict__ gp, int G, int const_diag = 0,
+                                                           float *__restrict__ Lt = nullptr) {
+  // Lt (rank x N, optional): the factor is kept COLUMN-major while it is built — a row of the N x k factor is 4 k bytes, so
+  // the correction sum below reads every 64-byte line of it whatever m is and the new column is one 4-byte store per line;
+  // column-major, step m reads m coalesced vectors and writes one.  L is then written once at the end (pivchol_untranspose).
   __shared__ float sval[4];
   __shared__ int sidx[4];
   __shared__ float szp[64];
@@ -2563,7 +2567,8 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
       for (int q = 0; q < 4; ++q) spw[threadIdx.x][q] = w[q];
     }
   }
-  if ((int)threadIdx.x < m) slp[threadIdx.x] = L[(size_t)piv * k + threadIdx.x];
+  if ((int)threadIdx.x < m)
+    slp[threadIdx.x] = Lt ? Lt[(size_t)threadIdx.x * N + piv] : L[(size_t)piv * k + threadIdx.x];
   __syncthreads();
   const float inv_sq = ok ? 1.0f / sqrtf(dp) : 0.f;
   bv = -1.f;
@@ -2598,10 +2603,15 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
         row = scale * pivchol_entry(Z + (size_t)i * ldz, szp, kind, group, ncomp, wts);
       }
       float corr = 0.f;
-      for (int q = 0; q < m; ++q) corr = __builtin_fmaf(L[(size_t)i * k + q], slp[q], corr);
+      if (Lt) {
+        for (int q = 0; q < m; ++q) corr = __builtin_fmaf(Lt[(size_t)q * N + i], slp[q], corr);
+      } else {
+        for (int q = 0; q < m; ++q) corr = __builtin_fmaf(L[(size_t)i * k + q], slp[q], corr);
+      }
       l = (row - corr) * inv_sq;
     }
-    L[(size_t)i * k + m] = l;
+    if (Lt) Lt[(size_t)m * N + i] = l;
+    else L[(size_t)i * k + m] = l;
     float nd = (const_diag ? d0 : dwork[i]) - l * l;
     nd = nd < 0.f ? 0.f : nd;
     nd = (i == piv) ? 0.f : nd;
@@ -2613,6 +2623,31 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
   if (threadIdx.x == 0) {
     pval_out[blockIdx.x] = bv;
     pidx_out[blockIdx.x] = bi;
+  }
+}
+
+// L (N x k, row-major) from the column-major scratch the steps filled: a workgroup owns 256 consecutive rows, reads 16
+// coalesced vectors at a time into LDS and writes them as 64-byte runs of its rows.
+__global__ __launch_bounds__(256) void pivchol_untranspose_kernel(const float *__restrict__ Lt, float *__restrict__ L, int N,
+                                                                  int k) {
+  __shared__ float tile[16 * 257];
+  const int r0 = blockIdx.x * 256;
+  const int rows = (N - r0 < 256) ? N - r0 : 256;
+  const int i = r0 + threadIdx.x;
+  const int ic = i < N ? i : N - 1;
+  for (int q0 = 0; q0 < k; q0 += 16) {
+    const int cw = (k - q0 < 16) ? k - q0 : 16;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = Lt[(size_t)(q0 + (q < cw ? q : cw - 1)) * N + ic];       // 16 loads in flight
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[q * 257 + threadIdx.x] = v[q];
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * cw; e += 256) {
+      const int r = e / cw, q = e - r * cw;
+      L[(size_t)(r0 + r) * k + q0 + q] = tile[q * 257 + r];
+    }
   }
 }
 
@@ -3974,7 +4009,7 @@ int rpgp_family_bilinear_grad_dense(const rpgp_family *fam, const float *Z, cons
 // diag_work: N + kPivcholScratch floats (residual diagonal + argmax partials of the multi-workgroup form)
 static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N, int ldz, int ncols, int rank,
                           float scale, float d0, int kind, int group, int ncomp, const float *wts, void *stream,
-                          const float *gp = nullptr, int G = 0) {
+                          const float *gp = nullptr, int G = 0, float *Lt = nullptr) {
   hipStream_t st = as_stream(stream);
   if (N <= 2048 && kind == RPGP_KIND_RBF && group == 1 && !wts && !gp) {      // launch-latency regime: one workgroup
     hipLaunchKernelGGL(pivchol_kernel, dim3(1), dim3(1024), 0, st, Z, L, diag_work, (int)N, ldz, ncols, rank, scale);
@@ -3983,9 +4018,13 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
   // (all greedy steps as ONE cooperative launch with grid barriers was built in round 5 and measured no faster than the
   //  per-step launches — a grid barrier ~8 us against a 1.5 - 2 us launch boundary: tools/experiments/r6_removed_forms.patch)
   int nb = (int)((N + 255) / 256);
-  if (nb > 512) nb = 512;
-  float *pval[2] = {diag_work + N, diag_work + N + 512};
-  int *pidx[2] = {reinterpret_cast<int *>(diag_work + N + 1024), reinterpret_cast<int *>(diag_work + N + 1536)};
+  // up to 2 048 workgroups: one row per thread up to N = 524 288.  (A cap of 512 made a thread of the C5 operator walk three
+  // rows one after the other at two waves per SIMD — a chain of dependent global round trips per row, 14 us per step with
+  // nothing to read from the factor yet.)
+  constexpr int kMaxParts = RPGP_PIVCHOL_SCRATCH / 4;
+  if (nb > kMaxParts) nb = kMaxParts;
+  float *pval[2] = {diag_work + N, diag_work + N + kMaxParts};
+  int *pidx[2] = {reinterpret_cast<int *>(diag_work + N + 2 * kMaxParts), reinterpret_cast<int *>(diag_work + N + 3 * kMaxParts)};
   if (gp) {    // SKI: the residual diagonal starts at diag(K_ski), which depends on the point
     const int drc = rpgp_ski_diag(Z, gp, diag_work, N, ldz, ncols, G, scale, stream);       // (rpgp_ski_base.hip)
     if (drc) return drc;
@@ -3995,7 +4034,7 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
   // the flagship operator's fast per-step kernel (own-row operands requested before the pivot is known); every other operator,
   // wide coordinate rows and ranks beyond 16 take the general per-step kernel
   const bool fast = kind == RPGP_KIND_RBF && group == 1 && !wts && !gp && ncols <= 32 &&
-                    rank <= 16 && (long long)nb * 256 >= N;
+                    rank <= 16 && N <= 131072;
   for (int m = 0; fast && m < rank; ++m)
     hipLaunchKernelGGL(pivchol_step_fast_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
                        pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, m == 0 ? 1 : 0);
@@ -4003,8 +4042,10 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
   for (int m = 0; m < rank; ++m) {
     hipLaunchKernelGGL(pivchol_step_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
                        pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, kind, group,
-                       ncomp, wts, gp, G, (m == 0 && !gp) ? 1 : 0);
+                       ncomp, wts, gp, G, (m == 0 && !gp) ? 1 : 0, Lt);
   }
+  if (Lt)
+    hipLaunchKernelGGL(pivchol_untranspose_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, Lt, L, (int)N, rank);
   return launch_status();
 }
 
@@ -4015,13 +4056,23 @@ int rpgp_pivoted_cholesky(const float *Z, float *L, float *diag_work, int64_t N,
   return pivchol_common(Z, L, diag_work, N, ldz, J, rank, scale, scale * (float)J, RPGP_KIND_RBF, 1, J, nullptr, stream);
 }
 
-int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, int64_t N, int ldz,
-                              int J, int G, int rank, float scale, void *stream) {
+// the SKI factor is built column-major from this size on (below it the factor sits in L2 and the row-major form is as fast)
+static const int64_t kPivcholColumnMajorMin = 65536;
+
+size_t rpgp_ski_pivoted_cholesky_work_floats(int64_t N, int rank) {
+  if (N <= 0 || rank <= 0) return 0;
+  return (size_t)N + RPGP_PIVCHOL_SCRATCH + (N >= kPivcholColumnMajorMin ? (size_t)N * (size_t)rank : 0);
+}
+
+int rpgp_ski_pivoted_cholesky(const float *Z, const float *grid_params, float *L, float *diag_work, size_t diag_work_floats,
+                              int64_t N, int ldz, int J, int G, int rank, float scale, void *stream) {
   if (!Z || !grid_params || !L || !diag_work || N <= 0 || J <= 0 || J > 64 || G < 8 || rank <= 0 || rank > 64 ||
       ldz < J || N > 0x7fffffffLL)
     return RPGP_EINVAL;
+  if (diag_work_floats < rpgp_ski_pivoted_cholesky_work_floats(N, rank)) return RPGP_EWORKSPACE;
+  float *Lt = N >= kPivcholColumnMajorMin ? diag_work + N + RPGP_PIVCHOL_SCRATCH : nullptr;
   return pivchol_common(Z, L, diag_work, N, ldz, J, rank, scale, scale * (float)J, RPGP_KIND_RBF, 1, J, nullptr, stream,
-                        grid_params, G);
+                        grid_params, G, Lt);
 }
 
 int rpgp_family_pivoted_cholesky(const rpgp_family *fam, const float *Z, float *L, float *diag_work, int64_t N,

@@ -655,9 +655,10 @@ def ski_pivoted_cholesky(Z, gp, scale, rank, grid_size=1024):
     Z = _require(Z, "Z", 2)
     N, J = Z.shape
     L = torch.empty((N, rank), dtype=torch.float32, device=Z.device)
-    work = torch.empty(N + _lib.RPGP_PIVCHOL_SCRATCH, dtype=torch.float32, device=Z.device)
+    # (residual diagonal + argmax partials and, for large N, the factor in column-major order while it is built)
+    work = torch.empty(lib.rpgp_ski_pivoted_cholesky_work_floats(N, int(rank)), dtype=torch.float32, device=Z.device)
     with _on(Z.device):
-        _lib.check(lib.rpgp_ski_pivoted_cholesky(Z.data_ptr(), gp.data_ptr(), L.data_ptr(), work.data_ptr(), N, J, J,
+        _lib.check(lib.rpgp_ski_pivoted_cholesky(Z.data_ptr(), gp.data_ptr(), L.data_ptr(), work.data_ptr(), work.numel(), N, J, J,
                                                  int(grid_size), int(rank), float(scale), _stream()),
                    "rpgp_ski_pivoted_cholesky")
     return L

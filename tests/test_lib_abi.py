@@ -24,7 +24,7 @@ def test_header_symbols_are_bound_and_exported():
         assert hasattr(lib, name), "librpgp.so does not export %s" % name
         assert name in _lib.SIGNATURES, "ctypes binding missing for %s" % name
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.rpgp_version() == 3
+    assert lib.rpgp_version() == 4
     assert b"invalid argument" in lib.rpgp_error_string(10001)
 
 

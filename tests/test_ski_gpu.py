@@ -211,10 +211,11 @@ def test_ski_mll_matches_exact_operator_on_gpu(gpu_device):
         assert abs(res[(ski, False)][2] - res[(ski, True)][2]) < 2e-2 * abs(res[(ski, True)][2])
 
 
-@pytest.mark.parametrize("N,J,G", [(3000, 3, 256), (20000, 20, 1024)])
+@pytest.mark.parametrize("N,J,G", [(3000, 3, 256), (20000, 20, 1024), (70001, 3, 512)])
 def test_ski_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, G):
     """rpgp_ski_pivoted_cholesky (one chip-wide launch per greedy step, entries from the interpolation weights and the
-    Toeplitz lags) against the generic row-by-row version that asks the operator for rows."""
+    Toeplitz lags) against the generic row-by-row version that asks the operator for rows.  From N = 65 536 on the factor is
+    built column-major in the scratch and written out once (the 70 001-row case: ragged last workgroup)."""
     from rpgp_amd.operators import SKIAdditiveOperator
     from rpgp_amd.precond import pivoted_cholesky
     rng = np.random.default_rng(N)
@@ -223,6 +224,13 @@ def test_ski_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, G):
     Lf = op.fused_pivoted_cholesky(10)
     Lg = pivoted_cholesky(op._diagonal(), op._get_rows, 10)
     assert Lf is not None and torch.allclose(Lf, Lg, rtol=2e-3, atol=3e-4)
+    assert torch.equal(Lf, op.fused_pivoted_cholesky(10))
+    from rpgp_amd import ops, _lib
+    lib = _lib.load()
+    assert lib.rpgp_ski_pivoted_cholesky_work_floats(N, 10) == N + _lib.RPGP_PIVCHOL_SCRATCH + (10 * N if N >= 65536 else 0)
+    small = torch.empty(N + _lib.RPGP_PIVCHOL_SCRATCH - 1, device=gpu_device)
+    assert lib.rpgp_ski_pivoted_cholesky(Z.data_ptr(), op.gp.data_ptr(), Lf.data_ptr(), small.data_ptr(), small.numel(), N, J, J,
+                                         G, 10, 0.9, None) == _lib.RPGP_EWORKSPACE
 
 
 @pytest.mark.parametrize("N,J,T,G", [(2500, 5, 3, 256), (3000, 20, 11, 1024)])

@@ -579,7 +579,7 @@ def _step_times(device):
     """Median time of one optimiser step (`-mll(model(X), y)`, backward, Adam, `loss.item()` — fitting/optimizing.py:65-76) of the
     additive RP model at the C2 / C3 / C5 shapes on synthetic data, 3 rounds of 20 steps each after 8 untimed ones."""
     import numpy as np
-    from rpgp_amd import settings
+    from rpgp_amd import fused_mll, settings
     from rpgp_amd.training import create_exact_gp, make_optimizer
     from rpgp_amd.models import ExactMarginalLogLikelihood
     out = {"what": "ms per step: preconditioned mBCG on [10 probes | y - c] at cg_tolerance 0.05, SLQ log-det, fused derivative, "
@@ -606,7 +606,7 @@ def _step_times(device):
                 loss = mll.negative(model(X), y)
                 loss.backward()
                 opt.step()
-                loss.item()
+                fused_mll.loss_value(loss)          # (the training loop's per-step read of the loss: training.train_to_convergence)
         ts = []
         with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
             model.train()

@@ -512,7 +512,11 @@ int rpgp_slq_logdet(const float *alpha_hist, const float *beta_hist, int iters, 
  *   rpgp_mbcg_solve normalises every column itself and returns Khat^-1 of the columns as given.
  * rpgp_step_value: inv_quad = sum_i full_rhs[i][col] solves[i][col] (N x T blocks);  out2[0] = (inv_quad + logdet) c1 + c2,
  *   out2[1] = inv_quad.  The workspace's first 4 bytes are an arrival counter: ZERO on entry (zero the buffer once), zero
- *   again on exit; it must not be shared between streams.
+ *   again on exit; it must not be shared between streams.  `ticket_out` (optional): the kernel also POSTS out2[0] to pinned
+ *   host memory and *ticket_out names the slot (-1: none); rpgp_step_value_wait(ticket, &v) returns that value on the calling
+ *   thread as soon as the kernel has run — the training loop's per-step `loss.item()` (fitting/optimizing.py:76) without
+ *   waiting for the derivative and the optimiser update queued behind it.  RPGP_EINVAL: the ticket is older than 16 posts, from
+ *   another thread, or the value has not arrived within 2 s (read out2[0] the ordinary way then).
  * rpgp_step_lr: the two sides of the bilinear derivative from the solve of [probes | r] (solves: N x (p + 1)):
  *   left = [solves_c gq / p | -gq alpha], right = [pre_probes (row stride ldp) | alpha], gq = g[0] * gscale (g: device scalar, the
  *   incoming gradient); partials[2 b], partials[2 b + 1] = workgroup b's sum(left * right), sum(alpha); *nparts_out workgroups.
@@ -527,7 +531,8 @@ int rpgp_step_probes(const float *L, int k, const float *e1, const float *e2, fl
                      const float *mean_dev, int64_t N, int p, float *full_rhs, void *stream);
 size_t rpgp_step_value_workspace_bytes(void);
 int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T, int col, double logdet, double c1, double c2,
-                    float *out2, void *workspace, size_t workspace_bytes, void *stream);
+                    float *out2, void *workspace, size_t workspace_bytes, int *ticket_out, void *stream);
+int rpgp_step_value_wait(int ticket, float *value_host);
 size_t rpgp_step_lr_workspace_bytes(void);
 int rpgp_step_lr(const float *solves, const float *pre_probes, int64_t ldp, const float *g, float gscale, int64_t N, int p,
                  float *left, float *right, float *partials, int *nparts_out, void *stream);

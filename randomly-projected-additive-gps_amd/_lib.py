@@ -110,7 +110,8 @@ SIGNATURES = {
     "rpgp_step_hyper": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rpgp_step_probes": (_int, [_vp, _int, _vp, _vp, _f32, _vp, _vp, _i64, _int, _vp, _vp]),
     "rpgp_step_value_workspace_bytes": (_sz, []),
-    "rpgp_step_value": (_int, [_vp, _vp, _i64, _int, _int, _f64, _f64, _f64, _vp, _vp, _sz, _vp]),
+    "rpgp_step_value": (_int, [_vp, _vp, _i64, _int, _int, _f64, _f64, _f64, _vp, _vp, _sz, _vp, _vp]),
+    "rpgp_step_value_wait": (_int, [_int, _vp]),
     "rpgp_step_lr_workspace_bytes": (_sz, []),
     "rpgp_step_lr": (_int, [_vp, _vp, _i64, _vp, _f32, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "rpgp_step_hyper_backward": (_int, [_vp, _vp, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _int, _vp, _f32, _f32, _f32, _vp,

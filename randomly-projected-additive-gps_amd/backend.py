@@ -56,6 +56,7 @@ class HipBackend:
     step_hyper = staticmethod(ops.step_hyper)
     step_probes = staticmethod(ops.step_probes)
     step_value = staticmethod(ops.step_value)
+    step_value_wait = staticmethod(ops.step_value_wait)
     step_lr = staticmethod(ops.step_lr)
     step_hyper_backward = staticmethod(ops.step_hyper_backward)
 

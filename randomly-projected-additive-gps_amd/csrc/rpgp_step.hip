@@ -43,6 +43,31 @@ struct HyperHost {
 };
 thread_local HyperHost g_hyper;
 
+// pinned ring of the objective's posted values (rpgp_step_value with a ticket): slot = {value, stamp}.  The training loop reads
+// the loss of EVERY step on the host (fitting/optimizing.py:76 `loss.item()`): a device-to-host copy there waits for the whole
+// step — derivative and optimiser update included — although the value exists since the end of the forward pass.  The kernel
+// that forms it posts it here as well, and the host picks it up when it wants it without touching the stream.
+constexpr int kValueSlots = 16;
+struct ValueHost {
+  float *host = nullptr, *dev = nullptr;       // kValueSlots x {value, stamp}
+  float issued[kValueSlots] = {0.f};           // the stamp of the latest ticket of each slot
+  int next = 0;
+  float counter = 0.f;
+  bool ok = false;
+  int init() {
+    if (ok) return 0;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), kValueSlots * 2 * sizeof(float),
+                                 hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < 2 * kValueSlots; ++i) host[i] = 0.f;
+    e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0);
+    if (e != hipSuccess) return (int)e;
+    ok = true;
+    return 0;
+  }
+};
+thread_local ValueHost g_value;
+
 // ---- hyper-parameters -> what the step needs ---------------------------------------------------------------------------------
 // dev_out: [0] outputscale  [1] noise  [2] mean  [3] sigmoid(raw_os)  [4] sigmoid(raw_noise)  [8 ..) ls[n_ls]  then sigmoid(raw_ls)[n_ls]
 // Peff[i][j] = W[j][i] / ls[i] (prescale, n_ls = d) | / ls[j] (n_ls = J) | / ls[0] (n_ls = 1)       (W: the Linear weight, J x d)
@@ -125,7 +150,7 @@ constexpr int kValueBlocks = 256;
 __global__ __launch_bounds__(256) void k_step_value(const float *__restrict__ rhs, const float *__restrict__ sol, long long N,
                                                     int T, int col, double logdet, double c1, double c2,
                                                     float *__restrict__ out, unsigned *__restrict__ counter,
-                                                    double *__restrict__ part) {
+                                                    double *__restrict__ part, float *__restrict__ host_slot, float stamp) {
   __shared__ double sh[256];
   double s = 0.0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
@@ -149,8 +174,15 @@ __global__ __launch_bounds__(256) void k_step_value(const float *__restrict__ rh
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       double tot = 0.0;
       for (unsigned q = 0; q < gridDim.x; ++q) tot += part[q];
-      out[0] = (float)((tot + logdet) * c1 + c2);
+      const float val = (float)((tot + logdet) * c1 + c2);
+      out[0] = val;
       out[1] = (float)tot;
+      if (host_slot) {                         // post the value to the host (mapped pinned memory), then the stamp
+        host_slot[0] = val;
+        __threadfence_system();
+        *reinterpret_cast<volatile float *>(host_slot + 1) = stamp;
+        __threadfence_system();
+      }
     }
   }
 }
@@ -303,15 +335,40 @@ int rpgp_step_probes(const float *L, int k, const float *e1, const float *e2, fl
 size_t rpgp_step_value_workspace_bytes(void) { return 256 + (size_t)kValueBlocks * sizeof(double); }
 
 int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T, int col, double logdet, double c1, double c2,
-                    float *out2, void *workspace, size_t workspace_bytes, void *stream) {
+                    float *out2, void *workspace, size_t workspace_bytes, int *ticket_out, void *stream) {
   if (!full_rhs || !solves || !out2 || N < 1 || T < 1 || col < 0 || col >= T) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_step_value_workspace_bytes()) return RPGP_EWORKSPACE;
   long long nb = (N + 1023) / 1024;                  // ~4 rows per thread
   if (nb > kValueBlocks) nb = kValueBlocks;
+  float *slot = nullptr;
+  float stamp = 0.f;
+  if (ticket_out) {
+    *ticket_out = -1;
+    if (g_value.init() == 0) {
+      const int sl = g_value.next;
+      g_value.next = (sl + 1) % kValueSlots;
+      g_value.counter = g_value.counter >= 1.0e6f ? 1.f : g_value.counter + 1.f;
+      stamp = g_value.counter;
+      g_value.issued[sl] = stamp;
+      slot = g_value.dev + 2 * sl;
+      *ticket_out = sl + kValueSlots * (int)stamp;
+    }
+  }
   hipLaunchKernelGGL(k_step_value, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), full_rhs, solves,
                      (long long)N, T, col, logdet, c1, c2, out2, reinterpret_cast<unsigned *>(workspace),
-                     reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + 256));
+                     reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + 256), slot, stamp);
   return (int)hipGetLastError();
+}
+
+int rpgp_step_value_wait(int ticket, float *value_host) {
+  if (ticket < 0 || !value_host || !g_value.ok) return RPGP_EINVAL;
+  const int sl = ticket % kValueSlots;
+  const float stamp = (float)(ticket / kValueSlots);
+  if (g_value.issued[sl] != stamp) return RPGP_EINVAL;        // the slot has been handed to a later call (or another thread's)
+  const volatile float *p = g_value.host + 2 * sl;
+  if (!rpgp_internal::spin_until([p, stamp] { return p[1] == stamp; }, 2000000)) return RPGP_EINVAL;
+  *value_host = p[0];
+  return 0;
 }
 
 size_t rpgp_step_lr_workspace_bytes(void) { return (size_t)kLrBlocks * 2 * sizeof(float); }

@@ -102,10 +102,12 @@ def _native_step_ok(model, target, raw_ls):
 
 class _FusedMLL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target, sign=1.0):
+    def forward(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target, sign=1.0, eager=False):
         # sign = -1: the training LOSS -mll as the node's value (fitting/optimizing.py:70 negates the objective; as a separate
         # tensor operation that is a launch each way plus two autograd nodes per step: exact either way, -(a x + c) = (-a) x - c)
         ctx.sign = sign
+        ctx.eager = None
+        ctx.want_eager = bool(eager)
         if _native_step_ok(model, target, raw_ls):
             done = _FusedMLL._forward_native(ctx, raw_ls, raw_os, raw_noise, mean_c, model, likelihood, target)
             if done is not None:
@@ -186,16 +188,44 @@ class _FusedMLL(torch.autograd.Function):
             lp, dlp = _prior(likelihood, noise_f)
             # mll = (-0.5 (inv_quad + logdet + n log 2 pi) + log p(sigma^2)) / n      (models.ExactMarginalLogLikelihood)
             sign = ctx.sign
-            out = be.step_value(full_rhs, solves, p, logdet, sign * -0.5 / n, sign * (-0.5 * n * LOG2PI + lp) / n)
+            # (the value is also posted to pinned host memory: `loss_value` below reads it without draining the stream)
+            global _posted
+            if hasattr(be, "step_value_wait"):
+                out, ticket = be.step_value(full_rhs, solves, p, logdet, sign * -0.5 / n, sign * (-0.5 * n * LOG2PI + lp) / n,
+                                            post=True)
+                _posted = (out.data_ptr(), ticket)
+            else:
+                out = be.step_value(full_rhs, solves, p, logdet, sign * -0.5 / n, sign * (-0.5 * n * LOG2PI + lp) / n)
         ctx.native = True
         ctx.n, ctx.dlp, ctx.prescale, ctx.zfac = n, dlp, pk.prescale, bk.input_scale_factor()
         ctx.X, ctx.W, ctx.hyp, ctx.op, ctx.pre = X, W, hyp, op, pre
         ctx.solves, ctx.probes = solves, full_rhs[:, :p]          # (solves[:, :p] = Khat^-1 z: the probes were not normalised)
         ctx.shapes = (raw_ls.shape, raw_os.shape, raw_noise.shape, mean_c.shape)
+        if ctx.want_eager:
+            # settings.eager_gradients: the derivative queued right behind the value, with the incoming gradient 1
+            ctx.eager = _FusedMLL._native_grads(ctx, _unit_gradient(X.device))
+            ctx.solves = ctx.probes = ctx.pre_probes = None
         return out[0]
 
     @staticmethod
     def _backward_native(ctx, g):
+        if ctx.eager is not None:
+            # the derivative ran behind the forward pass with g = 1: scale by the real incoming gradient (x * 1.0 = x: the same
+            # bits as the in-kernel form whenever the loss is differentiated directly)
+            grads = list(ctx.eager)
+            gd = g.reshape(()).to(grads[0].dtype)
+            try:
+                scaled = torch._foreach_mul(grads, gd)
+            except (RuntimeError, TypeError):
+                scaled = [t * gd for t in grads]
+            g_ls, g_os, g_nz, g_mu = scaled
+        else:
+            g_ls, g_os, g_nz, g_mu = _FusedMLL._native_grads(ctx, g)
+        s_ls, s_os, s_nz, s_mu = ctx.shapes
+        return g_ls.reshape(s_ls), g_os.reshape(s_os), g_nz.reshape(s_nz), g_mu.reshape(s_mu), None, None, None, None, None
+
+    @staticmethod
+    def _native_grads(ctx, g):
         be = _backend.get_backend()
         n = ctx.n
         with torch.no_grad(), trace_range("rpgp:derivative"):
@@ -217,8 +247,7 @@ class _FusedMLL(torch.autograd.Function):
             g_ls, g_os, g_nz, g_mu = be.step_hyper_backward(dPeff, ctx.W, n_ls, ctx.prescale, ctx.zfac, ctx.hyp,
                                                             gs.reshape(1), part, nparts, g, sign * -0.5 / n,
                                                             sign * ctx.dlp / n, gs_scale=gs_scale)
-        s_ls, s_os, s_nz, s_mu = ctx.shapes
-        return g_ls.reshape(s_ls), g_os.reshape(s_os), g_nz.reshape(s_nz), g_mu.reshape(s_mu), None, None, None, None
+        return g_ls, g_os, g_nz, g_mu
 
     @staticmethod
     def backward(ctx, g):
@@ -246,11 +275,46 @@ class _FusedMLL(torch.autograd.Function):
             g_noise = gn.reshape(()) + g.reshape(()) * (sign * ctx.dlp / n) if ctx.dlp != 0.0 else gn.reshape(())
             g_raw_noise = (g_noise * torch.sigmoid(raw_noise.reshape(()))).reshape(raw_noise.shape)
             g_mean = (-gr.sum()).reshape(1)                         # r = y - c
-        return g_raw_ls, g_raw_os, g_raw_noise, g_mean, None, None, None, None
+        return g_raw_ls, g_raw_os, g_raw_noise, g_mean, None, None, None, None, None
+
+
+_posted = None            # (data pointer of the latest native value, its host ticket): consumed by `evaluate`
+_unit = {}
+
+
+def _unit_gradient(device):
+    t = _unit.get(device)
+    if t is None:
+        t = _unit[device] = torch.ones(1, dtype=torch.float32, device=device)
+    return t
 
 
 def evaluate(model, likelihood, target, negate=False):
     """mll(model(X), y) per datum (ExactMarginalLogLikelihood's value) as one autograd node; `negate`: the loss -mll."""
+    global _posted
     pk = model.covar_module.base_kernel
-    return _FusedMLL.apply(pk.raw_lengthscale, model.covar_module.raw_outputscale, likelihood.raw_noise,
-                           model.mean_module.constant, model, likelihood, target, -1.0 if negate else 1.0)
+    params = (pk.raw_lengthscale, model.covar_module.raw_outputscale, likelihood.raw_noise, model.mean_module.constant)
+    eager = settings.eager_gradients.on() and torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    _posted = None
+    res = _FusedMLL.apply(*params, model, likelihood, target, -1.0 if negate else 1.0, eager)
+    if _posted is not None and _posted[0] == res.data_ptr():
+        try:
+            res._rpgp_ticket = _posted[1]             # read by `loss_value`
+        except Exception:
+            pass
+    _posted = None
+    return res
+
+
+def loss_value(loss):
+    """`loss.item()` of the training loop (fitting/optimizing.py:76).  A value of the fused objective was posted to pinned host
+    memory by the kernel that formed it, at the END OF THE FORWARD pass: reading it there does not wait for the derivative and
+    the optimiser update queued behind it, so the host prepares the next step while they run.  Anything else: `.item()`."""
+    ticket = getattr(loss, "_rpgp_ticket", None)
+    if ticket is not None:
+        be = _backend.get_backend()
+        wait = getattr(be, "step_value_wait", None)
+        v = wait(ticket) if wait is not None else None
+        if v is not None:
+            return v
+    return loss.item()

@@ -1285,8 +1285,10 @@ def step_probes(L, e1, e2, sqrt_noise, y, mean_dev):
 _value_ws = {}
 
 
-def step_value(full_rhs, solves, col, logdet, c1, c2):
-    """out[0] = (sum_i full_rhs[i][col] solves[i][col] + logdet) c1 + c2, out[1] = the inner product: rpgp_step_value."""
+def step_value(full_rhs, solves, col, logdet, c1, c2, post=False):
+    """out[0] = (sum_i full_rhs[i][col] solves[i][col] + logdet) c1 + c2, out[1] = the inner product: rpgp_step_value.
+    `post`: returns (out, ticket) — the kernel also posts out[0] to pinned host memory, `step_value_wait(ticket)` reads it."""
+    import ctypes
     lib = _lib.load()
     N, T = full_rhs.shape
     out = torch.empty(2, dtype=torch.float32, device=full_rhs.device)
@@ -1295,9 +1297,23 @@ def step_value(full_rhs, solves, col, logdet, c1, c2):
     if ws is None:              # (zeroed ONCE: the kernel leaves its arrival counter at zero; one buffer per stream)
         ws = _value_ws[key] = torch.zeros(lib.rpgp_step_value_workspace_bytes(), dtype=torch.uint8, device=full_rhs.device)
     with _on(full_rhs.device):
+        ticket = ctypes.c_int(-1)
         _lib.check(lib.rpgp_step_value(full_rhs.data_ptr(), solves.data_ptr(), N, T, int(col), float(logdet), float(c1), float(c2),
-                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "rpgp_step_value")
-    return out
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), ctypes.byref(ticket) if post else None,
+                                       _stream()), "rpgp_step_value")
+    return (out, ticket.value) if post else out
+
+
+def step_value_wait(ticket):
+    """The value a `step_value(..., post=True)` call posted to the host, or None when the ticket is stale (16 later posts),
+    from another thread, or not there within 2 s — the caller then reads the device tensor."""
+    import ctypes
+    if ticket is None or ticket < 0:
+        return None
+    v = ctypes.c_float(0)
+    if _lib.load().rpgp_step_value_wait(int(ticket), ctypes.byref(v)) != 0:
+        return None
+    return v.value
 
 
 def step_lr(solves, pre_probes, g, gscale):

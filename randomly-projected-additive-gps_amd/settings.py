@@ -120,6 +120,12 @@ fused_training = _setting("fused_training", True, flag=True)
 # the two sides of the derivative, the chain rule back to the raw parameters) as single launches (csrc/rpgp_step.hip) instead of
 # chains of element-wise torch launches: the step is host-bound there.  False = the torch operations (same arithmetic).
 step_kernels = _setting("step_kernels", True, flag=True)
+# ... and the derivative launched from the FORWARD pass (with the incoming gradient 1, scaled by the real one in backward): when
+# the objective is evaluated with gradients enabled, `backward()` follows — fitting/optimizing.py:70-72 — and the autograd
+# engine's start-up (~100 us of host time between the value and the first launch of the derivative) is otherwise idle time of
+# the device in every optimiser step.  False = the derivative is launched by backward() (a forward that is never followed by a
+# backward then does not pay for it).
+eager_gradients = _setting("eager_gradients", True, flag=True)
 # the all-reduce of the sharded multi-GPU solve: "rccl" (torch.distributed, backend nccl = RCCL over xGMI) or "ipc" (one-shot
 # kernel over IPC-mapped peer buffers, csrc/rpgp_comm.hip); the environment variable RPGP_COMM overrides it
 comm_backend = _setting("comm_backend", "rccl")

@@ -17,6 +17,7 @@ from .kernels import (AdditiveStructureRBFKernel, CustomAdditiveKernel, MemoryEf
 from .likelihoods import GaussianLikelihood, SmoothedBoxPrior
 from .models import ExactGPModel, ExactMarginalLogLikelihood
 from .ops import trace_range
+from . import fused_mll
 
 EXACT_GP_KINDS = ("full", "additive_rp", "strictly_additive", "additive", "rp_poly", "general_rp_poly")
 REFERENCE_ONLY_KINDS = ("rp", "deep_rp_poly", "multi_full", "duvenaud_additive", "sgpr")
@@ -284,7 +285,9 @@ def train_to_convergence(model, xs, ys, optimizer=None, lr=0.1, objective=None, 
         # (roctx ranges, live under `rocprofv3 --marker-trace` only: the optimiser's own update is what is left of this range
         #  behind the closure's)
         with trace_range("rpgp:optimiser_step"):
-            loss = optimizer_.step(closure).item()
+            # (`.item()` of the reference's loop; the fused objective posted its value to the host at the end of the forward
+            #  pass, so this does not wait for the derivative and the update behind it)
+            loss = fused_mll.loss_value(optimizer_.step(closure))
         if verbose > 1:
             print("epoch {}, iter {}, loss {}".format(i, 0, loss))
         losses[i] = loss

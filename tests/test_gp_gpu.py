@@ -421,6 +421,71 @@ def test_negated_objective_on_the_step_kernels_is_bitwise_the_negation(gpu_devic
         assert torch.equal(res[True][1][k], res[False][1][k]), k
 
 
+@pytest.mark.parametrize("ski", [False, True])
+def test_eager_gradients_and_posted_loss_are_the_ordinary_ones(gpu_device, ski):
+    """settings.eager_gradients (the derivative launched behind the value in the forward pass, scaled by the incoming gradient in
+    backward) and fused_mll.loss_value (the loss read from the value the kernel posted to pinned host memory): the same bits as
+    the derivative launched by backward() and as loss.item(); a scaled loss scales the gradients; no derivative under no_grad;
+    a stale ticket falls back to the device tensor."""
+    from rpgp_amd import backend, fused_mll, settings
+    from rpgp_amd.training import create_exact_gp
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    gen = torch.Generator().manual_seed(8)
+    N, d, J = 3000, 5, (3 if ski else 10)
+    X = torch.randn(N, d, generator=gen)
+    y = torch.sin(X).sum(1) + 0.1 * torch.randn(N, generator=gen)
+    X, y = X.to(gpu_device), ((y - y.mean()) / y.std()).to(gpu_device)
+    be = backend.get_backend()
+    calls = {"n": 0}
+    orig = be.step_lr
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    res = {}
+    be.step_lr = counted
+    try:
+        for mode in ("eager", "lazy", "eager_x2"):
+            torch.manual_seed(4)
+            np.random.seed(4)
+            model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                         prescale=True, space_proj=True, ski=ski,
+                                         ski_options={"grid_size": 512, "num_dims": 1} if ski else None)
+            model = model.to(gpu_device)
+            mll = ExactMarginalLogLikelihood(lik, model)
+            model.train()
+            with settings.eager_gradients(mode != "lazy"), settings.deterministic_probes(True), settings.cg_tolerance(1e-3):
+                n0 = calls["n"]
+                loss = mll.negative(model(X), y)
+                assert calls["n"] - n0 == (0 if mode == "lazy" else 1)          # the derivative's first launch: in forward or not
+                assert getattr(loss, "_rpgp_ticket", None) is not None
+                host = fused_mll.loss_value(loss)
+                assert host == loss.item()
+                (loss * 2.0 if mode == "eager_x2" else loss).backward()
+                assert calls["n"] - n0 == 1
+                if mode == "eager":
+                    with torch.no_grad():
+                        n1 = calls["n"]
+                        again = mll.negative(model(X), y)
+                        assert calls["n"] == n1 and torch.equal(again, loss.detach())
+                    # seventeen later posts: the first ticket's slot has been handed on, the value still comes back (from the device)
+                    first = loss
+                    with torch.no_grad():
+                        for _ in range(17):
+                            mll.negative(model(X), y)
+                    assert be.step_value_wait(first._rpgp_ticket) is None
+                    assert fused_mll.loss_value(first) == first.item()
+            res[mode] = (loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    finally:
+        del be.step_lr                       # (the instance attribute: the class's staticmethod is back)
+    assert torch.equal(res["eager"][0], res["lazy"][0])
+    assert res["eager"][1].keys() == res["lazy"][1].keys() and len(res["eager"][1]) >= 4
+    for k in res["eager"][1]:
+        assert torch.equal(res["eager"][1][k], res["lazy"][1][k]), k
+        assert torch.allclose(res["eager_x2"][1][k], 2.0 * res["lazy"][1][k], rtol=1e-6, atol=0.0), k
+
+
 def test_blocked_fp16x3_cholesky_factor(gpu_device):
     """precond.blocked_cholesky (round 5): the blocked float32 factorisation with fp16x3 trailing updates that the mixed-precision
     covariance solve and the Cholesky-preconditioned wide CG use beyond N = 16k.  Its factor is as accurate as the library's

@@ -388,7 +388,9 @@ static int woodbury_apply_impl(const float *L, int64_t ldl, const float *R, int6
   if (N == 0) return 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   long long blocks = (N * T + 255) / 256;
-  if (blocks > (Cinv ? 1024 : 8192)) blocks = Cinv ? 1024 : 8192;      // (every workgroup of the fused form pays K^2 T products)
+  // (every workgroup of the fused form pays K^2 T products at its head — 2 250 for the rank-15 preconditioner of a 10-probe
+  //  block, nine per thread; a cap of 1 024 workgroups made a thread of the C5 operator walk 15 elements one round trip at a time)
+  if (blocks > (Cinv ? 4096 : 8192)) blocks = Cinv ? 4096 : 8192;
   hipLaunchKernelGGL(woodbury_apply_kernel, dim3((int)blocks), dim3(256), (size_t)K * T * sizeof(double), st, L,
                      (long long)ldl, R, (long long)ldr, Tm, 1.0 / noise, out, (long long)ldo, (long long)N, K, T, Cinv);
   return (int)hipGetLastError();

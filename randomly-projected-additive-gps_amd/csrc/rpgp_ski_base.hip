@@ -606,17 +606,21 @@ __global__ __launch_bounds__(256) void ski_gather_wide_kernel(const float *__res
 
 // Derivative gather.  H holds Toeplitz-smoothed histograms of the 2T columns [L | R]:
 //   gZ[i][j] = scale * sum_k dw_k(z_ij) * sum_t ( L[i,t] H_R[j][idx+k][t] + R[i,t] H_L[j][idx+k][t] )
-//   rowS[i]  = sum_t L[i,t] * sum_j sum_k w_k H_R[j][idx+k][t]          (= L[i,:] . (K R)[i,:] / scale)
+//   rowS[b]  = sum over workgroup b's rows i of  sum_t L[i,t] * sum_j sum_k w_k H_R[j][idx+k][t]   (= L[i,:] . (K R)[i,:] / scale)
+// (round 6: one partial per WORKGROUP, fixed-order tree — the N per-row values were only ever added up, by one workgroup
+//  walking 391k floats: 34 us at C5)
 template <int TT>
 __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__restrict__ Z, const float *__restrict__ gp,
                                                               const float *__restrict__ H, const float *__restrict__ L,
                                                               const float *__restrict__ Rm, float *__restrict__ gZ,
                                                               float *__restrict__ rowS, long long N, int ldz, int ldg,
                                                               int J, int G, int T, float scale, float *__restrict__ rowC) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
+  __shared__ float ssum[256];
+  const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i0 < N;
+  const long long i = valid ? i0 : N - 1;
   // (loads from clamped indices, slots t >= T masked through li / ri = 0: a load under `t < T` compiles to a branch with its
-  //  own wait — 88 dependent round trips per projection in the loop below, which made this kernel latency-bound: 140 us at C5)
+  //  own wait — 88 dependent round trips per projection in the loop below, which made this kernel latency-bound)
   float li[TT], ri[TT];
 #pragma unroll
   for (int t = 0; t < TT; ++t) {
@@ -627,6 +631,11 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
   }
   float accS = 0.f;
   const int T2 = 2 * T;
+  // The training block (10 probes + the residual: T = 11): a grid row is 22 floats = 88 bytes, 8-byte aligned — eleven 8-byte
+  // loads instead of twenty-two 4-byte ones.  The lanes of a wave sit in 64 different grid rows, so every load instruction is
+  // 64 separate requests to the texture path whatever its width, and that path's request rate is what this kernel runs at
+  // (C5: 391k points x 3 projections x 4 taps x 22 four-byte requests = 140 us; the L2 holds all of H).
+  const bool pairs = TT == 12 && T == 11 && ((reinterpret_cast<uintptr_t>(H) & 7) == 0);
   for (int j = 0; j < J; ++j) {
     float w[4], dw[4];
     const float *gj = ski_grid_of(gp, J, j);
@@ -636,11 +645,28 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
     for (int k = 0; k < 4; ++k) {
       const float *hp = H + ((size_t)j * G + idx0 + k) * T2;   // [H_L (T) | H_R (T)]
       float hl[TT], hr[TT];
+      if (TT == 12 && pairs) {
+        float flat[24];
+        const float2 *hp2 = reinterpret_cast<const float2 *>(hp);
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        const int tc = t < T ? t : T - 1;
-        hr[t] = hp[T + tc];
-        hl[t] = hp[tc];
+        for (int q = 0; q < 11; ++q) {
+          const float2 v = hp2[q];
+          flat[2 * q] = v.x;
+          flat[2 * q + 1] = v.y;
+        }
+        flat[22] = flat[23] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          hl[t] = t < 11 ? flat[t] : 0.f;                 // (slot 11 meets li / ri = 0 either way)
+          hr[t] = t < 11 ? flat[11 + t] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          const int tc = t < T ? t : T - 1;
+          hr[t] = hp[T + tc];
+          hl[t] = hp[tc];
+        }
       }
       float a = 0.f, b = 0.f;
 #pragma unroll
@@ -651,11 +677,19 @@ __global__ __launch_bounds__(256) void ski_grad_gather_kernel(const float *__res
       gz = __builtin_fmaf(dw[k], a + b, gz);
       accj = __builtin_fmaf(w[k], a, accj);
     }
-    gZ[i * ldg + j] = scale * gz;
+    if (valid) {
+      gZ[i * ldg + j] = scale * gz;
+      if (rowC) rowC[i * J + j] = accj;      // per-projection part (H already carries the projection's weight)
+    }
     accS += accj;
-    if (rowC) rowC[i * J + j] = accj;      // per-projection part (H already carries the projection's weight)
   }
-  rowS[i] = accS;
+  ssum[threadIdx.x] = valid ? accS : 0.f;
+  __syncthreads();
+  for (int wd = 128; wd > 0; wd >>= 1) {
+    if ((int)threadIdx.x < wd) ssum[threadIdx.x] += ssum[threadIdx.x + wd];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowS[blockIdx.x] = ssum[0];
 }
 
 // Dense block of the SKI operator: out[m][n] = scale * sum_j w_j sum_{q,q'} w_q(z1_mj) w_q'(z2_nj) Toep[(idx_m + q) - (idx_n + q')]
@@ -1055,7 +1089,7 @@ static int ski_bilinear_finish_stage(const float *Z, const float *grid_params, c
     hipLaunchKernelGGL((ski_grad_gather_kernel<12>), dim3(nb), dim3(256), 0, st, Z, grid_params, H, L, R, gZ, row_scratch, (long long)N, ldz, ldg, J, G, T, scale, rowC);
   rc = launch_status();
   if (rc) return rc;
-  int src = rpgp_internal::sum_vector_launch(row_scratch, gscale, (int)N, 1.0f, st);
+  int src = rpgp_internal::sum_vector_launch(row_scratch, gscale, (int)nb, 1.0f, st);      // (one partial per workgroup)
   if (src) return src;
   if (gcomp) {
     src = rpgp_internal::sum_columns_launch(rowC, gcomp, (int)N, J, 1.0f, st);

@@ -112,31 +112,57 @@ __global__ __launch_bounds__(256) void k_step_hyper(const float *__restrict__ ra
 // normalises every right-hand-side column itself (k_init) and hands back Khat^-1 of the columns as given — exactly the
 // Khat^-1 z_p the derivative needs (the generic path divides by |z_p| first and multiplies the solves by it afterwards).
 constexpr int kMaxP = 16, kMaxKp = 64;
+// (round 6) The tiles of L (256 x k), e2 (256 x p) and the result (256 x (p + 1)) go through LDS as FLAT arrays: one row per
+// thread straight from memory makes every load instruction of a wave 64 requests 4 k bytes apart (C5, N = 391k: 37 us for 56 MB).
 __global__ __launch_bounds__(256) void k_step_probes(const float *__restrict__ L, int k, const float *__restrict__ e1,
                                                      const float *__restrict__ e2, float sqrt_noise,
                                                      const float *__restrict__ y, const float *__restrict__ mean_dev, long long N,
                                                      int p, float *__restrict__ full_rhs) {
-  __shared__ float se1[kMaxKp * kMaxP];                 // e1 padded to 16 columns
+  extern __shared__ float smem[];
+  float *se1 = smem;                                    // [k][16]: e1 padded to 16 columns
+  float *sL = se1 + kMaxKp * kMaxP;                     // [256][k | 1]   (odd row stride: conflict-free row reads)
+  const int ldl = k | 1;
+  float *sE = sL + 256 * ldl;                           // [256][p | 1], later the result rows [256][(p + 1) | 1]
+  const int lde = p | 1, T = p + 1, ldo = T | 1;
   for (int e = threadIdx.x; e < k * kMaxP; e += 256) {
     const int kk = e / kMaxP, c = e - kk * kMaxP;
     se1[e] = c < p ? e1[kk * p + c] : 0.f;
   }
-  __syncthreads();
   const float mu = mean_dev[0];
-  const int T = p + 1;
-  for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < N; row += (long long)gridDim.x * 256) {
-    float acc[kMaxP];
+  for (long long r0 = (long long)blockIdx.x * 256; r0 < N; r0 += (long long)gridDim.x * 256) {
+    const int rows = (int)((N - r0 < 256) ? N - r0 : 256);
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * k; e += 256) {
+      const int r = e / k, c = e - r * k;
+      sL[r * ldl + c] = L[r0 * k + e];
+    }
+    for (int e = threadIdx.x; e < rows * p; e += 256) {
+      const int r = e / p, c = e - r * p;
+      sE[r * lde + c] = e2[r0 * p + e];
+    }
+    const float yv = (int)threadIdx.x < rows ? y[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    float acc[kMaxP], ev[kMaxP];
 #pragma unroll
-    for (int c = 0; c < kMaxP; ++c) acc[c] = 0.f;
+    for (int c = 0; c < kMaxP; ++c) {
+      acc[c] = 0.f;
+      ev[c] = c < p ? sE[threadIdx.x * lde + c] : 0.f;
+    }
     for (int kk = 0; kk < k; ++kk) {
-      const float l = L[row * k + kk];
+      const float l = sL[threadIdx.x * ldl + kk];
 #pragma unroll
       for (int c = 0; c < kMaxP; ++c) acc[c] = __builtin_fmaf(l, se1[kk * kMaxP + c], acc[c]);
     }
+    __syncthreads();                                     // (sE is reused for the result rows)
 #pragma unroll
     for (int c = 0; c < kMaxP; ++c)
-      if (c < p) full_rhs[row * T + c] = acc[c] + sqrt_noise * e2[row * p + c];
-    full_rhs[row * T + p] = y[row] - mu;
+      if (c < p) sE[threadIdx.x * ldo + c] = acc[c] + sqrt_noise * ev[c];
+    sE[threadIdx.x * ldo + p] = yv - mu;
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * T; e += 256) {
+      const int r = e / T, c = e - r * T;
+      full_rhs[r0 * T + e] = sE[r * ldo + c];
+    }
   }
 }
 
@@ -146,15 +172,39 @@ __global__ __launch_bounds__(256) void k_step_probes(const float *__restrict__ L
 // — once per optimiser step, so the hand-off (every wave drains its stores, workgroup barrier, agent-scope release, arrive on
 // the counter; the last arriver: agent-scope acquire, plain loads — MI355X_MICROARCH.md "valid forms") costs nothing that
 // matters.  ws: [0] arrival counter (0 on entry, 0 again on exit), doubles from byte 256.
-constexpr int kValueBlocks = 256;
+constexpr int kValueBlocks = 1024;
+__device__ __forceinline__ void value_out(double tot, double logdet, double c1, double c2, float *__restrict__ out,
+                                          float *__restrict__ host_slot, float stamp) {
+  const float val = (float)((tot + logdet) * c1 + c2);
+  out[0] = val;
+  out[1] = (float)tot;
+  if (host_slot) {
+    // post {value, stamp} to the host as ONE 8-byte store to the mapped pinned slot: nothing to order, no system-scope fence
+    const unsigned long long both = (unsigned long long)__float_as_uint(val) | ((unsigned long long)__float_as_uint(stamp) << 32);
+    *reinterpret_cast<volatile unsigned long long *>(host_slot) = both;
+  }
+}
 __global__ __launch_bounds__(256) void k_step_value(const float *__restrict__ rhs, const float *__restrict__ sol, long long N,
                                                     int T, int col, double logdet, double c1, double c2,
                                                     float *__restrict__ out, unsigned *__restrict__ counter,
                                                     double *__restrict__ part, float *__restrict__ host_slot, float stamp) {
   __shared__ double sh[256];
   double s = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256)
-    s += (double)rhs[i * T + col] * (double)sol[i * T + col];
+  // (four rows of a thread in flight: the column of an N x T block is one 4-byte request per row, and a thread walking its
+  //  rows one round trip at a time made this 30 us at N = 391k)
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < N; i += 4 * stride) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = rhs[(i + u * stride) * T + col];
+      b[u] = sol[(i + u * stride) * T + col];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += (double)a[u] * (double)b[u];
+  }
+  for (; i < N; i += stride) s += (double)rhs[i * T + col] * (double)sol[i * T + col];
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
@@ -163,6 +213,7 @@ __global__ __launch_bounds__(256) void k_step_value(const float *__restrict__ rh
   }
   if (threadIdx.x == 0) {
     part[blockIdx.x] = sh[0];
+    if (counter == nullptr) return;            // two-launch form: k_step_value_finish adds the partials up
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -174,23 +225,34 @@ __global__ __launch_bounds__(256) void k_step_value(const float *__restrict__ rh
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       double tot = 0.0;
       for (unsigned q = 0; q < gridDim.x; ++q) tot += part[q];
-      const float val = (float)((tot + logdet) * c1 + c2);
-      out[0] = val;
-      out[1] = (float)tot;
-      if (host_slot) {                         // post the value to the host (mapped pinned memory), then the stamp
-        host_slot[0] = val;
-        __threadfence_system();
-        *reinterpret_cast<volatile float *>(host_slot + 1) = stamp;
-        __threadfence_system();
-      }
+      value_out(tot, logdet, c1, c2, out, host_slot, stamp);
     }
   }
+}
+
+// Many workgroups (N beyond ~64k): the partials are added by a second launch instead.  An agent-scope release per workgroup is a
+// write-back of what the solve left dirty in that XCD's L2, and with hundreds of workgroups arriving the single-launch form
+// spent 30 - 44 us in them at N = 391k (6 us at N = 7k, where it stays).
+__global__ __launch_bounds__(256) void k_step_value_finish(const double *__restrict__ part, int nparts, double logdet, double c1,
+                                                           double c2, float *__restrict__ out, float *__restrict__ host_slot,
+                                                           float stamp) {
+  __shared__ double sh[256];
+  // (index order within a thread, then the tree: a fixed order)
+  double s = 0.0;
+  for (int q = threadIdx.x; q < nparts; q += 256) s += part[q];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) value_out(sh[0], logdet, c1, c2, out, host_slot, stamp);
 }
 
 // ---- the two sides of the bilinear derivative ---------------------------------------------------------------------------------
 // left = [Khat^-1 z_p * (g_ld / p) | -g_iq alpha],  right = [M^-1 z_p | alpha]   with Khat^-1 z_p = sol[:, c];
 // g_iq = g_ld = g[0] * gscale (the incoming gradient is a device scalar).  Per block: partial sum(left * right), sum(alpha).
-constexpr int kLrBlocks = 512;
+constexpr int kLrBlocks = 4096;
 __global__ __launch_bounds__(256) void k_step_lr(const float *__restrict__ sol, const float *__restrict__ pre_probes,
                                                  long long ldp, const float *__restrict__ g, float gscale, long long N, int p,
                                                  float *__restrict__ left, float *__restrict__ right,
@@ -201,22 +263,39 @@ __global__ __launch_bounds__(256) void k_step_lr(const float *__restrict__ sol, 
   const int T = p + 1;
   const long long total = N * T;
   float a1 = 0.f, a2 = 0.f;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long row = e / T;
-    const int c = (int)(e - row * T);
-    const float sv = sol[e];
-    float l, r;
-    if (c < p) {
-      l = sv * gp;
-      r = pre_probes[row * ldp + c];
-    } else {
-      l = -gq * sv;
-      r = sv;
-      a2 += sv;
+  // (four elements of a thread in flight, up to 4 096 workgroups: 33 dependent round trips per thread were 30 us at N = 391k)
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long e0 = (long long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += 4 * stride) {
+    float sv[4], pv[4];
+    int cc[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long e = e0 + u * stride;
+      ok[u] = e < total;
+      const long long ec = ok[u] ? e : total - 1;
+      const long long row = ec / T;
+      cc[u] = (int)(ec - row * T);
+      sv[u] = sol[ec];
+      pv[u] = pre_probes[row * ldp + (cc[u] < p ? cc[u] : 0)];
     }
-    left[e] = l;
-    right[e] = r;
-    a1 = __builtin_fmaf(l, r, a1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const long long e = e0 + u * stride;
+      float l, r;
+      if (cc[u] < p) {
+        l = sv[u] * gp;
+        r = pv[u];
+      } else {
+        l = -gq * sv[u];
+        r = sv[u];
+        a2 += sv[u];
+      }
+      left[e] = l;
+      right[e] = r;
+      a1 = __builtin_fmaf(l, r, a1);
+    }
   }
   s1[threadIdx.x] = a1;
   s2[threadIdx.x] = a2;
@@ -327,7 +406,13 @@ int rpgp_step_probes(const float *L, int k, const float *e1, const float *e2, fl
   if (!L || !e1 || !e2 || !y || !mean_dev || !full_rhs || N < 1 || p < 1 || p > kMaxP || k < 1 || k > kMaxKp) return RPGP_EINVAL;
   long long nb = (N + 255) / 256;
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(k_step_probes, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), L, k, e1, e2,
+  const size_t lds = ((size_t)kMaxKp * kMaxP + 256 * (size_t)(k | 1) + 256 * (size_t)((p + 1) | 1)) * sizeof(float);
+  if (lds > 48 * 1024) {      // (rank-64 factors: 88 KB; the rank-15 preconditioner of a 10-probe block needs 30 KB)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_step_probes),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k_step_probes, dim3((unsigned)nb), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), L, k, e1, e2,
                      sqrt_noise, y, mean_dev, (long long)N, p, full_rhs);
   return (int)hipGetLastError();
 }
@@ -338,7 +423,7 @@ int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T
                     float *out2, void *workspace, size_t workspace_bytes, int *ticket_out, void *stream) {
   if (!full_rhs || !solves || !out2 || N < 1 || T < 1 || col < 0 || col >= T) return RPGP_EINVAL;
   if (!workspace || workspace_bytes < rpgp_step_value_workspace_bytes()) return RPGP_EWORKSPACE;
-  long long nb = (N + 1023) / 1024;                  // ~4 rows per thread
+  long long nb = (N + 1023) / 1024;                  // ~4 rows per thread (one batch of loads)
   if (nb > kValueBlocks) nb = kValueBlocks;
   float *slot = nullptr;
   float stamp = 0.f;
@@ -354,9 +439,14 @@ int rpgp_step_value(const float *full_rhs, const float *solves, int64_t N, int T
       *ticket_out = sl + kValueSlots * (int)stamp;
     }
   }
+  double *part = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + 256);
+  const bool two = nb > 64;
   hipLaunchKernelGGL(k_step_value, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), full_rhs, solves,
-                     (long long)N, T, col, logdet, c1, c2, out2, reinterpret_cast<unsigned *>(workspace),
-                     reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + 256), slot, stamp);
+                     (long long)N, T, col, logdet, c1, c2, out2, two ? nullptr : reinterpret_cast<unsigned *>(workspace), part,
+                     slot, stamp);
+  if (two)
+    hipLaunchKernelGGL(k_step_value_finish, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, (int)nb, logdet,
+                       c1, c2, out2, slot, stamp);
   return (int)hipGetLastError();
 }
 
@@ -365,9 +455,16 @@ int rpgp_step_value_wait(int ticket, float *value_host) {
   const int sl = ticket % kValueSlots;
   const float stamp = (float)(ticket / kValueSlots);
   if (g_value.issued[sl] != stamp) return RPGP_EINVAL;        // the slot has been handed to a later call (or another thread's)
-  const volatile float *p = g_value.host + 2 * sl;
-  if (!rpgp_internal::spin_until([p, stamp] { return p[1] == stamp; }, 2000000)) return RPGP_EINVAL;
-  *value_host = p[0];
+  // (one aligned 8-byte load: value and stamp of the same store)
+  const volatile unsigned long long *p = reinterpret_cast<const volatile unsigned long long *>(g_value.host + 2 * sl);
+  unsigned stamp_bits;
+  static_assert(sizeof(float) == sizeof(unsigned), "float bits");
+  __builtin_memcpy(&stamp_bits, &stamp, 4);
+  unsigned long long got = 0;
+  if (!rpgp_internal::spin_until([p, stamp_bits, &got] { got = *p; return (unsigned)(got >> 32) == stamp_bits; }, 2000000))
+    return RPGP_EINVAL;
+  const unsigned vb = (unsigned)(got & 0xffffffffull);
+  __builtin_memcpy(value_host, &vb, 4);
   return 0;
 }
 

@@ -644,7 +644,9 @@ def test_step_kernels_against_torch_formulas(gpu_device):
         gq = float(gten) * gscale
         assert abs(float(g_nz) - (float(part[0::2].double().sum()) + float(gten) * dlp_n) * float(torch.sigmoid(raw_nz))) < 1e-5
         assert abs(float(g_mu) + 2 * gq * float(part[1::2].double().sum())) < 1e-6
-    for N, k, p in ((3001, 15, 10), (70000, 9, 7)):
+    # (400 001 rows: the C5 size — several batches per thread, the workgroup caps; rank 64 with 16 probes: the 88 KB tile of the
+    #  probe kernel)
+    for N, k, p in ((3001, 15, 10), (70000, 9, 7), (400001, 15, 10), (5000, 64, 16)):
         L = torch.randn(N, k, generator=g).to(gpu_device)
         e1, e2 = torch.randn(k, p, generator=g).to(gpu_device), torch.randn(N, p, generator=g).to(gpu_device)
         y, mean = torch.randn(N, generator=g).to(gpu_device), torch.tensor([0.3], device=gpu_device)

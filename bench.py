@@ -603,10 +603,9 @@ def _step_times(device):
         def run(n):
             for _ in range(n):
                 opt.zero_grad()
-                loss = mll.negative(model(X), y)
-                loss.backward()
+                loss = mll.negative_and_backward(model(X), y)   # (the closure of training.train_to_convergence)
                 opt.step()
-                fused_mll.loss_value(loss)          # (the training loop's per-step read of the loss: training.train_to_convergence)
+                fused_mll.loss_value(loss)                      # (... and its per-step read of the loss)
         ts = []
         with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
             model.train()

@@ -627,6 +627,20 @@ class ExactMarginalLogLikelihood(nn.Module):
                 return fused_mll.evaluate(self.model, self.likelihood, target, negate=True)
         return -self(output, target)
 
+    def negative_and_backward(self, output, target):
+        """`loss = -mll(output, target); loss.backward()` of the training loop (fitting/optimizing.py:70-72), returning the loss.
+        For the fused objective on the step kernels the gradients are written into `.grad` without the autograd engine
+        (fused_mll.value_and_grad: same values, ~120 us of host time less per step); otherwise exactly the two statements."""
+        if isinstance(output, LazyPrior) and not output.materialized:
+            from . import fused_mll, settings
+            if output._model is self.model and self.likelihood is self.model.likelihood and settings.fused_training.on():
+                loss = fused_mll.value_and_grad(self.model, self.likelihood, target, negate=True)
+                if loss is not None:
+                    return loss
+        loss = self.negative(output, target)
+        loss.backward()
+        return loss
+
     def forward(self, output, target):
         n = target.shape[0]
         if isinstance(output, LazyPrior) and not output.materialized:

@@ -276,10 +276,14 @@ def train_to_convergence(model, xs, ys, optimizer=None, lr=0.1, objective=None, 
                 output = model(xs)
                 if isloss:
                     loss = objective(output, ys)
-                else:                     # (an objective that can negate itself does: models.ExactMarginalLogLikelihood.negative)
-                    neg = getattr(objective, "negative", None)
-                    loss = neg(output, ys) if neg is not None else -objective(output, ys)
-                loss.backward()
+                    loss.backward()
+                else:                     # (an objective that can form the loss and its gradients itself does:
+                    nb = getattr(objective, "negative_and_backward", None)     #  models.ExactMarginalLogLikelihood)
+                    if nb is not None:
+                        loss = nb(output, ys)
+                    else:
+                        loss = -objective(output, ys)
+                        loss.backward()
             return loss
 
         # (roctx ranges, live under `rocprofv3 --marker-trace` only: the optimiser's own update is what is left of this range

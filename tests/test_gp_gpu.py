@@ -446,7 +446,7 @@ def test_eager_gradients_and_posted_loss_are_the_ordinary_ones(gpu_device, ski):
     res = {}
     be.step_lr = counted
     try:
-        for mode in ("eager", "lazy", "eager_x2"):
+        for mode in ("eager", "lazy", "eager_x2", "direct"):
             torch.manual_seed(4)
             np.random.seed(4)
             model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
@@ -457,6 +457,18 @@ def test_eager_gradients_and_posted_loss_are_the_ordinary_ones(gpu_device, ski):
             model.train()
             with settings.eager_gradients(mode != "lazy"), settings.deterministic_probes(True), settings.cg_tolerance(1e-3):
                 n0 = calls["n"]
+                if mode == "direct":          # the training loop's closure: loss and .grad without the autograd engine
+                    loss = mll.negative_and_backward(model(X), y)
+                    assert not loss.requires_grad and calls["n"] - n0 == 1
+                    assert fused_mll.loss_value(loss) == loss.item()
+                    res[mode] = (loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()
+                                                        if p.grad is not None})
+                    # a second call accumulates, as backward() does
+                    mll.negative_and_backward(model(X), y)
+                    for k, p in model.named_parameters():
+                        if p.grad is not None:
+                            assert torch.allclose(p.grad, 2.0 * res[mode][1][k], rtol=1e-6, atol=0.0), k
+                    continue
                 loss = mll.negative(model(X), y)
                 assert calls["n"] - n0 == (0 if mode == "lazy" else 1)          # the derivative's first launch: in forward or not
                 assert getattr(loss, "_rpgp_ticket", None) is not None
@@ -484,6 +496,8 @@ def test_eager_gradients_and_posted_loss_are_the_ordinary_ones(gpu_device, ski):
     for k in res["eager"][1]:
         assert torch.equal(res["eager"][1][k], res["lazy"][1][k]), k
         assert torch.allclose(res["eager_x2"][1][k], 2.0 * res["lazy"][1][k], rtol=1e-6, atol=0.0), k
+        assert torch.equal(res["direct"][1][k], res["lazy"][1][k]), k
+    assert torch.equal(res["direct"][0], res["lazy"][0]) and res["direct"][1].keys() == res["lazy"][1].keys()
 
 
 def test_blocked_fp16x3_cholesky_factor(gpu_device):

@@ -3,7 +3,7 @@ operations around the native solve; this lists them by cumulative host time per 
 import cProfile, io, json, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from rpgp_amd import settings
+from rpgp_amd import fused_mll, settings
 from rpgp_amd.training import create_exact_gp, make_optimizer
 from rpgp_amd.models import ExactMarginalLogLikelihood
 SHAPES = {"C2": (7372, 8, 20, False, False), "C3": (14939, 18, 20, True, False), "C5": (391386, 3, 3, True, True)}
@@ -23,13 +23,13 @@ opt = make_optimizer(torch.optim.Adam, [p for p in model.parameters() if p.requi
 with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
     model.train()
     for it in range(warm):
-        opt.zero_grad(); loss = mll.negative(model(X), y); loss.backward(); opt.step()
+        opt.zero_grad(); loss = mll.negative_and_backward(model(X), y); opt.step(); fused_mll.loss_value(loss)
     torch.cuda.synchronize()
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     pr.enable()
     for it in range(steps):
-        opt.zero_grad(); loss = mll.negative(model(X), y); loss.backward(); opt.step()
+        opt.zero_grad(); loss = mll.negative_and_backward(model(X), y); opt.step(); fused_mll.loss_value(loss)
     torch.cuda.synchronize()
     pr.disable()
     t1 = time.perf_counter()

@@ -2,7 +2,7 @@
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from rpgp_amd import settings
+from rpgp_amd import fused_mll, settings
 from rpgp_amd.training import create_exact_gp, make_optimizer
 from rpgp_amd.models import ExactMarginalLogLikelihood
 SHAPES = {"C2": (7372, 8, 20, False, False), "C3": (14939, 18, 20, True, False), "C4": (50000, 20, 20, False, False),
@@ -23,9 +23,9 @@ opt = make_optimizer(torch.optim.Adam, [p for p in model.parameters() if p.requi
 with settings.cg_tolerance(0.05), settings.max_cg_iterations(10000):
     model.train()
     for it in range(warm):
-        opt.zero_grad(); loss = mll.negative(model(X), y); loss.backward(); opt.step()
+        opt.zero_grad(); loss = mll.negative_and_backward(model(X), y); opt.step(); fused_mll.loss_value(loss)
     torch.cuda.synchronize(); t0 = time.perf_counter(); b = time.time_ns()
     for it in range(steps):
-        opt.zero_grad(); loss = mll.negative(model(X), y); loss.backward(); opt.step()
+        opt.zero_grad(); loss = mll.negative_and_backward(model(X), y); opt.step(); fused_mll.loss_value(loss)
     torch.cuda.synchronize(); t1 = time.perf_counter(); e = time.time_ns()
 print(json.dumps({"shape": shape, "steps": steps, "warm": warm, "step_ms": (t1 - t0) / steps * 1e3, "t_begin_ns": b, "t_end_ns": e}))

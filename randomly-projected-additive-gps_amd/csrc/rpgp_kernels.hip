@@ -2626,6 +2626,127 @@ __global__ __launch_bounds__(256) void pivchol_step_kernel(const float *__restri
   }
 }
 
+// The grid-interpolation operator's step with few projections (the C5 shape: J = 3), one row per thread, the factor column-major:
+// as in pivchol_step_fast_kernel below, what does not depend on the pivot — the thread's coordinates and with them its taps
+// and weights, its residual diagonal entry, its entries of the factor's first m columns — is requested at the head of the kernel
+// and lands while the pivot is being found.  Same arithmetic in the same order as pivchol_step_kernel.
+__global__ __launch_bounds__(256) void pivchol_step_ski_fast_kernel(const float *__restrict__ Z, float *__restrict__ dwork,
+                                                                    const float *__restrict__ pval_in,
+                                                                    const int *__restrict__ pidx_in,
+                                                                    float *__restrict__ pval_out, int *__restrict__ pidx_out,
+                                                                    int nparts, int N, int ldz, int ncols, int m, float scale,
+                                                                    float d0, const float *__restrict__ gp, int G,
+                                                                    float *__restrict__ Lt) {
+  __shared__ float sval[4];
+  __shared__ int sidx[4];
+  __shared__ float slp[16];
+  __shared__ float spw[4][4];
+  __shared__ int spidx[4];
+  __shared__ float sdp;
+  __shared__ int spiv;
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  const bool own = i < N;
+  const int ic = own ? i : N - 1;
+  // the partials of the previous step (nparts <= 2 048: eight per thread, clamped, always loaded)
+  float pv[8];
+  int pi[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int q = tid + 256 * u;
+    const int qc = q < nparts ? q : nparts - 1;
+    pv[u] = pval_in[qc];
+    pi[u] = pidx_in[qc];
+  }
+  // own-row operands
+  float zr[4], lr[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) zr[j] = Z[(size_t)ic * ldz + (j < ncols ? j : ncols - 1)];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lr[q] = Lt[(size_t)(q < m ? q : 0) * N + ic];
+  const float dprev = dwork[ic];
+  const int kind = ski_kind(gp);
+  float ow[4][4], ohs[4], owj[4];
+  int oidx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float dw[4];
+    const float *gj = ski_grid_of(gp, ncols, j < ncols ? j : ncols - 1);
+    oidx[j] = ski_taps<false>(zr[j], gj[0], gj[2], G, ow[j], dw);
+    ohs[j] = gj[1];
+    owj[j] = ski_wj(gp, j < ncols ? j : ncols - 1);
+  }
+  float bv = -1.f;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int q = tid + 256 * u;
+    if (q < nparts && (pv[u] > bv || (pv[u] == bv && pi[u] < bi))) { bv = pv[u]; bi = pi[u]; }
+  }
+  block_argmax(bv, bi, sval, sidx);
+  if (tid == 0) { sdp = bv; spiv = bi; }
+  __syncthreads();
+  const int piv = spiv;
+  const float dp = sdp;
+  const bool ok = dp > 1e-10f * d0;
+  if (tid < ncols) {
+    const float zp = Z[(size_t)piv * ldz + tid];
+    float w[4], dw[4];
+    const float *gj = ski_grid_of(gp, ncols, tid);
+    spidx[tid] = ski_taps<false>(zp, gj[0], gj[2], G, w, dw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) spw[tid][q] = w[q];
+  }
+  if (tid < m) slp[tid] = Lt[(size_t)tid * N + piv];
+  __syncthreads();
+  const float inv_sq = ok ? 1.0f / sqrtf(dp) : 0.f;
+  bv = -1.f;
+  bi = 0x7fffffff;
+  if (own) {
+    float l = 0.f;
+    if (ok) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < ncols) {
+          const int delta = oidx[j] - spidx[j];
+          float tl[7];
+#pragma unroll
+          for (int u = 0; u < 7; ++u) {
+            const int lag = delta + u - 3;
+            tl[u] = ski_radial_f32(kind, lag < 0 ? -lag : lag, ohs[j]);
+          }
+          float aj = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) aj = __builtin_fmaf(ow[j][q] * spw[j][qq], tl[q - qq + 3], aj);
+          acc = __builtin_fmaf(owj[j], aj, acc);
+        }
+      }
+      const float row = scale * acc;
+      float corr = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (q < m) corr = __builtin_fmaf(lr[q], slp[q], corr);
+      l = (row - corr) * inv_sq;
+    }
+    Lt[(size_t)m * N + i] = l;
+    float nd = dprev - l * l;
+    nd = nd < 0.f ? 0.f : nd;
+    nd = (i == piv) ? 0.f : nd;
+    dwork[i] = nd;
+    bv = nd;
+    bi = i;
+  }
+  __syncthreads();
+  block_argmax(bv, bi, sval, sidx);
+  if (tid == 0) {
+    pval_out[blockIdx.x] = bv;
+    pidx_out[blockIdx.x] = bi;
+  }
+}
+
 // L (N x k, row-major) from the column-major scratch the steps filled: a workgroup owns 256 consecutive rows, reads 16
 // coalesced vectors at a time into LDS and writes them as 64-byte runs of its rows.
 __global__ __launch_bounds__(256) void pivchol_untranspose_kernel(const float *__restrict__ Lt, float *__restrict__ L, int N,
@@ -4039,7 +4160,12 @@ static int pivchol_common(const float *Z, float *L, float *diag_work, int64_t N,
     hipLaunchKernelGGL(pivchol_step_fast_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
                        pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, m == 0 ? 1 : 0);
   if (fast) return launch_status();
-  for (int m = 0; m < rank; ++m) {
+  // grid interpolation with few projections, one row per thread, column-major factor: own-row operands requested up front
+  const bool ski_fast = gp && Lt && ncols <= 4 && rank <= 16 && (long long)nb * 256 >= N && !wts;
+  for (int m = 0; ski_fast && m < rank; ++m)
+    hipLaunchKernelGGL(pivchol_step_ski_fast_kernel, dim3(nb), dim3(256), 0, st, Z, diag_work, pval[m & 1], pidx[m & 1],
+                       pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, m, scale, d0, gp, G, Lt);
+  for (int m = ski_fast ? rank : 0; m < rank; ++m) {
     hipLaunchKernelGGL(pivchol_step_kernel, dim3(nb), dim3(256), 0, st, Z, L, diag_work, pval[m & 1], pidx[m & 1],
                        pval[(m + 1) & 1], pidx[(m + 1) & 1], nb, (int)N, ldz, ncols, rank, m, scale, d0, kind, group,
                        ncomp, wts, gp, G, (m == 0 && !gp) ? 1 : 0, Lt);

@@ -211,7 +211,7 @@ def test_ski_mll_matches_exact_operator_on_gpu(gpu_device):
         assert abs(res[(ski, False)][2] - res[(ski, True)][2]) < 2e-2 * abs(res[(ski, True)][2])
 
 
-@pytest.mark.parametrize("N,J,G", [(3000, 3, 256), (20000, 20, 1024), (70001, 3, 512)])
+@pytest.mark.parametrize("N,J,G", [(3000, 3, 256), (20000, 20, 1024), (70001, 3, 512), (66000, 6, 256)])
 def test_ski_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, G):
     """rpgp_ski_pivoted_cholesky (one chip-wide launch per greedy step, entries from the interpolation weights and the
     Toeplitz lags) against the generic row-by-row version that asks the operator for rows.  From N = 65 536 on the factor is
@@ -225,6 +225,9 @@ def test_ski_fused_pivoted_cholesky_matches_generic(gpu_device, N, J, G):
     Lg = pivoted_cholesky(op._diagonal(), op._get_rows, 10)
     assert Lf is not None and torch.allclose(Lf, Lg, rtol=2e-3, atol=3e-4)
     assert torch.equal(Lf, op.fused_pivoted_cholesky(10))
+    # the first ten columns of a rank-17 factor are the rank-10 factor: at (70 001, 3) rank 17 runs the general step kernel, rank 10
+    # the one with the own-row operands requested up front — the same arithmetic in the same order
+    assert torch.equal(op.fused_pivoted_cholesky(17)[:, :10], Lf)
     from rpgp_amd import ops, _lib
     lib = _lib.load()
     assert lib.rpgp_ski_pivoted_cholesky_work_floats(N, 10) == N + _lib.RPGP_PIVCHOL_SCRATCH + (10 * N if N >= 65536 else 0)

@@ -500,6 +500,39 @@ def test_eager_gradients_and_posted_loss_are_the_ordinary_ones(gpu_device, ski):
     assert torch.equal(res["direct"][0], res["lazy"][0]) and res["direct"][1].keys() == res["lazy"][1].keys()
 
 
+@pytest.mark.parametrize("opt_name", ["adam", "lbfgs"])
+def test_training_loop_is_the_same_with_and_without_the_engine_free_closure(gpu_device, opt_name):
+    """train_to_convergence end to end: the closure through `negative_and_backward` + `loss_value` (derivative launched from the
+    forward pass, no autograd engine, loss read from the posted host value) against the plain `loss = -mll(...); loss.backward();
+    loss.item()` of settings.eager_gradients(False) — per-epoch losses and final parameters identical (the probes are fixed).
+    LBFGS evaluates the closure up to 25 times per epoch: more posted values than the ring has slots."""
+    from rpgp_amd import settings
+    from rpgp_amd.training import create_exact_gp, train_to_convergence
+    from rpgp_amd.models import ExactMarginalLogLikelihood
+    gen = torch.Generator().manual_seed(9)
+    N, d, J = 2600, 4, 8
+    X = torch.randn(N, d, generator=gen)
+    y = torch.sin(X).sum(1) + 0.1 * torch.randn(N, generator=gen)
+    X, y = X.to(gpu_device), ((y - y.mean()) / y.std()).to(gpu_device)
+    res = {}
+    for eager in (True, False):
+        torch.manual_seed(4)
+        np.random.seed(4)
+        model, lik = create_exact_gp(X, y, "additive_rp", J=J, noise_prior=True, kernel_type="RBF", learn_proj=False,
+                                     prescale=True)
+        model = model.to(gpu_device)
+        mll = ExactMarginalLogLikelihood(lik, model)
+        losses = []
+        opt = torch.optim.Adam if opt_name == "adam" else torch.optim.LBFGS
+        with settings.eager_gradients(eager), settings.deterministic_probes(True), settings.cg_tolerance(1e-3):
+            train_to_convergence(model, X, y, optimizer=opt, lr=0.1 if opt_name == "adam" else 0.005, objective=mll,
+                                 max_iter=4 if opt_name == "adam" else 2, check_conv=False, loss_log=losses)
+        res[eager] = (losses, {k: p.detach().clone() for k, p in model.named_parameters()})
+    assert res[True][0] == res[False][0] and len(res[True][0]) >= 2
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+
+
 def test_blocked_fp16x3_cholesky_factor(gpu_device):
     """precond.blocked_cholesky (round 5): the blocked float32 factorisation with fp16x3 trailing updates that the mixed-precision
     covariance solve and the Cholesky-preconditioned wide CG use beyond N = 16k.  Its factor is as accurate as the library's
